@@ -1,0 +1,184 @@
+/*
+ * recogym_hip.h — C ABI of librecogym_hip.so, the MI355X-native reco-gym-v1 step loop.
+ *
+ * The reference has no FFI: its boundary is the duck-typed Python class surface of
+ * recogym/envs/abstract.py + reco_env_v1.py.  This header is the boundary a
+ * native replacement of that path exports; every entry point cites the reference method(s)
+ * whose work it takes over.  The Python mirror of the reference classes that binds these
+ * symbols with ctypes lives in recogym_amd/ (see INTEGRATION.md for the stub a reference
+ * maintainer would add).
+ *
+ * Conventions
+ *   - plain C types only; device buffers are passed as raw pointers owned by the caller
+ *     (PyTorch-ROCm tensors in the Python host), streams as `void*` (a hipStream_t);
+ *   - every function returns 0 on success or a negative RG_E* code; rg_last_error() holds the
+ *     message of the last failure on the calling thread;
+ *   - nothing here allocates caller-visible memory: the caller sizes one workspace with
+ *     rg_sim_workspace_bytes() and hands it to rg_sim_create();
+ *   - no entry point synchronises the device except rg_sim_read_counters(), rg_sim_run() (a
+ *     host loop that polls the live-user count) and rg_sim_destroy();
+ *   - a handle is thread-compatible (one handle per thread / per GPU), not thread-safe;
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails with
+ *     RG_ENODEV.  The float64 CPU restatement used by the tests is a different library
+ *     (oracle/, test infrastructure only).
+ */
+#ifndef RECOGYM_HIP_H
+#define RECOGYM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RG_ABI_VERSION 1
+
+/* error codes */
+#define RG_OK 0
+#define RG_EINVAL (-1)   /* bad argument / configuration */
+#define RG_ENODEV (-2)   /* no HIP device, or a HIP runtime error */
+#define RG_ENOMEM (-3)   /* workspace / log buffer too small */
+#define RG_ESTATE (-4)   /* call sequence error (e.g. step before reset_users) */
+#define RG_ELIMIT (-5)   /* a hard limit was hit (max steps, log overflow) */
+
+/* Markov states — recogym/envs/abstract.py:41-43 */
+#define RG_STATE_ORGANIC 0
+#define RG_STATE_BANDIT 1
+#define RG_STATE_STOP 2
+
+/* policies that run on the device — the `agent` argument of generate_logs
+ * (abstract.py:241-254) */
+#define RG_POLICY_UNIFORM_ENV 0   /* agent=None: uniform action from the ENV stream, abstract.py:209-221 */
+#define RG_POLICY_RANDOM_AGENT 1  /* RandomAgent, agents/random_agent.py:22-33 */
+#define RG_POLICY_ORGANIC_USER_COUNT 2 /* OrganicUserEventCounterAgent, agents/organic_user_count.py:45-96 */
+#define RG_POLICY_EXTERNAL 3      /* actions supplied by the caller per step (gym.Env.step, abstract.py:123) */
+
+/*
+ * Everything the step loop needs from `env.config` (a Configuration built from env_1_args,
+ * reco_env_v1.py:18-29 + abstract.py:20-31) and from the agent's config.  POD, no pointers.
+ */
+typedef struct rg_config {
+    uint32_t num_products;          /* P   — config.num_products */
+    uint32_t K;                     /* K   — config.K */
+    uint64_t seed;                  /* config.random_seed + epoch — abstract.py:59-62 */
+    uint64_t policy_seed;           /* the agent's config.random_seed (env seed for UNIFORM_ENV) */
+    /* Normalised cumulative transition rows, i.e. what RandomState.choice(3, p=T[s]) compares
+     * its uniform against: cdf = cumsum(T[s]); cdf /= cdf[-1]   (reco_env_v1.py:54-61,87).
+     * Row 0 = organic, row 1 = bandit.  Computed on the host in float64 exactly as numpy does. */
+    double trans_cdf[2][3];
+    double sigma_omega_initial;     /* reco_env_v1.py:80 */
+    double sigma_omega;             /* reco_env_v1.py:96 */
+    uint32_t change_omega_for_bandits; /* reco_env_v1.py:95 */
+    uint32_t policy;                /* RG_POLICY_* */
+    /* OrganicUserEventCounter parameters (organic_user_count_args, organic_user_count.py:7-27) */
+    uint32_t ouc_select_randomly;
+    uint32_t ouc_exploit_explore;
+    uint32_t ouc_reverse_pop;
+    uint32_t ouc_history_cap;       /* max organic views kept per user on the device (0 = default) */
+    double ouc_epsilon;
+} rg_config;
+
+/*
+ * One emitted log row, 16 bytes — the device-side form of one row of the DataFrame that
+ * generate_logs builds (abstract.py:256-290,318-327).
+ *   code bit 31 : z  (0 = organic, 1 = bandit)
+ *   code bit 30 : c  (click; bandit rows only)
+ *   code bit 29 : phantom (the trailing never-drawn bandit row, abstract.py:311-316)
+ *   code bits 0..28 : v (organic) or a (bandit)
+ */
+typedef struct rg_event {
+    uint32_t u;      /* user id */
+    uint32_t t;      /* per-user event index == DefaultTimeGenerator time */
+    uint32_t code;
+    float ps;        /* propensity of the logged action (NaN on organic rows) */
+} rg_event;
+
+#define RG_EV_BANDIT 0x80000000u
+#define RG_EV_CLICK 0x40000000u
+#define RG_EV_PHANTOM 0x20000000u
+#define RG_EV_INDEX_MASK 0x1FFFFFFFu
+
+/* counters returned by rg_sim_read_counters */
+#define RG_CNT_ORGANIC 0        /* organic rows */
+#define RG_CNT_BANDIT 1         /* real bandit rows (phantom excluded) */
+#define RG_CNT_CLICKS 2         /* sum of c over bandit rows — bench_agents.py:203-206 */
+#define RG_CNT_PHANTOM 3        /* phantom rows (one per finished non-organic-only user) */
+#define RG_CNT_LIVE 4           /* users not yet in state stop */
+#define RG_CNT_STEP 5           /* Markov transitions performed per user so far (== current t) */
+#define RG_CNT_LOG_ROWS 6       /* rows written to the log buffer */
+#define RG_CNT_LOG_DROPPED 7    /* rows that did not fit (capacity exceeded) */
+#define RG_CNT_EXACT_DRAWS 8    /* organic draws resolved by the float64 path */
+#define RG_CNT_N 16
+
+typedef struct rg_sim rg_sim;
+
+const char* rg_last_error(void);
+int rg_abi_version(void);
+
+/* number of visible HIP devices (0 on a CPU-only box; never an error) */
+int rg_device_count(void);
+
+/* Bytes of device workspace a simulator over `n_users` concurrent users needs
+ * (omega, state lists, per-step counters, fp32 table copies, policy history). 0 on bad config. */
+size_t rg_sim_workspace_bytes(const rg_config* cfg, uint64_t n_users);
+
+/* AbstractEnv.init_gym (abstract.py:64-88) minus the table draws: binds a configuration and a
+ * caller-owned device workspace to a handle.  Host-only; performs no device work. */
+int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_workspace,
+                  size_t workspace_bytes);
+int rg_sim_destroy(rg_sim* sim);
+
+/* RecoEnv1.set_static_params / generate_beta results (reco_env_v1.py:51-75,133-174): row-major
+ * float64 device arrays Gamma (P,K), mu_organic (P), beta (P,K), mu_bandit (P), drawn on the
+ * host from RandomState(seed) so they are bit-identical to the reference's.  The library keeps
+ * the pointers (caller keeps them alive) and builds its fp32 tile copies in the workspace. */
+int rg_sim_set_tables(rg_sim* sim, const double* d_gamma, const double* d_mu_organic,
+                      const double* d_beta, const double* d_mu_bandit, void* stream);
+
+/* Where rows go.  d_log == NULL (or capacity 0) disables logging: only counters are kept. */
+int rg_sim_set_log(rg_sim* sim, rg_event* d_log, uint64_t capacity);
+
+/* RecoEnv1.reset + AbstractEnv.reset (reco_env_v1.py:78-82, abstract.py:90-103) for `n` users
+ * with ids first_user_id .. first_user_id+n-1 at once: state <- organic, t <- 0,
+ * omega <- sigma_omega_initial * Z(K).  Users with id < organic_only_below are the
+ * `num_organic_offline_users` warm-up users of generate_logs (abstract.py:293-297): they emit
+ * only their first organic session.  Re-seeds nothing; `seed`/`policy_seed` may be changed
+ * between runs with rg_sim_reseed (reset_random_seed(epoch), abstract.py:59-62). */
+int rg_sim_reset_users(rg_sim* sim, uint64_t first_user_id, uint64_t n,
+                       uint64_t organic_only_below, void* stream);
+int rg_sim_reseed(rg_sim* sim, uint64_t seed, uint64_t policy_seed);
+
+/* One Markov transition for every live user (one emitted row per live user, plus the phantom
+ * row of users that stop) — the batched form of AbstractEnv.step / step_offline /
+ * generate_organic_sessions (abstract.py:105-239) and RecoEnv1.update_product_view /
+ * draw_click / update_state (reco_env_v1.py:85-128).  With RG_POLICY_EXTERNAL,
+ * d_actions[i] is the action for the i-th user of the reset range (read only for users in the
+ * bandit state; a user that stops then gets no phantom row — the caller's agent owns it). */
+int rg_sim_step(rg_sim* sim, const int32_t* d_actions, void* stream);
+
+/* generate_logs' user loop (abstract.py:299-316) for all users at once: steps until every user
+ * reached `stop` or max_steps transitions were made.  Synchronises `stream`. */
+int rg_sim_run(rg_sim* sim, uint32_t max_steps, void* stream);
+
+/* Synchronises `stream` and copies RG_CNT_N counters to the host. */
+int rg_sim_read_counters(rg_sim* sim, int64_t* out, void* stream);
+
+/* Current Markov state per user of the reset range (int8, RG_STATE_*), for the gym.Env
+ * compatibility path.  d_state has n entries. */
+int rg_sim_export_state(rg_sim* sim, int8_t* d_state, void* stream);
+/* Copy omega (float64, user-major (n,K)) out, for debugging views (`env.omega`). */
+int rg_sim_export_omega(rg_sim* sim, double* d_omega, void* stream);
+
+/* Reorder a step-major device log into the reference's row order (user, then t; phantom last —
+ * SURVEY.md Appendix A.6).  d_rows_per_user (n+1 int64, exclusive prefix filled by this call)
+ * and d_sorted (n_rows) are caller-owned. */
+int rg_log_sort_by_user(const rg_event* d_log, uint64_t n_rows, uint64_t first_user_id,
+                        uint64_t n_users, int64_t* d_row_offsets, rg_event* d_sorted,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RECOGYM_HIP_H */

@@ -1,0 +1,56 @@
+"""Helpers shared by the parity tests: load a tests/golden fixture and rebuild its config."""
+import json
+import os
+
+import numpy as np
+
+from recogym_amd import _abi
+from recogym_amd.envs.configuration import Configuration
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+POLICY_OF = {None: _abi.RG_POLICY_UNIFORM_ENV, 'random': _abi.RG_POLICY_RANDOM_AGENT,
+             'ouc': _abi.RG_POLICY_ORGANIC_USER_COUNT}
+
+OUC_DEFAULTS = dict(select_randomly=True, epsilon=0.0, exploit_explore=True, reverse_pop=False)
+
+
+def fixtures(prefix):
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith(prefix) and f.endswith('.npz'))
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    meta = json.loads(str(z['meta']))
+    cols = {k: z[k] for k in z.files if k != 'meta'}
+    return meta, cols
+
+
+def policy_args(meta):
+    """-> dict(policy=, policy_seed=, ouc=) for make_rg_config / OracleEnv / the HIP env."""
+    kind = meta['agent']
+    aa = meta['agent_args']
+    out = dict(policy=POLICY_OF[kind], policy_seed=aa.get('random_seed'), ouc=None)
+    if kind == 'ouc':
+        out['ouc'] = {**OUC_DEFAULTS, **{k: v for k, v in aa.items() if k in OUC_DEFAULTS}}
+    return out
+
+
+def env_config(meta):
+    return Configuration(meta['env_args'])
+
+
+def assert_rows_equal(rows, cols, ps_rtol=1e-12, what=''):
+    """rows: structured array with u,t,z,v,a,c,ps[,p_click]; cols: fixture columns."""
+    assert len(rows) == len(cols['t']), f'{what}: {len(rows)} rows vs {len(cols["t"])}'
+    for k in ('u', 't', 'z', 'v', 'a', 'c'):
+        got = rows[k].astype(np.int64)
+        want = cols[k].astype(np.int64)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (f'{what}: column {k}: {bad.size} mismatches, first at row '
+                               f'{bad[0]}: got {got[bad[0]]} want {want[bad[0]]}')
+    np.testing.assert_allclose(rows['ps'], cols['ps'], rtol=ps_rtol, atol=0, equal_nan=True,
+                               err_msg=f'{what}: ps')
+    if 'p_click' in cols and 'p_click' in rows.dtype.names:
+        np.testing.assert_allclose(rows['p_click'], cols['p_click'], rtol=1e-12, atol=0,
+                                   equal_nan=True, err_msg=f'{what}: p_click')

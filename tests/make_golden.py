@@ -1,0 +1,193 @@
+"""Generates tests/golden/* by running the UNMODIFIED reference in this container.
+
+    python tests/make_golden.py            # needs /root/reference; ~1-2 minutes
+
+Two families (see oracle/recogym_oracle.c header):
+  mt_*.npz      logs of the reference on its own sequential MT19937 stream (as shipped)
+  philox_*.npz  logs of the reference's arithmetic with the counter RNG injected via `env.rng`
+  notebook_getting_started.json  the known-answer vectors stored in the reference's
+                `Getting Started.ipynb` (cells 7 and 9), transcribed from the notebook file
+                itself, plus the same sequences re-run here.
+Every fixture stores the env args / agent args it was made with, so the tests rebuild the
+identical configuration without the reference.
+"""
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+import ref_harness as rh  # noqa: E402
+
+GOLDEN = os.path.join(HERE, 'golden')
+
+BASE = dict(num_products=10, num_users=100, prob_leave_bandit=0.01, prob_leave_organic=0.01,
+            prob_bandit_to_organic=0.05, prob_organic_to_bandit=0.25, normalize_beta=False,
+            with_ps_all=False, K=5, sigma_omega_initial=1, sigma_omega=0.1, number_of_flips=0,
+            sigma_mu_organic=3, change_omega_for_bandits=False, num_clusters=2, phi_var=0.1)
+
+
+def make_agent(kind, agent_args):
+    rh.import_reference()
+    from recogym import Configuration
+    if kind == 'random':
+        from recogym.agents import RandomAgent, random_args
+        return RandomAgent(Configuration({**random_args, **agent_args}))
+    if kind == 'ouc':
+        from recogym.agents import OrganicUserEventCounterAgent, organic_user_count_args
+        return OrganicUserEventCounterAgent(
+            Configuration({**organic_user_count_args, **agent_args}))
+    raise ValueError(kind)
+
+
+def save(name, arrays, meta):
+    small = {}
+    for k, v in arrays.items():
+        if k in ('z', 'c'):
+            small[k] = v.astype(np.int8)
+        elif k in ('ps', 'p_click'):
+            small[k] = v
+        else:
+            small[k] = v.astype(np.int32)
+    path = os.path.join(GOLDEN, name + '.npz')
+    np.savez_compressed(path, meta=np.array(json.dumps(meta)), **small)
+    print(f'{name}: {len(arrays["t"])} rows -> {os.path.getsize(path) / 1024:.0f} KiB')
+
+
+def run_case(name, env_over, n_users, n_organic=0, agent_kind=None, agent_args=None,
+             injected=False):
+    args = {**BASE, **env_over}
+    env = rh.make_reference_env(args)
+    agent = None
+    agent_args = dict(agent_args or {})
+    if agent_kind:
+        agent_args.setdefault('num_products', args['num_products'])
+        agent = make_agent(agent_kind, agent_args)
+    p_click = None
+    if injected:
+        rng = rh.inject_counter_rng(env, agent, agent_args.get('random_seed'))
+    df = env.generate_logs(n_users, agent, n_organic)
+    arrays = rh.log_to_arrays(df)
+    if injected:
+        # p_click of every REAL bandit row, in row order (phantom rows are never drawn)
+        pc = np.full(len(df), np.nan)
+        is_b = arrays['z'] == 1
+        last_of_user = np.r_[arrays['u'][1:] != arrays['u'][:-1], True]
+        real = is_b & ~last_of_user
+        # organic-only users end with an organic row, main users with the phantom bandit row
+        assert real.sum() == len(rng.p_click_log), (real.sum(), len(rng.p_click_log))
+        pc[real] = rng.p_click_log
+        arrays['p_click'] = pc
+    meta = dict(env_args=args, n_users=n_users, n_organic=n_organic, agent=agent_kind,
+                agent_args=agent_args, rng='philox' if injected else 'mt')
+    save(name, arrays, meta)
+
+
+def notebook_goldens():
+    """Transcribe cells 7 and 9 of `Getting Started.ipynb` and re-run them on the reference."""
+    nb = json.load(open(os.path.join(rh.REFERENCE_ROOT, 'Getting Started.ipynb')))
+    out = {}
+    for cell_no in (7, 9):
+        text = ''.join(nb['cells'][cell_no]['outputs'][0]['text'])
+        steps = []
+        for line in text.strip().split('\n'):
+            m = re.match(r'Step: (\d+) - Action: (.*) - Observation: (\[.*\]) - Reward: (\w+)', line)
+            act = m.group(2)
+            if act.startswith('{'):
+                a = int(re.search(r"'a': (\d+)", act).group(1))
+                t = int(re.search(r"'t': (\d+)", act).group(1))
+            elif act == 'None':
+                a, t = None, None
+            else:
+                a, t = int(act), None
+            views = [[int(x), int(y)] for x, y in
+                     re.findall(r"\{'t': (\d+), 'u': 0, 'z': 'pageview', 'v': (\d+)\}", m.group(3))]
+            rew = None if m.group(4) == 'None' else int(m.group(4))
+            steps.append(dict(step=int(m.group(1)), action=a, action_t=t, views=views, reward=rew))
+        out[f'cell{cell_no}_stored'] = steps
+
+    # the same two cells executed here on the unmodified reference
+    args = {**BASE, 'random_seed': 42}
+    env = rh.make_reference_env(args)
+    env.reset()
+    observation, reward, done = None, 0, False
+    rerun7 = []
+    i = 0
+    while not done:
+        action, observation, reward, done, info = env.step_offline(observation, reward, done)
+        rerun7.append(dict(step=i, action=None if action is None else int(action['a']),
+                           action_t=None if action is None else int(action['t']),
+                           views=[[int(s['t']), int(s['v'])] for s in observation.sessions()],
+                           reward=None if reward is None else int(reward)))
+        i += 1
+    out['cell7_rerun'] = rerun7
+    out['cell7_done'] = bool(done)
+    actions = [None, 1, 2, 3, 4, 5]
+    env.reset()
+    done = False
+    rerun9 = []
+    i = 0
+    while not done and i < len(actions):
+        observation, reward, done, info = env.step(actions[i])
+        rerun9.append(dict(step=i, action=actions[i], action_t=None,
+                           views=[[int(s['t']), int(s['v'])] for s in observation.sessions()],
+                           reward=None if reward is None else int(reward)))
+        i += 1
+    out['cell9_rerun'] = rerun9
+    out['env_args'] = args
+    with open(os.path.join(GOLDEN, 'notebook_getting_started.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+    same7 = out['cell7_stored'] == out['cell7_rerun']
+    same9 = out['cell9_stored'] == out['cell9_rerun']
+    print(f'notebook goldens: cell7 stored==rerun {same7}, cell9 stored==rerun {same9}')
+    assert same7 and same9
+
+
+def main():
+    assert rh.reference_available(), 'needs /root/reference'
+    os.makedirs(GOLDEN, exist_ok=True)
+    notebook_goldens()
+    S = dict(random_seed=42)
+    # --- reference as shipped (sequential MT19937) ---
+    run_case('mt_config1', {**S, 'sigma_omega': 0.0}, 1000)                    # BASELINE config 1
+    run_case('mt_drift_organic_users', {**S}, 200, n_organic=20)
+    run_case('mt_random_agent', {**S, 'num_products': 50, 'K': 20}, 200,
+             agent_kind='random', agent_args=dict(random_seed=7))
+    run_case('mt_ouc', {**S, 'num_products': 50, 'K': 20}, 200,
+             agent_kind='ouc', agent_args=dict(random_seed=11))
+    run_case('mt_ouc_eps', {**S, 'num_products': 50, 'K': 20}, 150,
+             agent_kind='ouc', agent_args=dict(random_seed=12, epsilon=0.3))
+    run_case('mt_ouc_argmax', {**S, 'num_products': 50, 'K': 20}, 100,
+             agent_kind='ouc', agent_args=dict(random_seed=13, select_randomly=False))
+    run_case('mt_ouc_noexplore_revpop', {**S, 'num_products': 20, 'K': 8}, 100,
+             agent_kind='ouc', agent_args=dict(random_seed=14, exploit_explore=False,
+                                               epsilon=0.5, reverse_pop=True))
+    run_case('mt_flips_normbeta', {**S, 'num_products': 30, 'number_of_flips': 5,
+                                   'normalize_beta': True}, 150)
+    run_case('mt_change_omega', {**S, 'change_omega_for_bandits': True}, 150)
+    # --- reference arithmetic + injected counter RNG ---
+    run_case('philox_p10', {**S}, 300, n_organic=10, injected=True)
+    run_case('philox_p10_sigma0', {**S, 'sigma_omega': 0.0}, 300, injected=True)
+    run_case('philox_p1000_k20', {**S, 'num_products': 1000, 'K': 20, 'sigma_omega': 0.0}, 80,
+             injected=True)
+    run_case('philox_p10000_k20', {**S, 'num_products': 10000, 'K': 20}, 24, injected=True)
+    run_case('philox_p2000_k64', {**S, 'num_products': 2000, 'K': 64}, 30, injected=True)
+    run_case('philox_p257_k7', {**S, 'num_products': 257, 'K': 7, 'random_seed': 5}, 100,
+             injected=True)
+    run_case('philox_random_agent', {**S, 'num_products': 100, 'K': 20}, 120,
+             agent_kind='random', agent_args=dict(random_seed=5), injected=True)
+    run_case('philox_ouc', {**S, 'num_products': 50, 'K': 20}, 150,
+             agent_kind='ouc', agent_args=dict(random_seed=11), injected=True)
+    run_case('philox_ouc_eps', {**S, 'num_products': 50, 'K': 20}, 120,
+             agent_kind='ouc', agent_args=dict(random_seed=12, epsilon=0.2), injected=True)
+    run_case('philox_flips_normbeta', {**S, 'num_products': 30, 'number_of_flips': 5,
+                                       'normalize_beta': True}, 120, injected=True)
+    run_case('philox_change_omega', {**S, 'change_omega_for_bandits': True}, 120, injected=True)
+
+
+if __name__ == '__main__':
+    main()
