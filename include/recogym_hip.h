@@ -109,6 +109,7 @@ typedef struct rg_event {
 #define RG_CNT_LOG_ROWS 6       /* rows written to the log buffer */
 #define RG_CNT_LOG_DROPPED 7    /* rows that did not fit (capacity exceeded) */
 #define RG_CNT_EXACT_DRAWS 8    /* organic draws resolved by the float64 path */
+#define RG_CNT_HIST_OVERFLOW 9  /* OrganicUserEventCounter views that did not fit ouc_history_cap */
 #define RG_CNT_N 16
 
 typedef struct rg_sim rg_sim;
@@ -170,12 +171,16 @@ int rg_sim_export_state(rg_sim* sim, int8_t* d_state, void* stream);
 /* Copy omega (float64, user-major (n,K)) out, for debugging views (`env.omega`). */
 int rg_sim_export_omega(rg_sim* sim, double* d_omega, void* stream);
 
-/* Reorder a step-major device log into the reference's row order (user, then t; phantom last —
- * SURVEY.md Appendix A.6).  d_rows_per_user (n+1 int64, exclusive prefix filled by this call)
- * and d_sorted (n_rows) are caller-owned. */
-int rg_log_sort_by_user(const rg_event* d_log, uint64_t n_rows, uint64_t first_user_id,
-                        uint64_t n_users, int64_t* d_row_offsets, rg_event* d_sorted,
-                        void* stream);
+/* The row order of generate_logs' DataFrame (abstract.py:299-316): the
+ * step-major device log is scattered so that each user's rows are contiguous, ordered by t,
+ * the phantom row last, users in id order.  Caller-owned device buffers:
+ *   d_row_offsets  n+1 int64 — filled with the exclusive prefix of rows per user (last = total)
+ *   d_scratch      n + ceil(n/256) int64
+ *   d_sorted       sorted_capacity rows
+ * Synchronises `stream` once (to read the emitted-row count); fails with RG_ELIMIT when the
+ * log buffer overflowed. */
+int rg_sim_sort_log(rg_sim* sim, int64_t* d_row_offsets, int64_t* d_scratch, rg_event* d_sorted,
+                    uint64_t sorted_capacity, void* stream);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ RG_EV_PHANTOM = 0x20000000
 RG_EV_INDEX_MASK = 0x1FFFFFFF
 
 (RG_CNT_ORGANIC, RG_CNT_BANDIT, RG_CNT_CLICKS, RG_CNT_PHANTOM, RG_CNT_LIVE, RG_CNT_STEP,
- RG_CNT_LOG_ROWS, RG_CNT_LOG_DROPPED, RG_CNT_EXACT_DRAWS) = range(9)
+ RG_CNT_LOG_ROWS, RG_CNT_LOG_DROPPED, RG_CNT_EXACT_DRAWS, RG_CNT_HIST_OVERFLOW) = range(10)
 RG_CNT_N = 16
 
 RG_ERRORS = {-1: 'RG_EINVAL', -2: 'RG_ENODEV', -3: 'RG_ENOMEM', -4: 'RG_ESTATE', -5: 'RG_ELIMIT'}
@@ -73,8 +73,8 @@ SYMBOLS = {
     'rg_sim_read_counters': (C.c_int, [_SIM, C.POINTER(C.c_int64), C.c_void_p]),
     'rg_sim_export_state': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_export_omega': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
-    'rg_log_sort_by_user': (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
-                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    'rg_sim_sort_log': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                  C.c_void_p]),
 }
 
 LIB_NAME = 'librecogym_hip.so'

@@ -1,0 +1,940 @@
+// recogym_hip.hip — librecogym_hip.so: the reco-gym-v1 step loop as batched CDNA4 (gfx950) kernels.
+//
+// What runs here (reference file:line each kernel takes over; see DESIGN.md for the data layout
+// and the roofline of each kernel):
+//
+//   k_reset_users    RecoEnv1.reset / AbstractEnv.reset          reco_env_v1.py:78-82, abstract.py:90-103
+//   k_draw_exact     RecoEnv1.update_product_view (float64)      reco_env_v1.py:119-128
+//   k_draw_mfma      RecoEnv1.update_product_view (fp32 MFMA fast path with a certified margin;
+//                    draws it cannot certify are handed to k_draw_exact)
+//   k_advance        AbstractEnv.step / step_offline, RecoEnv1.draw_click / update_state, the
+//                    policy's act and the log rows of generate_logs
+//                                                                abstract.py:123-239,267-316
+//                                                                reco_env_v1.py:85-116
+//   k_sort_*         row order of generate_logs' DataFrame       abstract.py:299-327
+//
+// Lock-step structure: every live user advances exactly one Markov transition per step, so the
+// step index IS the per-user event time t (DefaultTimeGenerator).  Users that are in the
+// organic state at step t sit in list_o[t&1], users in the bandit state in list_b[t&1]; a step
+// reads those lists and appends survivors to the lists of step t+1.  All randomness is
+// addressed by (seed, user, t, purpose) (include/recogym_rng.h), so results do not depend on
+// list order, grid shape or the number of GPUs the users are sharded over.
+//
+// gfx950 only.  No CPU fallback: every compute entry point fails with RG_ENODEV without a device.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/recogym_hip.h"
+#include "../../include/recogym_rng.h"
+
+namespace {
+
+constexpr uint32_t kMaxSteps = 1u << 16;       // P(a user survives that long) ~ exp(-650)
+constexpr int kBlock = 256;                    // 4 waves of 64
+constexpr int kMaxGrid = 4096;
+constexpr uint32_t kDefaultHistoryCap = 256;
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(RG_ENODEV, "%s failed: %s", #expr, hipGetErrorString(e_));        \
+    } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Everything a kernel needs, passed by value.
+struct DevSim {
+    // configuration
+    uint32_t P, K;
+    uint64_t seed, policy_seed;
+    double cdf_o0, cdf_o1, cdf_b0, cdf_b1;   // normalised cumulative transition rows
+    double sigma0, sigma_omega;
+    uint32_t change_omega_for_bandits, policy;
+    uint32_t ouc_select_randomly, ouc_exploit_explore, ouc_reverse_pop, hist_cap;
+    double ouc_epsilon;
+    // user range
+    uint64_t first_user;
+    uint32_t n_users;         // users of the current reset range
+    uint32_t n_cap, n_pad;    // users the workspace was carved for (list stride), padded to 64
+    uint64_t organic_only_below;
+    // tables (caller-owned float64) and fp32 copies (workspace)
+    const double* gamma; const double* mu_o; const double* beta; const double* mu_b;
+    float* gamma32; float* mu32;
+    // state (workspace)
+    double* omega;            // [K][n_pad], K-major: lane-per-user accesses coalesce
+    uint32_t* list;           // [2 parity][2 state][n_users]
+    uint32_t* step_cnt;       // [kMaxSteps+2][2]: users in organic / bandit state at step t
+    uint64_t* log_base;       // [kMaxSteps+2]: first log row of step t
+    uint32_t* exact_list;     // [n_users] organic users whose draw needs the float64 path
+    uint32_t* exact_cnt;      // [kMaxSteps+2]
+    uint32_t* n_events;       // [n_users] rows the user emitted (set when it leaves)
+    rg_event* phantom;        // [n_users] trailing undrawn bandit row
+    uint8_t* has_phantom;     // [n_users]
+    uint32_t* hist;           // [hist_cap][n_pad] sorted distinct viewed products (OUC policy)
+    uint16_t* hist_cntv;      // [hist_cap][n_pad] view counts of those products
+    uint32_t* hist_n;         // [n_users] distinct products viewed
+    unsigned long long* counters;   // [RG_CNT_N]
+    // log
+    rg_event* log; uint64_t log_cap;
+};
+
+}  // namespace
+
+struct rg_sim {
+    rg_config cfg;
+    DevSim d;
+    void* workspace;
+    size_t workspace_bytes;
+    uint32_t t;               // next step to run
+    uint32_t live_upper;      // upper bound of live users (for grid sizing)
+    bool tables_set, users_reset;
+    uint32_t* h_pinned;       // 4 x u32 staging for the live-count readback
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// workspace carving (host)
+// ------------------------------------------------------------------------------------------
+struct Carve {
+    size_t off = 0;
+    char* base;
+    explicit Carve(void* b) : base(static_cast<char*>(b)) {}
+    template <class T> T* take(size_t n) {
+        off = align_up(off, 256);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+uint32_t hist_cap_of(const rg_config& c) {
+    if (c.policy != RG_POLICY_ORGANIC_USER_COUNT) return 0;
+    return c.ouc_history_cap ? c.ouc_history_cap : kDefaultHistoryCap;
+}
+
+size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
+    Carve w(base);
+    const size_t n_pad = align_up(n, 64);
+    const size_t P = c.num_products, K = c.K;
+    float* gamma32 = w.take<float>(align_up(P, 64) * K);
+    float* mu32 = w.take<float>(align_up(P, 64));
+    double* omega = w.take<double>(K * n_pad);
+    uint32_t* list = w.take<uint32_t>(4 * n);
+    uint32_t* step_cnt = w.take<uint32_t>(2 * (kMaxSteps + 2));
+    uint64_t* log_base = w.take<uint64_t>(kMaxSteps + 2);
+    uint32_t* exact_list = w.take<uint32_t>(n);
+    uint32_t* exact_cnt = w.take<uint32_t>(kMaxSteps + 2);
+    uint32_t* n_events = w.take<uint32_t>(n);
+    rg_event* phantom = w.take<rg_event>(n);
+    uint8_t* has_phantom = w.take<uint8_t>(n);
+    const size_t hc = hist_cap_of(c);
+    uint32_t* hist = w.take<uint32_t>(hc * n_pad);
+    uint16_t* hist_cntv = w.take<uint16_t>(hc * n_pad);
+    uint32_t* hist_n = w.take<uint32_t>(n);
+    unsigned long long* counters = w.take<unsigned long long>(RG_CNT_N);
+    if (d) {
+        d->gamma32 = gamma32; d->mu32 = mu32; d->omega = omega; d->list = list;
+        d->step_cnt = step_cnt; d->log_base = log_base; d->exact_list = exact_list;
+        d->exact_cnt = exact_cnt; d->n_events = n_events; d->phantom = phantom;
+        d->has_phantom = has_phantom; d->hist = hist; d->hist_cntv = hist_cntv;
+        d->hist_n = hist_n; d->counters = counters;
+        d->n_pad = static_cast<uint32_t>(n_pad);
+        d->hist_cap = static_cast<uint32_t>(hc);
+    }
+    return align_up(w.off, 256);
+}
+
+int validate(const rg_config* c, uint64_t n) {
+    if (!c) return fail(RG_EINVAL, "config is NULL");
+    if (c->num_products == 0 || c->num_products > RG_EV_INDEX_MASK)
+        return fail(RG_EINVAL, "num_products %u out of range [1, 2^29)", c->num_products);
+    if (c->K == 0 || c->K > 1024) return fail(RG_EINVAL, "K %u out of range [1, 1024]", c->K);
+    if (sizeof(double) * (c->K + (c->num_products + 63) / 64 + 1) * (kBlock / 64) > 64 * 1024)
+        return fail(RG_EINVAL, "num_products %u / K %u exceed the float64 draw kernel's LDS budget",
+                    c->num_products, c->K);
+    if (n == 0 || n >= (1ull << 31)) return fail(RG_EINVAL, "n_users %llu out of range", (unsigned long long)n);
+    if (c->policy > RG_POLICY_EXTERNAL) return fail(RG_EINVAL, "unknown policy %u", c->policy);
+    for (int s = 0; s < 2; ++s)
+        if (!(c->trans_cdf[s][0] >= 0.0 && c->trans_cdf[s][0] <= c->trans_cdf[s][1] &&
+              c->trans_cdf[s][1] <= 1.0))
+            return fail(RG_EINVAL, "transition cdf row %d is not monotone in [0,1]", s);
+    return RG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ uint32_t prefix_in_mask(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+__device__ __forceinline__ double sigmoid64(double x) { return 1.0 / (1.0 + exp(-x)); }
+// ff(): reco_env_v1.py:38-41
+__device__ __forceinline__ double ff64(double x) {
+    return sigmoid64(5.0 * sigmoid64(2.0 * sigmoid64(0.3 * x) - 2.0) - 6.0);
+}
+
+// Box-Muller pair j of the K normals addressed by (user, t, purpose)
+__device__ __forceinline__ void normal_pair(uint64_t seed, uint32_t user, uint32_t t, uint32_t j,
+                                            uint32_t purpose, double* z0, double* z1) {
+    const rg_u32x4 w = rg_draw(seed, user, t, j, purpose);
+    const double u1 = rg_uniform(w.w[0], w.w[1]);
+    const double u2 = rg_uniform(w.w[2], w.w[3]);
+    const double r = sqrt(-2.0 * log(1.0 - u1));
+    double s, c;
+    sincos(RG_TWO_PI * u2, &s, &c);
+    *z0 = r * c;
+    *z1 = r * s;
+}
+
+__device__ __forceinline__ uint32_t* list_ptr(const DevSim& d, uint32_t parity, uint32_t state) {
+    return d.list + (static_cast<size_t>(parity) * 2 + state) * d.n_cap;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_reset_users
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_reset_users(DevSim d) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0) {
+        d.step_cnt[0] = d.n_users;   // everyone starts organic (abstract.py:93)
+        d.step_cnt[1] = 0;
+        d.log_base[0] = 0;
+    }
+    if (i >= d.n_users) return;
+    const uint32_t user = static_cast<uint32_t>(d.first_user + i);
+    for (uint32_t j = 0; 2 * j < d.K; ++j) {
+        double z0, z1;
+        normal_pair(d.seed, user, 0u, j, RG_DRAW_RESET, &z0, &z1);
+        d.omega[static_cast<size_t>(2 * j) * d.n_pad + i] = 0.0 + d.sigma0 * z0;
+        if (2 * j + 1 < d.K) d.omega[static_cast<size_t>(2 * j + 1) * d.n_pad + i] = 0.0 + d.sigma0 * z1;
+    }
+    list_ptr(d, 0, RG_STATE_ORGANIC)[i] = i;
+    d.n_events[i] = 0;
+    d.has_phantom[i] = 0;
+    if (d.hist_cap) d.hist_n[i] = 0;
+}
+
+// fp32 copies of Gamma / mu_organic for the MFMA path (rows padded to a multiple of 64 products)
+__global__ void __launch_bounds__(kBlock) k_make_fp32_tables(DevSim d) {
+    const size_t P64 = (static_cast<size_t>(d.P) + 63) / 64 * 64;
+    const size_t n = P64 * d.K;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const size_t p = i / d.K;
+        d.gamma32[i] = p < d.P ? static_cast<float>(d.gamma[i]) : 0.0f;
+        if (i < P64) d.mu32[i] = i < d.P ? static_cast<float>(d.mu_o[i]) : -INFINITY;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The policy's act on the device.  Returns the action; writes the propensity.
+//   agent=None       abstract.py:209-221        uniform over P from the ENV stream
+//   RandomAgent      random_agent.py:22-33      uniform over P from the agent's stream
+//   OrganicUserEventCounter  organic_user_count.py:45-96 on the user's own view counts
+// ------------------------------------------------------------------------------------------
+__device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, uint32_t t,
+                               double* ps_out) {
+    const rg_u32x4 w = rg_draw(d.policy_seed, user, t, 0, RG_DRAW_POLICY);
+    if (d.policy != RG_POLICY_ORGANIC_USER_COUNT) {
+        *ps_out = 1.0 / static_cast<double>(d.P);
+        return rg_bounded(w.w[0], w.w[1], d.P);
+    }
+    // --- OrganicUserEventCounterModel.act over the user's sorted (product, count) history ---
+    const uint32_t nd = d.hist_n[slot];
+    const double eps = d.ouc_epsilon;
+    const uint32_t* hp = d.hist + slot;
+    const uint16_t* hc = d.hist_cntv + slot;
+    const size_t stride = d.n_pad;
+    bool explore = false;
+    if (d.ouc_exploit_explore) {
+        const double u0 = rg_uniform(w.w[0], w.w[1]);
+        const double c0 = eps, c1 = eps + (1.0 - eps);
+        explore = !(c0 / c1 <= u0);
+    }
+    const double u1 = rg_uniform(w.w[2], w.w[3]);
+    if (d.ouc_exploit_explore && !explore) {
+        // p_i = count_i / sum(counts): zero entries add exactly 0.0 to the running cdf, so the
+        // sequential float64 cumsum over all P products equals the one over the viewed ones.
+        double sum = 0.0;
+        for (uint32_t i = 0; i < nd; ++i) sum += static_cast<double>(hc[i * stride]);
+        if (d.ouc_select_randomly) {
+            double last = 0.0;
+            for (uint32_t i = 0; i < nd; ++i) last += static_cast<double>(hc[i * stride]) / sum;
+            double acc = 0.0;
+            uint32_t a = d.P - 1;     // searchsorted(..., 'right') on a cdf ending at 1.0
+            double pa = 0.0;
+            bool found = false;
+            for (uint32_t i = 0; i < nd; ++i) {
+                const double p = static_cast<double>(hc[i * stride]) / sum;
+                acc += p;
+                if (!found && !(acc / last <= u1)) { a = hp[i * stride]; pa = p; found = true; }
+            }
+            *ps_out = (1.0 - eps) * pa;
+            return a;
+        }
+        uint32_t best = 0; double bestp = -1.0;
+        for (uint32_t i = 0; i < nd; ++i) {
+            const double p = static_cast<double>(hc[i * stride]) / sum;
+            if (p > bestp) { bestp = p; best = hp[i * stride]; }
+        }
+        *ps_out = 1.0;
+        return best;
+    }
+    // Dense cases (explore flip, epsilon smoothing, reverse_pop): every product has mass, the
+    // float64 running sums are order-dependent, so walk all P products like numpy does.
+    // O(P) per act; used by parity tests and small P only (BASELINE configs use epsilon = 0).
+    auto count_of = [&](uint32_t p, uint32_t* cursor) -> double {
+        // history is sorted by product id; cursor walks it once
+        while (*cursor < nd && hp[*cursor * stride] < p) ++*cursor;
+        return (*cursor < nd && hp[*cursor * stride] == p)
+                   ? static_cast<double>(hc[*cursor * stride]) : 0.0;
+    };
+    auto feature = [&](double cnt) -> double {
+        if (d.ouc_exploit_explore) return cnt == 0.0 ? 1.0 : 0.0;   // explore: unseen products
+        return eps + cnt;
+    };
+    double sum = 0.0;
+    uint32_t cur = 0;
+    for (uint32_t p = 0; p < d.P; ++p) sum += feature(count_of(p, &cur));
+    double sum2 = 0.0;
+    if (!d.ouc_exploit_explore && d.ouc_reverse_pop) {
+        cur = 0;
+        for (uint32_t p = 0; p < d.P; ++p) sum2 += 1.0 - feature(count_of(p, &cur)) / sum;
+    }
+    auto prob = [&](double cnt) -> double {
+        double pr = feature(cnt) / sum;
+        if (!d.ouc_exploit_explore && d.ouc_reverse_pop) pr = (1.0 - pr) / sum2;
+        return pr;
+    };
+    if (d.ouc_select_randomly) {
+        double last = 0.0;
+        cur = 0;
+        for (uint32_t p = 0; p < d.P; ++p) last += prob(count_of(p, &cur));
+        double acc = 0.0, pa = 0.0;
+        uint32_t a = d.P - 1;
+        bool found = false;
+        cur = 0;
+        for (uint32_t p = 0; p < d.P; ++p) {
+            const double pr = prob(count_of(p, &cur));
+            acc += pr;
+            if (!found && !(acc / last <= u1)) { a = p; pa = pr; found = true; }
+        }
+        *ps_out = d.ouc_exploit_explore ? eps * pa : pa;
+        return a;
+    }
+    uint32_t best = 0; double bestp = -1.0;
+    cur = 0;
+    for (uint32_t p = 0; p < d.P; ++p) {
+        const double pr = prob(count_of(p, &cur));
+        if (pr > bestp) { bestp = pr; best = p; }
+    }
+    *ps_out = 1.0;
+    return best;
+}
+
+// ViewsFeaturesProvider.observe (agents/abstract.py:347-358): count one organic view, keeping the
+// user's (product, count) history sorted by product id.
+__device__ void history_add(const DevSim& d, uint32_t slot, uint32_t v) {
+    uint32_t* hp = d.hist + slot;
+    uint16_t* hc = d.hist_cntv + slot;
+    const size_t stride = d.n_pad;
+    const uint32_t nd = d.hist_n[slot];
+    uint32_t i = 0;
+    while (i < nd && hp[i * stride] < v) ++i;
+    if (i < nd && hp[i * stride] == v) {
+        if (hc[i * stride] == 0xFFFFu) { atomicAdd(&d.counters[RG_CNT_HIST_OVERFLOW], 1ull); return; }
+        hc[i * stride] += 1;
+        return;
+    }
+    if (nd >= d.hist_cap) { atomicAdd(&d.counters[RG_CNT_HIST_OVERFLOW], 1ull); return; }
+    for (uint32_t j = nd; j > i; --j) {
+        hp[j * stride] = hp[(j - 1) * stride];
+        hc[j * stride] = hc[(j - 1) * stride];
+    }
+    hp[i * stride] = v;
+    hc[i * stride] = 1;
+    d.hist_n[slot] = nd + 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_draw_exact — the organic product draw in float64, one wave per user.
+//   l = Gamma omega + mu_o ; p = softmax(l) ; v = first index with cumsum(p)/cumsum(p)[-1] > u
+// Pass 1: per-lane online (max, sum exp) over products lane, lane+64, ...; wave combine.
+// Pass 2: recompute exp(l - max) in product order, wave-wide inclusive scan per 64 products,
+//         first lane whose running prefix exceeds u * total wins.
+// With from_list == 0 it serves every organic user of the step (correctness-first path);
+// with from_list == 1 only the users the fp32 MFMA kernel could not certify.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_max(double x) {
+    for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o));
+    return x;
+}
+__device__ __forceinline__ double wave_sum(double x) {
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+__device__ __forceinline__ void write_organic_row(const DevSim& d, uint32_t t, uint32_t pos,
+                                                  uint32_t user, uint32_t v) {
+    const uint64_t row = d.log_base[t] + pos;
+    if (d.log && row < d.log_cap) {
+        rg_event e;
+        e.u = user; e.t = t; e.code = v; e.ps = __builtin_nanf("");
+        d.log[row] = e;
+    }
+}
+
+// inclusive scan of x over the 64 lanes of the wave
+__device__ __forceinline__ double wave_scan(double x, int lane) {
+    for (int o = 1; o < 64; o <<= 1) {
+        const double y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    return x;
+}
+
+__device__ __forceinline__ double logit64(const DevSim& d, const double* om, uint32_t p) {
+    const double* g = d.gamma + static_cast<size_t>(p) * d.K;
+    double l = 0.0;
+    for (uint32_t k = 0; k < d.K; ++k) l += g[k] * om[k];
+    return l + d.mu_o[p];
+}
+
+__global__ void __launch_bounds__(kBlock) k_draw_exact(DevSim d, uint32_t t, int from_list) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t n_chunks = (d.P + 63) / 64;
+    double* om = reinterpret_cast<double*>(smem_raw) + static_cast<size_t>(wave) * (d.K + n_chunks + 1);
+    double* chunk_prefix = om + d.K;     // exclusive running sum at the start of each 64-product chunk
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const uint32_t n = from_list ? d.exact_cnt[t] : n_o;
+    const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const uint32_t waves_total = gridDim.x * (kBlock / 64);
+    for (uint32_t w = blockIdx.x * (kBlock / 64) + wave; w < n; w += waves_total) {
+        const uint32_t pos = from_list ? d.exact_list[w] : w;
+        const uint32_t slot = cur[pos];
+        const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
+        for (uint32_t k = lane; k < d.K; k += 64) om[k] = d.omega[static_cast<size_t>(k) * d.n_pad + slot];
+        __builtin_amdgcn_wave_barrier();
+        // pass 1: max logit (reco_env_v1.py:121)
+        double m = -INFINITY;
+        for (uint32_t p = lane; p < d.P; p += 64) m = fmax(m, logit64(d, om, p));
+        const double M = wave_max(m);
+        // pass 2: running sum of exp(l - max) in product order, remembered per 64-product chunk.
+        // The reference normalises p = e / sum(e) before its cumsum and divides by cdf[-1];
+        // dividing every term by the same positive constants moves the decision only at the
+        // 1e-16 level, so the running sum of e is compared with u * total directly.
+        double run = 0.0;
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            const uint32_t p = c * 64 + lane;
+            const double e = p < d.P ? exp(logit64(d, om, p) - M) : 0.0;
+            if (lane == 0) chunk_prefix[c] = run;
+            run += __shfl(wave_scan(e, lane), 63);
+        }
+        if (lane == 0) chunk_prefix[n_chunks] = run;
+        __builtin_amdgcn_wave_barrier();
+        const rg_u32x4 rw = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
+        const double target = rg_uniform(rw.w[0], rw.w[1]) * run;
+        // first chunk whose inclusive running sum exceeds the target
+        uint32_t cstar = n_chunks - 1;
+        for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            const unsigned long long hit = __ballot(c < n_chunks && chunk_prefix[c + 1] > target);
+            if (hit) { cstar = c0 + static_cast<uint32_t>(__builtin_ctzll(hit)); break; }
+        }
+        // recompute that chunk (same code, same values) and find the product inside it
+        uint32_t v = d.P - 1;
+        {
+            const uint32_t p = cstar * 64 + lane;
+            const double e = p < d.P ? exp(logit64(d, om, p) - M) : 0.0;
+            const double x = chunk_prefix[cstar] + wave_scan(e, lane);
+            const unsigned long long hit = __ballot(p < d.P && x > target);
+            if (hit) v = cstar * 64 + static_cast<uint32_t>(__builtin_ctzll(hit));
+        }
+        if (lane == 0) {
+            write_organic_row(d, t, pos, user, v);
+            if (d.hist_cap) history_add(d, slot, v);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (from_list == 1 && blockIdx.x == 0 && threadIdx.x == 0)
+        atomicAdd(&d.counters[RG_CNT_EXACT_DRAWS], static_cast<unsigned long long>(n));
+}
+
+// ------------------------------------------------------------------------------------------
+// k_advance — one Markov transition for every live user (lane per user).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_advance(DevSim d, uint32_t t, const int32_t* actions) {
+    __shared__ uint32_t s_wave_o[4], s_wave_b[4], s_base_o, s_base_b;
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const uint32_t n_b = d.step_cnt[2 * t + RG_STATE_BANDIT];
+    const uint32_t n = n_o + n_b;
+    const uint32_t* cur_o = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const uint32_t* cur_b = list_ptr(d, t & 1, RG_STATE_BANDIT);
+    uint32_t* next_o = list_ptr(d, (t + 1) & 1, RG_STATE_ORGANIC);
+    uint32_t* next_b = list_ptr(d, (t + 1) & 1, RG_STATE_BANDIT);
+    uint32_t* next_cnt = d.step_cnt + 2 * (t + 1);
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.log_base[t + 1] = d.log_base[t] + n;
+
+    uint32_t clicks = 0, phantoms = 0;
+    const uint32_t n_iter = (n + kBlock - 1) / kBlock;
+    for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+        const uint32_t i = it * kBlock + threadIdx.x;
+        int ns = RG_STATE_STOP;       // inactive lanes look dead
+        uint32_t slot = 0;
+        if (i < n) {
+            const bool is_org = i < n_o;
+            slot = is_org ? cur_o[i] : cur_b[i - n_o];
+            const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
+            const rg_u32x4 w = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
+            const double u_trans = rg_uniform(w.w[2], w.w[3]);
+            bool click = false;
+            if (!is_org) {
+                // step_offline: the policy acts (abstract.py:202-221), then draw_click
+                double ps;
+                uint32_t a;
+                if (d.policy == RG_POLICY_EXTERNAL) { a = static_cast<uint32_t>(actions[slot]); ps = __builtin_nan(""); }
+                else a = policy_act(d, slot, user, t, &ps);
+                const double* b = d.beta + static_cast<size_t>(a) * d.K;
+                double x = 0.0;
+                for (uint32_t k = 0; k < d.K; ++k) x += b[k] * d.omega[static_cast<size_t>(k) * d.n_pad + slot];
+                const double ctr = ff64(x + d.mu_b[a]);
+                const double p0 = 1.0 - ctr;
+                click = (p0 / (p0 + ctr)) <= rg_uniform(w.w[0], w.w[1]);
+                clicks += click;
+                const uint64_t row = d.log_base[t] + i;
+                if (d.log && row < d.log_cap) {
+                    rg_event e;
+                    e.u = user; e.t = t;
+                    e.code = RG_EV_BANDIT | (click ? RG_EV_CLICK : 0u) | a;
+                    e.ps = static_cast<float>(ps);
+                    d.log[row] = e;
+                }
+            }
+            // update_state (reco_env_v1.py:85-100)
+            const double c0 = is_org ? d.cdf_o0 : d.cdf_b0, c1 = is_org ? d.cdf_o1 : d.cdf_b1;
+            ns = (c0 <= u_trans) + (c1 <= u_trans);
+            if (d.sigma_omega != 0.0 && (d.change_omega_for_bandits || ns == RG_STATE_ORGANIC)) {
+                for (uint32_t j = 0; 2 * j < d.K; ++j) {
+                    double z0, z1;
+                    normal_pair(d.seed, user, t, j, RG_DRAW_DRIFT, &z0, &z1);
+                    double* o0 = d.omega + static_cast<size_t>(2 * j) * d.n_pad + slot;
+                    *o0 = *o0 + d.sigma_omega * z0;
+                    if (2 * j + 1 < d.K) { double* o1 = o0 + d.n_pad; *o1 = *o1 + d.sigma_omega * z1; }
+                }
+            }
+            if (click) ns = RG_STATE_ORGANIC;          // abstract.py:180-181
+            const bool organic_only = (d.first_user + slot) < d.organic_only_below;
+            if (organic_only && ns != RG_STATE_ORGANIC) {
+                ns = RG_STATE_STOP;                    // warm-up users end with their first session
+                d.n_events[slot] = t + 1;
+            } else if (ns == RG_STATE_STOP) {
+                d.n_events[slot] = t + 1;
+                if (d.policy != RG_POLICY_EXTERNAL) {
+                    // final step_offline(done=True): one more act, reward 0 (abstract.py:223-233,311-316)
+                    double ps;
+                    const uint32_t a = policy_act(d, slot, user, t + 1, &ps);
+                    rg_event e;
+                    e.u = user; e.t = t + 1; e.code = RG_EV_BANDIT | RG_EV_PHANTOM | a;
+                    e.ps = static_cast<float>(ps);
+                    d.phantom[slot] = e;
+                    d.has_phantom[slot] = 1;
+                    phantoms += 1;
+                }
+            }
+        }
+        // ordered compaction of the survivors into next step's lists: ballot + mbcnt inside the
+        // wave, one returning atomic per list per block iteration
+        const unsigned long long m_o = __ballot(ns == RG_STATE_ORGANIC);
+        const unsigned long long m_b = __ballot(ns == RG_STATE_BANDIT);
+        if (lane == 0) { s_wave_o[wave] = __popcll(m_o); s_wave_b[wave] = __popcll(m_b); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t to = s_wave_o[0] + s_wave_o[1] + s_wave_o[2] + s_wave_o[3];
+            const uint32_t tb = s_wave_b[0] + s_wave_b[1] + s_wave_b[2] + s_wave_b[3];
+            s_base_o = to ? atomicAdd(&next_cnt[RG_STATE_ORGANIC], to) : 0u;
+            s_base_b = tb ? atomicAdd(&next_cnt[RG_STATE_BANDIT], tb) : 0u;
+        }
+        __syncthreads();
+        uint32_t off_o = s_base_o, off_b = s_base_b;
+        for (int w2 = 0; w2 < wave; ++w2) { off_o += s_wave_o[w2]; off_b += s_wave_b[w2]; }
+        if (ns == RG_STATE_ORGANIC) next_o[off_o + prefix_in_mask(m_o)] = slot;
+        if (ns == RG_STATE_BANDIT) next_b[off_b + prefix_in_mask(m_b)] = slot;
+        __syncthreads();
+    }
+    // counters: one atomic per wave per kernel
+    for (int o = 32; o > 0; o >>= 1) { clicks += __shfl_xor(clicks, o); phantoms += __shfl_xor(phantoms, o); }
+    if (lane == 0) {
+        if (clicks) atomicAdd(&d.counters[RG_CNT_CLICKS], static_cast<unsigned long long>(clicks));
+        if (phantoms) atomicAdd(&d.counters[RG_CNT_PHANTOM], static_cast<unsigned long long>(phantoms));
+    }
+}
+
+// totals that are sums over the per-step counts
+__global__ void k_totals(DevSim d, uint32_t t_now) {
+    __shared__ unsigned long long so[kBlock], sb[kBlock];
+    unsigned long long o = 0, b = 0;
+    for (uint32_t t = threadIdx.x; t < t_now; t += kBlock) { o += d.step_cnt[2 * t]; b += d.step_cnt[2 * t + 1]; }
+    so[threadIdx.x] = o; sb[threadIdx.x] = b;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { so[threadIdx.x] += so[threadIdx.x + s]; sb[threadIdx.x] += sb[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        d.counters[RG_CNT_ORGANIC] = so[0];
+        d.counters[RG_CNT_BANDIT] = sb[0];
+        d.counters[RG_CNT_LIVE] = static_cast<unsigned long long>(d.step_cnt[2 * t_now]) + d.step_cnt[2 * t_now + 1];
+        d.counters[RG_CNT_STEP] = t_now;
+        const unsigned long long rows = d.log_base[t_now];
+        d.counters[RG_CNT_LOG_ROWS] = d.log ? (rows < d.log_cap ? rows : d.log_cap) : 0ull;
+        d.counters[RG_CNT_LOG_DROPPED] = d.log ? (rows > d.log_cap ? rows - d.log_cap : 0ull) : 0ull;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_export_state(DevSim d, uint32_t t, int8_t* state) {
+    const uint32_t n_o = d.step_cnt[2 * t], n_b = d.step_cnt[2 * t + 1];
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_o + n_b; i += gridDim.x * kBlock) {
+        if (i < n_o) state[list_ptr(d, t & 1, 0)[i]] = RG_STATE_ORGANIC;
+        else state[list_ptr(d, t & 1, 1)[i - n_o]] = RG_STATE_BANDIT;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_export_omega(DevSim d, double* out) {
+    const size_t n = static_cast<size_t>(d.n_users) * d.K;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const size_t u = i / d.K, k = i % d.K;
+        out[i] = d.omega[k * d.n_pad + u];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// log reordering: rows of user u occupy [off[u], off[u] + n_events[u] + has_phantom[u])
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_rows_per_user(DevSim d, int64_t* rows) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock)
+        rows[i] = static_cast<int64_t>(d.n_events[i]) + d.has_phantom[i];
+}
+
+// exclusive scan, three phases (block sums -> scan of sums by one block -> add)
+__global__ void __launch_bounds__(kBlock) k_scan_block(const int64_t* in, int64_t* out, int64_t* block_sums, uint32_t n) {
+    __shared__ int64_t s[kBlock];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const int64_t x = i < n ? in[i] : 0;
+    s[threadIdx.x] = x;
+    __syncthreads();
+    for (int o = 1; o < kBlock; o <<= 1) {
+        const int64_t y = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+        __syncthreads();
+        s[threadIdx.x] += y;
+        __syncthreads();
+    }
+    if (i < n) out[i] = s[threadIdx.x] - x;
+    if (threadIdx.x == kBlock - 1) block_sums[blockIdx.x] = s[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(kBlock) k_scan_sums(int64_t* block_sums, uint32_t nb, int64_t* total) {
+    __shared__ int64_t s[kBlock];
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += kBlock) {
+        const uint32_t i = base + threadIdx.x;
+        const int64_t x = i < nb ? block_sums[i] : 0;
+        s[threadIdx.x] = x;
+        __syncthreads();
+        for (int o = 1; o < kBlock; o <<= 1) {
+            const int64_t y = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+            __syncthreads();
+            s[threadIdx.x] += y;
+            __syncthreads();
+        }
+        if (i < nb) block_sums[i] = carry + s[threadIdx.x] - x;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += s[kBlock - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void __launch_bounds__(kBlock) k_scan_add(int64_t* out, const int64_t* block_sums, uint32_t n) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] += block_sums[blockIdx.x];
+}
+
+__global__ void __launch_bounds__(kBlock) k_scatter_rows(DevSim d, uint64_t n_rows, const int64_t* off,
+                                                       rg_event* out, uint64_t out_cap) {
+    for (uint64_t r = blockIdx.x * static_cast<uint64_t>(kBlock) + threadIdx.x; r < n_rows;
+         r += static_cast<uint64_t>(gridDim.x) * kBlock) {
+        const rg_event e = d.log[r];
+        const uint64_t dst = static_cast<uint64_t>(off[e.u - d.first_user]) + e.t;
+        if (dst < out_cap) out[dst] = e;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_scatter_phantom(DevSim d, const int64_t* off, rg_event* out,
+                                                          uint64_t out_cap) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) {
+        if (!d.has_phantom[i]) continue;
+        const uint64_t dst = static_cast<uint64_t>(off[i]) + d.n_events[i];
+        if (dst < out_cap) out[dst] = d.phantom[i];
+    }
+}
+
+inline int grid_for(uint64_t n, int per_block = kBlock) {
+    uint64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > kMaxGrid) g = kMaxGrid;
+    return static_cast<int>(g);
+}
+
+int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
+    if (sim->t >= kMaxSteps) return fail(RG_ELIMIT, "more than %u steps", kMaxSteps);
+    const DevSim& d = sim->d;
+    const uint32_t t = sim->t;
+    const uint32_t upper = sim->live_upper;
+    // 1. organic product draws of this step (read omega before the transition drifts it)
+    {
+        const int grid = grid_for(upper, kBlock / 64);
+        const size_t smem = sizeof(double) * (d.K + (d.P + 63) / 64 + 1) * (kBlock / 64);
+        hipLaunchKernelGGL(k_draw_exact, dim3(grid), dim3(kBlock), smem, st, d, t, 0);
+    }
+    // 2. click draws, transitions, drift, next lists, bandit + phantom rows
+    hipLaunchKernelGGL(k_advance, dim3(grid_for(upper)), dim3(kBlock), 0, st, d, t, d_actions);
+    HIP_TRY(hipGetLastError());
+    sim->t = t + 1;
+    return RG_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+const char* rg_last_error(void) { return g_err; }
+int rg_abi_version(void) { return RG_ABI_VERSION; }
+
+int rg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+size_t rg_sim_workspace_bytes(const rg_config* cfg, uint64_t n_users) {
+    if (validate(cfg, n_users) != RG_OK) return 0;
+    return carve_all(*cfg, n_users, nullptr, nullptr);
+}
+
+int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_workspace,
+                  size_t workspace_bytes) {
+    if (!out) return fail(RG_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (int rc = validate(cfg, n_users)) return rc;
+    if (!d_workspace) return fail(RG_EINVAL, "workspace is NULL");
+    const size_t need = carve_all(*cfg, n_users, nullptr, nullptr);
+    if (workspace_bytes < need)
+        return fail(RG_ENOMEM, "workspace has %zu bytes, %zu needed", workspace_bytes, need);
+    if ((reinterpret_cast<uintptr_t>(d_workspace) & 255u) != 0)
+        return fail(RG_EINVAL, "workspace must be 256-byte aligned");
+    rg_sim* s = new (std::nothrow) rg_sim();
+    if (!s) return fail(RG_ENOMEM, "host allocation failed");
+    s->cfg = *cfg;
+    s->workspace = d_workspace;
+    s->workspace_bytes = workspace_bytes;
+    DevSim& d = s->d;
+    memset(&d, 0, sizeof(d));
+    carve_all(*cfg, n_users, d_workspace, &d);
+    d.P = cfg->num_products; d.K = cfg->K;
+    d.seed = cfg->seed; d.policy_seed = cfg->policy_seed;
+    d.cdf_o0 = cfg->trans_cdf[0][0]; d.cdf_o1 = cfg->trans_cdf[0][1];
+    d.cdf_b0 = cfg->trans_cdf[1][0]; d.cdf_b1 = cfg->trans_cdf[1][1];
+    d.sigma0 = cfg->sigma_omega_initial; d.sigma_omega = cfg->sigma_omega;
+    d.change_omega_for_bandits = cfg->change_omega_for_bandits;
+    d.policy = cfg->policy;
+    d.ouc_select_randomly = cfg->ouc_select_randomly;
+    d.ouc_exploit_explore = cfg->ouc_exploit_explore;
+    d.ouc_reverse_pop = cfg->ouc_reverse_pop;
+    d.ouc_epsilon = cfg->ouc_epsilon;
+    d.n_users = d.n_cap = static_cast<uint32_t>(n_users);
+    s->h_pinned = nullptr;
+    *out = s;
+    return RG_OK;
+}
+
+int rg_sim_destroy(rg_sim* sim) {
+    if (!sim) return RG_OK;
+    if (sim->h_pinned) (void)hipHostFree(sim->h_pinned);
+    delete sim;
+    return RG_OK;
+}
+
+int rg_sim_set_tables(rg_sim* sim, const double* d_gamma, const double* d_mu_organic,
+                      const double* d_beta, const double* d_mu_bandit, void* stream) {
+    if (!sim) return fail(RG_EINVAL, "sim is NULL");
+    if (!d_gamma || !d_mu_organic || !d_beta || !d_mu_bandit) return fail(RG_EINVAL, "table pointer is NULL");
+    if (rg_device_count() <= 0) return fail(RG_ENODEV, "no HIP device");
+    sim->d.gamma = d_gamma; sim->d.mu_o = d_mu_organic; sim->d.beta = d_beta; sim->d.mu_b = d_mu_bandit;
+    const size_t n = (static_cast<size_t>(sim->d.P) + 63) / 64 * 64 * sim->d.K;
+    hipLaunchKernelGGL(k_make_fp32_tables, dim3(grid_for(n)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), sim->d);
+    HIP_TRY(hipGetLastError());
+    sim->tables_set = true;
+    return RG_OK;
+}
+
+int rg_sim_set_log(rg_sim* sim, rg_event* d_log, uint64_t capacity) {
+    if (!sim) return fail(RG_EINVAL, "sim is NULL");
+    sim->d.log = capacity ? d_log : nullptr;
+    sim->d.log_cap = d_log ? capacity : 0;
+    return RG_OK;
+}
+
+int rg_sim_reseed(rg_sim* sim, uint64_t seed, uint64_t policy_seed) {
+    if (!sim) return fail(RG_EINVAL, "sim is NULL");
+    sim->cfg.seed = sim->d.seed = seed;
+    sim->cfg.policy_seed = sim->d.policy_seed = policy_seed;
+    return RG_OK;
+}
+
+int rg_sim_reset_users(rg_sim* sim, uint64_t first_user_id, uint64_t n, uint64_t organic_only_below,
+                       void* stream) {
+    if (!sim) return fail(RG_EINVAL, "sim is NULL");
+    if (!sim->tables_set) return fail(RG_ESTATE, "rg_sim_set_tables must be called first");
+    if (n == 0 || n > sim->d.n_cap) return fail(RG_EINVAL, "n %llu exceeds the %u users the workspace was sized for",
+                                                 (unsigned long long)n, sim->d.n_cap);
+    if (first_user_id + n > (1ull << 32)) return fail(RG_EINVAL, "user ids must fit 32 bits");
+    if (rg_device_count() <= 0) return fail(RG_ENODEV, "no HIP device");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DevSim& d = sim->d;
+    d.first_user = first_user_id;
+    d.organic_only_below = organic_only_below;
+    d.n_users = static_cast<uint32_t>(n);      // lists stay strided by the carve-time n_cap
+    HIP_TRY(hipMemsetAsync(d.step_cnt, 0, sizeof(uint32_t) * 2 * (kMaxSteps + 2), st));
+    HIP_TRY(hipMemsetAsync(d.exact_cnt, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
+    HIP_TRY(hipMemsetAsync(d.counters, 0, sizeof(unsigned long long) * RG_CNT_N, st));
+    hipLaunchKernelGGL(k_reset_users, dim3(grid_for(n)), dim3(kBlock), 0, st, d);
+    HIP_TRY(hipGetLastError());
+    sim->t = 0;
+    sim->live_upper = static_cast<uint32_t>(n);
+    sim->users_reset = true;
+    return RG_OK;
+}
+
+int rg_sim_step(rg_sim* sim, const int32_t* d_actions, void* stream) {
+    if (!sim) return fail(RG_EINVAL, "sim is NULL");
+    if (!sim->users_reset) return fail(RG_ESTATE, "rg_sim_reset_users must be called first");
+    if (sim->d.policy == RG_POLICY_EXTERNAL && !d_actions) return fail(RG_EINVAL, "external policy needs d_actions");
+    return launch_step(sim, d_actions, static_cast<hipStream_t>(stream));
+}
+
+int rg_sim_run(rg_sim* sim, uint32_t max_steps, void* stream) {
+    if (!sim) return fail(RG_EINVAL, "sim is NULL");
+    if (!sim->users_reset) return fail(RG_ESTATE, "rg_sim_reset_users must be called first");
+    if (sim->d.policy == RG_POLICY_EXTERNAL) return fail(RG_ESTATE, "rg_sim_run needs a device policy");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!sim->h_pinned) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sim->h_pinned), 4 * sizeof(uint32_t)));
+    uint32_t done_steps = 0;
+    const uint32_t chunk = 16;
+    while (done_steps < max_steps) {
+        const uint32_t todo = (max_steps - done_steps) < chunk ? (max_steps - done_steps) : chunk;
+        for (uint32_t i = 0; i < todo; ++i)
+            if (int rc = launch_step(sim, nullptr, st)) return rc;
+        done_steps += todo;
+        HIP_TRY(hipMemcpyAsync(sim->h_pinned, sim->d.step_cnt + 2 * sim->t, 2 * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const uint64_t live = static_cast<uint64_t>(sim->h_pinned[0]) + sim->h_pinned[1];
+        sim->live_upper = static_cast<uint32_t>(live);
+        if (live == 0) break;
+    }
+    return RG_OK;
+}
+
+int rg_sim_read_counters(rg_sim* sim, int64_t* out, void* stream) {
+    if (!sim || !out) return fail(RG_EINVAL, "NULL argument");
+    if (rg_device_count() <= 0) return fail(RG_ENODEV, "no HIP device");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(kBlock), 0, st, sim->d, sim->t);
+    HIP_TRY(hipGetLastError());
+    unsigned long long h[RG_CNT_N];
+    HIP_TRY(hipMemcpyAsync(h, sim->d.counters, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < RG_CNT_N; ++i) out[i] = static_cast<int64_t>(h[i]);
+    sim->live_upper = static_cast<uint32_t>(h[RG_CNT_LIVE]);
+    return RG_OK;
+}
+
+int rg_sim_export_state(rg_sim* sim, int8_t* d_state, void* stream) {
+    if (!sim || !d_state) return fail(RG_EINVAL, "NULL argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(d_state, RG_STATE_STOP, sim->d.n_users, st));
+    hipLaunchKernelGGL(k_export_state, dim3(grid_for(sim->live_upper)), dim3(kBlock), 0, st, sim->d, sim->t, d_state);
+    HIP_TRY(hipGetLastError());
+    return RG_OK;
+}
+
+int rg_sim_export_omega(rg_sim* sim, double* d_omega, void* stream) {
+    if (!sim || !d_omega) return fail(RG_EINVAL, "NULL argument");
+    hipLaunchKernelGGL(k_export_omega, dim3(grid_for(static_cast<uint64_t>(sim->d.n_users) * sim->d.K)),
+                       dim3(kBlock), 0, static_cast<hipStream_t>(stream), sim->d, d_omega);
+    HIP_TRY(hipGetLastError());
+    return RG_OK;
+}
+
+int rg_sim_sort_log(rg_sim* sim, int64_t* d_row_offsets, int64_t* d_scratch, rg_event* d_sorted,
+                    uint64_t sorted_capacity, void* stream) {
+    if (!sim || !d_row_offsets || !d_scratch || !d_sorted) return fail(RG_EINVAL, "NULL argument");
+    if (!sim->d.log) return fail(RG_ESTATE, "no log buffer is attached");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const DevSim& d = sim->d;
+    const uint32_t n = d.n_users;
+    const uint32_t nb = (n + kBlock - 1) / kBlock;
+    // d_row_offsets: n + 1 entries (last = total rows); d_scratch: n + nb entries
+    int64_t* rows = d_scratch;
+    int64_t* block_sums = d_scratch + n;
+    hipLaunchKernelGGL(k_rows_per_user, dim3(grid_for(n)), dim3(kBlock), 0, st, d, rows);
+    hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(kBlock), 0, st, rows, d_row_offsets, block_sums, n);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, st, block_sums, nb, d_row_offsets + n);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(kBlock), 0, st, d_row_offsets, block_sums, n);
+    // rows written so far = log_base[t]; read it on the device side via the scatter bound
+    uint64_t n_rows = 0;
+    HIP_TRY(hipMemcpyAsync(&n_rows, d.log_base + sim->t, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (n_rows > d.log_cap) return fail(RG_ELIMIT, "log overflow: %llu rows emitted, capacity %llu",
+                                        (unsigned long long)n_rows, (unsigned long long)d.log_cap);
+    hipLaunchKernelGGL(k_scatter_rows, dim3(grid_for(n_rows)), dim3(kBlock), 0, st, d, n_rows, d_row_offsets,
+                       d_sorted, sorted_capacity);
+    hipLaunchKernelGGL(k_scatter_phantom, dim3(grid_for(n)), dim3(kBlock), 0, st, d, d_row_offsets, d_sorted,
+                       sorted_capacity);
+    HIP_TRY(hipGetLastError());
+    return RG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,203 @@
+"""Simulator — thin Python owner of one `rg_sim` handle (include/recogym_hip.h).
+
+PyTorch-ROCm is plumbing here: it owns the device buffers (tables, workspace, log) and the
+stream; every bit of simulation work happens in librecogym_hip.so's HIP kernels.  There is no
+CPU fallback — constructing a Simulator without a HIP device raises.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _abi
+from .envs.static_params import draw_tables, make_rg_config
+
+# decoded log rows (host side), same field names as the oracle's rows
+ROW_DTYPE = np.dtype([('u', np.uint32), ('t', np.uint32), ('z', np.int32), ('v', np.int32),
+                      ('a', np.int32), ('c', np.int32), ('phantom', np.int32),
+                      ('ps', np.float64)])
+
+
+def require_device(device=None):
+    lib = _abi.load()
+    if not torch.cuda.is_available() or lib.rg_device_count() <= 0:
+        raise _abi.RecoGymHipError(
+            'recogym_amd needs a HIP device (MI355X / gfx950); there is no CPU fallback')
+    return torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+
+
+def default_log_capacity(config, n_users):
+    """Rows a run emits: each user lives ~Geometric(prob_leave) events plus its phantom row."""
+    p_stop = max(float(config.prob_leave_organic), 1e-6)
+    mean = 1.0 / p_stop + 1.0
+    return int(n_users * (mean + 1.0) + 8.0 * mean * math.sqrt(n_users) + 4096)
+
+
+def decode_rows(raw, uniform_ps=None):
+    """(n,4) int32 array of rg_event records -> structured host rows."""
+    raw = np.ascontiguousarray(raw).view(np.uint32).reshape(-1, 4)
+    n = raw.shape[0]
+    out = np.zeros(n, dtype=ROW_DTYPE)
+    code = raw[:, 2]
+    is_b = (code & _abi.RG_EV_BANDIT) != 0
+    idx = (code & _abi.RG_EV_INDEX_MASK).astype(np.int32)
+    out['u'] = raw[:, 0]
+    out['t'] = raw[:, 1]
+    out['z'] = is_b
+    out['v'] = np.where(is_b, -1, idx)
+    out['a'] = np.where(is_b, idx, -1)
+    out['c'] = np.where(is_b, (code & _abi.RG_EV_CLICK) != 0, -1)
+    out['phantom'] = (code & _abi.RG_EV_PHANTOM) != 0
+    ps = raw[:, 3].copy().view(np.float32).astype(np.float64)
+    if uniform_ps is not None:
+        ps = np.where(is_b, uniform_ps, np.nan)     # exact 1/P of the uniform policies
+    out['ps'] = np.where(is_b, ps, np.nan)
+    return out
+
+
+class Simulator:
+    """N concurrent users of one reco-gym-v1 environment on one GPU.
+
+    config       env Configuration (env_1_args keys)
+    n_users      capacity (users per reset range)
+    policy       _abi.RG_POLICY_*; policy_seed / ouc = the agent's parameters
+    epoch        added to config.random_seed (reset_random_seed(epoch), abstract.py:59-62)
+    log_capacity rows of device log to allocate; 0 = counters only; None = estimate
+    """
+
+    def __init__(self, config, n_users, policy=_abi.RG_POLICY_UNIFORM_ENV, policy_seed=None,
+                 ouc=None, epoch=0, log_capacity=None, device=None, tables=None):
+        self.lib = _abi.load()
+        self.device = require_device(device)
+        self.config = config
+        self.n_users = int(n_users)
+        self.rg_config = make_rg_config(config, config.random_seed + epoch, policy, policy_seed,
+                                        ouc)
+        self.policy = policy
+        host_tables = tables if tables is not None else draw_tables(config)
+        self.host_tables = host_tables
+        with torch.cuda.device(self.device):
+            self.tables = [torch.from_numpy(np.ascontiguousarray(t)).to(self.device)
+                           for t in host_tables]
+            need = self.lib.rg_sim_workspace_bytes(C.byref(self.rg_config), self.n_users)
+            if need == 0:
+                raise _abi.RecoGymHipError('rg_sim_workspace_bytes: ' +
+                                           self.lib.rg_last_error().decode())
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._h = C.c_void_p()
+            _abi.check(self.lib.rg_sim_create(C.byref(self._h), C.byref(self.rg_config),
+                                              self.n_users, self.workspace.data_ptr(), need),
+                       'rg_sim_create')
+            _abi.check(self.lib.rg_sim_set_tables(self._h, *[t.data_ptr() for t in self.tables],
+                                                  self._stream()), 'rg_sim_set_tables')
+            if log_capacity is None:
+                log_capacity = default_log_capacity(config, self.n_users)
+            self.log = None
+            self.set_log_capacity(log_capacity)
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_log_capacity(self, rows):
+        self.log_capacity = int(rows)
+        with torch.cuda.device(self.device):
+            self.log = (torch.empty((self.log_capacity, 4), dtype=torch.int32, device=self.device)
+                        if rows else None)
+        _abi.check(self.lib.rg_sim_set_log(self._h, self.log.data_ptr() if rows else None,
+                                           self.log_capacity), 'rg_sim_set_log')
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self.lib.rg_sim_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the step loop ----------------------------------------------------------------------
+    def reseed(self, seed, policy_seed=None):
+        ps = self.rg_config.policy_seed if policy_seed is None else policy_seed
+        self.rg_config.seed = seed
+        self.rg_config.policy_seed = ps
+        _abi.check(self.lib.rg_sim_reseed(self._h, seed, ps), 'rg_sim_reseed')
+
+    def reset_users(self, first_user_id=0, n=None, organic_only_below=0):
+        n = self.n_users if n is None else int(n)
+        self.first_user_id = int(first_user_id)
+        self.n_active = n
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.rg_sim_reset_users(self._h, self.first_user_id, n,
+                                                   int(organic_only_below), self._stream()),
+                       'rg_sim_reset_users')
+
+    def step(self, actions=None):
+        """One Markov transition for every live user; `actions` (int32 tensor, one per user of
+        the reset range) only with the external policy."""
+        ptr = None
+        if actions is not None:
+            assert actions.dtype == torch.int32 and actions.is_cuda
+            ptr = actions.data_ptr()
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.rg_sim_step(self._h, ptr, self._stream()), 'rg_sim_step')
+
+    def run(self, max_steps=1 << 16):
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.rg_sim_run(self._h, max_steps, self._stream()), 'rg_sim_run')
+
+    def counters(self):
+        out = (C.c_int64 * _abi.RG_CNT_N)()
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.rg_sim_read_counters(self._h, out, self._stream()),
+                       'rg_sim_read_counters')
+        names = ['organic', 'bandit', 'clicks', 'phantom', 'live', 'step', 'log_rows',
+                 'log_dropped', 'exact_draws', 'hist_overflow']
+        return {k: int(out[i]) for i, k in enumerate(names)}
+
+    def states(self):
+        with torch.cuda.device(self.device):
+            st = torch.empty(self.n_users, dtype=torch.int8, device=self.device)
+            _abi.check(self.lib.rg_sim_export_state(self._h, st.data_ptr(), self._stream()),
+                       'rg_sim_export_state')
+        return st[:self.n_active]
+
+    def omega(self):
+        with torch.cuda.device(self.device):
+            om = torch.empty((self.n_active, self.config.K), dtype=torch.float64,
+                             device=self.device)
+            _abi.check(self.lib.rg_sim_export_omega(self._h, om.data_ptr(), self._stream()),
+                       'rg_sim_export_omega')
+        return om
+
+    # -- logs -------------------------------------------------------------------------------
+    def sorted_log(self):
+        """Device log in the reference's row order -> (rows,4) int32 tensor + int64 offsets."""
+        if self.log is None:
+            raise _abi.RecoGymHipError('this Simulator keeps counters only (log_capacity=0)')
+        n = self.n_active
+        with torch.cuda.device(self.device):
+            offsets = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+            scratch = torch.empty(n + (n + 255) // 256 + 1, dtype=torch.int64, device=self.device)
+            cnt = self.counters()
+            total = cnt['organic'] + cnt['bandit'] + cnt['phantom']
+            if cnt['log_dropped']:
+                raise _abi.RecoGymHipError(
+                    f'log overflow: capacity {self.log_capacity}, '
+                    f'{cnt["log_rows"] + cnt["log_dropped"]} rows emitted')
+            out = torch.empty((total, 4), dtype=torch.int32, device=self.device)
+            _abi.check(self.lib.rg_sim_sort_log(self._h, offsets.data_ptr(), scratch.data_ptr(),
+                                                out.data_ptr(), total, self._stream()),
+                       'rg_sim_sort_log')
+        return out, offsets
+
+    def rows(self):
+        """Decoded host rows in the reference's order."""
+        out, _ = self.sorted_log()
+        uniform = None
+        if self.policy in (_abi.RG_POLICY_UNIFORM_ENV, _abi.RG_POLICY_RANDOM_AGENT):
+            uniform = 1.0 / float(self.config.num_products)
+        return decode_rows(out.cpu().numpy(), uniform)
