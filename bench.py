@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py — env steps/s (= log rows emitted/s) of the reco-gym-v1 step loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1: run directly)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic input: U concurrent users are
+reset and simulated to completion (every Markov transition, organic product draw, click draw,
+policy action and log row of `env.generate_logs(U, agent)`), inputs resident in HBM.  The
+workload is BASELINE.json's headline configuration (configs[2], the one `metric` is quoted on):
+reco-gym-v1, P=10 000 products, K=20, sigma_omega=0, OrganicUserEventCounterAgent in the loop,
+10 M users per GPU.  Users shard across ranks by id range with no data-path collective; one
+RCCL all-reduce of the click/impression counters closes each step, so per-GPU
+work is fixed as N grows ("weak").
+
+Prints ONE JSON line (rank 0).  `value` counts real rows (organic + bandit; the per-user
+phantom row is excluded) over all ranks / max-over-ranks wall time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (env overrides, users per GPU, policy)
+    'c3': (dict(num_products=10000, K=20, sigma_omega=0.0), 10_000_000, 'ouc'),
+    'c2': (dict(num_products=1000, K=20, sigma_omega=0.0), 1_000_000, 'random'),
+    'c4shard': (dict(num_products=100000, K=64, sigma_omega=0.1), 1_250_000, 'none'),
+    'tiny': (dict(num_products=100, K=20, sigma_omega=0.0), 20_000, 'ouc'),
+}
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBPS = 8000.0
+
+
+def make_sim(workload, users, device, log_rows):
+    from recogym_amd import _abi
+    from recogym_amd.envs.configuration import Configuration
+    from recogym_amd.envs.reco_env_v1 import env_1_args
+    from recogym_amd.sim import Simulator
+    over, _, pol = WORKLOADS[workload]
+    cfg = Configuration({**env_1_args, 'random_seed': 42, **over})
+    kw = {}
+    if pol == 'ouc':
+        kw = dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=42,
+                  ouc=dict(select_randomly=True, epsilon=0.0, exploit_explore=True,
+                           reverse_pop=False))
+    elif pol == 'random':
+        kw = dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=42)
+    return cfg, Simulator(cfg, users, device=device, log_capacity=log_rows, **kw), kw
+
+
+def cpu_baseline(workload, seconds_target=12.0):
+    """The oracle (plain-C float64 port of the reference loop, one core) on a bounded sample of
+    the same workload.  Test infrastructure used as the reported CPU baseline only."""
+    from oracle import oracle as orc
+    from recogym_amd import _abi
+    from recogym_amd.envs.configuration import Configuration
+    from recogym_amd.envs.reco_env_v1 import env_1_args
+    over, _, pol = WORKLOADS[workload]
+    cfg = Configuration({**env_1_args, 'random_seed': 42, **over})
+    kw = {}
+    if pol == 'ouc':
+        kw = dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=42,
+                  ouc=dict(select_randomly=True, epsilon=0.0, exploit_explore=True,
+                           reverse_pop=False))
+    elif pol == 'random':
+        kw = dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=42)
+    env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **kw)
+    users, events, elapsed = 0, 0, 0.0
+    batch = 50
+    while elapsed < seconds_target and users < 20000:
+        t0 = time.perf_counter()
+        rows = env.generate_logs(batch, first_user_id=users, capacity=batch * 2000 + 10000)
+        elapsed += time.perf_counter() - t0
+        events += int((rows['phantom'] == 0).sum())
+        users += batch
+        if elapsed < 1.0:
+            batch = min(batch * 2, 2000)
+    return dict(value=events / elapsed, unit='events/s', cores=1, kind='port',
+                sample=f'{users} users / {events} events of the same workload in {elapsed:.1f} s '
+                       f'(oracle/recogym_oracle.c, float64, 1 thread)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
+    ap.add_argument('--users', type=int, default=0, help='users per GPU (default: workload size)')
+    ap.add_argument('--no-log', action='store_true', help='counters only (no 16 B/row log writes)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
+    assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    device = torch.device(f'cuda:{local_rank}')
+    torch.cuda.set_device(device)
+
+    import __graft_entry__ as graft
+    if rank == 0:
+        graft.build()
+    if dist:
+        dist.barrier()
+
+    from recogym_amd.sim import default_log_capacity
+    users = args.users or WORKLOADS[args.workload][1]
+    over = WORKLOADS[args.workload][0]
+    cfg_probe, _, _ = WORKLOADS[args.workload]
+    from recogym_amd.envs.configuration import Configuration
+    from recogym_amd.envs.reco_env_v1 import env_1_args
+    log_rows = 0 if args.no_log else default_log_capacity(
+        Configuration({**env_1_args, **over}), users)
+    cfg, sim, _ = make_sim(args.workload, users, device, log_rows)
+    first_user = rank * users           # disjoint id ranges: identical to one big run
+
+    def one_step():
+        sim.reset_users(first_user, users)
+        sim.run()
+        c = sim.counters()
+        vec = torch.tensor([c['organic'], c['bandit'], c['clicks'], c['phantom']],
+                           dtype=torch.int64, device=device)
+        if dist:
+            dist.all_reduce(vec)        # the CTR reduction of test_agent / verify_agents
+        return c, vec
+
+    for _ in range(args.warmup):
+        one_step()
+
+    def sync():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    sync()
+    t0 = time.perf_counter()
+    totals = torch.zeros(4, dtype=torch.int64, device=device)
+    last = None
+    for _ in range(args.steps):
+        last, vec = one_step()
+        totals += vec
+    sync()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if dist:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    totals = totals.cpu().numpy()
+    events = int(totals[0] + totals[1])
+    assert last['hist_overflow'] == 0 and last['log_dropped'] == 0 and last['live'] == 0, last
+
+    # --- roofline of the dominant kernel (k_draw_mfma), HIP events on the launch stream ---
+    roofline = None
+    if rank == 0:
+        sim.set_profiling(True)
+        sim.reset_users(first_user, users)
+        sim.run()
+        prof = sim.profile()
+        c = sim.counters()
+        sim.set_profiling(False)
+        P, K = cfg.num_products, cfg.K
+        flops = 2.0 * P * K * c['organic']             # algorithmic: SURVEY.md §8(d)
+        launches = max(prof['steps'], 1)
+        avg_ms = prof['draw_mfma_ms'] / launches
+        achieved = flops / (prof['draw_mfma_ms'] * 1e-3) / 1e12 if prof['draw_mfma_ms'] else 0.0
+        roofline = dict(bound='mfma', kernel='k_draw_mfma', achieved=round(achieved, 3),
+                        peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        launches=launches, avg_launch_ms=round(avg_ms, 4),
+                        kernel_ms=dict(draw_mfma=round(prof['draw_mfma_ms'], 2),
+                                       draw_exact_f64=round(prof['draw_exact_ms'], 2),
+                                       advance=round(prof['advance_ms'], 2)),
+                        exact_fraction=round(c['exact_draws'] / max(c['organic'], 1), 5),
+                        hbm_algorithmic_GBps=round(
+                            (events / args.steps) * (8 * K + 8 + 16 + 3 + 35) / 1e9 /
+                            (elapsed / args.steps), 1))
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload)
+
+    if rank == 0:
+        out = {
+            'metric': 'env steps/sec (organic+bandit events emitted/sec), reco-gym-v1 P=10k K=20',
+            'value': events / elapsed,
+            'unit': 'events/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f64 state/click/transition math, f32 MFMA logits certified against f64',
+            'data': 'synthetic',
+            'config': {'workload': f'{args.workload}: reco-gym-v1 P={cfg.num_products} K={cfg.K} '
+                                   f'sigma_omega={cfg.sigma_omega} policy={WORKLOADS[args.workload][2]}',
+                       'users_per_gpu': users, 'users_total': users * world,
+                       'events_per_step': events // args.steps,
+                       'log': 'off' if args.no_log else '16 B/row device log',
+                       'ctr': float(totals[2]) / max(float(totals[1] + totals[3]), 1.0)},
+            'roofline': roofline,
+            'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -165,6 +165,13 @@ int rg_sim_run(rg_sim* sim, uint32_t max_steps, void* stream);
 /* Synchronises `stream` and copies RG_CNT_N counters to the host. */
 int rg_sim_read_counters(rg_sim* sim, int64_t* out, void* stream);
 
+/* Measurement aid for bench.py's roofline line: with profiling on, every step records HIP
+ * events on the stream the kernels are launched on.  rg_sim_get_profile returns
+ * out[0..2] = total milliseconds spent in the organic draw (fp32 MFMA kernel), in the float64
+ * resolve kernel and in the advance kernel, out[3] = profiled steps.  Off by default. */
+int rg_sim_set_profiling(rg_sim* sim, int on);
+int rg_sim_get_profile(rg_sim* sim, double* out);
+
 /* Current Markov state per user of the reset range (int8, RG_STATE_*), for the gym.Env
  * compatibility path.  d_state has n entries. */
 int rg_sim_export_state(rg_sim* sim, int8_t* d_state, void* stream);

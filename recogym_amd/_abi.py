@@ -71,6 +71,8 @@ SYMBOLS = {
     'rg_sim_step': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_run': (C.c_int, [_SIM, C.c_uint32, C.c_void_p]),
     'rg_sim_read_counters': (C.c_int, [_SIM, C.POINTER(C.c_int64), C.c_void_p]),
+    'rg_sim_set_profiling': (C.c_int, [_SIM, C.c_int]),
+    'rg_sim_get_profile': (C.c_int, [_SIM, C.POINTER(C.c_double)]),
     'rg_sim_export_state': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_export_omega': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_sort_log': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,

@@ -27,8 +27,10 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/recogym_hip.h"
 #include "../../include/recogym_rng.h"
@@ -76,7 +78,20 @@ struct DevSim {
     uint64_t organic_only_below;
     // tables (caller-owned float64) and fp32 copies (workspace)
     const double* gamma; const double* mu_o; const double* beta; const double* mu_b;
-    float* gamma32; float* mu32;
+    float* gamma32; float* mu32;   // [P_pad][KS] (k >= K zero, rows >= P zero) / [P_pad] (-inf pad)
+    double* gammaT;           // [K][PT] float64 transpose of Gamma, PT = P rounded up to 64 (coalesced f64 draw)
+    uint32_t PT;
+    float* exact_ref;         // [n_users] log2-scaled reference of a draw handed to the float64 kernel
+    float* stats;             // [2*KH] max_p |Gamma[p][k]|, then max_p ||Gamma[p]||_2, max_p |mu_o[p]|
+    // geometry of the MFMA draw kernel
+    uint32_t KH;              // MFMA k-steps per chunk (each 32x32x2 step consumes 2 k); 0 = no MFMA path
+    uint32_t KS;              // row stride of gamma32 / the LDS tile, floats (== 2 mod 4: conflict-free b64)
+    uint32_t TP;              // products per LDS tile (multiple of 32)
+    uint32_t P_pad;           // rows of gamma32 / mu32
+    uint32_t n_chunks;        // ceil(P / 32)
+    uint32_t sc_chunks;       // chunks per stored partial sum ("super-chunk")
+    uint32_t n_sc;            // super-chunks (<= kMaxSC)
+    uint32_t use_mfma;
     // state (workspace)
     double* omega;            // [K][n_pad], K-major: lane-per-user accesses coalesce
     uint32_t* list;           // [2 parity][2 state][n_users]
@@ -106,6 +121,12 @@ struct rg_sim {
     uint32_t live_upper;      // upper bound of live users (for grid sizing)
     bool tables_set, users_reset;
     uint32_t* h_pinned;       // 4 x u32 staging for the live-count readback
+    size_t mfma_smem;
+    bool profiling;
+    std::vector<hipEvent_t> prof_events;   // 4 per profiled step: before draw, after mfma, after exact, after advance
+    size_t prof_used;
+    double prof_ms[3];
+    uint64_t prof_launches;
 };
 
 namespace {
@@ -125,6 +146,31 @@ struct Carve {
     }
 };
 
+constexpr uint32_t kMaxSC = 32;           // stored partial sums per user in the MFMA draw kernel
+
+struct Geom { uint32_t KH, KS, TP, P_pad, n_chunks, sc_chunks, n_sc; };
+
+Geom geom_of(const rg_config& c) {
+    Geom g{};
+    const uint32_t need = (c.K + 1) / 2;
+    const uint32_t opts[] = {4, 10, 16, 32, 64};
+    for (uint32_t o : opts) if (!g.KH && need <= o) g.KH = o;
+    if (!g.KH) return g;                            // K > 128: float64 kernel only
+    g.KS = 2 * g.KH;
+    while (g.KS % 4 != 2) ++g.KS;
+    g.TP = 256;
+    while (g.TP > 32 && static_cast<size_t>(g.TP) * g.KS * 4 > 24 * 1024) g.TP /= 2;
+    g.P_pad = static_cast<uint32_t>(align_up(c.num_products, 256)) + 64;
+    g.n_chunks = (c.num_products + 31) / 32;
+    g.sc_chunks = (g.n_chunks + kMaxSC - 1) / kMaxSC;
+    g.n_sc = (g.n_chunks + g.sc_chunks - 1) / g.sc_chunks;
+    return g;
+}
+
+size_t mfma_smem_bytes(const Geom& g) {
+    return sizeof(float) * (static_cast<size_t>(g.TP) * g.KS + g.TP + 4 * 32 * 2 * g.KH + 2 * kMaxSC * 128);
+}
+
 uint32_t hist_cap_of(const rg_config& c) {
     if (c.policy != RG_POLICY_ORGANIC_USER_COUNT) return 0;
     return c.ouc_history_cap ? c.ouc_history_cap : kDefaultHistoryCap;
@@ -134,8 +180,14 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     Carve w(base);
     const size_t n_pad = align_up(n, 64);
     const size_t P = c.num_products, K = c.K;
-    float* gamma32 = w.take<float>(align_up(P, 64) * K);
-    float* mu32 = w.take<float>(align_up(P, 64));
+    const Geom g = geom_of(c);
+    (void)P; (void)K;
+    float* gamma32 = w.take<float>(static_cast<size_t>(g.P_pad) * (g.KS ? g.KS : 1));
+    float* mu32 = w.take<float>(g.P_pad ? g.P_pad : 1);
+    float* stats = w.take<float>(2 * g.KH + 2);
+    const size_t PT = align_up(P, 64);
+    double* gammaT = w.take<double>(K * PT);
+    float* exact_ref = w.take<float>(n);
     double* omega = w.take<double>(K * n_pad);
     uint32_t* list = w.take<uint32_t>(4 * n);
     uint32_t* step_cnt = w.take<uint32_t>(2 * (kMaxSteps + 2));
@@ -151,7 +203,10 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint32_t* hist_n = w.take<uint32_t>(n);
     unsigned long long* counters = w.take<unsigned long long>(RG_CNT_N);
     if (d) {
-        d->gamma32 = gamma32; d->mu32 = mu32; d->omega = omega; d->list = list;
+        d->gamma32 = gamma32; d->mu32 = mu32; d->stats = stats; d->omega = omega; d->list = list;
+        d->gammaT = gammaT; d->PT = static_cast<uint32_t>(PT); d->exact_ref = exact_ref;
+        d->KH = g.KH; d->KS = g.KS; d->TP = g.TP; d->P_pad = g.P_pad; d->n_chunks = g.n_chunks;
+        d->sc_chunks = g.sc_chunks; d->n_sc = g.n_sc; d->use_mfma = g.KH ? 1u : 0u;
         d->step_cnt = step_cnt; d->log_base = log_base; d->exact_list = exact_list;
         d->exact_cnt = exact_cnt; d->n_events = n_events; d->phantom = phantom;
         d->has_phantom = has_phantom; d->hist = hist; d->hist_cntv = hist_cntv;
@@ -217,36 +272,73 @@ __device__ __forceinline__ uint32_t* list_ptr(const DevSim& d, uint32_t parity, 
 // k_reset_users
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) k_reset_users(DevSim d) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         d.step_cnt[0] = d.n_users;   // everyone starts organic (abstract.py:93)
         d.step_cnt[1] = 0;
         d.log_base[0] = 0;
     }
-    if (i >= d.n_users) return;
-    const uint32_t user = static_cast<uint32_t>(d.first_user + i);
-    for (uint32_t j = 0; 2 * j < d.K; ++j) {
-        double z0, z1;
-        normal_pair(d.seed, user, 0u, j, RG_DRAW_RESET, &z0, &z1);
-        d.omega[static_cast<size_t>(2 * j) * d.n_pad + i] = 0.0 + d.sigma0 * z0;
-        if (2 * j + 1 < d.K) d.omega[static_cast<size_t>(2 * j + 1) * d.n_pad + i] = 0.0 + d.sigma0 * z1;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) {
+        const uint32_t user = static_cast<uint32_t>(d.first_user + i);
+        for (uint32_t j = 0; 2 * j < d.K; ++j) {
+            double z0, z1;
+            normal_pair(d.seed, user, 0u, j, RG_DRAW_RESET, &z0, &z1);
+            d.omega[static_cast<size_t>(2 * j) * d.n_pad + i] = 0.0 + d.sigma0 * z0;
+            if (2 * j + 1 < d.K) d.omega[static_cast<size_t>(2 * j + 1) * d.n_pad + i] = 0.0 + d.sigma0 * z1;
+        }
+        list_ptr(d, 0, RG_STATE_ORGANIC)[i] = i;
+        d.n_events[i] = 0;
+        d.has_phantom[i] = 0;
+        if (d.hist_cap) d.hist_n[i] = 0;
     }
-    list_ptr(d, 0, RG_STATE_ORGANIC)[i] = i;
-    d.n_events[i] = 0;
-    d.has_phantom[i] = 0;
-    if (d.hist_cap) d.hist_n[i] = 0;
 }
 
-// fp32 copies of Gamma / mu_organic for the MFMA path (rows padded to a multiple of 64 products)
+// fp32 copies of Gamma / mu_organic for the MFMA path: gamma32 [P_pad][KS] (columns >= K and rows
+// >= P are zero), mu32 [P_pad] (-inf beyond P, so padded products get probability exactly 0).
 __global__ void __launch_bounds__(kBlock) k_make_fp32_tables(DevSim d) {
-    const size_t P64 = (static_cast<size_t>(d.P) + 63) / 64 * 64;
-    const size_t n = P64 * d.K;
+    const size_t n = static_cast<size_t>(d.P_pad) * d.KS;
     for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
          i += static_cast<size_t>(gridDim.x) * kBlock) {
-        const size_t p = i / d.K;
-        d.gamma32[i] = p < d.P ? static_cast<float>(d.gamma[i]) : 0.0f;
-        if (i < P64) d.mu32[i] = i < d.P ? static_cast<float>(d.mu_o[i]) : -INFINITY;
+        const size_t p = i / d.KS, k = i % d.KS;
+        d.gamma32[i] = (p < d.P && k < d.K) ? static_cast<float>(d.gamma[p * d.K + k]) : 0.0f;
+        if (i < d.P_pad) d.mu32[i] = i < d.P ? static_cast<float>(d.mu_o[i]) : -INFINITY;
     }
+}
+
+// float64 transpose of Gamma for the float64 draw kernel: lane-per-product reads coalesce
+__global__ void __launch_bounds__(kBlock) k_make_gammaT(DevSim d) {
+    const size_t n = static_cast<size_t>(d.K) * d.PT;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const size_t k = i / d.PT, p = i % d.PT;
+        d.gammaT[i] = p < d.P ? d.gamma[p * d.K + k] : 0.0;
+    }
+}
+
+// Table statistics for the logit error bound of the MFMA path (one block per statistic):
+//   block k < 2KH : max_p |Gamma[p][k]|      block 2KH : max_p ||Gamma[p]||_2
+//   block 2KH+1   : max_p |mu_o[p]|
+__global__ void __launch_bounds__(kBlock) k_table_stats(DevSim d) {
+    __shared__ double red[kBlock];
+    const uint32_t which = blockIdx.x;
+    double m = 0.0;
+    for (uint32_t p = threadIdx.x; p < d.P; p += kBlock) {
+        double x;
+        if (which < 2 * d.KH) x = which < d.K ? fabs(d.gamma[static_cast<size_t>(p) * d.K + which]) : 0.0;
+        else if (which == 2 * d.KH) {
+            double q = 0.0;
+            for (uint32_t k = 0; k < d.K; ++k) { const double g = d.gamma[static_cast<size_t>(p) * d.K + k]; q += g * g; }
+            x = sqrt(q);
+        } else x = fabs(d.mu_o[p]);
+        m = fmax(m, x);
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s2 = kBlock / 2; s2 > 0; s2 >>= 1) {
+        if (threadIdx.x < s2) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s2]);
+        __syncthreads();
+    }
+    // round up: the bound must dominate the float64 value
+    if (threadIdx.x == 0) d.stats[which] = static_cast<float>(red[0] * (1.0 + 1e-6));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -417,9 +509,11 @@ __device__ __forceinline__ double wave_scan(double x, int lane) {
 }
 
 __device__ __forceinline__ double logit64(const DevSim& d, const double* om, uint32_t p) {
-    const double* g = d.gamma + static_cast<size_t>(p) * d.K;
+    // same association as the oracle / numpy: (sum_k Gamma[p][k] omega[k]) + mu[p], k ascending
+    const double* g = d.gammaT + p;
     double l = 0.0;
-    for (uint32_t k = 0; k < d.K; ++k) l += g[k] * om[k];
+#pragma unroll 4
+    for (uint32_t k = 0; k < d.K; ++k) l += g[static_cast<size_t>(k) * d.PT] * om[k];
     return l + d.mu_o[p];
 }
 
@@ -439,10 +533,15 @@ __global__ void __launch_bounds__(kBlock) k_draw_exact(DevSim d, uint32_t t, int
         const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
         for (uint32_t k = lane; k < d.K; k += 64) om[k] = d.omega[static_cast<size_t>(k) * d.n_pad + slot];
         __builtin_amdgcn_wave_barrier();
-        // pass 1: max logit (reco_env_v1.py:121)
-        double m = -INFINITY;
-        for (uint32_t p = lane; p < d.P; p += 64) m = fmax(m, logit64(d, om, p));
-        const double M = wave_max(m);
+        // pass 1: max logit (reco_env_v1.py:121).  Any shift gives the same float64 decision up
+        // to 1e-16, so a draw handed over by the MFMA kernel reuses that kernel's reference.
+        double M;
+        if (from_list) M = static_cast<double>(d.exact_ref[w]) * 0.69314718055994530942;
+        else {
+            double m = -INFINITY;
+            for (uint32_t p = lane; p < d.P; p += 64) m = fmax(m, logit64(d, om, p));
+            M = wave_max(m);
+        }
         // pass 2: running sum of exp(l - max) in product order, remembered per 64-product chunk.
         // The reference normalises p = e / sum(e) before its cumsum and divides by cdf[-1];
         // dividing every term by the same positive constants moves the decision only at the
@@ -483,6 +582,231 @@ __global__ void __launch_bounds__(kBlock) k_draw_exact(DevSim d, uint32_t t, int
     if (from_list == 1 && blockIdx.x == 0 && threadIdx.x == 0)
         atomicAdd(&d.counters[RG_CNT_EXACT_DRAWS], static_cast<unsigned long long>(n));
 }
+
+// ------------------------------------------------------------------------------------------
+// k_draw_mfma — the organic product draw on the fp32 matrix cores, with a certified margin.
+//
+// One wave = 32 organic users (MFMA columns) x all P products in chunks of 32 (MFMA rows):
+//     D[product i][user j] = mu[i] + sum_k Gamma32[i][k] * omega32[j][k]      (v_mfma_f32_32x32x2_f32)
+// "products as rows" puts the 32 logits of one user into two lanes (16 registers each), so
+// max / exp / sum over products is register-local; the two lanes of a user combine once per
+// super-chunk.  Gamma32 tiles ([TP][KS] floats, KS == 2 mod 4 -> conflict-free ds_read_b64)
+// and the mu tile are staged in LDS and shared by the block's 4 waves (128 users).
+//
+// Sampling v = first index with cumsum(p)/cumsum(p)[-1] > u needs the total before the prefix
+// search.  Pass 1 (MFMA) keeps, per user, the sum of exp(l - ref) of each of <= 32 super-chunks
+// (in LDS).  The search then picks the super-chunk from those sums in float64 and recomputes
+// only that super-chunk (1/32 of P) on the vector ALU in product order to find the index.
+//
+// The result is only ACCEPTED if it is provably the float64 answer: with delta bounding the
+// relative error of every fp32 prefix sum, v is certified iff
+//     C~[v-1] (1+delta) < u S~ (1-delta)   and   u S~ (1+delta) < C~[v] (1-delta).
+// Users that fail the test are appended to exact_list and resolved by k_draw_exact (float64).
+// ------------------------------------------------------------------------------------------
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kRescaleGap = 57.0f;        // re-reference when a logit exceeds the reference by > ~40 nats
+constexpr double kDeltaFixed = 3.0e-5;      // exp / summation / constant-rounding budget
+constexpr double kDeltaPerRescale = 6.0e-6;
+
+__device__ __forceinline__ float wave_scan_f32(float x, int lane) {
+    for (int o = 1; o < 64; o <<= 1) {
+        const float y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    return x;
+}
+
+__device__ __forceinline__ double readlane_f64(double x, int l) { return __shfl(x, l); }
+
+template <int KH>
+__global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_draw_mfma(DevSim d, uint32_t t) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* g_tile = reinterpret_cast<float*>(smem_raw);            // [TP][KS]
+    float* mu_tile = g_tile + static_cast<size_t>(d.TP) * d.KS;     // [TP]
+    float* om_tile = mu_tile + d.TP;                                // [4 waves][32 users][2KH]
+    float* scW = om_tile + 4 * 32 * 2 * KH;                         // [kMaxSC][128]
+    float* scQ = scW + kMaxSC * 128;                                // [kMaxSC][128]
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int j = lane & 31, h = lane >> 5;
+    const int col = wave * 32 + j;
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const uint32_t n_tiles = (n_o + 127) / 128;
+    const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const float mumax = d.stats[2 * KH + 1], g2max = d.stats[2 * KH];
+
+    for (uint32_t tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {
+        const uint32_t pos = tb * 128 + wave * 32 + j;
+        const bool active = pos < n_o;
+        const uint32_t slot = active ? cur[pos] : 0u;
+        // ---- B operand (omega32), its LDS copy for the search phase, and the logit bound ----
+        float b[KH];
+        float absdot = 0.0f, sq = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KH; ++s) {
+            const uint32_t k = h * KH + s;
+            float w = 0.0f;
+            if (active && k < d.K) w = static_cast<float>(d.omega[static_cast<size_t>(k) * d.n_pad + slot]);
+            b[s] = w;
+            om_tile[col * 2 * KH + k] = w;
+            absdot = fmaf(fabsf(w), d.stats[k], absdot);
+            sq = fmaf(w, w, sq);
+        }
+        absdot += __shfl_xor(absdot, 32);
+        sq += __shfl_xor(sq, 32);
+        const float Ahat = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
+
+        // ---- pass 1: MFMA logits, exp-sums per super-chunk ----
+        float q = 0.0f;            // reference, in log2 units (q = ref * log2 e)
+        double s_sc = 0.0;
+        uint32_t n_resc = 0;
+        for (uint32_t tile0 = 0; tile0 < d.n_chunks * 32; tile0 += d.TP) {
+            __syncthreads();
+            {   // cooperative tile load: TP*KS floats of gamma32 + TP floats of mu32 (16-byte vectors)
+                const float4* src = reinterpret_cast<const float4*>(d.gamma32 + static_cast<size_t>(tile0) * d.KS);
+                float4* dst = reinterpret_cast<float4*>(g_tile);
+                const uint32_t n4 = d.TP * d.KS / 4;
+                for (uint32_t i = threadIdx.x; i < n4; i += kBlock) dst[i] = src[i];
+                if (threadIdx.x < d.TP / 4)
+                    reinterpret_cast<float4*>(mu_tile)[threadIdx.x] =
+                        reinterpret_cast<const float4*>(d.mu32 + tile0)[threadIdx.x];
+            }
+            __syncthreads();
+            const uint32_t c_end = min(d.TP / 32, d.n_chunks - tile0 / 32);
+            for (uint32_t c = 0; c < c_end; ++c) {
+                const uint32_t ci = tile0 / 32 + c;
+                f32x16 acc;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float4 m4 = *reinterpret_cast<const float4*>(mu_tile + c * 32 + 8 * qq + 4 * h);
+                    acc[4 * qq + 0] = m4.x; acc[4 * qq + 1] = m4.y; acc[4 * qq + 2] = m4.z; acc[4 * qq + 3] = m4.w;
+                }
+                const float* arow = g_tile + (c * 32 + j) * d.KS + h * KH;
+#pragma unroll
+                for (int s = 0; s < KH; s += 2) {
+                    const float2 a2 = *reinterpret_cast<const float2*>(arow + s);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b[s + 1], acc, 0, 0, 0);
+                }
+                float cm = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) cm = fmaxf(cm, acc[r]);
+                const float cq = cm * kLog2e;
+                if (ci == 0) q = fmaxf(cq, -1.0e30f);
+                else if (cq > q + kRescaleGap) {
+                    s_sc *= static_cast<double>(__builtin_amdgcn_exp2f(q - cq));
+                    q = cq;
+                    n_resc += 1;
+                }
+                float e[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], kLog2e, -q));
+#pragma unroll
+                for (int w2 = 8; w2 > 0; w2 >>= 1)
+#pragma unroll
+                    for (int r = 0; r < w2; ++r) e[r] += e[r + w2];
+                s_sc += static_cast<double>(e[0]);
+                if ((ci + 1) % d.sc_chunks == 0 || ci + 1 == d.n_chunks) {
+                    // flush: bring both lanes of the user to a common reference, add, store
+                    const float q2 = fmaxf(q, __shfl_xor(q, 32));
+                    const float wv = static_cast<float>(s_sc) * __builtin_amdgcn_exp2f(q - q2);
+                    const float W = wv + __shfl_xor(wv, 32);
+                    const uint32_t sc = ci / d.sc_chunks;
+                    if (h == 0) { scW[sc * 128 + col] = W; scQ[sc * 128 + col] = q2; }
+                    s_sc = 0.0;
+                }
+            }
+        }
+        n_resc = max(n_resc, static_cast<uint32_t>(__shfl_xor(static_cast<int>(n_resc), 32)));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- search, part 1 (lane per user): total, target, super-chunk ----
+        const float Q = scQ[(d.n_sc - 1) * 128 + col];        // references only grow: the last is the max
+        double S = 0.0;
+        for (uint32_t sc = 0; sc < d.n_sc; ++sc)
+            S += static_cast<double>(scW[sc * 128 + col] * __builtin_amdgcn_exp2f(scQ[sc * 128 + col] - Q));
+        const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
+        const rg_u32x4 rw = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
+        const double tau = rg_uniform(rw.w[0], rw.w[1]) * S;
+        double pb = 0.0;
+        uint32_t sc_star = d.n_sc - 1;
+        {
+            double run = 0.0;
+            bool found = false;
+            for (uint32_t sc = 0; sc < d.n_sc; ++sc) {
+                const double Wd = static_cast<double>(scW[sc * 128 + col] * __builtin_amdgcn_exp2f(scQ[sc * 128 + col] - Q));
+                if (!found && run + Wd > tau) { found = true; sc_star = sc; pb = run; }
+                if (!found) run += Wd;
+            }
+            if (!found) pb = run - static_cast<double>(scW[(d.n_sc - 1) * 128 + col] *
+                                                      __builtin_amdgcn_exp2f(scQ[(d.n_sc - 1) * 128 + col] - Q));
+        }
+        const double delta = static_cast<double>(d.K + 3) * 5.9604644775390625e-08 * static_cast<double>(Ahat) +
+                             kDeltaFixed + kDeltaPerRescale * n_resc;
+        const unsigned long long act_mask = __ballot(active && h == 0);
+
+        // ---- search, part 2 (whole wave per user): recompute the chosen super-chunk on the VALU ----
+        uint32_t my_v = 0;
+        bool my_ok = false;
+        for (int jj = 0; jj < 32; ++jj) {
+            if (!((act_mask >> jj) & 1ull)) continue;
+            const uint32_t scj = __shfl(static_cast<int>(sc_star), jj);
+            const double pbj = readlane_f64(pb, jj);
+            const double tauj = readlane_f64(tau, jj);
+            const double deltaj = readlane_f64(delta, jj);
+            const float Qj = __shfl(Q, jj);
+            const float* om = om_tile + (wave * 32 + jj) * 2 * KH;
+            const uint32_t base = scj * d.sc_chunks * 32;
+            const uint32_t endp = min(base + d.sc_chunks * 32, d.n_chunks * 32);
+            double run = pbj, A = 0.0, B = 0.0;
+            uint32_t v = 0;
+            bool found = false;
+            for (uint32_t g = base; g < endp; g += 64) {
+                const uint32_t p = g + lane;      // < P_pad by construction
+                const float* grow = d.gamma32 + static_cast<size_t>(p) * d.KS;
+                float l = d.mu32[p];
+#pragma unroll 8
+                for (int k = 0; k < 2 * KH; k += 2) {
+                    const float2 gg = *reinterpret_cast<const float2*>(grow + k);
+                    l = fmaf(gg.x, om[k], l);
+                    l = fmaf(gg.y, om[k + 1], l);
+                }
+                const float e = (p < endp) ? __builtin_amdgcn_exp2f(fmaf(l, kLog2e, -Qj)) : 0.0f;
+                const float x = wave_scan_f32(e, lane);
+                const double px = run + static_cast<double>(x);
+                const unsigned long long hit = __ballot(p < endp && px > tauj);
+                if (hit) {
+                    const int L = __builtin_ctzll(hit);
+                    B = readlane_f64(px, L);
+                    A = L ? readlane_f64(px, L - 1) : run;
+                    v = g + L;
+                    found = true;
+                    break;
+                }
+                run += static_cast<double>(__shfl(x, 63));
+            }
+            const bool ok = found && v < d.P &&
+                            (v == 0 || A * (1.0 + deltaj) < tauj * (1.0 - deltaj)) &&
+                            (v == d.P - 1 || tauj * (1.0 + deltaj) < B * (1.0 - deltaj));
+            if (lane == jj) { my_v = v; my_ok = ok; }
+        }
+        // ---- emit (lane per user again, so the history inserts of 32 users overlap) ----
+        if (active && h == 0) {
+            if (my_ok) {
+                write_organic_row(d, t, pos, user, my_v);
+                if (d.hist_cap) history_add(d, slot, my_v);
+            } else {
+                const uint32_t xi = atomicAdd(&d.exact_cnt[t], 1u);
+                d.exact_list[xi] = pos;
+                d.exact_ref[xi] = Q;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------
 // k_advance — one Markov transition for every live user (lane per user).
@@ -713,21 +1037,66 @@ inline int grid_for(uint64_t n, int per_block = kBlock) {
     return static_cast<int>(g);
 }
 
+int prof_mark(rg_sim* sim, hipStream_t st) {
+    if (!sim->profiling) return RG_OK;
+    if (sim->prof_used == sim->prof_events.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        sim->prof_events.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(sim->prof_events[sim->prof_used++], st));
+    return RG_OK;
+}
+
 int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     if (sim->t >= kMaxSteps) return fail(RG_ELIMIT, "more than %u steps", kMaxSteps);
     const DevSim& d = sim->d;
     const uint32_t t = sim->t;
     const uint32_t upper = sim->live_upper;
+    if (int rc = prof_mark(sim, st)) return rc;
     // 1. organic product draws of this step (read omega before the transition drifts it)
-    {
+    const size_t smem_exact = sizeof(double) * (d.K + (d.P + 63) / 64 + 1) * (kBlock / 64);
+    if (d.use_mfma) {
+        const int grid = grid_for(upper, 128);
+        const size_t smem = sim->mfma_smem;
+        switch (d.KH) {
+            case 4: hipLaunchKernelGGL(k_draw_mfma<4>, dim3(grid), dim3(kBlock), smem, st, d, t); break;
+            case 10: hipLaunchKernelGGL(k_draw_mfma<10>, dim3(grid), dim3(kBlock), smem, st, d, t); break;
+            case 16: hipLaunchKernelGGL(k_draw_mfma<16>, dim3(grid), dim3(kBlock), smem, st, d, t); break;
+            case 32: hipLaunchKernelGGL(k_draw_mfma<32>, dim3(grid), dim3(kBlock), smem, st, d, t); break;
+            default: hipLaunchKernelGGL(k_draw_mfma<64>, dim3(grid), dim3(kBlock), smem, st, d, t); break;
+        }
+        if (int rc = prof_mark(sim, st)) return rc;
+        // draws the fp32 path could not certify -> float64 (a few percent of the organic users)
+        const int grid_x = grid_for(upper / 8 + 64, kBlock / 64);
+        hipLaunchKernelGGL(k_draw_exact, dim3(grid_x), dim3(kBlock), smem_exact, st, d, t, 1);
+    } else {
+        if (int rc = prof_mark(sim, st)) return rc;
         const int grid = grid_for(upper, kBlock / 64);
-        const size_t smem = sizeof(double) * (d.K + (d.P + 63) / 64 + 1) * (kBlock / 64);
-        hipLaunchKernelGGL(k_draw_exact, dim3(grid), dim3(kBlock), smem, st, d, t, 0);
+        hipLaunchKernelGGL(k_draw_exact, dim3(grid), dim3(kBlock), smem_exact, st, d, t, 0);
     }
+    if (int rc = prof_mark(sim, st)) return rc;
     // 2. click draws, transitions, drift, next lists, bandit + phantom rows
     hipLaunchKernelGGL(k_advance, dim3(grid_for(upper)), dim3(kBlock), 0, st, d, t, d_actions);
     HIP_TRY(hipGetLastError());
+    if (int rc = prof_mark(sim, st)) return rc;
     sim->t = t + 1;
+    return RG_OK;
+}
+
+// fold the recorded events into per-kernel totals (synchronises on the last event)
+int prof_collect(rg_sim* sim) {
+    if (!sim->prof_used) return RG_OK;
+    HIP_TRY(hipEventSynchronize(sim->prof_events[sim->prof_used - 1]));
+    for (size_t i = 0; i + 3 < sim->prof_used; i += 4) {
+        for (int k = 0; k < 3; ++k) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, sim->prof_events[i + k], sim->prof_events[i + k + 1]));
+            sim->prof_ms[k] += ms;
+        }
+        sim->prof_launches += 1;
+    }
+    sim->prof_used = 0;
     return RG_OK;
 }
 
@@ -784,6 +1153,19 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     d.ouc_epsilon = cfg->ouc_epsilon;
     d.n_users = d.n_cap = static_cast<uint32_t>(n_users);
     s->h_pinned = nullptr;
+    s->profiling = false; s->prof_used = 0; s->prof_launches = 0;
+    s->prof_ms[0] = s->prof_ms[1] = s->prof_ms[2] = 0.0;
+    s->mfma_smem = d.use_mfma ? mfma_smem_bytes(geom_of(*cfg)) : 0;
+    if (const char* e = getenv("RECOGYM_FORCE_EXACT")) if (e[0] == '1') d.use_mfma = 0;   // A/B switch for tests
+    if (s->mfma_smem > 64 * 1024) {
+        // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel instantiation
+        const int bytes = static_cast<int>(s->mfma_smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_draw_mfma<4>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_draw_mfma<10>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_draw_mfma<16>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_draw_mfma<32>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_draw_mfma<64>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    }
     *out = s;
     return RG_OK;
 }
@@ -791,6 +1173,7 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
 int rg_sim_destroy(rg_sim* sim) {
     if (!sim) return RG_OK;
     if (sim->h_pinned) (void)hipHostFree(sim->h_pinned);
+    for (hipEvent_t e : sim->prof_events) (void)hipEventDestroy(e);
     delete sim;
     return RG_OK;
 }
@@ -801,9 +1184,15 @@ int rg_sim_set_tables(rg_sim* sim, const double* d_gamma, const double* d_mu_org
     if (!d_gamma || !d_mu_organic || !d_beta || !d_mu_bandit) return fail(RG_EINVAL, "table pointer is NULL");
     if (rg_device_count() <= 0) return fail(RG_ENODEV, "no HIP device");
     sim->d.gamma = d_gamma; sim->d.mu_o = d_mu_organic; sim->d.beta = d_beta; sim->d.mu_b = d_mu_bandit;
-    const size_t n = (static_cast<size_t>(sim->d.P) + 63) / 64 * 64 * sim->d.K;
-    hipLaunchKernelGGL(k_make_fp32_tables, dim3(grid_for(n)), dim3(kBlock), 0,
+    hipLaunchKernelGGL(k_make_gammaT, dim3(grid_for(static_cast<size_t>(sim->d.K) * sim->d.PT)), dim3(kBlock), 0,
                        static_cast<hipStream_t>(stream), sim->d);
+    if (sim->d.use_mfma) {
+        const size_t n = static_cast<size_t>(sim->d.P_pad) * sim->d.KS;
+        hipLaunchKernelGGL(k_make_fp32_tables, dim3(grid_for(n)), dim3(kBlock), 0,
+                           static_cast<hipStream_t>(stream), sim->d);
+        hipLaunchKernelGGL(k_table_stats, dim3(2 * sim->d.KH + 2), dim3(kBlock), 0,
+                           static_cast<hipStream_t>(stream), sim->d);
+    }
     HIP_TRY(hipGetLastError());
     sim->tables_set = true;
     return RG_OK;
@@ -870,6 +1259,7 @@ int rg_sim_run(rg_sim* sim, uint32_t max_steps, void* stream) {
         HIP_TRY(hipMemcpyAsync(sim->h_pinned, sim->d.step_cnt + 2 * sim->t, 2 * sizeof(uint32_t),
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (int rc = prof_collect(sim)) return rc;
         const uint64_t live = static_cast<uint64_t>(sim->h_pinned[0]) + sim->h_pinned[1];
         sim->live_upper = static_cast<uint32_t>(live);
         if (live == 0) break;
@@ -888,6 +1278,22 @@ int rg_sim_read_counters(rg_sim* sim, int64_t* out, void* stream) {
     HIP_TRY(hipStreamSynchronize(st));
     for (int i = 0; i < RG_CNT_N; ++i) out[i] = static_cast<int64_t>(h[i]);
     sim->live_upper = static_cast<uint32_t>(h[RG_CNT_LIVE]);
+    return RG_OK;
+}
+
+int rg_sim_set_profiling(rg_sim* sim, int on) {
+    if (!sim) return fail(RG_EINVAL, "sim is NULL");
+    sim->profiling = on != 0;
+    sim->prof_used = 0; sim->prof_launches = 0;
+    sim->prof_ms[0] = sim->prof_ms[1] = sim->prof_ms[2] = 0.0;
+    return RG_OK;
+}
+
+int rg_sim_get_profile(rg_sim* sim, double* out) {
+    if (!sim || !out) return fail(RG_EINVAL, "NULL argument");
+    if (int rc = prof_collect(sim)) return rc;
+    out[0] = sim->prof_ms[0]; out[1] = sim->prof_ms[1]; out[2] = sim->prof_ms[2];
+    out[3] = static_cast<double>(sim->prof_launches);
     return RG_OK;
 }
 

@@ -158,6 +158,15 @@ class Simulator:
                  'log_dropped', 'exact_draws', 'hist_overflow']
         return {k: int(out[i]) for i, k in enumerate(names)}
 
+    def set_profiling(self, on=True):
+        _abi.check(self.lib.rg_sim_set_profiling(self._h, int(on)), 'rg_sim_set_profiling')
+
+    def profile(self):
+        """-> dict(draw_mfma_ms, draw_exact_ms, advance_ms, steps) measured with HIP events."""
+        out = (C.c_double * 4)()
+        _abi.check(self.lib.rg_sim_get_profile(self._h, out), 'rg_sim_get_profile')
+        return dict(draw_mfma_ms=out[0], draw_exact_ms=out[1], advance_ms=out[2], steps=int(out[3]))
+
     def states(self):
         with torch.cuda.device(self.device):
             st = torch.empty(self.n_users, dtype=torch.int8, device=self.device)
