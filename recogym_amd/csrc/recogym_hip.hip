@@ -82,6 +82,8 @@ struct DevSim {
     double* gammaT;           // [K][PT] float64 transpose of Gamma, PT = P rounded up to 64 (coalesced f64 draw)
     uint32_t PT;
     float* exact_ref;         // [n_users] log2-scaled reference of a draw handed to the float64 kernel
+    float2* sc_scratch;       // [kMaxGrid*4 waves][kMaxSC][32] {sum, reference} of the MFMA draw kernel
+    float* chunk_scratch;     // [kMaxGrid*4 waves][n_chunks][32] exp-sum of every 32-product chunk
     float* stats;             // [2*KH] max_p |Gamma[p][k]|, then max_p ||Gamma[p]||_2, max_p |mu_o[p]|
     // geometry of the MFMA draw kernel
     uint32_t KH;              // MFMA k-steps per chunk (each 32x32x2 step consumes 2 k); 0 = no MFMA path
@@ -92,6 +94,7 @@ struct DevSim {
     uint32_t sc_chunks;       // chunks per stored partial sum ("super-chunk")
     uint32_t n_sc;            // super-chunks (<= kMaxSC)
     uint32_t use_mfma;
+    uint32_t ablate;          // timing experiments only (RECOGYM_ABLATE); results are wrong when non-zero
     // state (workspace)
     double* omega;            // [K][n_pad], K-major: lane-per-user accesses coalesce
     uint32_t* list;           // [2 parity][2 state][n_users]
@@ -160,15 +163,17 @@ Geom geom_of(const rg_config& c) {
     while (g.KS % 4 != 2) ++g.KS;
     g.TP = 256;
     while (g.TP > 32 && static_cast<size_t>(g.TP) * g.KS * 4 > 24 * 1024) g.TP /= 2;
-    g.P_pad = static_cast<uint32_t>(align_up(c.num_products, 256)) + 64;
+    g.P_pad = static_cast<uint32_t>(align_up(c.num_products, 256)) + 128;
     g.n_chunks = (c.num_products + 31) / 32;
+    g.n_chunks = (g.n_chunks + 1) & ~1u;            // chunks are processed in pairs (two accumulators)
     g.sc_chunks = (g.n_chunks + kMaxSC - 1) / kMaxSC;
+    g.sc_chunks = (g.sc_chunks + 1) & ~1u;
     g.n_sc = (g.n_chunks + g.sc_chunks - 1) / g.sc_chunks;
     return g;
 }
 
 size_t mfma_smem_bytes(const Geom& g) {
-    return sizeof(float) * (static_cast<size_t>(g.TP) * g.KS + g.TP + 4 * 32 * 2 * g.KH + 2 * kMaxSC * 128);
+    return sizeof(float) * 2 * (static_cast<size_t>(g.TP) * g.KS + g.TP) + 256;   // double-buffered tiles
 }
 
 uint32_t hist_cap_of(const rg_config& c) {
@@ -188,6 +193,8 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     const size_t PT = align_up(P, 64);
     double* gammaT = w.take<double>(K * PT);
     float* exact_ref = w.take<float>(n);
+    float2* sc_scratch = w.take<float2>(g.KH ? static_cast<size_t>(kMaxGrid) * 4 * kMaxSC * 32 : 1);
+    float* chunk_scratch = w.take<float>(g.KH ? static_cast<size_t>(kMaxGrid) * 4 * g.n_chunks * 32 : 1);
     double* omega = w.take<double>(K * n_pad);
     uint32_t* list = w.take<uint32_t>(4 * n);
     uint32_t* step_cnt = w.take<uint32_t>(2 * (kMaxSteps + 2));
@@ -204,7 +211,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     unsigned long long* counters = w.take<unsigned long long>(RG_CNT_N);
     if (d) {
         d->gamma32 = gamma32; d->mu32 = mu32; d->stats = stats; d->omega = omega; d->list = list;
-        d->gammaT = gammaT; d->PT = static_cast<uint32_t>(PT); d->exact_ref = exact_ref;
+        d->gammaT = gammaT; d->PT = static_cast<uint32_t>(PT); d->exact_ref = exact_ref; d->sc_scratch = sc_scratch; d->chunk_scratch = chunk_scratch;
         d->KH = g.KH; d->KS = g.KS; d->TP = g.TP; d->P_pad = g.P_pad; d->n_chunks = g.n_chunks;
         d->sc_chunks = g.sc_chunks; d->n_sc = g.n_sc; d->use_mfma = g.KH ? 1u : 0u;
         d->step_cnt = step_cnt; d->log_base = log_base; d->exact_list = exact_list;
@@ -517,6 +524,23 @@ __device__ __forceinline__ double logit64(const DevSim& d, const double* om, uin
     return l + d.mu_o[p];
 }
 
+// four products per lane (p, p+64, p+128, p+192): four independent FMA chains keep 4x the loads
+// in flight — the float64 kernel is latency-bound otherwise.  Products >= P give -inf.
+__device__ __forceinline__ void logit64x4(const DevSim& d, const double* om, uint32_t p, double out[4]) {
+    uint32_t idx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { idx[u] = min(p + 64u * u, d.PT - 1); out[u] = 0.0; }
+#pragma unroll 2
+    for (uint32_t k = 0; k < d.K; ++k) {
+        const double w = om[k];
+        const double* g = d.gammaT + static_cast<size_t>(k) * d.PT;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) out[u] += g[idx[u]] * w;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) out[u] = (p + 64u * u < d.P) ? out[u] + d.mu_o[p + 64u * u] : -INFINITY;
+}
+
 __global__ void __launch_bounds__(kBlock) k_draw_exact(DevSim d, uint32_t t, int from_list) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -539,7 +563,11 @@ __global__ void __launch_bounds__(kBlock) k_draw_exact(DevSim d, uint32_t t, int
         if (from_list) M = static_cast<double>(d.exact_ref[w]) * 0.69314718055994530942;
         else {
             double m = -INFINITY;
-            for (uint32_t p = lane; p < d.P; p += 64) m = fmax(m, logit64(d, om, p));
+            for (uint32_t c = 0; c < n_chunks; c += 4) {
+                double l4[4];
+                logit64x4(d, om, c * 64 + lane, l4);
+                m = fmax(fmax(m, fmax(l4[0], l4[1])), fmax(l4[2], l4[3]));
+            }
             M = wave_max(m);
         }
         // pass 2: running sum of exp(l - max) in product order, remembered per 64-product chunk.
@@ -547,11 +575,17 @@ __global__ void __launch_bounds__(kBlock) k_draw_exact(DevSim d, uint32_t t, int
         // dividing every term by the same positive constants moves the decision only at the
         // 1e-16 level, so the running sum of e is compared with u * total directly.
         double run = 0.0;
-        for (uint32_t c = 0; c < n_chunks; ++c) {
-            const uint32_t p = c * 64 + lane;
-            const double e = p < d.P ? exp(logit64(d, om, p) - M) : 0.0;
-            if (lane == 0) chunk_prefix[c] = run;
-            run += __shfl(wave_scan(e, lane), 63);
+        for (uint32_t c = 0; c < n_chunks; c += 4) {
+            double l4[4];
+            logit64x4(d, om, c * 64 + lane, l4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (c + u < n_chunks) {
+                    const double e = exp(l4[u] - M);        // exp(-inf) == 0 for products >= P
+                    if (lane == 0) chunk_prefix[c + u] = run;
+                    run += __shfl(wave_scan(e, lane), 63);
+                }
+            }
         }
         if (lane == 0) chunk_prefix[n_chunks] = run;
         __builtin_amdgcn_wave_barrier();
@@ -567,8 +601,12 @@ __global__ void __launch_bounds__(kBlock) k_draw_exact(DevSim d, uint32_t t, int
         // recompute that chunk (same code, same values) and find the product inside it
         uint32_t v = d.P - 1;
         {
+            const uint32_t cg = cstar & ~3u;              // the group of four the chunk was computed in
+            double l4[4];
+            logit64x4(d, om, cg * 64 + lane, l4);
+            const double l = l4[cstar & 3u];
             const uint32_t p = cstar * 64 + lane;
-            const double e = p < d.P ? exp(logit64(d, om, p) - M) : 0.0;
+            const double e = exp(l - M);
             const double x = chunk_prefix[cstar] + wave_scan(e, lane);
             const unsigned long long hit = __ballot(p < d.P && x > target);
             if (hit) v = cstar * 64 + static_cast<uint32_t>(__builtin_ctzll(hit));
@@ -620,27 +658,45 @@ __device__ __forceinline__ float wave_scan_f32(float x, int lane) {
 
 __device__ __forceinline__ double readlane_f64(double x, int l) { return __shfl(x, l); }
 
+// async global -> LDS copy of `bytes` contiguous bytes (gfx950 global_load_lds_dwordx4: the LDS
+// destination is wave-uniform base + lane * 16), spread over the block's 4 waves
+__device__ __forceinline__ void glds_copy(const char* src, char* dst_lds, uint32_t bytes, int wave, int lane) {
+    for (uint32_t off = wave * 1024u; off < bytes; off += 4u * 1024u) {
+        if (off + lane * 16u < bytes)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + off + lane * 16u),
+                (__attribute__((address_space(3))) void*)(dst_lds + off), 16, 0, 0);
+    }
+}
+
+// exchange a value between lane l and lane l ^ 32 (the two lanes that share a user)
+__device__ __forceinline__ float swap32(float x) { return __shfl_xor(x, 32); }
+
 template <int KH>
 __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_draw_mfma(DevSim d, uint32_t t) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* g_tile = reinterpret_cast<float*>(smem_raw);            // [TP][KS]
-    float* mu_tile = g_tile + static_cast<size_t>(d.TP) * d.KS;     // [TP]
-    float* om_tile = mu_tile + d.TP;                                // [4 waves][32 users][2KH]
-    float* scW = om_tile + 4 * 32 * 2 * KH;                         // [kMaxSC][128]
-    float* scQ = scW + kMaxSC * 128;                                // [kMaxSC][128]
+    const uint32_t tile_f = d.TP * d.KS;                              // floats per Gamma tile
+    float* g_buf = reinterpret_cast<float*>(smem_raw);                // [2][TP][KS]
+    float* mu_buf = g_buf + 2 * tile_f;                               // [2][TP] (+ pad)
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int j = lane & 31, h = lane >> 5;
-    const int col = wave * 32 + j;
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
     const uint32_t n_tiles = (n_o + 127) / 128;
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
     const float mumax = d.stats[2 * KH + 1], g2max = d.stats[2 * KH];
+    const uint32_t n_ptiles = (d.n_chunks * 32 + d.TP - 1) / d.TP;
+    const uint32_t cpt = d.TP / 32;                                   // chunks per LDS tile
+    // per-wave scratch: exp-sum of every chunk [n_chunks][32 users] and {sum, reference} of
+    // every super-chunk [kMaxSC][32]
+    const size_t wslot = static_cast<size_t>(blockIdx.x) * 4 + wave;
+    float* scr_chunk = d.chunk_scratch + wslot * d.n_chunks * 32;
+    float2* scr = d.sc_scratch + wslot * kMaxSC * 32;
 
     for (uint32_t tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {
         const uint32_t pos = tb * 128 + wave * 32 + j;
         const bool active = pos < n_o;
         const uint32_t slot = active ? cur[pos] : 0u;
-        // ---- B operand (omega32), its LDS copy for the search phase, and the logit bound ----
+        // ---- B operand (omega32) and the logit error bound ----
         float b[KH];
         float absdot = 0.0f, sq = 0.0f;
 #pragma unroll
@@ -649,150 +705,214 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_draw_mfma(DevSim
             float w = 0.0f;
             if (active && k < d.K) w = static_cast<float>(d.omega[static_cast<size_t>(k) * d.n_pad + slot]);
             b[s] = w;
-            om_tile[col * 2 * KH + k] = w;
             absdot = fmaf(fabsf(w), d.stats[k], absdot);
             sq = fmaf(w, w, sq);
         }
-        absdot += __shfl_xor(absdot, 32);
-        sq += __shfl_xor(sq, 32);
+        absdot += swap32(absdot);
+        sq += swap32(sq);
         const float Ahat = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
 
-        // ---- pass 1: MFMA logits, exp-sums per super-chunk ----
-        float q = 0.0f;            // reference, in log2 units (q = ref * log2 e)
-        double s_sc = 0.0;
-        uint32_t n_resc = 0;
-        for (uint32_t tile0 = 0; tile0 < d.n_chunks * 32; tile0 += d.TP) {
-            __syncthreads();
-            {   // cooperative tile load: TP*KS floats of gamma32 + TP floats of mu32 (16-byte vectors)
-                const float4* src = reinterpret_cast<const float4*>(d.gamma32 + static_cast<size_t>(tile0) * d.KS);
-                float4* dst = reinterpret_cast<float4*>(g_tile);
-                const uint32_t n4 = d.TP * d.KS / 4;
-                for (uint32_t i = threadIdx.x; i < n4; i += kBlock) dst[i] = src[i];
-                if (threadIdx.x < d.TP / 4)
-                    reinterpret_cast<float4*>(mu_tile)[threadIdx.x] =
-                        reinterpret_cast<const float4*>(d.mu32 + tile0)[threadIdx.x];
+        // ---- pass 1: MFMA logits of chunk c overlap the exp-sum of chunk c-1 (software pipeline) ----
+        float q = -1.0e30f;        // per-USER reference in log2 units, constant within a super-chunk
+        float cqmax = -INFINITY;   // running max logit (log2 units) seen by this lane
+        double s_sc = 0.0;         // running exp-sum of the current super-chunk (both lanes of the user)
+        int n_resc = 0;
+        f32x16 acc_p0, acc_p1;     // logits of the previous chunk pair, waiting for their exp-sums
+        uint32_t ci_p = 0;         // index of its first chunk
+        bool have_p = false;
+
+        // exp-sum of one finished chunk: 16 logits per lane -> this user's chunk sum -> scratch
+        auto softmax_chunk = [&](const f32x16& lg, uint32_t ci) {
+            float cm = lg[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) cm = fmaxf(cm, lg[r]);
+            cqmax = fmaxf(cqmax, cm * kLog2e);
+            float e[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(lg[r], kLog2e, -q));
+#pragma unroll
+            for (int w2 = 8; w2 > 0; w2 >>= 1)
+#pragma unroll
+                for (int r = 0; r < w2; ++r) e[r] += e[r + w2];
+            const float wc = e[0] + swap32(e[0]);
+            if (h == 0) scr_chunk[ci * 32 + j] = wc;
+            s_sc += static_cast<double>(wc);
+        };
+        // end of a super-chunk: store {sum, reference}; re-reference if the max ran away
+        auto flush_sc = [&](uint32_t ci) {
+            if (h == 0) scr[(ci / d.sc_chunks) * 32 + j] = make_float2(static_cast<float>(s_sc), q);
+            s_sc = 0.0;
+            const float m2 = fmaxf(cqmax, swap32(cqmax));
+            if (m2 > q + kRescaleGap) { q = m2; n_resc += 1; }
+        };
+
+        __syncthreads();           // every wave is done with both LDS buffers (previous user tile)
+        glds_copy(reinterpret_cast<const char*>(d.gamma32), reinterpret_cast<char*>(g_buf), tile_f * 4, wave, lane);
+        if (wave == 3) glds_copy(reinterpret_cast<const char*>(d.mu32), reinterpret_cast<char*>(mu_buf), d.TP * 4, 0, lane);
+        for (uint32_t ti = 0; ti < n_ptiles; ++ti) {
+            __syncthreads();       // (hipcc drains vmcnt before the barrier) tile ti landed; tile ti-1 is free
+            if (ti + 1 < n_ptiles) {
+                const uint32_t nb = (ti + 1) & 1;
+                glds_copy(reinterpret_cast<const char*>(d.gamma32 + static_cast<size_t>(ti + 1) * tile_f),
+                          reinterpret_cast<char*>(g_buf + nb * tile_f), tile_f * 4, wave, lane);
+                if (wave == 3)
+                    glds_copy(reinterpret_cast<const char*>(d.mu32 + static_cast<size_t>(ti + 1) * d.TP),
+                              reinterpret_cast<char*>(mu_buf + nb * d.TP), d.TP * 4, 0, lane);
             }
-            __syncthreads();
-            const uint32_t c_end = min(d.TP / 32, d.n_chunks - tile0 / 32);
-            for (uint32_t c = 0; c < c_end; ++c) {
-                const uint32_t ci = tile0 / 32 + c;
-                f32x16 acc;
+            const float* g_tile = g_buf + (ti & 1) * tile_f;
+            const float* mu_tile = mu_buf + (ti & 1) * d.TP;
+            const uint32_t c_end = min(cpt, d.n_chunks - ti * cpt);     // even
+            for (uint32_t c = 0; c < c_end; c += 2) {
+                const uint32_t ci = ti * cpt + c;
+                // operands of chunks c, c+1: accumulators start at mu, A rows from the LDS tile
+                f32x16 acc0, acc1;
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
-                    const float4 m4 = *reinterpret_cast<const float4*>(mu_tile + c * 32 + 8 * qq + 4 * h);
-                    acc[4 * qq + 0] = m4.x; acc[4 * qq + 1] = m4.y; acc[4 * qq + 2] = m4.z; acc[4 * qq + 3] = m4.w;
+                    const float4 m0 = *reinterpret_cast<const float4*>(mu_tile + c * 32 + 8 * qq + 4 * h);
+                    const float4 m1 = *reinterpret_cast<const float4*>(mu_tile + c * 32 + 32 + 8 * qq + 4 * h);
+                    acc0[4 * qq + 0] = m0.x; acc0[4 * qq + 1] = m0.y; acc0[4 * qq + 2] = m0.z; acc0[4 * qq + 3] = m0.w;
+                    acc1[4 * qq + 0] = m1.x; acc1[4 * qq + 1] = m1.y; acc1[4 * qq + 2] = m1.z; acc1[4 * qq + 3] = m1.w;
                 }
-                const float* arow = g_tile + (c * 32 + j) * d.KS + h * KH;
+                const float* arow0 = g_tile + (c * 32 + j) * d.KS + h * KH;
+                const float* arow1 = arow0 + 32 * d.KS;
+                float2 a0[KH / 2], a1[KH / 2];
 #pragma unroll
-                for (int s = 0; s < KH; s += 2) {
-                    const float2 a2 = *reinterpret_cast<const float2*>(arow + s);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b[s], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b[s + 1], acc, 0, 0, 0);
+                for (int s = 0; s < KH / 2; ++s) {
+                    a0[s] = *reinterpret_cast<const float2*>(arow0 + 2 * s);
+                    a1[s] = *reinterpret_cast<const float2*>(arow1 + 2 * s);
                 }
-                float cm = acc[0];
+                // Two independent MFMA chains, interleaved: consecutive MFMAs never share an
+                // accumulator, so neither the exp-sum VALU work of the previous pair (same wave)
+                // nor another wave's instructions break a back-to-back dependent issue.
 #pragma unroll
-                for (int r = 1; r < 16; ++r) cm = fmaxf(cm, acc[r]);
-                const float cq = cm * kLog2e;
-                if (ci == 0) q = fmaxf(cq, -1.0e30f);
-                else if (cq > q + kRescaleGap) {
-                    s_sc *= static_cast<double>(__builtin_amdgcn_exp2f(q - cq));
-                    q = cq;
-                    n_resc += 1;
+                for (int s = 0; s < KH / 2; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s].x, b[2 * s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s].x, b[2 * s], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s].y, b[2 * s + 1], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s].y, b[2 * s + 1], acc1, 0, 0, 0);
                 }
-                float e[16];
+                if (have_p) {
+                    softmax_chunk(acc_p0, ci_p);
+                    softmax_chunk(acc_p1, ci_p + 1);
+                    if ((ci_p + 2) % d.sc_chunks == 0) flush_sc(ci_p);
+                } else {
+                    // very first chunk pair of the user tile: its own max sets the reference
+                    float cm = fmaxf(acc0[0], acc1[0]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(fmaf(acc[r], kLog2e, -q));
-#pragma unroll
-                for (int w2 = 8; w2 > 0; w2 >>= 1)
-#pragma unroll
-                    for (int r = 0; r < w2; ++r) e[r] += e[r + w2];
-                s_sc += static_cast<double>(e[0]);
-                if ((ci + 1) % d.sc_chunks == 0 || ci + 1 == d.n_chunks) {
-                    // flush: bring both lanes of the user to a common reference, add, store
-                    const float q2 = fmaxf(q, __shfl_xor(q, 32));
-                    const float wv = static_cast<float>(s_sc) * __builtin_amdgcn_exp2f(q - q2);
-                    const float W = wv + __shfl_xor(wv, 32);
-                    const uint32_t sc = ci / d.sc_chunks;
-                    if (h == 0) { scW[sc * 128 + col] = W; scQ[sc * 128 + col] = q2; }
-                    s_sc = 0.0;
+                    for (int r = 1; r < 16; ++r) cm = fmaxf(cm, fmaxf(acc0[r], acc1[r]));
+                    cm *= kLog2e;
+                    q = fmaxf(fmaxf(cm, swap32(cm)), -1.0e30f);
                 }
+                acc_p0 = acc0; acc_p1 = acc1; ci_p = ci; have_p = true;
             }
         }
-        n_resc = max(n_resc, static_cast<uint32_t>(__shfl_xor(static_cast<int>(n_resc), 32)));
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        softmax_chunk(acc_p0, ci_p);           // drain the pipeline
+        softmax_chunk(acc_p1, ci_p + 1);
+        flush_sc(ci_p);
+        n_resc = max(n_resc, __shfl_xor(n_resc, 32));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // scratch: written by lanes < 32, read below
 
-        // ---- search, part 1 (lane per user): total, target, super-chunk ----
-        const float Q = scQ[(d.n_sc - 1) * 128 + col];        // references only grow: the last is the max
+        // ---- search, part 1 (lane per user; lanes >= 32 mirror): total, target, super-chunk, chunk ----
+        const float Q = scr[(d.n_sc - 1) * 32 + j].y;          // references only grow: the last is the max
         double S = 0.0;
-        for (uint32_t sc = 0; sc < d.n_sc; ++sc)
-            S += static_cast<double>(scW[sc * 128 + col] * __builtin_amdgcn_exp2f(scQ[sc * 128 + col] - Q));
+        for (uint32_t sc = 0; sc < d.n_sc; ++sc) {
+            const float2 wq = scr[sc * 32 + j];
+            S += static_cast<double>(wq.x * __builtin_amdgcn_exp2f(wq.y - Q));
+        }
         const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
         const rg_u32x4 rw = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
         const double tau = rg_uniform(rw.w[0], rw.w[1]) * S;
         double pb = 0.0;
         uint32_t sc_star = d.n_sc - 1;
+        float f_star = 1.0f;
+        bool found_sc = false;
         {
             double run = 0.0;
-            bool found = false;
             for (uint32_t sc = 0; sc < d.n_sc; ++sc) {
-                const double Wd = static_cast<double>(scW[sc * 128 + col] * __builtin_amdgcn_exp2f(scQ[sc * 128 + col] - Q));
-                if (!found && run + Wd > tau) { found = true; sc_star = sc; pb = run; }
-                if (!found) run += Wd;
+                const float2 wq = scr[sc * 32 + j];
+                const float f = __builtin_amdgcn_exp2f(wq.y - Q);
+                const double Wd = static_cast<double>(wq.x * f);
+                if (!found_sc && run + Wd > tau) { found_sc = true; sc_star = sc; pb = run; f_star = f; }
+                if (!found_sc) run += Wd;
             }
-            if (!found) pb = run - static_cast<double>(scW[(d.n_sc - 1) * 128 + col] *
-                                                      __builtin_amdgcn_exp2f(scQ[(d.n_sc - 1) * 128 + col] - Q));
         }
+        // chunk inside the super-chunk (its chunk sums share the super-chunk's reference)
+        uint32_t c_star = 0;
+        bool found_c = false;
+        {
+            const uint32_t c0 = sc_star * d.sc_chunks, c1 = min(c0 + d.sc_chunks, d.n_chunks);
+            double run = pb;
+            for (uint32_t c = c0; c < c1; ++c) {
+                const double Wd = static_cast<double>(scr_chunk[c * 32 + j] * f_star);
+                if (!found_c && run + Wd > tau) { found_c = true; c_star = c; pb = run; }
+                if (!found_c) run += Wd;
+            }
+        }
+        found_c = found_c && found_sc;
         const double delta = static_cast<double>(d.K + 3) * 5.9604644775390625e-08 * static_cast<double>(Ahat) +
                              kDeltaFixed + kDeltaPerRescale * n_resc;
-        const unsigned long long act_mask = __ballot(active && h == 0);
 
-        // ---- search, part 2 (whole wave per user): recompute the chosen super-chunk on the VALU ----
+        // ---- search, part 2: recompute the 32 products of chunk c_star, 16 per lane, in registers ----
         uint32_t my_v = 0;
         bool my_ok = false;
-        for (int jj = 0; jj < 32; ++jj) {
-            if (!((act_mask >> jj) & 1ull)) continue;
-            const uint32_t scj = __shfl(static_cast<int>(sc_star), jj);
-            const double pbj = readlane_f64(pb, jj);
-            const double tauj = readlane_f64(tau, jj);
-            const double deltaj = readlane_f64(delta, jj);
-            const float Qj = __shfl(Q, jj);
-            const float* om = om_tile + (wave * 32 + jj) * 2 * KH;
-            const uint32_t base = scj * d.sc_chunks * 32;
-            const uint32_t endp = min(base + d.sc_chunks * 32, d.n_chunks * 32);
-            double run = pbj, A = 0.0, B = 0.0;
-            uint32_t v = 0;
-            bool found = false;
-            for (uint32_t g = base; g < endp; g += 64) {
-                const uint32_t p = g + lane;      // < P_pad by construction
-                const float* grow = d.gamma32 + static_cast<size_t>(p) * d.KS;
-                float l = d.mu32[p];
-#pragma unroll 8
-                for (int k = 0; k < 2 * KH; k += 2) {
-                    const float2 gg = *reinterpret_cast<const float2*>(grow + k);
-                    l = fmaf(gg.x, om[k], l);
-                    l = fmaf(gg.y, om[k + 1], l);
-                }
-                const float e = (p < endp) ? __builtin_amdgcn_exp2f(fmaf(l, kLog2e, -Qj)) : 0.0f;
-                const float x = wave_scan_f32(e, lane);
-                const double px = run + static_cast<double>(x);
-                const unsigned long long hit = __ballot(p < endp && px > tauj);
-                if (hit) {
-                    const int L = __builtin_ctzll(hit);
-                    B = readlane_f64(px, L);
-                    A = L ? readlane_f64(px, L - 1) : run;
-                    v = g + L;
-                    found = true;
-                    break;
-                }
-                run += static_cast<double>(__shfl(x, 63));
+        if (!(d.ablate & 1u)) {
+            // this lane's view of the whole omega32 vector of its user
+            float om[2 * KH];
+#pragma unroll
+            for (int s = 0; s < KH; ++s) {
+                const float o = swap32(b[s]);
+                om[s] = h ? o : b[s];
+                om[KH + s] = h ? b[s] : o;
             }
-            const bool ok = found && v < d.P &&
-                            (v == 0 || A * (1.0 + deltaj) < tauj * (1.0 - deltaj)) &&
-                            (v == d.P - 1 || tauj * (1.0 + deltaj) < B * (1.0 - deltaj));
-            if (lane == jj) { my_v = v; my_ok = ok; }
-        }
-        // ---- emit (lane per user again, so the history inserts of 32 users overlap) ----
+            const uint32_t p_first = c_star * 32 + 16 * h;        // < P_pad by construction
+            float pre[16];
+            float runf = 0.0f;
+#pragma unroll
+            for (int i2 = 0; i2 < 8; ++i2) {
+                // two rows = 2*KS floats, KS == 2 mod 4 -> a whole number of aligned float4
+                const float4* rp = reinterpret_cast<const float4*>(d.gamma32 + static_cast<size_t>(p_first + 2 * i2) * d.KS);
+                float rowpair[2 * (2 * KH + 2)];
+                constexpr int KSc = 2 * KH + 2;
+#pragma unroll
+                for (int v4 = 0; v4 < KSc / 2; ++v4) {
+                    const float4 x = rp[v4];
+                    rowpair[4 * v4 + 0] = x.x; rowpair[4 * v4 + 1] = x.y; rowpair[4 * v4 + 2] = x.z; rowpair[4 * v4 + 3] = x.w;
+                }
+                const float2 mu2 = *reinterpret_cast<const float2*>(d.mu32 + p_first + 2 * i2);
+                float l0 = mu2.x, l1 = mu2.y;
+#pragma unroll
+                for (int k = 0; k < 2 * KH; ++k) {
+                    l0 = fmaf(rowpair[k], om[k], l0);
+                    l1 = fmaf(rowpair[KSc + k], om[k], l1);
+                }
+                runf += __builtin_amdgcn_exp2f(fmaf(l0, kLog2e, -Q));
+                pre[2 * i2] = runf;
+                runf += __builtin_amdgcn_exp2f(fmaf(l1, kLog2e, -Q));
+                pre[2 * i2 + 1] = runf;
+            }
+            // prefix of lane h=1 starts after lane h=0's 16 products
+            const float t0 = swap32(runf);
+            const double base = pb + (h ? static_cast<double>(t0) : 0.0);
+            int idx = -1;
+            double A = base, B = base;
+#pragma unroll
+            for (int i = 15; i >= 0; --i) {
+                const double px = base + static_cast<double>(pre[i]);
+                if (px > tau) { idx = i; B = px; A = i ? base + static_cast<double>(pre[i - 1]) : base; }
+            }
+            // the user's answer is lane h=0's hit if it has one, else lane h=1's
+            const int idx_o = __shfl_xor(idx, 32);
+            const double A_o = __shfl_xor(A, 32), B_o = __shfl_xor(B, 32);
+            int vi; double Av, Bv;
+            if (h == 0) { if (idx >= 0) { vi = idx; Av = A; Bv = B; } else { vi = idx_o >= 0 ? 16 + idx_o : -1; Av = A_o; Bv = B_o; } }
+            else        { if (idx_o >= 0) { vi = idx_o; Av = A_o; Bv = B_o; } else { vi = idx >= 0 ? 16 + idx : -1; Av = A; Bv = B; } }
+            const uint32_t v = c_star * 32 + static_cast<uint32_t>(max(vi, 0));
+            my_v = v;
+            my_ok = found_c && vi >= 0 && v < d.P &&
+                    (v == 0 || Av * (1.0 + delta) < tau * (1.0 - delta)) &&
+                    (v == d.P - 1 || tau * (1.0 + delta) < Bv * (1.0 - delta));
+        } else { my_v = static_cast<uint32_t>(S) % d.P; my_ok = true; }
+        // ---- emit (lane per user) ----
         if (active && h == 0) {
             if (my_ok) {
                 write_organic_row(d, t, pos, user, my_v);
@@ -803,10 +923,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_draw_mfma(DevSim
                 d.exact_ref[xi] = Q;
             }
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
-
 
 // ------------------------------------------------------------------------------------------
 // k_advance — one Markov transition for every live user (lane per user).
@@ -1157,6 +1275,14 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     s->prof_ms[0] = s->prof_ms[1] = s->prof_ms[2] = 0.0;
     s->mfma_smem = d.use_mfma ? mfma_smem_bytes(geom_of(*cfg)) : 0;
     if (const char* e = getenv("RECOGYM_FORCE_EXACT")) if (e[0] == '1') d.use_mfma = 0;   // A/B switch for tests
+    d.ablate = 0;
+    if (const char* e = getenv("RECOGYM_ABLATE")) d.ablate = static_cast<uint32_t>(atoi(e));
+    if (const char* e = getenv("RECOGYM_LDS_PAD")) s->mfma_smem += static_cast<size_t>(atoi(e));
+    if (getenv("RECOGYM_DEBUG") && d.use_mfma && rg_device_count() > 0) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_draw_mfma<10>), kBlock, s->mfma_smem);
+        fprintf(stderr, "[recogym] k_draw_mfma<10>: dynamic LDS %zu B, occupancy API %d blocks/CU\n", s->mfma_smem, nb);
+    }
     if (s->mfma_smem > 64 * 1024) {
         // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel instantiation
         const int bytes = static_cast<int>(s->mfma_smem);
