@@ -1,1 +1,44 @@
-"""recogym_amd — MI355X-native vectorised reco-gym-v1 step loop."""
+"""recogym_amd — MI355X-native vectorised reco-gym-v1 step loop.
+
+Same public names as the reference's `recogym` package for the hot path:
+
+    import recogym_amd as recogym
+    env = recogym.make('reco-gym-v1'); env.init_gym({**recogym.env_1_args, 'random_seed': 42})
+    logs = env.generate_logs(1000)                       # pandas DataFrame, reference columns
+    recogym.test_agent(env, agent, 1000, 1000); recogym.verify_agents(env, 1000, {...})
+"""
+from .envs import Configuration, Context, DefaultContext, Observation, Session, OrganicSessions
+
+_REGISTRY = {}
+
+
+def register(id, entry_point, **kwargs):
+    _REGISTRY[id] = entry_point
+
+
+def make(env_id):
+    """gym.make for the ids this package registers (reference: recogym/__init__.py:37-45)."""
+    import importlib
+    module, cls = _REGISTRY[env_id].split(':')
+    return getattr(importlib.import_module(module), cls)()
+
+
+register(id='reco-gym-v1', entry_point='recogym_amd.envs.reco_env_v1:RecoEnv1')
+
+
+def __getattr__(name):
+    # torch-dependent pieces load lazily so that `import recogym_amd` works everywhere
+    if name in ('env_1_args', 'env_args', 'RecoEnv1'):
+        from .envs import reco_env_v1
+        return getattr(reco_env_v1, name)
+    if name == 'test_agent':
+        from .bench_agents import test_agent
+        return test_agent
+    if name == 'verify_agents':
+        from .evaluate_agent import verify_agents
+        return verify_agents
+    if name in ('Agent', 'RandomAgent', 'random_args', 'OrganicUserEventCounterAgent',
+                'organic_user_count_args'):
+        from . import agents
+        return getattr(agents, name)
+    raise AttributeError(name)

@@ -1,0 +1,3 @@
+from .abstract import Agent
+from .random_agent import RandomAgent, random_args
+from .organic_user_count import OrganicUserEventCounterAgent, organic_user_count_args

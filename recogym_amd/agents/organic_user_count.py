@@ -1,0 +1,82 @@
+"""OrganicUserEventCounterAgent — reference: recogym/agents/organic_user_count.py:45-96 acting on
+the per-user view counts of ViewsFeaturesProvider (recogym/agents/abstract.py:347-395).
+
+On the device the counts live as a sorted (product, count) history per user (rg_config.ouc_*);
+this class is the policy descriptor plus the host form of the same arithmetic.
+"""
+import numpy as np
+
+from .. import _abi, rng
+from ..envs.configuration import Configuration
+from .abstract import Agent
+
+organic_user_count_args = {
+    'num_products': 10,
+    'random_seed': np.random.randint(2 ** 31 - 1),
+    'select_randomly': True,      # sample proportionally to the counts (else argmax)
+    'epsilon': .0,
+    'exploit_explore': True,
+    'reverse_pop': False,
+    'weight_history_function': None,
+    'with_ps_all': False,
+}
+
+
+def _icdf(p, u):
+    """RandomState.choice(P, p=p) given its uniform."""
+    cdf = p.cumsum()
+    cdf /= cdf[-1]
+    return int(cdf.searchsorted(u, side='right'))
+
+
+class OrganicUserEventCounterAgent(Agent):
+    def __init__(self, config=Configuration(organic_user_count_args)):
+        super().__init__(config)
+        if getattr(config, 'weight_history_function', None) is not None:
+            raise NotImplementedError('weight_history_function is not supported (SURVEY.md §8f)')
+        self.views = np.zeros(config.num_products, dtype=np.int64)
+
+    def device_policy(self):
+        c = self.config
+        if getattr(c, 'with_ps_all', False):
+            return None
+        return dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=c.random_seed,
+                    ouc=dict(select_randomly=c.select_randomly, epsilon=c.epsilon,
+                             exploit_explore=c.exploit_explore,
+                             reverse_pop=getattr(c, 'reverse_pop', False)))
+
+    def reset(self):
+        self.views[:] = 0
+
+    def act(self, observation, reward, done):
+        c = self.config
+        for s in observation.sessions():
+            self.views[int(s['v'])] += 1
+        ctx = observation.context()
+        _, u0, u1 = rng.policy_uniforms(c.random_seed, ctx.user(), ctx.time())
+        eps = c.epsilon
+        f = self.views.astype(np.float64)
+        explore = False
+        if c.exploit_explore:
+            explore = not (eps / (eps + (1 - eps)) <= u0)
+            if explore:
+                f = (self.views == 0).astype(np.float64)
+            p = f / np.sum(f)
+        else:
+            f = eps + f
+            p = f / np.sum(f)
+            if getattr(c, 'reverse_pop', False):
+                p = 1 - p
+                p = p / np.sum(p)
+        if c.select_randomly:
+            a = _icdf(p, u1)
+            ps = ((eps if explore else 1 - eps) * p[a]) if c.exploit_explore else p[a]
+            ps_all = p if getattr(c, 'with_ps_all', False) else ()
+        else:
+            a = int(np.argmax(p))
+            ps = 1.0
+            ps_all = ()
+            if getattr(c, 'with_ps_all', False):
+                ps_all = np.zeros(c.num_products)
+                ps_all[a] = 1.0
+        return {**super().act(observation, reward, done), 'a': a, 'ps': ps, 'ps-a': ps_all}

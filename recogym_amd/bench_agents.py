@@ -1,0 +1,92 @@
+"""test_agent — reference: recogym/bench_agents.py:215-251 (+ _collect_stats, :66-212).
+
+Train an agent on offline users, evaluate it on online users, return the (median, 2.5 %, 97.5 %)
+quantiles of the Beta(successes + 1, failures + 1) CTR posterior.  The evaluation is the hot
+path: with a device-capable agent it runs as one batched simulation per rank and only the
+counters leave the GPU; ranks (if torch.distributed is initialised) simulate disjoint user-id
+ranges and all-reduce {clicks, impressions}.  Training keeps the reference's per-user protocol
+(agent.train on every observation) and is skipped for agents that have nothing to learn.
+"""
+from copy import deepcopy
+
+from scipy.stats.distributions import beta
+
+from . import parallel
+from .envs.reco_env_v1 import device_policy_of
+
+
+def evaluate_counts(env, agent, num_users):
+    """-> (successes, failures) of `agent` over users 0..num_users-1, summed over all ranks.
+    successes = sum of c over bandit rows, failures = bandit rows - successes; the phantom row
+    of every user counts as a failure exactly as in the reference (bench_agents.py:203-206)."""
+    rank, ws, _ = parallel.world()
+    if device_policy_of(agent) is not None:
+        first, count = parallel.shard_range(num_users, rank, ws)
+        clicks = shown = 0
+        dev = None
+        if count:
+            cnt, sim = env.simulate(count, agent, first_user_id=first, log=False)
+            clicks, shown = cnt['clicks'], cnt['bandit'] + cnt['phantom']
+            dev = sim.device
+            sim.close()
+        clicks, shown = parallel.all_reduce_counts([clicks, shown], dev)
+        return clicks, shown - clicks
+    # arbitrary Python agent: per-user path on rank 0's env (no sharding: agents are stateful)
+    data = env.generate_logs(num_users, agent)
+    rewards = data[data['z'] == 'bandit']['c']
+    successes = int(rewards.sum())
+    return successes, int(rewards.shape[0]) - successes
+
+
+def _learns(agent):
+    """Does agent.train do anything?  (Agent.train is a no-op for the device policies.)"""
+    from .agents.abstract import Agent
+    fn = getattr(type(agent), 'train', None)
+    return fn is not None and fn is not Agent.train and hasattr(agent, 'train')
+
+
+def _train(env, agent, num_offline_users, num_organic_offline_users):
+    """The reference's offline protocol (bench_agents.py:168-190)."""
+    uid = 0
+    for _ in range(num_organic_offline_users):
+        env.reset(uid)
+        uid += 1
+        obs, _, _, _ = env.step(None)
+        agent.train(obs, None, None, True)
+    for _ in range(num_offline_users):
+        env.reset(uid)
+        uid += 1
+        new_obs, _, done, reward = env.step(None)
+        while not done:
+            old_obs = new_obs
+            action, new_obs, reward, done, _ = env.step_offline(old_obs, reward, done)
+            agent.train(old_obs, action, reward, False)
+        old_obs = new_obs
+        action, _, reward, done, _ = env.step_offline(old_obs, reward, done)
+        agent.train(old_obs, action, reward, True)
+
+
+def test_agent(env, agent, num_offline_users=1000, num_online_users=100,
+               num_organic_offline_users=0, num_epochs=1, epoch_with_random_reset=False,
+               with_cache=False):
+    successes = failures = 0
+    for epoch in range(num_epochs):
+        new_agent = deepcopy(agent)
+        if epoch_with_random_reset:
+            train_env = deepcopy(env)
+            train_env.reset_random_seed(epoch)
+            eval_env = deepcopy(env)
+            eval_env.reset_random_seed(epoch)
+        else:
+            train_env = eval_env = env
+        if _learns(new_agent) and device_policy_of(new_agent) is None:
+            _train(train_env, new_agent, num_offline_users, num_organic_offline_users)
+        s, f = evaluate_counts(eval_env, new_agent, num_online_users)
+        successes += s
+        failures += f
+    return (beta.ppf(0.500, successes + 1, failures + 1),
+            beta.ppf(0.025, successes + 1, failures + 1),
+            beta.ppf(0.975, successes + 1, failures + 1))
+
+
+test_agent.__test__ = False      # not a pytest test

@@ -1,11 +1,382 @@
-"""placeholder, replaced below"""
-from .static_params import *  # noqa
+"""RecoEnv1 — the reference's `reco-gym-v1` environment surface over the HIP step loop.
+
+Reference surface mirrored here (same names, arguments, return values and assertion errors):
+    AbstractEnv   recogym/envs/abstract.py:46-327   init_gym, reset_random_seed, reset, step,
+                                                    step_offline, generate_logs
+    RecoEnv1      recogym/envs/reco_env_v1.py:44-174
+    env_args / env_1_args                           abstract.py:20-31, reco_env_v1.py:18-29
+
+What is different, on purpose (DESIGN.md §"drop-in boundary"):
+  * every draw is addressed by (random_seed + epoch, user id, t) instead of coming from one
+    sequential MT19937 stream, so a user's trajectory does not depend on the users simulated
+    before it and `generate_logs` is repeatable without deepcopy;
+  * `generate_logs` with `agent=None`, a RandomAgent or an OrganicUserEventCounterAgent runs all
+    users concurrently on the GPU; any other agent goes through the per-user path
+    (`reset`/`step_offline`, still HIP kernels, batch of one user);
+  * user / product ids wider than 16 bits are returned as UInt32 columns (the reference
+    overflows, SURVEY.md "facts");
+  * there is no CPU fallback: without a GPU, constructing the simulator raises.
+"""
+from copy import deepcopy
+
+import numpy as np
+import pandas as pd
+import torch
+
+from .. import _abi, rng
+from ..sim import Simulator, decode_rows
+from .configuration import Configuration
+from .context import DefaultContext
+from .features.time import DefaultTimeGenerator
+from .observation import Observation
+from .session import OrganicSessions
+from .static_params import draw_tables
+
+# Markov states — abstract.py:41-43
+organic = 0
+bandit = 1
+stop = 2
+
+# Arguments shared between all environments — abstract.py:20-31
 env_args = {
-    'num_products': 10, 'num_users': 100, 'random_seed': 0,
-    'prob_leave_bandit': 0.01, 'prob_leave_organic': 0.01,
-    'prob_bandit_to_organic': 0.05, 'prob_organic_to_bandit': 0.25,
-    'normalize_beta': False, 'with_ps_all': False,
+    'num_products': 10,
+    'num_users': 100,
+    'random_seed': np.random.randint(2 ** 31 - 1),
+    'prob_leave_bandit': 0.01,
+    'prob_leave_organic': 0.01,
+    'prob_bandit_to_organic': 0.05,
+    'prob_organic_to_bandit': 0.25,
+    'normalize_beta': False,
+    'with_ps_all': False,
 }
-env_1_args = {**env_args, 'K': 5, 'sigma_omega_initial': 1, 'sigma_omega': 0.1,
-              'number_of_flips': 0, 'sigma_mu_organic': 3, 'change_omega_for_bandits': False,
-              'normalize_beta': False}
+
+# reco_env_v1.py:18-29 (num_clusters / phi_var leak in from env_0_args in the reference and are
+# read by bench_agents' cache key, so they are kept)
+env_1_args = {
+    **env_args,
+    'num_clusters': 2,
+    'phi_var': 0.1,
+    'K': 5,
+    'sigma_omega_initial': 1,
+    'sigma_omega': 0.1,
+    'number_of_flips': 0,
+    'sigma_mu_organic': 3,
+    'change_omega_for_bandits': False,
+    'normalize_beta': False,
+}
+
+
+class Discrete:
+    """gym.spaces.Discrete stand-in (only `.n` is read)."""
+
+    def __init__(self, n):
+        self.n = n
+
+
+def device_policy_of(agent):
+    """-> dict(policy, policy_seed, ouc) if `agent` can run inside the batched device loop."""
+    if agent is None:
+        return dict(policy=_abi.RG_POLICY_UNIFORM_ENV, policy_seed=None, ouc=None)
+    if hasattr(agent, 'device_policy'):
+        return agent.device_policy()
+    # duck-type the reference's own agent classes
+    name = type(agent).__name__
+    cfg = getattr(agent, 'config', None)
+    if cfg is None or getattr(cfg, 'with_ps_all', False):
+        return None
+    if name == 'RandomAgent':
+        return dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=cfg.random_seed, ouc=None)
+    if name == 'OrganicUserEventCounterAgent' and \
+            getattr(cfg, 'weight_history_function', None) is None:
+        return dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=cfg.random_seed,
+                    ouc=dict(select_randomly=cfg.select_randomly, epsilon=cfg.epsilon,
+                             exploit_explore=cfg.exploit_explore,
+                             reverse_pop=getattr(cfg, 'reverse_pop', False)))
+    return None
+
+
+def rows_to_dataframe(rows, num_products, with_ps_all=False):
+    """Decoded device rows -> the DataFrame of generate_logs (abstract.py:256-265,318-327):
+    columns t (float32), u/v/a (nullable UInt16, UInt32 beyond the reference's ceiling),
+    z ('organic'/'bandit'), c (float32, NaN on organic rows), ps (float64), ps-a (object)."""
+    is_b = rows['z'] == 1
+    n = len(rows)
+    wide_u = n and int(rows['u'].max()) > 65535
+    wide_p = num_products > 65535
+    udt = pd.UInt32Dtype() if wide_u else pd.UInt16Dtype()
+    pdt = pd.UInt32Dtype() if wide_p else pd.UInt16Dtype()
+    ps_a = np.empty(n, dtype=object)
+    ps_a[:] = None
+    if with_ps_all:
+        uniform = np.ones(num_products) / num_products
+        for i in np.nonzero(is_b)[0]:
+            ps_a[i] = uniform
+    else:
+        filler = ()
+        for i in np.nonzero(is_b)[0]:
+            ps_a[i] = filler
+    data = {
+        't': rows['t'].astype(np.float32),
+        'u': pd.array(rows['u'].astype(np.int64), dtype=udt),
+        'z': np.where(is_b, 'bandit', 'organic').astype(object),
+        'v': pd.array(np.where(is_b, 0, rows['v']).astype(np.int64), dtype=pdt),
+        'a': pd.array(np.where(is_b, rows['a'], 0).astype(np.int64), dtype=pdt),
+        'c': np.where(is_b, rows['c'], np.nan).astype(np.float32),
+        'ps': np.where(is_b, rows['ps'], np.nan).astype(np.float64),
+        'ps-a': ps_a,
+    }
+    data['v'][is_b] = pd.NA
+    data['a'][~is_b] = pd.NA
+    return pd.DataFrame(data, columns=['t', 'u', 'z', 'v', 'a', 'c', 'ps', 'ps-a'])
+
+
+class RecoEnv1:
+    """Drop-in for the object `gym.make('reco-gym-v1')` returns."""
+
+    metadata = {}
+
+    def __init__(self):
+        self.first_step = True
+        self.config = None
+        self.state = None
+        self.current_user_id = None
+        self.current_time = None
+        self.empty_sessions = OrganicSessions()
+        self.agent = None
+        self._epoch = 0
+        self._tables = None
+        self._seq = None          # 1-user simulator behind reset()/step()
+        self._device = None
+
+    # -- construction -------------------------------------------------------------------------
+    def init_gym(self, args):
+        self.config = Configuration(args)
+        self.action_space = Discrete(self.config.num_products)
+        if 'time_generator' in args and not isinstance(args['time_generator'],
+                                                       DefaultTimeGenerator) \
+                and type(args['time_generator']).__name__ != 'DefaultTimeGenerator':
+            raise NotImplementedError(
+                'only DefaultTimeGenerator (t = event index) is supported by the device step '
+                'loop; NormalTimeGenerator is listed as next in SURVEY.md §8f')
+        self.time_generator = DefaultTimeGenerator(self.config)
+        self.agent = args['agent'] if 'agent' in args else None
+        self.reset_random_seed()
+        self._tables = draw_tables(self.config)      # set_static_params, bit-identical draws
+
+    def reset_random_seed(self, epoch=0):
+        assert (self.config.random_seed is not None)
+        self._epoch = epoch
+        if self._seq is not None:
+            self._seq.reseed(self.config.random_seed + epoch, self.config.random_seed + epoch)
+
+    @property
+    def seed(self):
+        return self.config.random_seed + self._epoch
+
+    # lazily materialised numpy views of the static tables, for debugging / notebooks
+    @property
+    def Gamma(self):
+        return self._tables[0]
+
+    @property
+    def mu_organic(self):
+        return self._tables[1].reshape(-1, 1)
+
+    @property
+    def beta(self):
+        return self._tables[2]
+
+    @property
+    def mu_bandit(self):
+        return self._tables[3].reshape(-1, 1)
+
+    @property
+    def omega(self):
+        return self._seq.omega().cpu().numpy().reshape(-1, 1) if self._seq is not None else None
+
+    def __deepcopy__(self, memo):
+        other = RecoEnv1()
+        other.config = self.config
+        other.action_space = getattr(self, 'action_space', None)
+        other.time_generator = DefaultTimeGenerator(self.config) if self.config else None
+        other.agent = deepcopy(self.agent, memo)
+        other._epoch = self._epoch
+        other._tables = self._tables               # read-only
+        other._device = self._device
+        return other
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st['_seq'] = None                          # device state is re-derived from the seed
+        return st
+
+    # -- the batched device path ----------------------------------------------------------------
+    def make_simulator(self, n_users, agent=None, log=True, device=None, policy=None):
+        pol = policy if policy is not None else device_policy_of(agent)
+        if pol is None:
+            raise ValueError(f'{type(agent).__name__} cannot run inside the device step loop')
+        if pol['policy_seed'] is None:
+            pol = dict(pol, policy_seed=self.seed)      # agent=None draws from the ENV stream
+        return Simulator(self.config, n_users, epoch=self._epoch, tables=self._tables,
+                         log_capacity=None if log else 0, device=device or self._device, **pol)
+
+    def simulate(self, num_users, agent=None, num_organic_users=0, first_user_id=0, log=True,
+                 device=None):
+        """All users at once on the GPU -> (counters dict, Simulator).  User ids are
+        first_user_id .. ; the first `num_organic_users` ids are organic-only warm-up users."""
+        total = num_users + num_organic_users
+        sim = self.make_simulator(total, agent, log=log, device=device)
+        while True:
+            sim.reset_users(first_user_id, total,
+                            organic_only_below=first_user_id + num_organic_users)
+            sim.run()
+            cnt = sim.counters()
+            if cnt['hist_overflow']:
+                raise _abi.RecoGymHipError('per-user view history overflowed ouc_history_cap')
+            if cnt['log_dropped'] == 0:
+                return cnt, sim
+            sim.set_log_capacity(cnt['log_rows'] + cnt['log_dropped'] + 1024)
+
+    # -- gym.Env episode API (one user at a time; batch of 1 on the device) -----------------------
+    def _seq_sim(self):
+        if self._seq is None:
+            self._seq = Simulator(self.config, 1, policy=_abi.RG_POLICY_EXTERNAL, epoch=self._epoch,
+                                  tables=self._tables, log_capacity=1 << 16, device=self._device)
+            self._act = torch.zeros(1, dtype=torch.int32, device=self._seq.device)
+        return self._seq
+
+    def reset(self, user_id=0):
+        self.first_step = True
+        self.state = organic
+        self.time_generator.reset()
+        if self.agent:
+            self.agent.reset()
+        self.current_time = self.time_generator.new_time()
+        self.current_user_id = user_id
+        sim = self._seq_sim()
+        sim.reseed(self.seed, self.seed)
+        sim.reset_users(user_id, 1)
+        self._rows_read = 0
+
+    def _advance(self, action=None):
+        """One Markov transition of the current user on the device -> the emitted row."""
+        sim = self._seq
+        if action is not None:
+            self._act.fill_(int(action))
+        sim.step(self._act)
+        raw = sim.log[self._rows_read:self._rows_read + 1].cpu().numpy()
+        self._rows_read += 1
+        row = decode_rows(raw)[0]
+        self.state = int(sim.states()[0].item())
+        self.current_time = self.time_generator.new_time()
+        return row
+
+    def generate_organic_sessions(self):
+        session = OrganicSessions()
+        while self.state == organic:
+            t, u = self.current_time, self.current_user_id
+            row = self._advance()
+            session.next(DefaultContext(t, u), int(row['v']))
+        return session
+
+    def step(self, action_id):
+        info = {}
+        if self.first_step:
+            assert (action_id is None)
+            self.first_step = False
+            sessions = self.generate_organic_sessions()
+            return (Observation(DefaultContext(self.current_time, self.current_user_id), sessions),
+                    None, self.state == stop, info)
+        assert (action_id is not None)
+        row = self._advance(action_id)
+        reward = int(row['c'])
+        sessions = self.generate_organic_sessions() if self.state == organic \
+            else self.empty_sessions
+        return (Observation(DefaultContext(self.current_time, self.current_user_id), sessions),
+                reward, self.state == stop, info)
+
+    def step_offline(self, observation, reward, done):
+        if self.first_step:
+            action = None
+        else:
+            assert (hasattr(self, 'agent'))
+            assert (observation is not None)
+            if self.agent:
+                action = self.agent.act(observation, reward, done)
+            else:
+                P = self.config.num_products
+                ctx = observation.context()
+                w = rng.draw(self.seed, ctx.user(), ctx.time(), 0, rng.DRAW_POLICY)
+                action = {
+                    't': ctx.time(), 'u': ctx.user(), 'a': rng.bounded(w[0], w[1], P),
+                    'ps': 1.0 / P,
+                    'ps-a': np.ones(P) / P if self.config.with_ps_all else (),
+                }
+        if done:
+            return (action,
+                    Observation(DefaultContext(self.current_time, self.current_user_id),
+                                self.empty_sessions),
+                    0, done, None)
+        observation, reward, done, info = self.step(action['a'] if action is not None else None)
+        return action, observation, reward, done, info
+
+    # -- generate_logs ----------------------------------------------------------------------------
+    def generate_logs(self, num_offline_users, agent=None, num_organic_offline_users=0):
+        """Logs of `agent` (None = uniform random actions) over the given number of users."""
+        use = agent if agent else self.agent
+        pol = device_policy_of(use)
+        if pol is not None:
+            cnt, sim = self.simulate(num_offline_users, use, num_organic_offline_users)
+            rows = sim.rows()
+            sim.close()
+            with_all = bool(getattr(self.config, 'with_ps_all', False)) and use is None
+            return rows_to_dataframe(rows, self.config.num_products, with_all)
+        return self._generate_logs_per_user(num_offline_users, use, num_organic_offline_users)
+
+    def _generate_logs_per_user(self, num_offline_users, agent, num_organic_offline_users):
+        """Any Python agent: the reference's loop (abstract.py:292-316), one user at a time."""
+        old_agent, self.agent = self.agent, agent
+        cols = {k: [] for k in ('t', 'u', 'z', 'v', 'a', 'c', 'ps', 'ps-a')}
+
+        def put(t, u, z, v, a, c, ps, ps_a):
+            for k, x in zip(cols, (t, u, z, v, a, c, ps, ps_a)):
+                cols[k].append(x)
+
+        def store_organic(obs):
+            for s in obs.sessions():
+                put(s['t'], s['u'], 'organic', s['v'], None, None, None, None)
+
+        def store_bandit(action, reward):
+            if action:
+                put(action['t'], action['u'], 'bandit', None, action['a'], reward, action['ps'],
+                    action['ps-a'] if 'ps-a' in action else ())
+
+        uid = 0
+        for _ in range(num_organic_offline_users):
+            self.reset(uid)
+            uid += 1
+            obs, _, _, _ = self.step(None)
+            store_organic(obs)
+        for _ in range(num_offline_users):
+            self.reset(uid)
+            uid += 1
+            obs, reward, done, _ = self.step(None)
+            while not done:
+                store_organic(obs)
+                action, obs, reward, done, _ = self.step_offline(obs, reward, done)
+                store_bandit(action, reward)
+            store_organic(obs)
+            action, _, reward, done, _ = self.step_offline(obs, reward, done)
+            assert done, 'Done must not be changed!'
+            store_bandit(action, reward)
+        self.agent = old_agent
+        wide_u = uid > 65536
+        wide_p = self.config.num_products > 65535
+        udt = pd.UInt32Dtype() if wide_u else pd.UInt16Dtype()
+        pdt = pd.UInt32Dtype() if wide_p else pd.UInt16Dtype()
+        cols['t'] = np.array(cols['t'], dtype=np.float32)
+        cols['u'] = pd.array(cols['u'], dtype=udt)
+        cols['v'] = pd.array(cols['v'], dtype=pdt)
+        cols['a'] = pd.array(cols['a'], dtype=pdt)
+        cols['c'] = np.array(cols['c'], dtype=np.float32)
+        return pd.DataFrame().from_dict(cols)

@@ -1,0 +1,186 @@
+"""The reference's class surface over the HIP path (needs a GPU): gym.make / init_gym /
+reset / step / step_offline / generate_logs / test_agent / verify_agents."""
+import json
+import os
+from copy import deepcopy
+
+import numpy as np
+import pandas as pd
+import pytest
+from scipy.stats.distributions import beta
+
+import golden_util as gu
+import recogym_amd as recogym
+from recogym_amd import _abi
+from recogym_amd.agents import Agent, OrganicUserEventCounterAgent, RandomAgent
+from recogym_amd.envs.configuration import Configuration
+
+pytestmark = pytest.mark.gpu
+
+
+def make_env(over):
+    env = recogym.make('reco-gym-v1')
+    env.init_gym({**recogym.env_1_args, **over})
+    return env
+
+
+def make_agent(meta):
+    aa = {'num_products': meta['env_args']['num_products'], 'with_ps_all': False,
+          **meta['agent_args']}
+    if meta['agent'] == 'random':
+        return RandomAgent(Configuration(aa))
+    if meta['agent'] == 'ouc':
+        return OrganicUserEventCounterAgent(Configuration(
+            {**gu.OUC_DEFAULTS, 'weight_history_function': None, **aa}))
+    return None
+
+
+def frame_to_cols(df):
+    return {
+        't': df['t'].values.astype(np.int64),
+        'u': df['u'].astype('Int64').fillna(-1).values.astype(np.int64),
+        'z': (df['z'].values == 'bandit').astype(np.int64),
+        'v': df['v'].astype('Int64').fillna(-1).values.astype(np.int64),
+        'a': df['a'].astype('Int64').fillna(-1).values.astype(np.int64),
+        'c': np.where(np.isnan(df['c'].values), -1, df['c'].values).astype(np.int64),
+        'ps': df['ps'].values.astype(np.float64),
+    }
+
+
+def assert_frames_match(cols, want, ps_rtol):
+    for k in ('t', 'u', 'z', 'v', 'a', 'c'):
+        assert np.array_equal(cols[k], want[k].astype(np.int64)), k
+    np.testing.assert_allclose(cols['ps'], want['ps'], rtol=ps_rtol, equal_nan=True)
+
+
+@pytest.mark.parametrize('name', ['philox_p10', 'philox_p1000_k20', 'philox_random_agent',
+                                  'philox_ouc', 'philox_ouc_eps', 'philox_flips_normbeta'])
+def test_generate_logs_dataframe_equals_the_reference_log(name):
+    meta, want = gu.load(name)
+    env = make_env(meta['env_args'])
+    df = env.generate_logs(meta['n_users'], make_agent(meta), meta['n_organic'])
+    assert list(df.columns) == ['t', 'u', 'z', 'v', 'a', 'c', 'ps', 'ps-a']
+    assert [str(df[c].dtype) for c in df.columns] == \
+        ['float32', 'UInt16', 'object', 'UInt16', 'UInt16', 'float32', 'float64', 'object']
+    assert_frames_match(frame_to_cols(df), want, 1e-6)
+    # repeatable, and deepcopy-safe like the reference's harness expects
+    df2 = deepcopy(env).generate_logs(meta['n_users'], make_agent(meta), meta['n_organic'])
+    pd.testing.assert_frame_equal(df, df2)
+
+
+@pytest.mark.parametrize('name', ['philox_random_agent', 'philox_ouc_eps', 'philox_p10'])
+def test_per_user_gym_path_equals_batched_path(name):
+    """reset/step/step_offline with the agent's Python act (batch of one user on the device)
+    logs exactly what the all-users-at-once device policy logs."""
+    meta, want = gu.load(name)
+    n = 25
+    env = make_env(meta['env_args'])
+    agent = make_agent(meta)
+    df_seq = env._generate_logs_per_user(n, agent, 0)
+    df_dev = make_env(meta['env_args']).generate_logs(n, make_agent(meta), 0)
+    a, b = frame_to_cols(df_seq), frame_to_cols(df_dev)
+    assert_frames_match(a, b, 1e-6)
+    keep = want['u'] < n + meta['n_organic']
+    if meta['n_organic'] == 0:
+        assert_frames_match(b, {k: v[keep] for k, v in want.items() if k != 'p_click'}, 1e-6)
+
+
+class FixedCycleAgent(Agent):
+    """A Python-only agent (no device form): cycles through the products; tests the generic path."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.i = 0
+
+    def reset(self):
+        self.i = 0
+
+    def act(self, observation, reward, done):
+        self.i += 1
+        return {**super().act(observation, reward, done),
+                'a': self.i % self.config.num_products, 'ps': 1.0, 'ps-a': ()}
+
+
+def test_arbitrary_python_agent_matches_oracle_step_api():
+    from oracle import oracle as orc
+    over = dict(random_seed=77, num_products=12, K=4)
+    env = make_env(over)
+    agent = FixedCycleAgent(Configuration({'num_products': 12}))
+    df = env.generate_logs(30, agent)
+    o = orc.OracleEnv(Configuration({**recogym.env_1_args, **over}), rng_mode=orc.RNG_PHILOX)
+    rows = []
+    for user in range(30):
+        o.reset(user)
+        i = 0
+        org, reward, done = o.step(None)
+        rows += [(int(r['t']), user, 0, int(r['v']), -1, -1) for r in org]
+        while not done:
+            i += 1
+            t = o.time
+            org, reward, done = o.step(i % 12)
+            rows.append((t, user, 1, -1, i % 12, reward))
+            rows += [(int(r['t']), user, 0, int(r['v']), -1, -1) for r in org]
+        i += 1
+        rows.append((o.time, user, 1, -1, i % 12, 0))
+    want = np.array(rows, dtype=np.int64)
+    got = frame_to_cols(df)
+    for j, k in enumerate(('t', 'u', 'z', 'v', 'a', 'c')):
+        assert np.array_equal(got[k], want[:, j]), k
+
+
+def test_step_protocol_and_assertions():
+    env = make_env(dict(random_seed=42))
+    env.reset()
+    with pytest.raises(AssertionError):
+        env.step(3)                                   # abstract.py:158
+    env.reset()
+    obs, reward, done, info = env.step(None)
+    assert reward is None and info == {} and len(obs.sessions()) >= 1
+    assert obs.sessions()[0] == {'t': 0, 'u': 0, 'z': 'pageview', 'v': obs.sessions()[0]['v']}
+    if not done:
+        with pytest.raises(AssertionError):
+            env.step(None)                            # abstract.py:174
+    # the Getting-Started loop shape (cell 7): step_offline until done, agent=None
+    env.reset()
+    observation, reward, done = None, 0, False
+    steps = 0
+    while not done:
+        action, observation, reward, done, info = env.step_offline(observation, reward, done)
+        assert (action is None) == (steps == 0)
+        if action is not None:
+            assert set(action) == {'t', 'u', 'a', 'ps', 'ps-a'} and action['ps'] == 0.1
+        steps += 1
+    assert steps >= 1
+
+
+def test_test_agent_and_verify_agents_quantiles():
+    from oracle import oracle as orc
+    over = dict(random_seed=5, num_products=40, K=10)
+    env = make_env(over)
+    agents = {
+        'random': RandomAgent(Configuration({'num_products': 40, 'random_seed': 1,
+                                             'with_ps_all': False})),
+        'organic-count': OrganicUserEventCounterAgent(Configuration(
+            {**gu.OUC_DEFAULTS, 'weight_history_function': None, 'num_products': 40,
+             'random_seed': 2, 'with_ps_all': False})),
+    }
+    n = 3000
+    df = recogym.verify_agents(env, n, agents)
+    assert list(df.columns) == ['Agent', '0.025', '0.500', '0.975']
+    cfg = Configuration({**recogym.env_1_args, **over})
+    for i, (name, agent) in enumerate(agents.items()):
+        o = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **agent.device_policy())
+        o.generate_logs(n)
+        c = o.counters()
+        s, f = c['clicks'], c['bandit'] + c['phantom'] - c['clicks']
+        assert df['0.500'][i] == beta.ppf(0.5, s + 1, f + 1)
+        assert df['0.025'][i] == beta.ppf(0.025, s + 1, f + 1)
+        q = recogym.test_agent(env, agent, 10, n)
+        assert q == (beta.ppf(0.5, s + 1, f + 1), beta.ppf(0.025, s + 1, f + 1),
+                     beta.ppf(0.975, s + 1, f + 1))
+    # the organic-count policy beats random on this environment (sanity)
+    assert df['0.500'][1] > df['0.500'][0]
+    # epochs re-key the env stream
+    assert recogym.test_agent(env, agents['random'], 0, 500, num_epochs=2,
+                              epoch_with_random_reset=True) != \
+        recogym.test_agent(env, agents['random'], 0, 500, num_epochs=1)

@@ -1,0 +1,167 @@
+"""CPU tests of the host side: policies' Python form vs the oracle, DataFrame assembly, user
+sharding + counter all-reduce under a 2-process gloo group (the multi-GPU path, on CPU)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from oracle import oracle as orc
+from recogym_amd import _abi, parallel, rng
+from recogym_amd.agents import OrganicUserEventCounterAgent, RandomAgent
+from recogym_amd.envs.configuration import Configuration
+from recogym_amd.envs.context import DefaultContext
+from recogym_amd.envs.observation import Observation
+from recogym_amd.envs.reco_env_v1 import (device_policy_of, env_1_args, rows_to_dataframe)
+from recogym_amd.envs.session import OrganicSessions
+from recogym_amd.sim import ROW_DTYPE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_rng_matches_c_header():
+    for c in [(0, 0, 0, 0), (1, 2, 3, 4), (2 ** 32 - 1, 7, 0, 1)]:
+        for k in [(0, 0), (42, 0), (0xdeadbeef, 0x1234)]:
+            assert rng.philox4x32_10(*c, *k) == tuple(int(x) for x in orc.philox(c, k))
+
+
+@pytest.mark.parametrize('kind,agent_args', [
+    ('random', dict(random_seed=5)),
+    ('ouc', dict(random_seed=11)),
+    ('ouc', dict(random_seed=12, epsilon=0.3)),
+    ('ouc', dict(random_seed=13, select_randomly=False)),
+    ('ouc', dict(random_seed=14, exploit_explore=False, epsilon=0.5, reverse_pop=True)),
+])
+def test_python_agents_equal_the_oracle_policies(kind, agent_args):
+    """Drive the oracle env step by step with the host agents' actions: every (a, ps) the
+    Python act returns must be the oracle's policy_act for the same (user, t, views)."""
+    P = 20
+    cfg = Configuration({**env_1_args, 'random_seed': 3, 'num_products': P, 'K': 6})
+    aa = {'num_products': P, 'with_ps_all': False, **agent_args}
+    if kind == 'random':
+        agent = RandomAgent(Configuration(aa))
+        meta = dict(agent='random', agent_args=aa)
+    else:
+        agent = OrganicUserEventCounterAgent(Configuration({**gu.OUC_DEFAULTS, **aa,
+                                                             'weight_history_function': None}))
+        meta = dict(agent='ouc', agent_args=aa)
+    pol = gu.policy_args(meta)
+    assert device_policy_of(agent)['policy'] == pol['policy']
+    env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol)
+    n_checked = 0
+    for user in range(40):
+        env.reset(user)
+        agent.reset()
+        rows, reward, done = env.step(None)
+        while True:
+            sess = OrganicSessions()
+            for r in rows:
+                sess.next(DefaultContext(int(r['t']), user), int(r['v']))
+            obs = Observation(DefaultContext(env.time, user), sess)
+            want_a, want_ps = env.policy_act()
+            got = agent.act(obs, reward, done)
+            assert got['a'] == want_a and got['t'] == env.time and got['u'] == user
+            assert got['ps'] == pytest.approx(want_ps, rel=1e-15)
+            n_checked += 1
+            if done:
+                break
+            rows, reward, done = env.step(got['a'])
+    assert n_checked > 1000
+
+
+def test_rows_to_dataframe_matches_reference_schema():
+    rows = np.zeros(4, dtype=ROW_DTYPE)
+    rows['u'] = [0, 0, 0, 1]; rows['t'] = [0, 1, 2, 0]; rows['z'] = [0, 1, 1, 0]
+    rows['v'] = [3, -1, -1, 9]; rows['a'] = [-1, 4, 2, -1]; rows['c'] = [-1, 1, 0, -1]
+    rows['ps'] = [np.nan, 0.1, 0.1, np.nan]
+    df = rows_to_dataframe(rows, 10)
+    assert list(df.columns) == ['t', 'u', 'z', 'v', 'a', 'c', 'ps', 'ps-a']
+    assert str(df['t'].dtype) == 'float32' and str(df['c'].dtype) == 'float32'
+    assert str(df['u'].dtype) == 'UInt16' and str(df['v'].dtype) == 'UInt16'
+    assert str(df['a'].dtype) == 'UInt16' and str(df['ps'].dtype) == 'float64'
+    assert list(df['z']) == ['organic', 'bandit', 'bandit', 'organic']
+    assert df['v'].isna().tolist() == [False, True, True, False]
+    assert df['a'].isna().tolist() == [True, False, False, True]
+    assert np.isnan(df['c'][0]) and df['c'][1] == 1.0
+    assert df['ps-a'][0] is None and df['ps-a'][1] == ()
+    # the reference's CTR reduction works on it unchanged (bench_agents.py:204-206)
+    rewards = df[~np.isnan(df['a'])]['c'] if False else df[df['z'] == 'bandit']['c']
+    assert rewards.sum() == 1 and rewards.shape[0] == 2
+    wide = rows.copy(); wide['u'] = [0, 0, 0, 70000]
+    assert str(rows_to_dataframe(wide, 100000)['u'].dtype) == 'UInt32'
+    assert str(rows_to_dataframe(wide, 100000)['v'].dtype) == 'UInt32'
+
+
+def test_shard_ranges_tile_the_users():
+    for n in (0, 1, 7, 10_000_000):
+        for ws in (1, 2, 3, 8):
+            rs = [parallel.shard_range(n, r, ws) for r in range(ws)]
+            assert rs[0][0] == 0 and sum(c for _, c in rs) == n
+            for (f0, c0), (f1, _) in zip(rs, rs[1:]):
+                assert f1 == f0 + c0
+            assert max(c for _, c in rs) - min(c for _, c in rs) <= 1
+
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'tests'))
+import torch.distributed as dist
+from oracle import oracle as orc
+from recogym_amd import _abi, bench_agents, evaluate_agent
+from recogym_amd.agents import RandomAgent
+from recogym_amd.envs.configuration import Configuration
+from recogym_amd.envs.reco_env_v1 import env_1_args
+
+class OracleBackedEnv:
+    """Stands in for RecoEnv1.simulate on a CPU-only box: same contract, oracle arithmetic.
+    (Test double only — the product has no CPU path.)"""
+    def __init__(self, cfg): self.config = cfg
+    def __deepcopy__(self, memo): return OracleBackedEnv(self.config)
+    def simulate(self, num_users, agent=None, num_organic_users=0, first_user_id=0, log=True, device=None):
+        pol = agent.device_policy()
+        env = orc.OracleEnv(self.config, rng_mode=orc.RNG_PHILOX, **pol)
+        env.generate_logs(num_users, first_user_id=first_user_id)
+        c = env.counters()
+        class S:
+            device = None
+            def close(self): pass
+        return dict(clicks=c['clicks'], bandit=c['bandit'], phantom=c['phantom'], organic=c['organic']), S()
+
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:' + sys.argv[2],
+                        rank=int(sys.argv[3]), world_size=int(sys.argv[4]))
+cfg = Configuration({**env_1_args, 'random_seed': 9, 'num_products': 30, 'K': 8})
+agent = RandomAgent(Configuration({'num_products': 30, 'random_seed': 4, 'with_ps_all': False}))
+s, f = bench_agents.evaluate_counts(OracleBackedEnv(cfg), agent, 301)
+q = bench_agents.test_agent(OracleBackedEnv(cfg), agent, 0, 301)
+df = evaluate_agent.verify_agents(OracleBackedEnv(cfg), 301, {'r': agent})
+print(json.dumps(dict(rank=dist.get_rank(), s=s, f=f, q=list(q), v=float(df['0.500'][0]))))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_counter_allreduce_equals_single_process(tmp_path):
+    """world_size 2 over gloo: each rank simulates its shard of user ids, the all-reduced
+    (successes, failures) and the Beta quantiles equal the single-process run on every rank."""
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r), '2'],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)
+             for r in range(2)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(eval(o.strip().splitlines()[-1].replace('true', 'True')))
+    # single process reference
+    cfg = Configuration({**env_1_args, 'random_seed': 9, 'num_products': 30, 'K': 8})
+    env1 = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, policy=_abi.RG_POLICY_RANDOM_AGENT,
+                         policy_seed=4)
+    env1.generate_logs(301)
+    c = env1.counters()
+    for o in outs:
+        assert o['s'] == c['clicks'] and o['f'] == c['bandit'] + c['phantom'] - c['clicks']
+    assert outs[0]['q'] == outs[1]['q'] and outs[0]['v'] == outs[1]['v'] == outs[0]['q'][0]
