@@ -93,7 +93,13 @@ struct DevSim {
     uint32_t n_chunks;        // ceil(P / 32)
     uint32_t sc_chunks;       // chunks per stored partial sum ("super-chunk")
     uint32_t n_sc;            // super-chunks (<= kMaxSC)
-    uint32_t use_mfma;
+    uint32_t use_mfma;        // 0 = float64 only, 1 = fp32 MFMA kernel, 2 = split-bf16 MFMA kernel
+    // split-bf16 kernel geometry: A row = [G1|G2|G3] (3K bf16, zero padded to 16*N1), row stride RS bytes
+    uint32_t N1, N2, N3;      // k-steps of the three MFMA groups (B = w1 / w2 / w3)
+    uint32_t RS;              // row stride of gsplit / its LDS tile, bytes ((RS/16) odd: conflict-free b128)
+    uint32_t TPB;             // products per LDS tile of the bf16 kernel
+    unsigned short* gsplit;   // [P_pad][RS/2] bf16 three-way split of fl32(Gamma log2 e), then 1,1,1 in the last 3 columns of 16*N1
+    float* mu32s;             // [P_pad] fl32(mu_o log2 e), -inf beyond P
     uint32_t ablate;          // timing experiments only (RECOGYM_ABLATE); results are wrong when non-zero
     // state (workspace)
     double* omega;            // [K][n_pad], K-major: lane-per-user accesses coalesce
@@ -124,7 +130,8 @@ struct rg_sim {
     uint32_t live_upper;      // upper bound of live users (for grid sizing)
     bool tables_set, users_reset;
     uint32_t* h_pinned;       // 4 x u32 staging for the live-count readback
-    size_t mfma_smem;
+    size_t mfma_smem, bf16_smem;
+    void (*bf16_kernel)(DevSim, uint32_t);
     bool profiling;
     std::vector<hipEvent_t> prof_events;   // 4 per profiled step: before draw, after mfma, after exact, after advance
     size_t prof_used;
@@ -151,7 +158,7 @@ struct Carve {
 
 constexpr uint32_t kMaxSC = 32;           // stored partial sums per user in the MFMA draw kernel
 
-struct Geom { uint32_t KH, KS, TP, P_pad, n_chunks, sc_chunks, n_sc; };
+struct Geom { uint32_t KH, KS, TP, P_pad, n_chunks, sc_chunks, n_sc, N1, N2, N3, RS, TPB; };
 
 Geom geom_of(const rg_config& c) {
     Geom g{};
@@ -163,17 +170,34 @@ Geom geom_of(const rg_config& c) {
     while (g.KS % 4 != 2) ++g.KS;
     g.TP = 256;
     while (g.TP > 32 && static_cast<size_t>(g.TP) * g.KS * 4 > 24 * 1024) g.TP /= 2;
-    g.P_pad = static_cast<uint32_t>(align_up(c.num_products, 256)) + 128;
+    g.P_pad = static_cast<uint32_t>(align_up(c.num_products, 256)) + 256;
     g.n_chunks = (c.num_products + 31) / 32;
-    g.n_chunks = (g.n_chunks + 1) & ~1u;            // chunks are processed in pairs (two accumulators)
+    g.n_chunks = (g.n_chunks + 3) & ~3u;            // chunks are processed in pairs of pairs
+    {   // split-bf16 classes (N1,N2,N3): smallest class with 3K <= 16 N1, 2K <= 16 N2, K <= 16 N3
+        const uint32_t cls[][3] = {{1, 1, 1}, {2, 1, 1}, {3, 2, 1}, {4, 3, 2}, {6, 4, 2}, {12, 8, 4}};
+        for (const auto& c3 : cls)
+            if (!g.N1 && 3 * c.K + 3 <= 16 * c3[0] && 2 * c.K <= 16 * c3[1] && c.K <= 16 * c3[2]) {
+                g.N1 = c3[0]; g.N2 = c3[1]; g.N3 = c3[2];
+            }
+        if (g.N1) {
+            g.RS = 32 * g.N1 + 16;
+            g.TPB = 128;
+            while (g.TPB > 64 && static_cast<size_t>(g.TPB) * g.RS > 20 * 1024) g.TPB /= 2;
+        }
+    }
     g.sc_chunks = (g.n_chunks + kMaxSC - 1) / kMaxSC;
-    g.sc_chunks = (g.sc_chunks + 1) & ~1u;
+    g.sc_chunks = (g.sc_chunks + 3) & ~3u;
     g.n_sc = (g.n_chunks + g.sc_chunks - 1) / g.sc_chunks;
     return g;
 }
 
+size_t bf16_smem_bytes(const Geom& g, uint32_t K) {
+    // double-buffered split tiles + mu tiles + the per-wave omega32 stage [4][32][K]
+    return 2 * (static_cast<size_t>(g.TPB) * g.RS + g.TPB * 4) + 4 * 32 * static_cast<size_t>(K) * 4 + 256;
+}
+
 size_t mfma_smem_bytes(const Geom& g) {
-    return sizeof(float) * 2 * (static_cast<size_t>(g.TP) * g.KS + g.TP) + 256;   // double-buffered tiles
+    return sizeof(float) * (2 * (static_cast<size_t>(g.TP) * g.KS + g.TP) + 64 + 4 * 32 * 2 * g.KH);   // tiles + omega stage
 }
 
 uint32_t hist_cap_of(const rg_config& c) {
@@ -193,6 +217,8 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     const size_t PT = align_up(P, 64);
     double* gammaT = w.take<double>(K * PT);
     float* exact_ref = w.take<float>(n);
+    unsigned short* gsplit = w.take<unsigned short>(g.N1 ? static_cast<size_t>(g.P_pad) * (g.RS / 2) : 1);
+    float* mu32s = w.take<float>(g.N1 ? g.P_pad : 1);
     float2* sc_scratch = w.take<float2>(g.KH ? static_cast<size_t>(kMaxGrid) * 4 * kMaxSC * 32 : 1);
     float* chunk_scratch = w.take<float>(g.KH ? static_cast<size_t>(kMaxGrid) * 4 * g.n_chunks * 32 : 1);
     double* omega = w.take<double>(K * n_pad);
@@ -212,6 +238,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     if (d) {
         d->gamma32 = gamma32; d->mu32 = mu32; d->stats = stats; d->omega = omega; d->list = list;
         d->gammaT = gammaT; d->PT = static_cast<uint32_t>(PT); d->exact_ref = exact_ref; d->sc_scratch = sc_scratch; d->chunk_scratch = chunk_scratch;
+        d->gsplit = gsplit; d->mu32s = mu32s; d->N1 = g.N1; d->N2 = g.N2; d->N3 = g.N3; d->RS = g.RS; d->TPB = g.TPB;
         d->KH = g.KH; d->KS = g.KS; d->TP = g.TP; d->P_pad = g.P_pad; d->n_chunks = g.n_chunks;
         d->sc_chunks = g.sc_chunks; d->n_sc = g.n_sc; d->use_mfma = g.KH ? 1u : 0u;
         d->step_cnt = step_cnt; d->log_base = log_base; d->exact_list = exact_list;
@@ -229,7 +256,7 @@ int validate(const rg_config* c, uint64_t n) {
     if (c->num_products == 0 || c->num_products > RG_EV_INDEX_MASK)
         return fail(RG_EINVAL, "num_products %u out of range [1, 2^29)", c->num_products);
     if (c->K == 0 || c->K > 1024) return fail(RG_EINVAL, "K %u out of range [1, 1024]", c->K);
-    if (sizeof(double) * (c->K + (c->num_products + 63) / 64 + 1) * (kBlock / 64) > 64 * 1024)
+    if (sizeof(double) * (static_cast<size_t>(c->K) * 64 + 64 + 16 * c->K + 16 * ((c->num_products + 63) / 64 + 1)) > 150 * 1024)
         return fail(RG_EINVAL, "num_products %u / K %u exceed the float64 draw kernel's LDS budget",
                     c->num_products, c->K);
     if (n == 0 || n >= (1ull << 31)) return fail(RG_EINVAL, "n_users %llu out of range", (unsigned long long)n);
@@ -308,6 +335,44 @@ __global__ void __launch_bounds__(kBlock) k_make_fp32_tables(DevSim d) {
         const size_t p = i / d.KS, k = i % d.KS;
         d.gamma32[i] = (p < d.P && k < d.K) ? static_cast<float>(d.gamma[p * d.K + k]) : 0.0f;
         if (i < d.P_pad) d.mu32[i] = i < d.P ? static_cast<float>(d.mu_o[i]) : -INFINITY;
+    }
+}
+
+__device__ __forceinline__ unsigned short bf16_rne(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return static_cast<unsigned short>(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short hbits) {
+    return __builtin_bit_cast(float, static_cast<unsigned>(hbits) << 16);
+}
+// x = s[0] + s[1] + s[2] up to ~2^-25 |x|: three bf16 pieces, 8 significant bits each
+__device__ __forceinline__ void bf16_split3(float x, unsigned short* sp) {
+    sp[0] = bf16_rne(x);
+    float r = x - bf16_to_f32(sp[0]);
+    sp[1] = bf16_rne(r);
+    r -= bf16_to_f32(sp[1]);
+    sp[2] = bf16_rne(r);
+}
+
+// gsplit[p] = [G1(K) | G2(K) | G3(K) | 0 ... 0 | 1 1 1] (bf16), the A operand rows of the split-bf16
+// kernel, G = fl32(Gamma log2 e): the MFMA then yields logits in log2 units, and the three ones
+// multiply the three bf16 pieces of -reference that sit in the user's B row.
+__global__ void __launch_bounds__(kBlock) k_make_split_table(DevSim d) {
+    const size_t rs2 = d.RS / 2;
+    const size_t n = static_cast<size_t>(d.P_pad) * rs2;
+    const double log2e = 1.4426950408889634074;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const size_t p = i / rs2, ke = i % rs2;
+        unsigned short v = 0;
+        if (p < d.P && ke < 3 * static_cast<size_t>(d.K)) {
+            unsigned short sp[3];
+            bf16_split3(static_cast<float>(d.gamma[p * d.K + ke % d.K] * log2e), sp);
+            v = sp[ke / d.K];
+        } else if (ke >= 16u * d.N1 - 3 && ke < 16u * d.N1) v = 0x3F80;   // bf16(1.0)
+        d.gsplit[i] = v;
+        if (i < d.P_pad) d.mu32s[i] = i < d.P ? static_cast<float>(d.mu_o[i] * log2e) : -INFINITY;
     }
 }
 
@@ -541,81 +606,126 @@ __device__ __forceinline__ void logit64x4(const DevSim& d, const double* om, uin
     for (int u = 0; u < 4; ++u) out[u] = (p + 64u * u < d.P) ? out[u] + d.mu_o[p + 64u * u] : -INFINITY;
 }
 
+// One block = up to kExactUsers users (2 per wave) that share float64 Gamma^T tiles staged in
+// LDS — read once per block instead of once per user (the table is P*K*8 bytes; unshared, the
+// float64 kernel was L2-bandwidth-bound).  Per 64-product chunk a lane holds its product's K
+// Gamma values in registers and dots them with each of its wave's users' omega (LDS broadcast).
+constexpr int kUPW = 4;                      // users per wave
+constexpr int kExactUsers = 4 * kUPW;        // users per block
+
 __global__ void __launch_bounds__(kBlock) k_draw_exact(DevSim d, uint32_t t, int from_list) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t n_chunks = (d.P + 63) / 64;
-    double* om = reinterpret_cast<double*>(smem_raw) + static_cast<size_t>(wave) * (d.K + n_chunks + 1);
-    double* chunk_prefix = om + d.K;     // exclusive running sum at the start of each 64-product chunk
+    // LDS: Gamma^T tile [K][64] doubles, mu tile [64], omega [users][K], chunk prefix [users][n_chunks+1]
+    double* g_tile = reinterpret_cast<double*>(smem_raw);
+    double* mu_tile = g_tile + static_cast<size_t>(d.K) * 64;
+    double* om_all = mu_tile + 64;
+    double* prefix_all = om_all + static_cast<size_t>(kExactUsers) * d.K;
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
     const uint32_t n = from_list ? d.exact_cnt[t] : n_o;
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
-    const uint32_t waves_total = gridDim.x * (kBlock / 64);
-    for (uint32_t w = blockIdx.x * (kBlock / 64) + wave; w < n; w += waves_total) {
-        const uint32_t pos = from_list ? d.exact_list[w] : w;
-        const uint32_t slot = cur[pos];
-        const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
-        for (uint32_t k = lane; k < d.K; k += 64) om[k] = d.omega[static_cast<size_t>(k) * d.n_pad + slot];
-        __builtin_amdgcn_wave_barrier();
-        // pass 1: max logit (reco_env_v1.py:121).  Any shift gives the same float64 decision up
-        // to 1e-16, so a draw handed over by the MFMA kernel reuses that kernel's reference.
-        double M;
-        if (from_list) M = static_cast<double>(d.exact_ref[w]) * 0.69314718055994530942;
-        else {
-            double m = -INFINITY;
-            for (uint32_t c = 0; c < n_chunks; c += 4) {
-                double l4[4];
-                logit64x4(d, om, c * 64 + lane, l4);
-                m = fmax(fmax(m, fmax(l4[0], l4[1])), fmax(l4[2], l4[3]));
-            }
-            M = wave_max(m);
-        }
-        // pass 2: running sum of exp(l - max) in product order, remembered per 64-product chunk.
-        // The reference normalises p = e / sum(e) before its cumsum and divides by cdf[-1];
-        // dividing every term by the same positive constants moves the decision only at the
-        // 1e-16 level, so the running sum of e is compared with u * total directly.
-        double run = 0.0;
-        for (uint32_t c = 0; c < n_chunks; c += 4) {
-            double l4[4];
-            logit64x4(d, om, c * 64 + lane, l4);
+    const uint32_t n_groups = (n + kExactUsers - 1) / kExactUsers;
+
+    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        uint32_t w_idx[kUPW], pos[kUPW], slot[kUPW], user[kUPW];
+        bool act[kUPW];
+        double M[kUPW], run[kUPW];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (c + u < n_chunks) {
-                    const double e = exp(l4[u] - M);        // exp(-inf) == 0 for products >= P
-                    if (lane == 0) chunk_prefix[c + u] = run;
-                    run += __shfl(wave_scan(e, lane), 63);
+        for (int u = 0; u < kUPW; ++u) {
+            w_idx[u] = grp * kExactUsers + wave * kUPW + u;
+            act[u] = w_idx[u] < n;
+            pos[u] = act[u] ? (from_list ? d.exact_list[w_idx[u]] : w_idx[u]) : 0u;
+            slot[u] = act[u] ? cur[pos[u]] : 0u;
+            user[u] = static_cast<uint32_t>(d.first_user + slot[u]);
+            run[u] = 0.0;
+            // a draw handed over by the MFMA kernel reuses that kernel's reference: any shift
+            // gives the same float64 decision up to 1e-16
+            M[u] = (from_list && act[u]) ? static_cast<double>(d.exact_ref[w_idx[u]]) * 0.69314718055994530942 : 0.0;
+        }
+        __syncthreads();      // previous group's LDS is free
+        double* om = om_all + static_cast<size_t>(wave * kUPW) * d.K;
+        double* pre = prefix_all + static_cast<size_t>(wave * kUPW) * (n_chunks + 1);
+#pragma unroll
+        for (int u = 0; u < kUPW; ++u)
+            for (uint32_t k = lane; k < d.K; k += 64)
+                om[u * d.K + k] = act[u] ? d.omega[static_cast<size_t>(k) * d.n_pad + slot[u]] : 0.0;
+
+        // sweeps over the products: mode 0 = max logit (reco_env_v1.py:121; skipped with a
+        // handed-over reference), mode 1 = running exp-sums per 64-product chunk
+        for (int mode = from_list ? 1 : 0; mode < 2; ++mode) {
+            double mx[kUPW];
+#pragma unroll
+            for (int u = 0; u < kUPW; ++u) mx[u] = -INFINITY;
+            for (uint32_t c = 0; c < n_chunks; ++c) {
+                __syncthreads();
+                // stage Gamma^T[:, c*64 .. c*64+63] and mu (coalesced: 64 consecutive doubles per k)
+                for (uint32_t i = threadIdx.x; i < d.K * 64; i += kBlock) {
+                    const uint32_t k = i >> 6, pp = i & 63;
+                    g_tile[i] = d.gammaT[static_cast<size_t>(k) * d.PT + c * 64 + pp];
+                }
+                if (threadIdx.x < 64) {
+                    const uint32_t p = c * 64 + threadIdx.x;
+                    mu_tile[threadIdx.x] = p < d.P ? d.mu_o[p] : -INFINITY;
+                }
+                __syncthreads();
+                // same association as the oracle / numpy: (sum_k Gamma[p][k] omega[k]) + mu[p]
+                double l[kUPW];
+#pragma unroll
+                for (int u = 0; u < kUPW; ++u) l[u] = 0.0;
+#pragma unroll 4
+                for (uint32_t k = 0; k < d.K; ++k) {
+                    const double g = g_tile[k * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < kUPW; ++u) l[u] += g * om[u * d.K + k];
+                }
+                const double mu = mu_tile[lane];        // -inf for products >= P: exp() gives exactly 0
+#pragma unroll
+                for (int u = 0; u < kUPW; ++u) {
+                    l[u] += mu;
+                    if (mode == 0) mx[u] = fmax(mx[u], l[u]);
+                    else {
+                        if (lane == 0) pre[u * (n_chunks + 1) + c] = run[u];
+                        run[u] += __shfl(wave_scan(exp(l[u] - M[u]), lane), 63);
+                    }
                 }
             }
+#pragma unroll
+            for (int u = 0; u < kUPW; ++u) {
+                if (mode == 0) M[u] = wave_max(mx[u]);
+                else if (lane == 0) pre[u * (n_chunks + 1) + n_chunks] = run[u];
+            }
         }
-        if (lane == 0) chunk_prefix[n_chunks] = run;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        const rg_u32x4 rw = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
-        const double target = rg_uniform(rw.w[0], rw.w[1]) * run;
-        // first chunk whose inclusive running sum exceeds the target
-        uint32_t cstar = n_chunks - 1;
-        for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64) {
-            const uint32_t c = c0 + lane;
-            const unsigned long long hit = __ballot(c < n_chunks && chunk_prefix[c + 1] > target);
-            if (hit) { cstar = c0 + static_cast<uint32_t>(__builtin_ctzll(hit)); break; }
-        }
-        // recompute that chunk (same code, same values) and find the product inside it
-        uint32_t v = d.P - 1;
-        {
-            const uint32_t cg = cstar & ~3u;              // the group of four the chunk was computed in
-            double l4[4];
-            logit64x4(d, om, cg * 64 + lane, l4);
-            const double l = l4[cstar & 3u];
+        // locate the chunk per user, then recompute it from global memory (once per user)
+#pragma unroll
+        for (int u = 0; u < kUPW; ++u) {
+            if (!act[u]) continue;
+            const double* omu = om + u * d.K;
+            const double* preu = pre + u * (n_chunks + 1);
+            const rg_u32x4 rw = rg_draw(d.seed, user[u], t, 0, RG_DRAW_EVENT);
+            const double target = rg_uniform(rw.w[0], rw.w[1]) * run[u];
+            uint32_t cstar = n_chunks - 1;
+            for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64) {
+                const uint32_t c = c0 + lane;
+                const unsigned long long hit = __ballot(c < n_chunks && preu[c + 1] > target);
+                if (hit) { cstar = c0 + static_cast<uint32_t>(__builtin_ctzll(hit)); break; }
+            }
+            uint32_t v = d.P - 1;
             const uint32_t p = cstar * 64 + lane;
-            const double e = exp(l - M);
-            const double x = chunk_prefix[cstar] + wave_scan(e, lane);
+            double lg = 0.0;
+            const double* g = d.gammaT + min(p, d.PT - 1);
+            for (uint32_t k = 0; k < d.K; ++k) lg += g[static_cast<size_t>(k) * d.PT] * omu[k];
+            lg = p < d.P ? lg + d.mu_o[p] : -INFINITY;
+            const double x = preu[cstar] + wave_scan(exp(lg - M[u]), lane);
             const unsigned long long hit = __ballot(p < d.P && x > target);
             if (hit) v = cstar * 64 + static_cast<uint32_t>(__builtin_ctzll(hit));
+            if (lane == 0) {
+                write_organic_row(d, t, pos[u], user[u], v);
+                if (d.hist_cap) history_add(d, slot[u], v);
+            }
         }
-        if (lane == 0) {
-            write_organic_row(d, t, pos, user, v);
-            if (d.hist_cap) history_add(d, slot, v);
-        }
-        __builtin_amdgcn_wave_barrier();
     }
     if (from_list == 1 && blockIdx.x == 0 && threadIdx.x == 0)
         atomicAdd(&d.counters[RG_CNT_EXACT_DRAWS], static_cast<unsigned long long>(n));
@@ -670,7 +780,134 @@ __device__ __forceinline__ void glds_copy(const char* src, char* dst_lds, uint32
 }
 
 // exchange a value between lane l and lane l ^ 32 (the two lanes that share a user)
-__device__ __forceinline__ float swap32(float x) { return __shfl_xor(x, 32); }
+__device__ __forceinline__ float swap32(float x) {
+    // v_permlane32_swap_b32 (gfx950): with both operands = x, r[0] = {lo, lo}, r[1] = {hi, hi}
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+
+// ------------------------------------------------------------------------------------------
+// Shared tail of the two MFMA draw kernels: given the per-chunk / per-super-chunk exp-sums a
+// wave left in its scratch, pick super-chunk -> chunk -> product for each of its 32 users,
+// certify the pick against float64 (see the header of k_draw_mfma) and emit the row or hand
+// the user to k_draw_exact.  `om` = this lane's user's omega32 vector in LDS (2*KH floats).
+// ------------------------------------------------------------------------------------------
+template <int KH>
+__device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, const float2* scr,
+                                                const float* scr_chunk, const float* om_lds,
+                                                float Ahat, int n_resc, bool active, uint32_t pos,
+                                                uint32_t slot, int j, int h) {
+        n_resc = max(n_resc, __shfl_xor(n_resc, 32));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // scratch: written by lanes < 32, read below
+
+        // ---- search, part 1 (lane per user; lanes >= 32 mirror): total, target, super-chunk, chunk ----
+        const float Q = scr[(d.n_sc - 1) * 32 + j].y;          // references only grow: the last is the max
+        double S = 0.0;
+        for (uint32_t sc = 0; sc < d.n_sc; ++sc) {
+            const float2 wq = scr[sc * 32 + j];
+            S += static_cast<double>(wq.x * __builtin_amdgcn_exp2f(wq.y - Q));
+        }
+        const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
+        const rg_u32x4 rw = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
+        const double tau = rg_uniform(rw.w[0], rw.w[1]) * S;
+        double pb = 0.0;
+        uint32_t sc_star = d.n_sc - 1;
+        float f_star = 1.0f;
+        bool found_sc = false;
+        {
+            double run = 0.0;
+            for (uint32_t sc = 0; sc < d.n_sc; ++sc) {
+                const float2 wq = scr[sc * 32 + j];
+                const float f = __builtin_amdgcn_exp2f(wq.y - Q);
+                const double Wd = static_cast<double>(wq.x * f);
+                if (!found_sc && run + Wd > tau) { found_sc = true; sc_star = sc; pb = run; f_star = f; }
+                if (!found_sc) run += Wd;
+            }
+        }
+        // chunk inside the super-chunk (its chunk sums share the super-chunk's reference)
+        uint32_t c_star = 0;
+        bool found_c = false;
+        {
+            const uint32_t c0 = sc_star * d.sc_chunks, c1 = min(c0 + d.sc_chunks, d.n_chunks);
+            double run = pb;
+            for (uint32_t c = c0; c < c1; ++c) {
+                const double Wd = static_cast<double>(scr_chunk[c * 32 + j] * f_star);
+                if (!found_c && run + Wd > tau) { found_c = true; c_star = c; pb = run; }
+                if (!found_c) run += Wd;
+            }
+        }
+        found_c = found_c && found_sc;
+        const double delta = static_cast<double>(d.K + 5) * 5.9604644775390625e-08 * static_cast<double>(Ahat) +
+                             kDeltaFixed + kDeltaPerRescale * n_resc;
+
+        // ---- search, part 2: recompute the 32 products of chunk c_star, 16 per lane, in registers ----
+        uint32_t my_v = 0;
+        bool my_ok = false;
+        if (!(d.ablate & 1u)) {
+            float om[2 * KH];
+#pragma unroll
+            for (int k = 0; k < 2 * KH; ++k) om[k] = om_lds[k];
+            const uint32_t p_first = c_star * 32 + 16 * h;        // < P_pad by construction
+            float pre[16];
+            float runf = 0.0f;
+#pragma unroll
+            for (int i2 = 0; i2 < 8; ++i2) {
+                // two rows = 2*KS floats, KS == 2 mod 4 -> a whole number of aligned float4
+                const float4* rp = reinterpret_cast<const float4*>(d.gamma32 + static_cast<size_t>(p_first + 2 * i2) * d.KS);
+                float rowpair[2 * (2 * KH + 2)];
+                constexpr int KSc = 2 * KH + 2;
+#pragma unroll
+                for (int v4 = 0; v4 < KSc / 2; ++v4) {
+                    const float4 x = rp[v4];
+                    rowpair[4 * v4 + 0] = x.x; rowpair[4 * v4 + 1] = x.y; rowpair[4 * v4 + 2] = x.z; rowpair[4 * v4 + 3] = x.w;
+                }
+                const float2 mu2 = *reinterpret_cast<const float2*>(d.mu32 + p_first + 2 * i2);
+                float l0 = mu2.x, l1 = mu2.y;
+#pragma unroll
+                for (int k = 0; k < 2 * KH; ++k) {
+                    l0 = fmaf(rowpair[k], om[k], l0);
+                    l1 = fmaf(rowpair[KSc + k], om[k], l1);
+                }
+                runf += __builtin_amdgcn_exp2f(fmaf(l0, kLog2e, -Q));
+                pre[2 * i2] = runf;
+                runf += __builtin_amdgcn_exp2f(fmaf(l1, kLog2e, -Q));
+                pre[2 * i2 + 1] = runf;
+            }
+            // prefix of lane h=1 starts after lane h=0's 16 products
+            const float t0 = swap32(runf);
+            const double base = pb + (h ? static_cast<double>(t0) : 0.0);
+            int idx = -1;
+            double A = base, B = base;
+#pragma unroll
+            for (int i = 15; i >= 0; --i) {
+                const double px = base + static_cast<double>(pre[i]);
+                if (px > tau) { idx = i; B = px; A = i ? base + static_cast<double>(pre[i - 1]) : base; }
+            }
+            // the user's answer is lane h=0's hit if it has one, else lane h=1's
+            const int idx_o = __shfl_xor(idx, 32);
+            const double A_o = __shfl_xor(A, 32), B_o = __shfl_xor(B, 32);
+            int vi; double Av, Bv;
+            if (h == 0) { if (idx >= 0) { vi = idx; Av = A; Bv = B; } else { vi = idx_o >= 0 ? 16 + idx_o : -1; Av = A_o; Bv = B_o; } }
+            else        { if (idx_o >= 0) { vi = idx_o; Av = A_o; Bv = B_o; } else { vi = idx >= 0 ? 16 + idx : -1; Av = A; Bv = B; } }
+            const uint32_t v = c_star * 32 + static_cast<uint32_t>(max(vi, 0));
+            my_v = v;
+            my_ok = found_c && vi >= 0 && v < d.P &&
+                    (v == 0 || Av * (1.0 + delta) < tau * (1.0 - delta)) &&
+                    (v == d.P - 1 || tau * (1.0 + delta) < Bv * (1.0 - delta));
+        } else { my_v = static_cast<uint32_t>(S) % d.P; my_ok = true; }
+        // ---- emit (lane per user) ----
+        if (active && h == 0) {
+            if (my_ok) {
+                write_organic_row(d, t, pos, user, my_v);
+                if (d.hist_cap) history_add(d, slot, my_v);
+            } else {
+                const uint32_t xi = atomicAdd(&d.exact_cnt[t], 1u);
+                d.exact_list[xi] = pos;
+                d.exact_ref[xi] = Q;
+            }
+        }
+}
 
 template <int KH>
 __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_draw_mfma(DevSim d, uint32_t t) {
@@ -678,6 +915,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_draw_mfma(DevSim
     const uint32_t tile_f = d.TP * d.KS;                              // floats per Gamma tile
     float* g_buf = reinterpret_cast<float*>(smem_raw);                // [2][TP][KS]
     float* mu_buf = g_buf + 2 * tile_f;                               // [2][TP] (+ pad)
+    float* om_stage = mu_buf + 2 * d.TP + 64;                         // [4 waves][32 users][2KH] omega32
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int j = lane & 31, h = lane >> 5;
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
@@ -705,6 +943,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_draw_mfma(DevSim
             float w = 0.0f;
             if (active && k < d.K) w = static_cast<float>(d.omega[static_cast<size_t>(k) * d.n_pad + slot]);
             b[s] = w;
+            om_stage[(wave * 32 + j) * 2 * KH + k] = w;
             absdot = fmaf(fabsf(w), d.stats[k], absdot);
             sq = fmaf(w, w, sq);
         }
@@ -809,121 +1048,222 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_draw_mfma(DevSim
         softmax_chunk(acc_p0, ci_p);           // drain the pipeline
         softmax_chunk(acc_p1, ci_p + 1);
         flush_sc(ci_p);
-        n_resc = max(n_resc, __shfl_xor(n_resc, 32));
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // scratch: written by lanes < 32, read below
-
-        // ---- search, part 1 (lane per user; lanes >= 32 mirror): total, target, super-chunk, chunk ----
-        const float Q = scr[(d.n_sc - 1) * 32 + j].y;          // references only grow: the last is the max
-        double S = 0.0;
-        for (uint32_t sc = 0; sc < d.n_sc; ++sc) {
-            const float2 wq = scr[sc * 32 + j];
-            S += static_cast<double>(wq.x * __builtin_amdgcn_exp2f(wq.y - Q));
-        }
-        const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
-        const rg_u32x4 rw = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
-        const double tau = rg_uniform(rw.w[0], rw.w[1]) * S;
-        double pb = 0.0;
-        uint32_t sc_star = d.n_sc - 1;
-        float f_star = 1.0f;
-        bool found_sc = false;
-        {
-            double run = 0.0;
-            for (uint32_t sc = 0; sc < d.n_sc; ++sc) {
-                const float2 wq = scr[sc * 32 + j];
-                const float f = __builtin_amdgcn_exp2f(wq.y - Q);
-                const double Wd = static_cast<double>(wq.x * f);
-                if (!found_sc && run + Wd > tau) { found_sc = true; sc_star = sc; pb = run; f_star = f; }
-                if (!found_sc) run += Wd;
-            }
-        }
-        // chunk inside the super-chunk (its chunk sums share the super-chunk's reference)
-        uint32_t c_star = 0;
-        bool found_c = false;
-        {
-            const uint32_t c0 = sc_star * d.sc_chunks, c1 = min(c0 + d.sc_chunks, d.n_chunks);
-            double run = pb;
-            for (uint32_t c = c0; c < c1; ++c) {
-                const double Wd = static_cast<double>(scr_chunk[c * 32 + j] * f_star);
-                if (!found_c && run + Wd > tau) { found_c = true; c_star = c; pb = run; }
-                if (!found_c) run += Wd;
-            }
-        }
-        found_c = found_c && found_sc;
-        const double delta = static_cast<double>(d.K + 3) * 5.9604644775390625e-08 * static_cast<double>(Ahat) +
-                             kDeltaFixed + kDeltaPerRescale * n_resc;
-
-        // ---- search, part 2: recompute the 32 products of chunk c_star, 16 per lane, in registers ----
-        uint32_t my_v = 0;
-        bool my_ok = false;
-        if (!(d.ablate & 1u)) {
-            // this lane's view of the whole omega32 vector of its user
-            float om[2 * KH];
-#pragma unroll
-            for (int s = 0; s < KH; ++s) {
-                const float o = swap32(b[s]);
-                om[s] = h ? o : b[s];
-                om[KH + s] = h ? b[s] : o;
-            }
-            const uint32_t p_first = c_star * 32 + 16 * h;        // < P_pad by construction
-            float pre[16];
-            float runf = 0.0f;
-#pragma unroll
-            for (int i2 = 0; i2 < 8; ++i2) {
-                // two rows = 2*KS floats, KS == 2 mod 4 -> a whole number of aligned float4
-                const float4* rp = reinterpret_cast<const float4*>(d.gamma32 + static_cast<size_t>(p_first + 2 * i2) * d.KS);
-                float rowpair[2 * (2 * KH + 2)];
-                constexpr int KSc = 2 * KH + 2;
-#pragma unroll
-                for (int v4 = 0; v4 < KSc / 2; ++v4) {
-                    const float4 x = rp[v4];
-                    rowpair[4 * v4 + 0] = x.x; rowpair[4 * v4 + 1] = x.y; rowpair[4 * v4 + 2] = x.z; rowpair[4 * v4 + 3] = x.w;
-                }
-                const float2 mu2 = *reinterpret_cast<const float2*>(d.mu32 + p_first + 2 * i2);
-                float l0 = mu2.x, l1 = mu2.y;
-#pragma unroll
-                for (int k = 0; k < 2 * KH; ++k) {
-                    l0 = fmaf(rowpair[k], om[k], l0);
-                    l1 = fmaf(rowpair[KSc + k], om[k], l1);
-                }
-                runf += __builtin_amdgcn_exp2f(fmaf(l0, kLog2e, -Q));
-                pre[2 * i2] = runf;
-                runf += __builtin_amdgcn_exp2f(fmaf(l1, kLog2e, -Q));
-                pre[2 * i2 + 1] = runf;
-            }
-            // prefix of lane h=1 starts after lane h=0's 16 products
-            const float t0 = swap32(runf);
-            const double base = pb + (h ? static_cast<double>(t0) : 0.0);
-            int idx = -1;
-            double A = base, B = base;
-#pragma unroll
-            for (int i = 15; i >= 0; --i) {
-                const double px = base + static_cast<double>(pre[i]);
-                if (px > tau) { idx = i; B = px; A = i ? base + static_cast<double>(pre[i - 1]) : base; }
-            }
-            // the user's answer is lane h=0's hit if it has one, else lane h=1's
-            const int idx_o = __shfl_xor(idx, 32);
-            const double A_o = __shfl_xor(A, 32), B_o = __shfl_xor(B, 32);
-            int vi; double Av, Bv;
-            if (h == 0) { if (idx >= 0) { vi = idx; Av = A; Bv = B; } else { vi = idx_o >= 0 ? 16 + idx_o : -1; Av = A_o; Bv = B_o; } }
-            else        { if (idx_o >= 0) { vi = idx_o; Av = A_o; Bv = B_o; } else { vi = idx >= 0 ? 16 + idx : -1; Av = A; Bv = B; } }
-            const uint32_t v = c_star * 32 + static_cast<uint32_t>(max(vi, 0));
-            my_v = v;
-            my_ok = found_c && vi >= 0 && v < d.P &&
-                    (v == 0 || Av * (1.0 + delta) < tau * (1.0 - delta)) &&
-                    (v == d.P - 1 || tau * (1.0 + delta) < Bv * (1.0 - delta));
-        } else { my_v = static_cast<uint32_t>(S) % d.P; my_ok = true; }
-        // ---- emit (lane per user) ----
-        if (active && h == 0) {
-            if (my_ok) {
-                write_organic_row(d, t, pos, user, my_v);
-                if (d.hist_cap) history_add(d, slot, my_v);
-            } else {
-                const uint32_t xi = atomicAdd(&d.exact_cnt[t], 1u);
-                d.exact_list[xi] = pos;
-                d.exact_ref[xi] = Q;
-            }
-        }
+        search_and_emit<KH>(d, t, scr, scr_chunk, om_stage + (wave * 32 + j) * 2 * KH, Ahat, n_resc,
+                            active, pos, slot, j, h);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_draw_bf16 — the same draw on the bf16 matrix cores with fp32-class accuracy.
+//
+// Measured on gfx950 (tools/ubench/mfma_coexec.hip, profiles/r1): the f32-input MFMA executes on
+// the vector ALU's datapath — its time and the exp-sum's VALU time ADD — while bf16 MFMA runs on
+// the separate matrix pipe and overlaps VALU work.  So the logit contraction is moved to bf16
+// MFMA without giving up fp32 accuracy: every fp32 operand is split into three bf16 pieces
+// (x = x1 + x2 + x3 up to 2^-25 |x|, 8 significant bits each) and the six cross terms with
+// i + j <= 4 are accumulated in the MFMA's fp32 accumulator (the dropped ones are <= 2^-23 |x y|):
+//     l = mu + G1 w1 + G2 w1 + G3 w1 + G1 w2 + G2 w2 + G1 w3
+// as three MFMA groups that SHARE the A fragments: A row = [G1 | G2 | G3] (3K bf16, zero padded),
+//     group 1: B = [w1 | w1 | w1]   (N1 k-steps of 16)
+//     group 2: B = [w2 | w2 | 0 ]   (N2 k-steps; the zeros of B mask the A columns beyond 2K)
+//     group 3: B = [w3 | 0  | 0 ]   (N3 k-steps)
+// K = 20: 9 x v_mfma_f32_32x32x16_bf16 (~32 cycles each, overlapping the exp-sum) instead of
+// 10 x v_mfma_f32_32x32x2_f32 (64 cycles each, serial with it).  Measured error vs float64:
+// <= 4.2 x 2^-24 x sum|terms| (profiles/r1/ubench_bf16_split_accuracy.txt), inside the same
+// (K+3) x 2^-24 budget of the certificate; everything after the logits is shared with
+// k_draw_mfma (exp-sums, scratch, search, certificate, float64 fallback).
+// ------------------------------------------------------------------------------------------
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+
+template <int KH, int N1, int N2, int N3>
+__global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 2 : 1)) k_draw_bf16(DevSim d, uint32_t t) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const uint32_t tile_b = d.TPB * d.RS;                             // bytes per split tile
+    char* g_buf = smem_raw;                                           // [2][TPB][RS]
+    float* mu_buf = reinterpret_cast<float*>(g_buf + 2 * tile_b);     // [2][TPB] (+ pad)
+    float* om_stage = mu_buf + 2 * d.TPB + 64;                        // [4 waves][32 users][2KH] omega32
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const uint32_t n_tiles = (n_o + 127) / 128;
+    const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const float mumax = d.stats[2 * KH + 1], g2max = d.stats[2 * KH];
+    const uint32_t cpt = d.TPB / 32;                                  // chunks per LDS tile (multiple of 4)
+    const uint32_t n_ptiles = (d.n_chunks + cpt - 1) / cpt;
+    const size_t wslot = static_cast<size_t>(blockIdx.x) * 4 + wave;
+    float* scr_chunk = d.chunk_scratch + wslot * d.n_chunks * 32;
+    float2* scr = d.sc_scratch + wslot * kMaxSC * 32;
+    float* omu = om_stage + (wave * 32 + j) * 2 * KH;                 // this lane's user's omega32
+
+    for (uint32_t tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {
+        const uint32_t pos = tb * 128 + wave * 32 + j;
+        const bool active = pos < n_o;
+        const uint32_t slot = active ? cur[pos] : 0u;
+        __syncthreads();           // every wave is done with the LDS buffers and stage (previous user tile)
+        glds_copy(reinterpret_cast<const char*>(d.gsplit), g_buf, tile_b, wave, lane);
+        if (wave == 3) glds_copy(reinterpret_cast<const char*>(d.mu32s), reinterpret_cast<char*>(mu_buf), d.TPB * 4, 0, lane);
+        // ---- omega32 of the user -> LDS stage (also the logit error bound) ----
+        float absdot = 0.0f, sq = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KH; ++s) {
+            const uint32_t k = h * KH + s;
+            float w = 0.0f;
+            if (active && k < d.K) w = static_cast<float>(d.omega[static_cast<size_t>(k) * d.n_pad + slot]);
+            omu[k] = w;
+            absdot = fmaf(fabsf(w), d.stats[k], absdot);
+            sq = fmaf(w, w, sq);
+        }
+        absdot += swap32(absdot);
+        sq += swap32(sq);
+        const float Ahat = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // ---- B fragments: lane (j, h) holds elements ke = 16 s + 8 h + e of its user's B rows ----
+        bf16x8 B1[N1], B2[N2], B3[N3];
+        {
+            const uint32_t K = d.K;
+#pragma unroll
+            for (int s = 0; s < N1; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t ke = 16 * s + 8 * h + e;
+                    unsigned short sp[3] = {0, 0, 0};
+                    if (ke < 3 * K) bf16_split3(omu[ke % K], sp);
+                    B1[s][e] = static_cast<short>(sp[0]);
+                    if (s < N2) B2[s < N2 ? s : 0][e] = static_cast<short>(ke < 2 * K ? sp[1] : 0);
+                    if (s < N3) B3[s < N3 ? s : 0][e] = static_cast<short>(ke < K ? sp[2] : 0);
+                }
+        }
+        // the reference rides in the MFMA: columns 16 N1 - 3 .. 16 N1 - 1 of A are 1, the matching
+        // B elements (lanes h == 1, elements 5..7 of the last k-step) hold the 3 bf16 pieces of -q
+        float q = 0.0f;            // per-USER reference in log2 units, constant within a super-chunk
+        auto set_reference = [&](float qn) {
+            q = qn;
+            unsigned short sp[3];
+            bf16_split3(-qn, sp);
+            if (h == 1) {
+                B1[N1 - 1][5] = static_cast<short>(sp[0]);
+                B1[N1 - 1][6] = static_cast<short>(sp[1]);
+                B1[N1 - 1][7] = static_cast<short>(sp[2]);
+            }
+        };
+
+        double s_sc = 0.0;         // running exp-sum of the current super-chunk
+        float wcmax = 0.0f;        // largest chunk sum of the current super-chunk
+        int n_resc = 0;
+
+        // logits (log2 units, reference already subtracted) of one chunk pair
+        auto mfma_pair = [&](const char* g_tile, const float* mu_tile, uint32_t c, f32x16& acc0, f32x16& acc1) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const float4 m0 = *reinterpret_cast<const float4*>(mu_tile + c * 32 + 8 * qq + 4 * h);
+                const float4 m1 = *reinterpret_cast<const float4*>(mu_tile + c * 32 + 32 + 8 * qq + 4 * h);
+                acc0[4 * qq + 0] = m0.x; acc0[4 * qq + 1] = m0.y; acc0[4 * qq + 2] = m0.z; acc0[4 * qq + 3] = m0.w;
+                acc1[4 * qq + 0] = m1.x; acc1[4 * qq + 1] = m1.y; acc1[4 * qq + 2] = m1.z; acc1[4 * qq + 3] = m1.w;
+            }
+            const char* arow0 = g_tile + (c * 32 + j) * d.RS + 16 * h;
+            const char* arow1 = arow0 + 32 * d.RS;
+            bf16x8 A0[N1], A1[N1];
+#pragma unroll
+            for (int s = 0; s < N1; ++s) {
+                A0[s] = *reinterpret_cast<const bf16x8*>(arow0 + 32 * s);
+                A1[s] = *reinterpret_cast<const bf16x8*>(arow1 + 32 * s);
+            }
+#pragma unroll
+            for (int s = 0; s < N1; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[s], B1[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[s], B1[s], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < N2; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[s], B2[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[s], B2[s], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < N3; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[s], B3[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[s], B3[s], acc1, 0, 0, 0);
+            }
+        };
+        // exp-sum of one finished chunk: 16 exp2 + a tree sum per lane, both lanes of the user added
+        auto expsum_chunk = [&](const f32x16& y, uint32_t ci) {
+            float e[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(y[r]);
+#pragma unroll
+            for (int w2 = 8; w2 > 0; w2 >>= 1)
+#pragma unroll
+                for (int r = 0; r < w2; ++r) e[r] += e[r + w2];
+            const float wc = e[0] + swap32(e[0]);
+            if (h == 0) scr_chunk[ci * 32 + j] = wc;
+            wcmax = fmaxf(wcmax, wc);
+            s_sc += static_cast<double>(wc);
+        };
+        // end of a super-chunk: store {sum, reference}; re-reference if a sum grew past 2^48
+        auto flush_sc = [&](uint32_t ci) {
+            if (h == 0) scr[(ci / d.sc_chunks) * 32 + j] = make_float2(static_cast<float>(s_sc), q);
+            s_sc = 0.0;
+            if (wcmax > 2.8e14f) {     // some logit is >= ~43 above the reference (log2 units)
+                set_reference(q + floorf(__builtin_amdgcn_logf(wcmax)));   // v_log_f32 = log2
+                n_resc += 1;
+            }
+            wcmax = 0.0f;
+        };
+
+        f32x16 ya0, ya1, yb0, yb1;     // two chunk pairs in flight: MFMA of one overlaps the exp-sum of the other
+        bool first = true;
+        uint32_t ci_b = 0;             // chunk index of the pair held in yb
+        for (uint32_t ti = 0; ti < n_ptiles; ++ti) {
+            __syncthreads();       // tile ti landed (hipcc drains vmcnt before the barrier); tile ti-1 is free
+            if (ti + 1 < n_ptiles) {
+                const uint32_t nb = (ti + 1) & 1;
+                glds_copy(reinterpret_cast<const char*>(d.gsplit) + static_cast<size_t>(ti + 1) * tile_b,
+                          g_buf + nb * tile_b, tile_b, wave, lane);
+                if (wave == 3)
+                    glds_copy(reinterpret_cast<const char*>(d.mu32s + static_cast<size_t>(ti + 1) * d.TPB),
+                              reinterpret_cast<char*>(mu_buf + nb * d.TPB), d.TPB * 4, 0, lane);
+            }
+            const char* g_tile = g_buf + (ti & 1) * tile_b;
+            const float* mu_tile = mu_buf + (ti & 1) * d.TPB;
+            const uint32_t c_end = min(cpt, d.n_chunks - ti * cpt);     // multiple of 4
+            for (uint32_t c = 0; c < c_end; c += 4) {
+                const uint32_t ci = ti * cpt + c;
+                mfma_pair(g_tile, mu_tile, c, ya0, ya1);
+                if (first) {
+                    // very first pair of the user tile: computed with reference 0; its max sets the
+                    // reference, then it is recomputed so that every stored sum shares a reference
+                    float cm = fmaxf(ya0[0], ya1[0]);
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) cm = fmaxf(cm, fmaxf(ya0[r], ya1[r]));
+                    set_reference(fmaxf(ceilf(fmaxf(cm, swap32(cm))), -1.0e30f));
+                    mfma_pair(g_tile, mu_tile, c, ya0, ya1);
+                    first = false;
+                } else {
+                    expsum_chunk(yb0, ci_b);
+                    expsum_chunk(yb1, ci_b + 1);
+                    if ((ci_b + 2) % d.sc_chunks == 0) flush_sc(ci_b);
+                }
+                mfma_pair(g_tile, mu_tile, c + 2, yb0, yb1);
+                expsum_chunk(ya0, ci);
+                expsum_chunk(ya1, ci + 1);
+                ci_b = ci + 2;
+            }
+        }
+        expsum_chunk(yb0, ci_b);               // drain the pipeline
+        expsum_chunk(yb1, ci_b + 1);
+        flush_sc(ci_b);
+        search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h);
+    }
+}
+
+// kernel selection by (KH, N1, N2, N3)
+typedef void (*draw_kernel_t)(DevSim, uint32_t);
+draw_kernel_t bf16_kernel_for(const DevSim& d) {
+#define RG_CASE(kh, a, b, c) if (d.KH == kh && d.N1 == a && d.N2 == b && d.N3 == c) return k_draw_bf16<kh, a, b, c>;
+    RG_CASE(4, 1, 1, 1) RG_CASE(4, 2, 1, 1) RG_CASE(10, 3, 2, 1) RG_CASE(10, 4, 3, 2)
+    RG_CASE(16, 4, 3, 2) RG_CASE(16, 6, 4, 2) RG_CASE(32, 12, 8, 4)
+#undef RG_CASE
+    return nullptr;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1173,8 +1513,15 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     const uint32_t upper = sim->live_upper;
     if (int rc = prof_mark(sim, st)) return rc;
     // 1. organic product draws of this step (read omega before the transition drifts it)
-    const size_t smem_exact = sizeof(double) * (d.K + (d.P + 63) / 64 + 1) * (kBlock / 64);
-    if (d.use_mfma) {
+    const size_t smem_exact = sizeof(double) * (static_cast<size_t>(d.K) * 64 + 64 + kExactUsers * d.K +
+                                                kExactUsers * ((d.P + 63) / 64 + 1));
+    if (d.use_mfma == 2) {
+        const int grid = grid_for(upper, 128);
+        hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid), dim3(kBlock), sim->bf16_smem, st, d, t);
+        if (int rc = prof_mark(sim, st)) return rc;
+        const int grid_x = grid_for(upper / 8 + 64, kExactUsers);
+        hipLaunchKernelGGL(k_draw_exact, dim3(grid_x), dim3(kBlock), smem_exact, st, d, t, 1);
+    } else if (d.use_mfma) {
         const int grid = grid_for(upper, 128);
         const size_t smem = sim->mfma_smem;
         switch (d.KH) {
@@ -1186,11 +1533,11 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         }
         if (int rc = prof_mark(sim, st)) return rc;
         // draws the fp32 path could not certify -> float64 (a few percent of the organic users)
-        const int grid_x = grid_for(upper / 8 + 64, kBlock / 64);
+        const int grid_x = grid_for(upper / 8 + 64, kExactUsers);
         hipLaunchKernelGGL(k_draw_exact, dim3(grid_x), dim3(kBlock), smem_exact, st, d, t, 1);
     } else {
         if (int rc = prof_mark(sim, st)) return rc;
-        const int grid = grid_for(upper, kBlock / 64);
+        const int grid = grid_for(upper, kExactUsers);
         hipLaunchKernelGGL(k_draw_exact, dim3(grid), dim3(kBlock), smem_exact, st, d, t, 0);
     }
     if (int rc = prof_mark(sim, st)) return rc;
@@ -1274,7 +1621,30 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     s->profiling = false; s->prof_used = 0; s->prof_launches = 0;
     s->prof_ms[0] = s->prof_ms[1] = s->prof_ms[2] = 0.0;
     s->mfma_smem = d.use_mfma ? mfma_smem_bytes(geom_of(*cfg)) : 0;
+    // kernel choice: split-bf16 MFMA when a class exists for K, else fp32 MFMA; RECOGYM_DRAW=f64|fp32|bf16 overrides
+    s->bf16_kernel = nullptr; s->bf16_smem = 0;
+    if (d.use_mfma && d.N1) {
+        s->bf16_kernel = bf16_kernel_for(d);
+        s->bf16_smem = bf16_smem_bytes(geom_of(*cfg), 2 * d.KH);
+        // the larger classes still spill registers; the fp32 kernel is faster there for now
+        if (s->bf16_kernel && d.N1 <= 4 && d.KH <= 10) d.use_mfma = 2;
+    }
+    if (const char* e = getenv("RECOGYM_DRAW")) {
+        if (!strcmp(e, "f64")) d.use_mfma = 0;
+        else if (!strcmp(e, "fp32") && d.KH) d.use_mfma = 1;
+        else if (!strcmp(e, "bf16") && s->bf16_kernel) d.use_mfma = 2;
+    }
     if (const char* e = getenv("RECOGYM_FORCE_EXACT")) if (e[0] == '1') d.use_mfma = 0;   // A/B switch for tests
+    {
+        const size_t se = sizeof(double) * (static_cast<size_t>(d.K) * 64 + 64 + kExactUsers * d.K +
+                                            kExactUsers * ((d.P + 63) / 64 + 1));
+        if (se > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_draw_exact),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(se));
+    }
+    if (s->bf16_kernel && s->bf16_smem > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s->bf16_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->bf16_smem));
     d.ablate = 0;
     if (const char* e = getenv("RECOGYM_ABLATE")) d.ablate = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_LDS_PAD")) s->mfma_smem += static_cast<size_t>(atoi(e));
@@ -1318,6 +1688,9 @@ int rg_sim_set_tables(rg_sim* sim, const double* d_gamma, const double* d_mu_org
                            static_cast<hipStream_t>(stream), sim->d);
         hipLaunchKernelGGL(k_table_stats, dim3(2 * sim->d.KH + 2), dim3(kBlock), 0,
                            static_cast<hipStream_t>(stream), sim->d);
+        if (sim->d.N1)
+            hipLaunchKernelGGL(k_make_split_table, dim3(grid_for(static_cast<size_t>(sim->d.P_pad) * (sim->d.RS / 2))),
+                               dim3(kBlock), 0, static_cast<hipStream_t>(stream), sim->d);
     }
     HIP_TRY(hipGetLastError());
     sim->tables_set = true;
