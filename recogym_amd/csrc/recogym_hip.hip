@@ -4,7 +4,7 @@
 // and the roofline of each kernel):
 //
 //   k_reset_users    RecoEnv1.reset / AbstractEnv.reset          reco_env_v1.py:78-82, abstract.py:90-103
-//   k_draw_exact     RecoEnv1.update_product_view (float64)      reco_env_v1.py:119-128
+//   k_exact_sums/pick RecoEnv1.update_product_view (float64)     reco_env_v1.py:119-128
 //   k_draw_mfma      RecoEnv1.update_product_view (fp32 MFMA fast path with a certified margin;
 //                    draws it cannot certify are handed to k_draw_exact)
 //   k_advance        AbstractEnv.step / step_offline, RecoEnv1.draw_click / update_state, the
@@ -82,6 +82,7 @@ struct DevSim {
     double* gammaT;           // [K][PT] float64 transpose of Gamma, PT = P rounded up to 64 (coalesced f64 draw)
     uint32_t PT;
     float* exact_ref;         // [n_users] log2-scaled reference of a draw handed to the float64 kernel
+    double* exact_sums;       // [n_users][PT/64] float64 exp-sum of every 64-product chunk
     float2* sc_scratch;       // [kMaxGrid*4 waves][kMaxSC][32] {sum, reference} of the MFMA draw kernel
     float* chunk_scratch;     // [kMaxGrid*4 waves][n_chunks][32] exp-sum of every 32-product chunk
     float* stats;             // [2*KH] max_p |Gamma[p][k]|, then max_p ||Gamma[p]||_2, max_p |mu_o[p]|
@@ -181,8 +182,7 @@ Geom geom_of(const rg_config& c) {
             }
         if (g.N1) {
             g.RS = 32 * g.N1 + 16;
-            g.TPB = 128;
-            while (g.TPB > 64 && static_cast<size_t>(g.TPB) * g.RS > 20 * 1024) g.TPB /= 2;
+            g.TPB = 128;                            // 4 chunks per tile: the kernel walks pairs of pairs
         }
     }
     g.sc_chunks = (g.n_chunks + kMaxSC - 1) / kMaxSC;
@@ -217,6 +217,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     const size_t PT = align_up(P, 64);
     double* gammaT = w.take<double>(K * PT);
     float* exact_ref = w.take<float>(n);
+    double* exact_sums = w.take<double>(n * (PT / 64));
     unsigned short* gsplit = w.take<unsigned short>(g.N1 ? static_cast<size_t>(g.P_pad) * (g.RS / 2) : 1);
     float* mu32s = w.take<float>(g.N1 ? g.P_pad : 1);
     float2* sc_scratch = w.take<float2>(g.KH ? static_cast<size_t>(kMaxGrid) * 4 * kMaxSC * 32 : 1);
@@ -237,7 +238,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     unsigned long long* counters = w.take<unsigned long long>(RG_CNT_N);
     if (d) {
         d->gamma32 = gamma32; d->mu32 = mu32; d->stats = stats; d->omega = omega; d->list = list;
-        d->gammaT = gammaT; d->PT = static_cast<uint32_t>(PT); d->exact_ref = exact_ref; d->sc_scratch = sc_scratch; d->chunk_scratch = chunk_scratch;
+        d->gammaT = gammaT; d->PT = static_cast<uint32_t>(PT); d->exact_ref = exact_ref; d->exact_sums = exact_sums; d->sc_scratch = sc_scratch; d->chunk_scratch = chunk_scratch;
         d->gsplit = gsplit; d->mu32s = mu32s; d->N1 = g.N1; d->N2 = g.N2; d->N3 = g.N3; d->RS = g.RS; d->TPB = g.TPB;
         d->KH = g.KH; d->KS = g.KS; d->TP = g.TP; d->P_pad = g.P_pad; d->n_chunks = g.n_chunks;
         d->sc_chunks = g.sc_chunks; d->n_sc = g.n_sc; d->use_mfma = g.KH ? 1u : 0u;
@@ -256,9 +257,8 @@ int validate(const rg_config* c, uint64_t n) {
     if (c->num_products == 0 || c->num_products > RG_EV_INDEX_MASK)
         return fail(RG_EINVAL, "num_products %u out of range [1, 2^29)", c->num_products);
     if (c->K == 0 || c->K > 1024) return fail(RG_EINVAL, "K %u out of range [1, 1024]", c->K);
-    if (sizeof(double) * (static_cast<size_t>(c->K) * 64 + 64 + 16 * c->K + 16 * ((c->num_products + 63) / 64 + 1)) > 150 * 1024)
-        return fail(RG_EINVAL, "num_products %u / K %u exceed the float64 draw kernel's LDS budget",
-                    c->num_products, c->K);
+    if (sizeof(double) * (static_cast<size_t>(c->K) * 64 + 64 + 16 * c->K) > 64 * 1024)
+        return fail(RG_EINVAL, "K %u exceeds the float64 draw kernel's LDS budget", c->K);
     if (n == 0 || n >= (1ull << 31)) return fail(RG_EINVAL, "n_users %llu out of range", (unsigned long long)n);
     if (c->policy > RG_POLICY_EXTERNAL) return fail(RG_EINVAL, "unknown policy %u", c->policy);
     for (int s = 0; s < 2; ++s)
@@ -606,126 +606,161 @@ __device__ __forceinline__ void logit64x4(const DevSim& d, const double* om, uin
     for (int u = 0; u < 4; ++u) out[u] = (p + 64u * u < d.P) ? out[u] + d.mu_o[p + 64u * u] : -INFINITY;
 }
 
-// One block = up to kExactUsers users (2 per wave) that share float64 Gamma^T tiles staged in
-// LDS — read once per block instead of once per user (the table is P*K*8 bytes; unshared, the
-// float64 kernel was L2-bandwidth-bound).  Per 64-product chunk a lane holds its product's K
-// Gamma values in registers and dots them with each of its wave's users' omega (LDS broadcast).
+// The float64 draw is split in two kernels so that a step with FEW users to resolve (the long
+// tail of the lock-step loop: ~1 400 of the ~1 800 steps of a 10 M-user run) is parallel over
+// PRODUCTS instead of serial over them:
+//   k_exact_sums  block = 16 users (4 per wave) x one slice of the 64-product chunks; the users
+//                 share float64 Gamma^T tiles staged in LDS (unshared, the kernel was
+//                 L2-bandwidth-bound: the table is P*K*8 bytes per user); writes exp-sums (or
+//                 maxima, mode 0) per (user, chunk) to scratch.
+//   k_exact_ref   (pure float64 mode only) reference = max logit per user.
+//   k_exact_pick  wave per user: prefix over the chunk sums, u * total located by ballot, that
+//                 chunk recomputed from the table, the row written.
 constexpr int kUPW = 4;                      // users per wave
 constexpr int kExactUsers = 4 * kUPW;        // users per block
 
-__global__ void __launch_bounds__(kBlock) k_draw_exact(DevSim d, uint32_t t, int from_list) {
+__global__ void __launch_bounds__(kBlock) k_exact_sums(DevSim d, uint32_t t, int from_list, int mode, uint32_t S) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t n_chunks = (d.P + 63) / 64;
-    // LDS: Gamma^T tile [K][64] doubles, mu tile [64], omega [users][K], chunk prefix [users][n_chunks+1]
+    const uint32_t n_chunks = d.PT / 64;
+    // LDS: Gamma^T tile [K][64] doubles, mu tile [64], omega [16 users][K]
     double* g_tile = reinterpret_cast<double*>(smem_raw);
     double* mu_tile = g_tile + static_cast<size_t>(d.K) * 64;
     double* om_all = mu_tile + 64;
-    double* prefix_all = om_all + static_cast<size_t>(kExactUsers) * d.K;
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
     const uint32_t n = from_list ? d.exact_cnt[t] : n_o;
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
     const uint32_t n_groups = (n + kExactUsers - 1) / kExactUsers;
+    const uint32_t cps = (n_chunks + S - 1) / S;               // chunks per slice
+    const uint32_t n_work = n_groups * S;
 
-    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        uint32_t w_idx[kUPW], pos[kUPW], slot[kUPW], user[kUPW];
+    for (uint32_t wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
+        const uint32_t grp = wk / S, slice = wk % S;
+        const uint32_t c0 = slice * cps, c1 = min(c0 + cps, n_chunks);
+        uint32_t w_idx[kUPW];
         bool act[kUPW];
-        double M[kUPW], run[kUPW];
+        double M[kUPW];
+        __syncthreads();      // previous work item's LDS is free
+        double* om = om_all + static_cast<size_t>(wave * kUPW) * d.K;
 #pragma unroll
         for (int u = 0; u < kUPW; ++u) {
             w_idx[u] = grp * kExactUsers + wave * kUPW + u;
             act[u] = w_idx[u] < n;
-            pos[u] = act[u] ? (from_list ? d.exact_list[w_idx[u]] : w_idx[u]) : 0u;
-            slot[u] = act[u] ? cur[pos[u]] : 0u;
-            user[u] = static_cast<uint32_t>(d.first_user + slot[u]);
-            run[u] = 0.0;
-            // a draw handed over by the MFMA kernel reuses that kernel's reference: any shift
-            // gives the same float64 decision up to 1e-16
-            M[u] = (from_list && act[u]) ? static_cast<double>(d.exact_ref[w_idx[u]]) * 0.69314718055994530942 : 0.0;
-        }
-        __syncthreads();      // previous group's LDS is free
-        double* om = om_all + static_cast<size_t>(wave * kUPW) * d.K;
-        double* pre = prefix_all + static_cast<size_t>(wave * kUPW) * (n_chunks + 1);
-#pragma unroll
-        for (int u = 0; u < kUPW; ++u)
+            const uint32_t pos = act[u] ? (from_list ? d.exact_list[w_idx[u]] : w_idx[u]) : 0u;
+            const uint32_t slot = act[u] ? cur[pos] : 0u;
+            // any shift gives the same float64 decision up to 1e-16: a draw handed over by the
+            // MFMA kernel reuses that kernel's reference, pure float64 mode uses k_exact_ref's
+            M[u] = (mode == 1 && act[u]) ? static_cast<double>(d.exact_ref[w_idx[u]]) * 0.69314718055994530942 : 0.0;
             for (uint32_t k = lane; k < d.K; k += 64)
-                om[u * d.K + k] = act[u] ? d.omega[static_cast<size_t>(k) * d.n_pad + slot[u]] : 0.0;
-
-        // sweeps over the products: mode 0 = max logit (reco_env_v1.py:121; skipped with a
-        // handed-over reference), mode 1 = running exp-sums per 64-product chunk
-        for (int mode = from_list ? 1 : 0; mode < 2; ++mode) {
-            double mx[kUPW];
-#pragma unroll
-            for (int u = 0; u < kUPW; ++u) mx[u] = -INFINITY;
-            for (uint32_t c = 0; c < n_chunks; ++c) {
-                __syncthreads();
-                // stage Gamma^T[:, c*64 .. c*64+63] and mu (coalesced: 64 consecutive doubles per k)
-                for (uint32_t i = threadIdx.x; i < d.K * 64; i += kBlock) {
-                    const uint32_t k = i >> 6, pp = i & 63;
-                    g_tile[i] = d.gammaT[static_cast<size_t>(k) * d.PT + c * 64 + pp];
-                }
-                if (threadIdx.x < 64) {
-                    const uint32_t p = c * 64 + threadIdx.x;
-                    mu_tile[threadIdx.x] = p < d.P ? d.mu_o[p] : -INFINITY;
-                }
-                __syncthreads();
-                // same association as the oracle / numpy: (sum_k Gamma[p][k] omega[k]) + mu[p]
-                double l[kUPW];
-#pragma unroll
-                for (int u = 0; u < kUPW; ++u) l[u] = 0.0;
-#pragma unroll 4
-                for (uint32_t k = 0; k < d.K; ++k) {
-                    const double g = g_tile[k * 64 + lane];
-#pragma unroll
-                    for (int u = 0; u < kUPW; ++u) l[u] += g * om[u * d.K + k];
-                }
-                const double mu = mu_tile[lane];        // -inf for products >= P: exp() gives exactly 0
-#pragma unroll
-                for (int u = 0; u < kUPW; ++u) {
-                    l[u] += mu;
-                    if (mode == 0) mx[u] = fmax(mx[u], l[u]);
-                    else {
-                        if (lane == 0) pre[u * (n_chunks + 1) + c] = run[u];
-                        run[u] += __shfl(wave_scan(exp(l[u] - M[u]), lane), 63);
-                    }
-                }
+                om[u * d.K + k] = act[u] ? d.omega[static_cast<size_t>(k) * d.n_pad + slot] : 0.0;
+        }
+        for (uint32_t c = c0; c < c1; ++c) {
+            __syncthreads();
+            // stage Gamma^T[:, c*64 .. c*64+63] and mu (coalesced: 64 consecutive doubles per k)
+            for (uint32_t i = threadIdx.x; i < d.K * 64; i += kBlock) {
+                const uint32_t k = i >> 6, pp = i & 63;
+                g_tile[i] = d.gammaT[static_cast<size_t>(k) * d.PT + c * 64 + pp];
             }
+            if (threadIdx.x < 64) {
+                const uint32_t p = c * 64 + threadIdx.x;
+                mu_tile[threadIdx.x] = p < d.P ? d.mu_o[p] : -INFINITY;
+            }
+            __syncthreads();
+            // same association as the oracle / numpy: (sum_k Gamma[p][k] omega[k]) + mu[p]
+            double l[kUPW];
+#pragma unroll
+            for (int u = 0; u < kUPW; ++u) l[u] = 0.0;
+#pragma unroll 4
+            for (uint32_t k = 0; k < d.K; ++k) {
+                const double g = g_tile[k * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < kUPW; ++u) l[u] += g * om[u * d.K + k];
+            }
+            const double mu = mu_tile[lane];        // -inf for products >= P: exp() gives exactly 0
 #pragma unroll
             for (int u = 0; u < kUPW; ++u) {
-                if (mode == 0) M[u] = wave_max(mx[u]);
-                else if (lane == 0) pre[u * (n_chunks + 1) + n_chunks] = run[u];
+                l[u] += mu;
+                const double r = mode == 0 ? wave_max(l[u]) : __shfl(wave_scan(exp(l[u] - M[u]), lane), 63);
+                if (lane == 0 && act[u]) d.exact_sums[static_cast<size_t>(w_idx[u]) * n_chunks + c] = r;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+}
+
+// pure float64 mode: the reference of every user = its max logit (reco_env_v1.py:121)
+__global__ void __launch_bounds__(kBlock) k_exact_ref(DevSim d, uint32_t t) {
+    const int lane = lane_id();
+    const uint32_t n_chunks = d.PT / 64;
+    const uint32_t n = d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const uint32_t waves_total = gridDim.x * (kBlock / 64);
+    for (uint32_t w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < n; w += waves_total) {
+        double m = -INFINITY;
+        for (uint32_t c = lane; c < n_chunks; c += 64) m = fmax(m, d.exact_sums[static_cast<size_t>(w) * n_chunks + c]);
+        m = wave_max(m);
+        if (lane == 0) d.exact_ref[w] = static_cast<float>(m * 1.4426950408889634074);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int from_list) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    double* om = reinterpret_cast<double*>(smem_raw) + static_cast<size_t>(wave) * d.K;
+    const uint32_t n_chunks = d.PT / 64;
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const uint32_t n = from_list ? d.exact_cnt[t] : n_o;
+    const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const uint32_t waves_total = gridDim.x * (kBlock / 64);
+    for (uint32_t w = blockIdx.x * (kBlock / 64) + wave; w < n; w += waves_total) {
+        const uint32_t pos = from_list ? d.exact_list[w] : w;
+        const uint32_t slot = cur[pos];
+        const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
+        const double M = static_cast<double>(d.exact_ref[w]) * 0.69314718055994530942;
+        const double* sums = d.exact_sums + static_cast<size_t>(w) * n_chunks;
+        for (uint32_t k = lane; k < d.K; k += 64) om[k] = d.omega[static_cast<size_t>(k) * d.n_pad + slot];
+        // total, in the same association the prefix below uses
+        double total = 0.0;
+        for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            total += __shfl(wave_scan(c < n_chunks ? sums[c] : 0.0, lane), 63);
+        }
+        // The reference normalises p = e / sum(e) before its cumsum and divides by cdf[-1];
+        // dividing every term by the same positive constants moves the decision only at the
+        // 1e-16 level, so the running sum of e is compared with u * total directly.
+        const rg_u32x4 rw = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
+        const double target = rg_uniform(rw.w[0], rw.w[1]) * total;
+        // first chunk whose inclusive running sum exceeds the target, and the sum before it
+        uint32_t cstar = n_chunks - 1;
+        double before = 0.0, run = 0.0;
+        bool found = false;
+        for (uint32_t c0 = 0; c0 < n_chunks && !found; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            const double x = c < n_chunks ? sums[c] : 0.0;
+            const double incl = wave_scan(x, lane);
+            const unsigned long long hit = __ballot(c < n_chunks && run + incl > target);
+            if (hit) {
+                const int L = __builtin_ctzll(hit);
+                cstar = c0 + L;
+                before = run + __shfl(incl - x, L);
+                found = true;
+            } else run += __shfl(incl, 63);
+        }
+        if (!found) before = run - sums[n_chunks - 1];      // u * total rounded up to total
         __builtin_amdgcn_wave_barrier();
-        // locate the chunk per user, then recompute it from global memory (once per user)
-#pragma unroll
-        for (int u = 0; u < kUPW; ++u) {
-            if (!act[u]) continue;
-            const double* omu = om + u * d.K;
-            const double* preu = pre + u * (n_chunks + 1);
-            const rg_u32x4 rw = rg_draw(d.seed, user[u], t, 0, RG_DRAW_EVENT);
-            const double target = rg_uniform(rw.w[0], rw.w[1]) * run[u];
-            uint32_t cstar = n_chunks - 1;
-            for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64) {
-                const uint32_t c = c0 + lane;
-                const unsigned long long hit = __ballot(c < n_chunks && preu[c + 1] > target);
-                if (hit) { cstar = c0 + static_cast<uint32_t>(__builtin_ctzll(hit)); break; }
-            }
-            uint32_t v = d.P - 1;
-            const uint32_t p = cstar * 64 + lane;
-            double lg = 0.0;
-            const double* g = d.gammaT + min(p, d.PT - 1);
-            for (uint32_t k = 0; k < d.K; ++k) lg += g[static_cast<size_t>(k) * d.PT] * omu[k];
-            lg = p < d.P ? lg + d.mu_o[p] : -INFINITY;
-            const double x = preu[cstar] + wave_scan(exp(lg - M[u]), lane);
-            const unsigned long long hit = __ballot(p < d.P && x > target);
-            if (hit) v = cstar * 64 + static_cast<uint32_t>(__builtin_ctzll(hit));
-            if (lane == 0) {
-                write_organic_row(d, t, pos[u], user[u], v);
-                if (d.hist_cap) history_add(d, slot[u], v);
-            }
+        // recompute that chunk (same arithmetic as k_exact_sums) and find the product inside it
+        const uint32_t p = cstar * 64 + lane;
+        double lg = 0.0;
+        const double* g = d.gammaT + p;                      // PT columns: always in range
+        for (uint32_t k = 0; k < d.K; ++k) lg += g[static_cast<size_t>(k) * d.PT] * om[k];
+        lg = p < d.P ? lg + d.mu_o[p] : -INFINITY;
+        const double xs = before + wave_scan(exp(lg - M), lane);
+        const unsigned long long hit = __ballot(p < d.P && xs > target);
+        const uint32_t v = hit ? cstar * 64 + static_cast<uint32_t>(__builtin_ctzll(hit))
+                               : min(cstar * 64 + 63, d.P - 1);
+        if (lane == 0) {
+            write_organic_row(d, t, pos, user, v);
+            if (d.hist_cap) history_add(d, slot, v);
         }
+        __builtin_amdgcn_wave_barrier();
     }
     if (from_list == 1 && blockIdx.x == 0 && threadIdx.x == 0)
         atomicAdd(&d.counters[RG_CNT_EXACT_DRAWS], static_cast<unsigned long long>(n));
@@ -1506,6 +1541,26 @@ int prof_mark(rg_sim* sim, hipStream_t st) {
     return RG_OK;
 }
 
+// float64 draw of this step: from_list = 1 resolves the users the MFMA kernel could not certify
+// (est = expected count), from_list = 0 serves every organic user (pure float64 mode)
+void launch_exact(rg_sim* sim, uint32_t t, int from_list, uint64_t est, hipStream_t st) {
+    const DevSim& d = sim->d;
+    const uint32_t n_chunks = d.PT / 64;
+    const uint64_t groups = (est + kExactUsers - 1) / kExactUsers;
+    uint32_t S = static_cast<uint32_t>(2048 / (groups ? groups : 1));
+    if (S > n_chunks / 4) S = n_chunks / 4;
+    if (S < 1) S = 1;
+    const int grid = grid_for(groups * S, 1);
+    const size_t smem = sizeof(double) * (static_cast<size_t>(d.K) * 64 + 64 + kExactUsers * d.K);
+    if (!from_list) {
+        hipLaunchKernelGGL(k_exact_sums, dim3(grid), dim3(kBlock), smem, st, d, t, 0, 0, S);
+        hipLaunchKernelGGL(k_exact_ref, dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t);
+    }
+    hipLaunchKernelGGL(k_exact_sums, dim3(grid), dim3(kBlock), smem, st, d, t, from_list, 1, S);
+    hipLaunchKernelGGL(k_exact_pick, dim3(grid_for(est, kBlock / 64)), dim3(kBlock),
+                       sizeof(double) * d.K * (kBlock / 64), st, d, t, from_list);
+}
+
 int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     if (sim->t >= kMaxSteps) return fail(RG_ELIMIT, "more than %u steps", kMaxSteps);
     const DevSim& d = sim->d;
@@ -1513,14 +1568,11 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     const uint32_t upper = sim->live_upper;
     if (int rc = prof_mark(sim, st)) return rc;
     // 1. organic product draws of this step (read omega before the transition drifts it)
-    const size_t smem_exact = sizeof(double) * (static_cast<size_t>(d.K) * 64 + 64 + kExactUsers * d.K +
-                                                kExactUsers * ((d.P + 63) / 64 + 1));
     if (d.use_mfma == 2) {
         const int grid = grid_for(upper, 128);
         hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid), dim3(kBlock), sim->bf16_smem, st, d, t);
         if (int rc = prof_mark(sim, st)) return rc;
-        const int grid_x = grid_for(upper / 8 + 64, kExactUsers);
-        hipLaunchKernelGGL(k_draw_exact, dim3(grid_x), dim3(kBlock), smem_exact, st, d, t, 1);
+        launch_exact(sim, t, 1, upper / 100 + 16, st);
     } else if (d.use_mfma) {
         const int grid = grid_for(upper, 128);
         const size_t smem = sim->mfma_smem;
@@ -1533,12 +1585,10 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         }
         if (int rc = prof_mark(sim, st)) return rc;
         // draws the fp32 path could not certify -> float64 (a few percent of the organic users)
-        const int grid_x = grid_for(upper / 8 + 64, kExactUsers);
-        hipLaunchKernelGGL(k_draw_exact, dim3(grid_x), dim3(kBlock), smem_exact, st, d, t, 1);
+        launch_exact(sim, t, 1, upper / 100 + 16, st);
     } else {
         if (int rc = prof_mark(sim, st)) return rc;
-        const int grid = grid_for(upper, kExactUsers);
-        hipLaunchKernelGGL(k_draw_exact, dim3(grid), dim3(kBlock), smem_exact, st, d, t, 0);
+        launch_exact(sim, t, 0, upper, st);
     }
     if (int rc = prof_mark(sim, st)) return rc;
     // 2. click draws, transitions, drift, next lists, bandit + phantom rows
@@ -1635,13 +1685,6 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
         else if (!strcmp(e, "bf16") && s->bf16_kernel) d.use_mfma = 2;
     }
     if (const char* e = getenv("RECOGYM_FORCE_EXACT")) if (e[0] == '1') d.use_mfma = 0;   // A/B switch for tests
-    {
-        const size_t se = sizeof(double) * (static_cast<size_t>(d.K) * 64 + 64 + kExactUsers * d.K +
-                                            kExactUsers * ((d.P + 63) / 64 + 1));
-        if (se > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_draw_exact),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(se));
-    }
     if (s->bf16_kernel && s->bf16_smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s->bf16_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->bf16_smem));

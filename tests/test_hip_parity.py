@@ -135,3 +135,22 @@ def test_more_than_a_million_users_shard_consistently():
     assert 95 < (whole_c['organic'] + whole_c['bandit']) / n < 108      # ~1/0.01 events per user
     for i in range(3):
         assert whole_chk[i] % 2 ** 64 == sum(p[1][i] for p in parts) % 2 ** 64
+
+
+@pytest.mark.parametrize('mode', ['f64', 'fp32', 'bf16'])
+@pytest.mark.parametrize('shape', [(10, 5), (1000, 20), (4100, 8), (700, 33)])
+def test_every_draw_kernel_matches_the_oracle(mode, shape, monkeypatch):
+    """The three organic-draw implementations (float64 only, fp32 MFMA + certificate, split-bf16
+    MFMA + certificate) each reproduce the oracle's rows."""
+    from oracle import oracle as orc
+    monkeypatch.setenv('RECOGYM_DRAW', mode)
+    P, K = shape
+    cfg = Configuration({**env_1_args, 'random_seed': 100 + P, 'num_products': P, 'K': K})
+    want = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX).generate_logs(600)
+    rows, cnt = run_sim(cfg, 600)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps')},
+                         ps_rtol=1e-6, what=f'{mode} {shape}')
+    if mode == 'f64':
+        assert cnt['exact_draws'] == 0      # counted only for draws handed over by an MFMA kernel
+    else:
+        assert cnt['exact_draws'] < 0.2 * cnt['organic']
