@@ -103,7 +103,9 @@ struct DevSim {
     float* mu32s;             // [P_pad] fl32(mu_o log2 e), -inf beyond P
     uint32_t ablate;          // timing experiments only (RECOGYM_ABLATE); results are wrong when non-zero
     // state (workspace)
-    double* omega;            // [K][n_pad], K-major: lane-per-user accesses coalesce
+    double* omega;            // [n_pad][OMS] user-major (OMS = K rounded up to 2): a user's vector is contiguous,
+                              // so the scrambled order of the live lists costs at most one extra cache line per user
+    uint32_t OMS;
     uint32_t* list;           // [2 parity][2 state][n_users]
     uint32_t* step_cnt;       // [kMaxSteps+2][2]: users in organic / bandit state at step t
     uint64_t* log_base;       // [kMaxSteps+2]: first log row of step t
@@ -112,8 +114,8 @@ struct DevSim {
     uint32_t* n_events;       // [n_users] rows the user emitted (set when it leaves)
     rg_event* phantom;        // [n_users] trailing undrawn bandit row
     uint8_t* has_phantom;     // [n_users]
-    uint32_t* hist;           // [hist_cap][n_pad] sorted distinct viewed products (OUC policy)
-    uint16_t* hist_cntv;      // [hist_cap][n_pad] view counts of those products
+    uint32_t* hist;           // [n_pad][hist_cap] sorted distinct viewed products (OUC policy), user-major
+    uint16_t* hist_cntv;      // [n_pad][hist_cap] view counts of those products
     uint32_t* hist_n;         // [n_users] distinct products viewed
     unsigned long long* counters;   // [RG_CNT_N]
     // log
@@ -132,7 +134,7 @@ struct rg_sim {
     bool tables_set, users_reset;
     uint32_t* h_pinned;       // 4 x u32 staging for the live-count readback
     size_t mfma_smem, bf16_smem;
-    void (*bf16_kernel)(DevSim, uint32_t);
+    void (*bf16_kernel)(DevSim, uint32_t, uint32_t);
     bool profiling;
     std::vector<hipEvent_t> prof_events;   // 4 per profiled step: before draw, after mfma, after exact, after advance
     size_t prof_used;
@@ -222,7 +224,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     float* mu32s = w.take<float>(g.N1 ? g.P_pad : 1);
     float2* sc_scratch = w.take<float2>(g.KH ? static_cast<size_t>(kMaxGrid) * 4 * kMaxSC * 32 : 1);
     float* chunk_scratch = w.take<float>(g.KH ? static_cast<size_t>(kMaxGrid) * 4 * g.n_chunks * 32 : 1);
-    double* omega = w.take<double>(K * n_pad);
+    double* omega = w.take<double>(((K + 1) & ~static_cast<size_t>(1)) * n_pad);
     uint32_t* list = w.take<uint32_t>(4 * n);
     uint32_t* step_cnt = w.take<uint32_t>(2 * (kMaxSteps + 2));
     uint64_t* log_base = w.take<uint64_t>(kMaxSteps + 2);
@@ -247,6 +249,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->has_phantom = has_phantom; d->hist = hist; d->hist_cntv = hist_cntv;
         d->hist_n = hist_n; d->counters = counters;
         d->n_pad = static_cast<uint32_t>(n_pad);
+        d->OMS = static_cast<uint32_t>((K + 1) & ~static_cast<size_t>(1));
         d->hist_cap = static_cast<uint32_t>(hc);
     }
     return align_up(w.off, 256);
@@ -316,8 +319,8 @@ __global__ void __launch_bounds__(kBlock) k_reset_users(DevSim d) {
         for (uint32_t j = 0; 2 * j < d.K; ++j) {
             double z0, z1;
             normal_pair(d.seed, user, 0u, j, RG_DRAW_RESET, &z0, &z1);
-            d.omega[static_cast<size_t>(2 * j) * d.n_pad + i] = 0.0 + d.sigma0 * z0;
-            if (2 * j + 1 < d.K) d.omega[static_cast<size_t>(2 * j + 1) * d.n_pad + i] = 0.0 + d.sigma0 * z1;
+            d.omega[static_cast<size_t>(i) * d.OMS + 2 * j] = 0.0 + d.sigma0 * z0;
+            if (2 * j + 1 < d.K) d.omega[static_cast<size_t>(i) * d.OMS + 2 * j + 1] = 0.0 + d.sigma0 * z1;
         }
         list_ptr(d, 0, RG_STATE_ORGANIC)[i] = i;
         d.n_events[i] = 0;
@@ -429,9 +432,9 @@ __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, ui
     // --- OrganicUserEventCounterModel.act over the user's sorted (product, count) history ---
     const uint32_t nd = d.hist_n[slot];
     const double eps = d.ouc_epsilon;
-    const uint32_t* hp = d.hist + slot;
-    const uint16_t* hc = d.hist_cntv + slot;
-    const size_t stride = d.n_pad;
+    const uint32_t* hp = d.hist + static_cast<size_t>(slot) * d.hist_cap;
+    const uint16_t* hc = d.hist_cntv + static_cast<size_t>(slot) * d.hist_cap;
+    const size_t stride = 1;
     bool explore = false;
     if (d.ouc_exploit_explore) {
         const double u0 = rg_uniform(w.w[0], w.w[1]);
@@ -522,9 +525,9 @@ __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, ui
 // ViewsFeaturesProvider.observe (agents/abstract.py:347-358): count one organic view, keeping the
 // user's (product, count) history sorted by product id.
 __device__ void history_add(const DevSim& d, uint32_t slot, uint32_t v) {
-    uint32_t* hp = d.hist + slot;
-    uint16_t* hc = d.hist_cntv + slot;
-    const size_t stride = d.n_pad;
+    uint32_t* hp = d.hist + static_cast<size_t>(slot) * d.hist_cap;
+    uint16_t* hc = d.hist_cntv + static_cast<size_t>(slot) * d.hist_cap;
+    const size_t stride = 1;
     const uint32_t nd = d.hist_n[slot];
     uint32_t i = 0;
     while (i < nd && hp[i * stride] < v) ++i;
@@ -652,7 +655,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums(DevSim d, uint32_t t, int
             // MFMA kernel reuses that kernel's reference, pure float64 mode uses k_exact_ref's
             M[u] = (mode == 1 && act[u]) ? static_cast<double>(d.exact_ref[w_idx[u]]) * 0.69314718055994530942 : 0.0;
             for (uint32_t k = lane; k < d.K; k += 64)
-                om[u * d.K + k] = act[u] ? d.omega[static_cast<size_t>(k) * d.n_pad + slot] : 0.0;
+                om[u * d.K + k] = act[u] ? d.omega[static_cast<size_t>(slot) * d.OMS + k] : 0.0;
         }
         for (uint32_t c = c0; c < c1; ++c) {
             __syncthreads();
@@ -716,7 +719,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int
         const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
         const double M = static_cast<double>(d.exact_ref[w]) * 0.69314718055994530942;
         const double* sums = d.exact_sums + static_cast<size_t>(w) * n_chunks;
-        for (uint32_t k = lane; k < d.K; k += 64) om[k] = d.omega[static_cast<size_t>(k) * d.n_pad + slot];
+        for (uint32_t k = lane; k < d.K; k += 64) om[k] = d.omega[static_cast<size_t>(slot) * d.OMS + k];
         // total, in the same association the prefix below uses
         double total = 0.0;
         for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64) {
@@ -837,7 +840,8 @@ __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, con
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // scratch: written by lanes < 32, read below
 
         // ---- search, part 1 (lane per user; lanes >= 32 mirror): total, target, super-chunk, chunk ----
-        const float Q = scr[(d.n_sc - 1) * 32 + j].y;          // references only grow: the last is the max
+        float Q = scr[j].y;                                    // common reference: the largest one
+        for (uint32_t sc = 1; sc < d.n_sc; ++sc) Q = fmaxf(Q, scr[sc * 32 + j].y);
         double S = 0.0;
         for (uint32_t sc = 0; sc < d.n_sc; ++sc) {
             const float2 wq = scr[sc * 32 + j];
@@ -976,7 +980,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_draw_mfma(DevSim
         for (int s = 0; s < KH; ++s) {
             const uint32_t k = h * KH + s;
             float w = 0.0f;
-            if (active && k < d.K) w = static_cast<float>(d.omega[static_cast<size_t>(k) * d.n_pad + slot]);
+            if (active && k < d.K) w = static_cast<float>(d.omega[static_cast<size_t>(slot) * d.OMS + k]);
             b[s] = w;
             om_stage[(wave * 32 + j) * 2 * KH + k] = w;
             absdot = fmaf(fabsf(w), d.stats[k], absdot);
@@ -1111,7 +1115,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_draw_mfma(DevSim
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
 template <int KH, int N1, int N2, int N3>
-__global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 2 : 1)) k_draw_bf16(DevSim d, uint32_t t) {
+__global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 2 : 1)) k_draw_bf16(DevSim d, uint32_t t, uint32_t S) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t tile_b = d.TPB * d.RS;                             // bytes per split tile
     char* g_buf = smem_raw;                                           // [2][TPB][RS]
@@ -1124,26 +1128,39 @@ __global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 2 : 1)) k_draw_bf16(DevSim 
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
     const float mumax = d.stats[2 * KH + 1], g2max = d.stats[2 * KH];
     const uint32_t cpt = d.TPB / 32;                                  // chunks per LDS tile (multiple of 4)
-    const uint32_t n_ptiles = (d.n_chunks + cpt - 1) / cpt;
-    const size_t wslot = static_cast<size_t>(blockIdx.x) * 4 + wave;
-    float* scr_chunk = d.chunk_scratch + wslot * d.n_chunks * 32;
-    float2* scr = d.sc_scratch + wslot * kMaxSC * 32;
+    // With few user tiles (the long tail of the lock-step loop) the products are split into S
+    // slices of whole super-chunks, one block per (user tile, slice), and the search runs in a
+    // second kernel (k_draw_search): a step's latency is one slice, not the whole product sweep.
+    const uint32_t scps = (d.n_sc + S - 1) / S;                       // super-chunks per slice
+    const uint32_t n_work = n_tiles * S;
     float* omu = om_stage + (wave * 32 + j) * 2 * KH;                 // this lane's user's omega32
 
-    for (uint32_t tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {
+    for (uint32_t wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
+        const uint32_t tb = wk / S, slice = wk % S;
+        const uint32_t chunk_lo = min(slice * scps * d.sc_chunks, d.n_chunks);
+        const uint32_t chunk_hi = min((slice + 1) * scps * d.sc_chunks, d.n_chunks);
+        if (chunk_lo >= chunk_hi) continue;
+        const uint32_t pt_lo = chunk_lo / cpt, pt_hi = (chunk_hi + cpt - 1) / cpt;   // product tiles
+        // scratch of this (user tile, wave): by block when fused, by user tile when sliced
+        const size_t wslot = (S == 1 ? static_cast<size_t>(blockIdx.x) : static_cast<size_t>(tb)) * 4 + wave;
+        float* scr_chunk = d.chunk_scratch + wslot * d.n_chunks * 32;
+        float2* scr = d.sc_scratch + wslot * kMaxSC * 32;
         const uint32_t pos = tb * 128 + wave * 32 + j;
         const bool active = pos < n_o;
         const uint32_t slot = active ? cur[pos] : 0u;
-        __syncthreads();           // every wave is done with the LDS buffers and stage (previous user tile)
-        glds_copy(reinterpret_cast<const char*>(d.gsplit), g_buf, tile_b, wave, lane);
-        if (wave == 3) glds_copy(reinterpret_cast<const char*>(d.mu32s), reinterpret_cast<char*>(mu_buf), d.TPB * 4, 0, lane);
+        __syncthreads();           // every wave is done with the LDS buffers and stage (previous work item)
+        glds_copy(reinterpret_cast<const char*>(d.gsplit) + static_cast<size_t>(pt_lo) * tile_b, g_buf + (pt_lo & 1) * tile_b,
+                  tile_b, wave, lane);
+        if (wave == 3)
+            glds_copy(reinterpret_cast<const char*>(d.mu32s + static_cast<size_t>(pt_lo) * d.TPB),
+                      reinterpret_cast<char*>(mu_buf + (pt_lo & 1) * d.TPB), d.TPB * 4, 0, lane);
         // ---- omega32 of the user -> LDS stage (also the logit error bound) ----
         float absdot = 0.0f, sq = 0.0f;
 #pragma unroll
         for (int s = 0; s < KH; ++s) {
             const uint32_t k = h * KH + s;
             float w = 0.0f;
-            if (active && k < d.K) w = static_cast<float>(d.omega[static_cast<size_t>(k) * d.n_pad + slot]);
+            if (active && k < d.K) w = static_cast<float>(d.omega[static_cast<size_t>(slot) * d.OMS + k]);
             omu[k] = w;
             absdot = fmaf(fabsf(w), d.stats[k], absdot);
             sq = fmaf(w, w, sq);
@@ -1248,9 +1265,9 @@ __global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 2 : 1)) k_draw_bf16(DevSim 
         f32x16 ya0, ya1, yb0, yb1;     // two chunk pairs in flight: MFMA of one overlaps the exp-sum of the other
         bool first = true;
         uint32_t ci_b = 0;             // chunk index of the pair held in yb
-        for (uint32_t ti = 0; ti < n_ptiles; ++ti) {
+        for (uint32_t ti = pt_lo; ti < pt_hi; ++ti) {
             __syncthreads();       // tile ti landed (hipcc drains vmcnt before the barrier); tile ti-1 is free
-            if (ti + 1 < n_ptiles) {
+            if (ti + 1 < pt_hi) {
                 const uint32_t nb = (ti + 1) & 1;
                 glds_copy(reinterpret_cast<const char*>(d.gsplit) + static_cast<size_t>(ti + 1) * tile_b,
                           g_buf + nb * tile_b, tile_b, wave, lane);
@@ -1260,7 +1277,7 @@ __global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 2 : 1)) k_draw_bf16(DevSim 
             }
             const char* g_tile = g_buf + (ti & 1) * tile_b;
             const float* mu_tile = mu_buf + (ti & 1) * d.TPB;
-            const uint32_t c_end = min(cpt, d.n_chunks - ti * cpt);     // multiple of 4
+            const uint32_t c_end = min(cpt, chunk_hi - ti * cpt);       // multiple of 4
             for (uint32_t c = 0; c < c_end; c += 4) {
                 const uint32_t ci = ti * cpt + c;
                 mfma_pair(g_tile, mu_tile, c, ya0, ya1);
@@ -1287,12 +1304,60 @@ __global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 2 : 1)) k_draw_bf16(DevSim 
         expsum_chunk(yb0, ci_b);               // drain the pipeline
         expsum_chunk(yb1, ci_b + 1);
         flush_sc(ci_b);
-        search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h);
+        if (S == 1) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h);
+    }
+}
+
+// second kernel of the sliced mode: the search over the sums all slices of a user tile left
+template <int KH>
+__global__ void __launch_bounds__(kBlock) k_draw_search(DevSim d, uint32_t t) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* om_stage = reinterpret_cast<float*>(smem_raw);             // [4 waves][32 users][2KH]
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const uint32_t n_tiles = (n_o + 127) / 128;
+    const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const float mumax = d.stats[2 * KH + 1], g2max = d.stats[2 * KH];
+    float* omu = om_stage + (wave * 32 + j) * 2 * KH;
+    for (uint32_t tb = blockIdx.x; tb < n_tiles; tb += gridDim.x) {
+        const size_t wslot = static_cast<size_t>(tb) * 4 + wave;
+        const uint32_t pos = tb * 128 + wave * 32 + j;
+        const bool active = pos < n_o;
+        const uint32_t slot = active ? cur[pos] : 0u;
+        float absdot = 0.0f, sq = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KH; ++s) {
+            const uint32_t k = h * KH + s;
+            float w = 0.0f;
+            if (active && k < d.K) w = static_cast<float>(d.omega[static_cast<size_t>(slot) * d.OMS + k]);
+            omu[k] = w;
+            absdot = fmaf(fabsf(w), d.stats[k], absdot);
+            sq = fmaf(w, w, sq);
+        }
+        absdot += swap32(absdot);
+        sq += swap32(sq);
+        const float Ahat = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        search_and_emit<KH>(d, t, d.sc_scratch + wslot * kMaxSC * 32, d.chunk_scratch + wslot * d.n_chunks * 32, omu,
+                            Ahat, 0, active, pos, slot, j, h);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
 // kernel selection by (KH, N1, N2, N3)
-typedef void (*draw_kernel_t)(DevSim, uint32_t);
+typedef void (*draw_kernel_t)(DevSim, uint32_t, uint32_t);
+typedef void (*search_kernel_t)(DevSim, uint32_t);
+search_kernel_t search_kernel_for(const DevSim& d) {
+    switch (d.KH) {
+        case 4: return k_draw_search<4>;
+        case 10: return k_draw_search<10>;
+        case 16: return k_draw_search<16>;
+        case 32: return k_draw_search<32>;
+        default: return k_draw_search<64>;
+    }
+}
 draw_kernel_t bf16_kernel_for(const DevSim& d) {
 #define RG_CASE(kh, a, b, c) if (d.KH == kh && d.N1 == a && d.N2 == b && d.N3 == c) return k_draw_bf16<kh, a, b, c>;
     RG_CASE(4, 1, 1, 1) RG_CASE(4, 2, 1, 1) RG_CASE(10, 3, 2, 1) RG_CASE(10, 4, 3, 2)
@@ -1336,9 +1401,23 @@ __global__ void __launch_bounds__(kBlock) k_advance(DevSim d, uint32_t t, const 
                 uint32_t a;
                 if (d.policy == RG_POLICY_EXTERNAL) { a = static_cast<uint32_t>(actions[slot]); ps = __builtin_nan(""); }
                 else a = policy_act(d, slot, user, t, &ps);
+                // beta[a] . omega, k ascending (the oracle's association); loads are issued eight
+                // k at a time — a plain loop leaves one HBM round trip per k on the critical path
                 const double* b = d.beta + static_cast<size_t>(a) * d.K;
+                const double* om = d.omega + static_cast<size_t>(slot) * d.OMS;
                 double x = 0.0;
-                for (uint32_t k = 0; k < d.K; ++k) x += b[k] * d.omega[static_cast<size_t>(k) * d.n_pad + slot];
+                for (uint32_t k0 = 0; k0 < d.K; k0 += 8) {
+                    double wv[8], bv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const uint32_t k = min(k0 + i, d.K - 1);
+                        wv[i] = om[k];
+                        bv[i] = b[k];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (k0 + i < d.K) x += bv[i] * wv[i];
+                }
                 const double ctr = ff64(x + d.mu_b[a]);
                 const double p0 = 1.0 - ctr;
                 click = (p0 / (p0 + ctr)) <= rg_uniform(w.w[0], w.w[1]);
@@ -1359,9 +1438,9 @@ __global__ void __launch_bounds__(kBlock) k_advance(DevSim d, uint32_t t, const 
                 for (uint32_t j = 0; 2 * j < d.K; ++j) {
                     double z0, z1;
                     normal_pair(d.seed, user, t, j, RG_DRAW_DRIFT, &z0, &z1);
-                    double* o0 = d.omega + static_cast<size_t>(2 * j) * d.n_pad + slot;
+                    double* o0 = d.omega + static_cast<size_t>(slot) * d.OMS + 2 * j;
                     *o0 = *o0 + d.sigma_omega * z0;
-                    if (2 * j + 1 < d.K) { double* o1 = o0 + d.n_pad; *o1 = *o1 + d.sigma_omega * z1; }
+                    if (2 * j + 1 < d.K) { double* o1 = o0 + 1; *o1 = *o1 + d.sigma_omega * z1; }
                 }
             }
             if (click) ns = RG_STATE_ORGANIC;          // abstract.py:180-181
@@ -1446,7 +1525,7 @@ __global__ void __launch_bounds__(kBlock) k_export_omega(DevSim d, double* out) 
     for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
          i += static_cast<size_t>(gridDim.x) * kBlock) {
         const size_t u = i / d.K, k = i % d.K;
-        out[i] = d.omega[k * d.n_pad + u];
+        out[i] = d.omega[u * d.OMS + k];
     }
 }
 
@@ -1569,8 +1648,16 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     if (int rc = prof_mark(sim, st)) return rc;
     // 1. organic product draws of this step (read omega before the transition drifts it)
     if (d.use_mfma == 2) {
-        const int grid = grid_for(upper, 128);
-        hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid), dim3(kBlock), sim->bf16_smem, st, d, t);
+        // few user tiles: slice the products so that the step's latency is a slice, not a sweep
+        const uint32_t tiles_up = (upper + 127) / 128;
+        uint32_t S = tiles_up >= 1024 ? 1u : 2048u / (tiles_up ? tiles_up : 1u);
+        if (S > d.n_sc) S = d.n_sc;
+        if (S < 1) S = 1;
+        const int grid = grid_for(static_cast<uint64_t>(tiles_up) * S, 1);
+        hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid), dim3(kBlock), sim->bf16_smem, st, d, t, S);
+        if (S > 1)
+            hipLaunchKernelGGL(search_kernel_for(d), dim3(grid_for(upper, 128)), dim3(kBlock),
+                               sizeof(float) * 4 * 32 * 2 * d.KH, st, d, t);
         if (int rc = prof_mark(sim, st)) return rc;
         launch_exact(sim, t, 1, upper / 100 + 16, st);
     } else if (d.use_mfma) {
