@@ -795,6 +795,10 @@ constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kRescaleGap = 57.0f;        // re-reference when a logit exceeds the reference by > ~40 nats
 constexpr double kDeltaFixed = 3.0e-5;      // exp / summation / constant-rounding budget
 constexpr double kDeltaPerRescale = 6.0e-6;
+// split-bf16 kernel: references are integers (exact in bf16 pieces, exact exp2 of differences) and
+// the logit leaves the MFMA already referenced and log2-scaled, so only the exp2 ulp (x2), the
+// summation trees (~20 roundings) and the recompute's own fma/constant roundings remain: < 5e-6
+constexpr double kDeltaFixedBf16 = 1.0e-5;
 
 __device__ __forceinline__ float wave_scan_f32(float x, int lane) {
     for (int o = 1; o < 64; o <<= 1) {
@@ -831,11 +835,15 @@ __device__ __forceinline__ float swap32(float x) {
 // certify the pick against float64 (see the header of k_draw_mfma) and emit the row or hand
 // the user to k_draw_exact.  `om` = this lane's user's omega32 vector in LDS (2*KH floats).
 // ------------------------------------------------------------------------------------------
+// where the exp-sum of chunk c of user column j sits in a wave's chunk scratch:
+// fp32 kernel: [chunk][32 users]; split-bf16 kernel: [tile of 4 chunks][32 users][4]
+#define CHUNK_AT(c, j) (tiled4 ? (((c) >> 2) * 32 + (j)) * 4 + ((c) & 3) : (c) * 32 + (j))
+
 template <int KH>
 __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, const float2* scr,
                                                 const float* scr_chunk, const float* om_lds,
                                                 float Ahat, int n_resc, bool active, uint32_t pos,
-                                                uint32_t slot, int j, int h) {
+                                                uint32_t slot, int j, int h, bool tiled4, double delta_fixed) {
         n_resc = max(n_resc, __shfl_xor(n_resc, 32));
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // scratch: written by lanes < 32, read below
 
@@ -871,14 +879,14 @@ __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, con
             const uint32_t c0 = sc_star * d.sc_chunks, c1 = min(c0 + d.sc_chunks, d.n_chunks);
             double run = pb;
             for (uint32_t c = c0; c < c1; ++c) {
-                const double Wd = static_cast<double>(scr_chunk[c * 32 + j] * f_star);
+                const double Wd = static_cast<double>(scr_chunk[CHUNK_AT(c, j)] * f_star);
                 if (!found_c && run + Wd > tau) { found_c = true; c_star = c; pb = run; }
                 if (!found_c) run += Wd;
             }
         }
         found_c = found_c && found_sc;
         const double delta = static_cast<double>(d.K + 5) * 5.9604644775390625e-08 * static_cast<double>(Ahat) +
-                             kDeltaFixed + kDeltaPerRescale * n_resc;
+                             delta_fixed + kDeltaPerRescale * n_resc;
 
         // ---- search, part 2: recompute the 32 products of chunk c_star, 16 per lane, in registers ----
         uint32_t my_v = 0;
@@ -1088,7 +1096,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_draw_mfma(DevSim
         softmax_chunk(acc_p1, ci_p + 1);
         flush_sc(ci_p);
         search_and_emit<KH>(d, t, scr, scr_chunk, om_stage + (wave * 32 + j) * 2 * KH, Ahat, n_resc,
-                            active, pos, slot, j, h);
+                            active, pos, slot, j, h, false, kDeltaFixed);
     }
 }
 
@@ -1115,7 +1123,11 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_draw_mfma(DevSim
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
 template <int KH, int N1, int N2, int N3>
-__global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 2 : 1)) k_draw_bf16(DevSim d, uint32_t t, uint32_t S) {
+__global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 3 : 1)) k_draw_bf16(DevSim d, uint32_t t, uint32_t S) {
+    // Register-lean form: ONE chunk (one accumulator) in flight per wave and no software pipeline,
+    // so that 4 waves fit on a SIMD (<= 128 VGPRs) — the matrix pipe, the exp unit and the LDS of
+    // a SIMD are kept busy by wave-level interleaving.  (A two-accumulator, ping-pong form of this
+    // kernel needed 228+ VGPRs = 2 waves per SIMD and was latency-bound at the same speed as one.)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t tile_b = d.TPB * d.RS;                             // bytes per split tile
     char* g_buf = smem_raw;                                           // [2][TPB][RS]
@@ -1188,7 +1200,7 @@ __global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 2 : 1)) k_draw_bf16(DevSim 
         }
         // the reference rides in the MFMA: columns 16 N1 - 3 .. 16 N1 - 1 of A are 1, the matching
         // B elements (lanes h == 1, elements 5..7 of the last k-step) hold the 3 bf16 pieces of -q
-        float q = 0.0f;            // per-USER reference in log2 units, constant within a super-chunk
+        float q = 0.0f;            // per-USER reference in log2 units (an integer), constant within a super-chunk
         auto set_reference = [&](float qn) {
             q = qn;
             unsigned short sp[3];
@@ -1204,56 +1216,39 @@ __global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 2 : 1)) k_draw_bf16(DevSim 
         float wcmax = 0.0f;        // largest chunk sum of the current super-chunk
         int n_resc = 0;
 
-        // logits (log2 units, reference already subtracted) of one chunk pair
-        auto mfma_pair = [&](const char* g_tile, const float* mu_tile, uint32_t c, f32x16& acc0, f32x16& acc1) {
+        // logits (log2 units, reference already subtracted) of one 32-product chunk
+        auto mfma_chunk = [&](const char* g_tile, const float* mu_tile, uint32_t c, f32x16& acc) {
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
                 const float4 m0 = *reinterpret_cast<const float4*>(mu_tile + c * 32 + 8 * qq + 4 * h);
-                const float4 m1 = *reinterpret_cast<const float4*>(mu_tile + c * 32 + 32 + 8 * qq + 4 * h);
-                acc0[4 * qq + 0] = m0.x; acc0[4 * qq + 1] = m0.y; acc0[4 * qq + 2] = m0.z; acc0[4 * qq + 3] = m0.w;
-                acc1[4 * qq + 0] = m1.x; acc1[4 * qq + 1] = m1.y; acc1[4 * qq + 2] = m1.z; acc1[4 * qq + 3] = m1.w;
+                acc[4 * qq + 0] = m0.x; acc[4 * qq + 1] = m0.y; acc[4 * qq + 2] = m0.z; acc[4 * qq + 3] = m0.w;
             }
-            const char* arow0 = g_tile + (c * 32 + j) * d.RS + 16 * h;
-            const char* arow1 = arow0 + 32 * d.RS;
-            bf16x8 A0[N1], A1[N1];
+            const char* arow = g_tile + (c * 32 + j) * d.RS + 16 * h;
+            bf16x8 A[N1];
 #pragma unroll
-            for (int s = 0; s < N1; ++s) {
-                A0[s] = *reinterpret_cast<const bf16x8*>(arow0 + 32 * s);
-                A1[s] = *reinterpret_cast<const bf16x8*>(arow1 + 32 * s);
-            }
+            for (int s = 0; s < N1; ++s) A[s] = *reinterpret_cast<const bf16x8*>(arow + 32 * s);
 #pragma unroll
-            for (int s = 0; s < N1; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[s], B1[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[s], B1[s], acc1, 0, 0, 0);
-            }
+            for (int s = 0; s < N1; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s], B1[s], acc, 0, 0, 0);
 #pragma unroll
-            for (int s = 0; s < N2; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[s], B2[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[s], B2[s], acc1, 0, 0, 0);
-            }
+            for (int s = 0; s < N2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s], B2[s], acc, 0, 0, 0);
 #pragma unroll
-            for (int s = 0; s < N3; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[s], B3[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[s], B3[s], acc1, 0, 0, 0);
-            }
+            for (int s = 0; s < N3; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s], B3[s], acc, 0, 0, 0);
         };
-        // exp-sum of one finished chunk: 16 exp2 + a tree sum per lane, both lanes of the user added
-        auto expsum_chunk = [&](const f32x16& y, uint32_t ci) {
-            float e[16];
+        // exp-sum of one chunk: 16 exp2 + a (packed) tree sum per lane; returns this lane's partial
+        using f32x2 = __attribute__((ext_vector_type(2))) float;
+        auto expsum_chunk = [&](f32x16& y) -> float {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) e[r] = __builtin_amdgcn_exp2f(y[r]);
-#pragma unroll
-            for (int w2 = 8; w2 > 0; w2 >>= 1)
-#pragma unroll
-                for (int r = 0; r < w2; ++r) e[r] += e[r + w2];
-            const float wc = e[0] + swap32(e[0]);
-            if (h == 0) scr_chunk[ci * 32 + j] = wc;
-            wcmax = fmaxf(wcmax, wc);
-            s_sc += static_cast<double>(wc);
+            for (int r = 0; r < 16; ++r) y[r] = __builtin_amdgcn_exp2f(y[r]);
+            f32x2 p0 = {y[0], y[1]}, p1 = {y[2], y[3]}, p2 = {y[4], y[5]}, p3 = {y[6], y[7]};
+            const f32x2 p4 = {y[8], y[9]}, p5 = {y[10], y[11]}, p6 = {y[12], y[13]}, p7 = {y[14], y[15]};
+            p0 += p4; p1 += p5; p2 += p6; p3 += p7;        // v_pk_add_f32
+            p0 += p2; p1 += p3;
+            p0 += p1;
+            return p0[0] + p0[1];
         };
         // end of a super-chunk: store {sum, reference}; re-reference if a sum grew past 2^48
-        auto flush_sc = [&](uint32_t ci) {
-            if (h == 0) scr[(ci / d.sc_chunks) * 32 + j] = make_float2(static_cast<float>(s_sc), q);
+        auto flush_sc = [&](uint32_t sc) {
+            scr[sc * 32 + j] = make_float2(static_cast<float>(s_sc), q);
             s_sc = 0.0;
             if (wcmax > 2.8e14f) {     // some logit is >= ~43 above the reference (log2 units)
                 set_reference(q + floorf(__builtin_amdgcn_logf(wcmax)));   // v_log_f32 = log2
@@ -1262,9 +1257,9 @@ __global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 2 : 1)) k_draw_bf16(DevSim 
             wcmax = 0.0f;
         };
 
-        f32x16 ya0, ya1, yb0, yb1;     // two chunk pairs in flight: MFMA of one overlaps the exp-sum of the other
-        bool first = true;
-        uint32_t ci_b = 0;             // chunk index of the pair held in yb
+        f32x16 y;
+        uint32_t sc_cur = chunk_lo / d.sc_chunks;              // super-chunk being accumulated
+        uint32_t sc_left = d.sc_chunks / 4;                    // tiles left in it (TPB = 128: 4 chunks per tile)
         for (uint32_t ti = pt_lo; ti < pt_hi; ++ti) {
             __syncthreads();       // tile ti landed (hipcc drains vmcnt before the barrier); tile ti-1 is free
             if (ti + 1 < pt_hi) {
@@ -1277,34 +1272,30 @@ __global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 2 : 1)) k_draw_bf16(DevSim 
             }
             const char* g_tile = g_buf + (ti & 1) * tile_b;
             const float* mu_tile = mu_buf + (ti & 1) * d.TPB;
-            const uint32_t c_end = min(cpt, chunk_hi - ti * cpt);       // multiple of 4
-            for (uint32_t c = 0; c < c_end; c += 4) {
-                const uint32_t ci = ti * cpt + c;
-                mfma_pair(g_tile, mu_tile, c, ya0, ya1);
-                if (first) {
-                    // very first pair of the user tile: computed with reference 0; its max sets the
-                    // reference, then it is recomputed so that every stored sum shares a reference
-                    float cm = fmaxf(ya0[0], ya1[0]);
+            if (ti == pt_lo) {
+                // first chunk of the work item with reference 0: its max (an integer after ceil, so
+                // exact in bf16 pieces and in exp2 differences) becomes the reference
+                mfma_chunk(g_tile, mu_tile, 0, y);
+                float cm = y[0];
 #pragma unroll
-                    for (int r = 1; r < 16; ++r) cm = fmaxf(cm, fmaxf(ya0[r], ya1[r]));
-                    set_reference(fmaxf(ceilf(fmaxf(cm, swap32(cm))), -1.0e30f));
-                    mfma_pair(g_tile, mu_tile, c, ya0, ya1);
-                    first = false;
-                } else {
-                    expsum_chunk(yb0, ci_b);
-                    expsum_chunk(yb1, ci_b + 1);
-                    if ((ci_b + 2) % d.sc_chunks == 0) flush_sc(ci_b);
-                }
-                mfma_pair(g_tile, mu_tile, c + 2, yb0, yb1);
-                expsum_chunk(ya0, ci);
-                expsum_chunk(ya1, ci + 1);
-                ci_b = ci + 2;
+                for (int r = 1; r < 16; ++r) cm = fmaxf(cm, y[r]);
+                set_reference(fmaxf(ceilf(fmaxf(cm, swap32(cm))), -1.0e30f));
             }
+            // the four chunks of the tile; their sums leave as one 16-byte store per user
+            float4 w4;
+            mfma_chunk(g_tile, mu_tile, 0, y); w4.x = expsum_chunk(y);
+            mfma_chunk(g_tile, mu_tile, 1, y); w4.y = expsum_chunk(y);
+            mfma_chunk(g_tile, mu_tile, 2, y); w4.z = expsum_chunk(y);
+            mfma_chunk(g_tile, mu_tile, 3, y); w4.w = expsum_chunk(y);
+            w4.x += swap32(w4.x); w4.y += swap32(w4.y); w4.z += swap32(w4.z); w4.w += swap32(w4.w);
+            // scratch layout [tile][user][4 chunks]; both lanes of the user hold the same sums: no branch
+            *reinterpret_cast<float4*>(scr_chunk + (static_cast<size_t>(ti) * 32 + j) * 4) = w4;
+            wcmax = fmaxf(fmaxf(wcmax, fmaxf(w4.x, w4.y)), fmaxf(w4.z, w4.w));
+            s_sc += static_cast<double>((w4.x + w4.y) + (w4.z + w4.w));
+            if (--sc_left == 0) { flush_sc(sc_cur); ++sc_cur; sc_left = d.sc_chunks / 4; }
         }
-        expsum_chunk(yb0, ci_b);               // drain the pipeline
-        expsum_chunk(yb1, ci_b + 1);
-        flush_sc(ci_b);
-        if (S == 1) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h);
+        if (sc_left != d.sc_chunks / 4) flush_sc(sc_cur);
+        if (S == 1) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, kDeltaFixedBf16);
     }
 }
 
@@ -1341,7 +1332,7 @@ __global__ void __launch_bounds__(kBlock) k_draw_search(DevSim d, uint32_t t) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         search_and_emit<KH>(d, t, d.sc_scratch + wslot * kMaxSC * 32, d.chunk_scratch + wslot * d.n_chunks * 32, omu,
-                            Ahat, 0, active, pos, slot, j, h);
+                            Ahat, 0, active, pos, slot, j, h, true, kDeltaFixedBf16);
         __builtin_amdgcn_wave_barrier();
     }
 }
