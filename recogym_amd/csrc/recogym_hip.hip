@@ -574,6 +574,32 @@ __device__ __forceinline__ void write_organic_row(const DevSim& d, uint32_t t, u
     }
 }
 
+// exp(x) in float64 for x <= ~700 (0 for x <= -750, incl. -inf): Cody-Waite reduction by ln 2 and a
+// degree-13 Taylor polynomial on |r| <= 0.3466 (remainder 4e-18), ~20 instructions instead of the
+// device library's ~55.  Accuracy ~1 ulp; the float64 path only has to agree with the oracle's
+// libm exp to ~1e-15 relative (deviations at that level cannot move an index).
+__device__ __forceinline__ double exp64(double x) {
+    x = fmax(x, -750.0);
+    const double kf = rint(x * 1.4426950408889634074);
+    double r = fma(-kf, 6.93147180369123816490e-01, x);
+    r = fma(-kf, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;            // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);          // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);         // 1/11!
+    p = fma(p, r, 2.755731922398589e-07);         // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);        // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);          // 1/8!
+    p = fma(p, r, 1.984126984126984e-04);         // 1/7!
+    p = fma(p, r, 1.388888888888889e-03);         // 1/6!
+    p = fma(p, r, 8.333333333333333e-03);         // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);        // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);        // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, static_cast<int>(kf));
+}
+
 // inclusive scan of x over the 64 lanes of the wave
 __device__ __forceinline__ double wave_scan(double x, int lane) {
     for (int o = 1; o < 64; o <<= 1) {
@@ -626,6 +652,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums(DevSim d, uint32_t t, int
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t n_chunks = d.PT / 64;
+    const uint32_t n_cc = (n_chunks + 7) / 8;                  // coarse chunks of 8 x 64 products
     // LDS: Gamma^T tile [K][64] doubles, mu tile [64], omega [16 users][K]
     double* g_tile = reinterpret_cast<double*>(smem_raw);
     double* mu_tile = g_tile + static_cast<size_t>(d.K) * 64;
@@ -634,15 +661,18 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums(DevSim d, uint32_t t, int
     const uint32_t n = from_list ? d.exact_cnt[t] : n_o;
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
     const uint32_t n_groups = (n + kExactUsers - 1) / kExactUsers;
-    const uint32_t cps = (n_chunks + S - 1) / S;               // chunks per slice
+    const uint32_t cps = ((n_cc + S - 1) / S) * 8;             // chunks per slice (whole coarse chunks)
     const uint32_t n_work = n_groups * S;
 
     for (uint32_t wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
         const uint32_t grp = wk / S, slice = wk % S;
         const uint32_t c0 = slice * cps, c1 = min(c0 + cps, n_chunks);
+        if (c0 >= c1) continue;
         uint32_t w_idx[kUPW];
         bool act[kUPW];
-        double M[kUPW];
+        double M[kUPW], part[kUPW];
+#pragma unroll
+        for (int u = 0; u < kUPW; ++u) part[u] = 0.0;
         __syncthreads();      // previous work item's LDS is free
         double* om = om_all + static_cast<size_t>(wave * kUPW) * d.K;
 #pragma unroll
@@ -655,20 +685,46 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums(DevSim d, uint32_t t, int
             // MFMA kernel reuses that kernel's reference, pure float64 mode uses k_exact_ref's
             M[u] = (mode == 1 && act[u]) ? static_cast<double>(d.exact_ref[w_idx[u]]) * 0.69314718055994530942 : 0.0;
             for (uint32_t k = lane; k < d.K; k += 64)
-                om[u * d.K + k] = act[u] ? d.omega[static_cast<size_t>(slot) * d.OMS + k] : 0.0;
+                om[k * kUPW + u] = act[u] ? d.omega[static_cast<size_t>(slot) * d.OMS + k] : 0.0;   // [k][user]
         }
+        // The next chunk's Gamma^T tile is fetched into registers while the current one is being
+        // used (the tile is K*64 doubles = K/4 per thread; staged through registers for K <= 32),
+        // so the L2/HBM latency of the staging is off the per-chunk critical path.
+        constexpr int kPF = 8;
+        const bool prefetch = d.K * 64 <= kPF * kBlock;
+        double pf[kPF];
+        double pf_mu = 0.0;
+        auto fetch = [&](uint32_t c) {
+#pragma unroll
+            for (int i = 0; i < kPF; ++i) {
+                const uint32_t idx = threadIdx.x + i * kBlock;
+                if (idx < d.K * 64) pf[i] = d.gammaT[static_cast<size_t>(idx >> 6) * d.PT + c * 64 + (idx & 63)];
+            }
+            if (threadIdx.x < 64) { const uint32_t p = c * 64 + threadIdx.x; pf_mu = p < d.P ? d.mu_o[p] : -INFINITY; }
+        };
+        if (prefetch) fetch(c0);
         for (uint32_t c = c0; c < c1; ++c) {
             __syncthreads();
             // stage Gamma^T[:, c*64 .. c*64+63] and mu (coalesced: 64 consecutive doubles per k)
-            for (uint32_t i = threadIdx.x; i < d.K * 64; i += kBlock) {
-                const uint32_t k = i >> 6, pp = i & 63;
-                g_tile[i] = d.gammaT[static_cast<size_t>(k) * d.PT + c * 64 + pp];
-            }
-            if (threadIdx.x < 64) {
-                const uint32_t p = c * 64 + threadIdx.x;
-                mu_tile[threadIdx.x] = p < d.P ? d.mu_o[p] : -INFINITY;
+            if (prefetch) {
+#pragma unroll
+                for (int i = 0; i < kPF; ++i) {
+                    const uint32_t idx = threadIdx.x + i * kBlock;
+                    if (idx < d.K * 64) g_tile[idx] = pf[i];
+                }
+                if (threadIdx.x < 64) mu_tile[threadIdx.x] = pf_mu;
+            } else {
+                for (uint32_t i = threadIdx.x; i < d.K * 64; i += kBlock) {
+                    const uint32_t k = i >> 6, pp = i & 63;
+                    g_tile[i] = d.gammaT[static_cast<size_t>(k) * d.PT + c * 64 + pp];
+                }
+                if (threadIdx.x < 64) {
+                    const uint32_t p = c * 64 + threadIdx.x;
+                    mu_tile[threadIdx.x] = p < d.P ? d.mu_o[p] : -INFINITY;
+                }
             }
             __syncthreads();
+            if (prefetch && c + 1 < c1) fetch(c + 1);
             // same association as the oracle / numpy: (sum_k Gamma[p][k] omega[k]) + mu[p]
             double l[kUPW];
 #pragma unroll
@@ -676,15 +732,25 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums(DevSim d, uint32_t t, int
 #pragma unroll 4
             for (uint32_t k = 0; k < d.K; ++k) {
                 const double g = g_tile[k * 64 + lane];
-#pragma unroll
-                for (int u = 0; u < kUPW; ++u) l[u] += g * om[u * d.K + k];
+                const double4 o4 = *reinterpret_cast<const double4*>(om + k * kUPW);   // 2 broadcast ds_read_b128
+                l[0] += g * o4.x; l[1] += g * o4.y; l[2] += g * o4.z; l[3] += g * o4.w;
             }
             const double mu = mu_tile[lane];        // -inf for products >= P: exp() gives exactly 0
+            // lane-local accumulation; one cross-lane reduction per coarse chunk (8 x 64 products) —
+            // float64 cross-lane ops go through the LDS crossbar and dominated this kernel
 #pragma unroll
             for (int u = 0; u < kUPW; ++u) {
                 l[u] += mu;
-                const double r = mode == 0 ? wave_max(l[u]) : __shfl(wave_scan(exp(l[u] - M[u]), lane), 63);
-                if (lane == 0 && act[u]) d.exact_sums[static_cast<size_t>(w_idx[u]) * n_chunks + c] = r;
+                part[u] = mode == 0 ? fmax(part[u] == 0.0 && (c & 7) == 0 ? -INFINITY : part[u], l[u])
+                                    : part[u] + exp64(l[u] - M[u]);
+            }
+            if ((c & 7) == 7 || c + 1 == c1) {
+#pragma unroll
+                for (int u = 0; u < kUPW; ++u) {
+                    const double r = mode == 0 ? wave_max(part[u]) : wave_sum(part[u]);
+                    if (lane == 0 && act[u]) d.exact_sums[static_cast<size_t>(w_idx[u]) * n_cc + (c >> 3)] = r;
+                    part[u] = 0.0;
+                }
             }
         }
     }
@@ -693,12 +759,12 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums(DevSim d, uint32_t t, int
 // pure float64 mode: the reference of every user = its max logit (reco_env_v1.py:121)
 __global__ void __launch_bounds__(kBlock) k_exact_ref(DevSim d, uint32_t t) {
     const int lane = lane_id();
-    const uint32_t n_chunks = d.PT / 64;
+    const uint32_t n_cc = (d.PT / 64 + 7) / 8;
     const uint32_t n = d.step_cnt[2 * t + RG_STATE_ORGANIC];
     const uint32_t waves_total = gridDim.x * (kBlock / 64);
     for (uint32_t w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < n; w += waves_total) {
         double m = -INFINITY;
-        for (uint32_t c = lane; c < n_chunks; c += 64) m = fmax(m, d.exact_sums[static_cast<size_t>(w) * n_chunks + c]);
+        for (uint32_t c = lane; c < n_cc; c += 64) m = fmax(m, d.exact_sums[static_cast<size_t>(w) * n_cc + c]);
         m = wave_max(m);
         if (lane == 0) d.exact_ref[w] = static_cast<float>(m * 1.4426950408889634074);
     }
@@ -709,6 +775,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int
     const int wave = threadIdx.x >> 6, lane = lane_id();
     double* om = reinterpret_cast<double*>(smem_raw) + static_cast<size_t>(wave) * d.K;
     const uint32_t n_chunks = d.PT / 64;
+    const uint32_t n_cc = (n_chunks + 7) / 8;
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
     const uint32_t n = from_list ? d.exact_cnt[t] : n_o;
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
@@ -718,47 +785,52 @@ __global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int
         const uint32_t slot = cur[pos];
         const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
         const double M = static_cast<double>(d.exact_ref[w]) * 0.69314718055994530942;
-        const double* sums = d.exact_sums + static_cast<size_t>(w) * n_chunks;
+        const double* sums = d.exact_sums + static_cast<size_t>(w) * n_cc;
         for (uint32_t k = lane; k < d.K; k += 64) om[k] = d.omega[static_cast<size_t>(slot) * d.OMS + k];
-        // total, in the same association the prefix below uses
+        // total over the coarse-chunk sums, in the same association the prefix below uses
         double total = 0.0;
-        for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64) {
+        for (uint32_t c0 = 0; c0 < n_cc; c0 += 64) {
             const uint32_t c = c0 + lane;
-            total += __shfl(wave_scan(c < n_chunks ? sums[c] : 0.0, lane), 63);
+            total += __shfl(wave_scan(c < n_cc ? sums[c] : 0.0, lane), 63);
         }
         // The reference normalises p = e / sum(e) before its cumsum and divides by cdf[-1];
         // dividing every term by the same positive constants moves the decision only at the
         // 1e-16 level, so the running sum of e is compared with u * total directly.
         const rg_u32x4 rw = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
         const double target = rg_uniform(rw.w[0], rw.w[1]) * total;
-        // first chunk whose inclusive running sum exceeds the target, and the sum before it
-        uint32_t cstar = n_chunks - 1;
+        // first coarse chunk whose inclusive running sum exceeds the target, and the sum before it
+        uint32_t ccstar = n_cc - 1;
         double before = 0.0, run = 0.0;
         bool found = false;
-        for (uint32_t c0 = 0; c0 < n_chunks && !found; c0 += 64) {
+        for (uint32_t c0 = 0; c0 < n_cc && !found; c0 += 64) {
             const uint32_t c = c0 + lane;
-            const double x = c < n_chunks ? sums[c] : 0.0;
+            const double x = c < n_cc ? sums[c] : 0.0;
             const double incl = wave_scan(x, lane);
-            const unsigned long long hit = __ballot(c < n_chunks && run + incl > target);
+            const unsigned long long hit = __ballot(c < n_cc && run + incl > target);
             if (hit) {
                 const int L = __builtin_ctzll(hit);
-                cstar = c0 + L;
+                ccstar = c0 + L;
                 before = run + __shfl(incl - x, L);
                 found = true;
             } else run += __shfl(incl, 63);
         }
-        if (!found) before = run - sums[n_chunks - 1];      // u * total rounded up to total
+        if (!found) before = run - sums[n_cc - 1];          // u * total rounded up to total
         __builtin_amdgcn_wave_barrier();
-        // recompute that chunk (same arithmetic as k_exact_sums) and find the product inside it
-        const uint32_t p = cstar * 64 + lane;
-        double lg = 0.0;
-        const double* g = d.gammaT + p;                      // PT columns: always in range
-        for (uint32_t k = 0; k < d.K; ++k) lg += g[static_cast<size_t>(k) * d.PT] * om[k];
-        lg = p < d.P ? lg + d.mu_o[p] : -INFINITY;
-        const double xs = before + wave_scan(exp(lg - M), lane);
-        const unsigned long long hit = __ballot(p < d.P && xs > target);
-        const uint32_t v = hit ? cstar * 64 + static_cast<uint32_t>(__builtin_ctzll(hit))
-                               : min(cstar * 64 + 63, d.P - 1);
+        // walk the 8 x 64 products of that coarse chunk in product order
+        uint32_t v = min(ccstar * 512 + 511, d.P - 1);       // if rounding leaves no hit: its last product
+        double acc = before;
+        for (uint32_t i = 0; i < 8; ++i) {
+            const uint32_t p = ccstar * 512 + i * 64 + lane;
+            if (ccstar * 8 + i >= n_chunks) break;
+            double lg = 0.0;
+            const double* g = d.gammaT + p;                  // PT columns: always in range
+            for (uint32_t k = 0; k < d.K; ++k) lg += g[static_cast<size_t>(k) * d.PT] * om[k];
+            lg = p < d.P ? lg + d.mu_o[p] : -INFINITY;
+            const double incl = wave_scan(exp64(lg - M), lane);
+            const unsigned long long hit = __ballot(p < d.P && acc + incl > target);
+            if (hit) { v = ccstar * 512 + i * 64 + static_cast<uint32_t>(__builtin_ctzll(hit)); break; }
+            acc += __shfl(incl, 63);
+        }
         if (lane == 0) {
             write_organic_row(d, t, pos, user, v);
             if (d.hist_cap) history_add(d, slot, v);
@@ -1618,7 +1690,7 @@ void launch_exact(rg_sim* sim, uint32_t t, int from_list, uint64_t est, hipStrea
     const uint32_t n_chunks = d.PT / 64;
     const uint64_t groups = (est + kExactUsers - 1) / kExactUsers;
     uint32_t S = static_cast<uint32_t>(2048 / (groups ? groups : 1));
-    if (S > n_chunks / 4) S = n_chunks / 4;
+    if (S > (n_chunks + 7) / 8) S = (n_chunks + 7) / 8;
     if (S < 1) S = 1;
     const int grid = grid_for(groups * S, 1);
     const size_t smem = sizeof(double) * (static_cast<size_t>(d.K) * 64 + 64 + kExactUsers * d.K);
