@@ -179,7 +179,7 @@ def main():
         launches = max(prof['steps'], 1)
         avg_ms = prof['draw_mfma_ms'] / launches
         achieved = flops / (prof['draw_mfma_ms'] * 1e-3) / 1e12 if prof['draw_mfma_ms'] else 0.0
-        roofline = dict(bound='mfma', kernel='k_draw_mfma', achieved=round(achieved, 3),
+        roofline = dict(bound='mfma', kernel='k_draw_bf16 (split-bf16 MFMA organic draw; fp32-equivalent flops 2*P*K per draw)', achieved=round(achieved, 3),
                         peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                         frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
                         launches=launches, avg_launch_ms=round(avg_ms, 4),
@@ -206,7 +206,7 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f64 state/click/transition math, f32 MFMA logits certified against f64',
+            'dtype': 'f64 (state, click, transition, policy); organic logits on MFMA as 3-way split bf16 = fp32-class, every index certified against f64',
             'data': 'synthetic',
             'config': {'workload': f'{args.workload}: reco-gym-v1 P={cfg.num_products} K={cfg.K} '
                                    f'sigma_omega={cfg.sigma_omega} policy={WORKLOADS[args.workload][2]}',
