@@ -184,6 +184,7 @@ def main():
                         frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
                         launches=launches, avg_launch_ms=round(avg_ms, 4),
                         kernel_ms=dict(draw_mfma=round(prof['draw_mfma_ms'], 2),
+                                       draw_search=round(prof['draw_search_ms'], 2),
                                        draw_exact_f64=round(prof['draw_exact_ms'], 2),
                                        advance=round(prof['advance_ms'], 2)),
                         exact_fraction=round(c['exact_draws'] / max(c['organic'], 1), 5),

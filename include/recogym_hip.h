@@ -167,8 +167,9 @@ int rg_sim_read_counters(rg_sim* sim, int64_t* out, void* stream);
 
 /* Measurement aid for bench.py's roofline line: with profiling on, every step records HIP
  * events on the stream the kernels are launched on.  rg_sim_get_profile returns
- * out[0..2] = total milliseconds spent in the organic draw (fp32 MFMA kernel), in the float64
- * resolve kernel and in the advance kernel, out[3] = profiled steps.  Off by default. */
+ * out[0..3] = total milliseconds spent in the MFMA organic-draw kernel, in its search kernel
+ * (sliced mode only), in the float64 resolve kernels and in the advance kernel; out[4] =
+ * profiled steps.  `out` must hold 5 doubles.  Off by default. */
 int rg_sim_set_profiling(rg_sim* sim, int on);
 int rg_sim_get_profile(rg_sim* sim, double* out);
 

@@ -136,9 +136,9 @@ struct rg_sim {
     size_t mfma_smem, bf16_smem;
     void (*bf16_kernel)(DevSim, uint32_t, uint32_t);
     bool profiling;
-    std::vector<hipEvent_t> prof_events;   // 4 per profiled step: before draw, after mfma, after exact, after advance
+    std::vector<hipEvent_t> prof_events;   // 5 per profiled step: before draw, after mfma, after search, after exact, after advance
     size_t prof_used;
-    double prof_ms[3];
+    double prof_ms[4];
     uint64_t prof_launches;
 };
 
@@ -1432,8 +1432,10 @@ draw_kernel_t bf16_kernel_for(const DevSim& d) {
 // ------------------------------------------------------------------------------------------
 // k_advance — one Markov transition for every live user (lane per user).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_advance(DevSim d, uint32_t t, const int32_t* actions) {
-    __shared__ uint32_t s_wave_o[4], s_wave_b[4], s_base_o, s_base_b;
+constexpr int kAdvBlock = 256;
+__global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, const int32_t* actions) {
+    constexpr int kSub = 1;                     // block iterations that share one reservation
+    __shared__ uint32_t s_cnt_o[kSub][kAdvBlock / 64], s_cnt_b[kSub][kAdvBlock / 64], s_base_o, s_base_b;
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
     const uint32_t n_b = d.step_cnt[2 * t + RG_STATE_BANDIT];
     const uint32_t n = n_o + n_b;
@@ -1446,9 +1448,14 @@ __global__ void __launch_bounds__(kBlock) k_advance(DevSim d, uint32_t t, const 
     if (blockIdx.x == 0 && threadIdx.x == 0) d.log_base[t + 1] = d.log_base[t] + n;
 
     uint32_t clicks = 0, phantoms = 0;
-    const uint32_t n_iter = (n + kBlock - 1) / kBlock;
+    const uint32_t n_iter = (n + kSub * kAdvBlock - 1) / (kSub * kAdvBlock);
     for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
-        const uint32_t i = it * kBlock + threadIdx.x;
+      int ns_j[kSub];
+      uint32_t slot_j[kSub];
+      unsigned long long mo_j[kSub], mb_j[kSub];
+#pragma unroll
+      for (int sub = 0; sub < kSub; ++sub) {
+        const uint32_t i = (it * kSub + sub) * kAdvBlock + threadIdx.x;
         int ns = RG_STATE_STOP;       // inactive lanes look dead
         uint32_t slot = 0;
         if (i < n) {
@@ -1526,23 +1533,39 @@ __global__ void __launch_bounds__(kBlock) k_advance(DevSim d, uint32_t t, const 
                 }
             }
         }
-        // ordered compaction of the survivors into next step's lists: ballot + mbcnt inside the
-        // wave, one returning atomic per list per block iteration
-        const unsigned long long m_o = __ballot(ns == RG_STATE_ORGANIC);
-        const unsigned long long m_b = __ballot(ns == RG_STATE_BANDIT);
-        if (lane == 0) { s_wave_o[wave] = __popcll(m_o); s_wave_b[wave] = __popcll(m_b); }
+        ns_j[sub] = ns; slot_j[sub] = slot;
+        mo_j[sub] = __ballot(ns == RG_STATE_ORGANIC);
+        mb_j[sub] = __ballot(ns == RG_STATE_BANDIT);
+        if (lane == 0) { s_cnt_o[sub][wave] = __popcll(mo_j[sub]); s_cnt_b[sub][wave] = __popcll(mb_j[sub]); }
+      }
+        // Ordered compaction of the survivors into next step's lists: ballot + mbcnt inside the
+        // wave, one returning 64-bit atomic per block iteration reserves room in both lists.
         __syncthreads();
         if (threadIdx.x == 0) {
-            const uint32_t to = s_wave_o[0] + s_wave_o[1] + s_wave_o[2] + s_wave_o[3];
-            const uint32_t tb = s_wave_b[0] + s_wave_b[1] + s_wave_b[2] + s_wave_b[3];
-            s_base_o = to ? atomicAdd(&next_cnt[RG_STATE_ORGANIC], to) : 0u;
-            s_base_b = tb ? atomicAdd(&next_cnt[RG_STATE_BANDIT], tb) : 0u;
+            uint32_t to = 0, tb = 0;
+#pragma unroll
+            for (int sub = 0; sub < kSub; ++sub)
+#pragma unroll
+                for (int w2 = 0; w2 < kAdvBlock / 64; ++w2) { to += s_cnt_o[sub][w2]; tb += s_cnt_b[sub][w2]; }
+            // step_cnt[t+1] = {organic, bandit} is an aligned u32 pair: reserve both lists at once
+            unsigned long long base = 0;
+            if (to | tb)
+                base = atomicAdd(reinterpret_cast<unsigned long long*>(next_cnt),
+                                 static_cast<unsigned long long>(to) | (static_cast<unsigned long long>(tb) << 32));
+            s_base_o = static_cast<uint32_t>(base);
+            s_base_b = static_cast<uint32_t>(base >> 32);
         }
         __syncthreads();
         uint32_t off_o = s_base_o, off_b = s_base_b;
-        for (int w2 = 0; w2 < wave; ++w2) { off_o += s_wave_o[w2]; off_b += s_wave_b[w2]; }
-        if (ns == RG_STATE_ORGANIC) next_o[off_o + prefix_in_mask(m_o)] = slot;
-        if (ns == RG_STATE_BANDIT) next_b[off_b + prefix_in_mask(m_b)] = slot;
+#pragma unroll
+        for (int sub = 0; sub < kSub; ++sub) {
+            uint32_t wo = off_o, wb = off_b;
+            for (int w2 = 0; w2 < wave; ++w2) { wo += s_cnt_o[sub][w2]; wb += s_cnt_b[sub][w2]; }
+            if (ns_j[sub] == RG_STATE_ORGANIC) next_o[wo + prefix_in_mask(mo_j[sub])] = slot_j[sub];
+            if (ns_j[sub] == RG_STATE_BANDIT) next_b[wb + prefix_in_mask(mb_j[sub])] = slot_j[sub];
+#pragma unroll
+            for (int w2 = 0; w2 < kAdvBlock / 64; ++w2) { off_o += s_cnt_o[sub][w2]; off_b += s_cnt_b[sub][w2]; }
+        }
         __syncthreads();
     }
     // counters: one atomic per wave per kernel
@@ -1718,6 +1741,7 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         if (S < 1) S = 1;
         const int grid = grid_for(static_cast<uint64_t>(tiles_up) * S, 1);
         hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid), dim3(kBlock), sim->bf16_smem, st, d, t, S);
+        if (int rc = prof_mark(sim, st)) return rc;
         if (S > 1)
             hipLaunchKernelGGL(search_kernel_for(d), dim3(grid_for(upper, 128)), dim3(kBlock),
                                sizeof(float) * 4 * 32 * 2 * d.KH, st, d, t);
@@ -1734,15 +1758,17 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
             default: hipLaunchKernelGGL(k_draw_mfma<64>, dim3(grid), dim3(kBlock), smem, st, d, t); break;
         }
         if (int rc = prof_mark(sim, st)) return rc;
+        if (int rc = prof_mark(sim, st)) return rc;
         // draws the fp32 path could not certify -> float64 (a few percent of the organic users)
         launch_exact(sim, t, 1, upper / 100 + 16, st);
     } else {
+        if (int rc = prof_mark(sim, st)) return rc;
         if (int rc = prof_mark(sim, st)) return rc;
         launch_exact(sim, t, 0, upper, st);
     }
     if (int rc = prof_mark(sim, st)) return rc;
     // 2. click draws, transitions, drift, next lists, bandit + phantom rows
-    hipLaunchKernelGGL(k_advance, dim3(grid_for(upper)), dim3(kBlock), 0, st, d, t, d_actions);
+    hipLaunchKernelGGL(k_advance, dim3(grid_for(upper, kAdvBlock)), dim3(kAdvBlock), 0, st, d, t, d_actions);
     HIP_TRY(hipGetLastError());
     if (int rc = prof_mark(sim, st)) return rc;
     sim->t = t + 1;
@@ -1753,8 +1779,8 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
 int prof_collect(rg_sim* sim) {
     if (!sim->prof_used) return RG_OK;
     HIP_TRY(hipEventSynchronize(sim->prof_events[sim->prof_used - 1]));
-    for (size_t i = 0; i + 3 < sim->prof_used; i += 4) {
-        for (int k = 0; k < 3; ++k) {
+    for (size_t i = 0; i + 4 < sim->prof_used; i += 5) {
+        for (int k = 0; k < 4; ++k) {
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, sim->prof_events[i + k], sim->prof_events[i + k + 1]));
             sim->prof_ms[k] += ms;
@@ -1819,7 +1845,7 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     d.n_users = d.n_cap = static_cast<uint32_t>(n_users);
     s->h_pinned = nullptr;
     s->profiling = false; s->prof_used = 0; s->prof_launches = 0;
-    s->prof_ms[0] = s->prof_ms[1] = s->prof_ms[2] = 0.0;
+    s->prof_ms[0] = s->prof_ms[1] = s->prof_ms[2] = s->prof_ms[3] = 0.0;
     s->mfma_smem = d.use_mfma ? mfma_smem_bytes(geom_of(*cfg)) : 0;
     // kernel choice: split-bf16 MFMA when a class exists for K, else fp32 MFMA; RECOGYM_DRAW=f64|fp32|bf16 overrides
     s->bf16_kernel = nullptr; s->bf16_smem = 0;
@@ -1977,15 +2003,15 @@ int rg_sim_set_profiling(rg_sim* sim, int on) {
     if (!sim) return fail(RG_EINVAL, "sim is NULL");
     sim->profiling = on != 0;
     sim->prof_used = 0; sim->prof_launches = 0;
-    sim->prof_ms[0] = sim->prof_ms[1] = sim->prof_ms[2] = 0.0;
+    sim->prof_ms[0] = sim->prof_ms[1] = sim->prof_ms[2] = sim->prof_ms[3] = 0.0;
     return RG_OK;
 }
 
 int rg_sim_get_profile(rg_sim* sim, double* out) {
     if (!sim || !out) return fail(RG_EINVAL, "NULL argument");
     if (int rc = prof_collect(sim)) return rc;
-    out[0] = sim->prof_ms[0]; out[1] = sim->prof_ms[1]; out[2] = sim->prof_ms[2];
-    out[3] = static_cast<double>(sim->prof_launches);
+    out[0] = sim->prof_ms[0]; out[1] = sim->prof_ms[1]; out[2] = sim->prof_ms[2]; out[3] = sim->prof_ms[3];
+    out[4] = static_cast<double>(sim->prof_launches);
     return RG_OK;
 }
 
