@@ -179,7 +179,7 @@ def main():
         launches = max(prof['steps'], 1)
         avg_ms = prof['draw_mfma_ms'] / launches
         achieved = flops / (prof['draw_mfma_ms'] * 1e-3) / 1e12 if prof['draw_mfma_ms'] else 0.0
-        roofline = dict(bound='mfma', kernel='k_draw_bf16 (split-bf16 MFMA organic draw; fp32-equivalent flops 2*P*K per draw)', achieved=round(achieved, 3),
+        roofline = dict(bound='mfma', kernel='organic draw MFMA kernel (k_draw_bf16: 3-way split bf16, fp32-class; k_draw_mfma for K classes without one); algorithmic flops 2*P*K per draw vs the fp32 MFMA peak', achieved=round(achieved, 3),
                         peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
                         frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
                         launches=launches, avg_launch_ms=round(avg_ms, 4),
