@@ -179,9 +179,19 @@ def main():
         launches = max(prof['steps'], 1)
         avg_ms = prof['draw_mfma_ms'] / launches
         achieved = flops / (prof['draw_mfma_ms'] * 1e-3) / 1e12 if prof['draw_mfma_ms'] else 0.0
+        # HBM traffic of that kernel: PMC counters cannot be read from inside this process, so the
+        # per-draw figure measured offline with rocprofv3 --pmc (profiles/r1/pmc_traffic.json) is
+        # scaled to the average launch of this run; null when the workload differs from the profiled one
+        traffic = None
+        try:
+            pt = json.load(open(os.path.join(ROOT, 'profiles', 'r1', 'pmc_traffic.json')))
+            if (P, K) == (10000, 20):
+                traffic = pt['hbm_bytes_per_organic_draw'] * c['organic'] / launches
+        except Exception:
+            traffic = None
         roofline = dict(bound='mfma', kernel='organic draw MFMA kernel (k_draw_bf16: 3-way split bf16, fp32-class; k_draw_mfma for K classes without one); algorithmic flops 2*P*K per draw vs the fp32 MFMA peak', achieved=round(achieved, 3),
                         peak=FP32_MFMA_PEAK_TFLOPS, unit='TFLOP/s',
-                        frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                         launches=launches, avg_launch_ms=round(avg_ms, 4),
                         kernel_ms=dict(draw_mfma=round(prof['draw_mfma_ms'], 2),
                                        draw_search=round(prof['draw_search_ms'], 2),

@@ -154,3 +154,53 @@ def test_every_draw_kernel_matches_the_oracle(mode, shape, monkeypatch):
         assert cnt['exact_draws'] == 0      # counted only for draws handed over by an MFMA kernel
     else:
         assert cnt['exact_draws'] < 0.2 * cnt['organic']
+
+
+def test_full_size_log_invariants():
+    """BASELINE config 2 at full size (P=1000, K=20, 1 M users, RandomAgent): the oracle cannot
+    run this in seconds, so check the size-independent properties of the reference's log
+     on every one of the ~1e8 rows, on the device."""
+    from recogym_amd.sim import Simulator
+    cfg = Configuration({**env_1_args, 'random_seed': 42, 'num_products': 1000, 'K': 20,
+                         'sigma_omega': 0.0})
+    n = 1_000_000
+    sim = Simulator(cfg, n, device='cuda:0', policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=7)
+    sim.reset_users(0, n)
+    sim.run()
+    cnt = sim.counters()
+    log, off = sim.sorted_log()
+    log = log.to(torch.int64)
+    u, t, code = log[:, 0], log[:, 1], log[:, 2] & 0xFFFFFFFF
+    is_b = (code & _abi.RG_EV_BANDIT) != 0
+    click = (code & _abi.RG_EV_CLICK) != 0
+    phantom = (code & _abi.RG_EV_PHANTOM) != 0
+    idx = code & _abi.RG_EV_INDEX_MASK
+    rows = log.shape[0]
+    assert rows == cnt['organic'] + cnt['bandit'] + cnt['phantom'] and cnt['phantom'] == n
+    assert int(off[-1]) == rows
+    # users appear in id order, every user's t runs 0, 1, 2, ... without gaps
+    first = off[:-1]
+    last = off[1:] - 1
+    assert bool((u[first] == torch.arange(n, device=u.device)).all())
+    assert bool((u[1:] >= u[:-1]).all())
+    same = u[1:] == u[:-1]
+    assert bool((t[1:][same] == t[:-1][same] + 1).all()) and bool((t[first] == 0).all())
+    # first row organic; last row = the phantom bandit row with c = 0; no other phantom rows
+    assert bool((~is_b[first]).all())
+    assert bool((is_b[last] & phantom[last] & ~click[last]).all())
+    assert int(phantom.sum()) == n
+    # a click is always followed by an organic row of the same user (abstract.py:180-185)
+    cpos = torch.nonzero(click).squeeze(1)
+    assert bool((~is_b[cpos + 1] & (u[cpos + 1] == u[cpos])).all())
+    assert int(click.sum()) == cnt['clicks']
+    # indices in range, organic rows carry no click flag
+    assert int(idx.max()) < 1000 and not bool((click & ~is_b).any())
+    # statistics of the Markov chain (SURVEY.md §6): ~100.6 events per user, 21.8 % organic, CTR ~1.1 %
+    ev = cnt['organic'] + cnt['bandit']
+    assert 99.0 < ev / n < 102.5
+    assert 0.21 < cnt['organic'] / ev < 0.23
+    assert 0.009 < cnt['clicks'] / (cnt['bandit'] + cnt['phantom']) < 0.014
+    # uniform policy: actions cover the catalogue evenly (chi-square-ish bound)
+    a_hist = torch.bincount(idx[is_b], minlength=1000).double()
+    assert float((a_hist.max() - a_hist.min()) / a_hist.mean()) < 0.05
+    sim.close()
