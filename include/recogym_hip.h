@@ -53,6 +53,8 @@ extern "C" {
 #define RG_POLICY_RANDOM_AGENT 1  /* RandomAgent, agents/random_agent.py:22-33 */
 #define RG_POLICY_ORGANIC_USER_COUNT 2 /* OrganicUserEventCounterAgent, agents/organic_user_count.py:45-96 */
 #define RG_POLICY_EXTERNAL 3      /* actions supplied by the caller per step (gym.Env.step, abstract.py:123) */
+#define RG_POLICY_LAST_VIEW_TABLE 4 /* frozen policy a = table[last product viewed]: BanditMFSquare inference,
+                                     agents/bandit_mf.py:52-87 (argmax_a <E_p[a], E_u[lpv]> is a P-entry table) */
 
 /*
  * Everything the step loop needs from `env.config` (a Configuration built from env_1_args,
@@ -136,6 +138,11 @@ int rg_sim_destroy(rg_sim* sim);
  * the pointers (caller keeps them alive) and builds its fp32 tile copies in the workspace. */
 int rg_sim_set_tables(rg_sim* sim, const double* d_gamma, const double* d_mu_organic,
                       const double* d_beta, const double* d_mu_bandit, void* stream);
+
+/* RG_POLICY_LAST_VIEW_TABLE: per-product device tables, kept by pointer (caller keeps them alive):
+ * d_action[p] = action taken when the user's last organic view was p, d_ps[p] = the `ps` value
+ * logged with it (NULL = 1.0; BanditMFSquare logs its logit there, bandit_mf.py:84). */
+int rg_sim_set_policy_table(rg_sim* sim, const int32_t* d_action, const float* d_ps);
 
 /* Where rows go.  d_log == NULL (or capacity 0) disables logging: only counters are kept. */
 int rg_sim_set_log(rg_sim* sim, rg_event* d_log, uint64_t capacity);

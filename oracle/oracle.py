@@ -46,6 +46,7 @@ def lib():
         L.rgo_env_create.restype = C.c_void_p
         L.rgo_env_create.argtypes = [C.POINTER(_abi.RgConfig), C.c_int] + [C.c_void_p] * 4
         L.rgo_env_destroy.argtypes = [C.c_void_p]
+        L.rgo_env_set_policy_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rgo_env_reseed.argtypes = [C.c_void_p, C.c_uint64]
         L.rgo_env_reseed_policy.argtypes = [C.c_void_p, C.c_uint64]
         L.rgo_env_reset.argtypes = [C.c_void_p, C.c_uint32]
@@ -81,7 +82,7 @@ class OracleEnv:
     """The reference's RecoEnv1, restated: reset / step / generate_logs over the C library."""
 
     def __init__(self, config, rng_mode=RNG_PHILOX, policy=_abi.RG_POLICY_UNIFORM_ENV,
-                 policy_seed=None, ouc=None, epoch=0, tables=None):
+                 policy_seed=None, ouc=None, epoch=0, tables=None, policy_table=None, policy_ps=None):
         self.config = config
         self.rg_config = make_rg_config(config, config.random_seed + epoch, policy, policy_seed,
                                         ouc)
@@ -89,6 +90,11 @@ class OracleEnv:
         self._ptrs = [t.ctypes.data_as(C.c_void_p) for t in self.tables]
         self._h = lib().rgo_env_create(C.byref(self.rg_config), rng_mode, *self._ptrs)
         self._rows = np.zeros(4096, dtype=ROW_DTYPE)
+        if policy_table is not None:
+            self._pt = np.ascontiguousarray(policy_table, dtype=np.int32)
+            self._pp = None if policy_ps is None else np.ascontiguousarray(policy_ps, dtype=np.float64)
+            lib().rgo_env_set_policy_table(self._h, self._pt.ctypes.data_as(C.c_void_p),
+                                           None if self._pp is None else self._pp.ctypes.data_as(C.c_void_p))
 
     def __del__(self):
         if getattr(self, '_h', None):

@@ -160,6 +160,9 @@ typedef struct rgo_env {
     rgo_mt pol_mt;            /* agent.rng / agent.model.rng in MT mode */
     /* policy state: ViewsFeaturesProvider.views (agents/abstract.py:379-395) */
     int32_t* views;           /* (P) */
+    int32_t last_view;        /* BanditMFSquare.last_product_viewed (bandit_mf.py:60-65) */
+    const int32_t* pol_table; /* RG_POLICY_LAST_VIEW_TABLE: action per last viewed product */
+    const double* pol_ps;     /* and the ps logged with it (NULL = 1.0) */
     /* scratch */
     double* buf;              /* (P) */
     double* zbuf;             /* (K) */
@@ -189,6 +192,11 @@ rgo_env* rgo_env_create(const rg_config* cfg, int rng_mode, const double* gamma,
 void rgo_env_destroy(rgo_env* e) {
     if (!e) return;
     free(e->omega); free(e->views); free(e->buf); free(e->zbuf); free(e);
+}
+
+void rgo_env_set_policy_table(rgo_env* e, const int32_t* table, const double* ps) {
+    e->pol_table = table;
+    e->pol_ps = ps;
 }
 
 /* AbstractEnv.reset_random_seed (abstract.py:59-62): seed is already random_seed + epoch. */
@@ -335,6 +343,7 @@ static void generate_organic_sessions(rgo_env* e, rgo_session* out) {
         r.ps = NAN; r.p_click = NAN;
         push_row(out, &r);
         e->views[v] += 1;
+        e->last_view = v;
         e->counters[0] += 1;
         update_state(e);
     }
@@ -387,6 +396,12 @@ int32_t rgo_env_policy_act(rgo_env* e, double* ps_out) {
             a = rg_bounded(w.w[0], w.w[1], P);
         *ps_out = 1.0 / (double)P;
         return (int32_t)a;
+    }
+
+    if (e->cfg.policy == RG_POLICY_LAST_VIEW_TABLE) {
+        /* BanditMFSquare.act with frozen embeddings: argmax_a <E_p[a], E_u[lpv]> is a table */
+        *ps_out = e->pol_ps ? e->pol_ps[e->last_view] : 1.0;
+        return e->pol_table[e->last_view];
     }
 
     /* OrganicUserEventCounterModel.act */

@@ -38,7 +38,7 @@ def __getattr__(name):
         from .evaluate_agent import verify_agents
         return verify_agents
     if name in ('Agent', 'RandomAgent', 'random_args', 'OrganicUserEventCounterAgent',
-                'organic_user_count_args'):
+                'organic_user_count_args', 'LastViewTableAgent'):
         from . import agents
         return getattr(agents, name)
     raise AttributeError(name)

@@ -117,6 +117,8 @@ struct DevSim {
     uint32_t* hist;           // [n_pad][hist_cap] sorted distinct viewed products (OUC policy), user-major
     uint16_t* hist_cntv;      // [n_pad][hist_cap] view counts of those products
     uint32_t* hist_n;         // [n_users] distinct products viewed
+    uint32_t* lpv;            // [n_users] last product viewed (RG_POLICY_LAST_VIEW_TABLE)
+    const int32_t* pol_table; const float* pol_ps;   // caller-owned per-product tables of that policy
     unsigned long long* counters;   // [RG_CNT_N]
     // log
     rg_event* log; uint64_t log_cap;
@@ -237,6 +239,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint32_t* hist = w.take<uint32_t>(hc * n_pad);
     uint16_t* hist_cntv = w.take<uint16_t>(hc * n_pad);
     uint32_t* hist_n = w.take<uint32_t>(n);
+    uint32_t* lpv = w.take<uint32_t>(c.policy == RG_POLICY_LAST_VIEW_TABLE ? n : 1);
     unsigned long long* counters = w.take<unsigned long long>(RG_CNT_N);
     if (d) {
         d->gamma32 = gamma32; d->mu32 = mu32; d->stats = stats; d->omega = omega; d->list = list;
@@ -247,7 +250,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->step_cnt = step_cnt; d->log_base = log_base; d->exact_list = exact_list;
         d->exact_cnt = exact_cnt; d->n_events = n_events; d->phantom = phantom;
         d->has_phantom = has_phantom; d->hist = hist; d->hist_cntv = hist_cntv;
-        d->hist_n = hist_n; d->counters = counters;
+        d->hist_n = hist_n; d->counters = counters; d->lpv = (c.policy == RG_POLICY_LAST_VIEW_TABLE) ? lpv : nullptr;
         d->n_pad = static_cast<uint32_t>(n_pad);
         d->OMS = static_cast<uint32_t>((K + 1) & ~static_cast<size_t>(1));
         d->hist_cap = static_cast<uint32_t>(hc);
@@ -263,7 +266,7 @@ int validate(const rg_config* c, uint64_t n) {
     if (sizeof(double) * (static_cast<size_t>(c->K) * 64 + 64 + 16 * c->K) > 64 * 1024)
         return fail(RG_EINVAL, "K %u exceeds the float64 draw kernel's LDS budget", c->K);
     if (n == 0 || n >= (1ull << 31)) return fail(RG_EINVAL, "n_users %llu out of range", (unsigned long long)n);
-    if (c->policy > RG_POLICY_EXTERNAL) return fail(RG_EINVAL, "unknown policy %u", c->policy);
+    if (c->policy > RG_POLICY_LAST_VIEW_TABLE) return fail(RG_EINVAL, "unknown policy %u", c->policy);
     for (int s = 0; s < 2; ++s)
         if (!(c->trans_cdf[s][0] >= 0.0 && c->trans_cdf[s][0] <= c->trans_cdf[s][1] &&
               c->trans_cdf[s][1] <= 1.0))
@@ -424,6 +427,11 @@ __global__ void __launch_bounds__(kBlock) k_table_stats(DevSim d) {
 // ------------------------------------------------------------------------------------------
 __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, uint32_t t,
                                double* ps_out) {
+    if (d.policy == RG_POLICY_LAST_VIEW_TABLE) {
+        const uint32_t p = d.lpv[slot];
+        *ps_out = d.pol_ps ? static_cast<double>(d.pol_ps[p]) : 1.0;
+        return static_cast<uint32_t>(d.pol_table[p]);
+    }
     const rg_u32x4 w = rg_draw(d.policy_seed, user, t, 0, RG_DRAW_POLICY);
     if (d.policy != RG_POLICY_ORGANIC_USER_COUNT) {
         *ps_out = 1.0 / static_cast<double>(d.P);
@@ -572,6 +580,7 @@ __device__ __forceinline__ void write_organic_row(const DevSim& d, uint32_t t, u
         e.u = user; e.t = t; e.code = v; e.ps = __builtin_nanf("");
         d.log[row] = e;
     }
+    if (d.lpv) d.lpv[user - static_cast<uint32_t>(d.first_user)] = v;   // BanditMFSquare.update_lpv, bandit_mf.py:60-65
 }
 
 // exp(x) in float64 for x <= ~700 (0 for x <= -750, incl. -inf): Cody-Waite reduction by ln 2 and a
@@ -1916,6 +1925,15 @@ int rg_sim_set_tables(rg_sim* sim, const double* d_gamma, const double* d_mu_org
     return RG_OK;
 }
 
+int rg_sim_set_policy_table(rg_sim* sim, const int32_t* d_action, const float* d_ps) {
+    if (!sim) return fail(RG_EINVAL, "sim is NULL");
+    if (sim->d.policy != RG_POLICY_LAST_VIEW_TABLE) return fail(RG_ESTATE, "policy is not RG_POLICY_LAST_VIEW_TABLE");
+    if (!d_action) return fail(RG_EINVAL, "action table is NULL");
+    sim->d.pol_table = d_action;
+    sim->d.pol_ps = d_ps;
+    return RG_OK;
+}
+
 int rg_sim_set_log(rg_sim* sim, rg_event* d_log, uint64_t capacity) {
     if (!sim) return fail(RG_EINVAL, "sim is NULL");
     sim->d.log = capacity ? d_log : nullptr;
@@ -1934,6 +1952,8 @@ int rg_sim_reset_users(rg_sim* sim, uint64_t first_user_id, uint64_t n, uint64_t
                        void* stream) {
     if (!sim) return fail(RG_EINVAL, "sim is NULL");
     if (!sim->tables_set) return fail(RG_ESTATE, "rg_sim_set_tables must be called first");
+    if (sim->d.policy == RG_POLICY_LAST_VIEW_TABLE && !sim->d.pol_table)
+        return fail(RG_ESTATE, "rg_sim_set_policy_table must be called first");
     if (n == 0 || n > sim->d.n_cap) return fail(RG_EINVAL, "n %llu exceeds the %u users the workspace was sized for",
                                                  (unsigned long long)n, sim->d.n_cap);
     if (first_user_id + n > (1ull << 32)) return fail(RG_EINVAL, "user ids must fit 32 bits");

@@ -215,7 +215,7 @@ class RecoEnv1:
         pol = policy if policy is not None else device_policy_of(agent)
         if pol is None:
             raise ValueError(f'{type(agent).__name__} cannot run inside the device step loop')
-        if pol['policy_seed'] is None:
+        if pol.get('policy_seed') is None:
             pol = dict(pol, policy_seed=self.seed)      # agent=None draws from the ENV stream
         return Simulator(self.config, n_users, epoch=self._epoch, tables=self._tables,
                          log_capacity=None if log else 0, device=device or self._device, **pol)

@@ -67,7 +67,8 @@ class Simulator:
     """
 
     def __init__(self, config, n_users, policy=_abi.RG_POLICY_UNIFORM_ENV, policy_seed=None,
-                 ouc=None, epoch=0, log_capacity=None, device=None, tables=None):
+                 ouc=None, epoch=0, log_capacity=None, device=None, tables=None, policy_table=None,
+                 policy_ps=None):
         self.lib = _abi.load()
         self.device = require_device(device)
         self.config = config
@@ -91,6 +92,13 @@ class Simulator:
                        'rg_sim_create')
             _abi.check(self.lib.rg_sim_set_tables(self._h, *[t.data_ptr() for t in self.tables],
                                                   self._stream()), 'rg_sim_set_tables')
+            if policy == _abi.RG_POLICY_LAST_VIEW_TABLE:
+                self.policy_table = torch.as_tensor(np.ascontiguousarray(policy_table, dtype=np.int32)).to(self.device)
+                self.policy_ps = None if policy_ps is None else \
+                    torch.as_tensor(np.ascontiguousarray(policy_ps, dtype=np.float32)).to(self.device)
+                _abi.check(self.lib.rg_sim_set_policy_table(
+                    self._h, self.policy_table.data_ptr(),
+                    None if self.policy_ps is None else self.policy_ps.data_ptr()), 'rg_sim_set_policy_table')
             if log_capacity is None:
                 log_capacity = default_log_capacity(config, self.n_users)
             self.log = None

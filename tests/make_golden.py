@@ -41,6 +41,13 @@ def make_agent(kind, agent_args):
         from recogym.agents import OrganicUserEventCounterAgent, organic_user_count_args
         return OrganicUserEventCounterAgent(
             Configuration({**organic_user_count_args, **agent_args}))
+    if kind == 'bmf':
+        import torch
+        from recogym.agents import BanditMFSquare, bandit_mf_square_args
+        torch.manual_seed(agent_args.get('torch_seed', 0))
+        return BanditMFSquare(Configuration({**bandit_mf_square_args,
+                                             'num_products': agent_args['num_products'],
+                                             'embed_dim': agent_args.get('embed_dim', 5)}))
     raise ValueError(kind)
 
 
@@ -49,7 +56,7 @@ def save(name, arrays, meta):
     for k, v in arrays.items():
         if k in ('z', 'c'):
             small[k] = v.astype(np.int8)
-        elif k in ('ps', 'p_click'):
+        elif k in ('ps', 'p_click') or k.startswith('bmf_'):
             small[k] = v
         else:
             small[k] = v.astype(np.int32)
@@ -69,7 +76,7 @@ def run_case(name, env_over, n_users, n_organic=0, agent_kind=None, agent_args=N
         agent = make_agent(agent_kind, agent_args)
     p_click = None
     if injected:
-        rng = rh.inject_counter_rng(env, agent, agent_args.get('random_seed'))
+        rng = rh.inject_counter_rng(env, None if agent_kind == 'bmf' else agent, agent_args.get('random_seed'))
     df = env.generate_logs(n_users, agent, n_organic)
     arrays = rh.log_to_arrays(df)
     if injected:
@@ -84,6 +91,9 @@ def run_case(name, env_over, n_users, n_organic=0, agent_kind=None, agent_args=N
         arrays['p_click'] = pc
     meta = dict(env_args=args, n_users=n_users, n_organic=n_organic, agent=agent_kind,
                 agent_args=agent_args, rng='philox' if injected else 'mt')
+    if agent_kind == 'bmf':      # the (untrained) embeddings the frozen device policy is built from
+        arrays['bmf_product_embedding'] = agent.product_embedding.weight.detach().numpy().astype(np.float64)
+        arrays['bmf_user_embedding'] = agent.user_embedding.weight.detach().numpy().astype(np.float64)
     save(name, arrays, meta)
 
 
@@ -187,6 +197,8 @@ def main():
     run_case('philox_flips_normbeta', {**S, 'num_products': 30, 'number_of_flips': 5,
                                        'normalize_beta': True}, 120, injected=True)
     run_case('philox_change_omega', {**S, 'change_omega_for_bandits': True}, 120, injected=True)
+    run_case('philox_bandit_mf', {**S, 'num_products': 40, 'K': 10}, 150, agent_kind='bmf',
+             agent_args=dict(torch_seed=3, embed_dim=5), injected=True)
 
 
 if __name__ == '__main__':

@@ -35,6 +35,24 @@ def make_agent(meta):
     return None
 
 
+def test_frozen_bandit_mf_agent_device_and_host_forms():
+    """LastViewTableAgent built from the reference BanditMFSquare's (untrained) embeddings: the
+    device policy reproduces the reference's log, and the per-user path with the Python act
+    logs the same rows."""
+    from recogym_amd.agents import LastViewTableAgent
+    meta, want = gu.load('philox_bandit_mf')
+    cfg = Configuration({'num_products': meta['env_args']['num_products'], 'with_ps_all': False})
+    agent = LastViewTableAgent.from_bandit_mf(cfg, want['bmf_product_embedding'],
+                                              want['bmf_user_embedding'])
+    env = make_env(meta['env_args'])
+    df = env.generate_logs(meta['n_users'], agent)
+    assert_frames_match(frame_to_cols(df), want, 1e-5)
+    df_seq = make_env(meta['env_args'])._generate_logs_per_user(20, agent, 0)
+    keep = want['u'] < 20
+    assert_frames_match(frame_to_cols(df_seq), {k: v[keep] for k, v in want.items()
+                                                if k in ('t', 'u', 'z', 'v', 'a', 'c', 'ps')}, 1e-5)
+
+
 def frame_to_cols(df):
     return {
         't': df['t'].values.astype(np.int64),
