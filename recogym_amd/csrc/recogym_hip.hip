@@ -1475,6 +1475,14 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
             const double u_trans = rg_uniform(w.w[2], w.w[3]);
             bool click = false;
             if (!is_org) {
+                // Touch the two cache lines of the user's omega row (and the head of its view
+                // history) NOW: they arrive while the policy draws and walks the history, instead
+                // of costing another HBM round trip after it — this kernel is latency-bound.
+                const double* om_row = d.omega + static_cast<size_t>(slot) * d.OMS;
+                const double touch0 = om_row[0], touch1 = om_row[d.K - 1];
+                uint32_t touch2 = 0;
+                if (d.hist_cap) touch2 = d.hist[static_cast<size_t>(slot) * d.hist_cap] +
+                                         d.hist_cntv[static_cast<size_t>(slot) * d.hist_cap];
                 // step_offline: the policy acts (abstract.py:202-221), then draw_click
                 double ps;
                 uint32_t a;
@@ -1497,6 +1505,7 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                     for (int i = 0; i < 8; ++i)
                         if (k0 + i < d.K) x += bv[i] * wv[i];
                 }
+                asm volatile("" ::"v"(touch0), "v"(touch1), "v"(touch2));   // keeps the early loads alive
                 const double ctr = ff64(x + d.mu_b[a]);
                 const double p0 = 1.0 - ctr;
                 click = (p0 / (p0 + ctr)) <= rg_uniform(w.w[0], w.w[1]);
