@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/recogym_hip.h"
@@ -41,6 +42,11 @@ constexpr uint32_t kMaxSteps = 1u << 16;       // P(a user survives that long) ~
 constexpr int kBlock = 256;                    // 4 waves of 64
 constexpr int kMaxGrid = 4096;
 constexpr uint32_t kDefaultHistoryCap = 256;
+// runs smaller than this keep slot == user index throughout (RECOGYM_REPACK_MIN overrides: tests)
+inline uint64_t repack_min_users() {
+    const char* e = getenv("RECOGYM_REPACK_MIN");
+    return e ? static_cast<uint64_t>(strtoull(e, nullptr, 10)) : (1ull << 18);
+}
 
 thread_local char g_err[512] = "";
 
@@ -111,13 +117,17 @@ struct DevSim {
     uint64_t* log_base;       // [kMaxSteps+2]: first log row of step t
     uint32_t* exact_list;     // [n_users] organic users whose draw needs the float64 path
     uint32_t* exact_cnt;      // [kMaxSteps+2]
-    uint32_t* n_events;       // [n_users] rows the user emitted (set when it leaves)
-    rg_event* phantom;        // [n_users] trailing undrawn bandit row
+    uint32_t* n_events;       // [n_users] rows the user emitted (set when it leaves); these three are indexed by
+    rg_event* phantom;        // [n_users] trailing undrawn bandit row                  USER INDEX (uid), not by slot
     uint8_t* has_phantom;     // [n_users]
     uint32_t* hist;           // [n_pad][hist_cap] sorted distinct viewed products (OUC policy), user-major
     uint16_t* hist_cntv;      // [n_pad][hist_cap] view counts of those products
     uint32_t* hist_n;         // [n_users] distinct products viewed
     uint32_t* lpv;            // [n_users] last product viewed (RG_POLICY_LAST_VIEW_TABLE)
+    uint32_t* uid;            // [n_users] slot -> user index (user id = first_user + uid[slot]); identity until a repack
+    // second copy of the slot-indexed state: k_repack_copy moves the live users' state into it, densely
+    // and in list order, and the host swaps the pointers (restores the locality the lists lose over time)
+    double* omega_alt; uint32_t* hist_alt; uint16_t* hist_cntv_alt; uint32_t* hist_n_alt; uint32_t* lpv_alt; uint32_t* uid_alt;
     const int32_t* pol_table; const float* pol_ps;   // caller-owned per-product tables of that policy
     unsigned long long* counters;   // [RG_CNT_N]
     // log
@@ -134,6 +144,8 @@ struct rg_sim {
     uint32_t t;               // next step to run
     uint32_t live_upper;      // upper bound of live users (for grid sizing)
     bool tables_set, users_reset;
+    bool repacked;            // slots no longer equal user indices (since the last reset)
+    uint32_t repack_every;    // steps between repacks (RECOGYM_REPACK, 0 = never)
     uint32_t* h_pinned;       // 4 x u32 staging for the live-count readback
     size_t mfma_smem, bf16_smem;
     void (*bf16_kernel)(DevSim, uint32_t, uint32_t);
@@ -241,7 +253,17 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint32_t* hist_n = w.take<uint32_t>(n);
     uint32_t* lpv = w.take<uint32_t>(c.policy == RG_POLICY_LAST_VIEW_TABLE ? n : 1);
     unsigned long long* counters = w.take<unsigned long long>(RG_CNT_N);
+    uint32_t* uid = w.take<uint32_t>(n);
+    const bool rp = n >= repack_min_users();      // small runs never repack: no second copy
+    double* omega_alt = w.take<double>(rp ? ((K + 1) & ~static_cast<size_t>(1)) * n_pad : 1);
+    uint32_t* hist_alt = w.take<uint32_t>(rp ? hc * n_pad : 1);
+    uint16_t* hist_cntv_alt = w.take<uint16_t>(rp ? hc * n_pad : 1);
+    uint32_t* hist_n_alt = w.take<uint32_t>(rp ? n : 1);
+    uint32_t* lpv_alt = w.take<uint32_t>(rp && c.policy == RG_POLICY_LAST_VIEW_TABLE ? n : 1);
+    uint32_t* uid_alt = w.take<uint32_t>(rp ? n : 1);
     if (d) {
+        d->uid = uid; d->omega_alt = omega_alt; d->hist_alt = hist_alt; d->hist_cntv_alt = hist_cntv_alt;
+        d->hist_n_alt = hist_n_alt; d->lpv_alt = lpv_alt; d->uid_alt = uid_alt;
         d->gamma32 = gamma32; d->mu32 = mu32; d->stats = stats; d->omega = omega; d->list = list;
         d->gammaT = gammaT; d->PT = static_cast<uint32_t>(PT); d->exact_ref = exact_ref; d->exact_sums = exact_sums; d->sc_scratch = sc_scratch; d->chunk_scratch = chunk_scratch;
         d->gsplit = gsplit; d->mu32s = mu32s; d->N1 = g.N1; d->N2 = g.N2; d->N3 = g.N3; d->RS = g.RS; d->TPB = g.TPB;
@@ -326,6 +348,7 @@ __global__ void __launch_bounds__(kBlock) k_reset_users(DevSim d) {
             if (2 * j + 1 < d.K) d.omega[static_cast<size_t>(i) * d.OMS + 2 * j + 1] = 0.0 + d.sigma0 * z1;
         }
         list_ptr(d, 0, RG_STATE_ORGANIC)[i] = i;
+        d.uid[i] = i;
         d.n_events[i] = 0;
         d.has_phantom[i] = 0;
         if (d.hist_cap) d.hist_n[i] = 0;
@@ -572,7 +595,7 @@ __device__ __forceinline__ double wave_sum(double x) {
     return x;
 }
 
-__device__ __forceinline__ void write_organic_row(const DevSim& d, uint32_t t, uint32_t pos,
+__device__ __forceinline__ void write_organic_row(const DevSim& d, uint32_t t, uint32_t pos, uint32_t slot,
                                                   uint32_t user, uint32_t v) {
     const uint64_t row = d.log_base[t] + pos;
     if (d.log && row < d.log_cap) {
@@ -580,7 +603,7 @@ __device__ __forceinline__ void write_organic_row(const DevSim& d, uint32_t t, u
         e.u = user; e.t = t; e.code = v; e.ps = __builtin_nanf("");
         d.log[row] = e;
     }
-    if (d.lpv) d.lpv[user - static_cast<uint32_t>(d.first_user)] = v;   // BanditMFSquare.update_lpv, bandit_mf.py:60-65
+    if (d.lpv) d.lpv[slot] = v;   // BanditMFSquare.update_lpv, bandit_mf.py:60-65
 }
 
 // exp(x) in float64 for x <= ~700 (0 for x <= -750, incl. -inf): Cody-Waite reduction by ln 2 and a
@@ -792,7 +815,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int
     for (uint32_t w = blockIdx.x * (kBlock / 64) + wave; w < n; w += waves_total) {
         const uint32_t pos = from_list ? d.exact_list[w] : w;
         const uint32_t slot = cur[pos];
-        const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
+        const uint32_t user = static_cast<uint32_t>(d.first_user + d.uid[slot]);
         const double M = static_cast<double>(d.exact_ref[w]) * 0.69314718055994530942;
         const double* sums = d.exact_sums + static_cast<size_t>(w) * n_cc;
         for (uint32_t k = lane; k < d.K; k += 64) om[k] = d.omega[static_cast<size_t>(slot) * d.OMS + k];
@@ -841,7 +864,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int
             acc += __shfl(incl, 63);
         }
         if (lane == 0) {
-            write_organic_row(d, t, pos, user, v);
+            write_organic_row(d, t, pos, slot, user, v);
             if (d.hist_cap) history_add(d, slot, v);
         }
         __builtin_amdgcn_wave_barrier();
@@ -936,7 +959,7 @@ __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, con
             const float2 wq = scr[sc * 32 + j];
             S += static_cast<double>(wq.x * __builtin_amdgcn_exp2f(wq.y - Q));
         }
-        const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
+        const uint32_t user = static_cast<uint32_t>(d.first_user + d.uid[slot]);
         const rg_u32x4 rw = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
         const double tau = rg_uniform(rw.w[0], rw.w[1]) * S;
         double pb = 0.0;
@@ -1027,7 +1050,7 @@ __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, con
         // ---- emit (lane per user) ----
         if (active && h == 0) {
             if (my_ok) {
-                write_organic_row(d, t, pos, user, my_v);
+                write_organic_row(d, t, pos, slot, user, my_v);
                 if (d.hist_cap) history_add(d, slot, my_v);
             } else {
                 const uint32_t xi = atomicAdd(&d.exact_cnt[t], 1u);
@@ -1470,7 +1493,8 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
         if (i < n) {
             const bool is_org = i < n_o;
             slot = is_org ? cur_o[i] : cur_b[i - n_o];
-            const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
+            const uint32_t uidx = d.uid[slot];
+            const uint32_t user = static_cast<uint32_t>(d.first_user + uidx);
             const rg_u32x4 w = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
             const double u_trans = rg_uniform(w.w[2], w.w[3]);
             bool click = false;
@@ -1486,7 +1510,7 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                 // step_offline: the policy acts (abstract.py:202-221), then draw_click
                 double ps;
                 uint32_t a;
-                if (d.policy == RG_POLICY_EXTERNAL) { a = static_cast<uint32_t>(actions[slot]); ps = __builtin_nan(""); }
+                if (d.policy == RG_POLICY_EXTERNAL) { a = static_cast<uint32_t>(actions[uidx]); ps = __builtin_nan(""); }
                 else a = policy_act(d, slot, user, t, &ps);
                 // beta[a] . omega, k ascending (the oracle's association); loads are issued eight
                 // k at a time — a plain loop leaves one HBM round trip per k on the critical path
@@ -1532,12 +1556,12 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                 }
             }
             if (click) ns = RG_STATE_ORGANIC;          // abstract.py:180-181
-            const bool organic_only = (d.first_user + slot) < d.organic_only_below;
+            const bool organic_only = (d.first_user + uidx) < d.organic_only_below;
             if (organic_only && ns != RG_STATE_ORGANIC) {
                 ns = RG_STATE_STOP;                    // warm-up users end with their first session
-                d.n_events[slot] = t + 1;
+                d.n_events[uidx] = t + 1;
             } else if (ns == RG_STATE_STOP) {
-                d.n_events[slot] = t + 1;
+                d.n_events[uidx] = t + 1;
                 if (d.policy != RG_POLICY_EXTERNAL) {
                     // final step_offline(done=True): one more act, reward 0 (abstract.py:223-233,311-316)
                     double ps;
@@ -1545,8 +1569,8 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                     rg_event e;
                     e.u = user; e.t = t + 1; e.code = RG_EV_BANDIT | RG_EV_PHANTOM | a;
                     e.ps = static_cast<float>(ps);
-                    d.phantom[slot] = e;
-                    d.has_phantom[slot] = 1;
+                    d.phantom[uidx] = e;
+                    d.has_phantom[uidx] = 1;
                     phantoms += 1;
                 }
             }
@@ -1619,8 +1643,8 @@ __global__ void k_totals(DevSim d, uint32_t t_now) {
 __global__ void __launch_bounds__(kBlock) k_export_state(DevSim d, uint32_t t, int8_t* state) {
     const uint32_t n_o = d.step_cnt[2 * t], n_b = d.step_cnt[2 * t + 1];
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_o + n_b; i += gridDim.x * kBlock) {
-        if (i < n_o) state[list_ptr(d, t & 1, 0)[i]] = RG_STATE_ORGANIC;
-        else state[list_ptr(d, t & 1, 1)[i - n_o]] = RG_STATE_BANDIT;
+        if (i < n_o) state[d.uid[list_ptr(d, t & 1, 0)[i]]] = RG_STATE_ORGANIC;
+        else state[d.uid[list_ptr(d, t & 1, 1)[i - n_o]]] = RG_STATE_BANDIT;
     }
 }
 
@@ -1630,6 +1654,61 @@ __global__ void __launch_bounds__(kBlock) k_export_omega(DevSim d, double* out) 
          i += static_cast<size_t>(gridDim.x) * kBlock) {
         const size_t u = i / d.K, k = i % d.K;
         out[i] = d.omega[u * d.OMS + k];
+    }
+}
+
+// live users only (after a repack the slots of users that left are gone); `out` is zero-filled first
+__global__ void __launch_bounds__(kBlock) k_export_omega_live(DevSim d, uint32_t t, double* out) {
+    const uint32_t n_o = d.step_cnt[2 * t], n_b = d.step_cnt[2 * t + 1];
+    const size_t n = static_cast<size_t>(n_o + n_b) * d.K;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const uint32_t li = static_cast<uint32_t>(i / d.K), k = static_cast<uint32_t>(i % d.K);
+        const uint32_t slot = li < n_o ? list_ptr(d, t & 1, 0)[li] : list_ptr(d, t & 1, 1)[li - n_o];
+        out[static_cast<size_t>(d.uid[slot]) * d.K + k] = d.omega[static_cast<size_t>(slot) * d.OMS + k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// repack: the live lists lose their order step by step (the block that reserves first writes
+// first) and thin out as users leave, so the per-user gathers of omega / the view history turn
+// into scattered single-line fetches (measured: k_advance 0.22 -> 0.57 ns/event between steps
+// 0-20 and 220-240 of the 10 M-user run).  Every few steps the state of the users still alive is
+// therefore copied into the second buffer in list order — new slot = position in [organic |
+// bandit] — and the lists become the identity.  Pure relabelling: user ids travel in uid[].
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_repack_copy(DevSim d, uint32_t t) {
+    const uint32_t n_o = d.step_cnt[2 * t], n_b = d.step_cnt[2 * t + 1], n = n_o + n_b;
+    const uint32_t* cur_o = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const uint32_t* cur_b = list_ptr(d, t & 1, RG_STATE_BANDIT);
+    const uint32_t sub = threadIdx.x & 31;                       // 32 lanes move one user
+    const uint32_t groups = gridDim.x * (kBlock / 32);
+    for (uint32_t i = blockIdx.x * (kBlock / 32) + (threadIdx.x >> 5); i < n; i += groups) {
+        const uint32_t old = i < n_o ? cur_o[i] : cur_b[i - n_o];
+        for (uint32_t k = sub; k < d.OMS; k += 32)
+            d.omega_alt[static_cast<size_t>(i) * d.OMS + k] = d.omega[static_cast<size_t>(old) * d.OMS + k];
+        if (sub == 0) {
+            d.uid_alt[i] = d.uid[old];
+            if (d.lpv) d.lpv_alt[i] = d.lpv[old];
+        }
+        if (d.hist_cap) {
+            const uint32_t hn = d.hist_n[old];
+            if (sub == 0) d.hist_n_alt[i] = hn;
+            for (uint32_t e = sub; e < hn; e += 32) {
+                d.hist_alt[static_cast<size_t>(i) * d.hist_cap + e] = d.hist[static_cast<size_t>(old) * d.hist_cap + e];
+                d.hist_cntv_alt[static_cast<size_t>(i) * d.hist_cap + e] = d.hist_cntv[static_cast<size_t>(old) * d.hist_cap + e];
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_repack_lists(DevSim d, uint32_t t) {
+    const uint32_t n_o = d.step_cnt[2 * t], n_b = d.step_cnt[2 * t + 1];
+    uint32_t* cur_o = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    uint32_t* cur_b = list_ptr(d, t & 1, RG_STATE_BANDIT);
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_o + n_b; i += gridDim.x * kBlock) {
+        if (i < n_o) cur_o[i] = i;
+        else cur_b[i - n_o] = i;
     }
 }
 
@@ -1749,6 +1828,16 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     const DevSim& d = sim->d;
     const uint32_t t = sim->t;
     const uint32_t upper = sim->live_upper;
+    if (sim->repack_every && t && t % sim->repack_every == 0 && sim->d.n_cap >= repack_min_users() && upper >= repack_min_users() / 4) {
+        DevSim& m = sim->d;
+        hipLaunchKernelGGL(k_repack_copy, dim3(grid_for(upper, kBlock / 32)), dim3(kBlock), 0, st, m, t);
+        hipLaunchKernelGGL(k_repack_lists, dim3(grid_for(upper)), dim3(kBlock), 0, st, m, t);
+        std::swap(m.omega, m.omega_alt); std::swap(m.hist, m.hist_alt); std::swap(m.hist_cntv, m.hist_cntv_alt);
+        std::swap(m.hist_n, m.hist_n_alt); std::swap(m.uid, m.uid_alt);
+        if (m.lpv) std::swap(m.lpv, m.lpv_alt);
+        sim->repacked = true;
+        if (getenv("RECOGYM_DEBUG")) fprintf(stderr, "[recogym] repack at t=%u (upper %u)\n", t, upper);
+    }
     if (int rc = prof_mark(sim, st)) return rc;
     // 1. organic product draws of this step (read omega before the transition drifts it)
     if (d.use_mfma == 2) {
@@ -1883,6 +1972,9 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s->bf16_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->bf16_smem));
     d.ablate = 0;
+    s->repack_every = 16;
+    s->repacked = false;
+    if (const char* e = getenv("RECOGYM_REPACK")) s->repack_every = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_ABLATE")) d.ablate = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_LDS_PAD")) s->mfma_smem += static_cast<size_t>(atoi(e));
     if (getenv("RECOGYM_DEBUG") && d.use_mfma && rg_device_count() > 0) {
@@ -1980,6 +2072,7 @@ int rg_sim_reset_users(rg_sim* sim, uint64_t first_user_id, uint64_t n, uint64_t
     sim->t = 0;
     sim->live_upper = static_cast<uint32_t>(n);
     sim->users_reset = true;
+    sim->repacked = false;
     return RG_OK;
 }
 
@@ -2055,8 +2148,14 @@ int rg_sim_export_state(rg_sim* sim, int8_t* d_state, void* stream) {
 
 int rg_sim_export_omega(rg_sim* sim, double* d_omega, void* stream) {
     if (!sim || !d_omega) return fail(RG_EINVAL, "NULL argument");
-    hipLaunchKernelGGL(k_export_omega, dim3(grid_for(static_cast<uint64_t>(sim->d.n_users) * sim->d.K)),
-                       dim3(kBlock), 0, static_cast<hipStream_t>(stream), sim->d, d_omega);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (sim->repacked) {     // slots of users that left are gone: their rows read 0
+        HIP_TRY(hipMemsetAsync(d_omega, 0, sizeof(double) * sim->d.n_users * sim->d.K, st));
+        hipLaunchKernelGGL(k_export_omega_live, dim3(grid_for(static_cast<uint64_t>(sim->live_upper) * sim->d.K)),
+                           dim3(kBlock), 0, st, sim->d, sim->t, d_omega);
+    } else
+        hipLaunchKernelGGL(k_export_omega, dim3(grid_for(static_cast<uint64_t>(sim->d.n_users) * sim->d.K)),
+                           dim3(kBlock), 0, st, sim->d, d_omega);
     HIP_TRY(hipGetLastError());
     return RG_OK;
 }

@@ -83,6 +83,71 @@ def test_hip_matches_oracle(case):
         (oc['organic'], oc['bandit'], oc['clicks'], oc['phantom'])
 
 
+@pytest.mark.parametrize('case', [0, 4, 7, 9, 10])
+def test_repacked_state_matches_oracle(case, monkeypatch):
+    """The state repack (live users' omega / view history / user ids copied into list order every
+    few steps; on by default from 2^18 users) is a pure relabelling: forced on for small runs, every
+    3 steps, the rows still equal the oracle's."""
+    from oracle import oracle as orc
+    monkeypatch.setenv('RECOGYM_REPACK_MIN', '1')
+    monkeypatch.setenv('RECOGYM_REPACK', '3')
+    over, n_users, n_org, pol = CASES[case]
+    cfg = Configuration({**env_1_args, **over})
+    want = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol).generate_logs(n_users, n_org)
+    rows, cnt = run_sim(cfg, n_users, n_org, **pol)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps')},
+                         ps_rtol=1e-6, what=f'repacked case {case}')
+    assert (rows['phantom'] == want['phantom']).all()
+    assert cnt['hist_overflow'] == 0 and cnt['live'] == 0
+
+
+def test_repacked_fixture_last_view_table(monkeypatch):
+    """Same, for the policy whose per-user state (last product viewed) also moves."""
+    monkeypatch.setenv('RECOGYM_REPACK_MIN', '1')
+    monkeypatch.setenv('RECOGYM_REPACK', '2')
+    meta, cols = gu.load('philox_bandit_mf')
+    rows, cnt = run_sim(gu.env_config(meta), meta['n_users'], meta['n_organic'],
+                        **gu.policy_args(meta, cols))
+    gu.assert_rows_equal(rows, cols, ps_rtol=1e-5, what='repacked philox_bandit_mf')
+
+
+def test_omega_export_after_repack(monkeypatch):
+    """omega() / states() address users, not slots, after a repack (sigma_omega = 0: a live user's
+    omega is still its reset draw; rows of users that left read 0)."""
+    from oracle import oracle as orc
+    from recogym_amd.sim import Simulator
+    monkeypatch.setenv('RECOGYM_REPACK_MIN', '1')
+    monkeypatch.setenv('RECOGYM_REPACK', '2')
+    cfg = Configuration({**env_1_args, 'random_seed': 8, 'num_products': 20, 'K': 7, 'sigma_omega': 0.0,
+                         'prob_leave_organic': 0.1, 'prob_leave_bandit': 0.1})
+    sim = Simulator(cfg, 400, device='cuda:0')
+    sim.reset_users(50, 400)
+    for _ in range(9):
+        sim.step()
+    om = sim.omega().cpu().numpy()
+    st = sim.states().cpu().numpy()
+    sim.close()
+    o = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX)
+    want = o.generate_logs(400, first_user_id=50)
+    n_rows = np.bincount(want['u'] - 50, minlength=400)
+    alive9 = n_rows - 1 > 9            # rows minus the phantom row = events; alive at t = 9 needs a 10th event
+    assert 20 < alive9.sum() < 380
+    assert ((st != _abi.RG_STATE_STOP) == alive9).all()
+    bad = np.flatnonzero(~alive9 & (om != 0).any(axis=1))
+    def reset_omega(i):
+        o.reset(50 + int(i))
+        return o.omega
+    diag = ''
+    if len(bad):
+        own = sum(np.allclose(om[i], reset_omega(i)) for i in bad[:20])
+        live_ok = sum(np.allclose(om[i], reset_omega(i)) for i in np.flatnonzero(alive9)[:20])
+        diag = f'{len(bad)} dead rows non-zero; {own}/20 hold the user\'s own omega; live rows right {live_ok}/20'
+    assert len(bad) == 0, diag
+    for i in np.flatnonzero(alive9)[:40]:
+        o.reset(50 + int(i))
+        np.testing.assert_allclose(om[i], o.omega, rtol=1e-13, atol=1e-15)
+
+
 def test_user_sharding_is_invisible():
     """Trajectories are keyed by (seed, user id): simulating users [0,N) at once or in four
     shards with first_user offsets gives identical rows (the multi-GPU contract)."""
