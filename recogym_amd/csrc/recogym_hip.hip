@@ -87,6 +87,8 @@ struct DevSim {
     float* gamma32; float* mu32;   // [P_pad][KS] (k >= K zero, rows >= P zero) / [P_pad] (-inf pad)
     double* gammaT;           // [K][PT] float64 transpose of Gamma, PT = P rounded up to 64 (coalesced f64 draw)
     uint32_t PT;
+    double* gamma_rm;         // [PT][4 XKB + 4] row-major float64 Gamma, k zero-padded to 4 XKB, then mu_o (-inf beyond P):
+    uint32_t XKB;             // one row = what one product costs the user-per-lane float64 kernel in scalar loads; 0 = K > 64
     float* exact_ref;         // [n_users] log2-scaled reference of a draw handed to the float64 kernel
     double* exact_sums;       // [n_users][PT/64] float64 exp-sum of every 64-product chunk
     float2* sc_scratch;       // [kMaxGrid*4 waves][kMaxSC][32] {sum, reference} of the MFMA draw kernel
@@ -216,6 +218,13 @@ size_t mfma_smem_bytes(const Geom& g) {
     return sizeof(float) * (2 * (static_cast<size_t>(g.TP) * g.KS + g.TP) + 64 + 4 * 32 * 2 * g.KH);   // tiles + omega stage
 }
 
+// K classes of the user-per-lane float64 kernel (omega lives in 8 XKB registers per lane)
+uint32_t exact_kb_of(uint32_t K) {
+    const uint32_t opts[] = {1, 2, 3, 4, 5, 6, 8, 12, 16};
+    for (uint32_t o : opts) if (K <= 4 * o) return o;
+    return 0;
+}
+
 uint32_t hist_cap_of(const rg_config& c) {
     if (c.policy != RG_POLICY_ORGANIC_USER_COUNT) return 0;
     return c.ouc_history_cap ? c.ouc_history_cap : kDefaultHistoryCap;
@@ -232,6 +241,8 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     float* stats = w.take<float>(2 * g.KH + 2);
     const size_t PT = align_up(P, 64);
     double* gammaT = w.take<double>(K * PT);
+    const uint32_t xkb = exact_kb_of(c.K);
+    double* gamma_rm = w.take<double>(xkb ? PT * (4 * static_cast<size_t>(xkb) + 4) : 1);
     float* exact_ref = w.take<float>(n);
     double* exact_sums = w.take<double>(n * (PT / 64));
     unsigned short* gsplit = w.take<unsigned short>(g.N1 ? static_cast<size_t>(g.P_pad) * (g.RS / 2) : 1);
@@ -265,6 +276,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->uid = uid; d->omega_alt = omega_alt; d->hist_alt = hist_alt; d->hist_cntv_alt = hist_cntv_alt;
         d->hist_n_alt = hist_n_alt; d->lpv_alt = lpv_alt; d->uid_alt = uid_alt;
         d->gamma32 = gamma32; d->mu32 = mu32; d->stats = stats; d->omega = omega; d->list = list;
+        d->gamma_rm = gamma_rm; d->XKB = xkb;
         d->gammaT = gammaT; d->PT = static_cast<uint32_t>(PT); d->exact_ref = exact_ref; d->exact_sums = exact_sums; d->sc_scratch = sc_scratch; d->chunk_scratch = chunk_scratch;
         d->gsplit = gsplit; d->mu32s = mu32s; d->N1 = g.N1; d->N2 = g.N2; d->N3 = g.N3; d->RS = g.RS; d->TPB = g.TPB;
         d->KH = g.KH; d->KS = g.KS; d->TP = g.TP; d->P_pad = g.P_pad; d->n_chunks = g.n_chunks;
@@ -412,6 +424,19 @@ __global__ void __launch_bounds__(kBlock) k_make_gammaT(DevSim d) {
          i += static_cast<size_t>(gridDim.x) * kBlock) {
         const size_t k = i / d.PT, p = i % d.PT;
         d.gammaT[i] = p < d.P ? d.gamma[p * d.K + k] : 0.0;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_make_gamma_rm(DevSim d) {
+    const uint32_t rs = 4 * d.XKB + 4;
+    const size_t n = static_cast<size_t>(d.PT) * rs;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const size_t p = i / rs, c = i % rs;
+        double v = 0.0;
+        if (c < d.K) v = p < d.P ? d.gamma[p * d.K + c] : 0.0;
+        else if (c == 4 * d.XKB) v = p < d.P ? d.mu_o[p] : -INFINITY;
+        d.gamma_rm[i] = v;
     }
 }
 
@@ -788,10 +813,74 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums(DevSim d, uint32_t t, int
     }
 }
 
-// pure float64 mode: the reference of every user = its max logit (reco_env_v1.py:121)
-__global__ void __launch_bounds__(kBlock) k_exact_ref(DevSim d, uint32_t t) {
+// User-per-lane variant of k_exact_sums for K <= 64 (the one that runs; the tile kernel above
+// remains for larger K).  With a product per lane every FMA needs an omega value broadcast from
+// LDS, and the LDS return path (64 lanes x 16 B per ds_read_b128, shared by the CU's 4 SIMDs)
+// capped that kernel at ~1/5 of the float64 FMA rate.  Here a lane owns a USER: its omega sits
+// in registers, the Gamma row of the product being visited is wave-uniform and arrives through
+// the scalar cache (s_load) as the SGPR operand of v_fma_f64, and the running exp-sum of a
+// lane is sequential in product order — no LDS, no cross-lane traffic, no barriers.
+// Work item = (64 users of the list, one slice of the 64-product chunks); one sum per chunk.
+typedef const __attribute__((address_space(4))) double kdouble;   // constant address space: uniform loads become s_load
+
+template <int KB>
+__global__ void __launch_bounds__(kBlock) k_exact_sums_u(DevSim d, uint32_t t, int from_list, int mode, uint32_t S) {
     const int lane = lane_id();
-    const uint32_t n_cc = (d.PT / 64 + 7) / 8;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t n_cc = d.PT / 64;                           // one stored sum per 64-product chunk
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const uint32_t n = from_list ? d.exact_cnt[t] : n_o;
+    const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const uint32_t n_groups = (n + 63) / 64;
+    const uint32_t ccps = (n_cc + S - 1) / S;                  // chunks per slice
+    const uint32_t n_work = n_groups * S;
+    constexpr uint32_t RSd = 4 * KB + 4;
+    for (uint32_t wk = blockIdx.x * (kBlock / 64) + wave; wk < n_work; wk += gridDim.x * (kBlock / 64)) {
+        const uint32_t grp = wk / S, slice = wk % S;
+        const uint32_t cc0 = slice * ccps, cc1 = min(cc0 + ccps, n_cc);
+        if (cc0 >= cc1) continue;
+        const uint32_t w_idx = grp * 64 + lane;
+        const bool act = w_idx < n;
+        const uint32_t pos = act ? (from_list ? d.exact_list[w_idx] : w_idx) : 0u;
+        const uint32_t slot = act ? cur[pos] : 0u;
+        double om[4 * KB];
+#pragma unroll
+        for (int k = 0; k < 4 * KB; ++k)
+            om[k] = (act && static_cast<uint32_t>(k) < d.K) ? d.omega[static_cast<size_t>(slot) * d.OMS + k] : 0.0;
+        const double M = (mode == 1 && act) ? static_cast<double>(d.exact_ref[w_idx]) * 0.69314718055994530942 : 0.0;
+        for (uint32_t cc = cc0; cc < cc1; ++cc) {
+            double acc = mode == 0 ? -INFINITY : 0.0;
+            const uint32_t p1 = cc * 64 + 64;                  // PT is a multiple of 64
+#pragma unroll 2
+            for (uint32_t p = cc * 64; p < p1; ++p) {
+                kdouble* row = (kdouble*)(d.gamma_rm) + static_cast<size_t>(p) * RSd;   // C-style: address-space cast
+                // same association as the oracle / numpy: (sum_k Gamma[p][k] omega[k]) + mu[p], k ascending
+                // (the zero-padded k leave the sum unchanged)
+                double l = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4 * KB; ++k) l += row[k] * om[k];
+                l += row[4 * KB];                              // -inf for products >= P: exp gives exactly 0
+                acc = mode == 0 ? fmax(acc, l) : acc + exp64(l - M);
+            }
+            if (act) d.exact_sums[static_cast<size_t>(w_idx) * n_cc + cc] = acc;
+        }
+    }
+}
+
+typedef void (*exact_u_kernel_t)(DevSim, uint32_t, int, int, uint32_t);
+exact_u_kernel_t exact_u_kernel_for(uint32_t kb) {
+    switch (kb) {
+        case 1: return k_exact_sums_u<1>;   case 2: return k_exact_sums_u<2>;   case 3: return k_exact_sums_u<3>;
+        case 4: return k_exact_sums_u<4>;   case 5: return k_exact_sums_u<5>;   case 6: return k_exact_sums_u<6>;
+        case 8: return k_exact_sums_u<8>;   case 12: return k_exact_sums_u<12>; case 16: return k_exact_sums_u<16>;
+        default: return nullptr;
+    }
+}
+
+// pure float64 mode: the reference of every user = its max logit (reco_env_v1.py:121)
+__global__ void __launch_bounds__(kBlock) k_exact_ref(DevSim d, uint32_t t, uint32_t G) {
+    const int lane = lane_id();
+    const uint32_t n_cc = (d.PT / 64 + G - 1) / G;
     const uint32_t n = d.step_cnt[2 * t + RG_STATE_ORGANIC];
     const uint32_t waves_total = gridDim.x * (kBlock / 64);
     for (uint32_t w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < n; w += waves_total) {
@@ -802,12 +891,13 @@ __global__ void __launch_bounds__(kBlock) k_exact_ref(DevSim d, uint32_t t) {
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int from_list) {
+// G = 64-product chunks per stored sum (8: tile kernel's coarse chunks, 1: user-per-lane kernel)
+__global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int from_list, uint32_t G) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
     double* om = reinterpret_cast<double*>(smem_raw) + static_cast<size_t>(wave) * d.K;
     const uint32_t n_chunks = d.PT / 64;
-    const uint32_t n_cc = (n_chunks + 7) / 8;
+    const uint32_t n_cc = (n_chunks + G - 1) / G;
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
     const uint32_t n = from_list ? d.exact_cnt[t] : n_o;
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
@@ -848,19 +938,19 @@ __global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int
         }
         if (!found) before = run - sums[n_cc - 1];          // u * total rounded up to total
         __builtin_amdgcn_wave_barrier();
-        // walk the 8 x 64 products of that coarse chunk in product order
-        uint32_t v = min(ccstar * 512 + 511, d.P - 1);       // if rounding leaves no hit: its last product
+        // walk the G x 64 products of that coarse chunk in product order
+        uint32_t v = min(ccstar * G * 64 + G * 64 - 1, d.P - 1);   // if rounding leaves no hit: its last product
         double acc = before;
-        for (uint32_t i = 0; i < 8; ++i) {
-            const uint32_t p = ccstar * 512 + i * 64 + lane;
-            if (ccstar * 8 + i >= n_chunks) break;
+        for (uint32_t i = 0; i < G; ++i) {
+            const uint32_t p = (ccstar * G + i) * 64 + lane;
+            if (ccstar * G + i >= n_chunks) break;
             double lg = 0.0;
             const double* g = d.gammaT + p;                  // PT columns: always in range
             for (uint32_t k = 0; k < d.K; ++k) lg += g[static_cast<size_t>(k) * d.PT] * om[k];
             lg = p < d.P ? lg + d.mu_o[p] : -INFINITY;
             const double incl = wave_scan(exp64(lg - M), lane);
             const unsigned long long hit = __ballot(p < d.P && acc + incl > target);
-            if (hit) { v = ccstar * 512 + i * 64 + static_cast<uint32_t>(__builtin_ctzll(hit)); break; }
+            if (hit) { v = (ccstar * G + i) * 64 + static_cast<uint32_t>(__builtin_ctzll(hit)); break; }
             acc += __shfl(incl, 63);
         }
         if (lane == 0) {
@@ -1808,6 +1898,21 @@ int prof_mark(rg_sim* sim, hipStream_t st) {
 void launch_exact(rg_sim* sim, uint32_t t, int from_list, uint64_t est, hipStream_t st) {
     const DevSim& d = sim->d;
     const uint32_t n_chunks = d.PT / 64;
+    if (exact_u_kernel_t ku = (getenv("RECOGYM_EXACT_TILE") ? nullptr : exact_u_kernel_for(d.XKB))) {
+        const uint64_t groups = (est + 63) / 64;
+        uint32_t S = static_cast<uint32_t>(4096 / (groups ? groups : 1));   // ~16 waves per CU
+        if (S > n_chunks) S = n_chunks;
+        if (S < 1) S = 1;
+        const int grid = grid_for(groups * S, kBlock / 64);
+        if (!from_list) {
+            hipLaunchKernelGGL(ku, dim3(grid), dim3(kBlock), 0, st, d, t, 0, 0, S);
+            hipLaunchKernelGGL(k_exact_ref, dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t, 1u);
+        }
+        hipLaunchKernelGGL(ku, dim3(grid), dim3(kBlock), 0, st, d, t, from_list, 1, S);
+        hipLaunchKernelGGL(k_exact_pick, dim3(grid_for(est, kBlock / 64)), dim3(kBlock),
+                           sizeof(double) * d.K * (kBlock / 64), st, d, t, from_list, 1u);
+        return;
+    }
     const uint64_t groups = (est + kExactUsers - 1) / kExactUsers;
     uint32_t S = static_cast<uint32_t>(2048 / (groups ? groups : 1));
     if (S > (n_chunks + 7) / 8) S = (n_chunks + 7) / 8;
@@ -1816,11 +1921,11 @@ void launch_exact(rg_sim* sim, uint32_t t, int from_list, uint64_t est, hipStrea
     const size_t smem = sizeof(double) * (static_cast<size_t>(d.K) * 64 + 64 + kExactUsers * d.K);
     if (!from_list) {
         hipLaunchKernelGGL(k_exact_sums, dim3(grid), dim3(kBlock), smem, st, d, t, 0, 0, S);
-        hipLaunchKernelGGL(k_exact_ref, dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t);
+        hipLaunchKernelGGL(k_exact_ref, dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t, 8u);
     }
     hipLaunchKernelGGL(k_exact_sums, dim3(grid), dim3(kBlock), smem, st, d, t, from_list, 1, S);
     hipLaunchKernelGGL(k_exact_pick, dim3(grid_for(est, kBlock / 64)), dim3(kBlock),
-                       sizeof(double) * d.K * (kBlock / 64), st, d, t, from_list);
+                       sizeof(double) * d.K * (kBlock / 64), st, d, t, from_list, 8u);
 }
 
 int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
@@ -2011,6 +2116,9 @@ int rg_sim_set_tables(rg_sim* sim, const double* d_gamma, const double* d_mu_org
     sim->d.gamma = d_gamma; sim->d.mu_o = d_mu_organic; sim->d.beta = d_beta; sim->d.mu_b = d_mu_bandit;
     hipLaunchKernelGGL(k_make_gammaT, dim3(grid_for(static_cast<size_t>(sim->d.K) * sim->d.PT)), dim3(kBlock), 0,
                        static_cast<hipStream_t>(stream), sim->d);
+    if (sim->d.XKB)
+        hipLaunchKernelGGL(k_make_gamma_rm, dim3(grid_for(static_cast<size_t>(sim->d.PT) * (4 * sim->d.XKB + 4))), dim3(kBlock), 0,
+                           static_cast<hipStream_t>(stream), sim->d);
     if (sim->d.use_mfma) {
         const size_t n = static_cast<size_t>(sim->d.P_pad) * sim->d.KS;
         hipLaunchKernelGGL(k_make_fp32_tables, dim3(grid_for(n)), dim3(kBlock), 0,
