@@ -657,6 +657,36 @@ __device__ __forceinline__ double exp64(double x) {
     return ldexp(p, static_cast<int>(kf));
 }
 
+// Table variant for the kernel that spends its time in exp: exp(x) = 2^e * T[j] * exp(r) with
+// n = rint(x * 32/ln 2) = 32 e + j and |r| <= ln 2 / 64, so a degree-6 polynomial is enough
+// (remainder r^7/5040 < 4e-18) — ~15 float64 instructions instead of ~35.  T[j] = 2^(j/32),
+// correctly rounded; `tab` is the block's LDS copy (32 doubles, one bank pair each: conflict-free).
+__device__ const double kExp2Tab32[32] = {
+    0x1.0000000000000p+0, 0x1.059b0d3158574p+0, 0x1.0b5586cf9890fp+0, 0x1.11301d0125b51p+0,
+    0x1.172b83c7d517bp+0, 0x1.1d4873168b9aap+0, 0x1.2387a6e756238p+0, 0x1.29e9df51fdee1p+0,
+    0x1.306fe0a31b715p+0, 0x1.371a7373aa9cbp+0, 0x1.3dea64c123422p+0, 0x1.44e086061892dp+0,
+    0x1.4bfdad5362a27p+0, 0x1.5342b569d4f82p+0, 0x1.5ab07dd485429p+0, 0x1.6247eb03a5585p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.71f75e8ec5f74p+0, 0x1.7a11473eb0187p+0, 0x1.82589994cce13p+0,
+    0x1.8ace5422aa0dbp+0, 0x1.93737b0cdc5e5p+0, 0x1.9c49182a3f090p+0, 0x1.a5503b23e255dp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b7f76f2fb5e47p+0, 0x1.c199bdd85529cp+0, 0x1.cb720dcef9069p+0,
+    0x1.d5818dcfba487p+0, 0x1.dfc97337b9b5fp+0, 0x1.ea4afa2a490dap+0, 0x1.f50765b6e4540p+0};
+
+__device__ __forceinline__ double exp64t(double x, const double* tab) {
+    x = fmax(x, -750.0);                                   // e^-750 underflows to exactly 0 (also takes -inf)
+    const double nf = rint(x * 0x1.71547652b82fep+5);      // 32 / ln 2
+    double r = fma(nf, -0x1.62e42fe000000p-6, x);          // ln 2 / 32, high part (29 bits: nf * hi is exact)
+    r = fma(nf, -0x1.f473de6af278fp-35, r);                // low part
+    const int n = static_cast<int>(nf);
+    double p = 1.3888888888888889e-03;                     // 1/6!
+    p = fma(p, r, 8.3333333333333332e-03);                 // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);                 // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);                 // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(tab[n & 31] * p, n >> 5);
+}
+
 // inclusive scan of x over the 64 lanes of the wave
 __device__ __forceinline__ double wave_scan(double x, int lane) {
     for (int o = 1; o < 64; o <<= 1) {
@@ -825,6 +855,9 @@ typedef const __attribute__((address_space(4))) double kdouble;   // constant ad
 
 template <int KB>
 __global__ void __launch_bounds__(kBlock) k_exact_sums_u(DevSim d, uint32_t t, int from_list, int mode, uint32_t S) {
+    __shared__ double exp_tab[32];
+    if (threadIdx.x < 32) exp_tab[threadIdx.x] = kExp2Tab32[threadIdx.x];
+    __syncthreads();
     const int lane = lane_id();
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t n_cc = d.PT / 64;                           // one stored sum per 64-product chunk
@@ -860,7 +893,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_u(DevSim d, uint32_t t, i
 #pragma unroll
                 for (int k = 0; k < 4 * KB; ++k) l += row[k] * om[k];
                 l += row[4 * KB];                              // -inf for products >= P: exp gives exactly 0
-                acc = mode == 0 ? fmax(acc, l) : acc + exp64(l - M);
+                acc = mode == 0 ? fmax(acc, l) : acc + exp64t(l - M, exp_tab);
             }
             if (act) d.exact_sums[static_cast<size_t>(w_idx) * n_cc + cc] = acc;
         }
@@ -1900,10 +1933,14 @@ void launch_exact(rg_sim* sim, uint32_t t, int from_list, uint64_t est, hipStrea
     const uint32_t n_chunks = d.PT / 64;
     if (exact_u_kernel_t ku = (getenv("RECOGYM_EXACT_TILE") ? nullptr : exact_u_kernel_for(d.XKB))) {
         const uint64_t groups = (est + 63) / 64;
-        uint32_t S = static_cast<uint32_t>(4096 / (groups ? groups : 1));   // ~16 waves per CU
+        // The kernel's stall is the scalar-load latency of a Gamma row (the table streams through
+        // L2), hidden only by other waves: fill every SIMD to the kernel's occupancy (6 waves) and
+        // cut the work ~4x finer than that so the grid-stride loop balances.
+        uint32_t S = static_cast<uint32_t>(24576 / (groups ? groups : 1));
         if (S > n_chunks) S = n_chunks;
         if (S < 1) S = 1;
-        const int grid = grid_for(groups * S, kBlock / 64);
+        int grid = grid_for(groups * S, kBlock / 64);
+        if (grid > 1536) grid = 1536;
         if (!from_list) {
             hipLaunchKernelGGL(ku, dim3(grid), dim3(kBlock), 0, st, d, t, 0, 0, S);
             hipLaunchKernelGGL(k_exact_ref, dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t, 1u);
