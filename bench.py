@@ -196,7 +196,8 @@ def main():
                         kernel_ms=dict(draw_mfma=round(prof['draw_mfma_ms'], 2),
                                        draw_search=round(prof['draw_search_ms'], 2),
                                        draw_exact_f64=round(prof['draw_exact_ms'], 2),
-                                       advance=round(prof['advance_ms'], 2)),
+                                       advance=round(prof['advance_ms'], 2),
+                                       tail=round(prof['tail_ms'], 2)),
                         exact_fraction=round(c['exact_draws'] / max(c['organic'], 1), 5),
                         hbm_algorithmic_GBps=round(
                             (events / args.steps) * (8 * K + 8 + 16 + 3 + 35) / 1e9 /

@@ -166,7 +166,10 @@ int rg_sim_reseed(rg_sim* sim, uint64_t seed, uint64_t policy_seed);
 int rg_sim_step(rg_sim* sim, const int32_t* d_actions, void* stream);
 
 /* generate_logs' user loop (abstract.py:299-316) for all users at once: steps until every user
- * reached `stop` or max_steps transitions were made.  Synchronises `stream`. */
+ * reached `stop` or max_steps transitions were made.  Synchronises `stream`.  With max_steps >=
+ * 65536 ("to the end") the last users of the run (<= 4096 alive at a 16-step poll; RECOGYM_TAIL overrides) are walked
+ * to their end one user per workgroup instead of step by step; rows, counters and the sorted
+ * log are the same, RG_CNT_STEP then reports the longest trajectory. */
 int rg_sim_run(rg_sim* sim, uint32_t max_steps, void* stream);
 
 /* Synchronises `stream` and copies RG_CNT_N counters to the host. */
@@ -176,7 +179,8 @@ int rg_sim_read_counters(rg_sim* sim, int64_t* out, void* stream);
  * events on the stream the kernels are launched on.  rg_sim_get_profile returns
  * out[0..3] = total milliseconds spent in the MFMA organic-draw kernel, in its search kernel
  * (sliced mode only), in the float64 resolve kernels and in the advance kernel; out[4] =
- * profiled steps.  `out` must hold 5 doubles.  Off by default. */
+ * profiled steps; out[5] = milliseconds in the tail kernel (rg_sim_run finishes the last users
+ * of a run user by user instead of step by step).  `out` must hold 6 doubles.  Off by default. */
 int rg_sim_set_profiling(rg_sim* sim, int on);
 int rg_sim_get_profile(rg_sim* sim, double* out);
 

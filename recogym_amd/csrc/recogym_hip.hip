@@ -148,6 +148,8 @@ struct rg_sim {
     bool tables_set, users_reset;
     bool repacked;            // slots no longer equal user indices (since the last reset)
     uint32_t repack_every;    // steps between repacks (RECOGYM_REPACK, 0 = never)
+    uint32_t tail_below;      // rg_sim_run hands the run to k_tail once at most this many users live (RECOGYM_TAIL, 0 = never)
+    double prof_tail_ms;
     uint32_t* h_pinned;       // 4 x u32 staging for the live-count readback
     size_t mfma_smem, bf16_smem;
     void (*bf16_kernel)(DevSim, uint32_t, uint32_t);
@@ -1741,6 +1743,213 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_tail — the end of a run, user by user instead of step by step.
+//
+// Once few users are left (10 M users: ~1 300 of the ~1 800 lock-step steps serve < 1 % of the
+// events) a lock-step step costs its launch/latency floor (~110 us) whatever the population.
+// Trajectories are independent, so the remaining users are handed to this kernel instead: a
+// block takes a user (ticket counter) and walks it to its end — the organic draws in float64
+// across the block (the arithmetic of k_exact_*: lane per product, 64-product chunk sums, prefix
+// search), the click / transition / policy / history work of k_advance on thread 0.  Rows go to
+// log rows log_base[t0] + ticket (the sorted log does not depend on raw positions); events of
+// steps > t0 are counted in the kCntTail* counters (step t0's are in step_cnt[t0]).
+// ------------------------------------------------------------------------------------------
+constexpr int kCntTailRows = 10, kCntTailOrganic = 11, kCntTailBandit = 12, kCntTailMaxT = 13, kCntTailTicket = 14,
+              kCntTailLimit = 15;   // internal slots of counters[] (RG_CNT_N = 16)
+
+__global__ void __launch_bounds__(kBlock) k_tail(DevSim d, uint32_t t0) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* om = reinterpret_cast<double*>(smem_raw);                       // [K rounded up to 2]
+    double* csum = om + ((d.K + 1) & ~1u);                                   // [n_chunks rounded up to 4]
+    __shared__ uint32_t s_next, s_v;
+    __shared__ int s_state, s_drift;
+    __shared__ double s_max[kBlock / 64];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t n_o = d.step_cnt[2 * t0 + RG_STATE_ORGANIC], n_b = d.step_cnt[2 * t0 + RG_STATE_BANDIT];
+    const uint32_t n = n_o + n_b;
+    const uint32_t n_chunks = d.PT / 64;
+    const uint32_t* cur_o = list_ptr(d, t0 & 1, RG_STATE_ORGANIC);
+    const uint32_t* cur_b = list_ptr(d, t0 & 1, RG_STATE_BANDIT);
+    unsigned long long c_org = 0, c_ban = 0, c_clicks = 0, c_ph = 0;          // thread 0 only
+    uint32_t c_maxt = 0;
+
+    // block maximum of the logits (pass 0) or chunk sums of exp(l - ref) into csum + that maximum
+    auto sweep = [&](bool sums, double ref) -> double {
+        double wmax = -INFINITY;
+        for (uint32_t g = wave; g * 4 < n_chunks; g += kBlock / 64) {
+            double l[4];
+            logit64x4(d, om, g * 256 + lane, l);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                wmax = fmax(wmax, l[u]);
+                if (sums) {
+                    const double sm = wave_sum(exp64(l[u] - ref));
+                    if (lane == 0) csum[g * 4 + u] = sm;                     // chunks past P: every logit -inf -> 0
+                }
+            }
+        }
+        wmax = wave_max(wmax);
+        __syncthreads();                       // s_max of the previous sweep has been read
+        if (lane == 0) s_max[wave] = wmax;
+        __syncthreads();
+        double m = s_max[0];
+        for (int w2 = 1; w2 < kBlock / 64; ++w2) m = fmax(m, s_max[w2]);
+        return m;
+    };
+
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_next = static_cast<uint32_t>(atomicAdd(&d.counters[kCntTailTicket], 1ull));
+        __syncthreads();
+        const uint32_t i = s_next;
+        if (i >= n) break;
+        const uint32_t slot = i < n_o ? cur_o[i] : cur_b[i - n_o];
+        int state = i < n_o ? RG_STATE_ORGANIC : RG_STATE_BANDIT;
+        const uint32_t uidx = d.uid[slot];
+        const uint32_t user = static_cast<uint32_t>(d.first_user + uidx);
+        for (uint32_t k = threadIdx.x; k < d.K; k += kBlock) om[k] = d.omega[static_cast<size_t>(slot) * d.OMS + k];
+        bool have_ref = false;
+        double Mref = 0.0;
+        __syncthreads();
+        for (uint32_t t = t0;; ++t) {
+            const rg_u32x4 w = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
+            if (state == RG_STATE_ORGANIC) {
+                // ---- organic product draw, float64 across the block ----
+                if (!have_ref) { Mref = sweep(false, 0.0); have_ref = true; }
+                double m = sweep(true, Mref);
+                // any shift near the maximum gives the same decisions (1e-16 level); if omega drifted
+                // the kept reference far from it, take the sums again with the fresh one
+                if (!(fabs(m - Mref) <= 400.0)) { Mref = m; m = sweep(true, Mref); }
+                if (wave == 0) {
+                    double total = 0.0;
+                    for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64) {
+                        const uint32_t c = c0 + lane;
+                        total += __shfl(wave_scan(c < n_chunks ? csum[c] : 0.0, lane), 63);
+                    }
+                    const double target = rg_uniform(w.w[0], w.w[1]) * total;
+                    uint32_t cstar = n_chunks - 1;
+                    double before = 0.0, run = 0.0;
+                    bool found = false;
+                    for (uint32_t c0 = 0; c0 < n_chunks && !found; c0 += 64) {
+                        const uint32_t c = c0 + lane;
+                        const double x = c < n_chunks ? csum[c] : 0.0;
+                        const double incl = wave_scan(x, lane);
+                        const unsigned long long hit = __ballot(c < n_chunks && run + incl > target);
+                        if (hit) {
+                            const int L = __builtin_ctzll(hit);
+                            cstar = c0 + L;
+                            before = run + __shfl(incl - x, L);
+                            found = true;
+                        } else run += __shfl(incl, 63);
+                    }
+                    if (!found) before = run - csum[n_chunks - 1];
+                    const uint32_t p = cstar * 64 + lane;
+                    double lg = 0.0;
+                    const double* g = d.gammaT + p;
+                    for (uint32_t k = 0; k < d.K; ++k) lg += g[static_cast<size_t>(k) * d.PT] * om[k];
+                    lg = p < d.P ? lg + d.mu_o[p] : -INFINITY;
+                    const double incl = wave_scan(exp64(lg - Mref), lane);
+                    const unsigned long long hit = __ballot(p < d.P && before + incl > target);
+                    const uint32_t v = hit ? cstar * 64 + static_cast<uint32_t>(__builtin_ctzll(hit))
+                                           : min(cstar * 64 + 63, d.P - 1);
+                    if (lane == 0) s_v = v;
+                }
+                Mref = m;                                  // reference of this user's next draw
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                if (t > t0) { if (state == RG_STATE_ORGANIC) c_org += 1; else c_ban += 1; }
+                const double u_trans = rg_uniform(w.w[2], w.w[3]);
+                bool click = false;
+                if (state == RG_STATE_ORGANIC) {
+                    const uint32_t v = s_v;
+                    const uint64_t row = d.log_base[t0] + atomicAdd(&d.counters[kCntTailRows], 1ull);
+                    if (d.log && row < d.log_cap) {
+                        rg_event e;
+                        e.u = user; e.t = t; e.code = v; e.ps = __builtin_nanf("");
+                        d.log[row] = e;
+                    }
+                    if (d.lpv) d.lpv[slot] = v;
+                    if (d.hist_cap) history_add(d, slot, v);
+                } else {
+                    double ps;
+                    const uint32_t a = policy_act(d, slot, user, t, &ps);
+                    const double* b = d.beta + static_cast<size_t>(a) * d.K;
+                    double x = 0.0;
+                    for (uint32_t k = 0; k < d.K; ++k) x += b[k] * om[k];
+                    const double ctr = ff64(x + d.mu_b[a]);
+                    const double p0 = 1.0 - ctr;
+                    click = (p0 / (p0 + ctr)) <= rg_uniform(w.w[0], w.w[1]);
+                    c_clicks += click;
+                    const uint64_t row = d.log_base[t0] + atomicAdd(&d.counters[kCntTailRows], 1ull);
+                    if (d.log && row < d.log_cap) {
+                        rg_event e;
+                        e.u = user; e.t = t;
+                        e.code = RG_EV_BANDIT | (click ? RG_EV_CLICK : 0u) | a;
+                        e.ps = static_cast<float>(ps);
+                        d.log[row] = e;
+                    }
+                }
+                const double c0 = state == RG_STATE_ORGANIC ? d.cdf_o0 : d.cdf_b0;
+                const double c1 = state == RG_STATE_ORGANIC ? d.cdf_o1 : d.cdf_b1;
+                int ns = (c0 <= u_trans) + (c1 <= u_trans);
+                s_drift = d.sigma_omega != 0.0 && (d.change_omega_for_bandits || ns == RG_STATE_ORGANIC);
+                if (click) ns = RG_STATE_ORGANIC;
+                const bool organic_only = (d.first_user + uidx) < d.organic_only_below;
+                if (organic_only && ns != RG_STATE_ORGANIC) {
+                    ns = RG_STATE_STOP;
+                    d.n_events[uidx] = t + 1;
+                } else if (ns == RG_STATE_STOP) {
+                    d.n_events[uidx] = t + 1;
+                    double ps;
+                    const uint32_t a = policy_act(d, slot, user, t + 1, &ps);
+                    rg_event e;
+                    e.u = user; e.t = t + 1; e.code = RG_EV_BANDIT | RG_EV_PHANTOM | a;
+                    e.ps = static_cast<float>(ps);
+                    d.phantom[uidx] = e;
+                    d.has_phantom[uidx] = 1;
+                    c_ph += 1;
+                } else if (t + 2 >= kMaxSteps) {
+                    ns = RG_STATE_STOP;                    // same bound as the lock-step loop; reported by the host
+                    d.n_events[uidx] = t + 1;
+                    atomicAdd(&d.counters[kCntTailLimit], 1ull);
+                }
+                if (ns == RG_STATE_STOP) c_maxt = max(c_maxt, t + 1);
+                s_state = ns;
+            }
+            __syncthreads();
+            state = s_state;
+            if (s_drift && state != RG_STATE_STOP) {
+                // omega drift of this step (k_advance applies it before the click override, which
+                // only changes the state) — pair j by thread j
+                for (uint32_t j = threadIdx.x; 2 * j < d.K; j += kBlock) {
+                    double z0, z1;
+                    normal_pair(d.seed, user, t, j, RG_DRAW_DRIFT, &z0, &z1);
+                    om[2 * j] = om[2 * j] + d.sigma_omega * z0;
+                    if (2 * j + 1 < d.K) om[2 * j + 1] = om[2 * j + 1] + d.sigma_omega * z1;
+                }
+            }
+            __syncthreads();
+            if (state == RG_STATE_STOP) break;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (c_org) atomicAdd(&d.counters[kCntTailOrganic], c_org);
+        if (c_ban) atomicAdd(&d.counters[kCntTailBandit], c_ban);
+        if (c_clicks) atomicAdd(&d.counters[RG_CNT_CLICKS], c_clicks);
+        if (c_ph) atomicAdd(&d.counters[RG_CNT_PHANTOM], c_ph);
+        if (c_maxt) atomicMax(&d.counters[kCntTailMaxT], static_cast<unsigned long long>(c_maxt));
+    }
+}
+
+// closes the books of the tail: step t0 + 1 exists, is empty, and starts after the tail's rows
+__global__ void k_tail_finish(DevSim d, uint32_t t0) {
+    d.log_base[t0 + 1] = d.log_base[t0] + d.counters[kCntTailRows];
+    d.step_cnt[2 * (t0 + 1)] = 0;
+    d.step_cnt[2 * (t0 + 1) + 1] = 0;
+}
+
 // totals that are sums over the per-step counts
 __global__ void k_totals(DevSim d, uint32_t t_now) {
     __shared__ unsigned long long so[kBlock], sb[kBlock];
@@ -1753,10 +1962,10 @@ __global__ void k_totals(DevSim d, uint32_t t_now) {
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        d.counters[RG_CNT_ORGANIC] = so[0];
-        d.counters[RG_CNT_BANDIT] = sb[0];
+        d.counters[RG_CNT_ORGANIC] = so[0] + d.counters[kCntTailOrganic];
+        d.counters[RG_CNT_BANDIT] = sb[0] + d.counters[kCntTailBandit];
         d.counters[RG_CNT_LIVE] = static_cast<unsigned long long>(d.step_cnt[2 * t_now]) + d.step_cnt[2 * t_now + 1];
-        d.counters[RG_CNT_STEP] = t_now;
+        d.counters[RG_CNT_STEP] = max(static_cast<unsigned long long>(t_now), d.counters[kCntTailMaxT]);
         const unsigned long long rows = d.log_base[t_now];
         d.counters[RG_CNT_LOG_ROWS] = d.log ? (rows < d.log_cap ? rows : d.log_cap) : 0ull;
         d.counters[RG_CNT_LOG_DROPPED] = d.log ? (rows > d.log_cap ? rows - d.log_cap : 0ull) : 0ull;
@@ -2116,6 +2325,9 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     d.ablate = 0;
     s->repack_every = 16;
     s->repacked = false;
+    s->tail_below = 4096;
+    s->prof_tail_ms = 0.0;
+    if (const char* e = getenv("RECOGYM_TAIL")) s->tail_below = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_REPACK")) s->repack_every = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_ABLATE")) d.ablate = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_LDS_PAD")) s->mfma_smem += static_cast<size_t>(atoi(e));
@@ -2248,6 +2460,33 @@ int rg_sim_run(rg_sim* sim, uint32_t max_steps, void* stream) {
         const uint64_t live = static_cast<uint64_t>(sim->h_pinned[0]) + sim->h_pinned[1];
         sim->live_upper = static_cast<uint32_t>(live);
         if (live == 0) break;
+        // few users left: finish them user by user (k_tail) instead of ~1 000 more latency-bound steps
+        const size_t tail_smem = sizeof(double) * (((sim->d.K + 1) & ~1u) + ((sim->d.PT / 64 + 3) & ~3u));
+        if (live <= sim->tail_below && max_steps >= kMaxSteps && tail_smem <= 48 * 1024 && sim->t + 2 < kMaxSteps) {
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            if (sim->profiling) {
+                HIP_TRY(hipEventCreate(&ev[0])); HIP_TRY(hipEventCreate(&ev[1]));
+                HIP_TRY(hipEventRecord(ev[0], st));
+            }
+            const int grid = static_cast<int>(live < 2048 ? live : 2048);
+            hipLaunchKernelGGL(k_tail, dim3(grid), dim3(kBlock), tail_smem, st, sim->d, sim->t);
+            hipLaunchKernelGGL(k_tail_finish, dim3(1), dim3(1), 0, st, sim->d, sim->t);
+            HIP_TRY(hipGetLastError());
+            if (sim->profiling) HIP_TRY(hipEventRecord(ev[1], st));
+            unsigned long long* h64 = reinterpret_cast<unsigned long long*>(sim->h_pinned);
+            HIP_TRY(hipMemcpyAsync(h64, sim->d.counters + kCntTailLimit, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (sim->profiling) {
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+                sim->prof_tail_ms += ms;
+                (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
+            }
+            sim->t += 1;
+            sim->live_upper = 0;
+            if (*h64) return fail(RG_ELIMIT, "more than %u steps", kMaxSteps);
+            break;
+        }
     }
     return RG_OK;
 }
@@ -2271,6 +2510,7 @@ int rg_sim_set_profiling(rg_sim* sim, int on) {
     sim->profiling = on != 0;
     sim->prof_used = 0; sim->prof_launches = 0;
     sim->prof_ms[0] = sim->prof_ms[1] = sim->prof_ms[2] = sim->prof_ms[3] = 0.0;
+    sim->prof_tail_ms = 0.0;
     return RG_OK;
 }
 
@@ -2279,6 +2519,7 @@ int rg_sim_get_profile(rg_sim* sim, double* out) {
     if (int rc = prof_collect(sim)) return rc;
     out[0] = sim->prof_ms[0]; out[1] = sim->prof_ms[1]; out[2] = sim->prof_ms[2]; out[3] = sim->prof_ms[3];
     out[4] = static_cast<double>(sim->prof_launches);
+    out[5] = sim->prof_tail_ms;
     return RG_OK;
 }
 

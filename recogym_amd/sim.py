@@ -170,11 +170,11 @@ class Simulator:
         _abi.check(self.lib.rg_sim_set_profiling(self._h, int(on)), 'rg_sim_set_profiling')
 
     def profile(self):
-        """-> dict(draw_mfma_ms, draw_search_ms, draw_exact_ms, advance_ms, steps), HIP events."""
-        out = (C.c_double * 5)()
+        """-> dict(draw_mfma_ms, draw_search_ms, draw_exact_ms, advance_ms, steps, tail_ms), HIP events."""
+        out = (C.c_double * 6)()
         _abi.check(self.lib.rg_sim_get_profile(self._h, out), 'rg_sim_get_profile')
         return dict(draw_mfma_ms=out[0], draw_search_ms=out[1], draw_exact_ms=out[2],
-                    advance_ms=out[3], steps=int(out[4]))
+                    advance_ms=out[3], steps=int(out[4]), tail_ms=out[5])
 
     def states(self):
         with torch.cuda.device(self.device):

@@ -101,6 +101,24 @@ def test_repacked_state_matches_oracle(case, monkeypatch):
     assert cnt['hist_overflow'] == 0 and cnt['live'] == 0
 
 
+@pytest.mark.parametrize('case', [0, 2, 4, 8, 9, 12])
+def test_lock_step_to_the_end_matches_oracle(case, monkeypatch):
+    """rg_sim_run normally finishes the last users of a run with the per-user tail kernel (every
+    small case here runs mostly in it); with RECOGYM_TAIL=0 the lock-step kernels run to the end."""
+    from oracle import oracle as orc
+    monkeypatch.setenv('RECOGYM_TAIL', '0')
+    over, n_users, n_org, pol = CASES[case]
+    cfg = Configuration({**env_1_args, **over})
+    want_env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol)
+    want = want_env.generate_logs(n_users, n_org)
+    rows, cnt = run_sim(cfg, n_users, n_org, **pol)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps')},
+                         ps_rtol=1e-6, what=f'lock-step case {case}')
+    oc = want_env.counters()
+    assert (cnt['organic'], cnt['bandit'], cnt['clicks'], cnt['phantom']) == \
+        (oc['organic'], oc['bandit'], oc['clicks'], oc['phantom'])
+
+
 def test_repacked_fixture_last_view_table(monkeypatch):
     """Same, for the policy whose per-user state (last product viewed) also moves."""
     monkeypatch.setenv('RECOGYM_REPACK_MIN', '1')
