@@ -1528,6 +1528,324 @@ __global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 3 : 1)) k_draw_bf16(DevSim 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_draw_bf16p — the same computation as k_draw_bf16 with the instruction stream arranged for
+// the matrix pipe (tools/ubench/chunk_il.hip, chunk_loop.hip):
+//   * a wave's back-to-back MFMAs keep the SIMD's VALU issue port, so other waves' exp work does
+//     NOT fill in behind them, and a dependent accumulator chain leaves ~25 unusable idle cycles
+//     per MFMA: the one-accumulator loop above costs MFMA time + VALU time + LDS latency;
+//   * with two independent chains (a PAIR of chunks) interleaved in one wave and the exp-sum of
+//     the PREVIOUS pair plus the LDS operand loads of the NEXT pair placed in the issue slots
+//     between the MFMAs (order pinned with sched_barrier), everything but the MFMA stream hides.
+// Per pair: 2 (N1+N2+N3) MFMAs, 32 exps + 2 trees of the previous pair, 2 N1 + 8 ds_read_b128
+// of the next pair.  One barrier per product tile, placed between its two pairs: at that point
+// every wave holds the tile's operands in registers (so the buffer is refilled with tile + 2)
+// and the tile after it has landed (so the second pair's stream can fetch from it).
+// Needs ~200 VGPRs = 2 waves per SIMD; one such wave already paces the matrix pipe.
+// ------------------------------------------------------------------------------------------
+#define RG_PIN() __builtin_amdgcn_sched_barrier(0)
+
+// Tile DMA the compiler does not see.  hipcc puts s_waitcnt vmcnt(0) in front of the first ds_read
+// that follows a global/buffer load to LDS (the DMA may alias the read), which turns the tile
+// prefetch into a synchronous load.  The pipelined kernel only reads a tile after the barrier
+// that publishes it, so it issues the DMA opaquely (buffer_load_dwordx4 ... lds: LDS address =
+// M0 + lane * 16, memory address = resource base + scalar offset + lane offset) and waits for it
+// itself (RG_DMA_WAIT) right before that barrier.  The LDS reads stay ordinary compiler-visible loads.
+typedef int rg_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma_to_lds_b128(rg_v4i rsrc, uint32_t lds_addr, uint32_t lane_off, uint32_t s_off) {
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(lane_off), "s"(rsrc), "s"(s_off) : "m0", "memory");
+}
+// raw buffer resource over [p, p + 2 GiB): base, stride 0, num_records, gfx9 raw-buffer flags
+__device__ __forceinline__ rg_v4i raw_buffer_rsrc(const void* p) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    rg_v4i r;
+    r[0] = static_cast<int>(static_cast<uint32_t>(a));
+    r[1] = static_cast<int>(static_cast<uint32_t>(a >> 32) & 0xffffu);
+    r[2] = 0x7fffffff;
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* generic_ptr) {
+    return static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const char*)generic_ptr));
+}
+#define RG_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+template <int KH, int N1, int N2, int N3>
+__global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, uint32_t S) {
+    constexpr int NM = N1 + N2 + N3;          // MFMAs per chunk
+    constexpr int EXS = NM > 3 ? NM - 3 : 1;  // MFMA slots that carry the exps (and the A loads); the rest carry the mu loads
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const uint32_t tile_b = d.TPB * d.RS;                             // bytes per split tile
+    char* g_buf = smem_raw;                                           // [2][TPB][RS]
+    float* mu_buf = reinterpret_cast<float*>(g_buf + 2 * tile_b);     // [2][TPB] (+ pad)
+    float* om_stage = mu_buf + 2 * d.TPB + 64;                        // [4 waves][32 users][2KH] omega32
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();   // scalar: per-wave pointers stay in SGPRs
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const uint32_t n_tiles = (n_o + 127) / 128;
+    const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const float mumax = d.stats[2 * KH + 1], g2max = d.stats[2 * KH];
+    const uint32_t scps = (d.n_sc + S - 1) / S;                       // super-chunks per slice
+    const uint32_t n_work = n_tiles * S;
+    float* omu = om_stage + (wave * 32 + j) * 2 * KH;                 // this lane's user's omega32
+
+    struct PairOps { bf16x8 A0[N1], A1[N1]; };
+
+    for (uint32_t wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
+        const uint32_t tb = wk / S, slice = wk % S;
+        const uint32_t chunk_lo = min(slice * scps * d.sc_chunks, d.n_chunks);
+        const uint32_t chunk_hi = min((slice + 1) * scps * d.sc_chunks, d.n_chunks);
+        if (chunk_lo >= chunk_hi) continue;
+        const uint32_t pt_lo = chunk_lo / 4, pt_hi = (chunk_hi + 3) / 4;   // product tiles (TPB = 128: 4 chunks each)
+        const uint32_t np = 2 * (pt_hi - pt_lo);                          // pairs of chunks
+        const size_t wslot = (S == 1 ? static_cast<size_t>(blockIdx.x) : static_cast<size_t>(tb)) * 4 + wave;
+        float* scr_chunk = d.chunk_scratch + wslot * d.n_chunks * 32;
+        float2* scr = d.sc_scratch + wslot * kMaxSC * 32;
+        const uint32_t pos = tb * 128 + wave * 32 + j;
+        const bool active = pos < n_o;
+        const uint32_t slot = active ? cur[pos] : 0u;
+        __syncthreads();           // every wave is done with the LDS buffers and stage (previous work item)
+        // tile ti -> LDS buffer ti & 1 (async DMA).  Source = buffer resource (SGPRs) + scalar offset +
+        // lane * 16: one VGPR of address state, nothing to spill/reload next to the DMA
+        const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
+        const rg_v4i rs_g = raw_buffer_rsrc(d.gsplit), rs_m = raw_buffer_rsrc(d.mu32s);
+        const uint32_t g_lds = lds_addr_of(g_buf), mu_lds = lds_addr_of(mu_buf);
+        auto fetch_tile = [&](uint32_t ti) {
+            constexpr uint32_t TB = 128u * (32u * N1 + 16u);
+            for (uint32_t off = static_cast<uint32_t>(wave) * 1024u; off < TB; off += 4096u)
+                dma_to_lds_b128(rs_g, g_lds + (ti & 1) * TB + off, lane16, ti * TB + off);
+            if (wave == 3 && lane < 32) dma_to_lds_b128(rs_m, mu_lds + (ti & 1) * 512u, lane16, ti * 512u);
+        };
+        fetch_tile(pt_lo);
+        // ---- omega32 of the user -> LDS stage (also the logit error bound) ----
+        float absdot = 0.0f, sq = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KH; ++s) {
+            const uint32_t k = h * KH + s;
+            float w = 0.0f;
+            if (active && k < d.K) w = static_cast<float>(d.omega[static_cast<size_t>(slot) * d.OMS + k]);
+            omu[k] = w;
+            absdot = fmaf(fabsf(w), d.stats[k], absdot);
+            sq = fmaf(w, w, sq);
+        }
+        absdot += swap32(absdot);
+        sq += swap32(sq);
+        const float Ahat = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // ---- B fragments, all three groups in MFMA order: [w1|w1|w1|-q] (N1), [w2|w2|0] (N2), [w3|0|0] (N3) ----
+        bf16x8 Bm[NM];
+        {
+            const uint32_t K = d.K;
+#pragma unroll
+            for (int s = 0; s < N1; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t ke = 16 * s + 8 * h + e;
+                    unsigned short sp[3] = {0, 0, 0};
+                    if (ke < 3 * K) bf16_split3(omu[ke % K], sp);
+                    Bm[s][e] = static_cast<short>(sp[0]);
+                    if (s < N2) Bm[N1 + (s < N2 ? s : 0)][e] = static_cast<short>(ke < 2 * K ? sp[1] : 0);
+                    if (s < N3) Bm[N1 + N2 + (s < N3 ? s : 0)][e] = static_cast<short>(ke < K ? sp[2] : 0);
+                }
+        }
+        float q = 0.0f;            // reference (log2 units, an integer) of the MFMAs being issued
+        auto set_reference = [&](float qn) {
+            q = qn;
+            unsigned short sp[3];
+            bf16_split3(-qn, sp);
+            if (h == 1) {
+                Bm[N1 - 1][5] = static_cast<short>(sp[0]);
+                Bm[N1 - 1][6] = static_cast<short>(sp[1]);
+                Bm[N1 - 1][7] = static_cast<short>(sp[2]);
+            }
+        };
+        // this lane's operand rows in buffer 0, pair 0 (everything else is a constant offset from these)
+        constexpr uint32_t RSc = 32 * N1 + 16, TILE_B = 128 * RSc;
+        const char* a_lane = g_buf + j * RSc + 16 * h;
+        const char* m_lane = reinterpret_cast<const char*>(mu_buf) + 16 * h;
+        auto a_base = [&](uint32_t pi) { return a_lane + ((pt_lo + (pi >> 1)) & 1) * TILE_B + (pi & 1) * (64 * RSc); };
+        auto m_base = [&](uint32_t pi) { return m_lane + ((pt_lo + (pi >> 1)) & 1) * (128 * 4) + (pi & 1) * (64 * 4); };
+        auto load_a = [&](PairOps& o, const char* ab, int idx) {        // A row block idx of the pair's chunk 0 / 1
+            if (idx < N1) o.A0[idx < N1 ? idx : 0] = *reinterpret_cast<const bf16x8*>(ab + 32 * idx);
+            else o.A1[idx - N1 < N1 ? idx - N1 : 0] = *reinterpret_cast<const bf16x8*>(ab + 32 * RSc + 32 * (idx - N1));
+        };
+        auto load_mu = [&](f32x16& acc, const char* mb, int which, int qq) {   // mu quad qq, into the accumulator it seeds
+            const float4 m = *reinterpret_cast<const float4*>(mb + 128 * which + 32 * qq);
+            acc[4 * qq] = m.x; acc[4 * qq + 1] = m.y; acc[4 * qq + 2] = m.z; acc[4 * qq + 3] = m.w;
+        };
+        auto amap = [](int m) { return m < N1 ? m : (m < N1 + N2 ? m - N1 : m - N1 - N2); };
+        using f32x2 = __attribute__((ext_vector_type(2))) float;
+        // One pair: MFMAs of (cur) into (a0, a1), which already hold the pair's mu | exp-sum of (p0, p1) ->
+        // (s0, s1) | A rows of pair pi_next -> nxt, its mu -> (p0, p1) once their exps are done.
+        // The exps feed four running packed sums per chunk as they are produced (slots < EXS), so
+        // the logit registers are free for the mu quads fetched in the last slots.
+        auto stream = [&](const PairOps& co, PairOps& no, uint32_t pi_next, f32x16& a0, f32x16& a1,
+                          f32x16& p0, f32x16& p1, float& s0, float& s1) {
+            f32x2 x0[4], x1[4];
+            const char* ab = a_base(pi_next);
+            const char* mb = m_base(pi_next);
+            RG_PIN();
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(co.A0[amap(m)], Bm[m], a0, 0, 0, 0);
+                if (m < EXS) {
+                    asm volatile("" : "+v"(p0));                        // (exps may not float above this slot)
+#pragma unroll
+                    for (int i = (2 * m) * (2 * N1) / (2 * EXS); i < (2 * m + 1) * (2 * N1) / (2 * EXS); ++i) load_a(no, ab, i);
+#pragma unroll
+                    for (int e = (m * 8 / EXS) * 2; e < ((m + 1) * 8 / EXS) * 2; e += 2) {       // exps in pairs
+                        f32x2 y = {__builtin_amdgcn_exp2f(p0[e]), __builtin_amdgcn_exp2f(p0[e + 1])};
+                        asm volatile("" : "+v"(y));                     // with the pin on p0 above: keeps these pure ops in this slot
+                        if (e < 8) x0[e / 2] = y; else x0[(e / 2) & 3] += y;
+                    }
+                } else {
+#pragma unroll
+                    for (int qq = (m - EXS) * 4 / (NM - EXS); qq < (m - EXS + 1) * 4 / (NM - EXS); ++qq) load_mu(p0, mb, 0, qq);
+                }
+                RG_PIN();
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(co.A1[amap(m)], Bm[m], a1, 0, 0, 0);
+                if (m < EXS) {
+                    asm volatile("" : "+v"(p1));
+#pragma unroll
+                    for (int i = (2 * m + 1) * (2 * N1) / (2 * EXS); i < (2 * m + 2) * (2 * N1) / (2 * EXS); ++i) load_a(no, ab, i);
+#pragma unroll
+                    for (int e = (m * 8 / EXS) * 2; e < ((m + 1) * 8 / EXS) * 2; e += 2) {
+                        f32x2 y = {__builtin_amdgcn_exp2f(p1[e]), __builtin_amdgcn_exp2f(p1[e + 1])};
+                        asm volatile("" : "+v"(y));                     // with the pin on p1 above: keeps these pure ops in this slot
+                        if (e < 8) x1[e / 2] = y; else x1[(e / 2) & 3] += y;
+                    }
+                } else {
+#pragma unroll
+                    for (int qq = (m - EXS) * 4 / (NM - EXS); qq < (m - EXS + 1) * 4 / (NM - EXS); ++qq) load_mu(p1, mb, 1, qq);
+                }
+                RG_PIN();
+            }
+            x0[0] += x0[2]; x0[1] += x0[3]; x0[0] += x0[1];
+            x1[0] += x1[2]; x1[1] += x1[3]; x1[0] += x1[1];
+            s0 = x0[0][0] + x0[0][1];
+            s1 = x1[0][0] + x1[0][1];
+            RG_PIN();
+        };
+        auto tree = [](const f32x16& y) -> float {
+            f32x2 x0 = {y[0], y[1]}, x1 = {y[2], y[3]}, x2 = {y[4], y[5]}, x3 = {y[6], y[7]};
+            const f32x2 x4 = {y[8], y[9]}, x5 = {y[10], y[11]}, x6 = {y[12], y[13]}, x7 = {y[14], y[15]};
+            x0 += x4; x1 += x5; x2 += x6; x3 += x7; x0 += x2; x1 += x3; x0 += x1;
+            return x0[0] + x0[1];
+        };
+
+        // ---- per-chunk bookkeeping, one pair behind the MFMAs ----
+        double s_sc = 0.0;         // running exp-sum of the super-chunk being summed
+        float wcmax = 0.0f;        // its largest chunk sum
+        int n_resc = 0;
+        float q_done = 0.0f;       // reference the pending sums were taken with
+        float q_next = 0.0f;       // reference to switch to at the next super-chunk start
+        uint32_t sc_cur = chunk_lo / d.sc_chunks;
+        uint32_t sc_left = d.sc_chunks / 4;                    // tiles left in it
+        float2 wlo = make_float2(0.f, 0.f);
+        auto book = [&](uint32_t pe, float s0, float s1) {    // sums of pair pe (chunks 2pe, 2pe+1 of the work item)
+            s0 += swap32(s0);
+            s1 += swap32(s1);
+            if (!(pe & 1)) { wlo = make_float2(s0, s1); return; }
+            const uint32_t ti = pt_lo + (pe >> 1);
+            const float4 w4 = make_float4(wlo.x, wlo.y, s0, s1);
+            // scratch layout [tile][user][4 chunks]; both lanes of the user hold the same sums: no branch
+            if (!(d.ablate & 16u)) *reinterpret_cast<float4*>(scr_chunk + (static_cast<size_t>(ti) * 32 + j) * 4) = w4;
+            wcmax = fmaxf(fmaxf(wcmax, fmaxf(w4.x, w4.y)), fmaxf(w4.z, w4.w));
+            s_sc += static_cast<double>((w4.x + w4.y) + (w4.z + w4.w));
+            if (--sc_left == 0) {
+                scr[sc_cur * 32 + j] = make_float2(static_cast<float>(s_sc), q_done);
+                s_sc = 0.0;
+                // some logit is >= ~43 above the reference: re-reference from the next super-chunk
+                // that has not started (its MFMAs are a pair ahead of these sums)
+                if (wcmax > 2.8e14f) q_next = fmaxf(q_next, q_done + floorf(__builtin_amdgcn_logf(wcmax)));
+                wcmax = 0.0f;
+                ++sc_cur;
+                sc_left = d.sc_chunks / 4;
+            }
+        };
+
+        PairOps oa, ob;
+        f32x16 a0, a1, p0, p1;
+        RG_DMA_WAIT();
+        __syncthreads();           // tile pt_lo landed
+        if (pt_lo + 1 < pt_hi) fetch_tile(pt_lo + 1);
+#pragma unroll
+        for (int i = 0; i < 2 * N1; ++i) load_a(oa, a_base(0), i);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) { load_mu(a0, m_base(0), 0, qq); load_mu(a1, m_base(0), 1, qq); load_mu(p0, m_base(0), 0, qq); }
+        RG_PIN();
+        {   // first chunk with reference 0: its max (an integer after ceil, so exact in bf16 pieces
+            // and in exp2 differences) becomes the reference
+#pragma unroll
+            for (int m = 0; m < NM; ++m) p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa.A0[amap(m)], Bm[m], p0, 0, 0, 0);
+            float cm = p0[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) cm = fmaxf(cm, p0[r]);
+            set_reference(fmaxf(ceilf(fmaxf(cm, swap32(cm))), -1.0e30f));
+            q_done = q_next = q;
+        }
+        // head: pair 0's MFMAs with nothing to exp yet; pair 1's A rows and mu arrive meanwhile
+        RG_PIN();
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa.A0[amap(m)], Bm[m], a0, 0, 0, 0);
+            if (m < N1) load_a(ob, a_base(1), m);
+            else if (m < N1 + 4) load_mu(p0, m_base(1), 0, m - N1);
+            RG_PIN();
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa.A1[amap(m)], Bm[m], a1, 0, 0, 0);
+            if (m < N1) load_a(ob, a_base(1), N1 + m);
+            else if (m < N1 + 4) load_mu(p1, m_base(1), 1, m - N1);
+            RG_PIN();
+        }
+        if (NM < N1 + 4) {
+#pragma unroll
+            for (int qq = (NM > N1 ? NM - N1 : 0); qq < 4; ++qq) { load_mu(p0, m_base(1), 0, qq); load_mu(p1, m_base(1), 1, qq); }
+        }
+        RG_PIN();
+        uint32_t sc_issue_left = d.sc_chunks / 4;              // tiles left in the super-chunk being ISSUED
+        // Steady state, straight-line (no branch touches an accumulator, or the allocator starts copying
+        // 16-register tuples around): [second pair of tile T | first pair of tile T + 1] per iteration.
+        uint32_t pi = 1;
+        for (; pi + 1 < np; pi += 2) {
+            float s0, s1;
+            const uint32_t T = pt_lo + (pi >> 1);
+            // ---- tile barrier: every wave holds tile T's operands; tile T + 1 has landed ----
+            RG_DMA_WAIT();
+            if (!(d.ablate & 64u)) __syncthreads();
+            if (T + 2 < pt_hi && !(d.ablate & 32u)) fetch_tile(T + 2);
+            stream(ob, oa, pi + 1, p0, p1, a0, a1, s0, s1);                  // MFMAs of pair pi | sums of pair pi - 1
+            book(pi - 1, s0, s1);
+            if (--sc_issue_left == 0) sc_issue_left = d.sc_chunks / 4;
+            // ---- first pair of tile T + 1 ----
+            const bool sc_start = sc_issue_left == d.sc_chunks / 4;          // a super-chunk starts: the pending sums
+            if (sc_start) {                                                  // belong to the one before
+                q_done = q;
+                if (q_next != q) { set_reference(q_next); n_resc += 1; }
+            }
+            stream(oa, ob, pi + 2, a0, a1, p0, p1, s0, s1);                  // MFMAs of pair pi + 1 | sums of pair pi
+            book(pi, s0, s1);                                                // (may flush the finished super-chunk with q_done)
+            if (sc_start) q_done = q;
+        }
+        {   // the last pair (second pair of the last tile), then its own sums
+            float s0, s1;
+            RG_DMA_WAIT();
+            if (!(d.ablate & 64u)) __syncthreads();
+            stream(ob, oa, pi, p0, p1, a0, a1, s0, s1);                      // (operand fetch of a "next" pair: this one again, unused)
+            book(pi - 1, s0, s1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p0[r] = __builtin_amdgcn_exp2f(p0[r]); p1[r] = __builtin_amdgcn_exp2f(p1[r]); }
+            q_done = q;
+            book(pi, tree(p0), tree(p1));
+        }
+        if (sc_left != d.sc_chunks / 4) {                      // partial last super-chunk
+            scr[sc_cur * 32 + j] = make_float2(static_cast<float>(s_sc), q_done);
+        }
+        if (S == 1) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, kDeltaFixedBf16);
+    }
+}
+
 // second kernel of the sliced mode: the search over the sums all slices of a user tile left
 template <int KH>
 __global__ void __launch_bounds__(kBlock) k_draw_search(DevSim d, uint32_t t) {
@@ -1577,6 +1895,12 @@ search_kernel_t search_kernel_for(const DevSim& d) {
         case 32: return k_draw_search<32>;
         default: return k_draw_search<64>;
     }
+}
+draw_kernel_t bf16p_kernel_for(const DevSim& d) {
+#define RG_CASE(kh, a, b, c) if (d.KH == kh && d.N1 == a && d.N2 == b && d.N3 == c) return k_draw_bf16p<kh, a, b, c>;
+    RG_CASE(4, 1, 1, 1) RG_CASE(4, 2, 1, 1) RG_CASE(10, 3, 2, 1) RG_CASE(10, 4, 3, 2)
+#undef RG_CASE
+    return nullptr;
 }
 draw_kernel_t bf16_kernel_for(const DevSim& d) {
 #define RG_CASE(kh, a, b, c) if (d.KH == kh && d.N1 == a && d.N2 == b && d.N3 == c) return k_draw_bf16<kh, a, b, c>;
@@ -2309,6 +2633,12 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     s->bf16_kernel = nullptr; s->bf16_smem = 0;
     if (d.use_mfma && d.N1) {
         s->bf16_kernel = bf16_kernel_for(d);
+        // the pipelined form (two chunks in flight, exp-sum and operand loads inside the MFMA stream)
+        // where its ~200 VGPRs fit; RECOGYM_BF16=lean keeps the one-accumulator kernel (A/B tests)
+        const char* lean = getenv("RECOGYM_BF16");
+        if (!(lean && !strcmp(lean, "lean")))
+            if (static_cast<size_t>(d.P_pad) * d.RS < (1ull << 31))     // its DMA uses 31-bit buffer offsets
+                if (draw_kernel_t kp = bf16p_kernel_for(d)) s->bf16_kernel = kp;
         s->bf16_smem = bf16_smem_bytes(geom_of(*cfg), 2 * d.KH);
         // the larger classes still spill registers; the fp32 kernel is faster there for now
         if (s->bf16_kernel && d.N1 <= 4 && d.KH <= 10) d.use_mfma = 2;
