@@ -105,6 +105,7 @@ struct DevSim {
     uint32_t use_mfma;        // 0 = float64 only, 1 = fp32 MFMA kernel, 2 = split-bf16 MFMA kernel
     // split-bf16 kernel geometry: A row = [G1|G2|G3] (3K bf16, zero padded to 16*N1), row stride RS bytes
     uint32_t N1, N2, N3;      // k-steps of the three MFMA groups (B = w1 / w2 / w3)
+    uint32_t f16;             // 1: gsplit holds the two-way fp16 split [G1|G2|G1|0..|1] (one group of N1 k-steps)
     uint32_t RS;              // row stride of gsplit / its LDS tile, bytes ((RS/16) odd: conflict-free b128)
     uint32_t TPB;             // products per LDS tile of the bf16 kernel
     unsigned short* gsplit;   // [P_pad][RS/2] bf16 three-way split of fl32(Gamma log2 e), then 1,1,1 in the last 3 columns of 16*N1
@@ -179,7 +180,7 @@ struct Carve {
 
 constexpr uint32_t kMaxSC = 32;           // stored partial sums per user in the MFMA draw kernel
 
-struct Geom { uint32_t KH, KS, TP, P_pad, n_chunks, sc_chunks, n_sc, N1, N2, N3, RS, TPB; };
+struct Geom { uint32_t KH, KS, TP, P_pad, n_chunks, sc_chunks, n_sc, N1, N2, N3, RS, TPB, F16; };
 
 Geom geom_of(const rg_config& c) {
     Geom g{};
@@ -200,6 +201,15 @@ Geom geom_of(const rg_config& c) {
             if (!g.N1 && 3 * c.K + 3 <= 16 * c3[0] && 2 * c.K <= 16 * c3[1] && c.K <= 16 * c3[2]) {
                 g.N1 = c3[0]; g.N2 = c3[1]; g.N3 = c3[2];
             }
+        // two-way fp16 split (one MFMA group: A = [G1|G2|G1|..|1], B = [w1|w1|w2|..|-q]) where 3K + 1 columns fit
+        // 64 and a kernel exists for (KH, N1); RECOGYM_DRAW=bf16 / RECOGYM_BF16=lean keep the three-way bf16 split
+        const char* e_draw = getenv("RECOGYM_DRAW");
+        const char* e_lean = getenv("RECOGYM_BF16");
+        const bool want_f16 = !(e_draw && !strcmp(e_draw, "bf16")) && !(e_lean && !strcmp(e_lean, "lean"));
+        if (want_f16 && 3 * c.K + 1 <= 64 && g.KH <= 16) {
+            g.F16 = 1;
+            g.N1 = (3 * c.K + 1 + 15) / 16; g.N2 = 0; g.N3 = 0;
+        }
         if (g.N1) {
             g.RS = 32 * g.N1 + 16;
             g.TPB = 128;                            // 4 chunks per tile: the kernel walks pairs of pairs
@@ -280,7 +290,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->gamma32 = gamma32; d->mu32 = mu32; d->stats = stats; d->omega = omega; d->list = list;
         d->gamma_rm = gamma_rm; d->XKB = xkb;
         d->gammaT = gammaT; d->PT = static_cast<uint32_t>(PT); d->exact_ref = exact_ref; d->exact_sums = exact_sums; d->sc_scratch = sc_scratch; d->chunk_scratch = chunk_scratch;
-        d->gsplit = gsplit; d->mu32s = mu32s; d->N1 = g.N1; d->N2 = g.N2; d->N3 = g.N3; d->RS = g.RS; d->TPB = g.TPB;
+        d->gsplit = gsplit; d->mu32s = mu32s; d->N1 = g.N1; d->N2 = g.N2; d->N3 = g.N3; d->RS = g.RS; d->TPB = g.TPB; d->f16 = g.F16;
         d->KH = g.KH; d->KS = g.KS; d->TP = g.TP; d->P_pad = g.P_pad; d->n_chunks = g.n_chunks;
         d->sc_chunks = g.sc_chunks; d->n_sc = g.n_sc; d->use_mfma = g.KH ? 1u : 0u;
         d->step_cnt = step_cnt; d->log_base = log_base; d->exact_list = exact_list;
@@ -389,6 +399,14 @@ __device__ __forceinline__ unsigned short bf16_rne(float x) {
 __device__ __forceinline__ float bf16_to_f32(unsigned short hbits) {
     return __builtin_bit_cast(float, static_cast<unsigned>(hbits) << 16);
 }
+// x = h[0] + h[1] up to max(2^-22 |x|, 2^-25): two fp16 pieces, 11 significant bits each (the
+// second piece turns subnormal below 2^-14: absolute granularity 2^-24)
+__device__ __forceinline__ void f16_split2(float x, unsigned short* sp) {
+    const _Float16 h1 = static_cast<_Float16>(x);
+    const _Float16 h2 = static_cast<_Float16>(x - static_cast<float>(h1));
+    sp[0] = __builtin_bit_cast(unsigned short, h1);
+    sp[1] = __builtin_bit_cast(unsigned short, h2);
+}
 // x = s[0] + s[1] + s[2] up to ~2^-25 |x|: three bf16 pieces, 8 significant bits each
 __device__ __forceinline__ void bf16_split3(float x, unsigned short* sp) {
     sp[0] = bf16_rne(x);
@@ -409,7 +427,13 @@ __global__ void __launch_bounds__(kBlock) k_make_split_table(DevSim d) {
          i += static_cast<size_t>(gridDim.x) * kBlock) {
         const size_t p = i / rs2, ke = i % rs2;
         unsigned short v = 0;
-        if (p < d.P && ke < 3 * static_cast<size_t>(d.K)) {
+        if (d.f16) {
+            if (p < d.P && ke < 3 * static_cast<size_t>(d.K)) {
+                unsigned short sp[2];
+                f16_split2(static_cast<float>(d.gamma[p * d.K + ke % d.K] * log2e), sp);
+                v = sp[ke / d.K == 1 ? 1 : 0];                              // [G1 | G2 | G1]
+            } else if (ke == 16u * d.N1 - 1) v = 0x3C00;                   // fp16(1.0): the reference column
+        } else if (p < d.P && ke < 3 * static_cast<size_t>(d.K)) {
             unsigned short sp[3];
             bf16_split3(static_cast<float>(d.gamma[p * d.K + ke % d.K] * log2e), sp);
             v = sp[ke / d.K];
@@ -1077,12 +1101,21 @@ __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, con
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // scratch: written by lanes < 32, read below
 
         // ---- search, part 1 (lane per user; lanes >= 32 mirror): total, target, super-chunk, chunk ----
-        float Q = scr[j].y;                                    // common reference: the largest one
-        for (uint32_t sc = 1; sc < d.n_sc; ++sc) Q = fmaxf(Q, scr[sc * 32 + j].y);
+        // All <= kMaxSC super-chunk records are fetched in one burst (they sit in L2, ~1 us away:
+        // walking them with a data-dependent loop cost ~30 us per 128 users) and then live in registers.
+        float2 rec[kMaxSC];
+#pragma unroll
+        for (uint32_t sc = 0; sc < kMaxSC; ++sc)
+            rec[sc] = sc < d.n_sc ? scr[sc * 32 + j] : make_float2(0.0f, -INFINITY);   // unused: weight 0
+        float Q = rec[0].y;                                    // common reference: the largest one
+#pragma unroll
+        for (uint32_t sc = 1; sc < kMaxSC; ++sc) Q = fmaxf(Q, rec[sc].y);
         double S = 0.0;
-        for (uint32_t sc = 0; sc < d.n_sc; ++sc) {
-            const float2 wq = scr[sc * 32 + j];
-            S += static_cast<double>(wq.x * __builtin_amdgcn_exp2f(wq.y - Q));
+#pragma unroll
+        for (uint32_t sc = 0; sc < kMaxSC; ++sc) {
+            rec[sc].y = __builtin_amdgcn_exp2f(rec[sc].y - Q);
+            rec[sc].x *= rec[sc].y;
+            if (sc < d.n_sc) S += static_cast<double>(rec[sc].x);
         }
         const uint32_t user = static_cast<uint32_t>(d.first_user + d.uid[slot]);
         const rg_u32x4 rw = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
@@ -1093,13 +1126,13 @@ __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, con
         bool found_sc = false;
         {
             double run = 0.0;
-            for (uint32_t sc = 0; sc < d.n_sc; ++sc) {
-                const float2 wq = scr[sc * 32 + j];
-                const float f = __builtin_amdgcn_exp2f(wq.y - Q);
-                const double Wd = static_cast<double>(wq.x * f);
-                if (!found_sc && run + Wd > tau) { found_sc = true; sc_star = sc; pb = run; f_star = f; }
-                if (!found_sc) run += Wd;
+#pragma unroll
+            for (uint32_t sc = 0; sc < kMaxSC; ++sc) {
+                const double Wd = static_cast<double>(rec[sc].x);
+                if (sc < d.n_sc && !found_sc && run + Wd > tau) { found_sc = true; sc_star = sc; pb = run; f_star = rec[sc].y; }
+                if (sc < d.n_sc && !found_sc) run += Wd;
             }
+            if (!found_sc) f_star = 1.0f;
         }
         // chunk inside the super-chunk (its chunk sums share the super-chunk's reference)
         uint32_t c_star = 0;
@@ -1107,10 +1140,30 @@ __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, con
         {
             const uint32_t c0 = sc_star * d.sc_chunks, c1 = min(c0 + d.sc_chunks, d.n_chunks);
             double run = pb;
-            for (uint32_t c = c0; c < c1; ++c) {
-                const double Wd = static_cast<double>(scr_chunk[CHUNK_AT(c, j)] * f_star);
-                if (!found_c && run + Wd > tau) { found_c = true; c_star = c; pb = run; }
-                if (!found_c) run += Wd;
+            if (tiled4) {
+                // [tile][user][4 chunks]: one 16-byte load per tile, four tiles in flight
+                for (uint32_t cb = c0; cb < c1; cb += 16) {
+                    float4 w4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        w4[i] = cb + 4 * i < c1 ? *reinterpret_cast<const float4*>(scr_chunk + (((cb >> 2) + i) * 32 + j) * 4)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float4 q4 = w4[i >> 2];
+                        const float wv = (i & 3) == 0 ? q4.x : (i & 3) == 1 ? q4.y : (i & 3) == 2 ? q4.z : q4.w;
+                        const double Wd = static_cast<double>(wv * f_star);
+                        const uint32_t c = cb + i;
+                        if (c < c1 && !found_c && run + Wd > tau) { found_c = true; c_star = c; pb = run; }
+                        if (c < c1 && !found_c) run += Wd;
+                    }
+                }
+            } else {
+                for (uint32_t c = c0; c < c1; ++c) {
+                    const double Wd = static_cast<double>(scr_chunk[CHUNK_AT(c, j)] * f_star);
+                    if (!found_c && run + Wd > tau) { found_c = true; c_star = c; pb = run; }
+                    if (!found_c) run += Wd;
+                }
             }
         }
         found_c = found_c && found_sc;
@@ -1545,6 +1598,17 @@ __global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 3 : 1)) k_draw_bf16(DevSim 
 // ------------------------------------------------------------------------------------------
 #define RG_PIN() __builtin_amdgcn_sched_barrier(0)
 
+// Certificate budget of the two-way fp16 split on top of the accumulation budget (K+5) 2^-24 Ahat:
+// x = h1 + h2 + e with |e| <= max(2^-22 |x|, 2^-25), and the h2 h2 cross term is dropped, so a
+// logit is off by <= 3 x 2^-22 sum|g_k w_k| + 2^-25 sum_k (|g_k| + |w_k|) in log2 units, i.e. relative
+// error of its exp <= 12 x 2^-24 Ahat + 2^-25 (sum_k max_p |Gamma_pk| + ln 2 sum_k |omega_k|).
+__device__ __forceinline__ double f16_extra_delta(const DevSim& d, float Ahat, float absw) {
+    float gsum = 0.0f;
+    for (uint32_t k = 0; k < d.K; ++k) gsum += d.stats[k];
+    return 12.0 * 5.9604644775390625e-08 * static_cast<double>(Ahat) +
+           2.98023223876953125e-08 * (static_cast<double>(gsum) + 0.6931471805599453 * static_cast<double>(absw));
+}
+
 // Tile DMA the compiler does not see.  hipcc puts s_waitcnt vmcnt(0) in front of the first ds_read
 // that follows a global/buffer load to LDS (the DMA may alias the read), which turns the tile
 // prefetch into a synchronous load.  The pipelined kernel only reads a tile after the barrier
@@ -1571,10 +1635,12 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* generic_ptr) {
 }
 #define RG_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
-template <int KH, int N1, int N2, int N3>
+template <int KH, int N1, int N2, int N3, bool F16>
 __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, uint32_t S) {
-    constexpr int NM = N1 + N2 + N3;          // MFMAs per chunk
-    constexpr int EXS = NM > 3 ? NM - 3 : 1;  // MFMA slots that carry the exps (and the A loads); the rest carry the mu loads
+    constexpr int NM = F16 ? N1 : N1 + N2 + N3;   // MFMAs per chunk (fp16 two-way split: one group)
+    // MFMA slots that carry the exps (and the A loads); the rest carry the mu loads.  The fp16 form is VALU-bound:
+    // its exps spread over all slots but the last
+    constexpr int EXS = F16 ? (NM > 1 ? NM - 1 : 1) : (NM > 3 ? NM - 3 : 1);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t tile_b = d.TPB * d.RS;                             // bytes per split tile
     char* g_buf = smem_raw;                                           // [2][TPB][RS]
@@ -1619,7 +1685,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         };
         fetch_tile(pt_lo);
         // ---- omega32 of the user -> LDS stage (also the logit error bound) ----
-        float absdot = 0.0f, sq = 0.0f;
+        float absdot = 0.0f, sq = 0.0f, absw = 0.0f;
 #pragma unroll
         for (int s = 0; s < KH; ++s) {
             const uint32_t k = h * KH + s;
@@ -1628,10 +1694,13 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             omu[k] = w;
             absdot = fmaf(fabsf(w), d.stats[k], absdot);
             sq = fmaf(w, w, sq);
+            absw += fabsf(w);
         }
         absdot += swap32(absdot);
         sq += swap32(sq);
+        absw += swap32(absw);
         const float Ahat = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
+        const double delta_fixed = kDeltaFixedBf16 + (F16 ? f16_extra_delta(d, Ahat, absw) : 0.0);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         // ---- B fragments, all three groups in MFMA order: [w1|w1|w1|-q] (N1), [w2|w2|0] (N2), [w3|0|0] (N3) ----
@@ -1643,15 +1712,28 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const uint32_t ke = 16 * s + 8 * h + e;
-                    unsigned short sp[3] = {0, 0, 0};
-                    if (ke < 3 * K) bf16_split3(omu[ke % K], sp);
-                    Bm[s][e] = static_cast<short>(sp[0]);
-                    if (s < N2) Bm[N1 + (s < N2 ? s : 0)][e] = static_cast<short>(ke < 2 * K ? sp[1] : 0);
-                    if (s < N3) Bm[N1 + N2 + (s < N3 ? s : 0)][e] = static_cast<short>(ke < K ? sp[2] : 0);
+                    if (F16) {                                 // [w1 | w1 | w2 | 0 .. | -q]
+                        unsigned short sp[2] = {0, 0};
+                        if (ke < 3 * K) f16_split2(omu[ke % K], sp);
+                        Bm[s][e] = static_cast<short>(ke < 2 * K ? sp[0] : sp[1]);
+                    } else {
+                        unsigned short sp[3] = {0, 0, 0};
+                        if (ke < 3 * K) bf16_split3(omu[ke % K], sp);
+                        Bm[s][e] = static_cast<short>(sp[0]);
+                        if (s < N2) Bm[(N1 + (s < N2 ? s : 0)) % NM][e] = static_cast<short>(ke < 2 * K ? sp[1] : 0);
+                        if (s < N3) Bm[(N1 + N2 + (s < N3 ? s : 0)) % NM][e] = static_cast<short>(ke < K ? sp[2] : 0);
+                    }
                 }
         }
         float q = 0.0f;            // reference (log2 units, an integer) of the MFMAs being issued
         auto set_reference = [&](float qn) {
+            if (F16) {
+                // one fp16 piece: an integer |q| <= 2047 is exact (beyond that nothing certifies anyway)
+                qn = fminf(fmaxf(qn, -2047.0f), 2047.0f);
+                q = qn;
+                if (h == 1) Bm[N1 - 1][7] = static_cast<short>(__builtin_bit_cast(unsigned short, static_cast<_Float16>(-qn)));
+                return;
+            }
             q = qn;
             unsigned short sp[3];
             bf16_split3(-qn, sp);
@@ -1675,7 +1757,12 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             const float4 m = *reinterpret_cast<const float4*>(mb + 128 * which + 32 * qq);
             acc[4 * qq] = m.x; acc[4 * qq + 1] = m.y; acc[4 * qq + 2] = m.z; acc[4 * qq + 3] = m.w;
         };
-        auto amap = [](int m) { return m < N1 ? m : (m < N1 + N2 ? m - N1 : m - N1 - N2); };
+        auto amap = [](int m) { return F16 ? m : (m < N1 ? m : (m < N1 + N2 ? m - N1 : m - N1 - N2)); };
+        auto mm = [](const bf16x8& a, const bf16x8& b, const f32x16& c) -> f32x16 {
+            using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+            if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+            return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+        };
         using f32x2 = __attribute__((ext_vector_type(2))) float;
         // One pair: MFMAs of (cur) into (a0, a1), which already hold the pair's mu | exp-sum of (p0, p1) ->
         // (s0, s1) | A rows of pair pi_next -> nxt, its mu -> (p0, p1) once their exps are done.
@@ -1689,7 +1776,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             RG_PIN();
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(co.A0[amap(m)], Bm[m], a0, 0, 0, 0);
+                a0 = mm(co.A0[amap(m)], Bm[m], a0);
                 if (m < EXS) {
                     asm volatile("" : "+v"(p0));                        // (exps may not float above this slot)
 #pragma unroll
@@ -1702,10 +1789,10 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
                     }
                 } else {
 #pragma unroll
-                    for (int qq = (m - EXS) * 4 / (NM - EXS); qq < (m - EXS + 1) * 4 / (NM - EXS); ++qq) load_mu(p0, mb, 0, qq);
+                    for (int qq = (m - EXS) * 4 / (NM > EXS ? NM - EXS : 1); qq < (m - EXS + 1) * 4 / (NM > EXS ? NM - EXS : 1); ++qq) load_mu(p0, mb, 0, qq);
                 }
                 RG_PIN();
-                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(co.A1[amap(m)], Bm[m], a1, 0, 0, 0);
+                a1 = mm(co.A1[amap(m)], Bm[m], a1);
                 if (m < EXS) {
                     asm volatile("" : "+v"(p1));
 #pragma unroll
@@ -1718,9 +1805,13 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
                     }
                 } else {
 #pragma unroll
-                    for (int qq = (m - EXS) * 4 / (NM - EXS); qq < (m - EXS + 1) * 4 / (NM - EXS); ++qq) load_mu(p1, mb, 1, qq);
+                    for (int qq = (m - EXS) * 4 / (NM > EXS ? NM - EXS : 1); qq < (m - EXS + 1) * 4 / (NM > EXS ? NM - EXS : 1); ++qq) load_mu(p1, mb, 1, qq);
                 }
                 RG_PIN();
+            }
+            if (NM == EXS) {       // single-MFMA class: no slot left for the mu quads
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) { load_mu(p0, mb, 0, qq); load_mu(p1, mb, 1, qq); }
             }
             x0[0] += x0[2]; x0[1] += x0[3]; x0[0] += x0[1];
             x1[0] += x1[2]; x1[1] += x1[3]; x1[0] += x1[1];
@@ -1745,6 +1836,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         uint32_t sc_left = d.sc_chunks / 4;                    // tiles left in it
         float2 wlo = make_float2(0.f, 0.f);
         auto book = [&](uint32_t pe, float s0, float s1) {    // sums of pair pe (chunks 2pe, 2pe+1 of the work item)
+            if (d.ablate & 256u) { wcmax += s0 + s1; return; }
             s0 += swap32(s0);
             s1 += swap32(s1);
             if (!(pe & 1)) { wlo = make_float2(s0, s1); return; }
@@ -1779,7 +1871,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         {   // first chunk with reference 0: its max (an integer after ceil, so exact in bf16 pieces
             // and in exp2 differences) becomes the reference
 #pragma unroll
-            for (int m = 0; m < NM; ++m) p0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa.A0[amap(m)], Bm[m], p0, 0, 0, 0);
+            for (int m = 0; m < NM; ++m) p0 = mm(oa.A0[amap(m)], Bm[m], p0);
             float cm = p0[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) cm = fmaxf(cm, p0[r]);
@@ -1790,11 +1882,11 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         RG_PIN();
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa.A0[amap(m)], Bm[m], a0, 0, 0, 0);
+            a0 = mm(oa.A0[amap(m)], Bm[m], a0);
             if (m < N1) load_a(ob, a_base(1), m);
             else if (m < N1 + 4) load_mu(p0, m_base(1), 0, m - N1);
             RG_PIN();
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa.A1[amap(m)], Bm[m], a1, 0, 0, 0);
+            a1 = mm(oa.A1[amap(m)], Bm[m], a1);
             if (m < N1) load_a(ob, a_base(1), N1 + m);
             else if (m < N1 + 4) load_mu(p1, m_base(1), 1, m - N1);
             RG_PIN();
@@ -1842,7 +1934,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         if (sc_left != d.sc_chunks / 4) {                      // partial last super-chunk
             scr[sc_cur * 32 + j] = make_float2(static_cast<float>(s_sc), q_done);
         }
-        if (S == 1) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, kDeltaFixedBf16);
+        if (S == 1 && !(d.ablate & 128u)) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, delta_fixed);
     }
 }
 
@@ -1863,7 +1955,7 @@ __global__ void __launch_bounds__(kBlock) k_draw_search(DevSim d, uint32_t t) {
         const uint32_t pos = tb * 128 + wave * 32 + j;
         const bool active = pos < n_o;
         const uint32_t slot = active ? cur[pos] : 0u;
-        float absdot = 0.0f, sq = 0.0f;
+        float absdot = 0.0f, sq = 0.0f, absw = 0.0f;
 #pragma unroll
         for (int s = 0; s < KH; ++s) {
             const uint32_t k = h * KH + s;
@@ -1872,14 +1964,16 @@ __global__ void __launch_bounds__(kBlock) k_draw_search(DevSim d, uint32_t t) {
             omu[k] = w;
             absdot = fmaf(fabsf(w), d.stats[k], absdot);
             sq = fmaf(w, w, sq);
+            absw += fabsf(w);
         }
         absdot += swap32(absdot);
         sq += swap32(sq);
+        absw += swap32(absw);
         const float Ahat = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         search_and_emit<KH>(d, t, d.sc_scratch + wslot * kMaxSC * 32, d.chunk_scratch + wslot * d.n_chunks * 32, omu,
-                            Ahat, 0, active, pos, slot, j, h, true, kDeltaFixedBf16);
+                            Ahat, 0, active, pos, slot, j, h, true, kDeltaFixedBf16 + (d.f16 ? f16_extra_delta(d, Ahat, absw) : 0.0));
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -1897,7 +1991,13 @@ search_kernel_t search_kernel_for(const DevSim& d) {
     }
 }
 draw_kernel_t bf16p_kernel_for(const DevSim& d) {
-#define RG_CASE(kh, a, b, c) if (d.KH == kh && d.N1 == a && d.N2 == b && d.N3 == c) return k_draw_bf16p<kh, a, b, c>;
+    if (d.f16) {
+#define RG_CASE(kh, a) if (d.KH == kh && d.N1 == a) return k_draw_bf16p<kh, a, 0, 0, true>;
+        RG_CASE(4, 1) RG_CASE(4, 2) RG_CASE(10, 2) RG_CASE(10, 3) RG_CASE(10, 4) RG_CASE(16, 4)
+#undef RG_CASE
+        return nullptr;
+    }
+#define RG_CASE(kh, a, b, c) if (d.KH == kh && d.N1 == a && d.N2 == b && d.N3 == c) return k_draw_bf16p<kh, a, b, c, false>;
     RG_CASE(4, 1, 1, 1) RG_CASE(4, 2, 1, 1) RG_CASE(10, 3, 2, 1) RG_CASE(10, 4, 3, 2)
 #undef RG_CASE
     return nullptr;
@@ -2632,7 +2732,7 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     // kernel choice: split-bf16 MFMA when a class exists for K, else fp32 MFMA; RECOGYM_DRAW=f64|fp32|bf16 overrides
     s->bf16_kernel = nullptr; s->bf16_smem = 0;
     if (d.use_mfma && d.N1) {
-        s->bf16_kernel = bf16_kernel_for(d);
+        s->bf16_kernel = d.f16 ? nullptr : bf16_kernel_for(d);
         // the pipelined form (two chunks in flight, exp-sum and operand loads inside the MFMA stream)
         // where its ~200 VGPRs fit; RECOGYM_BF16=lean keeps the one-accumulator kernel (A/B tests)
         const char* lean = getenv("RECOGYM_BF16");
@@ -2641,12 +2741,12 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
                 if (draw_kernel_t kp = bf16p_kernel_for(d)) s->bf16_kernel = kp;
         s->bf16_smem = bf16_smem_bytes(geom_of(*cfg), 2 * d.KH);
         // the larger classes still spill registers; the fp32 kernel is faster there for now
-        if (s->bf16_kernel && d.N1 <= 4 && d.KH <= 10) d.use_mfma = 2;
+        if (s->bf16_kernel && (d.f16 || (d.N1 <= 4 && d.KH <= 10))) d.use_mfma = 2;
     }
     if (const char* e = getenv("RECOGYM_DRAW")) {
         if (!strcmp(e, "f64")) d.use_mfma = 0;
         else if (!strcmp(e, "fp32") && d.KH) d.use_mfma = 1;
-        else if (!strcmp(e, "bf16") && s->bf16_kernel) d.use_mfma = 2;
+        else if ((!strcmp(e, "bf16") || !strcmp(e, "f16")) && s->bf16_kernel) d.use_mfma = 2;
     }
     if (const char* e = getenv("RECOGYM_FORCE_EXACT")) if (e[0] == '1') d.use_mfma = 0;   // A/B switch for tests
     if (s->bf16_kernel && s->bf16_smem > 64 * 1024)

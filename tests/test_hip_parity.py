@@ -220,11 +220,12 @@ def test_more_than_a_million_users_shard_consistently():
         assert whole_chk[i] % 2 ** 64 == sum(p[1][i] for p in parts) % 2 ** 64
 
 
-@pytest.mark.parametrize('mode', ['f64', 'fp32', 'bf16'])
+@pytest.mark.parametrize('mode', ['f64', 'fp32', 'bf16', 'f16'])
 @pytest.mark.parametrize('shape', [(10, 5), (1000, 20), (4100, 8), (700, 33)])
 def test_every_draw_kernel_matches_the_oracle(mode, shape, monkeypatch):
-    """The three organic-draw implementations (float64 only, fp32 MFMA + certificate, split-bf16
-    MFMA + certificate) each reproduce the oracle's rows."""
+    """The organic-draw implementations (float64 only, fp32 MFMA + certificate, three-way split-bf16
+    MFMA + certificate, two-way split-fp16 MFMA + certificate — the default where 3K + 1 <= 64) each
+    reproduce the oracle's rows."""
     from oracle import oracle as orc
     monkeypatch.setenv('RECOGYM_DRAW', mode)
     P, K = shape
