@@ -221,9 +221,9 @@ Geom geom_of(const rg_config& c) {
     return g;
 }
 
-size_t bf16_smem_bytes(const Geom& g, uint32_t K) {
-    // double-buffered split tiles + mu tiles + the per-wave omega32 stage [4][32][K]
-    return 2 * (static_cast<size_t>(g.TPB) * g.RS + g.TPB * 4) + 4 * 32 * static_cast<size_t>(K) * 4 + 256;
+size_t bf16_smem_bytes(const Geom& g, uint32_t K, uint32_t buffers) {
+    // split tiles + mu tiles (2 buffers: lean kernel, 3: pipelined kernel) + the per-wave omega32 stage [4][32][K]
+    return buffers * (static_cast<size_t>(g.TPB) * g.RS + g.TPB * 4) + 4 * 32 * static_cast<size_t>(K) * 4 + 256;
 }
 
 size_t mfma_smem_bytes(const Geom& g) {
@@ -1634,6 +1634,15 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* generic_ptr) {
     return static_cast<uint32_t>(reinterpret_cast<size_t>((__attribute__((address_space(3))) const char*)generic_ptr));
 }
 #define RG_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// Tile barrier without the fence of __syncthreads (which drains every outstanding store and DMA):
+// waits until at most N of this wave's vector-memory operations are still in flight (they complete
+// in issue order) and its LDS reads have returned, then rendezvous.
+#define RG_TILE_BARRIER(N)                                                     \
+    do {                                                                       \
+        asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)" ::: "memory");       \
+        __builtin_amdgcn_s_barrier();                                          \
+        asm volatile("" ::: "memory");                                         \
+    } while (0)
 
 template <int KH, int N1, int N2, int N3, bool F16>
 __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, uint32_t S) {
@@ -1643,9 +1652,9 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
     constexpr int EXS = F16 ? (NM > 1 ? NM - 1 : 1) : (NM > 3 ? NM - 3 : 1);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t tile_b = d.TPB * d.RS;                             // bytes per split tile
-    char* g_buf = smem_raw;                                           // [2][TPB][RS]
-    float* mu_buf = reinterpret_cast<float*>(g_buf + 2 * tile_b);     // [2][TPB] (+ pad)
-    float* om_stage = mu_buf + 2 * d.TPB + 64;                        // [4 waves][32 users][2KH] omega32
+    char* g_buf = smem_raw;                                           // [3][TPB][RS]: the tile in use and two in flight
+    float* mu_buf = reinterpret_cast<float*>(g_buf + 3 * tile_b);     // [3][TPB] (+ pad)
+    float* om_stage = mu_buf + 3 * d.TPB + 64;                        // [4 waves][32 users][2KH] omega32
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();   // scalar: per-wave pointers stay in SGPRs
     const int j = lane & 31, h = lane >> 5;
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
@@ -1680,8 +1689,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         auto fetch_tile = [&](uint32_t ti) {
             constexpr uint32_t TB = 128u * (32u * N1 + 16u);
             for (uint32_t off = static_cast<uint32_t>(wave) * 1024u; off < TB; off += 4096u)
-                dma_to_lds_b128(rs_g, g_lds + (ti & 1) * TB + off, lane16, ti * TB + off);
-            if (wave == 3 && lane < 32) dma_to_lds_b128(rs_m, mu_lds + (ti & 1) * 512u, lane16, ti * 512u);
+                dma_to_lds_b128(rs_g, g_lds + ((ti - pt_lo) % 3u) * TB + off, lane16, ti * TB + off);
+            if (wave == 3 && lane < 32) dma_to_lds_b128(rs_m, mu_lds + ((ti - pt_lo) % 3u) * 512u, lane16, ti * 512u);
         };
         fetch_tile(pt_lo);
         // ---- omega32 of the user -> LDS stage (also the logit error bound) ----
@@ -1747,8 +1756,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         constexpr uint32_t RSc = 32 * N1 + 16, TILE_B = 128 * RSc;
         const char* a_lane = g_buf + j * RSc + 16 * h;
         const char* m_lane = reinterpret_cast<const char*>(mu_buf) + 16 * h;
-        auto a_base = [&](uint32_t pi) { return a_lane + ((pt_lo + (pi >> 1)) & 1) * TILE_B + (pi & 1) * (64 * RSc); };
-        auto m_base = [&](uint32_t pi) { return m_lane + ((pt_lo + (pi >> 1)) & 1) * (128 * 4) + (pi & 1) * (64 * 4); };
+        auto a_base = [&](uint32_t pi) { return a_lane + ((pi >> 1) % 3u) * TILE_B + (pi & 1) * (64 * RSc); };
+        auto m_base = [&](uint32_t pi) { return m_lane + ((pi >> 1) % 3u) * (128 * 4) + (pi & 1) * (64 * 4); };
         auto load_a = [&](PairOps& o, const char* ab, int idx) {        // A row block idx of the pair's chunk 0 / 1
             if (idx < N1) o.A0[idx < N1 ? idx : 0] = *reinterpret_cast<const bf16x8*>(ab + 32 * idx);
             else o.A1[idx - N1 < N1 ? idx - N1 : 0] = *reinterpret_cast<const bf16x8*>(ab + 32 * RSc + 32 * (idx - N1));
@@ -1863,6 +1872,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         RG_DMA_WAIT();
         __syncthreads();           // tile pt_lo landed
         if (pt_lo + 1 < pt_hi) fetch_tile(pt_lo + 1);
+        if (pt_lo + 2 < pt_hi) fetch_tile(pt_lo + 2);
 #pragma unroll
         for (int i = 0; i < 2 * N1; ++i) load_a(oa, a_base(0), i);
 #pragma unroll
@@ -1903,10 +1913,14 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         for (; pi + 1 < np; pi += 2) {
             float s0, s1;
             const uint32_t T = pt_lo + (pi >> 1);
-            // ---- tile barrier: every wave holds tile T's operands; tile T + 1 has landed ----
-            RG_DMA_WAIT();
-            if (!(d.ablate & 64u)) __syncthreads();
-            if (T + 2 < pt_hi && !(d.ablate & 32u)) fetch_tile(T + 2);
+            // ---- tile barrier: every wave holds tile T's operands (its buffer is refilled with tile T + 3);
+            // tile T + 1 has landed.  Issued behind its DMA, per wave: the DMA of tile T + 2 (>= 4 operations) and
+            // the scratch stores of the tiles finished since (0, 1, then always 2) -> those may stay in flight ----
+            if (T + 2 >= pt_hi) RG_TILE_BARRIER(0);            // nothing was issued behind tile T + 1 but stores
+            else if (pi == 1) RG_TILE_BARRIER(4);               // DMA(T + 2)
+            else if (pi == 3) RG_TILE_BARRIER(5);               // + one store
+            else RG_TILE_BARRIER(6);                            // + two stores
+            if (T + 3 < pt_hi && !(d.ablate & 32u)) fetch_tile(T + 3);
             stream(ob, oa, pi + 1, p0, p1, a0, a1, s0, s1);                  // MFMAs of pair pi | sums of pair pi - 1
             book(pi - 1, s0, s1);
             if (--sc_issue_left == 0) sc_issue_left = d.sc_chunks / 4;
@@ -1922,8 +1936,6 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         }
         {   // the last pair (second pair of the last tile), then its own sums
             float s0, s1;
-            RG_DMA_WAIT();
-            if (!(d.ablate & 64u)) __syncthreads();
             stream(ob, oa, pi, p0, p1, a0, a1, s0, s1);                      // (operand fetch of a "next" pair: this one again, unused)
             book(pi - 1, s0, s1);
 #pragma unroll
@@ -2739,7 +2751,7 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
         if (!(lean && !strcmp(lean, "lean")))
             if (static_cast<size_t>(d.P_pad) * d.RS < (1ull << 31))     // its DMA uses 31-bit buffer offsets
                 if (draw_kernel_t kp = bf16p_kernel_for(d)) s->bf16_kernel = kp;
-        s->bf16_smem = bf16_smem_bytes(geom_of(*cfg), 2 * d.KH);
+        s->bf16_smem = bf16_smem_bytes(geom_of(*cfg), 2 * d.KH, s->bf16_kernel == bf16p_kernel_for(d) ? 3u : 2u);
         // the larger classes still spill registers; the fp32 kernel is faster there for now
         if (s->bf16_kernel && (d.f16 || (d.N1 <= 4 && d.KH <= 10))) d.use_mfma = 2;
     }
