@@ -1617,8 +1617,9 @@ __device__ __forceinline__ double f16_extra_delta(const DevSim& d, float Ahat, f
 // itself (RG_DMA_WAIT) right before that barrier.  The LDS reads stay ordinary compiler-visible loads.
 typedef int rg_v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void dma_to_lds_b128(rg_v4i rsrc, uint32_t lds_addr, uint32_t lane_off, uint32_t s_off) {
-    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_addr), "v"(lane_off), "s"(rsrc), "s"(s_off) : "m0", "memory");
+    uint32_t keep_m0;          // M0 is the compiler's: borrowed and put back
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep_m0) : "s"(lds_addr), "v"(lane_off), "s"(rsrc), "s"(s_off) : "memory");
 }
 // raw buffer resource over [p, p + 2 GiB): base, stride 0, num_records, gfx9 raw-buffer flags
 __device__ __forceinline__ rg_v4i raw_buffer_rsrc(const void* p) {

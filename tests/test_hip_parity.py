@@ -62,6 +62,10 @@ CASES = [
     (dict(num_products=25, K=6, random_seed=13), 600, 0,
      dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=24,
           ouc=dict(gu.OUC_DEFAULTS, exploit_explore=False, epsilon=0.5, reverse_pop=True))),
+    # more than 65536 products: the view history keeps separate (product u32, count u16) arrays
+    # instead of packed 16+16-bit entries
+    (dict(num_products=70000, K=4, random_seed=14), 120, 0,
+     dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=25, ouc=dict(gu.OUC_DEFAULTS))),
 ]
 
 
