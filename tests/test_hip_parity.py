@@ -244,6 +244,20 @@ def test_every_draw_kernel_matches_the_oracle(mode, shape, monkeypatch):
         assert cnt['exact_draws'] < 0.2 * cnt['organic']
 
 
+@pytest.mark.parametrize('draw', ['f64', 'f16'])
+def test_product_per_lane_float64_kernel_matches_the_oracle(draw, monkeypatch):
+    """RECOGYM_EXACT_TILE=1 selects the first float64 resolve kernel (a product per lane, Gamma^T tiles
+    in LDS; the only one for K > 64) instead of the user-per-lane one."""
+    from oracle import oracle as orc
+    monkeypatch.setenv('RECOGYM_EXACT_TILE', '1')
+    monkeypatch.setenv('RECOGYM_DRAW', draw)
+    cfg = Configuration({**env_1_args, 'random_seed': 321, 'num_products': 1500, 'K': 20})
+    want = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX).generate_logs(500)
+    rows, cnt = run_sim(cfg, 500)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps')},
+                         ps_rtol=1e-6, what=f'tile kernel, {draw}')
+
+
 def test_full_size_log_invariants():
     """BASELINE config 2 at full size (P=1000, K=20, 1 M users, RandomAgent): the oracle cannot
     run this in seconds, so check the size-independent properties of the reference's log

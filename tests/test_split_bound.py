@@ -1,0 +1,41 @@
+"""The error budget the certificate grants the two-way fp16 operand split (DESIGN.md §2,
+`f16_extra_delta` in recogym_hip.hip), checked numerically on the host: the device forms
+l = sum_k (h1(g) h1(w) + h2(g) h1(w) + h1(g) h2(w)) with exact products and fp32 accumulation; here
+the same three terms are summed exactly (float64 holds fp16 x fp16 products exactly), so what is
+measured is the REPRESENTATION error the split adds on top of the accumulation budget."""
+import numpy as np
+import pytest
+
+
+def split2(x):
+    x = np.asarray(x, dtype=np.float32)
+    h1 = x.astype(np.float16)
+    h2 = (x - h1.astype(np.float32)).astype(np.float16)
+    return h1.astype(np.float64), h2.astype(np.float64)
+
+
+@pytest.mark.parametrize('scale_g, scale_w', [(1.0, 1.0), (3.0, 0.2), (0.05, 4.0), (1e-3, 1e-3), (30.0, 10.0)])
+def test_fp16_split_error_is_inside_its_budget(scale_g, scale_w):
+    rng = np.random.RandomState(7)
+    K, n = 20, 20000
+    log2e = 1.4426950408889634
+    g = (rng.randn(n, K) * scale_g * log2e).astype(np.float32)     # fl32(Gamma log2 e) rows
+    w = (rng.randn(n, K) * scale_w).astype(np.float32)             # fl32(omega)
+    g1, g2 = split2(g)
+    w1, w2 = split2(w)
+    kept = (g1 * w1 + g2 * w1 + g1 * w2).sum(axis=1)               # what the MFMA sums (exactly)
+    true = (g.astype(np.float64) * w.astype(np.float64)).sum(axis=1)
+    err = np.abs(kept - true)                                      # log2 units
+    terms = np.abs(g.astype(np.float64) * w.astype(np.float64)).sum(axis=1)
+    budget = 3 * 2.0 ** -22 * terms + 2.0 ** -25 * (np.abs(g).sum(axis=1) + np.abs(w).sum(axis=1))
+    assert (err <= budget).all(), float((err / budget).max())
+    # and it is not a vacuous bound: the worst case uses a fair share of it
+    assert (err / budget).max() > 0.02
+
+
+def test_fp16_pieces_reconstruct_fp32():
+    rng = np.random.RandomState(3)
+    x = (rng.randn(100000) * np.exp(rng.uniform(-12, 6, 100000))).astype(np.float32)
+    h1, h2 = split2(x)
+    e = np.abs(x.astype(np.float64) - h1 - h2)
+    assert (e <= np.maximum(2.0 ** -22 * np.abs(x), 2.0 ** -25)).all()
