@@ -167,7 +167,7 @@ int rg_sim_step(rg_sim* sim, const int32_t* d_actions, void* stream);
 
 /* generate_logs' user loop (abstract.py:299-316) for all users at once: steps until every user
  * reached `stop` or max_steps transitions were made.  Synchronises `stream`.  With max_steps >=
- * 65536 ("to the end") the last users of the run (<= 4096 alive at a 16-step poll; RECOGYM_TAIL overrides) are walked
+ * 65536 ("to the end") the last users of the run (<= 4096 alive at a 16-step poll, fewer for tables larger than 10^4 x 20; RECOGYM_TAIL overrides) are walked
  * to their end one user per workgroup instead of step by step; rows, counters and the sorted
  * log are the same, RG_CNT_STEP then reports the longest trajectory. */
 int rg_sim_run(rg_sim* sim, uint32_t max_steps, void* stream);

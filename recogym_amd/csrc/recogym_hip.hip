@@ -2768,7 +2768,14 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     d.ablate = 0;
     s->repack_every = 16;
     s->repacked = false;
-    s->tail_below = 4096;
+    {   // a per-user draw streams the whole Gamma table through one CU: the population at which the tail
+        // kernel beats the latency floor of the lock-step steps shrinks with P * K (4096 users at 10^4 x 20)
+        const double scale = 2.0e5 / (static_cast<double>(d.P) * static_cast<double>(d.K));
+        // (only where the lock-step draw kernel slices products for small populations; the fp32 and float64
+        // kernels sweep all P per step, so for them the tail kernel wins much earlier)
+        const double tb = 4096.0 * ((scale < 1.0 && d.use_mfma == 2) ? scale : 1.0);
+        s->tail_below = tb < 64.0 ? 64u : static_cast<uint32_t>(tb);
+    }
     s->prof_tail_ms = 0.0;
     if (const char* e = getenv("RECOGYM_TAIL")) s->tail_below = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_REPACK")) s->repack_every = static_cast<uint32_t>(atoi(e));
