@@ -2066,6 +2066,15 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                 // of costing another HBM round trip after it — this kernel is latency-bound.
                 const double* om_row = d.omega + static_cast<size_t>(slot) * d.OMS;
                 const double touch0 = om_row[0], touch1 = om_row[d.K - 1];
+                // K even and <= 24 (rows are 16-byte aligned): the whole omega row is fetched here as 16-byte
+                // loads and held across the policy, so that only beta's row is left on the critical path
+                const bool pre = d.K <= 24 && !(d.K & 1);
+                double2 wpre[12];
+                if (pre) {
+#pragma unroll
+                    for (int k2 = 0; k2 < 12; ++k2)
+                        wpre[k2] = *reinterpret_cast<const double2*>(om_row + 2 * min(static_cast<uint32_t>(k2), d.K / 2 - 1));
+                }
                 uint32_t touch2 = 0;
                 if (d.hist_cap) touch2 = d.hist[static_cast<size_t>(slot) * d.hist_cap] +
                                          d.hist_cntv[static_cast<size_t>(slot) * d.hist_cap];
@@ -2079,6 +2088,15 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                 const double* b = d.beta + static_cast<size_t>(a) * d.K;
                 const double* om = d.omega + static_cast<size_t>(slot) * d.OMS;
                 double x = 0.0;
+                if (pre) {
+                    double2 bpre[12];
+#pragma unroll
+                    for (int k2 = 0; k2 < 12; ++k2)
+                        bpre[k2] = *reinterpret_cast<const double2*>(b + 2 * min(static_cast<uint32_t>(k2), d.K / 2 - 1));
+#pragma unroll
+                    for (int k2 = 0; k2 < 12; ++k2)
+                        if (static_cast<uint32_t>(2 * k2) < d.K) { x += bpre[k2].x * wpre[k2].x; x += bpre[k2].y * wpre[k2].y; }
+                } else
                 for (uint32_t k0 = 0; k0 < d.K; k0 += 8) {
                     double wv[8], bv[8];
 #pragma unroll
