@@ -212,10 +212,44 @@ class Simulator:
                        'rg_sim_sort_log')
         return out, offsets
 
-    def rows(self):
-        """Decoded host rows in the reference's order."""
+    def sorted_log_host(self):
+        """-> ((n, 4) int32 host array of the log in the reference's row order, exact `ps` of the
+        uniform policies or None)."""
         out, _ = self.sorted_log()
         uniform = None
         if self.policy in (_abi.RG_POLICY_UNIFORM_ENV, _abi.RG_POLICY_RANDOM_AGENT):
             uniform = 1.0 / float(self.config.num_products)
-        return decode_rows(out.cpu().numpy(), uniform)
+        return out.cpu().numpy(), uniform
+
+    def log_columns(self):
+        """The log in the reference's row order, decoded ON THE DEVICE into the columns of the
+        reference's DataFrame and copied to the host column by column:
+        dict(t f32, u i32, is_bandit bool, v i32, a i32, c f32 (NaN on organic rows), ps f64 (NaN))."""
+        out, _ = self.sorted_log()
+        with torch.cuda.device(self.device):
+            code = out[:, 2]
+            is_b = (code & _abi.RG_EV_BANDIT) != 0
+            idx = code & _abi.RG_EV_INDEX_MASK
+            zero = torch.zeros((), dtype=torch.int32, device=out.device)
+            nan32 = torch.full((), float('nan'), dtype=torch.float32, device=out.device)
+            nan64 = torch.full((), float('nan'), dtype=torch.float64, device=out.device)
+            if self.policy in (_abi.RG_POLICY_UNIFORM_ENV, _abi.RG_POLICY_RANDOM_AGENT):
+                ps_b = torch.full((), 1.0 / float(self.config.num_products), dtype=torch.float64,
+                                  device=out.device)                 # exact 1/P of the uniform policies
+            else:
+                ps_b = out[:, 3].contiguous().view(torch.float32).to(torch.float64)
+            cols = dict(
+                t=out[:, 1].to(torch.float32),
+                u=out[:, 0].contiguous(),
+                is_bandit=is_b,
+                v=torch.where(is_b, zero, idx),
+                a=torch.where(is_b, idx, zero),
+                c=torch.where(is_b, ((code & _abi.RG_EV_CLICK) != 0).to(torch.float32), nan32),
+                ps=torch.where(is_b, ps_b, nan64),
+            )
+            return {k: v.cpu().numpy() for k, v in cols.items()}
+
+    def rows(self):
+        """Decoded host rows in the reference's order."""
+        raw, uniform = self.sorted_log_host()
+        return decode_rows(raw, uniform)

@@ -165,3 +165,34 @@ def test_two_rank_gloo_counter_allreduce_equals_single_process(tmp_path):
     for o in outs:
         assert o['s'] == c['clicks'] and o['f'] == c['bandit'] + c['phantom'] - c['clicks']
     assert outs[0]['q'] == outs[1]['q'] and outs[0]['v'] == outs[1]['v'] == outs[0]['q'][0]
+
+
+def test_log_materialisation_paths_agree():
+    """the device-decoded column path (columns_to_dataframe) and the host decode of raw
+    rg_event records (raw_log_to_dataframe) build the same DataFrame as the reference-shaped two-step
+    path rows_to_dataframe(decode_rows(raw)) — dtypes included, ids beyond the UInt16 ceiling too."""
+    import pandas as pd
+    from recogym_amd import _abi
+    from recogym_amd.envs.reco_env_v1 import (columns_to_dataframe, raw_log_to_dataframe,
+                                              rows_to_dataframe)
+    from recogym_amd.sim import decode_rows
+    rng = np.random.RandomState(0)
+    for n, users, P, uniform in ((5000, 300, 50, None), (5000, 70000, 70000, 1.0 / 70000)):
+        raw = np.zeros((n, 4), dtype=np.uint32)
+        raw[:, 0] = np.sort(rng.randint(0, users, n))
+        raw[:, 1] = rng.randint(0, 300, n)
+        is_b = rng.rand(n) < 0.7
+        click = is_b & (rng.rand(n) < 0.1)
+        raw[:, 2] = (rng.randint(0, P, n) | np.where(is_b, _abi.RG_EV_BANDIT, 0)
+                     | np.where(click, _abi.RG_EV_CLICK, 0)).astype(np.uint32)
+        raw[:, 3] = rng.rand(n).astype(np.float32).view(np.uint32)
+        want = rows_to_dataframe(decode_rows(raw.view(np.int32), uniform), P)
+        pd.testing.assert_frame_equal(raw_log_to_dataframe(raw.view(np.int32), P, uniform), want)
+        code = raw[:, 2]
+        idx = (code & _abi.RG_EV_INDEX_MASK).astype(np.int32)
+        ps = raw[:, 3].copy().view(np.float32).astype(np.float64) if uniform is None else np.full(n, uniform)
+        cols = dict(t=raw[:, 1].astype(np.float32), u=raw[:, 0].astype(np.int32), is_bandit=is_b,
+                    v=np.where(is_b, 0, idx).astype(np.int32), a=np.where(is_b, idx, 0).astype(np.int32),
+                    c=np.where(is_b, click.astype(np.float32), np.float32('nan')).astype(np.float32),
+                    ps=np.where(is_b, ps, np.nan))
+        pd.testing.assert_frame_equal(columns_to_dataframe(cols, P), want)
