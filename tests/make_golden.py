@@ -157,9 +157,45 @@ def notebook_goldens():
     assert same7 and same9
 
 
+def train_feed_golden(fixture):
+    """The training set the UNMODIFIED reference builds from a log: the rows of an
+    existing fixture are pushed through ModelBuilder.train's bookkeeping (agents/abstract.py:55-83:
+    one dict entry per organic session row / per action) and AbstractFeatureProvider.train_data
+    (agents/abstract.py:190-279) is run on them."""
+    rh.import_reference()
+    from recogym import Configuration
+    from recogym.agents.abstract import AbstractFeatureProvider
+    f = np.load(os.path.join(GOLDEN, fixture + '.npz'), allow_pickle=False)
+    meta = json.loads(str(f['meta']))
+    fp = AbstractFeatureProvider(Configuration({'num_products': meta['env_args']['num_products']}),
+                                 is_sparse=True)
+    for i in range(len(f['t'])):
+        bandit = int(f['z'][i]) == 1
+        fp.data['t'].append(int(f['t'][i]))
+        fp.data['u'].append(int(f['u'][i]))
+        fp.data['z'].append('bandit' if bandit else 'organic')
+        fp.data['v'].append(None if bandit else int(f['v'][i]))
+        fp.data['a'].append(int(f['a'][i]) if bandit else None)
+        fp.data['c'].append(int(f['c'][i]) if bandit else None)
+        fp.data['ps'].append(float(f['ps'][i]) if bandit else None)
+    feats, actions, deltas, pss = fp.train_data()
+    feats = feats.tocsr()
+    feats.sort_indices()
+    path = os.path.join(GOLDEN, 'train_feed_' + fixture + '.npz')
+    np.savez_compressed(path, data=feats.data, indices=feats.indices, indptr=feats.indptr,
+                        shape=np.array(feats.shape), actions=actions, deltas=deltas, pss=pss,
+                        data_dtype=np.array(str(feats.dtype)))
+    print(f'train_feed_{fixture}: {feats.shape[0]} rows, nnz {feats.nnz}, dtype {feats.dtype} -> '
+          f'{os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def main():
     assert rh.reference_available(), 'needs /root/reference'
     os.makedirs(GOLDEN, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == 'train_feed':     # only the §8f-3 fixtures (fast)
+        for fx in ('philox_ouc', 'mt_random_agent'):
+            train_feed_golden(fx)
+        return
     notebook_goldens()
     S = dict(random_seed=42)
     # --- reference as shipped (sequential MT19937) ---
@@ -199,6 +235,8 @@ def main():
     run_case('philox_change_omega', {**S, 'change_omega_for_bandits': True}, 120, injected=True)
     run_case('philox_bandit_mf', {**S, 'num_products': 40, 'K': 10}, 150, agent_kind='bmf',
              agent_args=dict(torch_seed=3, embed_dim=5), injected=True)
+    for fx in ('philox_ouc', 'mt_random_agent'):
+        train_feed_golden(fx)
 
 
 if __name__ == '__main__':
