@@ -222,7 +222,12 @@ def main():
                         exact_fraction=round(c['exact_draws'] / max(c['organic'], 1), 5),
                         hbm_algorithmic_GBps=round(
                             (events / args.steps) * (8 * K + 8 + 16 + 3 + 35) / 1e9 /
-                            (elapsed / args.steps), 1))
+                            (elapsed / args.steps), 1),
+                        # whole-job algorithmic HBM bytes (omega read, lists, row, action, history)
+                        # against the 8 TB/s roofline: the job is compute(exp)-bound, not HBM-bound
+                        hbm_roofline_frac=round(
+                            (events / args.steps) * (8 * K + 8 + 16 + 3 + 35) / 1e9 /
+                            (elapsed / args.steps) / HBM_PEAK_GBPS, 4))
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload)
