@@ -2650,6 +2650,7 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         // few user tiles: slice the products so that the step's latency is a slice, not a sweep
         const uint32_t tiles_up = (upper + 127) / 128;
         uint32_t S = tiles_up >= 1024 ? 1u : 2048u / (tiles_up ? tiles_up : 1u);
+        if (const char* e = getenv("RECOGYM_SLICES")) S = static_cast<uint32_t>(atoi(e));   // tests: force either form
         if (S > d.n_sc) S = d.n_sc;
         if (S < 1) S = 1;
         const int grid = grid_for(static_cast<uint64_t>(tiles_up) * S, 1);

@@ -258,6 +258,35 @@ def test_product_per_lane_float64_kernel_matches_the_oracle(draw, monkeypatch):
                          ps_rtol=1e-6, what=f'tile kernel, {draw}')
 
 
+def test_fused_and_sliced_draw_forms_agree_at_scale(monkeypatch):
+    """The draw kernel runs in two forms: whole product sweeps with the search fused in (steps with
+    >= 1024 user tiles) and product slices + k_draw_search (fewer).  Small oracle-checked runs only
+    ever take the second; here both forms are forced on the same 150 000-user run and must produce
+    the same log (order-independent checksum of every row) and counters."""
+    from recogym_amd.sim import Simulator
+    cfg = Configuration({**env_1_args, 'random_seed': 9, 'num_products': 1000, 'K': 20})
+    n = 150_000
+
+    def run(slices):
+        monkeypatch.setenv('RECOGYM_SLICES', slices)
+        sim = Simulator(cfg, n, device='cuda:0', policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=3,
+                        ouc=dict(gu.OUC_DEFAULTS))
+        sim.reset_users(0, n)
+        sim.run()
+        c = sim.counters()
+        rows = sim.log[:c['log_rows']].to(torch.int64)
+        chk = [(rows[:, i] * (rows[:, 1] + 7) * (rows[:, 0] + 13)).sum().item() for i in range(4)]
+        sim.close()
+        return c, chk
+
+    fused_c, fused_chk = run('1')
+    sliced_c, sliced_chk = run('4')
+    for k in ('organic', 'bandit', 'clicks', 'phantom', 'log_rows'):
+        assert fused_c[k] == sliced_c[k], k
+    assert fused_chk == sliced_chk
+    assert fused_c['live'] == 0 and fused_c['hist_overflow'] == 0
+
+
 def test_full_size_log_invariants():
     """BASELINE config 2 at full size (P=1000, K=20, 1 M users, RandomAgent): the oracle cannot
     run this in seconds, so check the size-independent properties of the reference's log
