@@ -258,6 +258,36 @@ def test_product_per_lane_float64_kernel_matches_the_oracle(draw, monkeypatch):
                          ps_rtol=1e-6, what=f'tile kernel, {draw}')
 
 
+@pytest.mark.parametrize('shape', [(10000, 20, 40_000), (1000, 20, 300_000)])
+def test_certified_draws_equal_float64_draws_at_scale(shape, monkeypatch):
+    """The float64-only draw path is the oracle's arithmetic (checked row for row on small runs) and
+    does not depend on the run size; the certified fp16-split MFMA path must log exactly the same
+    rows on runs far beyond what the CPU oracle can replay (BASELINE config 3's table: ~10^6 draws
+    at P = 10 000, and 7.5 * 10^6 at P = 1000 through the fused form of the kernel)."""
+    from recogym_amd.sim import Simulator
+    P, K, n = shape
+    cfg = Configuration({**env_1_args, 'random_seed': 17, 'num_products': P, 'K': K})
+
+    def run(mode):
+        monkeypatch.setenv('RECOGYM_DRAW', mode)
+        sim = Simulator(cfg, n, device='cuda:0', policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=5,
+                        ouc=dict(gu.OUC_DEFAULTS))
+        sim.reset_users(1000, n)
+        sim.run()
+        c = sim.counters()
+        rows = sim.log[:c['log_rows']].to(torch.int64)
+        chk = [(rows[:, i] * (rows[:, 1] + 7) * (rows[:, 0] + 13)).sum().item() for i in range(4)]
+        sim.close()
+        return c, chk
+
+    fast_c, fast_chk = run('f16')
+    ref_c, ref_chk = run('f64')
+    assert 0 < fast_c['exact_draws'] < 0.1 * fast_c['organic'] and ref_c['exact_draws'] == 0
+    for k in ('organic', 'bandit', 'clicks', 'phantom', 'log_rows'):
+        assert fast_c[k] == ref_c[k], k
+    assert fast_chk == ref_chk
+
+
 def test_fused_and_sliced_draw_forms_agree_at_scale(monkeypatch):
     """The draw kernel runs in two forms: whole product sweeps with the search fused in (steps with
     >= 1024 user tiles) and product slices + k_draw_search (fewer).  Small oracle-checked runs only
