@@ -288,6 +288,34 @@ def test_certified_draws_equal_float64_draws_at_scale(shape, monkeypatch):
     assert fast_chk == ref_chk
 
 
+def test_repack_and_tail_kernel_do_not_change_the_log_at_scale(monkeypatch):
+    """300 000 users (above the 2^18 threshold where the state repack is on by default): the run with
+    the repack every 16 steps and the per-user tail kernel must log the same rows as plain lock-step
+    to the end without repack."""
+    from recogym_amd.sim import Simulator
+    cfg = Configuration({**env_1_args, 'random_seed': 23, 'num_products': 100, 'K': 20, 'sigma_omega': 0.05})
+    n = 300_000
+
+    def run(repack, tail):
+        monkeypatch.setenv('RECOGYM_REPACK', repack)
+        monkeypatch.setenv('RECOGYM_TAIL', tail)
+        sim = Simulator(cfg, n, device='cuda:0', policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=5,
+                        ouc=dict(gu.OUC_DEFAULTS))
+        sim.reset_users(0, n)
+        sim.run()
+        c = sim.counters()
+        rows = sim.log[:c['log_rows']].to(torch.int64)
+        chk = [(rows[:, i] * (rows[:, 1] + 7) * (rows[:, 0] + 13)).sum().item() for i in range(4)]
+        sim.close()
+        return c, chk
+
+    a_c, a_chk = run('16', '4096')
+    b_c, b_chk = run('0', '0')
+    for k in ('organic', 'bandit', 'clicks', 'phantom', 'log_rows'):
+        assert a_c[k] == b_c[k], k
+    assert a_chk == b_chk
+
+
 def test_fused_and_sliced_draw_forms_agree_at_scale(monkeypatch):
     """The draw kernel runs in two forms: whole product sweeps with the search fused in (steps with
     >= 1024 user tiles) and product slices + k_draw_search (fewer).  Small oracle-checked runs only
