@@ -90,3 +90,65 @@ def train_data_from_log(log, num_products, is_sparse=True):
     if not is_sparse:
         return np.asarray(feats.todense(), dtype=np.float64), actions, deltas, pss
     return feats, actions, deltas, pss
+
+
+def train_data_from_log_torch(cols, num_products):
+    """The same training set built with torch ops on whatever device the log columns live on
+    (`Simulator.log_columns_device()` keeps them on the GPU): -> dict(crow, col, val (int16), actions
+    (int16), deltas (int16), pss (float64)) of torch tensors; `crow/col/val` are the CSR arrays of
+    the (n_bandit_rows, P) feature matrix with sorted column indices.  Same algorithm as
+    train_data_from_log (group organic rows by (user, product); one entry per later bandit row of the
+    user; count by searchsorted on composite keys); the sort by (row, column) that scipy does inside
+    its COO->CSR conversion is one torch.sort here."""
+    import torch
+    u = cols['u'].to(torch.int64) & 0xFFFFFFFF
+    is_b = cols['is_bandit'].to(torch.bool)
+    v = cols['v'].to(torch.int64)
+    dev = u.device
+    n = u.numel()
+    P = int(num_products)
+    pos = torch.arange(n, device=dev, dtype=torch.int64)
+    b_pos = pos[is_b]
+    nb = b_pos.numel()
+    out = dict(actions=cols['a'][is_b].to(torch.int16),
+               deltas=torch.nan_to_num(cols['c'][is_b].to(torch.float32)).to(torch.int16),
+               pss=cols['ps'][is_b].to(torch.float64))
+    o_pos = pos[~is_b]
+    if nb == 0 or o_pos.numel() == 0:
+        out.update(crow=torch.zeros(nb + 1, dtype=torch.int64, device=dev),
+                   col=torch.zeros(0, dtype=torch.int64, device=dev),
+                   val=torch.zeros(0, dtype=torch.int16, device=dev), shape=(nb, P))
+        return out
+    ib = is_b.to(torch.int64)
+    b_incl = torch.cumsum(ib, 0)
+    b_before = b_incl - ib
+    last_of_user = torch.ones(n, dtype=torch.bool, device=dev)
+    last_of_user[:-1] = u[1:] != u[:-1]
+    ends = pos[last_of_user]
+    user_of_row = torch.cumsum(last_of_user.to(torch.int64), 0) - last_of_user.to(torch.int64)
+    row_end = ends[user_of_row]
+    key = user_of_row[o_pos] * P + v[o_pos]
+    key_s, order = torch.sort(key, stable=True)
+    pos_s = o_pos[order]
+    new_grp = torch.ones_like(key_s, dtype=torch.bool)
+    new_grp[1:] = key_s[1:] != key_s[:-1]
+    g_start = torch.nonzero(new_grp).flatten()
+    g_of_view = torch.cumsum(new_grp.to(torch.int64), 0) - 1
+    first_pos = pos_s[g_start]
+    k_lo = b_before[first_pos]
+    k_hi = b_incl[row_end[first_pos]]
+    m = k_hi - k_lo
+    total = int(m.sum().item())
+    grp = torch.repeat_interleave(torch.arange(g_start.numel(), device=dev), m)
+    within = torch.arange(total, device=dev, dtype=torch.int64) - torch.repeat_interleave(torch.cumsum(m, 0) - m, m)
+    rows = k_lo[grp] + within
+    ccol = (key_s[g_start] % P)[grp]
+    big = n + 1
+    view_keys = g_of_view * big + pos_s
+    q = grp * big + b_pos[rows]
+    vals = torch.searchsorted(view_keys, q, right=False) - g_start[grp]
+    rc, perm = torch.sort(rows * P + ccol)
+    crow = torch.zeros(nb + 1, dtype=torch.int64, device=dev)
+    crow[1:] = torch.cumsum(torch.bincount(rows, minlength=nb), 0)
+    out.update(crow=crow, col=rc % P, val=vals[perm].to(torch.int16), shape=(nb, P))
+    return out

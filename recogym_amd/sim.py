@@ -221,7 +221,7 @@ class Simulator:
             uniform = 1.0 / float(self.config.num_products)
         return out.cpu().numpy(), uniform
 
-    def log_columns(self):
+    def log_columns(self, on_device=False):
         """The log in the reference's row order, decoded ON THE DEVICE into the columns of the
         reference's DataFrame and copied to the host column by column:
         dict(t f32, u i32, is_bandit bool, v i32, a i32, c f32 (NaN on organic rows), ps f64 (NaN))."""
@@ -247,7 +247,12 @@ class Simulator:
                 c=torch.where(is_b, ((code & _abi.RG_EV_CLICK) != 0).to(torch.float32), nan32),
                 ps=torch.where(is_b, ps_b, nan64),
             )
-            return {k: v.cpu().numpy() for k, v in cols.items()}
+            return cols if on_device else {k: v.cpu().numpy() for k, v in cols.items()}
+
+    def log_columns_device(self):
+        """log_columns() left on the device (torch tensors), e.g. for
+        agents.feature_feed.train_data_from_log_torch."""
+        return self.log_columns(on_device=True)
 
     def rows(self):
         """Decoded host rows in the reference's order."""

@@ -202,3 +202,25 @@ def test_test_agent_and_verify_agents_quantiles():
     assert recogym.test_agent(env, agents['random'], 0, 500, num_epochs=2,
                               epoch_with_random_reset=True) != \
         recogym.test_agent(env, agents['random'], 0, 500, num_epochs=1)
+
+
+def test_training_feed_on_device_equals_host_feed():
+    """SURVEY §8f-3 on the GPU: the torch feed over Simulator.log_columns_device() builds the same
+    CSR training set as the host (numpy) feed, which is pinned against the reference's train_data."""
+    from recogym_amd.agents.feature_feed import train_data_from_log, train_data_from_log_torch
+    from recogym_amd.sim import Simulator
+    cfg = Configuration({**recogym.env_1_args, 'random_seed': 77, 'num_products': 300, 'K': 12})
+    sim = Simulator(cfg, 3000, device='cuda:0', policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=3)
+    sim.reset_users(0, 3000)
+    sim.run()
+    dev_cols = sim.log_columns_device()
+    host_cols = sim.log_columns()
+    sim.close()
+    F, A, D, S = train_data_from_log(host_cols, 300)
+    t = train_data_from_log_torch(dev_cols, 300)
+    assert t['crow'].is_cuda
+    assert np.array_equal(t['crow'].cpu().numpy(), F.indptr)
+    assert np.array_equal(t['col'].cpu().numpy(), F.indices)
+    assert np.array_equal(t['val'].cpu().numpy(), F.data)
+    assert np.array_equal(t['actions'].cpu().numpy(), A) and np.array_equal(t['deltas'].cpu().numpy(), D)
+    np.testing.assert_array_equal(t['pss'].cpu().numpy(), S)

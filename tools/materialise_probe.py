@@ -24,3 +24,16 @@ for rep in range(2):
     print(f'{n} users, {rows/1e6:.1f} M rows: simulate {t1-t0:.2f}s | sort+decode on device+copy {t2-t1:.2f}s ({rows/(t2-t1)/1e6:.0f} M rows/s) | '
           f'DataFrame {t3-t2:.2f}s ({rows/(t3-t2)/1e6:.1f} M rows/s) | end to end {rows/(t3-t0)/1e6:.1f} M rows/s', flush=True)
 print(df.dtypes.to_dict())
+
+# --- training feed on the device over the same kind of log ---
+import torch
+from recogym_amd.agents.feature_feed import train_data_from_log_torch
+cnt, sim = env.simulate(n, agent, 0)
+dev_cols = sim.log_columns_device()
+for rep in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    t = train_data_from_log_torch(dev_cols, 1000)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    print(f'training feed on device: {dev_cols["u"].numel()/1e6:.1f} M log rows -> {t["crow"].numel()-1} feature rows, '
+          f'{t["col"].numel()/1e6:.0f} M CSR entries in {t1-t0:.2f} s = {dev_cols["u"].numel()/(t1-t0)/1e6:.1f} M rows/s', flush=True)
+sim.close()
