@@ -230,7 +230,7 @@ def main():
                             (events / args.steps) * (8 * K + 8 + 16 + 3 + 35) / 1e9 /
                             (elapsed / args.steps) / HBM_PEAK_GBPS, 4))
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:     # the CPU leg runs at N = 1 only
         cpu = cpu_baseline(args.workload)
 
     if rank == 0:
