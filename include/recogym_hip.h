@@ -55,6 +55,9 @@ extern "C" {
 #define RG_POLICY_EXTERNAL 3      /* actions supplied by the caller per step (gym.Env.step, abstract.py:123) */
 #define RG_POLICY_LAST_VIEW_TABLE 4 /* frozen policy a = table[last product viewed]: BanditMFSquare inference,
                                      agents/bandit_mf.py:52-87 (argmax_a <E_p[a], E_u[lpv]> is a P-entry table) */
+#define RG_POLICY_LOGREG_FROZEN 5 /* frozen LogregMulticlassIpsAgent (select_randomly = False), agents/logreg_ips.py:60-87:
+                                     a = classes[argmax_c (sum_p views[p] W[c][p] + b[c])] over the user's view counts
+                                     (ViewsFeaturesProvider, agents/abstract.py:316-409), ps = 1 */
 
 /*
  * Everything the step loop needs from `env.config` (a Configuration built from env_1_args,
@@ -143,6 +146,15 @@ int rg_sim_set_tables(rg_sim* sim, const double* d_gamma, const double* d_mu_org
  * d_action[p] = action taken when the user's last organic view was p, d_ps[p] = the `ps` value
  * logged with it (NULL = 1.0; BanditMFSquare logs its logit there, bandit_mf.py:84). */
 int rg_sim_set_policy_table(rg_sim* sim, const int32_t* d_action, const float* d_ps);
+
+/* RG_POLICY_LOGREG_FROZEN: the fitted model's arrays on the device, kept by pointer: d_coef_t =
+ * sklearn's coef_ TRANSPOSED, row-major [num_products][n_classes] float64; d_intercept [n_classes];
+ * d_classes [n_classes] = classes_ (the action of every class).  A two-class sklearn model (coef_ of
+ * one row) is passed as two classes with a zero first row/intercept.  Scores are accumulated exactly
+ * as scipy's CSR x dense product does (viewed products ascending, multiply then add, intercept
+ * last), so the argmax is sklearn's predict() bit for bit. */
+int rg_sim_set_logreg(rg_sim* sim, const double* d_coef_t, const double* d_intercept,
+                      const int32_t* d_classes, uint32_t n_classes);
 
 /* Where rows go.  d_log == NULL (or capacity 0) disables logging: only counters are kept. */
 int rg_sim_set_log(rg_sim* sim, rg_event* d_log, uint64_t capacity);

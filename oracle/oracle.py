@@ -47,6 +47,7 @@ def lib():
         L.rgo_env_create.argtypes = [C.POINTER(_abi.RgConfig), C.c_int] + [C.c_void_p] * 4
         L.rgo_env_destroy.argtypes = [C.c_void_p]
         L.rgo_env_set_policy_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rgo_env_set_logreg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.rgo_env_reseed.argtypes = [C.c_void_p, C.c_uint64]
         L.rgo_env_reseed_policy.argtypes = [C.c_void_p, C.c_uint64]
         L.rgo_env_reset.argtypes = [C.c_void_p, C.c_uint32]
@@ -82,7 +83,8 @@ class OracleEnv:
     """The reference's RecoEnv1, restated: reset / step / generate_logs over the C library."""
 
     def __init__(self, config, rng_mode=RNG_PHILOX, policy=_abi.RG_POLICY_UNIFORM_ENV,
-                 policy_seed=None, ouc=None, epoch=0, tables=None, policy_table=None, policy_ps=None):
+                 policy_seed=None, ouc=None, epoch=0, tables=None, policy_table=None, policy_ps=None,
+                 logreg=None):
         self.config = config
         self.rg_config = make_rg_config(config, config.random_seed + epoch, policy, policy_seed,
                                         ouc)
@@ -95,6 +97,13 @@ class OracleEnv:
             self._pp = None if policy_ps is None else np.ascontiguousarray(policy_ps, dtype=np.float64)
             lib().rgo_env_set_policy_table(self._h, self._pt.ctypes.data_as(C.c_void_p),
                                            None if self._pp is None else self._pp.ctypes.data_as(C.c_void_p))
+
+        if logreg is not None:     # dict(coef_t (P, C) float64, intercept (C,), classes (C,) int32)
+            self._lr = (np.ascontiguousarray(logreg['coef_t'], dtype=np.float64),
+                        np.ascontiguousarray(logreg['intercept'], dtype=np.float64),
+                        np.ascontiguousarray(logreg['classes'], dtype=np.int32))
+            lib().rgo_env_set_logreg(self._h, *[x.ctypes.data_as(C.c_void_p) for x in self._lr],
+                                     len(self._lr[2]))
 
     def __del__(self):
         if getattr(self, '_h', None):

@@ -163,6 +163,8 @@ typedef struct rgo_env {
     int32_t last_view;        /* BanditMFSquare.last_product_viewed (bandit_mf.py:60-65) */
     const int32_t* pol_table; /* RG_POLICY_LAST_VIEW_TABLE: action per last viewed product */
     const double* pol_ps;     /* and the ps logged with it (NULL = 1.0) */
+    const double* lr_coef_t;  /* RG_POLICY_LOGREG_FROZEN: coef_ transposed [P][n_classes], */
+    const double* lr_intercept; const int32_t* lr_classes; uint32_t lr_n;   /* intercept_, classes_ */
     /* scratch */
     double* buf;              /* (P) */
     double* zbuf;             /* (K) */
@@ -192,6 +194,12 @@ rgo_env* rgo_env_create(const rg_config* cfg, int rng_mode, const double* gamma,
 void rgo_env_destroy(rgo_env* e) {
     if (!e) return;
     free(e->omega); free(e->views); free(e->buf); free(e->zbuf); free(e);
+}
+
+/* LogregMulticlassIpsAgent with a fitted model (agents/logreg_ips.py:60-87, select_randomly = False) */
+void rgo_env_set_logreg(rgo_env* e, const double* coef_t, const double* intercept,
+                        const int32_t* classes, uint32_t n_classes) {
+    e->lr_coef_t = coef_t; e->lr_intercept = intercept; e->lr_classes = classes; e->lr_n = n_classes;
 }
 
 void rgo_env_set_policy_table(rgo_env* e, const int32_t* table, const double* ps) {
@@ -402,6 +410,25 @@ int32_t rgo_env_policy_act(rgo_env* e, double* ps_out) {
         /* BanditMFSquare.act with frozen embeddings: argmax_a <E_p[a], E_u[lpv]> is a table */
         *ps_out = e->pol_ps ? e->pol_ps[e->last_view] : 1.0;
         return e->pol_table[e->last_view];
+    }
+
+    if (e->cfg.policy == RG_POLICY_LOGREG_FROZEN) {
+        /* logreg.predict(features): decision_function = X @ coef_.T + intercept_ (sklearn
+         * linear_model/_base.py), X = the 1 x P CSR row of view counts (agents/abstract.py:316-409).
+         * scipy's csr_matvecs (sparsetools/csr.h) adds count * coef_t[p][:] for the stored (ascending)
+         * products with a separate multiply and add; the file is built with -ffp-contract=off, so the
+         * plain expression below is that arithmetic.  argmax = first maximum (numpy). */
+        uint32_t best = 0;
+        double best_s = 0.0;
+        for (uint32_t c = 0; c < e->lr_n; ++c) {
+            double sc = 0.0;
+            for (uint32_t p = 0; p < P; ++p)
+                if (e->views[p]) sc = sc + (double)e->views[p] * e->lr_coef_t[(size_t)p * e->lr_n + c];
+            sc = sc + e->lr_intercept[c];
+            if (c == 0 || sc > best_s) { best = c; best_s = sc; }
+        }
+        *ps_out = 1.0;
+        return e->lr_classes[best];
     }
 
     /* OrganicUserEventCounterModel.act */

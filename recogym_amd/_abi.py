@@ -16,6 +16,7 @@ RG_POLICY_RANDOM_AGENT = 1
 RG_POLICY_ORGANIC_USER_COUNT = 2
 RG_POLICY_EXTERNAL = 3
 RG_POLICY_LAST_VIEW_TABLE = 4
+RG_POLICY_LOGREG_FROZEN = 5
 
 RG_EV_BANDIT = 0x80000000
 RG_EV_CLICK = 0x40000000
@@ -67,6 +68,7 @@ SYMBOLS = {
     'rg_sim_set_tables': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     'rg_sim_set_policy_table': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
+    'rg_sim_set_logreg': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     'rg_sim_set_log': (C.c_int, [_SIM, C.c_void_p, C.c_uint64]),
     'rg_sim_reset_users': (C.c_int, [_SIM, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     'rg_sim_reseed': (C.c_int, [_SIM, C.c_uint64, C.c_uint64]),

@@ -1,0 +1,56 @@
+"""Frozen multinomial logistic-regression policy — the inference side of the reference's
+LogregMulticlassIpsAgent (recogym/agents/logreg_ips.py:60-87, `select_randomly = False`): with a
+fitted sklearn model the agent's act is `classes_[argmax(views @ coef_.T + intercept_)]` over the
+user's cumulative view counts (ViewsFeaturesProvider, agents/abstract.py:316-409), `ps = 1`.
+
+Training stays outside the step loop: `agents.feature_feed.train_data_from_log` builds the
+reference's `(features, actions, deltas, pss)` from a log, sklearn fits on it (the reference's own
+`build()`: weights = deltas / pss, logreg_ips.py:89-99), and this class carries the fitted arrays
+into the device step loop (RG_POLICY_LOGREG_FROZEN).  Scores are accumulated exactly like scipy's
+CSR x dense product (viewed products ascending, multiply then add, intercept last), so the action
+is sklearn's predict() bit for bit — on the device, in the oracle and in `act` below."""
+import numpy as np
+
+from .. import _abi
+from .abstract import Agent
+
+
+class LogregFrozenAgent(Agent):
+    def __init__(self, config, coef, intercept, classes):
+        """coef (n_classes, P) / intercept (n_classes,) / classes (n_classes,) as sklearn stores them;
+        a two-class model (coef of one row) is expanded to two rows (zero first row)."""
+        super().__init__(config)
+        coef = np.atleast_2d(np.asarray(coef, dtype=np.float64))
+        intercept = np.atleast_1d(np.asarray(intercept, dtype=np.float64))
+        classes = np.asarray(classes, dtype=np.int32)
+        if coef.shape[0] == 1 and len(classes) == 2:       # sklearn's binary form: score > 0 -> classes_[1]
+            coef = np.vstack([np.zeros_like(coef), coef])
+            intercept = np.r_[0.0, intercept]
+        assert coef.shape == (len(classes), config.num_products) and intercept.shape == (len(classes),)
+        self.coef_t = np.ascontiguousarray(coef.T)          # (P, n_classes): what the ABI takes
+        self.intercept = np.ascontiguousarray(intercept)
+        self.classes = np.ascontiguousarray(classes)
+        self.reset()
+
+    @classmethod
+    def from_sklearn(cls, config, logreg):
+        return cls(config, logreg.coef_, logreg.intercept_, logreg.classes_)
+
+    def device_policy(self):
+        if getattr(self.config, 'with_ps_all', False):
+            return None
+        return dict(policy=_abi.RG_POLICY_LOGREG_FROZEN, policy_seed=0, ouc=None,
+                    logreg=dict(coef_t=self.coef_t, intercept=self.intercept, classes=self.classes))
+
+    def reset(self):
+        self.views = np.zeros(self.config.num_products, dtype=np.int64)
+
+    def act(self, observation, reward, done):
+        for session in observation.sessions():
+            self.views[int(session['v'])] += 1
+        score = np.zeros(len(self.classes))
+        for p in np.flatnonzero(self.views):                 # ascending, multiply then add
+            score = score + np.float64(self.views[p]) * self.coef_t[p]
+        score = score + self.intercept
+        return {**super().act(observation, reward, done), 'a': int(self.classes[int(np.argmax(score))]),
+                'ps': 1.0, 'ps-a': ()}

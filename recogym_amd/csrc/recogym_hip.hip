@@ -132,6 +132,7 @@ struct DevSim {
     // and in list order, and the host swaps the pointers (restores the locality the lists lose over time)
     double* omega_alt; uint32_t* hist_alt; uint16_t* hist_cntv_alt; uint32_t* hist_n_alt; uint32_t* lpv_alt; uint32_t* uid_alt;
     const int32_t* pol_table; const float* pol_ps;   // caller-owned per-product tables of that policy
+    const double* lr_coef_t; const double* lr_intercept; const int32_t* lr_classes; uint32_t lr_n;   // RG_POLICY_LOGREG_FROZEN
     unsigned long long* counters;   // [RG_CNT_N]
     // log
     rg_event* log; uint64_t log_cap;
@@ -238,7 +239,7 @@ uint32_t exact_kb_of(uint32_t K) {
 }
 
 uint32_t hist_cap_of(const rg_config& c) {
-    if (c.policy != RG_POLICY_ORGANIC_USER_COUNT) return 0;
+    if (c.policy != RG_POLICY_ORGANIC_USER_COUNT && c.policy != RG_POLICY_LOGREG_FROZEN) return 0;
     return c.ouc_history_cap ? c.ouc_history_cap : kDefaultHistoryCap;
 }
 
@@ -312,7 +313,7 @@ int validate(const rg_config* c, uint64_t n) {
     if (sizeof(double) * (static_cast<size_t>(c->K) * 64 + 64 + 16 * c->K) > 64 * 1024)
         return fail(RG_EINVAL, "K %u exceeds the float64 draw kernel's LDS budget", c->K);
     if (n == 0 || n >= (1ull << 31)) return fail(RG_EINVAL, "n_users %llu out of range", (unsigned long long)n);
-    if (c->policy > RG_POLICY_LAST_VIEW_TABLE) return fail(RG_EINVAL, "unknown policy %u", c->policy);
+    if (c->policy > RG_POLICY_LOGREG_FROZEN) return fail(RG_EINVAL, "unknown policy %u", c->policy);
     for (int s = 0; s < 2; ++s)
         if (!(c->trans_cdf[s][0] >= 0.0 && c->trans_cdf[s][0] <= c->trans_cdf[s][1] &&
               c->trans_cdf[s][1] <= 1.0))
@@ -505,6 +506,26 @@ __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, ui
         const uint32_t p = d.lpv[slot];
         *ps_out = d.pol_ps ? static_cast<double>(d.pol_ps[p]) : 1.0;
         return static_cast<uint32_t>(d.pol_table[p]);
+    }
+    if (d.policy == RG_POLICY_LOGREG_FROZEN) {
+        // sklearn predict(): decision_function = X @ coef_.T + intercept_ with X the 1 x P CSR row of view
+        // counts.  scipy's csr_matvecs adds count * coef_t[p][:] for the viewed products in ascending
+        // order with a separate multiply and add (no FMA), then the intercept is added: reproduced
+        // exactly, so ties and near-ties break like the reference's argmax (first maximum).
+        const uint32_t nd = d.hist_n[slot];
+        const uint32_t* hp = d.hist + static_cast<size_t>(slot) * d.hist_cap;
+        const uint16_t* hc = d.hist_cntv + static_cast<size_t>(slot) * d.hist_cap;
+        uint32_t best = 0;
+        double best_s = 0.0;
+        for (uint32_t c = 0; c < d.lr_n; ++c) {
+            double sc = 0.0;
+            for (uint32_t i = 0; i < nd; ++i)
+                sc = __dadd_rn(sc, __dmul_rn(static_cast<double>(hc[i]), d.lr_coef_t[static_cast<size_t>(hp[i]) * d.lr_n + c]));
+            sc = __dadd_rn(sc, d.lr_intercept[c]);
+            if (c == 0 || sc > best_s) { best = c; best_s = sc; }
+        }
+        *ps_out = 1.0;
+        return static_cast<uint32_t>(d.lr_classes[best]);
     }
     const rg_u32x4 w = rg_draw(d.policy_seed, user, t, 0, RG_DRAW_POLICY);
     if (d.policy != RG_POLICY_ORGANIC_USER_COUNT) {
@@ -2861,6 +2882,16 @@ int rg_sim_set_policy_table(rg_sim* sim, const int32_t* d_action, const float* d
     return RG_OK;
 }
 
+int rg_sim_set_logreg(rg_sim* sim, const double* d_coef_t, const double* d_intercept,
+                      const int32_t* d_classes, uint32_t n_classes) {
+    if (!sim) return fail(RG_EINVAL, "sim is NULL");
+    if (sim->d.policy != RG_POLICY_LOGREG_FROZEN) return fail(RG_ESTATE, "policy is not RG_POLICY_LOGREG_FROZEN");
+    if (!d_coef_t || !d_intercept || !d_classes || n_classes == 0) return fail(RG_EINVAL, "NULL model array or no classes");
+    sim->d.lr_coef_t = d_coef_t; sim->d.lr_intercept = d_intercept; sim->d.lr_classes = d_classes;
+    sim->d.lr_n = n_classes;
+    return RG_OK;
+}
+
 int rg_sim_set_log(rg_sim* sim, rg_event* d_log, uint64_t capacity) {
     if (!sim) return fail(RG_EINVAL, "sim is NULL");
     sim->d.log = capacity ? d_log : nullptr;
@@ -2881,6 +2912,8 @@ int rg_sim_reset_users(rg_sim* sim, uint64_t first_user_id, uint64_t n, uint64_t
     if (!sim->tables_set) return fail(RG_ESTATE, "rg_sim_set_tables must be called first");
     if (sim->d.policy == RG_POLICY_LAST_VIEW_TABLE && !sim->d.pol_table)
         return fail(RG_ESTATE, "rg_sim_set_policy_table must be called first");
+    if (sim->d.policy == RG_POLICY_LOGREG_FROZEN && !sim->d.lr_coef_t)
+        return fail(RG_ESTATE, "rg_sim_set_logreg must be called first");
     if (n == 0 || n > sim->d.n_cap) return fail(RG_EINVAL, "n %llu exceeds the %u users the workspace was sized for",
                                                  (unsigned long long)n, sim->d.n_cap);
     if (first_user_id + n > (1ull << 32)) return fail(RG_EINVAL, "user ids must fit 32 bits");

@@ -92,6 +92,11 @@ def device_policy_of(agent):
                     ouc=dict(select_randomly=cfg.select_randomly, epsilon=cfg.epsilon,
                              exploit_explore=cfg.exploit_explore,
                              reverse_pop=getattr(cfg, 'reverse_pop', False)))
+    if name == 'LogregMulticlassIpsAgent' and not getattr(cfg, 'select_randomly', False) \
+            and getattr(agent, 'model', None) is not None and hasattr(agent.model, 'logreg'):
+        # the reference's own agent object with a built model: run its fitted arrays on the device
+        from ..agents.logreg_frozen import LogregFrozenAgent
+        return LogregFrozenAgent.from_sklearn(cfg, agent.model.logreg).device_policy()
     return None
 
 

@@ -68,7 +68,7 @@ class Simulator:
 
     def __init__(self, config, n_users, policy=_abi.RG_POLICY_UNIFORM_ENV, policy_seed=None,
                  ouc=None, epoch=0, log_capacity=None, device=None, tables=None, policy_table=None,
-                 policy_ps=None):
+                 policy_ps=None, logreg=None):
         self.lib = _abi.load()
         self.device = require_device(device)
         self.config = config
@@ -99,6 +99,16 @@ class Simulator:
                 _abi.check(self.lib.rg_sim_set_policy_table(
                     self._h, self.policy_table.data_ptr(),
                     None if self.policy_ps is None else self.policy_ps.data_ptr()), 'rg_sim_set_policy_table')
+            if policy == _abi.RG_POLICY_LOGREG_FROZEN:
+                # dict(coef_t (P, C) float64 = sklearn coef_.T, intercept (C,), classes (C,))
+                self.logreg = (
+                    torch.as_tensor(np.ascontiguousarray(logreg['coef_t'], dtype=np.float64)).to(self.device),
+                    torch.as_tensor(np.ascontiguousarray(logreg['intercept'], dtype=np.float64)).to(self.device),
+                    torch.as_tensor(np.ascontiguousarray(logreg['classes'], dtype=np.int32)).to(self.device))
+                assert self.logreg[0].shape == (config.num_products, self.logreg[2].numel())
+                _abi.check(self.lib.rg_sim_set_logreg(self._h, self.logreg[0].data_ptr(), self.logreg[1].data_ptr(),
+                                                      self.logreg[2].data_ptr(), self.logreg[2].numel()),
+                           'rg_sim_set_logreg')
             if log_capacity is None:
                 log_capacity = default_log_capacity(config, self.n_users)
             self.log = None

@@ -10,7 +10,8 @@ from recogym_amd.envs.configuration import Configuration
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 POLICY_OF = {None: _abi.RG_POLICY_UNIFORM_ENV, 'random': _abi.RG_POLICY_RANDOM_AGENT,
-             'ouc': _abi.RG_POLICY_ORGANIC_USER_COUNT, 'bmf': _abi.RG_POLICY_LAST_VIEW_TABLE}
+             'ouc': _abi.RG_POLICY_ORGANIC_USER_COUNT, 'bmf': _abi.RG_POLICY_LAST_VIEW_TABLE,
+             'logreg': _abi.RG_POLICY_LOGREG_FROZEN}
 
 OUC_DEFAULTS = dict(select_randomly=True, epsilon=0.0, exploit_explore=True, reverse_pop=False)
 
@@ -37,6 +38,11 @@ def policy_args(meta, cols=None):
         ag = LastViewTableAgent.from_bandit_mf(Configuration({'num_products': meta['env_args']['num_products']}),
                                                cols['bmf_product_embedding'], cols['bmf_user_embedding'])
         out.update(policy_seed=0, policy_table=ag.table, policy_ps=ag.ps)
+    if kind == 'logreg':
+        from recogym_amd.agents import LogregFrozenAgent
+        ag = LogregFrozenAgent(Configuration({'num_products': meta['env_args']['num_products']}),
+                               cols['logreg_coef'], cols['logreg_intercept'], cols['logreg_classes'])
+        out.update(policy_seed=0, **{k: v for k, v in ag.device_policy().items() if k == 'logreg'})
     if kind == 'ouc':
         out['ouc'] = {**OUC_DEFAULTS, **{k: v for k, v in aa.items() if k in OUC_DEFAULTS}}
     return out

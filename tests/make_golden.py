@@ -157,6 +157,53 @@ def notebook_goldens():
     assert same7 and same9
 
 
+def run_logreg_case(name, env_over, n_train, n_users):
+    """LogregMulticlassIpsAgent of the UNMODIFIED reference (agents/logreg_ips.py): trained by the
+    reference's own build() (train_data + sklearn fit) on a uniform-policy log of n_train users that the
+    reference generated, then run through generate_logs with the counter RNG injected into the env (the
+    agent itself draws nothing: select_randomly = False).  The fitted arrays travel with the fixture."""
+    rh.import_reference()
+    from recogym import Configuration
+    from recogym.agents import LogregMulticlassIpsAgent, logreg_multiclass_ips_args
+    args = {**BASE, **env_over}
+    train_env = rh.make_reference_env({**args, 'random_seed': args['random_seed'] + 1000})
+    train_log = train_env.generate_logs(n_train)
+    agent = LogregMulticlassIpsAgent(Configuration({**logreg_multiclass_ips_args,
+                                                    'num_products': args['num_products'],
+                                                    'random_seed': 7, 'select_randomly': False}))
+    d = agent.model_builder.data
+    for _, r in train_log.iterrows():                       # ModelBuilder.train's bookkeeping, row by row
+        bandit = r['z'] == 'bandit'
+        d['t'].append(int(r['t'])); d['u'].append(int(r['u'])); d['z'].append(r['z'])
+        d['v'].append(None if bandit else int(r['v']))
+        d['a'].append(int(r['a']) if bandit else None)
+        d['c'].append(int(r['c']) if bandit else None)
+        d['ps'].append(float(r['ps']) if bandit else None)
+    env = rh.make_reference_env(args)
+    rh.inject_counter_rng(env, None, None)
+    df = env.generate_logs(n_users, agent)                  # first act() builds the model
+    lr = agent.model.logreg
+    arrays = rh.log_to_arrays(df)
+    arrays['logreg_coef'] = np.asarray(lr.coef_, dtype=np.float64)
+    arrays['logreg_intercept'] = np.asarray(lr.intercept_, dtype=np.float64)
+    arrays['logreg_classes'] = np.asarray(lr.classes_, dtype=np.int64)
+    meta = dict(env_args=args, n_users=n_users, n_organic=0, agent='logreg',
+                agent_args=dict(n_train=n_train, clicks_in_training=int(np.nansum(train_log['c'].to_numpy(dtype=float)))),
+                rng='philox')
+    small = {}
+    for k, v in arrays.items():
+        if k in ('z', 'c'):
+            small[k] = v.astype(np.int8)
+        elif k == 'ps' or k.startswith('logreg_'):
+            small[k] = v
+        else:
+            small[k] = v.astype(np.int32)
+    path = os.path.join(GOLDEN, name + '.npz')
+    np.savez_compressed(path, meta=np.array(json.dumps(meta)), **small)
+    print(f'{name}: {len(arrays["t"])} rows, {len(lr.classes_)} classes, actions used '
+          f'{len(np.unique(arrays["a"][arrays["z"] == 1]))} -> {os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def train_feed_golden(fixture):
     """The training set the UNMODIFIED reference builds from a log: the rows of an
     existing fixture are pushed through ModelBuilder.train's bookkeeping (agents/abstract.py:55-83:
@@ -195,6 +242,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'train_feed':     # only the §8f-3 fixtures (fast)
         for fx in ('philox_ouc', 'mt_random_agent'):
             train_feed_golden(fx)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'logreg':         # only the §8f-1 LogReg fixture
+        run_logreg_case('philox_logreg', {'random_seed': 42, 'num_products': 30, 'K': 8}, 1500, 200)
         return
     notebook_goldens()
     S = dict(random_seed=42)
@@ -237,6 +287,7 @@ def main():
              agent_args=dict(torch_seed=3, embed_dim=5), injected=True)
     for fx in ('philox_ouc', 'mt_random_agent'):
         train_feed_golden(fx)
+    run_logreg_case('philox_logreg', {**S, 'num_products': 30, 'K': 8}, 1500, 200)
 
 
 if __name__ == '__main__':

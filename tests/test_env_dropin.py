@@ -53,6 +53,53 @@ def test_frozen_bandit_mf_agent_device_and_host_forms():
                                                 if k in ('t', 'u', 'z', 'v', 'a', 'c', 'ps')}, 1e-5)
 
 
+def test_frozen_logreg_agent_device_and_host_forms():
+    """LogregFrozenAgent carrying the model the reference's LogregMulticlassIpsAgent fitted: the
+    device policy reproduces the reference's log row for row (every action is an argmax over 30
+    class scores: the accumulation order is scipy's), and so does the per-user path with the
+    Python act."""
+    from recogym_amd.agents import LogregFrozenAgent
+    meta, want = gu.load('philox_logreg')
+    cfg = Configuration({'num_products': meta['env_args']['num_products'], 'with_ps_all': False})
+    agent = LogregFrozenAgent(cfg, want['logreg_coef'], want['logreg_intercept'], want['logreg_classes'])
+    env = make_env(meta['env_args'])
+    df = env.generate_logs(meta['n_users'], agent)
+    assert_frames_match(frame_to_cols(df), want, 1e-12)
+    df_seq = make_env(meta['env_args'])._generate_logs_per_user(15, agent, 0)
+    keep = want['u'] < 15
+    assert_frames_match(frame_to_cols(df_seq), {k: v[keep] for k, v in want.items()
+                                                if k in ('t', 'u', 'z', 'v', 'a', 'c', 'ps')}, 1e-12)
+
+
+def test_log_to_training_feed_to_sklearn_to_frozen_device_policy():
+    """The §8f chain end to end: a uniform-policy log from the device -> train_data_from_log ->
+    sklearn's LogisticRegression fitted like the reference's build() (weights = deltas / pss,
+    logreg_ips.py:89-99) -> LogregFrozenAgent in the device loop.  The new log equals the oracle's
+    with the same frozen model, and every logged action IS sklearn's predict() on the feature row
+    the feed rebuilds for it."""
+    import warnings
+    from sklearn.linear_model import LogisticRegression
+    from oracle import oracle as orc
+    from recogym_amd.agents import LogregFrozenAgent, train_data_from_log
+    over = {'random_seed': 3, 'num_products': 25, 'K': 6}
+    env = make_env(over)
+    log = env.generate_logs(800)
+    feats, actions, deltas, pss = train_data_from_log(log, 25)
+    assert deltas.sum() > 5
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        lr = LogisticRegression(solver='lbfgs', max_iter=5000, random_state=1).fit(feats, actions, deltas / pss)
+    cfg = Configuration({'num_products': 25, 'with_ps_all': False})
+    agent = LogregFrozenAgent.from_sklearn(cfg, lr)
+    df = make_env(over).generate_logs(300, agent)
+    pol = agent.device_policy()
+    want = orc.OracleEnv(Configuration({**recogym.env_1_args, **over}), rng_mode=orc.RNG_PHILOX,
+                         policy=pol['policy'], policy_seed=0, logreg=pol['logreg']).generate_logs(300)
+    assert_frames_match(frame_to_cols(df), {k: want[k] for k in ('t', 'u', 'z', 'v', 'a', 'c', 'ps')}, 1e-12)
+    f2, a2, _, _ = train_data_from_log(df, 25)
+    assert np.array_equal(lr.predict(f2), a2)
+
+
 def frame_to_cols(df):
     return {
         't': df['t'].values.astype(np.int64),

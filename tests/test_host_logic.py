@@ -196,3 +196,41 @@ def test_log_materialisation_paths_agree():
                     c=np.where(is_b, click.astype(np.float32), np.float32('nan')).astype(np.float32),
                     ps=np.where(is_b, ps, np.nan))
         pd.testing.assert_frame_equal(columns_to_dataframe(cols, P), want)
+
+
+def test_frozen_logreg_act_is_sklearn_predict():
+    """LogregFrozenAgent.act (the host form of RG_POLICY_LOGREG_FROZEN) on the model stored with the
+    reference's LogReg fixture: for random view-count vectors the action equals sklearn's own
+    predict() computed from the same arrays (decision_function of a CSR row: ascending products,
+    multiply then add, intercept last) — including the two-class form."""
+    import warnings
+    from scipy import sparse
+    from sklearn.linear_model import LogisticRegression
+    import golden_util as gu
+    from recogym_amd.agents import LogregFrozenAgent
+    from recogym_amd.envs.configuration import Configuration
+    from recogym_amd.envs.context import DefaultContext
+    from recogym_amd.envs.observation import Observation
+    from recogym_amd.envs.session import OrganicSessions
+    meta, cols = gu.load('philox_logreg')
+    P = meta['env_args']['num_products']
+    lr = LogisticRegression()
+    lr.coef_, lr.intercept_, lr.classes_ = cols['logreg_coef'], cols['logreg_intercept'], cols['logreg_classes']
+    rng = np.random.RandomState(5)
+    models = [lr]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        X = rng.poisson(0.3, size=(200, P)); y = (X[:, 0] + rng.rand(200) > 0.8).astype(int) * 7 + 3
+        models.append(LogisticRegression(max_iter=500).fit(X, y))          # two classes {3, 10}
+    for m in models:
+        agent = LogregFrozenAgent.from_sklearn(Configuration({'num_products': P}), m)
+        for trial in range(300):
+            agent.reset()
+            sessions = OrganicSessions()
+            counts = np.zeros(P, dtype=np.int16)
+            for t in range(rng.randint(0, 15)):
+                v = int(rng.randint(0, P))
+                sessions.next(DefaultContext(t, 0), v)
+                counts[v] += 1
+            a = agent.act(Observation(DefaultContext(99, 0), sessions), 0, False)
+            assert a['a'] == m.predict(sparse.csr_matrix(counts.reshape(1, P)))[0] and a['ps'] == 1.0
