@@ -60,8 +60,11 @@ def make_sim(workload, users, device, log_rows):
 
 
 def cpu_baseline(workload, seconds_target=12.0):
-    """The oracle (plain-C float64 port of the reference loop, one core) on a bounded sample of
-    the same workload.  Test infrastructure used as the reported CPU baseline only."""
+    """The oracle (plain-C float64 port of the reference loop) on a bounded sample of the same workload,
+    on ALL host cores: trajectories are keyed by (seed, user id), so every thread replays its own id
+    range with its own oracle instance (ctypes releases the GIL).  Test infrastructure used as the
+    reported CPU baseline only."""
+    import threading
     from oracle import oracle as orc
     from recogym_amd import _abi
     from recogym_amd.envs.configuration import Configuration
@@ -75,20 +78,34 @@ def cpu_baseline(workload, seconds_target=12.0):
                            reverse_pop=False))
     elif pol == 'random':
         kw = dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=42)
-    env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **kw)
-    users, events, elapsed = 0, 0, 0.0
-    batch = 50
-    while elapsed < seconds_target and users < 20000:
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    orc.lib()                                   # build / load once, before the threads start
+    results = [None] * cores
+
+    def work(k):
+        env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **kw)
+        first = 1_000_000 * k                   # disjoint id ranges
+        users, events, batch = 0, 0, 25
         t0 = time.perf_counter()
-        rows = env.generate_logs(batch, first_user_id=users, capacity=batch * 2000 + 10000)
-        elapsed += time.perf_counter() - t0
-        events += int((rows['phantom'] == 0).sum())
-        users += batch
-        if elapsed < 1.0:
-            batch = min(batch * 2, 2000)
-    return dict(value=events / elapsed, unit='events/s', cores=1, kind='port',
-                sample=f'{users} users / {events} events of the same workload in {elapsed:.1f} s '
-                       f'(oracle/recogym_oracle.c, float64, 1 thread)')
+        while time.perf_counter() - t0 < seconds_target and users < 20000:
+            rows = env.generate_logs(batch, first_user_id=first + users, capacity=batch * 2000 + 10000)
+            events += int((rows['phantom'] == 0).sum())
+            users += batch
+        results[k] = (users, events, time.perf_counter() - t0)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+    t0 = time.perf_counter()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    wall = time.perf_counter() - t0
+    users = sum(r[0] for r in results)
+    events = sum(r[1] for r in results)
+    return dict(value=events / wall, unit='events/s', cores=cores, kind='port',
+                per_core=events / wall / cores,
+                sample=f'{users} users / {events} events of the same workload in {wall:.1f} s on {cores} '
+                       f'threads (oracle/recogym_oracle.c, float64, one oracle instance per thread)')
 
 
 def main():
