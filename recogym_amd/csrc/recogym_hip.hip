@@ -2044,6 +2044,59 @@ draw_kernel_t bf16_kernel_for(const DevSim& d) {
     return nullptr;
 }
 
+// RG_POLICY_LOGREG_FROZEN for one user, computed by the whole wave: lane = class (c, c + 64, ...), so the
+// coef_t rows of the viewed products are read as coalesced 512-byte runs instead of one gather per
+// lane and class.  Same arithmetic as policy_act's scalar loop (per class: viewed products ascending,
+// multiply then add, intercept last); the wave reduction keeps the smallest class index among equal
+// maxima = numpy's first-maximum argmax.  `slot` must be wave-uniform.
+__device__ uint32_t logreg_act_wave(const DevSim& d, uint32_t slot, int lane) {
+    const uint32_t nd = d.hist_n[slot];
+    const uint32_t* hp = d.hist + static_cast<size_t>(slot) * d.hist_cap;
+    const uint16_t* hc = d.hist_cntv + static_cast<size_t>(slot) * d.hist_cap;
+    double best_s = -INFINITY;
+    uint32_t best_c = 0xFFFFFFFFu;
+    // four class blocks per pass and four history entries per batch: 16 independent loads in flight per
+    // lane (one load per term on a dependent chain left this latency-bound); per class the terms are
+    // still added in ascending product order
+    for (uint32_t c0 = 0; c0 < d.lr_n; c0 += 256) {
+        double sc[4] = {0.0, 0.0, 0.0, 0.0};
+        uint32_t cc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cc[q] = min(c0 + 64u * q + lane, d.lr_n - 1);     // clamped: masked below
+        for (uint32_t i0 = 0; i0 < nd; i0 += 4) {
+            double w[4][4], cnt[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t i = min(i0 + e, nd - 1);
+                cnt[e] = static_cast<double>(hc[i]);
+                const double* row = d.lr_coef_t + static_cast<size_t>(hp[i]) * d.lr_n;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[e][q] = row[cc[q]];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (i0 + e < nd) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sc[q] = __dadd_rn(sc[q], __dmul_rn(cnt[e], w[e][q]));
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t c = c0 + 64u * q + lane;
+            if (c < d.lr_n) {
+                const double v = __dadd_rn(sc[q], d.lr_intercept[c]);
+                if (best_c == 0xFFFFFFFFu || v > best_s) { best_s = v; best_c = c; }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double os = __shfl_xor(best_s, o);
+        const uint32_t oc = __shfl_xor(best_c, o);
+        if (oc != 0xFFFFFFFFu && (best_c == 0xFFFFFFFFu || os > best_s || (os == best_s && oc < best_c))) { best_s = os; best_c = oc; }
+    }
+    return static_cast<uint32_t>(d.lr_classes[best_c]);
+}
+
 // ------------------------------------------------------------------------------------------
 // k_advance — one Markov transition for every live user (lane per user).
 // ------------------------------------------------------------------------------------------
@@ -2073,6 +2126,20 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
         const uint32_t i = (it * kSub + sub) * kAdvBlock + threadIdx.x;
         int ns = RG_STATE_STOP;       // inactive lanes look dead
         uint32_t slot = 0;
+        uint32_t lr_a = 0;            // RG_POLICY_LOGREG_FROZEN: this user's action for its current view history
+        if (d.policy == RG_POLICY_LOGREG_FROZEN) {
+            // the policy reads only the history, which this kernel does not change: one act per live user serves
+            // its bandit event AND its phantom row.  Computed user by user by the whole wave (lane = class).
+            uint32_t my_slot = 0;
+            if (i < n) my_slot = i < n_o ? cur_o[i] : cur_b[i - n_o];
+            unsigned long long todo = __ballot(i < n);
+            while (todo) {
+                const int L = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint32_t a_L = logreg_act_wave(d, static_cast<uint32_t>(__shfl(static_cast<int>(my_slot), L)), lane);
+                if (lane == L) lr_a = a_L;
+            }
+        }
         if (i < n) {
             const bool is_org = i < n_o;
             slot = is_org ? cur_o[i] : cur_b[i - n_o];
@@ -2103,6 +2170,7 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                 double ps;
                 uint32_t a;
                 if (d.policy == RG_POLICY_EXTERNAL) { a = static_cast<uint32_t>(actions[uidx]); ps = __builtin_nan(""); }
+                else if (d.policy == RG_POLICY_LOGREG_FROZEN) { a = lr_a; ps = 1.0; }
                 else a = policy_act(d, slot, user, t, &ps);
                 // beta[a] . omega, k ascending (the oracle's association); loads are issued eight
                 // k at a time — a plain loop leaves one HBM round trip per k on the critical path
@@ -2165,8 +2233,8 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                 d.n_events[uidx] = t + 1;
                 if (d.policy != RG_POLICY_EXTERNAL) {
                     // final step_offline(done=True): one more act, reward 0 (abstract.py:223-233,311-316)
-                    double ps;
-                    const uint32_t a = policy_act(d, slot, user, t + 1, &ps);
+                    double ps = 1.0;
+                    const uint32_t a = d.policy == RG_POLICY_LOGREG_FROZEN ? lr_a : policy_act(d, slot, user, t + 1, &ps);
                     rg_event e;
                     e.u = user; e.t = t + 1; e.code = RG_EV_BANDIT | RG_EV_PHANTOM | a;
                     e.ps = static_cast<float>(ps);
@@ -2815,6 +2883,9 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
         // kernels sweep all P per step, so for them the tail kernel wins much earlier)
         const double tb = 4096.0 * ((scale < 1.0 && d.use_mfma == 2) ? scale : 1.0);
         s->tail_below = tb < 64.0 ? 64u : static_cast<uint32_t>(tb);
+        // the tail kernel runs a policy on one thread: fine for a history walk, not for n_classes x views
+        // score loops — the frozen LogReg policy stays in lock-step (wave-cooperative acts) to the end
+        if (d.policy == RG_POLICY_LOGREG_FROZEN) s->tail_below = 0;
     }
     s->prof_tail_ms = 0.0;
     if (const char* e = getenv("RECOGYM_TAIL")) s->tail_below = static_cast<uint32_t>(atoi(e));
