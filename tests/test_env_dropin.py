@@ -251,6 +251,34 @@ def test_test_agent_and_verify_agents_quantiles():
         recogym.test_agent(env, agents['random'], 0, 500, num_epochs=1)
 
 
+def test_verify_agents_with_the_two_frozen_model_policies():
+    """BASELINE config 4 in miniature: verify_agents A/B-tests a frozen BanditMFSquare table against a
+    frozen LogReg model, both inside the device loop; the quantiles are those of the oracle's
+    click counts for the same two policies."""
+    from oracle import oracle as orc
+    from recogym_amd.agents import LastViewTableAgent, LogregFrozenAgent
+    meta, w = gu.load('philox_logreg')
+    P = meta['env_args']['num_products']
+    env = make_env(meta['env_args'])
+    rng = np.random.RandomState(0)
+    cfgp = Configuration({'num_products': P, 'with_ps_all': False})
+    agents = {
+        'bandit-mf': LastViewTableAgent.from_bandit_mf(cfgp, rng.randn(P, 5), rng.randn(P, 5)),
+        'logreg-ips': LogregFrozenAgent(cfgp, w['logreg_coef'], w['logreg_intercept'], w['logreg_classes']),
+    }
+    n = 2000
+    df = recogym.verify_agents(env, n, agents)
+    cfg = Configuration({**recogym.env_1_args, **meta['env_args']})
+    for i, agent in enumerate(agents.values()):
+        pol = {k: v for k, v in agent.device_policy().items()}
+        o = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol)
+        o.generate_logs(n)
+        c = o.counters()
+        s_, f_ = c['clicks'], c['bandit'] + c['phantom'] - c['clicks']
+        assert df['0.500'][i] == beta.ppf(0.5, s_ + 1, f_ + 1)
+        assert df['0.975'][i] == beta.ppf(0.975, s_ + 1, f_ + 1)
+
+
 def test_training_feed_on_device_equals_host_feed():
     """SURVEY §8f-3 on the GPU: the torch feed over Simulator.log_columns_device() builds the same
     CSR training set as the host (numpy) feed, which is pinned against the reference's train_data."""
