@@ -288,6 +288,33 @@ def test_certified_draws_equal_float64_draws_at_scale(shape, monkeypatch):
     assert fast_chk == ref_chk
 
 
+@pytest.mark.parametrize('K', [2, 9, 11, 15, 16, 21, 22, 27, 32, 40, 65])
+def test_every_K_class_matches_the_oracle(K):
+    """One run per embedding-size class of the draw kernels (fp16 split: N1 = 1..4 with KH = 4 / 10 / 16;
+    bf16 split classes up to K = 32; fp32 MFMA beyond; float64 resolve classes KB = 1..16 and the tile
+    kernel for K > 64), default kernel selection, rows vs the oracle."""
+    from oracle import oracle as orc
+    cfg = Configuration({**env_1_args, 'random_seed': 500 + K, 'num_products': 333, 'K': K,
+                         'sigma_omega': 0.07})
+    want = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX).generate_logs(250)
+    rows, cnt = run_sim(cfg, 250)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps')},
+                         ps_rtol=1e-6, what=f'K={K}')
+    assert cnt['live'] == 0
+
+
+@pytest.mark.parametrize('P', [2, 31, 33, 127, 129, 255, 383, 513, 2049])
+def test_product_counts_around_tile_boundaries_match_the_oracle(P):
+    """P just below / above the 32-product chunk, the 128-product LDS tile, the 64-product float64
+    chunk and the super-chunk granularity, with the headline K = 20 kernel class."""
+    from oracle import oracle as orc
+    cfg = Configuration({**env_1_args, 'random_seed': 900 + P, 'num_products': P, 'K': 20})
+    want = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX).generate_logs(300)
+    rows, cnt = run_sim(cfg, 300)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps')},
+                         ps_rtol=1e-6, what=f'P={P}')
+
+
 def test_repack_and_tail_kernel_do_not_change_the_log_at_scale(monkeypatch):
     """300 000 users (above the 2^18 threshold where the state repack is on by default): the run with
     the repack every 16 steps and the per-user tail kernel must log the same rows as plain lock-step
