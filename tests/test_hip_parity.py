@@ -315,6 +315,23 @@ def test_product_counts_around_tile_boundaries_match_the_oracle(P):
                          ps_rtol=1e-6, what=f'P={P}')
 
 
+@pytest.mark.parametrize('mode', ['f16', 'bf16', 'fp32'])
+@pytest.mark.parametrize('sigma_mu', [30.0, 200.0])
+def test_wide_logit_range_re_references_and_still_matches_the_oracle(mode, sigma_mu, monkeypatch):
+    """mu_organic spread over hundreds of nats: the running reference of the MFMA kernels has to be
+    re-based inside a product sweep (logits far above the first chunk's maximum), exp2 saturates on
+    the way, and with sigma_mu = 200 whole super-chunks underflow — whatever the fast path makes of
+    it, the certificate must only let float64-identical indices through."""
+    from oracle import oracle as orc
+    monkeypatch.setenv('RECOGYM_DRAW', mode)
+    cfg = Configuration({**env_1_args, 'random_seed': 77, 'num_products': 3000, 'K': 20,
+                         'sigma_mu_organic': sigma_mu})
+    want = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX).generate_logs(400)
+    rows, cnt = run_sim(cfg, 400)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps')},
+                         ps_rtol=1e-6, what=f'{mode} sigma_mu={sigma_mu}')
+
+
 def test_repack_and_tail_kernel_do_not_change_the_log_at_scale(monkeypatch):
     """300 000 users (above the 2^18 threshold where the state repack is on by default): the run with
     the repack every 16 steps and the per-user tail kernel must log the same rows as plain lock-step
