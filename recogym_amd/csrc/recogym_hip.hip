@@ -3,15 +3,23 @@
 // What runs here (reference file:line each kernel takes over; see DESIGN.md for the data layout
 // and the roofline of each kernel):
 //
-//   k_reset_users    RecoEnv1.reset / AbstractEnv.reset          reco_env_v1.py:78-82, abstract.py:90-103
-//   k_exact_sums/pick RecoEnv1.update_product_view (float64)     reco_env_v1.py:119-128
-//   k_draw_mfma      RecoEnv1.update_product_view (fp32 MFMA fast path with a certified margin;
-//                    draws it cannot certify are handed to k_draw_exact)
-//   k_advance        AbstractEnv.step / step_offline, RecoEnv1.draw_click / update_state, the
-//                    policy's act and the log rows of generate_logs
-//                                                                abstract.py:123-239,267-316
-//                                                                reco_env_v1.py:85-116
-//   k_sort_*         row order of generate_logs' DataFrame       abstract.py:299-327
+//   k_reset_users     RecoEnv1.reset / AbstractEnv.reset          reco_env_v1.py:78-82, abstract.py:90-103
+//   k_draw_bf16p      RecoEnv1.update_product_view                reco_env_v1.py:119-128
+//                     the default: logits on the 16-bit matrix pipe as a two-way fp16 (or three-way
+//                     bf16) split of the fp32 operands, pipelined pairs of chunks, every index
+//                     certified against float64 (search_and_emit); k_draw_bf16 = its
+//                     one-accumulator form, k_draw_mfma = fp32 MFMA (K classes without a 16-bit
+//                     instantiation), k_draw_search = the search of the product-sliced form
+//   k_exact_sums_u / k_exact_pick (k_exact_sums: K > 64)
+//                     the same draw in float64 for the draws the fast path cannot certify
+//   k_advance         AbstractEnv.step / step_offline, RecoEnv1.draw_click / update_state, the
+//                     policy's act (policy_act / logreg_act_wave) and the log rows of generate_logs
+//                                                                 abstract.py:123-239,267-316
+//                                                                 reco_env_v1.py:85-116
+//   k_tail            all of the above for the last users of a run, one user per workgroup
+//   k_repack_*        no reference counterpart: restores the locality of the per-user state
+//   k_rows_per_user, k_scan_*, k_scatter_*
+//                     row order of generate_logs' DataFrame       abstract.py:299-327
 //
 // Lock-step structure: every live user advances exactly one Markov transition per step, so the
 // step index IS the per-user event time t (DefaultTimeGenerator).  Users that are in the
