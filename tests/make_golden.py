@@ -157,7 +157,7 @@ def notebook_goldens():
     assert same7 and same9
 
 
-def run_logreg_case(name, env_over, n_train, n_users):
+def run_logreg_case(name, env_over, n_train, n_users, injected=True):
     """LogregMulticlassIpsAgent of the UNMODIFIED reference (agents/logreg_ips.py): trained by the
     reference's own build() (train_data + sklearn fit) on a uniform-policy log of n_train users that the
     reference generated, then run through generate_logs with the counter RNG injected into the env (the
@@ -180,7 +180,8 @@ def run_logreg_case(name, env_over, n_train, n_users):
         d['c'].append(int(r['c']) if bandit else None)
         d['ps'].append(float(r['ps']) if bandit else None)
     env = rh.make_reference_env(args)
-    rh.inject_counter_rng(env, None, None)
+    if injected:
+        rh.inject_counter_rng(env, None, None)              # else: the reference exactly as shipped (MT19937)
     df = env.generate_logs(n_users, agent)                  # first act() builds the model
     lr = agent.model.logreg
     arrays = rh.log_to_arrays(df)
@@ -189,7 +190,7 @@ def run_logreg_case(name, env_over, n_train, n_users):
     arrays['logreg_classes'] = np.asarray(lr.classes_, dtype=np.int64)
     meta = dict(env_args=args, n_users=n_users, n_organic=0, agent='logreg',
                 agent_args=dict(n_train=n_train, clicks_in_training=int(np.nansum(train_log['c'].to_numpy(dtype=float)))),
-                rng='philox')
+                rng='philox' if injected else 'mt')
     small = {}
     for k, v in arrays.items():
         if k in ('z', 'c'):
@@ -245,6 +246,7 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'logreg':         # only the §8f-1 LogReg fixture
         run_logreg_case('philox_logreg', {'random_seed': 42, 'num_products': 30, 'K': 8}, 1500, 200)
+        run_logreg_case('mt_logreg', {'random_seed': 42, 'num_products': 30, 'K': 8}, 1500, 120, injected=False)
         return
     notebook_goldens()
     S = dict(random_seed=42)
@@ -288,6 +290,7 @@ def main():
     for fx in ('philox_ouc', 'mt_random_agent'):
         train_feed_golden(fx)
     run_logreg_case('philox_logreg', {**S, 'num_products': 30, 'K': 8}, 1500, 200)
+    run_logreg_case('mt_logreg', {**S, 'num_products': 30, 'K': 8}, 1500, 120, injected=False)
 
 
 if __name__ == '__main__':
