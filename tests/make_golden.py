@@ -244,6 +244,10 @@ def main():
         for fx in ('philox_ouc', 'mt_random_agent'):
             train_feed_golden(fx)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'mt_bmf':
+        run_case('mt_bandit_mf', {'random_seed': 42, 'num_products': 40, 'K': 10}, 120, agent_kind='bmf',
+                 agent_args=dict(torch_seed=3, embed_dim=5))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'logreg':         # only the §8f-1 LogReg fixture
         run_logreg_case('philox_logreg', {'random_seed': 42, 'num_products': 30, 'K': 8}, 1500, 200)
         run_logreg_case('mt_logreg', {'random_seed': 42, 'num_products': 30, 'K': 8}, 1500, 120, injected=False)
@@ -267,6 +271,8 @@ def main():
     run_case('mt_flips_normbeta', {**S, 'num_products': 30, 'number_of_flips': 5,
                                    'normalize_beta': True}, 150)
     run_case('mt_change_omega', {**S, 'change_omega_for_bandits': True}, 150)
+    run_case('mt_bandit_mf', {**S, 'num_products': 40, 'K': 10}, 120, agent_kind='bmf',
+             agent_args=dict(torch_seed=3, embed_dim=5))
     # --- reference arithmetic + injected counter RNG ---
     run_case('philox_p10', {**S}, 300, n_organic=10, injected=True)
     run_case('philox_p10_sigma0', {**S, 'sigma_omega': 0.0}, 300, injected=True)
