@@ -279,6 +279,21 @@ def test_verify_agents_with_the_two_frozen_model_policies():
         assert df['0.975'][i] == beta.ppf(0.975, s_ + 1, f_ + 1)
 
 
+def test_test_agent_trains_logreg_from_a_device_log_like_the_per_user_protocol(monkeypatch):
+    """test_agent with the trainable LogregMulticlassIpsAgent: the fast path (offline log produced on the
+    device in one go, vectorised training feed) returns the same CTR quantiles as the reference's
+    per-user offline protocol (env.reset / step_offline / agent.train for every user), because both
+    show the agent the same rows and the fit is deterministic."""
+    from recogym_amd import bench_agents
+    from recogym_amd.agents import LogregMulticlassIpsAgent, logreg_multiclass_ips_args
+    over = {'random_seed': 11, 'num_products': 12, 'K': 5}
+    cfg = Configuration({**logreg_multiclass_ips_args, 'num_products': 12, 'random_seed': 4, 'max_iter': 400})
+    fast = recogym.test_agent(make_env(over), LogregMulticlassIpsAgent(cfg), 250, 1500)
+    monkeypatch.delattr(LogregMulticlassIpsAgent, 'train_from_log')      # -> bench_agents._train, row by row
+    slow = recogym.test_agent(make_env(over), LogregMulticlassIpsAgent(cfg), 250, 1500)
+    assert fast == slow and 0.0 < fast[1] < fast[0] < fast[2] < 0.1
+
+
 def test_training_feed_on_device_equals_host_feed():
     """SURVEY §8f-3 on the GPU: the torch feed over Simulator.log_columns_device() builds the same
     CSR training set as the host (numpy) feed, which is pinned against the reference's train_data."""

@@ -86,3 +86,35 @@ def test_edge_cases_against_the_row_by_row_loop(seed):
         np.testing.assert_array_equal(pss, want[3])
         dense = train_data_from_log(log, P, is_sparse=False)[0]
         assert dense.dtype == np.float64 and np.array_equal(dense, want[0])
+
+
+def test_trainable_logreg_agent_row_by_row_equals_whole_log():
+    """recogym_amd.agents.LogregMulticlassIpsAgent: feeding a log through train() observation by
+    observation (the reference's offline protocol) and handing the same log to train_from_log()
+    give the same training set, hence the same sklearn fit, bit for bit."""
+    from recogym_amd.agents import LogregMulticlassIpsAgent, logreg_multiclass_ips_args
+    from recogym_amd.envs.configuration import Configuration
+    from recogym_amd.envs.context import DefaultContext
+    from recogym_amd.envs.observation import Observation
+    from recogym_amd.envs.session import OrganicSessions
+    meta, cols = gu.load('philox_ouc')
+    keep = cols['u'] < 60
+    cols = {k: v[keep] for k, v in cols.items()}
+    P = meta['env_args']['num_products']
+    cfg = Configuration({**logreg_multiclass_ips_args, 'num_products': P, 'random_seed': 3, 'max_iter': 300})
+    slow, fast = LogregMulticlassIpsAgent(cfg), LogregMulticlassIpsAgent(cfg)
+    sessions, cur = OrganicSessions(), None
+    for i in range(len(cols['u'])):
+        u, t = int(cols['u'][i]), int(cols['t'][i])
+        if u != cur:
+            cur, sessions = u, OrganicSessions()
+        if cols['z'][i] == 0:
+            sessions.next(DefaultContext(t, u), int(cols['v'][i]))
+        else:
+            action = {'t': t, 'u': u, 'a': int(cols['a'][i]), 'ps': float(cols['ps'][i]), 'ps-a': ()}
+            slow.train(Observation(DefaultContext(t, u), sessions), action, int(cols['c'][i]), False)
+            sessions = OrganicSessions()
+    fast.train_from_log(log_columns_of(cols))
+    a, b = slow.build(), fast.build()
+    assert np.array_equal(a.coef_t, b.coef_t) and np.array_equal(a.intercept, b.intercept)
+    assert np.array_equal(a.classes, b.classes) and a.coef_t.shape[1] == len(a.classes) > 2
