@@ -5,3 +5,4 @@ from .last_view_table import LastViewTableAgent
 from .logreg_frozen import LogregFrozenAgent
 from .logreg_ips import LogregMulticlassIpsAgent, logreg_multiclass_ips_args
 from .feature_feed import train_data_from_log
+from .bandit_mf import BanditMFSquareAgent, bandit_mf_square_args

@@ -57,7 +57,7 @@ class LogregMulticlassIpsAgent(Agent):
             r['u'].append(action['u']); r['is_bandit'].append(True); r['v'].append(0)
             r['a'].append(action['a']); r['c'].append(reward); r['ps'].append(action['ps'])
 
-    def train_from_log(self, log):
+    def train_from_log(self, log, num_organic_users=0):
         """A whole log (DataFrame of generate_logs or Simulator.log_columns()) instead of row-by-row train calls."""
         self._log = log
 

@@ -83,7 +83,7 @@ def test_agent(env, agent, num_offline_users=1000, num_online_users=100,
             # the offline protocol shows the agent exactly the rows of generate_logs(offline users) under the
             # env's own uniform policy (bench_agents.py:168-190): produce that log on the device in one go
             cnt, sim = train_env.simulate(num_offline_users, None, num_organic_offline_users)
-            new_agent.train_from_log(sim.log_columns())
+            new_agent.train_from_log(sim.log_columns(), num_organic_offline_users)
             sim.close()
         elif _learns(new_agent) and (getattr(new_agent, 'needs_training', False) or device_policy_of(new_agent) is None):
             _train(train_env, new_agent, num_offline_users, num_organic_offline_users)

@@ -205,6 +205,41 @@ def run_logreg_case(name, env_over, n_train, n_users, injected=True):
           f'{len(np.unique(arrays["a"][arrays["z"] == 1]))} -> {os.path.getsize(path) / 1024:.0f} KiB')
 
 
+def bandit_mf_training_golden(fixture):
+    """BanditMFSquare of the UNMODIFIED reference (agents/bandit_mf.py) trained on an existing fixture log
+    through its own train(): one call per bandit row with the observation that preceded it (what the
+    offline protocol of bench_agents.py:168-190 does).  Stores the initial and the trained embeddings."""
+    rh.import_reference()
+    import torch
+    from recogym import Configuration, Observation, DefaultContext
+    from recogym.envs.session import OrganicSessions
+    from recogym.agents import BanditMFSquare, bandit_mf_square_args
+    f = np.load(os.path.join(GOLDEN, fixture + '.npz'), allow_pickle=False)
+    meta = json.loads(str(f['meta']))
+    P = meta['env_args']['num_products']
+    torch.manual_seed(5)
+    agent = BanditMFSquare(Configuration({**bandit_mf_square_args, 'num_products': P}))
+    init_p = agent.product_embedding.weight.detach().numpy().copy()
+    init_u = agent.user_embedding.weight.detach().numpy().copy()
+    sessions, cur = OrganicSessions(), None
+    for i in range(len(f['t'])):
+        u, t = int(f['u'][i]), int(f['t'][i])
+        if u != cur:
+            cur, sessions = u, OrganicSessions()
+        if int(f['z'][i]) == 0:
+            sessions.next(DefaultContext(t, u), int(f['v'][i]))
+        else:
+            action = {'t': t, 'u': u, 'a': int(f['a'][i]), 'ps': float(f['ps'][i]), 'ps-a': ()}
+            agent.train(Observation(DefaultContext(t, u), sessions), action, int(f['c'][i]), False)
+            sessions = OrganicSessions()
+    path = os.path.join(GOLDEN, 'bandit_mf_training_' + fixture + '.npz')
+    np.savez_compressed(path, init_product=init_p, init_user=init_u,
+                        product=agent.product_embedding.weight.detach().numpy(),
+                        user=agent.user_embedding.weight.detach().numpy(),
+                        steps=np.array(agent.curr_step))
+    print(f'bandit_mf_training_{fixture}: {agent.curr_step} train calls -> {os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def train_feed_golden(fixture):
     """The training set the UNMODIFIED reference builds from a log: the rows of an
     existing fixture are pushed through ModelBuilder.train's bookkeeping (agents/abstract.py:55-83:
@@ -243,6 +278,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'train_feed':     # only the §8f-3 fixtures (fast)
         for fx in ('philox_ouc', 'mt_random_agent'):
             train_feed_golden(fx)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'bmf_training':
+        bandit_mf_training_golden('mt_random_agent')
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'mt_bmf':
         run_case('mt_bandit_mf', {'random_seed': 42, 'num_products': 40, 'K': 10}, 120, agent_kind='bmf',
@@ -297,6 +335,7 @@ def main():
         train_feed_golden(fx)
     run_logreg_case('philox_logreg', {**S, 'num_products': 30, 'K': 8}, 1500, 200)
     run_logreg_case('mt_logreg', {**S, 'num_products': 30, 'K': 8}, 1500, 120, injected=False)
+    bandit_mf_training_golden('mt_random_agent')
 
 
 if __name__ == '__main__':

@@ -294,6 +294,22 @@ def test_test_agent_trains_logreg_from_a_device_log_like_the_per_user_protocol(m
     assert fast == slow and 0.0 < fast[1] < fast[0] < fast[2] < 0.1
 
 
+def test_test_agent_trains_bandit_mf_from_a_device_log_like_the_per_user_protocol(monkeypatch):
+    """Same for the trainable BanditMFSquareAgent (torch RMSprop on mini-batches): log-fed training from a
+    device-generated offline log == the per-user agent.train protocol, so test_agent returns the same
+    quantiles either way."""
+    import torch
+    from recogym_amd.agents import BanditMFSquareAgent, bandit_mf_square_args
+    over = {'random_seed': 21, 'num_products': 15, 'K': 5}
+    cfg = Configuration({**bandit_mf_square_args, 'num_products': 15})
+    rng = np.random.RandomState(1)
+    ip, iu = rng.randn(15, 5).astype(np.float32), rng.randn(15, 5).astype(np.float32)
+    fast = recogym.test_agent(make_env(over), BanditMFSquareAgent(cfg, ip, iu), 200, 1500, num_organic_offline_users=10)
+    monkeypatch.delattr(BanditMFSquareAgent, 'train_from_log')
+    slow = recogym.test_agent(make_env(over), BanditMFSquareAgent(cfg, ip, iu), 200, 1500, num_organic_offline_users=10)
+    assert fast == slow and 0.0 < fast[0] < 0.1
+
+
 def test_training_feed_on_device_equals_host_feed():
     """SURVEY §8f-3 on the GPU: the torch feed over Simulator.log_columns_device() builds the same
     CSR training set as the host (numpy) feed, which is pinned against the reference's train_data."""

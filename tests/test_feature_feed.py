@@ -118,3 +118,80 @@ def test_trainable_logreg_agent_row_by_row_equals_whole_log():
     a, b = slow.build(), fast.build()
     assert np.array_equal(a.coef_t, b.coef_t) and np.array_equal(a.intercept, b.intercept)
     assert np.array_equal(a.classes, b.classes) and a.coef_t.shape[1] == len(a.classes) > 2
+
+
+def _bmf_training_case():
+    import os
+    meta, cols = gu.load('mt_random_agent')
+    g = np.load(os.path.join(GOLDEN, 'bandit_mf_training_mt_random_agent.npz'))
+    return meta, cols, g
+
+
+def test_bandit_mf_training_from_a_log_equals_the_reference_training():
+    """recogym_amd.agents.BanditMFSquareAgent.train_from_log on the fixture log, starting from the
+    reference agent's initial embeddings, ends at the embeddings the UNMODIFIED reference reached
+    through its own train() calls (490 RMSprop steps; float32 torch arithmetic on the CPU: compared to
+    1e-6, exact on the machine that made the fixture), and so does the call-by-call train()."""
+    from recogym_amd.agents import BanditMFSquareAgent, bandit_mf_square_args
+    from recogym_amd.envs.configuration import Configuration
+    from recogym_amd.envs.context import DefaultContext
+    from recogym_amd.envs.observation import Observation
+    from recogym_amd.envs.session import OrganicSessions
+    meta, cols, g = _bmf_training_case()
+    cfg = Configuration({**bandit_mf_square_args, 'num_products': meta['env_args']['num_products']})
+    fast = BanditMFSquareAgent(cfg, g['init_product'], g['init_user'])
+    fast.train_from_log(log_columns_of(cols))
+    assert fast.curr_step == int(g['steps'])
+    np.testing.assert_allclose(fast.product_embedding.weight.detach().numpy(), g['product'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(fast.user_embedding.weight.detach().numpy(), g['user'], rtol=1e-6, atol=1e-7)
+    slow = BanditMFSquareAgent(cfg, g['init_product'], g['init_user'])
+    sessions, cur = OrganicSessions(), None
+    for i in range(len(cols['u'])):
+        u, t = int(cols['u'][i]), int(cols['t'][i])
+        if u != cur:
+            cur, sessions = u, OrganicSessions()
+        if cols['z'][i] == 0:
+            sessions.next(DefaultContext(t, u), int(cols['v'][i]))
+        else:
+            slow.train(Observation(DefaultContext(t, u), sessions),
+                       {'t': t, 'u': u, 'a': int(cols['a'][i]), 'ps': float(cols['ps'][i]), 'ps-a': ()},
+                       int(cols['c'][i]), False)
+            sessions = OrganicSessions()
+    assert np.array_equal(slow.product_embedding.weight.detach().numpy(), fast.product_embedding.weight.detach().numpy())
+    assert np.array_equal(slow.user_embedding.weight.detach().numpy(), fast.user_embedding.weight.detach().numpy())
+    # and the frozen policy both produce is the same table
+    assert np.array_equal(slow.frozen().table, fast.frozen().table)
+
+
+def test_bandit_mf_training_with_organic_only_users():
+    """The offline protocol calls train once (no action) for every organic-only warm-up user; those calls
+    count towards the mini-batch clock.  Log-fed training reproduces that."""
+    from recogym_amd.agents import BanditMFSquareAgent, bandit_mf_square_args
+    from recogym_amd.envs.configuration import Configuration
+    from recogym_amd.envs.context import DefaultContext
+    from recogym_amd.envs.observation import Observation
+    from recogym_amd.envs.session import OrganicSessions
+    meta, cols = gu.load('mt_drift_organic_users')
+    P, n_org = meta['env_args']['num_products'], meta['n_organic']
+    cfg = Configuration({**bandit_mf_square_args, 'num_products': P})
+    rng = np.random.RandomState(0)
+    ip, iu = rng.randn(P, 5).astype(np.float32), rng.randn(P, 5).astype(np.float32)
+    fast = BanditMFSquareAgent(cfg, ip, iu)
+    fast.train_from_log(log_columns_of(cols), n_org)
+    slow = BanditMFSquareAgent(cfg, ip, iu)
+    for uid in np.unique(cols['u']):
+        sessions = OrganicSessions()
+        for i in np.flatnonzero(cols['u'] == uid):
+            t = int(cols['t'][i])
+            if cols['z'][i] == 0:
+                sessions.next(DefaultContext(t, int(uid)), int(cols['v'][i]))
+            else:
+                slow.train(Observation(DefaultContext(t, int(uid)), sessions),
+                           {'t': t, 'u': int(uid), 'a': int(cols['a'][i]), 'ps': float(cols['ps'][i]), 'ps-a': ()},
+                           int(cols['c'][i]), False)
+                sessions = OrganicSessions()
+        if uid < n_org:
+            slow.train(Observation(DefaultContext(0, int(uid)), sessions), None, None, True)
+    assert slow.curr_step == fast.curr_step > 0
+    assert np.array_equal(slow.product_embedding.weight.detach().numpy(), fast.product_embedding.weight.detach().numpy())
+    assert np.array_equal(slow.user_embedding.weight.detach().numpy(), fast.user_embedding.weight.detach().numpy())
