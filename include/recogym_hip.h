@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION 1
+#define RG_ABI_VERSION 2
 
 /* error codes */
 #define RG_OK 0
@@ -115,7 +115,9 @@ typedef struct rg_event {
 #define RG_CNT_LOG_DROPPED 7    /* rows that did not fit (capacity exceeded) */
 #define RG_CNT_EXACT_DRAWS 8    /* organic draws resolved by the float64 path */
 #define RG_CNT_HIST_OVERFLOW 9  /* OrganicUserEventCounter views that did not fit ouc_history_cap */
-#define RG_CNT_N 16
+#define RG_CNT_EXACT_SWEEPS 10  /* float64 product sweeps those draws needed (== EXACT_DRAWS unless sigma_omega = 0,
+                                   where a user's float64 sums are taken once and reused) */
+#define RG_CNT_N 24             /* out[] of rg_sim_read_counters; slots past the named ones are internal */
 
 typedef struct rg_sim rg_sim;
 
@@ -158,6 +160,13 @@ int rg_sim_set_logreg(rg_sim* sim, const double* d_coef_t, const double* d_inter
 
 /* Where rows go.  d_log == NULL (or capacity 0) disables logging: only counters are kept. */
 int rg_sim_set_log(rg_sim* sim, rg_event* d_log, uint64_t capacity);
+
+/* Optional float64 side arrays of the log, `capacity` (of rg_sim_set_log) doubles each, caller-owned device
+ * memory; either may be NULL.  d_ps[row] receives the propensity of bandit row `row` in float64 — the dtype of
+ * the reference's `ps` column (abstract.py:283-290,318-327; IPS estimators divide by it) — and d_p_click[row]
+ * the click probability ff(beta[a].omega + mu_bandit[a]) the click of that row was drawn with
+ * (reco_env_v1.py:104-116).  Entries of organic rows are not written.  rg_sim_set_log detaches them. */
+int rg_sim_set_log_aux(rg_sim* sim, double* d_ps, double* d_p_click);
 
 /* RecoEnv1.reset + AbstractEnv.reset (reco_env_v1.py:78-82, abstract.py:90-103) for `n` users
  * with ids first_user_id .. first_user_id+n-1 at once: state <- organic, t <- 0,
@@ -212,6 +221,21 @@ int rg_sim_export_omega(rg_sim* sim, double* d_omega, void* stream);
  * log buffer overflowed. */
 int rg_sim_sort_log(rg_sim* sim, int64_t* d_row_offsets, int64_t* d_scratch, rg_event* d_sorted,
                     uint64_t sorted_capacity, void* stream);
+
+/* The side arrays of rg_sim_set_log_aux in the row order rg_sim_sort_log produced (`d_row_offsets` as filled
+ * by it): NaN on organic rows, and for p_click on the phantom row (never drawn).  Either output may be NULL. */
+int rg_sim_sort_log_aux(rg_sim* sim, const int64_t* d_row_offsets, double* d_sorted_ps,
+                        double* d_sorted_p_click, uint64_t sorted_capacity, void* stream);
+
+/* ---- test hooks (the parity suite's adversarial certificate test; not part of the reference surface) ----
+ * rg_sim_debug_set_omega: overwrite omega of the reset range, (n, K) float64 user-major, right after
+ * rg_sim_reset_users.  rg_sim_debug_set_uniforms: d_u[i] replaces the uniform of user index i's next organic
+ * product draws (NULL restores the addressed draws).  rg_sim_debug_uncertified: d_flags[i] = 1 iff user
+ * index i's organic draw of the LAST step was not certified by the matrix-core kernel and went to the
+ * float64 resolve (n bytes). */
+int rg_sim_debug_set_omega(rg_sim* sim, const double* d_omega, void* stream);
+int rg_sim_debug_set_uniforms(rg_sim* sim, const double* d_u);
+int rg_sim_debug_uncertified(rg_sim* sim, uint8_t* d_flags, void* stream);
 
 #ifdef __cplusplus
 }

@@ -168,6 +168,7 @@ typedef struct rgo_env {
     /* scratch */
     double* buf;              /* (P) */
     double* zbuf;             /* (K) */
+    double* cdfbuf;           /* (P) scratch of icdf_right */
     int64_t counters[4];      /* organic, bandit (real), clicks, phantom */
 } rgo_env;
 
@@ -182,6 +183,7 @@ rgo_env* rgo_env_create(const rg_config* cfg, int rng_mode, const double* gamma,
     e->views = (int32_t*)calloc(cfg->num_products, sizeof(int32_t));
     e->buf = (double*)calloc(cfg->num_products, sizeof(double));
     e->zbuf = (double*)calloc(cfg->K, sizeof(double));
+    e->cdfbuf = (double*)calloc(cfg->num_products, sizeof(double));   /* per-instance scratch: no malloc per draw */
     e->state = RG_STATE_ORGANIC;
     e->first_step = 1;
     /* init_gym: reset_random_seed (abstract.py:88); agents seed their own RandomState at
@@ -193,7 +195,7 @@ rgo_env* rgo_env_create(const rg_config* cfg, int rng_mode, const double* gamma,
 
 void rgo_env_destroy(rgo_env* e) {
     if (!e) return;
-    free(e->omega); free(e->views); free(e->buf); free(e->zbuf); free(e);
+    free(e->omega); free(e->views); free(e->buf); free(e->zbuf); free(e->cdfbuf); free(e);
 }
 
 /* LogregMulticlassIpsAgent with a fitted model (agents/logreg_ips.py:60-87, select_randomly = False) */
@@ -285,9 +287,7 @@ static int32_t update_product_view(rgo_env* e) {
     for (uint32_t p = 0; p < P; ++p) { l[p] = exp(l[p] - mx); s += l[p]; }
     for (uint32_t p = 0; p < P; ++p) l[p] = l[p] / s;
     const double u = draw_event_uniform(e, e->time, 0);
-    double* cdf = (double*)malloc(sizeof(double) * P);
-    const uint32_t v = icdf_right(l, P, u, cdf);
-    free(cdf);
+    const uint32_t v = icdf_right(l, P, u, e->cdfbuf);
     return (int32_t)v;
 }
 
@@ -461,9 +461,7 @@ int32_t rgo_env_policy_act(rgo_env* e, double* ps_out) {
     if (e->cfg.ouc_select_randomly) {
         const double u1 = (e->rng_mode == RGO_RNG_MT) ? mt_double(&e->pol_mt)
                                                      : rg_uniform(w.w[2], w.w[3]);
-        double* cdf = (double*)malloc(sizeof(double) * P);
-        const uint32_t a = icdf_right(f, P, u1, cdf);
-        free(cdf);
+        const uint32_t a = icdf_right(f, P, u1, e->cdfbuf);
         if (e->cfg.ouc_exploit_explore)
             *ps_out = (is_explore ? eps : 1.0 - eps) * f[a];
         else

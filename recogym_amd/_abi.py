@@ -7,7 +7,7 @@ infrastructure and is never imported from this package.)
 import ctypes as C
 import os
 
-RG_ABI_VERSION = 1
+RG_ABI_VERSION = 2
 
 RG_STATE_ORGANIC, RG_STATE_BANDIT, RG_STATE_STOP = 0, 1, 2
 
@@ -24,8 +24,9 @@ RG_EV_PHANTOM = 0x20000000
 RG_EV_INDEX_MASK = 0x1FFFFFFF
 
 (RG_CNT_ORGANIC, RG_CNT_BANDIT, RG_CNT_CLICKS, RG_CNT_PHANTOM, RG_CNT_LIVE, RG_CNT_STEP,
- RG_CNT_LOG_ROWS, RG_CNT_LOG_DROPPED, RG_CNT_EXACT_DRAWS, RG_CNT_HIST_OVERFLOW) = range(10)
-RG_CNT_N = 16
+ RG_CNT_LOG_ROWS, RG_CNT_LOG_DROPPED, RG_CNT_EXACT_DRAWS, RG_CNT_HIST_OVERFLOW,
+ RG_CNT_EXACT_SWEEPS) = range(11)
+RG_CNT_N = 24
 
 RG_ERRORS = {-1: 'RG_EINVAL', -2: 'RG_ENODEV', -3: 'RG_ENOMEM', -4: 'RG_ESTATE', -5: 'RG_ELIMIT'}
 
@@ -81,6 +82,12 @@ SYMBOLS = {
     'rg_sim_export_omega': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_sort_log': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                   C.c_void_p]),
+    'rg_sim_set_log_aux': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
+    'rg_sim_sort_log_aux': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                      C.c_void_p]),
+    'rg_sim_debug_set_omega': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
+    'rg_sim_debug_set_uniforms': (C.c_int, [_SIM, C.c_void_p]),
+    'rg_sim_debug_uncertified': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
 }
 
 LIB_NAME = 'librecogym_hip.so'

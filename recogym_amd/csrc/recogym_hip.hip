@@ -119,6 +119,17 @@ struct DevSim {
     unsigned short* gsplit;   // [P_pad][RS/2] bf16 three-way split of fl32(Gamma log2 e), then 1,1,1 in the last 3 columns of 16*N1
     float* mu32s;             // [P_pad] fl32(mu_o log2 e), -inf beyond P
     uint32_t ablate;          // timing experiments only (RECOGYM_ABLATE); results are wrong when non-zero
+    // sigma_omega == 0: a user's omega — hence its softmax — never changes after the reset, so the exp-sums of its
+    // first product sweep (step 0: every user starts organic) are kept PER USER (index = user index, never moved by
+    // the repack; row n_cap is a dummy that inactive lanes write) and every later draw of that user is only the
+    // search over them (k_draw_search), with the same certificate and the same float64 resolve
+    uint32_t use_cache;
+    float2* cache_rec;        // [n_cap + 1][kMaxSC] {sum, reference} of every super-chunk
+    float* cache_chunk;       // [n_cap + 1][n_chunks] exp-sum of every 32-product chunk
+    uint8_t* cache_resc;      // [n_cap + 1] re-references of the sweep (certificate budget)
+    uint8_t* f64_valid;       // [n_cap] exact_sums / exact_ref rows (indexed by user index in this mode) are valid
+    uint32_t* exact_cnt_b;    // [kMaxSteps+2] draws to resolve whose float64 sums are already there: they sit at the
+                              // BACK of exact_list (entry n_cap - 1 - i); those that need the sums at the front
     // state (workspace)
     double* omega;            // [n_pad][OMS] user-major (OMS = K rounded up to 2): a user's vector is contiguous,
                               // so the scrambled order of the live lists costs at most one extra cache line per user
@@ -144,6 +155,12 @@ struct DevSim {
     unsigned long long* counters;   // [RG_CNT_N]
     // log
     rg_event* log; uint64_t log_cap;
+    // optional float64 side arrays, one entry per log row (same raw position): the propensity `ps` as the
+    // reference logs it (float64, abstract.py:318-327) and the click probability of the row (reco_env_v1.py:104-116)
+    double* aux_ps; double* aux_pclick;
+    double* phantom_ps;       // [n_users] float64 propensity of the phantom row
+    // test hooks (rg_sim_debug_*): per-user-index uniforms replacing the organic draw's u at the next step
+    const double* u_override;
 };
 
 }  // namespace
@@ -230,6 +247,13 @@ Geom geom_of(const rg_config& c) {
     return g;
 }
 
+// the per-user sum cache exists where omega cannot change (sigma_omega == 0) and a 16-bit MFMA kernel class serves K
+// (RECOGYM_CACHE=0: A/B tests)
+bool cache_wanted(const rg_config& c, const Geom& g) {
+    const char* e = getenv("RECOGYM_CACHE");
+    return c.sigma_omega == 0.0 && g.N1 != 0 && !(e && e[0] == '0');
+}
+
 size_t bf16_smem_bytes(const Geom& g, uint32_t K, uint32_t buffers) {
     // split tiles + mu tiles (2 buffers: lean kernel, 3: pipelined kernel) + the per-wave omega32 stage [4][32][K]
     return buffers * (static_cast<size_t>(g.TPB) * g.RS + g.TPB * 4) + 4 * 32 * static_cast<size_t>(K) * 4 + 256;
@@ -286,6 +310,13 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint32_t* lpv = w.take<uint32_t>(c.policy == RG_POLICY_LAST_VIEW_TABLE ? n : 1);
     unsigned long long* counters = w.take<unsigned long long>(RG_CNT_N);
     uint32_t* uid = w.take<uint32_t>(n);
+    double* phantom_ps = w.take<double>(n);
+    const bool cache = cache_wanted(c, g);
+    float2* cache_rec = w.take<float2>(cache ? (n + 1) * kMaxSC : 1);
+    float* cache_chunk = w.take<float>(cache ? (n + 1) * static_cast<size_t>(g.n_chunks) : 1);
+    uint8_t* cache_resc = w.take<uint8_t>(cache ? n + 1 : 1);
+    uint8_t* f64_valid = w.take<uint8_t>(cache ? n : 1);
+    uint32_t* exact_cnt_b = w.take<uint32_t>(kMaxSteps + 2);
     const bool rp = n >= repack_min_users();      // small runs never repack: no second copy
     double* omega_alt = w.take<double>(rp ? ((K + 1) & ~static_cast<size_t>(1)) * n_pad : 1);
     uint32_t* hist_alt = w.take<uint32_t>(rp ? hc * n_pad : 1);
@@ -294,6 +325,9 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint32_t* lpv_alt = w.take<uint32_t>(rp && c.policy == RG_POLICY_LAST_VIEW_TABLE ? n : 1);
     uint32_t* uid_alt = w.take<uint32_t>(rp ? n : 1);
     if (d) {
+        d->phantom_ps = phantom_ps;
+        d->use_cache = cache ? 1u : 0u; d->cache_rec = cache_rec; d->cache_chunk = cache_chunk; d->cache_resc = cache_resc;
+        d->f64_valid = f64_valid; d->exact_cnt_b = exact_cnt_b;
         d->uid = uid; d->omega_alt = omega_alt; d->hist_alt = hist_alt; d->hist_cntv_alt = hist_cntv_alt;
         d->hist_n_alt = hist_n_alt; d->lpv_alt = lpv_alt; d->uid_alt = uid_alt;
         d->gamma32 = gamma32; d->mu32 = mu32; d->stats = stats; d->omega = omega; d->list = list;
@@ -359,6 +393,14 @@ __device__ __forceinline__ void normal_pair(uint64_t seed, uint32_t user, uint32
     *z1 = r * s;
 }
 
+// the uniform of a user's organic product draw at step t (word pair 0 of the event draw); the test hook
+// rg_sim_debug_set_uniforms replaces it by a caller-chosen value per user index
+__device__ __forceinline__ double organic_uniform(const DevSim& d, uint32_t uidx, uint32_t user, uint32_t t) {
+    if (d.u_override) return d.u_override[uidx];
+    const rg_u32x4 rw = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
+    return rg_uniform(rw.w[0], rw.w[1]);
+}
+
 __device__ __forceinline__ uint32_t* list_ptr(const DevSim& d, uint32_t parity, uint32_t state) {
     return d.list + (static_cast<size_t>(parity) * 2 + state) * d.n_cap;
 }
@@ -385,6 +427,7 @@ __global__ void __launch_bounds__(kBlock) k_reset_users(DevSim d) {
         d.n_events[i] = 0;
         d.has_phantom[i] = 0;
         if (d.hist_cap) d.hist_n[i] = 0;
+        if (d.use_cache) { d.f64_valid[i] = 0; d.cache_resc[i] = 0; }
     }
 }
 
@@ -823,6 +866,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums(DevSim d, uint32_t t, int
             act[u] = w_idx[u] < n;
             const uint32_t pos = act[u] ? (from_list ? d.exact_list[w_idx[u]] : w_idx[u]) : 0u;
             const uint32_t slot = act[u] ? cur[pos] : 0u;
+            if (from_list && d.use_cache && act[u]) w_idx[u] = d.uid[slot];    // sums / reference rows are per user in this mode
             // any shift gives the same float64 decision up to 1e-16: a draw handed over by the
             // MFMA kernel reuses that kernel's reference, pure float64 mode uses k_exact_ref's
             M[u] = (mode == 1 && act[u]) ? static_cast<double>(d.exact_ref[w_idx[u]]) * 0.69314718055994530942 : 0.0;
@@ -927,10 +971,11 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_u(DevSim d, uint32_t t, i
         const uint32_t grp = wk / S, slice = wk % S;
         const uint32_t cc0 = slice * ccps, cc1 = min(cc0 + ccps, n_cc);
         if (cc0 >= cc1) continue;
-        const uint32_t w_idx = grp * 64 + lane;
+        uint32_t w_idx = grp * 64 + lane;
         const bool act = w_idx < n;
         const uint32_t pos = act ? (from_list ? d.exact_list[w_idx] : w_idx) : 0u;
         const uint32_t slot = act ? cur[pos] : 0u;
+        if (from_list && d.use_cache && act) w_idx = d.uid[slot];             // sums / reference rows are per user in this mode
         double om[4 * KB];
 #pragma unroll
         for (int k = 0; k < 4 * KB; ++k)
@@ -987,15 +1032,19 @@ __global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int
     const uint32_t n_chunks = d.PT / 64;
     const uint32_t n_cc = (n_chunks + G - 1) / G;
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
-    const uint32_t n = from_list ? d.exact_cnt[t] : n_o;
+    const bool cached = from_list && d.use_cache;
+    const uint32_t n_a = from_list ? d.exact_cnt[t] : n_o;              // draws whose sums the previous kernel took
+    const uint32_t n = n_a + (cached ? d.exact_cnt_b[t] : 0u);          // + draws of users whose sums were there already
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
     const uint32_t waves_total = gridDim.x * (kBlock / 64);
     for (uint32_t w = blockIdx.x * (kBlock / 64) + wave; w < n; w += waves_total) {
-        const uint32_t pos = from_list ? d.exact_list[w] : w;
+        const uint32_t pos = from_list ? d.exact_list[w < n_a ? w : d.n_cap - 1u - (w - n_a)] : w;
         const uint32_t slot = cur[pos];
-        const uint32_t user = static_cast<uint32_t>(d.first_user + d.uid[slot]);
-        const double M = static_cast<double>(d.exact_ref[w]) * 0.69314718055994530942;
-        const double* sums = d.exact_sums + static_cast<size_t>(w) * n_cc;
+        const uint32_t uidx = d.uid[slot];
+        const uint32_t user = static_cast<uint32_t>(d.first_user + uidx);
+        const uint32_t row = cached ? uidx : w;
+        const double M = static_cast<double>(d.exact_ref[row]) * 0.69314718055994530942;
+        const double* sums = d.exact_sums + static_cast<size_t>(row) * n_cc;
         for (uint32_t k = lane; k < d.K; k += 64) om[k] = d.omega[static_cast<size_t>(slot) * d.OMS + k];
         // total over the coarse-chunk sums, in the same association the prefix below uses
         double total = 0.0;
@@ -1006,8 +1055,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int
         // The reference normalises p = e / sum(e) before its cumsum and divides by cdf[-1];
         // dividing every term by the same positive constants moves the decision only at the
         // 1e-16 level, so the running sum of e is compared with u * total directly.
-        const rg_u32x4 rw = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
-        const double target = rg_uniform(rw.w[0], rw.w[1]) * total;
+        const double target = organic_uniform(d, uidx, user, t) * total;
         // first coarse chunk whose inclusive running sum exceeds the target, and the sum before it
         uint32_t ccstar = n_cc - 1;
         double before = 0.0, run = 0.0;
@@ -1044,11 +1092,14 @@ __global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int
         if (lane == 0) {
             write_organic_row(d, t, pos, slot, user, v);
             if (d.hist_cap) history_add(d, slot, v);
+            if (cached && w < n_a) d.f64_valid[uidx] = 1;
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (from_list == 1 && blockIdx.x == 0 && threadIdx.x == 0)
+    if (from_list == 1 && blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&d.counters[RG_CNT_EXACT_DRAWS], static_cast<unsigned long long>(n));
+        atomicAdd(&d.counters[RG_CNT_EXACT_SWEEPS], static_cast<unsigned long long>(n_a));
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1121,11 +1172,30 @@ __device__ __forceinline__ float swap32(float x) {
 // fp32 kernel: [chunk][32 users]; split-bf16 kernel: [tile of 4 chunks][32 users][4]
 #define CHUNK_AT(c, j) (tiled4 ? (((c) >> 2) * 32 + (j)) * 4 + ((c) & 3) : (c) * 32 + (j))
 
+// Where a lane finds / leaves its user's sums: record of super-chunk sc at rec[sc * rec_stride], the four chunk
+// sums of product tile ti (16 bytes) at chunk[ti * tile_stride].  Per-wave scratch (users interleaved, one sweep's
+// lifetime) or the per-user cache of the sigma_omega == 0 mode.
+struct SumsView { float2* rec; uint32_t rec_stride; float* chunk; uint32_t tile_stride; };
+
+__device__ __forceinline__ SumsView sums_view(const DevSim& d, float2* scr, float* scr_chunk, int j, bool active, uint32_t slot) {
+    SumsView v;
+    if (d.use_cache) {
+        const size_t row = active ? d.uid[slot] : d.n_cap;          // inactive lanes: the dummy row
+        v.rec = d.cache_rec + row * kMaxSC; v.rec_stride = 1;
+        v.chunk = d.cache_chunk + row * d.n_chunks; v.tile_stride = 4;
+    } else {
+        v.rec = scr + j; v.rec_stride = 32;
+        v.chunk = scr_chunk + 4 * j; v.tile_stride = 128;
+    }
+    return v;
+}
+
 template <int KH>
 __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, const float2* scr,
                                                 const float* scr_chunk, const float* om_lds,
                                                 float Ahat, int n_resc, bool active, uint32_t pos,
-                                                uint32_t slot, int j, int h, bool tiled4, double delta_fixed) {
+                                                uint32_t slot, int j, int h, bool tiled4, double delta_fixed,
+                                                const SumsView* view = nullptr) {
         n_resc = max(n_resc, __shfl_xor(n_resc, 32));
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // scratch: written by lanes < 32, read below
 
@@ -1135,7 +1205,8 @@ __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, con
         float2 rec[kMaxSC];
 #pragma unroll
         for (uint32_t sc = 0; sc < kMaxSC; ++sc)
-            rec[sc] = sc < d.n_sc ? scr[sc * 32 + j] : make_float2(0.0f, -INFINITY);   // unused: weight 0
+            rec[sc] = sc < d.n_sc ? (view ? view->rec[sc * view->rec_stride] : scr[sc * 32 + j])
+                                  : make_float2(0.0f, -INFINITY);                          // unused: weight 0
         float Q = rec[0].y;                                    // common reference: the largest one
 #pragma unroll
         for (uint32_t sc = 1; sc < kMaxSC; ++sc) Q = fmaxf(Q, rec[sc].y);
@@ -1147,8 +1218,7 @@ __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, con
             if (sc < d.n_sc) S += static_cast<double>(rec[sc].x);
         }
         const uint32_t user = static_cast<uint32_t>(d.first_user + d.uid[slot]);
-        const rg_u32x4 rw = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
-        const double tau = rg_uniform(rw.w[0], rw.w[1]) * S;
+        const double tau = organic_uniform(d, d.uid[slot], user, t) * S;
         double pb = 0.0;
         uint32_t sc_star = d.n_sc - 1;
         float f_star = 1.0f;
@@ -1175,7 +1245,8 @@ __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, con
                     float4 w4[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        w4[i] = cb + 4 * i < c1 ? *reinterpret_cast<const float4*>(scr_chunk + (((cb >> 2) + i) * 32 + j) * 4)
+                        w4[i] = cb + 4 * i < c1 ? (view ? *reinterpret_cast<const float4*>(view->chunk + ((cb >> 2) + i) * view->tile_stride)
+                                                        : *reinterpret_cast<const float4*>(scr_chunk + (((cb >> 2) + i) * 32 + j) * 4))
                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
@@ -1259,6 +1330,14 @@ __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, con
             if (my_ok) {
                 write_organic_row(d, t, pos, slot, user, my_v);
                 if (d.hist_cap) history_add(d, slot, my_v);
+            } else if (d.use_cache) {
+                // float64 sums are per-user constants in this mode: taken once (front of the list), reused after (back)
+                const uint32_t uidx = d.uid[slot];
+                if (d.f64_valid[uidx]) d.exact_list[d.n_cap - 1u - atomicAdd(&d.exact_cnt_b[t], 1u)] = pos;
+                else {
+                    d.exact_list[atomicAdd(&d.exact_cnt[t], 1u)] = pos;
+                    d.exact_ref[uidx] = Q;
+                }
             } else {
                 const uint32_t xi = atomicAdd(&d.exact_cnt[t], 1u);
                 d.exact_list[xi] = pos;
@@ -1710,6 +1789,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         const uint32_t pos = tb * 128 + wave * 32 + j;
         const bool active = pos < n_o;
         const uint32_t slot = active ? cur[pos] : 0u;
+        const SumsView view = sums_view(d, scr, scr_chunk, j, active, slot);
         __syncthreads();           // every wave is done with the LDS buffers and stage (previous work item)
         // tile ti -> LDS buffer ti & 1 (async DMA).  Source = buffer resource (SGPRs) + scalar offset +
         // lane * 16: one VGPR of address state, nothing to spill/reload next to the DMA
@@ -1882,11 +1962,11 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             const uint32_t ti = pt_lo + (pe >> 1);
             const float4 w4 = make_float4(wlo.x, wlo.y, s0, s1);
             // scratch layout [tile][user][4 chunks]; both lanes of the user hold the same sums: no branch
-            if (!(d.ablate & 16u)) *reinterpret_cast<float4*>(scr_chunk + (static_cast<size_t>(ti) * 32 + j) * 4) = w4;
+            if (!(d.ablate & 16u)) *reinterpret_cast<float4*>(view.chunk + static_cast<size_t>(ti) * view.tile_stride) = w4;
             wcmax = fmaxf(fmaxf(wcmax, fmaxf(w4.x, w4.y)), fmaxf(w4.z, w4.w));
             s_sc += static_cast<double>((w4.x + w4.y) + (w4.z + w4.w));
             if (--sc_left == 0) {
-                scr[sc_cur * 32 + j] = make_float2(static_cast<float>(s_sc), q_done);
+                view.rec[sc_cur * view.rec_stride] = make_float2(static_cast<float>(s_sc), q_done);
                 s_sc = 0.0;
                 // some logit is >= ~43 above the reference: re-reference from the next super-chunk
                 // that has not started (its MFMAs are a pair ahead of these sums)
@@ -1974,9 +2054,10 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             book(pi, tree(p0), tree(p1));
         }
         if (sc_left != d.sc_chunks / 4) {                      // partial last super-chunk
-            scr[sc_cur * 32 + j] = make_float2(static_cast<float>(s_sc), q_done);
+            view.rec[sc_cur * view.rec_stride] = make_float2(static_cast<float>(s_sc), q_done);
         }
-        if (S == 1 && !(d.ablate & 128u)) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, delta_fixed);
+        if (d.use_cache && S == 1 && active && h == 0) d.cache_resc[d.uid[slot]] = static_cast<uint8_t>(min(n_resc, 255));
+        if (S == 1 && !(d.ablate & 128u)) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, delta_fixed, &view);
     }
 }
 
@@ -2014,8 +2095,10 @@ __global__ void __launch_bounds__(kBlock) k_draw_search(DevSim d, uint32_t t) {
         const float Ahat = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        const SumsView view = sums_view(d, d.sc_scratch + wslot * kMaxSC * 32, d.chunk_scratch + wslot * d.n_chunks * 32, j, active, slot);
+        const int n_resc = (d.use_cache && active) ? d.cache_resc[d.uid[slot]] : 0;
         search_and_emit<KH>(d, t, d.sc_scratch + wslot * kMaxSC * 32, d.chunk_scratch + wslot * d.n_chunks * 32, omu,
-                            Ahat, 0, active, pos, slot, j, h, true, kDeltaFixedBf16 + (d.f16 ? f16_extra_delta(d, Ahat, absw) : 0.0));
+                            Ahat, n_resc, active, pos, slot, j, h, true, kDeltaFixedBf16 + (d.f16 ? f16_extra_delta(d, Ahat, absw) : 0.0), &view);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -2218,6 +2301,8 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                     e.code = RG_EV_BANDIT | (click ? RG_EV_CLICK : 0u) | a;
                     e.ps = static_cast<float>(ps);
                     d.log[row] = e;
+                    if (d.aux_ps) d.aux_ps[row] = ps;
+                    if (d.aux_pclick) d.aux_pclick[row] = ctr;
                 }
             }
             // update_state (reco_env_v1.py:85-100)
@@ -2247,6 +2332,7 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                     e.u = user; e.t = t + 1; e.code = RG_EV_BANDIT | RG_EV_PHANTOM | a;
                     e.ps = static_cast<float>(ps);
                     d.phantom[uidx] = e;
+                    d.phantom_ps[uidx] = ps;
                     d.has_phantom[uidx] = 1;
                     phantoms += 1;
                 }
@@ -2307,8 +2393,8 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
 // log rows log_base[t0] + ticket (the sorted log does not depend on raw positions); events of
 // steps > t0 are counted in the kCntTail* counters (step t0's are in step_cnt[t0]).
 // ------------------------------------------------------------------------------------------
-constexpr int kCntTailRows = 10, kCntTailOrganic = 11, kCntTailBandit = 12, kCntTailMaxT = 13, kCntTailTicket = 14,
-              kCntTailLimit = 15;   // internal slots of counters[] (RG_CNT_N = 16)
+constexpr int kCntTailRows = 16, kCntTailOrganic = 17, kCntTailBandit = 18, kCntTailMaxT = 19, kCntTailTicket = 20,
+              kCntTailLimit = 21;   // internal slots of counters[] (RG_CNT_N = 24)
 
 __global__ void __launch_bounds__(kBlock) k_tail(DevSim d, uint32_t t0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -2441,6 +2527,8 @@ __global__ void __launch_bounds__(kBlock) k_tail(DevSim d, uint32_t t0) {
                         e.code = RG_EV_BANDIT | (click ? RG_EV_CLICK : 0u) | a;
                         e.ps = static_cast<float>(ps);
                         d.log[row] = e;
+                        if (d.aux_ps) d.aux_ps[row] = ps;
+                        if (d.aux_pclick) d.aux_pclick[row] = ctr;
                     }
                 }
                 const double c0 = state == RG_STATE_ORGANIC ? d.cdf_o0 : d.cdf_b0;
@@ -2460,6 +2548,7 @@ __global__ void __launch_bounds__(kBlock) k_tail(DevSim d, uint32_t t0) {
                     e.u = user; e.t = t + 1; e.code = RG_EV_BANDIT | RG_EV_PHANTOM | a;
                     e.ps = static_cast<float>(ps);
                     d.phantom[uidx] = e;
+                    d.phantom_ps[uidx] = ps;
                     d.has_phantom[uidx] = 1;
                     c_ph += 1;
                 } else if (t + 2 >= kMaxSteps) {
@@ -2539,6 +2628,22 @@ __global__ void __launch_bounds__(kBlock) k_export_omega(DevSim d, double* out) 
         const size_t u = i / d.K, k = i % d.K;
         out[i] = d.omega[u * d.OMS + k];
     }
+}
+
+// test hooks
+__global__ void __launch_bounds__(kBlock) k_debug_set_omega(DevSim d, const double* in) {
+    const size_t n = static_cast<size_t>(d.n_users) * d.K;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const size_t u = i / d.K, k = i % d.K;
+        d.omega[u * d.OMS + k] = in[i];
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_debug_uncertified(DevSim d, uint32_t t_prev, uint8_t* flags) {
+    const uint32_t n_a = d.exact_cnt[t_prev], n = n_a + (d.use_cache ? d.exact_cnt_b[t_prev] : 0u);
+    const uint32_t* lst = list_ptr(d, t_prev & 1, RG_STATE_ORGANIC);
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        flags[d.uid[lst[d.exact_list[i < n_a ? i : d.n_cap - 1u - (i - n_a)]]]] = 1;
 }
 
 // live users only (after a repack the slots of users that left are gone); `out` is zero-filled first
@@ -2669,6 +2774,33 @@ __global__ void __launch_bounds__(kBlock) k_scatter_phantom(DevSim d, const int6
     }
 }
 
+// the float64 side arrays in the same order: NaN where the reference's column is NaN (organic rows; p_click of
+// the phantom row, which is never drawn)
+__global__ void __launch_bounds__(kBlock) k_scatter_aux(DevSim d, uint64_t n_rows, const int64_t* off,
+                                                      double* out_ps, double* out_pc, uint64_t out_cap) {
+    const double nan = __builtin_nan("");
+    for (uint64_t r = blockIdx.x * static_cast<uint64_t>(kBlock) + threadIdx.x; r < n_rows;
+         r += static_cast<uint64_t>(gridDim.x) * kBlock) {
+        const rg_event e = d.log[r];
+        const uint64_t dst = static_cast<uint64_t>(off[e.u - d.first_user]) + e.t;
+        if (dst >= out_cap) continue;
+        const bool is_b = (e.code & RG_EV_BANDIT) != 0;
+        if (out_ps) out_ps[dst] = (is_b && d.aux_ps) ? d.aux_ps[r] : nan;
+        if (out_pc) out_pc[dst] = (is_b && d.aux_pclick) ? d.aux_pclick[r] : nan;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_scatter_aux_phantom(DevSim d, const int64_t* off, double* out_ps,
+                                                              double* out_pc, uint64_t out_cap) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) {
+        if (!d.has_phantom[i]) continue;
+        const uint64_t dst = static_cast<uint64_t>(off[i]) + d.n_events[i];
+        if (dst >= out_cap) continue;
+        if (out_ps) out_ps[dst] = d.phantom_ps[i];
+        if (out_pc) out_pc[dst] = __builtin_nan("");
+    }
+}
+
 inline int grid_for(uint64_t n, int per_block = kBlock) {
     uint64_t g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -2743,7 +2875,14 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     }
     if (int rc = prof_mark(sim, st)) return rc;
     // 1. organic product draws of this step (read omega before the transition drifts it)
-    if (d.use_mfma == 2) {
+    if (d.use_mfma == 2 && d.use_cache && t > 0) {
+        // sigma_omega == 0, after step 0: every live user's exp-sums are in the per-user cache — search only
+        if (int rc = prof_mark(sim, st)) return rc;
+        hipLaunchKernelGGL(search_kernel_for(d), dim3(grid_for(upper, 128)), dim3(kBlock),
+                           sizeof(float) * 4 * 32 * 2 * d.KH, st, d, t);
+        if (int rc = prof_mark(sim, st)) return rc;
+        launch_exact(sim, t, 1, upper / 100 + 16, st);
+    } else if (d.use_mfma == 2) {
         // few user tiles: slice the products so that the step's latency is a slice, not a sweep
         const uint32_t tiles_up = (upper + 127) / 128;
         uint32_t S = tiles_up >= 1024 ? 1u : 2048u / (tiles_up ? tiles_up : 1u);
@@ -2878,6 +3017,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
         else if ((!strcmp(e, "bf16") || !strcmp(e, "f16")) && s->bf16_kernel) d.use_mfma = 2;
     }
     if (const char* e = getenv("RECOGYM_FORCE_EXACT")) if (e[0] == '1') d.use_mfma = 0;   // A/B switch for tests
+    // the per-user sum cache is written by the pipelined 16-bit kernel only
+    if (!(d.use_mfma == 2 && s->bf16_kernel && s->bf16_kernel == bf16p_kernel_for(d))) d.use_cache = 0;
     if (s->bf16_kernel && s->bf16_smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s->bf16_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->bf16_smem));
@@ -2975,6 +3116,14 @@ int rg_sim_set_log(rg_sim* sim, rg_event* d_log, uint64_t capacity) {
     if (!sim) return fail(RG_EINVAL, "sim is NULL");
     sim->d.log = capacity ? d_log : nullptr;
     sim->d.log_cap = d_log ? capacity : 0;
+    sim->d.aux_ps = nullptr; sim->d.aux_pclick = nullptr;     // side arrays are sized with the log: re-attach
+    return RG_OK;
+}
+
+int rg_sim_set_log_aux(rg_sim* sim, double* d_ps, double* d_p_click) {
+    if (!sim) return fail(RG_EINVAL, "sim is NULL");
+    if ((d_ps || d_p_click) && !sim->d.log) return fail(RG_ESTATE, "attach a log buffer first (rg_sim_set_log)");
+    sim->d.aux_ps = d_ps; sim->d.aux_pclick = d_p_click;
     return RG_OK;
 }
 
@@ -3004,6 +3153,7 @@ int rg_sim_reset_users(rg_sim* sim, uint64_t first_user_id, uint64_t n, uint64_t
     d.n_users = static_cast<uint32_t>(n);      // lists stay strided by the carve-time n_cap
     HIP_TRY(hipMemsetAsync(d.step_cnt, 0, sizeof(uint32_t) * 2 * (kMaxSteps + 2), st));
     HIP_TRY(hipMemsetAsync(d.exact_cnt, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
+    HIP_TRY(hipMemsetAsync(d.exact_cnt_b, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
     HIP_TRY(hipMemsetAsync(d.counters, 0, sizeof(unsigned long long) * RG_CNT_N, st));
     hipLaunchKernelGGL(k_reset_users, dim3(grid_for(n)), dim3(kBlock), 0, st, d);
     HIP_TRY(hipGetLastError());
@@ -3127,6 +3277,31 @@ int rg_sim_export_omega(rg_sim* sim, double* d_omega, void* stream) {
     return RG_OK;
 }
 
+int rg_sim_debug_set_uniforms(rg_sim* sim, const double* d_u) {
+    if (!sim) return fail(RG_EINVAL, "sim is NULL");
+    sim->d.u_override = d_u;
+    return RG_OK;
+}
+
+int rg_sim_debug_set_omega(rg_sim* sim, const double* d_omega, void* stream) {
+    if (!sim || !d_omega) return fail(RG_EINVAL, "NULL argument");
+    if (!sim->users_reset || sim->t != 0) return fail(RG_ESTATE, "only right after rg_sim_reset_users");
+    hipLaunchKernelGGL(k_debug_set_omega, dim3(grid_for(static_cast<uint64_t>(sim->d.n_users) * sim->d.K)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), sim->d, d_omega);
+    HIP_TRY(hipGetLastError());
+    return RG_OK;
+}
+
+int rg_sim_debug_uncertified(rg_sim* sim, uint8_t* d_flags, void* stream) {
+    if (!sim || !d_flags) return fail(RG_EINVAL, "NULL argument");
+    if (sim->t == 0) return fail(RG_ESTATE, "no step has run");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(d_flags, 0, sim->d.n_users, st));
+    hipLaunchKernelGGL(k_debug_uncertified, dim3(grid_for(sim->d.n_users)), dim3(kBlock), 0, st, sim->d, sim->t - 1, d_flags);
+    HIP_TRY(hipGetLastError());
+    return RG_OK;
+}
+
 int rg_sim_sort_log(rg_sim* sim, int64_t* d_row_offsets, int64_t* d_scratch, rg_event* d_sorted,
                     uint64_t sorted_capacity, void* stream) {
     if (!sim || !d_row_offsets || !d_scratch || !d_sorted) return fail(RG_EINVAL, "NULL argument");
@@ -3152,6 +3327,26 @@ int rg_sim_sort_log(rg_sim* sim, int64_t* d_row_offsets, int64_t* d_scratch, rg_
                        d_sorted, sorted_capacity);
     hipLaunchKernelGGL(k_scatter_phantom, dim3(grid_for(n)), dim3(kBlock), 0, st, d, d_row_offsets, d_sorted,
                        sorted_capacity);
+    HIP_TRY(hipGetLastError());
+    return RG_OK;
+}
+
+int rg_sim_sort_log_aux(rg_sim* sim, const int64_t* d_row_offsets, double* d_sorted_ps, double* d_sorted_p_click,
+                        uint64_t sorted_capacity, void* stream) {
+    if (!sim || !d_row_offsets) return fail(RG_EINVAL, "NULL argument");
+    if (!sim->d.log) return fail(RG_ESTATE, "no log buffer is attached");
+    if (!d_sorted_ps && !d_sorted_p_click) return RG_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const DevSim& d = sim->d;
+    uint64_t n_rows = 0;
+    HIP_TRY(hipMemcpyAsync(&n_rows, d.log_base + sim->t, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (n_rows > d.log_cap) return fail(RG_ELIMIT, "log overflow: %llu rows emitted, capacity %llu",
+                                        (unsigned long long)n_rows, (unsigned long long)d.log_cap);
+    hipLaunchKernelGGL(k_scatter_aux, dim3(grid_for(n_rows)), dim3(kBlock), 0, st, d, n_rows, d_row_offsets,
+                       d_sorted_ps, d_sorted_p_click, sorted_capacity);
+    hipLaunchKernelGGL(k_scatter_aux_phantom, dim3(grid_for(d.n_users)), dim3(kBlock), 0, st, d, d_row_offsets,
+                       d_sorted_ps, d_sorted_p_click, sorted_capacity);
     HIP_TRY(hipGetLastError());
     return RG_OK;
 }

@@ -17,6 +17,7 @@ from .envs.static_params import draw_tables, make_rg_config
 ROW_DTYPE = np.dtype([('u', np.uint32), ('t', np.uint32), ('z', np.int32), ('v', np.int32),
                       ('a', np.int32), ('c', np.int32), ('phantom', np.int32),
                       ('ps', np.float64)])
+ROW_DTYPE_PCLICK = np.dtype(ROW_DTYPE.descr + [('p_click', np.float64)])
 
 
 def require_device(device=None):
@@ -34,11 +35,12 @@ def default_log_capacity(config, n_users):
     return int(n_users * (mean + 1.0) + 8.0 * mean * math.sqrt(n_users) + 4096)
 
 
-def decode_rows(raw, uniform_ps=None):
-    """(n,4) int32 array of rg_event records -> structured host rows."""
+def decode_rows(raw, uniform_ps=None, ps64=None, p_click=None):
+    """(n,4) int32 array of rg_event records -> structured host rows.  `ps64` / `p_click`: the float64
+    side arrays in the same order (Simulator.sorted_aux_host), else ps is the row's float32 value."""
     raw = np.ascontiguousarray(raw).view(np.uint32).reshape(-1, 4)
     n = raw.shape[0]
-    out = np.zeros(n, dtype=ROW_DTYPE)
+    out = np.zeros(n, dtype=ROW_DTYPE if p_click is None else ROW_DTYPE_PCLICK)
     code = raw[:, 2]
     is_b = (code & _abi.RG_EV_BANDIT) != 0
     idx = (code & _abi.RG_EV_INDEX_MASK).astype(np.int32)
@@ -49,7 +51,9 @@ def decode_rows(raw, uniform_ps=None):
     out['a'] = np.where(is_b, idx, -1)
     out['c'] = np.where(is_b, (code & _abi.RG_EV_CLICK) != 0, -1)
     out['phantom'] = (code & _abi.RG_EV_PHANTOM) != 0
-    ps = raw[:, 3].copy().view(np.float32).astype(np.float64)
+    ps = raw[:, 3].copy().view(np.float32).astype(np.float64) if ps64 is None else ps64
+    if p_click is not None:
+        out['p_click'] = np.where(is_b & (out['phantom'] == 0), p_click, np.nan)
     if uniform_ps is not None:
         ps = np.where(is_b, uniform_ps, np.nan)     # exact 1/P of the uniform policies
     out['ps'] = np.where(is_b, ps, np.nan)
@@ -64,11 +68,14 @@ class Simulator:
     policy       _abi.RG_POLICY_*; policy_seed / ouc = the agent's parameters
     epoch        added to config.random_seed (reset_random_seed(epoch), abstract.py:59-62)
     log_capacity rows of device log to allocate; 0 = counters only; None = estimate
+    ps_float64   keep the propensity of every bandit row in float64 beside the 16-byte row (the dtype of
+                 the reference's `ps` column); default: on for the policies whose ps is not a constant
+    p_click      also keep the click probability of every bandit row (parity checks)
     """
 
     def __init__(self, config, n_users, policy=_abi.RG_POLICY_UNIFORM_ENV, policy_seed=None,
                  ouc=None, epoch=0, log_capacity=None, device=None, tables=None, policy_table=None,
-                 policy_ps=None, logreg=None):
+                 policy_ps=None, logreg=None, ps_float64=None, p_click=False):
         self.lib = _abi.load()
         self.device = require_device(device)
         self.config = config
@@ -76,6 +83,9 @@ class Simulator:
         self.rg_config = make_rg_config(config, config.random_seed + epoch, policy, policy_seed,
                                         ouc)
         self.policy = policy
+        self.ps_float64 = (policy in (_abi.RG_POLICY_ORGANIC_USER_COUNT, _abi.RG_POLICY_LAST_VIEW_TABLE)
+                           if ps_float64 is None else bool(ps_float64))
+        self.keep_p_click = bool(p_click)
         host_tables = tables if tables is not None else draw_tables(config)
         self.host_tables = host_tables
         with torch.cuda.device(self.device):
@@ -125,6 +135,16 @@ class Simulator:
                         if rows else None)
         _abi.check(self.lib.rg_sim_set_log(self._h, self.log.data_ptr() if rows else None,
                                            self.log_capacity), 'rg_sim_set_log')
+        self.aux_ps = self.aux_p_click = None
+        if rows and (self.ps_float64 or self.keep_p_click):
+            with torch.cuda.device(self.device):
+                if self.ps_float64:
+                    self.aux_ps = torch.empty(self.log_capacity, dtype=torch.float64, device=self.device)
+                if self.keep_p_click:
+                    self.aux_p_click = torch.empty(self.log_capacity, dtype=torch.float64, device=self.device)
+            _abi.check(self.lib.rg_sim_set_log_aux(
+                self._h, None if self.aux_ps is None else self.aux_ps.data_ptr(),
+                None if self.aux_p_click is None else self.aux_p_click.data_ptr()), 'rg_sim_set_log_aux')
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
@@ -173,7 +193,7 @@ class Simulator:
             _abi.check(self.lib.rg_sim_read_counters(self._h, out, self._stream()),
                        'rg_sim_read_counters')
         names = ['organic', 'bandit', 'clicks', 'phantom', 'live', 'step', 'log_rows',
-                 'log_dropped', 'exact_draws', 'hist_overflow']
+                 'log_dropped', 'exact_draws', 'hist_overflow', 'exact_sweeps']
         return {k: int(out[i]) for i, k in enumerate(names)}
 
     def set_profiling(self, on=True):
@@ -222,6 +242,17 @@ class Simulator:
                        'rg_sim_sort_log')
         return out, offsets
 
+    def sorted_aux(self, offsets, total):
+        """The float64 side arrays (ps, p_click) in the order of sorted_log(); None where not kept."""
+        with torch.cuda.device(self.device):
+            ps = None if self.aux_ps is None else torch.empty(total, dtype=torch.float64, device=self.device)
+            pc = None if self.aux_p_click is None else torch.empty(total, dtype=torch.float64, device=self.device)
+            if ps is not None or pc is not None:
+                _abi.check(self.lib.rg_sim_sort_log_aux(
+                    self._h, offsets.data_ptr(), None if ps is None else ps.data_ptr(),
+                    None if pc is None else pc.data_ptr(), total, self._stream()), 'rg_sim_sort_log_aux')
+        return ps, pc
+
     def sorted_log_host(self):
         """-> ((n, 4) int32 host array of the log in the reference's row order, exact `ps` of the
         uniform policies or None)."""
@@ -235,7 +266,8 @@ class Simulator:
         """The log in the reference's row order, decoded ON THE DEVICE into the columns of the
         reference's DataFrame and copied to the host column by column:
         dict(t f32, u i32, is_bandit bool, v i32, a i32, c f32 (NaN on organic rows), ps f64 (NaN))."""
-        out, _ = self.sorted_log()
+        out, offsets = self.sorted_log()
+        ps64, _ = self.sorted_aux(offsets, out.shape[0])
         with torch.cuda.device(self.device):
             code = out[:, 2]
             is_b = (code & _abi.RG_EV_BANDIT) != 0
@@ -246,6 +278,8 @@ class Simulator:
             if self.policy in (_abi.RG_POLICY_UNIFORM_ENV, _abi.RG_POLICY_RANDOM_AGENT):
                 ps_b = torch.full((), 1.0 / float(self.config.num_products), dtype=torch.float64,
                                   device=out.device)                 # exact 1/P of the uniform policies
+            elif ps64 is not None:
+                ps_b = ps64                                          # float64 as the policy computed it
             else:
                 ps_b = out[:, 3].contiguous().view(torch.float32).to(torch.float64)
             cols = dict(
@@ -266,5 +300,10 @@ class Simulator:
 
     def rows(self):
         """Decoded host rows in the reference's order."""
-        raw, uniform = self.sorted_log_host()
-        return decode_rows(raw, uniform)
+        out, offsets = self.sorted_log()
+        ps64, pc = self.sorted_aux(offsets, out.shape[0])
+        uniform = None
+        if self.policy in (_abi.RG_POLICY_UNIFORM_ENV, _abi.RG_POLICY_RANDOM_AGENT):
+            uniform = 1.0 / float(self.config.num_products)
+        return decode_rows(out.cpu().numpy(), uniform, None if ps64 is None else ps64.cpu().numpy(),
+                           None if pc is None else pc.cpu().numpy())

@@ -290,6 +290,15 @@ def main():
         run_logreg_case('philox_logreg', {'random_seed': 42, 'num_products': 30, 'K': 8}, 1500, 200)
         run_logreg_case('mt_logreg', {'random_seed': 42, 'num_products': 30, 'K': 8}, 1500, 120, injected=False)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'r2':             # round-2 additions only
+        S = dict(random_seed=42)
+        # the reference's dtype ceiling (np.int16 product ids), BASELINE config 4's K and drift
+        run_case('philox_p32767_k64_drift', {**S, 'num_products': 32767, 'K': 64, 'sigma_omega': 0.1}, 10,
+                 injected=True)
+        # BASELINE config 3's table shape with its agent in the loop
+        run_case('philox_ouc_p10000', {**S, 'num_products': 10000, 'K': 20, 'sigma_omega': 0.0}, 40,
+                 agent_kind='ouc', agent_args=dict(random_seed=11), injected=True)
+        return
     notebook_goldens()
     S = dict(random_seed=42)
     # --- reference as shipped (sequential MT19937) ---
@@ -331,6 +340,10 @@ def main():
     run_case('philox_change_omega', {**S, 'change_omega_for_bandits': True}, 120, injected=True)
     run_case('philox_bandit_mf', {**S, 'num_products': 40, 'K': 10}, 150, agent_kind='bmf',
              agent_args=dict(torch_seed=3, embed_dim=5), injected=True)
+    run_case('philox_p32767_k64_drift', {**S, 'num_products': 32767, 'K': 64, 'sigma_omega': 0.1}, 10,
+             injected=True)
+    run_case('philox_ouc_p10000', {**S, 'num_products': 10000, 'K': 20, 'sigma_omega': 0.0}, 40,
+             agent_kind='ouc', agent_args=dict(random_seed=11), injected=True)
     for fx in ('philox_ouc', 'mt_random_agent'):
         train_feed_golden(fx)
     run_logreg_case('philox_logreg', {**S, 'num_products': 30, 'K': 8}, 1500, 200)
