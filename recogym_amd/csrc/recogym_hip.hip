@@ -93,6 +93,8 @@ struct DevSim {
     // tables (caller-owned float64) and fp32 copies (workspace)
     const double* gamma; const double* mu_o; const double* beta; const double* mu_b;
     float* gamma32; float* mu32;   // [P_pad][KS] (k >= K zero, rows >= P zero) / [P_pad] (-inf pad)
+    float* gamma32t;          // [n_chunks][2 KH][32]: the same values chunk by chunk, k-major inside a chunk — a lane per
+                              // product reads one k of its chunk as one coalesced 128-byte run (k_draw_cached)
     double* gammaT;           // [K][PT] float64 transpose of Gamma, PT = P rounded up to 64 (coalesced f64 draw)
     uint32_t PT;
     double* gamma_rm;         // [PT][4 XKB + 4] row-major float64 Gamma, k zero-padded to 4 XKB, then mu_o (-inf beyond P):
@@ -127,6 +129,11 @@ struct DevSim {
     float2* cache_rec;        // [n_cap + 1][kMaxSC] {sum, reference} of every super-chunk
     float* cache_chunk;       // [n_cap + 1][n_chunks] exp-sum of every 32-product chunk
     uint8_t* cache_resc;      // [n_cap + 1] re-references of the sweep (certificate budget)
+    // what every later draw of a user starts from, one contiguous row per user (k_cache_finalize builds it from the
+    // records above right after step 0): [0,32) super-chunk sums scaled to the common reference | 32: that reference,
+    // 33: the certificate's delta (rounded up), 34-35: - | [36,44) 32 int8: reference offset of every super-chunk
+    // (scale of its chunk sums) | [44, 44 + 2 KH) omega32.  256 bytes at K <= 20: two lines instead of six
+    float* cache_row; uint32_t cache_row_f;   // row stride in floats (multiple of 32)
     uint8_t* f64_valid;       // [n_cap] exact_sums / exact_ref rows (indexed by user index in this mode) are valid
     uint32_t* exact_cnt_b;    // [kMaxSteps+2] draws to resolve whose float64 sums are already there: they sit at the
                               // BACK of exact_list (entry n_cap - 1 - i); those that need the sums at the front
@@ -142,14 +149,16 @@ struct DevSim {
     uint32_t* n_events;       // [n_users] rows the user emitted (set when it leaves); these three are indexed by
     rg_event* phantom;        // [n_users] trailing undrawn bandit row                  USER INDEX (uid), not by slot
     uint8_t* has_phantom;     // [n_users]
-    uint32_t* hist;           // [n_pad][hist_cap] sorted distinct viewed products (OUC policy), user-major
-    uint16_t* hist_cntv;      // [n_pad][hist_cap] view counts of those products
-    uint32_t* hist_n;         // [n_users] distinct products viewed
+    // per-user view history (OUC / frozen LogReg policies), user-major rows of hist_cap 64-bit entries:
+    //   entry 0        header: (views so far << 32) | distinct products viewed (nd)
+    //   entries 1..nd  (product << 32) | view count, ascending by product (== ascending as integers)
+    // one 128-byte line holds the header and the first 15 products: most users' whole history
+    unsigned long long* hist;
     uint32_t* lpv;            // [n_users] last product viewed (RG_POLICY_LAST_VIEW_TABLE)
     uint32_t* uid;            // [n_users] slot -> user index (user id = first_user + uid[slot]); identity until a repack
     // second copy of the slot-indexed state: k_repack_copy moves the live users' state into it, densely
     // and in list order, and the host swaps the pointers (restores the locality the lists lose over time)
-    double* omega_alt; uint32_t* hist_alt; uint16_t* hist_cntv_alt; uint32_t* hist_n_alt; uint32_t* lpv_alt; uint32_t* uid_alt;
+    double* omega_alt; unsigned long long* hist_alt; uint32_t* lpv_alt; uint32_t* uid_alt;
     const int32_t* pol_table; const float* pol_ps;   // caller-owned per-product tables of that policy
     const double* lr_coef_t; const double* lr_intercept; const int32_t* lr_classes; uint32_t lr_n;   // RG_POLICY_LOGREG_FROZEN
     unsigned long long* counters;   // [RG_CNT_N]
@@ -174,6 +183,7 @@ struct rg_sim {
     uint32_t live_upper;      // upper bound of live users (for grid sizing)
     bool tables_set, users_reset;
     bool repacked;            // slots no longer equal user indices (since the last reset)
+    bool cached_search_old;   // RECOGYM_CACHED=search: the first form of the cached draw (k_draw_search over the cache)
     uint32_t repack_every;    // steps between repacks (RECOGYM_REPACK, 0 = never)
     uint32_t tail_below;      // rg_sim_run hands the run to k_tail once at most this many users live (RECOGYM_TAIL, 0 = never)
     double prof_tail_ms;
@@ -272,7 +282,9 @@ uint32_t exact_kb_of(uint32_t K) {
 
 uint32_t hist_cap_of(const rg_config& c) {
     if (c.policy != RG_POLICY_ORGANIC_USER_COUNT && c.policy != RG_POLICY_LOGREG_FROZEN) return 0;
-    return c.ouc_history_cap ? c.ouc_history_cap : kDefaultHistoryCap;
+    // entries per row: the header + the distinct products kept, rounded up to whole 16-byte pairs
+    const uint32_t hc = ((c.ouc_history_cap ? c.ouc_history_cap : kDefaultHistoryCap - 1u) + 2u) & ~1u;
+    return hc < 16u ? 16u : hc;                  // at least the one line the register paths load
 }
 
 size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
@@ -283,6 +295,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     (void)P; (void)K;
     float* gamma32 = w.take<float>(static_cast<size_t>(g.P_pad) * (g.KS ? g.KS : 1));
     float* mu32 = w.take<float>(g.P_pad ? g.P_pad : 1);
+    float* gamma32t = w.take<float>(cache_wanted(c, g) ? static_cast<size_t>(g.n_chunks) * 2 * g.KH * 32 : 1);
     float* stats = w.take<float>(2 * g.KH + 2);
     const size_t PT = align_up(P, 64);
     double* gammaT = w.take<double>(K * PT);
@@ -304,9 +317,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     rg_event* phantom = w.take<rg_event>(n);
     uint8_t* has_phantom = w.take<uint8_t>(n);
     const size_t hc = hist_cap_of(c);
-    uint32_t* hist = w.take<uint32_t>(hc * n_pad);
-    uint16_t* hist_cntv = w.take<uint16_t>(hc * n_pad);
-    uint32_t* hist_n = w.take<uint32_t>(n);
+    unsigned long long* hist = w.take<unsigned long long>(hc * n_pad);
     uint32_t* lpv = w.take<uint32_t>(c.policy == RG_POLICY_LAST_VIEW_TABLE ? n : 1);
     unsigned long long* counters = w.take<unsigned long long>(RG_CNT_N);
     uint32_t* uid = w.take<uint32_t>(n);
@@ -315,22 +326,22 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     float2* cache_rec = w.take<float2>(cache ? (n + 1) * kMaxSC : 1);
     float* cache_chunk = w.take<float>(cache ? (n + 1) * static_cast<size_t>(g.n_chunks) : 1);
     uint8_t* cache_resc = w.take<uint8_t>(cache ? n + 1 : 1);
+    const uint32_t cache_row_f = (44u + 2u * g.KH + 31u) & ~31u;
+    float* cache_row = w.take<float>(cache ? (n + 1) * static_cast<size_t>(cache_row_f) : 1);
     uint8_t* f64_valid = w.take<uint8_t>(cache ? n : 1);
     uint32_t* exact_cnt_b = w.take<uint32_t>(kMaxSteps + 2);
     const bool rp = n >= repack_min_users();      // small runs never repack: no second copy
     double* omega_alt = w.take<double>(rp ? ((K + 1) & ~static_cast<size_t>(1)) * n_pad : 1);
-    uint32_t* hist_alt = w.take<uint32_t>(rp ? hc * n_pad : 1);
-    uint16_t* hist_cntv_alt = w.take<uint16_t>(rp ? hc * n_pad : 1);
-    uint32_t* hist_n_alt = w.take<uint32_t>(rp ? n : 1);
+    unsigned long long* hist_alt = w.take<unsigned long long>(rp ? hc * n_pad : 1);
     uint32_t* lpv_alt = w.take<uint32_t>(rp && c.policy == RG_POLICY_LAST_VIEW_TABLE ? n : 1);
     uint32_t* uid_alt = w.take<uint32_t>(rp ? n : 1);
     if (d) {
         d->phantom_ps = phantom_ps;
         d->use_cache = cache ? 1u : 0u; d->cache_rec = cache_rec; d->cache_chunk = cache_chunk; d->cache_resc = cache_resc;
-        d->f64_valid = f64_valid; d->exact_cnt_b = exact_cnt_b;
-        d->uid = uid; d->omega_alt = omega_alt; d->hist_alt = hist_alt; d->hist_cntv_alt = hist_cntv_alt;
-        d->hist_n_alt = hist_n_alt; d->lpv_alt = lpv_alt; d->uid_alt = uid_alt;
-        d->gamma32 = gamma32; d->mu32 = mu32; d->stats = stats; d->omega = omega; d->list = list;
+        d->f64_valid = f64_valid; d->exact_cnt_b = exact_cnt_b; d->cache_row = cache_row; d->cache_row_f = cache_row_f;
+        d->uid = uid; d->omega_alt = omega_alt; d->hist_alt = hist_alt;
+        d->lpv_alt = lpv_alt; d->uid_alt = uid_alt;
+        d->gamma32 = gamma32; d->mu32 = mu32; d->gamma32t = gamma32t; d->stats = stats; d->omega = omega; d->list = list;
         d->gamma_rm = gamma_rm; d->XKB = xkb;
         d->gammaT = gammaT; d->PT = static_cast<uint32_t>(PT); d->exact_ref = exact_ref; d->exact_sums = exact_sums; d->sc_scratch = sc_scratch; d->chunk_scratch = chunk_scratch;
         d->gsplit = gsplit; d->mu32s = mu32s; d->N1 = g.N1; d->N2 = g.N2; d->N3 = g.N3; d->RS = g.RS; d->TPB = g.TPB; d->f16 = g.F16;
@@ -338,8 +349,8 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->sc_chunks = g.sc_chunks; d->n_sc = g.n_sc; d->use_mfma = g.KH ? 1u : 0u;
         d->step_cnt = step_cnt; d->log_base = log_base; d->exact_list = exact_list;
         d->exact_cnt = exact_cnt; d->n_events = n_events; d->phantom = phantom;
-        d->has_phantom = has_phantom; d->hist = hist; d->hist_cntv = hist_cntv;
-        d->hist_n = hist_n; d->counters = counters; d->lpv = (c.policy == RG_POLICY_LAST_VIEW_TABLE) ? lpv : nullptr;
+        d->has_phantom = has_phantom; d->hist = hist;
+        d->counters = counters; d->lpv = (c.policy == RG_POLICY_LAST_VIEW_TABLE) ? lpv : nullptr;
         d->n_pad = static_cast<uint32_t>(n_pad);
         d->OMS = static_cast<uint32_t>((K + 1) & ~static_cast<size_t>(1));
         d->hist_cap = static_cast<uint32_t>(hc);
@@ -426,7 +437,7 @@ __global__ void __launch_bounds__(kBlock) k_reset_users(DevSim d) {
         d.uid[i] = i;
         d.n_events[i] = 0;
         d.has_phantom[i] = 0;
-        if (d.hist_cap) d.hist_n[i] = 0;
+        if (d.hist_cap) d.hist[static_cast<size_t>(i) * d.hist_cap] = 0ull;
         if (d.use_cache) { d.f64_valid[i] = 0; d.cache_resc[i] = 0; }
     }
 }
@@ -440,6 +451,14 @@ __global__ void __launch_bounds__(kBlock) k_make_fp32_tables(DevSim d) {
         const size_t p = i / d.KS, k = i % d.KS;
         d.gamma32[i] = (p < d.P && k < d.K) ? static_cast<float>(d.gamma[p * d.K + k]) : 0.0f;
         if (i < d.P_pad) d.mu32[i] = i < d.P ? static_cast<float>(d.mu_o[i]) : -INFINITY;
+    }
+    if (d.use_cache) {
+        const size_t K2 = 2 * d.KH, nt = static_cast<size_t>(d.n_chunks) * K2 * 32;
+        for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < nt;
+             i += static_cast<size_t>(gridDim.x) * kBlock) {
+            const size_t c = i / (K2 * 32), k = (i / 32) % K2, p = c * 32 + (i & 31);
+            d.gamma32t[i] = (p < d.P && k < d.K) ? static_cast<float>(d.gamma[p * d.K + k]) : 0.0f;
+        }
     }
 }
 
@@ -545,6 +564,30 @@ __global__ void __launch_bounds__(kBlock) k_table_stats(DevSim d) {
     if (threadIdx.x == 0) d.stats[which] = static_cast<float>(red[0] * (1.0 + 1e-6));
 }
 
+typedef unsigned long long hent_t;
+__device__ __forceinline__ hent_t* hist_row(const DevSim& d, uint32_t slot) { return d.hist + static_cast<size_t>(slot) * d.hist_cap; }
+__device__ __forceinline__ uint32_t h_prod(hent_t e) { return static_cast<uint32_t>(e >> 32); }
+__device__ __forceinline__ uint32_t h_cnt(hent_t e) { return static_cast<uint32_t>(e); }
+constexpr int kHistRegs = 16;   // header + 15 products: one 128-byte line, held in registers
+
+// the first line of a history row: 8 independent 16-byte loads (one latency instead of a dependent walk)
+__device__ __forceinline__ void hist_load_line(const hent_t* row, hent_t e[kHistRegs]) {
+#pragma unroll
+    for (int i = 0; i < kHistRegs / 2; ++i) {
+        const ulonglong2 x = reinterpret_cast<const ulonglong2*>(row)[i];
+        e[2 * i] = x.x; e[2 * i + 1] = x.y;
+    }
+}
+
+// !(acc / last <= u) exactly as float64 evaluates it, without the division where the answer is clear:
+// acc < fl(u last)(1 - 2^-50) implies fl(acc / last) <= u, acc > fl(u last)(1 + 2^-50) implies fl(acc / last) > u
+__device__ __forceinline__ bool cdf_exceeds(double acc, double last, double u) {
+    const double tl = u * last;
+    if (acc < tl * 0x1.ffffffffffff8p-1) return false;
+    if (acc > tl * 0x1.0000000000004p+0) return true;
+    return !(acc / last <= u);
+}
+
 // ------------------------------------------------------------------------------------------
 // The policy's act on the device.  Returns the action; writes the propensity.
 //   agent=None       abstract.py:209-221        uniform over P from the ENV stream
@@ -563,15 +606,14 @@ __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, ui
         // counts.  scipy's csr_matvecs adds count * coef_t[p][:] for the viewed products in ascending
         // order with a separate multiply and add (no FMA), then the intercept is added: reproduced
         // exactly, so ties and near-ties break like the reference's argmax (first maximum).
-        const uint32_t nd = d.hist_n[slot];
-        const uint32_t* hp = d.hist + static_cast<size_t>(slot) * d.hist_cap;
-        const uint16_t* hc = d.hist_cntv + static_cast<size_t>(slot) * d.hist_cap;
+        const hent_t* hr = hist_row(d, slot);
+        const uint32_t nd = h_cnt(hr[0]);
         uint32_t best = 0;
         double best_s = 0.0;
         for (uint32_t c = 0; c < d.lr_n; ++c) {
             double sc = 0.0;
-            for (uint32_t i = 0; i < nd; ++i)
-                sc = __dadd_rn(sc, __dmul_rn(static_cast<double>(hc[i]), d.lr_coef_t[static_cast<size_t>(hp[i]) * d.lr_n + c]));
+            for (uint32_t i = 1; i <= nd; ++i)
+                sc = __dadd_rn(sc, __dmul_rn(static_cast<double>(h_cnt(hr[i])), d.lr_coef_t[static_cast<size_t>(h_prod(hr[i])) * d.lr_n + c]));
             sc = __dadd_rn(sc, d.lr_intercept[c]);
             if (c == 0 || sc > best_s) { best = c; best_s = sc; }
         }
@@ -584,11 +626,8 @@ __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, ui
         return rg_bounded(w.w[0], w.w[1], d.P);
     }
     // --- OrganicUserEventCounterModel.act over the user's sorted (product, count) history ---
-    const uint32_t nd = d.hist_n[slot];
+    const hent_t* hr = hist_row(d, slot);
     const double eps = d.ouc_epsilon;
-    const uint32_t* hp = d.hist + static_cast<size_t>(slot) * d.hist_cap;
-    const uint16_t* hc = d.hist_cntv + static_cast<size_t>(slot) * d.hist_cap;
-    const size_t stride = 1;
     bool explore = false;
     if (d.ouc_exploit_explore) {
         const double u0 = rg_uniform(w.w[0], w.w[1]);
@@ -599,39 +638,74 @@ __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, ui
     if (d.ouc_exploit_explore && !explore) {
         // p_i = count_i / sum(counts): zero entries add exactly 0.0 to the running cdf, so the
         // sequential float64 cumsum over all P products equals the one over the viewed ones.
-        double sum = 0.0;
-        for (uint32_t i = 0; i < nd; ++i) sum += static_cast<double>(hc[i * stride]);
+        // sum(counts) = the views so far (integers: exact in float64 in any order) sits in the header.
+        hent_t e[kHistRegs];
+        hist_load_line(hr, e);
+        const uint32_t nd = h_cnt(e[0]);
+        const double sum = static_cast<double>(h_prod(e[0]));
+        if (nd < kHistRegs) {
+            // the whole history is in registers: p_i once, then the cdf walk without touching memory again
+            double pr[kHistRegs - 1];
+            double last = 0.0;
+#pragma unroll
+            for (int i = 1; i < kHistRegs; ++i) {
+                pr[i - 1] = 0.0;
+                if (static_cast<uint32_t>(i) <= nd) { pr[i - 1] = static_cast<double>(h_cnt(e[i])) / sum; last += pr[i - 1]; }
+            }
+            if (d.ouc_select_randomly) {
+                double acc = 0.0, pa = 0.0;
+                uint32_t a = d.P - 1;     // searchsorted(..., 'right') on a cdf ending at 1.0
+                bool found = false;
+#pragma unroll
+                for (int i = 1; i < kHistRegs; ++i)
+                    if (static_cast<uint32_t>(i) <= nd && !found) {
+                        acc += pr[i - 1];
+                        if (cdf_exceeds(acc, last, u1)) { a = h_prod(e[i]); pa = pr[i - 1]; found = true; }
+                    }
+                *ps_out = (1.0 - eps) * pa;
+                return a;
+            }
+            uint32_t best = 0; double bestp = -1.0;
+#pragma unroll
+            for (int i = 1; i < kHistRegs; ++i)
+                if (static_cast<uint32_t>(i) <= nd && pr[i - 1] > bestp) { bestp = pr[i - 1]; best = h_prod(e[i]); }
+            *ps_out = 1.0;
+            return best;
+        }
         if (d.ouc_select_randomly) {
             double last = 0.0;
-            for (uint32_t i = 0; i < nd; ++i) last += static_cast<double>(hc[i * stride]) / sum;
+            for (uint32_t i = 1; i <= nd; ++i) last += static_cast<double>(h_cnt(hr[i])) / sum;
             double acc = 0.0;
-            uint32_t a = d.P - 1;     // searchsorted(..., 'right') on a cdf ending at 1.0
+            uint32_t a = d.P - 1;
             double pa = 0.0;
             bool found = false;
-            for (uint32_t i = 0; i < nd; ++i) {
-                const double p = static_cast<double>(hc[i * stride]) / sum;
+            for (uint32_t i = 1; i <= nd && !found; ++i) {
+                const hent_t x = hr[i];
+                const double p = static_cast<double>(h_cnt(x)) / sum;
                 acc += p;
-                if (!found && !(acc / last <= u1)) { a = hp[i * stride]; pa = p; found = true; }
+                if (!(acc / last <= u1)) { a = h_prod(x); pa = p; found = true; }
             }
             *ps_out = (1.0 - eps) * pa;
             return a;
         }
         uint32_t best = 0; double bestp = -1.0;
-        for (uint32_t i = 0; i < nd; ++i) {
-            const double p = static_cast<double>(hc[i * stride]) / sum;
-            if (p > bestp) { bestp = p; best = hp[i * stride]; }
+        for (uint32_t i = 1; i <= nd; ++i) {
+            const hent_t x = hr[i];
+            const double p = static_cast<double>(h_cnt(x)) / sum;
+            if (p > bestp) { bestp = p; best = h_prod(x); }
         }
         *ps_out = 1.0;
         return best;
     }
+    const uint32_t nd = h_cnt(hr[0]);
     // Dense cases (explore flip, epsilon smoothing, reverse_pop): every product has mass, the
     // float64 running sums are order-dependent, so walk all P products like numpy does.
     // O(P) per act; used by parity tests and small P only (BASELINE configs use epsilon = 0).
     auto count_of = [&](uint32_t p, uint32_t* cursor) -> double {
         // history is sorted by product id; cursor walks it once
-        while (*cursor < nd && hp[*cursor * stride] < p) ++*cursor;
-        return (*cursor < nd && hp[*cursor * stride] == p)
-                   ? static_cast<double>(hc[*cursor * stride]) : 0.0;
+        while (*cursor < nd && h_prod(hr[1 + *cursor]) < p) ++*cursor;
+        return (*cursor < nd && h_prod(hr[1 + *cursor]) == p)
+                   ? static_cast<double>(h_cnt(hr[1 + *cursor])) : 0.0;
     };
     auto feature = [&](double cnt) -> double {
         if (d.ouc_exploit_explore) return cnt == 0.0 ? 1.0 : 0.0;   // explore: unseen products
@@ -679,25 +753,54 @@ __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, ui
 // ViewsFeaturesProvider.observe (agents/abstract.py:347-358): count one organic view, keeping the
 // user's (product, count) history sorted by product id.
 __device__ void history_add(const DevSim& d, uint32_t slot, uint32_t v) {
-    uint32_t* hp = d.hist + static_cast<size_t>(slot) * d.hist_cap;
-    uint16_t* hc = d.hist_cntv + static_cast<size_t>(slot) * d.hist_cap;
-    const size_t stride = 1;
-    const uint32_t nd = d.hist_n[slot];
-    uint32_t i = 0;
-    while (i < nd && hp[i * stride] < v) ++i;
-    if (i < nd && hp[i * stride] == v) {
-        if (hc[i * stride] == 0xFFFFu) { atomicAdd(&d.counters[RG_CNT_HIST_OVERFLOW], 1ull); return; }
-        hc[i * stride] += 1;
+    hent_t* hr = hist_row(d, slot);
+    hent_t e[kHistRegs];
+    hist_load_line(hr, e);
+    const uint32_t nd = h_cnt(e[0]);
+    const hent_t key = static_cast<hent_t>(v) << 32;
+    if (nd < kHistRegs) {
+        // header + every product in registers: position by comparison, the shifted tail written back
+        // as whole 16-byte pairs (entries beyond nd + 1 of the line are don't-care)
+        uint32_t pos = 1;                       // first entry with product >= v (nd + 1 if none)
+        bool hit = false;
+#pragma unroll
+        for (int i = 1; i < kHistRegs; ++i)
+            if (static_cast<uint32_t>(i) <= nd) {
+                pos += e[i] < key ? 1u : 0u;
+                hit = hit || h_prod(e[i]) == v;
+            }
+        if (hit) {
+#pragma unroll
+            for (int i = 1; i < kHistRegs; ++i)
+                if (static_cast<uint32_t>(i) == pos) hr[i] = e[i] + 1ull;
+            hr[0] = e[0] + (1ull << 32);
+            return;
+        }
+        if (nd + 1 >= d.hist_cap) { atomicAdd(&d.counters[RG_CNT_HIST_OVERFLOW], 1ull); return; }
+        hent_t f[kHistRegs + 2];                 // the row after the insertion
+        f[0] = e[0] + (1ull << 32) + 1ull;
+#pragma unroll
+        for (int i = 1; i < kHistRegs + 1; ++i)
+            f[i] = static_cast<uint32_t>(i) < pos ? e[i < kHistRegs ? i : 0] : (static_cast<uint32_t>(i) == pos ? (key | 1ull) : e[i - 1]);
+        f[kHistRegs + 1] = 0ull;
+        hr[0] = f[0];
+#pragma unroll
+        for (int i = 0; i < (kHistRegs + 2) / 2; ++i)
+            if (static_cast<uint32_t>(2 * i + 1) >= pos && static_cast<uint32_t>(2 * i) <= nd + 1)
+                reinterpret_cast<ulonglong2*>(hr)[i] = make_ulonglong2(i == 0 ? f[0] : f[2 * i], f[2 * i + 1]);
         return;
     }
-    if (nd >= d.hist_cap) { atomicAdd(&d.counters[RG_CNT_HIST_OVERFLOW], 1ull); return; }
-    for (uint32_t j = nd; j > i; --j) {
-        hp[j * stride] = hp[(j - 1) * stride];
-        hc[j * stride] = hc[(j - 1) * stride];
+    uint32_t i = 1;
+    while (i <= nd && hr[i] < key) ++i;
+    if (i <= nd && h_prod(hr[i]) == v) {
+        hr[i] += 1ull;
+        hr[0] = e[0] + (1ull << 32);
+        return;
     }
-    hp[i * stride] = v;
-    hc[i * stride] = 1;
-    d.hist_n[slot] = nd + 1;
+    if (nd + 1 >= d.hist_cap) { atomicAdd(&d.counters[RG_CNT_HIST_OVERFLOW], 1ull); return; }
+    for (uint32_t j = nd + 1; j > i; --j) hr[j] = hr[j - 1];
+    hr[i] = key | 1ull;
+    hr[0] = e[0] + (1ull << 32) + 1ull;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2103,6 +2206,252 @@ __global__ void __launch_bounds__(kBlock) k_draw_search(DevSim d, uint32_t t) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// k_draw_cached — the organic draw of a user whose exp-sums are in the per-user cache
+// (sigma_omega == 0, every step after the first): search only, no product sweep.
+//
+// Phase 1-2, a lane per user (64 per wave): the user's <= 32 super-chunk records (256 contiguous
+// bytes) -> total, target u S, super-chunk; the chunk sums of that super-chunk -> chunk.
+// Phase 3, two users at a time, a lane per product: the 32 products of the chosen chunk are
+// recomputed in fp32 from Gamma32 stored chunk by chunk and k-major (every load is one 128-byte run per
+// user; a lane-per-user gather of 32 rows cost 88 scattered 16-byte loads per lane and made the first
+// version of this path address-rate-bound: 1.06 ns per draw), prefix sum across the 32 lanes,
+// index, the two neighbouring prefix values and the margin certificate of search_and_emit.  The
+// result travels back to the user's own lane; rows, view history and the hand-over to the float64
+// resolve are done a lane per user again.
+// ------------------------------------------------------------------------------------------
+// after step 0 (slot == user index: nothing has been repacked yet), a lane per user
+template <int KH>
+__global__ void __launch_bounds__(kBlock) k_cache_finalize(DevSim d) {
+    constexpr int K2 = 2 * KH;
+    const float mumax = d.stats[2 * KH + 1], g2max = d.stats[2 * KH];
+    float gsum = 0.0f;
+    if (d.f16) for (uint32_t k = 0; k < d.K; ++k) gsum += d.stats[k];
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) {
+        float* row = d.cache_row + static_cast<size_t>(i) * d.cache_row_f;
+        // omega32 and the logit error bound, exactly as the sweep kernel computes them
+        float absdot = 0.0f, sq = 0.0f, absw = 0.0f;
+        for (int k = 0; k < K2; ++k) {
+            const float w = static_cast<uint32_t>(k) < d.K ? static_cast<float>(d.omega[static_cast<size_t>(i) * d.OMS + k]) : 0.0f;
+            row[44 + k] = w;
+            absdot = fmaf(fabsf(w), d.stats[k], absdot);
+            sq = fmaf(w, w, sq);
+            absw += fabsf(w);
+        }
+        const float Ahat = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
+        double delta = static_cast<double>(d.K + 5) * 5.9604644775390625e-08 * static_cast<double>(Ahat) + kDeltaFixedBf16 +
+                       kDeltaPerRescale * static_cast<double>(d.cache_resc[i]);
+        if (d.f16) delta += 12.0 * 5.9604644775390625e-08 * static_cast<double>(Ahat) +
+                            2.98023223876953125e-08 * (static_cast<double>(gsum) + 0.6931471805599453 * static_cast<double>(absw));
+        const float2* rec = d.cache_rec + static_cast<size_t>(i) * kMaxSC;
+        float Q = -INFINITY;
+        for (uint32_t sc = 0; sc < d.n_sc; ++sc) Q = fmaxf(Q, rec[sc].y);
+        uint32_t offw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t sc = 0; sc < kMaxSC; ++sc) {
+            float x = 0.0f;
+            uint32_t off = 127u;                                        // unused / out of range: weight 0, never chosen
+            if (sc < d.n_sc) {
+                const float2 r = rec[sc];
+                const float dq = Q - r.y;                               // references are integers (log2 units)
+                if (dq < 127.0f) { off = static_cast<uint32_t>(dq); x = r.x * __builtin_amdgcn_exp2f(-dq); }
+            }
+            row[sc] = x;
+            offw[sc >> 2] |= off << (8 * (sc & 3));
+        }
+        row[32] = Q;
+        row[33] = static_cast<float>(delta * 1.000001);                 // rounded up: the budget must not shrink
+        row[34] = 0.0f; row[35] = 0.0f;
+        for (int q = 0; q < 8; ++q) row[36 + q] = __builtin_bit_cast(float, offw[q]);
+    }
+}
+
+template <int KH>
+__global__ void __launch_bounds__(kBlock, (KH <= 16 ? 3 : 2)) k_draw_cached(DevSim d, uint32_t t) {
+    constexpr int K2 = 2 * KH;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    float* om_w = reinterpret_cast<float*>(smem_raw) + static_cast<size_t>(wave) * 64 * K2;   // [64 users][K2] omega32
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const uint32_t n_groups = (n_o + 63) / 64;
+    for (uint32_t grp = blockIdx.x * (kBlock / 64) + wave; grp < n_groups; grp += gridDim.x * (kBlock / 64)) {
+        const uint32_t pos = grp * 64 + lane;
+        const bool active = pos < n_o;
+        const uint32_t slot = active ? cur[pos] : 0u;
+        const uint32_t uidx = active ? d.uid[slot] : 0u;
+        const size_t row = active ? uidx : d.n_cap;                       // inactive lanes read the dummy row
+        // ---- phase 1: the user's row — scaled super-chunk sums, reference, delta, offsets, omega32 ----
+        const float4* rp = reinterpret_cast<const float4*>(d.cache_row + row * d.cache_row_f);
+        float W[kMaxSC];
+#pragma unroll
+        for (int i = 0; i < kMaxSC / 4; ++i) {
+            const float4 x = rp[i];
+            W[4 * i] = x.x; W[4 * i + 1] = x.y; W[4 * i + 2] = x.z; W[4 * i + 3] = x.w;
+        }
+        const float4 hdr = rp[8];
+        const float4 of0 = rp[9], of1 = rp[10];
+        {
+            float* o = om_w + lane * K2;
+#pragma unroll
+            for (int k4 = 0; k4 < K2 / 4; ++k4) *reinterpret_cast<float4*>(o + 4 * k4) = rp[11 + k4];
+#pragma unroll
+            for (int k = (K2 / 4) * 4; k < K2; ++k) o[k] = reinterpret_cast<const float*>(rp)[44 + k];
+        }
+        const float Q = hdr.x;
+        const double delta = static_cast<double>(hdr.y);
+        double S = 0.0;
+#pragma unroll
+        for (uint32_t sc = 0; sc < kMaxSC; ++sc) S += static_cast<double>(W[sc]);     // unused records hold 0
+        const uint32_t user = static_cast<uint32_t>(d.first_user + uidx);
+        const double tau = organic_uniform(d, uidx, user, t) * S;
+        double pb = 0.0;
+        uint32_t sc_star = d.n_sc - 1;
+        bool found_sc = false;
+        {
+            double run = 0.0;
+#pragma unroll
+            for (uint32_t sc = 0; sc < kMaxSC; ++sc) {
+                const double Wd = static_cast<double>(W[sc]);
+                if (sc < d.n_sc && !found_sc && run + Wd > tau) { found_sc = true; sc_star = sc; pb = run; }
+                if (sc < d.n_sc && !found_sc) run += Wd;
+            }
+        }
+        // scale of that super-chunk's chunk sums: 2^-(offset of its reference)
+        uint32_t offw;
+        {
+            const uint32_t q = sc_star >> 2;
+            const float4 o4 = q < 4 ? of0 : of1;
+            const float ow = (q & 3) == 0 ? o4.x : (q & 3) == 1 ? o4.y : (q & 3) == 2 ? o4.z : o4.w;
+            offw = (__builtin_bit_cast(uint32_t, ow) >> (8 * (sc_star & 3))) & 0xFFu;
+        }
+        if (offw >= 127u) found_sc = false;
+        const float f_star = found_sc ? __builtin_amdgcn_exp2f(-static_cast<float>(offw)) : 1.0f;
+        // ---- phase 2: the chunk inside that super-chunk ----
+        uint32_t c_star = 0;
+        bool found_c = false;
+        {
+            const uint32_t c0 = sc_star * d.sc_chunks, c1 = min(c0 + d.sc_chunks, d.n_chunks);
+            const float* cp = d.cache_chunk + row * d.n_chunks;
+            double run = pb;
+            for (uint32_t cb = c0; cb < c1; cb += 16) {
+                float4 w4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    w4[i] = cb + 4 * i < c1 ? *reinterpret_cast<const float4*>(cp + cb + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float4 q4 = w4[i >> 2];
+                    const float wv = (i & 3) == 0 ? q4.x : (i & 3) == 1 ? q4.y : (i & 3) == 2 ? q4.z : q4.w;
+                    const double Wd = static_cast<double>(wv * f_star);
+                    const uint32_t c = cb + i;
+                    if (c < c1 && !found_c && run + Wd > tau) { found_c = true; c_star = c; pb = run; }
+                    if (c < c1 && !found_c) run += Wd;
+                }
+            }
+        }
+        found_c = found_c && found_sc;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // omega32 stage written above, read by other lanes below
+        __builtin_amdgcn_wave_barrier();
+        // ---- phase 3: two users per pass — user i on lanes 0-31, user i + 32 on lanes 32-63 (each user's own lane
+        // sits in the half that works for it) — a lane per product of the chosen chunk ----
+        const int half = lane >> 5, p = lane & 31;
+        const uint32_t n_here = min(32u, n_o - grp * 64);
+        uint32_t my_v = 0;
+        bool my_ok = false;
+        // the table values of pass i + 1 are requested before pass i is worked on: a pass is a chain of ~15
+        // dependent cross-lane / memory round trips, and nothing else of this wave would overlap the L2 latency
+        float gn[K2], mun;
+        uint32_t csn = static_cast<uint32_t>(__shfl(static_cast<int>(c_star), 32 * half));
+        {
+            const float* gp = d.gamma32t + (static_cast<size_t>(csn) * K2) * 32 + p;
+#pragma unroll
+            for (int k = 0; k < K2; ++k) gn[k] = gp[k * 32];
+            mun = d.mu32[csn * 32 + p];
+        }
+        if (d.ablate & 1024u) { my_v = c_star * 32; my_ok = c_star * 32 < d.P; }
+        else
+        for (uint32_t i = 0; i < n_here; ++i) {
+            const int src = static_cast<int>(i) + 32 * half;             // the user this half works for
+            const uint32_t cs = csn;
+            float g[K2];
+#pragma unroll
+            for (int k = 0; k < K2; ++k) g[k] = gn[k];
+            float l = mun;
+            if (i + 1 < n_here) {
+                csn = static_cast<uint32_t>(__shfl(static_cast<int>(c_star), src + 1));
+                const float* gp = d.gamma32t + (static_cast<size_t>(csn) * K2) * 32 + p;
+#pragma unroll
+                for (int k = 0; k < K2; ++k) gn[k] = gp[k * 32];
+                mun = d.mu32[csn * 32 + p];
+            }
+            const float Qs = __shfl(Q, src);
+            const double pbs = __shfl(pb, src), taus = __shfl(tau, src);
+            const float* o = om_w + src * K2;
+#pragma unroll
+            for (int k4 = 0; k4 < K2 / 4; ++k4) {
+                const float4 w4 = *reinterpret_cast<const float4*>(o + 4 * k4);
+                l = fmaf(g[4 * k4], w4.x, l); l = fmaf(g[4 * k4 + 1], w4.y, l);
+                l = fmaf(g[4 * k4 + 2], w4.z, l); l = fmaf(g[4 * k4 + 3], w4.w, l);
+            }
+#pragma unroll
+            for (int k = (K2 / 4) * 4; k < K2; ++k) l = fmaf(g[k], o[k], l);
+            const float e = __builtin_amdgcn_exp2f(fmaf(l, kLog2e, -Qs));
+            float incl = e;                                              // inclusive prefix over the half's 32 lanes
+#pragma unroll
+            for (int o2 = 1; o2 < 32; o2 <<= 1) {
+                const float y = __shfl_up(incl, o2, 32);
+                if (p >= o2) incl += y;
+            }
+            const double px = pbs + static_cast<double>(incl);
+            const unsigned long long hits = __ballot(px > taus);
+            const uint32_t hmask = static_cast<uint32_t>(half ? (hits >> 32) : hits);
+            const int idx = hmask ? __builtin_ctz(hmask) : -1;
+            const int li = half * 32 + max(idx, 0);
+            const double Bv = __shfl(px, li);
+            const double Av = idx > 0 ? __shfl(px, li - 1) : pbs;
+            if (lane == src) {
+                const uint32_t v = cs * 32 + static_cast<uint32_t>(max(idx, 0));
+                my_v = v;
+                my_ok = found_c && idx >= 0 && v < d.P &&
+                        (v == 0 || Av * (1.0 + delta) < tau * (1.0 - delta)) &&
+                        (v == d.P - 1 || tau * (1.0 + delta) < Bv * (1.0 - delta));
+            }
+        }
+        // ---- emit (a lane per user) ----
+        if (active) {
+            if (my_ok) {
+                write_organic_row(d, t, pos, slot, user, my_v);
+                if (d.hist_cap && !(d.ablate & 2048u)) history_add(d, slot, my_v);
+            } else if (d.f64_valid[uidx]) d.exact_list[d.n_cap - 1u - atomicAdd(&d.exact_cnt_b[t], 1u)] = pos;
+            else {
+                d.exact_list[atomicAdd(&d.exact_cnt[t], 1u)] = pos;
+                d.exact_ref[uidx] = Q;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                                 // the omega32 stage is reused by the next group
+    }
+}
+
+typedef void (*finalize_kernel_t)(DevSim);
+finalize_kernel_t finalize_kernel_for(const DevSim& d) {
+    switch (d.KH) {
+        case 4: return k_cache_finalize<4>;
+        case 10: return k_cache_finalize<10>;
+        case 16: return k_cache_finalize<16>;
+        default: return k_cache_finalize<32>;
+    }
+}
+typedef void (*cached_kernel_t)(DevSim, uint32_t);
+cached_kernel_t cached_kernel_for(const DevSim& d) {
+    switch (d.KH) {
+        case 4: return k_draw_cached<4>;
+        case 10: return k_draw_cached<10>;
+        case 16: return k_draw_cached<16>;
+        default: return k_draw_cached<32>;
+    }
+}
+
 // kernel selection by (KH, N1, N2, N3)
 typedef void (*draw_kernel_t)(DevSim, uint32_t, uint32_t);
 typedef void (*search_kernel_t)(DevSim, uint32_t);
@@ -2141,9 +2490,8 @@ draw_kernel_t bf16_kernel_for(const DevSim& d) {
 // multiply then add, intercept last); the wave reduction keeps the smallest class index among equal
 // maxima = numpy's first-maximum argmax.  `slot` must be wave-uniform.
 __device__ uint32_t logreg_act_wave(const DevSim& d, uint32_t slot, int lane) {
-    const uint32_t nd = d.hist_n[slot];
-    const uint32_t* hp = d.hist + static_cast<size_t>(slot) * d.hist_cap;
-    const uint16_t* hc = d.hist_cntv + static_cast<size_t>(slot) * d.hist_cap;
+    const hent_t* hr = hist_row(d, slot) + 1;             // entries after the header
+    const uint32_t nd = h_cnt(hr[-1]);
     double best_s = -INFINITY;
     uint32_t best_c = 0xFFFFFFFFu;
     // four class blocks per pass and four history entries per batch: 16 independent loads in flight per
@@ -2158,9 +2506,9 @@ __device__ uint32_t logreg_act_wave(const DevSim& d, uint32_t slot, int lane) {
             double w[4][4], cnt[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const uint32_t i = min(i0 + e, nd - 1);
-                cnt[e] = static_cast<double>(hc[i]);
-                const double* row = d.lr_coef_t + static_cast<size_t>(hp[i]) * d.lr_n;
+                const hent_t x = hr[min(i0 + e, nd - 1)];
+                cnt[e] = static_cast<double>(h_cnt(x));
+                const double* row = d.lr_coef_t + static_cast<size_t>(h_prod(x)) * d.lr_n;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) w[e][q] = row[cc[q]];
             }
@@ -2255,8 +2603,7 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                         wpre[k2] = *reinterpret_cast<const double2*>(om_row + 2 * min(static_cast<uint32_t>(k2), d.K / 2 - 1));
                 }
                 uint32_t touch2 = 0;
-                if (d.hist_cap) touch2 = d.hist[static_cast<size_t>(slot) * d.hist_cap] +
-                                         d.hist_cntv[static_cast<size_t>(slot) * d.hist_cap];
+                if (d.hist_cap) touch2 = static_cast<uint32_t>(d.hist[static_cast<size_t>(slot) * d.hist_cap]);
                 // step_offline: the policy acts (abstract.py:202-221), then draw_click
                 double ps;
                 uint32_t a;
@@ -2681,12 +3028,10 @@ __global__ void __launch_bounds__(kBlock) k_repack_copy(DevSim d, uint32_t t) {
             if (d.lpv) d.lpv_alt[i] = d.lpv[old];
         }
         if (d.hist_cap) {
-            const uint32_t hn = d.hist_n[old];
-            if (sub == 0) d.hist_n_alt[i] = hn;
-            for (uint32_t e = sub; e < hn; e += 32) {
-                d.hist_alt[static_cast<size_t>(i) * d.hist_cap + e] = d.hist[static_cast<size_t>(old) * d.hist_cap + e];
-                d.hist_cntv_alt[static_cast<size_t>(i) * d.hist_cap + e] = d.hist_cntv[static_cast<size_t>(old) * d.hist_cap + e];
-            }
+            const hent_t* src = d.hist + static_cast<size_t>(old) * d.hist_cap;
+            hent_t* dst = d.hist_alt + static_cast<size_t>(i) * d.hist_cap;
+            const uint32_t hn = h_cnt(src[0]) + 1u;               // header + products
+            for (uint32_t e = sub; e < hn; e += 32) dst[e] = src[e];
         }
     }
 }
@@ -2867,8 +3212,7 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         DevSim& m = sim->d;
         hipLaunchKernelGGL(k_repack_copy, dim3(grid_for(upper, kBlock / 32)), dim3(kBlock), 0, st, m, t);
         hipLaunchKernelGGL(k_repack_lists, dim3(grid_for(upper)), dim3(kBlock), 0, st, m, t);
-        std::swap(m.omega, m.omega_alt); std::swap(m.hist, m.hist_alt); std::swap(m.hist_cntv, m.hist_cntv_alt);
-        std::swap(m.hist_n, m.hist_n_alt); std::swap(m.uid, m.uid_alt);
+        std::swap(m.omega, m.omega_alt); std::swap(m.hist, m.hist_alt); std::swap(m.uid, m.uid_alt);
         if (m.lpv) std::swap(m.lpv, m.lpv_alt);
         sim->repacked = true;
         if (getenv("RECOGYM_DEBUG")) fprintf(stderr, "[recogym] repack at t=%u (upper %u)\n", t, upper);
@@ -2878,8 +3222,12 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     if (d.use_mfma == 2 && d.use_cache && t > 0) {
         // sigma_omega == 0, after step 0: every live user's exp-sums are in the per-user cache — search only
         if (int rc = prof_mark(sim, st)) return rc;
-        hipLaunchKernelGGL(search_kernel_for(d), dim3(grid_for(upper, 128)), dim3(kBlock),
-                           sizeof(float) * 4 * 32 * 2 * d.KH, st, d, t);
+        if (sim->cached_search_old)
+            hipLaunchKernelGGL(search_kernel_for(d), dim3(grid_for(upper, 128)), dim3(kBlock),
+                               sizeof(float) * 4 * 32 * 2 * d.KH, st, d, t);
+        else
+            hipLaunchKernelGGL(cached_kernel_for(d), dim3(grid_for(upper, kBlock)), dim3(kBlock),
+                               sizeof(float) * (kBlock / 64) * 64 * 2 * d.KH, st, d, t);
         if (int rc = prof_mark(sim, st)) return rc;
         launch_exact(sim, t, 1, upper / 100 + 16, st);
     } else if (d.use_mfma == 2) {
@@ -2895,6 +3243,8 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         if (S > 1)
             hipLaunchKernelGGL(search_kernel_for(d), dim3(grid_for(upper, 128)), dim3(kBlock),
                                sizeof(float) * 4 * 32 * 2 * d.KH, st, d, t);
+        if (d.use_cache)       // step 0 of a sigma_omega == 0 run: the rows every later draw starts from
+            hipLaunchKernelGGL(finalize_kernel_for(d), dim3(grid_for(d.n_users)), dim3(kBlock), 0, st, d);
         if (int rc = prof_mark(sim, st)) return rc;
         launch_exact(sim, t, 1, upper / 100 + 16, st);
     } else if (d.use_mfma) {
@@ -3037,6 +3387,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
         if (d.policy == RG_POLICY_LOGREG_FROZEN) s->tail_below = 0;
     }
     s->prof_tail_ms = 0.0;
+    s->cached_search_old = false;
+    if (const char* e = getenv("RECOGYM_CACHED")) s->cached_search_old = !strcmp(e, "search");
     if (const char* e = getenv("RECOGYM_TAIL")) s->tail_below = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_REPACK")) s->repack_every = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_ABLATE")) d.ablate = static_cast<uint32_t>(atoi(e));
