@@ -1,20 +1,21 @@
 #!/usr/bin/env python
 """bench.py — env steps/s (= log rows emitted/s) of the reco-gym-v1 step loop on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N=1: run directly)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W      N > 1 without a launcher: bench.py starts its own N
+                                                       ranks under torch.distributed.run (127.0.0.1 rendezvous)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (also fine)
 
-A "step" is one pass of the hot path over one batch of synthetic input: U concurrent users are
-reset and simulated to completion (every Markov transition, organic product draw, click draw,
-policy action and log row of `env.generate_logs(U, agent)`), inputs resident in HBM.  The
-workload is BASELINE.json's headline configuration (configs[2], the one `metric` is quoted on):
-reco-gym-v1, P=10 000 products, K=20, sigma_omega=0, OrganicUserEventCounterAgent in the loop,
-10 M users per GPU.  Users shard across ranks by id range with no data-path collective; one
-RCCL all-reduce of the click/impression counters closes each step, so per-GPU
-work is fixed as N grows ("weak").
+A "step" is one pass of the hot path over one batch of synthetic input: the rank's users are reset and
+simulated to completion (every Markov transition, organic product draw, click draw, policy action and log row
+of `env.generate_logs(U, agent)`), inputs resident in HBM.  The default workload is BASELINE.json's headline
+configuration (configs[2], the one `metric` is quoted on): reco-gym-v1, P=10 000 products, K=20, sigma_omega=0,
+OrganicUserEventCounterAgent in the loop, 10 M users per GPU.  Users shard across ranks by id range with no
+data-path collective; one RCCL all-reduce of the click/impression counters closes each step.
+`--scaling weak` (default) keeps the per-GPU users fixed as N grows, `--scaling strong` keeps the TOTAL fixed
+(10 M users over N GPUs, the way north_star states the target).
 
-Prints ONE JSON line (rank 0).  `value` counts real rows (organic + bandit; the per-user
-phantom row is excluded) over all ranks / max-over-ranks wall time.
+Prints ONE JSON line (rank 0).  `value` counts real rows (organic + bandit; the per-user phantom row is
+excluded) over all ranks / max-over-ranks wall time.
 """
 import argparse
 import json
@@ -25,87 +26,155 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 WORKLOADS = {
-    # name: (env overrides, users per GPU, policy)
-    'c3': (dict(num_products=10000, K=20, sigma_omega=0.0), 10_000_000, 'ouc'),
-    'c2': (dict(num_products=1000, K=20, sigma_omega=0.0), 1_000_000, 'random'),
-    'c4shard': (dict(num_products=100000, K=64, sigma_omega=0.1), 1_250_000, 'none'),
-    'tiny': (dict(num_products=100, K=20, sigma_omega=0.0), 20_000, 'ouc'),
+    # name: (env overrides, users per GPU (weak) , users in total (strong), policy)
+    'c3': (dict(num_products=10000, K=20, sigma_omega=0.0), 10_000_000, 10_000_000, 'ouc'),
+    'c3drift': (dict(num_products=10000, K=20, sigma_omega=0.1), 10_000_000, 10_000_000, 'ouc'),
+    'c2': (dict(num_products=1000, K=20, sigma_omega=0.0), 1_000_000, 1_000_000, 'random'),
+    'c4shard': (dict(num_products=100000, K=64, sigma_omega=0.1), 1_250_000, 10_000_000, 'none'),
+    'tiny': (dict(num_products=100, K=20, sigma_omega=0.0), 20_000, 20_000, 'ouc'),
 }
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-F16_MFMA_PEAK_TFLOPS = 2516.6      # v_mfma_f32_32x32x16_f16, dense (256 CUs x 4 SIMDs x 1024 flop/cycle x 2.4 GHz)
-BF16_MFMA_PEAK_TFLOPS = 2516.6
+F16_MFMA_PEAK_TFLOPS = 2516.6      # v_mfma_f32_32x32x16_f16 / bf16, dense (256 CUs x 4 SIMDs x 1024 flop/cycle x 2.4 GHz)
+F64_VALU_PEAK_TFLOPS = 78.6
 HBM_PEAK_GBPS = 8000.0
 
 
-def make_sim(workload, users, device, log_rows):
+def policy_kwargs(pol):
     from recogym_amd import _abi
+    if pol == 'ouc':
+        return dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=42,
+                    ouc=dict(select_randomly=True, epsilon=0.0, exploit_explore=True, reverse_pop=False))
+    if pol == 'random':
+        return dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=42)
+    return {}
+
+
+def make_config(workload):
     from recogym_amd.envs.configuration import Configuration
     from recogym_amd.envs.reco_env_v1 import env_1_args
+    return Configuration({**env_1_args, 'random_seed': 42, **WORKLOADS[workload][0]})
+
+
+def make_sim(workload, users, device, log_rows):
     from recogym_amd.sim import Simulator
-    over, _, pol = WORKLOADS[workload]
-    cfg = Configuration({**env_1_args, 'random_seed': 42, **over})
-    kw = {}
-    if pol == 'ouc':
-        kw = dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=42,
-                  ouc=dict(select_randomly=True, epsilon=0.0, exploit_explore=True,
-                           reverse_pop=False))
-    elif pol == 'random':
-        kw = dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=42)
-    return cfg, Simulator(cfg, users, device=device, log_capacity=log_rows, **kw), kw
+    cfg = make_config(workload)
+    return cfg, Simulator(cfg, users, device=device, log_capacity=log_rows, **policy_kwargs(WORKLOADS[workload][3]))
 
 
 def cpu_baseline(workload, seconds_target=12.0):
-    """The oracle (plain-C float64 port of the reference loop) on a bounded sample of the same workload,
-    on ALL host cores: trajectories are keyed by (seed, user id), so every thread replays its own id
-    range with its own oracle instance (ctypes releases the GIL).  Test infrastructure used as the
-    reported CPU baseline only."""
+    """The oracle (plain-C float64 port of the reference loop, oracle/recogym_oracle.c) on a bounded sample of the
+    same workload on ALL host cores: trajectories are keyed by (seed, user id), so every thread replays its own id
+    range with its own oracle instance (ctypes releases the GIL; no allocation inside the loop).  Test
+    infrastructure used as the reported CPU baseline only.  The unmodified NumPy reference cannot run on the GPU
+    box (no /root/reference there): its events/s measured in the build container is quoted beside it."""
     import threading
     from oracle import oracle as orc
-    from recogym_amd import _abi
-    from recogym_amd.envs.configuration import Configuration
-    from recogym_amd.envs.reco_env_v1 import env_1_args
-    over, _, pol = WORKLOADS[workload]
-    cfg = Configuration({**env_1_args, 'random_seed': 42, **over})
-    kw = {}
-    if pol == 'ouc':
-        kw = dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=42,
-                  ouc=dict(select_randomly=True, epsilon=0.0, exploit_explore=True,
-                           reverse_pop=False))
-    elif pol == 'random':
-        kw = dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=42)
+    cfg = make_config(workload)
+    kw = policy_kwargs(WORKLOADS[workload][3])
     cores = max(1, min(os.cpu_count() or 1, 64))
     orc.lib()                                   # build / load once, before the threads start
-    results = [None] * cores
 
-    def work(k):
-        env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **kw)
-        first = 1_000_000 * k                   # disjoint id ranges
-        users, events, batch = 0, 0, 25
+    def measure(n_threads, seconds):
+        results = [None] * n_threads
+
+        def work(k):
+            env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **kw)
+            first = 1_000_000 * k               # disjoint id ranges
+            users, events, batch = 0, 0, 25
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < seconds and users < 20000:
+                rows = env.generate_logs(batch, first_user_id=first + users, capacity=batch * 2000 + 10000)
+                events += int((rows['phantom'] == 0).sum())
+                users += batch
+            results[k] = (users, events)
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
         t0 = time.perf_counter()
-        while time.perf_counter() - t0 < seconds_target and users < 20000:
-            rows = env.generate_logs(batch, first_user_id=first + users, capacity=batch * 2000 + 10000)
-            events += int((rows['phantom'] == 0).sum())
-            users += batch
-        results[k] = (users, events, time.perf_counter() - t0)
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        wall = time.perf_counter() - t0
+        return sum(r[0] for r in results), sum(r[1] for r in results), wall
 
-    threads = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
-    t0 = time.perf_counter()
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    wall = time.perf_counter() - t0
-    users = sum(r[0] for r in results)
-    events = sum(r[1] for r in results)
-    return dict(value=events / wall, unit='events/s', cores=cores, kind='port',
-                per_core=events / wall / cores,
-                sample=f'{users} users / {events} events of the same workload in {wall:.1f} s on {cores} '
-                       f'threads (oracle/recogym_oracle.c, float64, one oracle instance per thread)')
+    u1, e1, w1 = measure(1, 3.0)
+    users, events, wall = measure(cores, seconds_target)
+    out = dict(value=events / wall, unit='events/s', cores=cores, kind='port',
+               per_core=events / wall / cores, one_thread=e1 / w1,
+               sample=f'{users} users / {events} events of the same workload in {wall:.1f} s on {cores} threads '
+                      f'(oracle/recogym_oracle.c, float64, one oracle instance per thread); one thread alone: '
+                      f'{e1 / w1:.0f} events/s')
+    try:      # the NumPy reference itself, measured where /root/reference exists (tools/time_reference.py)
+        ref = json.load(open(os.path.join(ROOT, 'profiles', 'r2', 'numpy_reference_cpu.json')))
+        case = {'c3': 'c3', 'c3drift': 'c3', 'c2': 'c2', 'c4shard': 'c4_capped', 'tiny': 'c1'}[workload]
+        rc = ref['cases'][case]
+        out['reference_numpy'] = dict(
+            one_core_events_per_s=rc['one_core_events_per_s'], all_core_events_per_s=rc['all_core_events_per_s'],
+            processes=rc['processes'], case=case, env=rc['env'], agent=rc['agent'], users=rc['users'],
+            provenance=f"unmodified criteo-research/reco-gym (NumPy {ref['numpy']}, numba absent) timed by "
+                       f"tools/time_reference.py in the build container ({ref['cpu_count']} vCPU), NOT on this box; "
+                       f"profiles/r2/numpy_reference_cpu.json")
+    except Exception:
+        out['reference_numpy'] = None
+    return out
+
+
+def kernel_rooflines(cfg, prof, c, users, cached, pol):
+    """Per-kernel rooflines from the HIP-event timings the library records on its launch stream
+    (rg_sim_set_profiling).  Algorithmic units follow SURVEY.md §8d (stated in DESIGN.md §6)."""
+    P, K = cfg.num_products, cfg.K
+    f16_split = (3 * K + 1) <= 64
+    out = {}
+    # organic product sweeps on the matrix pipe: 2*P*K flop per swept draw.  With sigma_omega = 0 only a user's
+    # first draw sweeps (the rest search the per-user cache); otherwise every lock-step organic draw does.
+    swept = users if cached else c['organic']
+    if prof['draw_mfma_ms'] > 0:
+        tf = 2.0 * P * K * swept / (prof['draw_mfma_ms'] * 1e-3) / 1e12
+        peak = F16_MFMA_PEAK_TFLOPS if K <= 64 else FP32_MFMA_PEAK_TFLOPS
+        out['draw_sweep'] = dict(kernel='k_draw_bf16p' if K <= 21 else 'k_draw_* (K class)', bound='mfma',
+                                 ms=round(prof['draw_mfma_ms'], 2), units=int(swept), unit_name='swept draws',
+                                 achieved=round(tf, 2), peak=peak, unit='TFLOP/s', frac=round(tf / peak, 4),
+                                 executed_mfma_tflops=round(tf * (64.0 if f16_split else 144.0) / K, 1) if K <= 21 else None)
+    # cached draw (sigma_omega = 0, t >= 1): per draw the user's 32 super-chunk sums (128 B), the chosen
+    # super-chunk's chunk sums (48 B), omega32 (4K) and the 16-byte row: HBM gather
+    if cached and prof['draw_search_ms'] > 0:
+        n = c['organic'] - users
+        by = 128 + 48 + 4 * K + 16
+        gbps = by * n / (prof['draw_search_ms'] * 1e-3) / 1e9
+        out['draw_cached'] = dict(kernel='k_draw_cached', bound='hbm', ms=round(prof['draw_search_ms'], 2), units=int(n),
+                                  unit_name='cached draws', bytes_per_unit=by, achieved=round(gbps, 1),
+                                  peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(gbps / HBM_PEAK_GBPS, 4))
+    # float64 resolve: per sweep P * (2K + ~16) float64 flop-equivalents on the VALU
+    if prof['draw_exact_ms'] > 0 and c['exact_sweeps'] > 0:
+        tf = c['exact_sweeps'] * float(P) * (2 * K + 16) / (prof['draw_exact_ms'] * 1e-3) / 1e12
+        out['draw_exact_f64'] = dict(kernel='k_exact_sums_u + k_exact_pick', bound='f64 valu', ms=round(prof['draw_exact_ms'], 2),
+                                     units=int(c['exact_sweeps']), unit_name='float64 sweeps', achieved=round(tf, 2),
+                                     peak=F64_VALU_PEAK_TFLOPS, unit='TFLOP/s', frac=round(tf / F64_VALU_PEAK_TFLOPS, 4),
+                                     resolved_draws=int(c['exact_draws']))
+    # advance: SURVEY.md 8d bytes per event — bandit: omega 4K + state 8 + row 16 + action 3 (+35 history with the
+    # OUC agent in the loop); organic: state 8 (+ omega write 4K when it drifts)
+    if prof['advance_ms'] > 0:
+        b_b = 4 * K + 8 + 16 + 3 + (35 if pol == 'ouc' else 0)
+        b_o = 8 + (4 * K if cfg.sigma_omega != 0 else 0)
+        by = b_b * c['bandit'] + b_o * c['organic']
+        gbps = by / (prof['advance_ms'] * 1e-3) / 1e9
+        out['advance'] = dict(kernel='k_advance', bound='hbm', ms=round(prof['advance_ms'], 2),
+                              units=int(c['bandit'] + c['organic']), unit_name='events',
+                              bytes_per_unit=round(by / max(c['bandit'] + c['organic'], 1), 1),
+                              achieved=round(gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(gbps / HBM_PEAK_GBPS, 4))
+    return out
+
+
+def measured_traffic(name):
+    """HBM bytes per unit of a kernel from the committed rocprofv3 --pmc passes (profiles/r2/pmc_traffic.json;
+    PMC counters cannot be read from inside this process) — None when that kernel was not profiled."""
+    try:
+        pt = json.load(open(os.path.join(ROOT, 'profiles', 'r2', 'pmc_traffic.json')))
+        return pt['kernels'][name]
+    except Exception:
+        return None
 
 
 def main():
@@ -114,20 +183,20 @@ def main():
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
-    ap.add_argument('--users', type=int, default=0, help='users per GPU (default: workload size)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--users', type=int, default=0, help='users per GPU (weak) / in total (strong); default: workload size')
     ap.add_argument('--no-log', action='store_true', help='counters only (no 16 B/row log writes)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-drift-line', action='store_true', help='skip the sigma_omega > 0 companion measurement')
     args = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
+    from recogym_amd import parallel
+    rc = parallel.self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    if rc is not None:
+        sys.exit(rc)
+
+    import torch
+    rank, local_rank, world, dist = parallel.init_from_env('nccl')
     assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     device = torch.device(f'cuda:{local_rank}')
     torch.cuda.set_device(device)
@@ -139,120 +208,115 @@ def main():
         dist.barrier()
 
     from recogym_amd.sim import default_log_capacity
-    users = args.users or WORKLOADS[args.workload][1]
-    over = WORKLOADS[args.workload][0]
-    cfg_probe, _, _ = WORKLOADS[args.workload]
-    from recogym_amd.envs.configuration import Configuration
-    from recogym_amd.envs.reco_env_v1 import env_1_args
-    log_rows = 0 if args.no_log else default_log_capacity(
-        Configuration({**env_1_args, **over}), users)
-    cfg, sim, _ = make_sim(args.workload, users, device, log_rows)
-    first_user = rank * users           # disjoint id ranges: identical to one big run
+    _, per_gpu, total, pol = WORKLOADS[args.workload]
+    if args.scaling == 'weak':
+        users = args.users or per_gpu
+        first_user = rank * users       # disjoint id ranges: identical to one big run
+        users_total = users * world
+    else:
+        users_total = args.users or total
+        first_user, users = parallel.shard_range(users_total, rank, world)
 
-    def one_step():
-        sim.reset_users(first_user, users)
-        sim.run()
-        c = sim.counters()
+    def build(workload, n):
+        log_rows = 0 if args.no_log else default_log_capacity(make_config(workload), n)
+        return make_sim(workload, n, device, log_rows)
+
+    cfg, sim = build(args.workload, users)
+
+    def one_step(s=None):
+        s = s or sim
+        s.reset_users(first_user, users)
+        s.run()
+        c = s.counters()
         vec = torch.tensor([c['organic'], c['bandit'], c['clicks'], c['phantom']],
                            dtype=torch.int64, device=device)
         if dist:
             dist.all_reduce(vec)        # the CTR reduction of test_agent / verify_agents
         return c, vec
 
-    for _ in range(args.warmup):
-        one_step()
-
     def sync():
         if dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    sync()
-    t0 = time.perf_counter()
-    totals = torch.zeros(4, dtype=torch.int64, device=device)
-    last = None
-    for _ in range(args.steps):
-        last, vec = one_step()
-        totals += vec
-    sync()
-    elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if dist:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-    totals = totals.cpu().numpy()
+    def timed(s, steps, warmup):
+        for _ in range(warmup):
+            one_step(s)
+        sync()
+        t0 = time.perf_counter()
+        totals = torch.zeros(4, dtype=torch.int64, device=device)
+        last = None
+        for _ in range(steps):
+            last, vec = one_step(s)
+            totals += vec
+        sync()
+        elapsed = time.perf_counter() - t0
+        el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        if dist:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item()), totals.cpu().numpy(), last
+
+    elapsed, totals, last = timed(sim, args.steps, args.warmup)
     events = int(totals[0] + totals[1])
     assert last['hist_overflow'] == 0 and last['log_dropped'] == 0 and last['live'] == 0, last
 
-    # --- roofline of the dominant kernel (k_draw_mfma), HIP events on the launch stream ---
-    roofline = None
+    def profile(s, config):
+        s.set_profiling(True)
+        s.reset_users(first_user, users)
+        s.run()
+        prof = s.profile()
+        c = s.counters()
+        s.set_profiling(False)
+        cached = config.sigma_omega == 0 and os.environ.get('RECOGYM_CACHE', '1') != '0' and config.K <= 63
+        return prof, c, kernel_rooflines(config, prof, c, users, cached, pol)
+
+    # --- per-kernel rooflines, HIP events on the launch stream; `roofline` = the kernel with the most time ---
+    roofline = kernels = None
     if rank == 0:
-        sim.set_profiling(True)
-        sim.reset_users(first_user, users)
-        sim.run()
-        prof = sim.profile()
-        c = sim.counters()
-        sim.set_profiling(False)
-        P, K = cfg.num_products, cfg.K
-        flops = 2.0 * P * K * c['organic']             # algorithmic: SURVEY.md §8(d)
+        prof, c, kernels = profile(sim, cfg)
+        dom = max((k for k in kernels if kernels[k]['bound'] in ('hbm', 'mfma')), key=lambda k: kernels[k]['ms'])
+        roofline = dict(kernels[dom])
         launches = max(prof['steps'], 1)
-        avg_ms = prof['draw_mfma_ms'] / launches
-        achieved = flops / (prof['draw_mfma_ms'] * 1e-3) / 1e12 if prof['draw_mfma_ms'] else 0.0
-        # HBM traffic of that kernel: PMC counters cannot be read from inside this process, so the
-        # per-draw figure measured offline with rocprofv3 --pmc (profiles/r1/pmc_traffic.json) is
-        # scaled to the average launch of this run; null when the workload differs from the profiled one
-        traffic = None
-        try:
-            pt = json.load(open(os.path.join(ROOT, 'profiles', 'r1', 'pmc_traffic.json')))
-            if (P, K) == (10000, 20):
-                traffic = pt['hbm_bytes_per_organic_draw'] * c['organic'] / launches
-        except Exception:
-            traffic = None
-        # The dominant kernel (k_draw_bf16p) puts the logit contraction on the f16 matrix pipe as a
-        # two-way fp16 split of fp32 operands (3 cross terms + the reference = 61 of 64 k-columns for
-        # K = 20), so `achieved` = algorithmic flops (2*P*K per draw) against the dense
-        # f16 MFMA peak.  What binds the kernel after that split is VALU issue, about half of it the
-        # one v_exp_f32 per logit: its rate is reported beside it as `exp`.
-        exps = float(P) * c['organic']
-        exp_rate = exps / (prof['draw_mfma_ms'] * 1e-3) if prof['draw_mfma_ms'] else 0.0
-        # v_exp_f32 issue cost ~5/3 of a plain VALU op (MI355X_MICROARCH.md) = ~6.7 cycles per wave64
-        exp_peak = 256 * 4 * (64 / (4 * 5.0 / 3.0)) * 2.4e9
-        f16_split = (3 * K + 1) <= 64
-        peak = F16_MFMA_PEAK_TFLOPS if f16_split else BF16_MFMA_PEAK_TFLOPS
-        roofline = dict(bound='mfma',
-                        kernel='organic draw kernel k_draw_bf16p (logits on the matrix pipe as a '
-                               + ('two-way fp16' if f16_split else 'three-way bf16') +
-                               ' split of fp32 operands, fp32 accumulate, every index certified against '
-                               'float64); algorithmic flops 2*P*K per draw vs the dense MFMA peak of that dtype',
-                        achieved=round(achieved, 3), peak=peak, unit='TFLOP/s',
-                        frac=round(achieved / peak, 4), traffic=traffic,
-                        launches=launches, avg_launch_ms=round(avg_ms, 4),
-                        executed_mfma_tflops=round(achieved * (64.0 if f16_split else 144.0) / K, 1),
-                        fp32_class_equiv_frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                        exp=dict(achieved_per_s=round(exp_rate, 1), peak_per_s=exp_peak,
-                                 frac=round(exp_rate / exp_peak, 4),
-                                 note='v_exp_f32: one per (user, product) logit = about half of the kernel\'s VALU issue slots; the kernel is VALU-issue bound'),
-                        kernel_ms=dict(draw_mfma=round(prof['draw_mfma_ms'], 2),
-                                       draw_search=round(prof['draw_search_ms'], 2),
-                                       draw_exact_f64=round(prof['draw_exact_ms'], 2),
-                                       advance=round(prof['advance_ms'], 2),
-                                       tail=round(prof['tail_ms'], 2)),
-                        exact_fraction=round(c['exact_draws'] / max(c['organic'], 1), 5),
-                        hbm_algorithmic_GBps=round(
-                            (events / args.steps) * (8 * K + 8 + 16 + 3 + 35) / 1e9 /
-                            (elapsed / args.steps), 1),
-                        # whole-job algorithmic HBM bytes (omega read, lists, row, action, history)
-                        # against the 8 TB/s roofline: the job is compute(exp)-bound, not HBM-bound
-                        hbm_roofline_frac=round(
-                            (events / args.steps) * (8 * K + 8 + 16 + 3 + 35) / 1e9 /
-                            (elapsed / args.steps) / HBM_PEAK_GBPS, 4))
+        if roofline['unit'] == 'GB/s':
+            roofline['achieved_is'] = ('algorithmic bytes (SURVEY.md 8d figure per unit x units) / total kernel time over '
+                                       f'{launches} launches; bound by scattered per-user gathers, not by streaming bandwidth')
+        roofline['launches'] = launches
+        roofline['avg_launch_ms'] = round(roofline['ms'] / launches, 4)
+        pmc = measured_traffic(roofline['kernel'].split(' ')[0])
+        roofline['traffic'] = None if pmc is None else pmc['hbm_bytes_per_unit'] * roofline['units'] / launches
+        roofline['traffic_source'] = None if pmc is None else pmc['source']
+        roofline['tail_ms'] = round(prof['tail_ms'], 2)
+        roofline['exact_fraction'] = round(c['exact_draws'] / max(c['organic'], 1), 5)
+        roofline['whole_job_hbm_algorithmic_GBps'] = round(
+            (events / args.steps / world) * (4 * cfg.K + 8 + 16 + 3 + (35 if pol == 'ouc' else 0)) / 1e9 / (elapsed / args.steps), 1)
+    sim.close()
+    del sim
+    torch.cuda.empty_cache()
+
+    # --- the sigma_omega > 0 companion of the headline workload: no per-user cache is possible there, every
+    # organic draw sweeps all P products on the matrix pipe — the line that shows the sweep kernel's quality ---
+    drift = None
+    if args.workload == 'c3' and not args.no_drift_line:
+        dcfg, dsim = build('c3drift', users)
+        d_el, d_tot, d_last = timed(dsim, 1, 1)
+        if rank == 0:
+            d_prof, d_c, d_k = profile(dsim, dcfg)
+            drift = dict(workload='c3drift: the same with sigma_omega=0.1 (omega drifts at every organic transition)',
+                         value=float(d_tot[0] + d_tot[1]) / d_el, unit='events/s', ms_per_step=1e3 * d_el,
+                         steps=1, warmup=1, kernels=d_k,
+                         exact_fraction=round(d_c['exact_draws'] / max(d_c['organic'], 1), 5))
+        dsim.close()
+        del dsim
+        torch.cuda.empty_cache()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:     # the CPU leg runs at N = 1 only
         cpu = cpu_baseline(args.workload)
 
     if rank == 0:
+        w = WORKLOADS[args.workload][0]
         out = {
-            'metric': 'env steps/sec (organic+bandit events emitted/sec), reco-gym-v1 P=10k K=20',
+            'metric': f'env steps/sec (organic+bandit events emitted/sec), reco-gym-v1 P={w["num_products"]} K={w["K"]}',
             'value': events / elapsed,
             'unit': 'events/s',
             'n_gpus': world,
@@ -260,17 +324,20 @@ def main():
             'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': args.scaling,
             'vs_baseline': None,
-            'dtype': 'f64 (state, click, transition, policy); organic logits on MFMA as a 2-way fp16 split of fp32 operands (fp32 accumulate), every index certified against f64',
+            'dtype': 'f64 (state, click, transition, policy, propensities); organic logits on MFMA as a 2-way fp16 split '
+                     'of fp32 operands (fp32 accumulate), every index certified against f64',
             'data': 'synthetic',
             'config': {'workload': f'{args.workload}: reco-gym-v1 P={cfg.num_products} K={cfg.K} '
-                                   f'sigma_omega={cfg.sigma_omega} policy={WORKLOADS[args.workload][2]}',
-                       'users_per_gpu': users, 'users_total': users * world,
+                                   f'sigma_omega={cfg.sigma_omega} policy={pol}',
+                       'users_per_gpu': users, 'users_total': users_total,
                        'events_per_step': events // args.steps,
-                       'log': 'off' if args.no_log else '16 B/row device log',
+                       'log': 'off' if args.no_log else '16 B/row device log + float64 ps side array',
                        'ctr': float(totals[2]) / max(float(totals[1] + totals[3]), 1.0)},
             'roofline': roofline,
+            'kernels': kernels,
+            'sigma_omega_gt0': drift,
             'cpu_baseline': cpu,
         }
         print(json.dumps(out))

@@ -234,3 +234,34 @@ def test_frozen_logreg_act_is_sklearn_predict():
                 counts[v] += 1
             a = agent.act(Observation(DefaultContext(99, 0), sessions), 0, False)
             assert a['a'] == m.predict(sparse.csr_matrix(counts.reshape(1, P)))[0] and a['ps'] == 1.0
+
+
+def test_self_launch_starts_its_own_ranks():
+    """`python bench.py --gpus N` must work without a launcher (the driver starts it that way): the script re-runs
+    itself under torch.distributed.run.  Same code path (parallel.self_launch + parallel.init_from_env) on CPU/gloo
+    with 2 ranks: shards tile the id range and the all-reduce sees both ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'launch_probe.py'), '--procs', '2', '--users', '1001'],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith('PROBE')][-1]
+    assert line == f'PROBE world=2 users=1001 ranks=2 idsum={sum(range(1001))}', line
+    # and a single process needs no launcher at all
+    out1 = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'launch_probe.py'), '--procs', '1'],
+                          capture_output=True, text=True, timeout=300, env=env)
+    assert out1.returncode == 0 and 'PROBE world=1 users=1001 ranks=1' in out1.stdout, out1.stderr[-2000:]
+
+
+def test_bench_workloads_and_cli_are_consistent():
+    """bench.py's argument surface the driver relies on (--gpus/--steps/--warmup, defaults that finish in
+    minutes) and its workload table (metric text follows the workload; strong scaling keeps the total fixed)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.WORKLOADS['c3'][0] == dict(num_products=10000, K=20, sigma_omega=0.0) and bench.WORKLOADS['c3'][3] == 'ouc'
+    assert bench.WORKLOADS['c4shard'][1] * 8 == bench.WORKLOADS['c4shard'][2] == 10_000_000
+    from recogym_amd import parallel
+    shards = [parallel.shard_range(10_000_000, r, 8) for r in range(8)]
+    assert sum(c for _, c in shards) == 10_000_000 and shards[0][0] == 0
+    assert all(shards[i][0] + shards[i][1] == shards[i + 1][0] for i in range(7))
