@@ -201,7 +201,8 @@ int rg_sim_read_counters(rg_sim* sim, int64_t* out, void* stream);
  * out[0..3] = total milliseconds spent in the MFMA organic-draw kernel, in its search kernel
  * (sliced mode only), in the float64 resolve kernels and in the advance kernel; out[4] =
  * profiled steps; out[5] = milliseconds in the tail kernel (rg_sim_run finishes the last users
- * of a run user by user instead of step by step).  `out` must hold 6 doubles.  Off by default. */
+ * of a run user by user instead of step by step, or — sigma_omega = 0 — the whole run user-major: k_walk);
+ * out[6], out[7] = milliseconds in round 1 / round 2 of k_walk.  `out` must hold 8 doubles.  Off by default. */
 int rg_sim_set_profiling(rg_sim* sim, int on);
 int rg_sim_get_profile(rg_sim* sim, double* out);
 

@@ -78,9 +78,14 @@ class LogregMulticlassIpsAgent(Agent):
         c = self.config
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')          # sklearn deprecates the spelled-out 'multinomial'
-            self.logreg = LogisticRegression(solver=getattr(c, 'solver', 'lbfgs'),
-                                             max_iter=getattr(c, 'max_iter', 5000),
-                                             random_state=c.random_seed).fit(feats, actions, deltas / pss)
+            kw = dict(solver=getattr(c, 'solver', 'lbfgs'), max_iter=getattr(c, 'max_iter', 5000),
+                      random_state=c.random_seed)
+            try:       # the reference asks for the softmax model explicitly (logreg_ips.py:93): with only two
+                # distinct actions in the log sklearn's default would fit a binary/OvR model instead
+                model = LogisticRegression(multi_class='multinomial', **kw)
+            except TypeError:                        # a scikit-learn without the argument: multinomial is its only form
+                model = LogisticRegression(**kw)
+            self.logreg = model.fit(feats, actions, deltas / pss)
         self.frozen = LogregFrozenAgent.from_sklearn(c, self.logreg)
         return self.frozen
 

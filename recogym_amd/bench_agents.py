@@ -15,8 +15,9 @@ from . import parallel
 from .envs.reco_env_v1 import device_policy_of
 
 
-def evaluate_counts(env, agent, num_users):
-    """-> (successes, failures) of `agent` over users 0..num_users-1, summed over all ranks.
+def evaluate_counts(env, agent, num_users, first_user_id=0):
+    """-> (successes, failures) of `agent` over users first_user_id .. first_user_id + num_users - 1, summed
+    over all ranks.
     successes = sum of c over bandit rows, failures = bandit rows - successes; the phantom row
     of every user counts as a failure exactly as in the reference (bench_agents.py:203-206)."""
     rank, ws, _ = parallel.world()
@@ -25,14 +26,14 @@ def evaluate_counts(env, agent, num_users):
         clicks = shown = 0
         dev = None
         if count:
-            cnt, sim = env.simulate(count, agent, first_user_id=first, log=False)
+            cnt, sim = env.simulate(count, agent, first_user_id=first_user_id + first, log=False)
             clicks, shown = cnt['clicks'], cnt['bandit'] + cnt['phantom']
             dev = sim.device
             sim.close()
         clicks, shown = parallel.all_reduce_counts([clicks, shown], dev)
         return clicks, shown - clicks
     # arbitrary Python agent: per-user path on rank 0's env (no sharding: agents are stateful)
-    data = env.generate_logs(num_users, agent)
+    data = env.generate_logs(num_users, agent, first_user_id=first_user_id)
     rewards = data[data['z'] == 'bandit']['c']
     successes = int(rewards.sum())
     return successes, int(rewards.shape[0]) - successes
@@ -45,9 +46,9 @@ def _learns(agent):
     return fn is not None and fn is not Agent.train and hasattr(agent, 'train')
 
 
-def _train(env, agent, num_offline_users, num_organic_offline_users):
+def _train(env, agent, num_offline_users, num_organic_offline_users, first_user_id=0):
     """The reference's offline protocol (bench_agents.py:168-190)."""
-    uid = 0
+    uid = first_user_id
     for _ in range(num_organic_offline_users):
         env.reset(uid)
         uid += 1
@@ -69,8 +70,17 @@ def _train(env, agent, num_offline_users, num_organic_offline_users):
 def test_agent(env, agent, num_offline_users=1000, num_online_users=100,
                num_organic_offline_users=0, num_epochs=1, epoch_with_random_reset=False,
                with_cache=False):
+    # The reference draws every user from one sequential stream: the online (evaluation) users are fresh draws that
+    # follow the offline (training) users, and without a random reset every epoch continues that stream.  With
+    # addressed draws (seed, user id, t) the same is obtained by user-id ranges: an epoch takes the ids
+    # [base, base + organic + offline) for training and the next `num_online_users` ids for evaluation; without
+    # epoch_with_random_reset the next epoch starts where this one ended (with it, the epoch re-keys the draws
+    # and ids restart at 0, as the reference's reset_random_seed(epoch) restarts its stream).
     successes = failures = 0
+    per_epoch = num_organic_offline_users + num_offline_users + num_online_users
     for epoch in range(num_epochs):
+        base = 0 if epoch_with_random_reset else epoch * per_epoch
+        eval_first = base + num_organic_offline_users + num_offline_users
         new_agent = deepcopy(agent)
         if epoch_with_random_reset:
             train_env = deepcopy(env)
@@ -82,12 +92,12 @@ def test_agent(env, agent, num_offline_users=1000, num_online_users=100,
         if hasattr(new_agent, 'train_from_log') and getattr(train_env, 'agent', None) is None:
             # the offline protocol shows the agent exactly the rows of generate_logs(offline users) under the
             # env's own uniform policy (bench_agents.py:168-190): produce that log on the device in one go
-            cnt, sim = train_env.simulate(num_offline_users, None, num_organic_offline_users)
+            cnt, sim = train_env.simulate(num_offline_users, None, num_organic_offline_users, first_user_id=base)
             new_agent.train_from_log(sim.log_columns(), num_organic_offline_users)
             sim.close()
         elif _learns(new_agent) and (getattr(new_agent, 'needs_training', False) or device_policy_of(new_agent) is None):
-            _train(train_env, new_agent, num_offline_users, num_organic_offline_users)
-        s, f = evaluate_counts(eval_env, new_agent, num_online_users)
+            _train(train_env, new_agent, num_offline_users, num_organic_offline_users, first_user_id=base)
+        s, f = evaluate_counts(eval_env, new_agent, num_online_users, first_user_id=eval_first)
         successes += s
         failures += f
     return (beta.ppf(0.500, successes + 1, failures + 1),

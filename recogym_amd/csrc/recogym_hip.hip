@@ -134,6 +134,10 @@ struct DevSim {
     // 33: the certificate's delta (rounded up), 34-35: - | [36,44) 32 int8: reference offset of every super-chunk
     // (scale of its chunk sums) | [44, 44 + 2 KH) omega32.  256 bytes at K <= 20: two lines instead of six
     float* cache_row; uint32_t cache_row_f;   // row stride in floats (multiple of 32)
+    // user-major walk of the sigma_omega == 0 mode (k_walk): users parked at their first uncertified draw
+    uint32_t sweep_only;      // the step-0 sweep only fills the cache (no search, no rows): k_walk draws t = 0 too
+    uint32_t* park_list;      // [n_cap + 64] user indices, reserved in chunks of 64 (0xFFFFFFFF = unused entry)
+    uint32_t* park_t;         // [n_cap] time of the parked draw
     uint8_t* f64_valid;       // [n_cap] exact_sums / exact_ref rows (indexed by user index in this mode) are valid
     uint32_t* exact_cnt_b;    // [kMaxSteps+2] draws to resolve whose float64 sums are already there: they sit at the
                               // BACK of exact_list (entry n_cap - 1 - i); those that need the sums at the front
@@ -184,6 +188,9 @@ struct rg_sim {
     bool tables_set, users_reset;
     bool repacked;            // slots no longer equal user indices (since the last reset)
     bool cached_search_old;   // RECOGYM_CACHED=search: the first form of the cached draw (k_draw_search over the cache)
+    bool walk;                // rg_sim_run "to the end" walks the run user-major (k_walk) instead of step-major
+    int n_cus;                // compute units of the device (grid of the persistent walk kernel)
+    double prof_walk_ms[2];   // round 1 / round 2 of k_walk
     uint32_t repack_every;    // steps between repacks (RECOGYM_REPACK, 0 = never)
     uint32_t tail_below;      // rg_sim_run hands the run to k_tail once at most this many users live (RECOGYM_TAIL, 0 = never)
     double prof_tail_ms;
@@ -215,6 +222,7 @@ struct Carve {
 };
 
 constexpr uint32_t kMaxSC = 32;           // stored partial sums per user in the MFMA draw kernel
+constexpr uint32_t kHoleCode = 0xFFFFFFFFu;   // rg_event.code of an unused raw-log entry (no real row has every bit set: P < 2^29)
 
 struct Geom { uint32_t KH, KS, TP, P_pad, n_chunks, sc_chunks, n_sc, N1, N2, N3, RS, TPB, F16; };
 
@@ -330,6 +338,8 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     float* cache_row = w.take<float>(cache ? (n + 1) * static_cast<size_t>(cache_row_f) : 1);
     uint8_t* f64_valid = w.take<uint8_t>(cache ? n : 1);
     uint32_t* exact_cnt_b = w.take<uint32_t>(kMaxSteps + 2);
+    uint32_t* park_list = w.take<uint32_t>(cache ? n + 64 + 64 * 8192 : 1);
+    uint32_t* park_t = w.take<uint32_t>(cache ? n : 1);
     const bool rp = n >= repack_min_users();      // small runs never repack: no second copy
     double* omega_alt = w.take<double>(rp ? ((K + 1) & ~static_cast<size_t>(1)) * n_pad : 1);
     unsigned long long* hist_alt = w.take<unsigned long long>(rp ? hc * n_pad : 1);
@@ -339,6 +349,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->phantom_ps = phantom_ps;
         d->use_cache = cache ? 1u : 0u; d->cache_rec = cache_rec; d->cache_chunk = cache_chunk; d->cache_resc = cache_resc;
         d->f64_valid = f64_valid; d->exact_cnt_b = exact_cnt_b; d->cache_row = cache_row; d->cache_row_f = cache_row_f;
+        d->park_list = park_list; d->park_t = park_t; d->sweep_only = 0;
         d->uid = uid; d->omega_alt = omega_alt; d->hist_alt = hist_alt;
         d->lpv_alt = lpv_alt; d->uid_alt = uid_alt;
         d->gamma32 = gamma32; d->mu32 = mu32; d->gamma32t = gamma32t; d->stats = stats; d->omega = omega; d->list = list;
@@ -1064,7 +1075,8 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_u(DevSim d, uint32_t t, i
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t n_cc = d.PT / 64;                           // one stored sum per 64-product chunk
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
-    const uint32_t n = from_list ? d.exact_cnt[t] : n_o;
+    // from_list == 2: the users k_walk parked (park_list, `t` = its length; entries 0xFFFFFFFF are unused)
+    const uint32_t n = from_list == 2 ? t : (from_list ? d.exact_cnt[t] : n_o);
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
     const uint32_t n_groups = (n + 63) / 64;
     const uint32_t ccps = (n_cc + S - 1) / S;                  // chunks per slice
@@ -1075,10 +1087,18 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_u(DevSim d, uint32_t t, i
         const uint32_t cc0 = slice * ccps, cc1 = min(cc0 + ccps, n_cc);
         if (cc0 >= cc1) continue;
         uint32_t w_idx = grp * 64 + lane;
-        const bool act = w_idx < n;
-        const uint32_t pos = act ? (from_list ? d.exact_list[w_idx] : w_idx) : 0u;
-        const uint32_t slot = act ? cur[pos] : 0u;
-        if (from_list && d.use_cache && act) w_idx = d.uid[slot];             // sums / reference rows are per user in this mode
+        bool act = w_idx < n;
+        uint32_t slot;
+        if (from_list == 2) {
+            slot = act ? d.park_list[w_idx] : 0xFFFFFFFFu;
+            act = slot != 0xFFFFFFFFu;
+            if (!act) slot = 0u;
+            w_idx = slot;                                                  // slot == user index: nothing was repacked
+        } else {
+            const uint32_t pos = act ? (from_list ? d.exact_list[w_idx] : w_idx) : 0u;
+            slot = act ? cur[pos] : 0u;
+            if (from_list && d.use_cache && act) w_idx = d.uid[slot];         // sums / reference rows are per user in this mode
+        }
         double om[4 * KB];
 #pragma unroll
         for (int k = 0; k < 4 * KB; ++k)
@@ -1127,13 +1147,64 @@ __global__ void __launch_bounds__(kBlock) k_exact_ref(DevSim d, uint32_t t, uint
     }
 }
 
+// The float64 pick of one user, by a whole wave (every argument wave-uniform): prefix over the stored chunk sums ->
+// the chunk that holds u * total -> its products walked in product order.  `om` = the user's omega in LDS.
 // G = 64-product chunks per stored sum (8: tile kernel's coarse chunks, 1: user-per-lane kernel)
+__device__ __forceinline__ uint32_t exact_pick_wave(const DevSim& d, const double* sums, const double* om, double M,
+                                                    double u, uint32_t G, int lane) {
+    const uint32_t n_chunks = d.PT / 64;
+    const uint32_t n_cc = (n_chunks + G - 1) / G;
+    // total over the coarse-chunk sums, in the same association the prefix below uses
+    double total = 0.0;
+    for (uint32_t c0 = 0; c0 < n_cc; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        total += __shfl(wave_scan(c < n_cc ? sums[c] : 0.0, lane), 63);
+    }
+    // The reference normalises p = e / sum(e) before its cumsum and divides by cdf[-1];
+    // dividing every term by the same positive constants moves the decision only at the
+    // 1e-16 level, so the running sum of e is compared with u * total directly.
+    const double target = u * total;
+    // first coarse chunk whose inclusive running sum exceeds the target, and the sum before it
+    uint32_t ccstar = n_cc - 1;
+    double before = 0.0, run = 0.0;
+    bool found = false;
+    for (uint32_t c0 = 0; c0 < n_cc && !found; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        const double x = c < n_cc ? sums[c] : 0.0;
+        const double incl = wave_scan(x, lane);
+        const unsigned long long hit = __ballot(c < n_cc && run + incl > target);
+        if (hit) {
+            const int L = __builtin_ctzll(hit);
+            ccstar = c0 + L;
+            before = run + __shfl(incl - x, L);
+            found = true;
+        } else run += __shfl(incl, 63);
+    }
+    if (!found) before = run - sums[n_cc - 1];          // u * total rounded up to total
+    __builtin_amdgcn_wave_barrier();
+    // walk the G x 64 products of that coarse chunk in product order
+    uint32_t v = min(ccstar * G * 64 + G * 64 - 1, d.P - 1);   // if rounding leaves no hit: its last product
+    double acc = before;
+    for (uint32_t i = 0; i < G; ++i) {
+        const uint32_t p = (ccstar * G + i) * 64 + lane;
+        if (ccstar * G + i >= n_chunks) break;
+        double lg = 0.0;
+        const double* g = d.gammaT + p;                  // PT columns: always in range
+        for (uint32_t k = 0; k < d.K; ++k) lg += g[static_cast<size_t>(k) * d.PT] * om[k];
+        lg = p < d.P ? lg + d.mu_o[p] : -INFINITY;
+        const double incl = wave_scan(exp64(lg - M), lane);
+        const unsigned long long hit = __ballot(p < d.P && acc + incl > target);
+        if (hit) { v = (ccstar * G + i) * 64 + static_cast<uint32_t>(__builtin_ctzll(hit)); break; }
+        acc += __shfl(incl, 63);
+    }
+    return v;
+}
+
 __global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int from_list, uint32_t G) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
     double* om = reinterpret_cast<double*>(smem_raw) + static_cast<size_t>(wave) * d.K;
-    const uint32_t n_chunks = d.PT / 64;
-    const uint32_t n_cc = (n_chunks + G - 1) / G;
+    const uint32_t n_cc = (d.PT / 64 + G - 1) / G;
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
     const bool cached = from_list && d.use_cache;
     const uint32_t n_a = from_list ? d.exact_cnt[t] : n_o;              // draws whose sums the previous kernel took
@@ -1149,49 +1220,9 @@ __global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int
         const double M = static_cast<double>(d.exact_ref[row]) * 0.69314718055994530942;
         const double* sums = d.exact_sums + static_cast<size_t>(row) * n_cc;
         for (uint32_t k = lane; k < d.K; k += 64) om[k] = d.omega[static_cast<size_t>(slot) * d.OMS + k];
-        // total over the coarse-chunk sums, in the same association the prefix below uses
-        double total = 0.0;
-        for (uint32_t c0 = 0; c0 < n_cc; c0 += 64) {
-            const uint32_t c = c0 + lane;
-            total += __shfl(wave_scan(c < n_cc ? sums[c] : 0.0, lane), 63);
-        }
-        // The reference normalises p = e / sum(e) before its cumsum and divides by cdf[-1];
-        // dividing every term by the same positive constants moves the decision only at the
-        // 1e-16 level, so the running sum of e is compared with u * total directly.
-        const double target = organic_uniform(d, uidx, user, t) * total;
-        // first coarse chunk whose inclusive running sum exceeds the target, and the sum before it
-        uint32_t ccstar = n_cc - 1;
-        double before = 0.0, run = 0.0;
-        bool found = false;
-        for (uint32_t c0 = 0; c0 < n_cc && !found; c0 += 64) {
-            const uint32_t c = c0 + lane;
-            const double x = c < n_cc ? sums[c] : 0.0;
-            const double incl = wave_scan(x, lane);
-            const unsigned long long hit = __ballot(c < n_cc && run + incl > target);
-            if (hit) {
-                const int L = __builtin_ctzll(hit);
-                ccstar = c0 + L;
-                before = run + __shfl(incl - x, L);
-                found = true;
-            } else run += __shfl(incl, 63);
-        }
-        if (!found) before = run - sums[n_cc - 1];          // u * total rounded up to total
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        // walk the G x 64 products of that coarse chunk in product order
-        uint32_t v = min(ccstar * G * 64 + G * 64 - 1, d.P - 1);   // if rounding leaves no hit: its last product
-        double acc = before;
-        for (uint32_t i = 0; i < G; ++i) {
-            const uint32_t p = (ccstar * G + i) * 64 + lane;
-            if (ccstar * G + i >= n_chunks) break;
-            double lg = 0.0;
-            const double* g = d.gammaT + p;                  // PT columns: always in range
-            for (uint32_t k = 0; k < d.K; ++k) lg += g[static_cast<size_t>(k) * d.PT] * om[k];
-            lg = p < d.P ? lg + d.mu_o[p] : -INFINITY;
-            const double incl = wave_scan(exp64(lg - M), lane);
-            const unsigned long long hit = __ballot(p < d.P && acc + incl > target);
-            if (hit) { v = (ccstar * G + i) * 64 + static_cast<uint32_t>(__builtin_ctzll(hit)); break; }
-            acc += __shfl(incl, 63);
-        }
+        const uint32_t v = exact_pick_wave(d, sums, om, M, organic_uniform(d, uidx, user, t), G, lane);
         if (lane == 0) {
             write_organic_row(d, t, pos, slot, user, v);
             if (d.hist_cap) history_add(d, slot, v);
@@ -2160,7 +2191,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             view.rec[sc_cur * view.rec_stride] = make_float2(static_cast<float>(s_sc), q_done);
         }
         if (d.use_cache && S == 1 && active && h == 0) d.cache_resc[d.uid[slot]] = static_cast<uint8_t>(min(n_resc, 255));
-        if (S == 1 && !(d.ablate & 128u)) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, delta_fixed, &view);
+        if (S == 1 && !(d.ablate & 128u) && !d.sweep_only) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, delta_fixed, &view);
     }
 }
 
@@ -2229,40 +2260,68 @@ __global__ void __launch_bounds__(kBlock) k_cache_finalize(DevSim d) {
     float gsum = 0.0f;
     if (d.f16) for (uint32_t k = 0; k < d.K; ++k) gsum += d.stats[k];
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) {
-        float* row = d.cache_row + static_cast<size_t>(i) * d.cache_row_f;
+        // everything is staged in registers and leaves as 16-byte stores (a row is 256-byte aligned)
+        float4* row4 = reinterpret_cast<float4*>(d.cache_row + static_cast<size_t>(i) * d.cache_row_f);
         // omega32 and the logit error bound, exactly as the sweep kernel computes them
+        float om[K2];
         float absdot = 0.0f, sq = 0.0f, absw = 0.0f;
-        for (int k = 0; k < K2; ++k) {
-            const float w = static_cast<uint32_t>(k) < d.K ? static_cast<float>(d.omega[static_cast<size_t>(i) * d.OMS + k]) : 0.0f;
-            row[44 + k] = w;
-            absdot = fmaf(fabsf(w), d.stats[k], absdot);
-            sq = fmaf(w, w, sq);
-            absw += fabsf(w);
+        {
+            const double* om_row = d.omega + static_cast<size_t>(i) * d.OMS;
+#pragma unroll
+            for (int k2 = 0; k2 < KH; ++k2) {
+                double2 w2 = make_double2(0.0, 0.0);
+                if (static_cast<uint32_t>(2 * k2) < d.K) w2 = *reinterpret_cast<const double2*>(om_row + 2 * k2);
+                om[2 * k2] = static_cast<float>(w2.x);
+                om[2 * k2 + 1] = static_cast<uint32_t>(2 * k2 + 1) < d.K ? static_cast<float>(w2.y) : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < K2; ++k) {
+                absdot = fmaf(fabsf(om[k]), d.stats[k], absdot);
+                sq = fmaf(om[k], om[k], sq);
+                absw += fabsf(om[k]);
+            }
         }
         const float Ahat = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
         double delta = static_cast<double>(d.K + 5) * 5.9604644775390625e-08 * static_cast<double>(Ahat) + kDeltaFixedBf16 +
                        kDeltaPerRescale * static_cast<double>(d.cache_resc[i]);
         if (d.f16) delta += 12.0 * 5.9604644775390625e-08 * static_cast<double>(Ahat) +
                             2.98023223876953125e-08 * (static_cast<double>(gsum) + 0.6931471805599453 * static_cast<double>(absw));
-        const float2* rec = d.cache_rec + static_cast<size_t>(i) * kMaxSC;
+        float2 rec[kMaxSC];
+        {
+            const float4* rp = reinterpret_cast<const float4*>(d.cache_rec + static_cast<size_t>(i) * kMaxSC);
+#pragma unroll
+            for (uint32_t q = 0; q < kMaxSC / 2; ++q) {
+                const float4 x = rp[q];
+                rec[2 * q] = make_float2(x.x, x.y); rec[2 * q + 1] = make_float2(x.z, x.w);
+            }
+        }
         float Q = -INFINITY;
-        for (uint32_t sc = 0; sc < d.n_sc; ++sc) Q = fmaxf(Q, rec[sc].y);
+#pragma unroll
+        for (uint32_t sc = 0; sc < kMaxSC; ++sc) if (sc < d.n_sc) Q = fmaxf(Q, rec[sc].y);
         uint32_t offw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        float W[kMaxSC];
+#pragma unroll
         for (uint32_t sc = 0; sc < kMaxSC; ++sc) {
             float x = 0.0f;
             uint32_t off = 127u;                                        // unused / out of range: weight 0, never chosen
             if (sc < d.n_sc) {
-                const float2 r = rec[sc];
-                const float dq = Q - r.y;                               // references are integers (log2 units)
-                if (dq < 127.0f) { off = static_cast<uint32_t>(dq); x = r.x * __builtin_amdgcn_exp2f(-dq); }
+                const float dq = Q - rec[sc].y;                         // references are integers (log2 units)
+                if (dq < 127.0f) { off = static_cast<uint32_t>(dq); x = rec[sc].x * __builtin_amdgcn_exp2f(-dq); }
             }
-            row[sc] = x;
+            W[sc] = x;
             offw[sc >> 2] |= off << (8 * (sc & 3));
         }
-        row[32] = Q;
-        row[33] = static_cast<float>(delta * 1.000001);                 // rounded up: the budget must not shrink
-        row[34] = 0.0f; row[35] = 0.0f;
-        for (int q = 0; q < 8; ++q) row[36 + q] = __builtin_bit_cast(float, offw[q]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) row4[q] = make_float4(W[4 * q], W[4 * q + 1], W[4 * q + 2], W[4 * q + 3]);
+        row4[8] = make_float4(Q, static_cast<float>(delta * 1.000001), 0.0f, 0.0f);   // delta rounded up: the budget must not shrink
+        row4[9] = make_float4(__builtin_bit_cast(float, offw[0]), __builtin_bit_cast(float, offw[1]),
+                              __builtin_bit_cast(float, offw[2]), __builtin_bit_cast(float, offw[3]));
+        row4[10] = make_float4(__builtin_bit_cast(float, offw[4]), __builtin_bit_cast(float, offw[5]),
+                               __builtin_bit_cast(float, offw[6]), __builtin_bit_cast(float, offw[7]));
+#pragma unroll
+        for (int k4 = 0; k4 < K2 / 4; ++k4) row4[11 + k4] = make_float4(om[4 * k4], om[4 * k4 + 1], om[4 * k4 + 2], om[4 * k4 + 3]);
+#pragma unroll
+        for (int k = (K2 / 4) * 4; k < K2; ++k) reinterpret_cast<float*>(row4)[44 + k] = om[k];
     }
 }
 
@@ -2741,7 +2800,7 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
 // steps > t0 are counted in the kCntTail* counters (step t0's are in step_cnt[t0]).
 // ------------------------------------------------------------------------------------------
 constexpr int kCntTailRows = 16, kCntTailOrganic = 17, kCntTailBandit = 18, kCntTailMaxT = 19, kCntTailTicket = 20,
-              kCntTailLimit = 21;   // internal slots of counters[] (RG_CNT_N = 24)
+              kCntTailLimit = 21, kCntWalkTicket = 22, kCntParkCnt = 23;   // internal slots of counters[] (RG_CNT_N = 24)
 
 __global__ void __launch_bounds__(kBlock) k_tail(DevSim d, uint32_t t0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -2938,6 +2997,414 @@ __global__ void k_tail_finish(DevSim d, uint32_t t0) {
     d.step_cnt[2 * (t0 + 1) + 1] = 0;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// k_walk — sigma_omega == 0: the whole run user-major instead of step-major.
+//
+// With omega fixed, nothing a user does depends on any other user or on a shared product sweep: after the
+// one batched sweep that fills the per-user cache (k_draw_bf16p at t = 0) a trajectory is a chain of
+// cached draws (k_draw_cached's arithmetic), policy acts, click draws and transitions (k_advance's
+// arithmetic) addressed by (user, t).  So a lane takes a user and walks it to its end, and takes the next
+// user from the queue when it stops: no live lists, no compaction, no repack, no per-step launches (the
+// lock-step form spent ~200 us of launch/latency floor per step on ~800 steps), and the ~260 k users in
+// flight (omega, cache row, view history: < 1 KB each) stay in the Infinity Cache instead of being
+// re-gathered from HBM every step.  Per-lane times differ (a refilled lane starts at t = 0): every draw is
+// addressed, rows carry (u, t), and rg_sim_sort_log orders them.
+//
+// Draws the certificate rejects need the user's float64 sums.  A lane cannot take them alone, and a
+// wave-wide sweep per such draw is 3x less efficient than the user-per-lane kernel, so the user is PARKED
+// (appended to park_list with its time) and its lane refilled; after round 1, k_exact_sums_u takes the
+// sums of all parked users in one batch and round 2 walks them to their end — the parked draw and any
+// later uncertified draw of theirs are float64 picks from the stored sums (exact_pick_wave), inline.
+//
+// Raw log: a wave reserves rows in chunks (one atomic per `chunk_rows` rows, not per row or per step) and
+// marks the entries it does not use (kHoleCode); the sort skips them.
+// ------------------------------------------------------------------------------------------
+template <int KH>
+__global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_walk(DevSim d, uint32_t n_work, int round, uint32_t chunk_rows) {
+    constexpr int K2 = 2 * KH;
+    constexpr int kEmpty = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    // per wave: omega32 stage [64][K2] floats | float64 omega of the user being picked [K rounded to 2] | mailbox [64] {idx, A, B}
+    char* wbase = smem_raw + static_cast<size_t>(wave) * (64 * K2 * 4 + ((d.K + 1) & ~1u) * 8 + 64 * 24);
+    float* om_w = reinterpret_cast<float*>(wbase);
+    double* om_d = reinterpret_cast<double*>(wbase + 64 * K2 * 4);
+    double* mbox = om_d + ((d.K + 1) & ~1u);                       // [64][3]
+    const uint32_t n_cc = d.PT / 64;
+
+    uint32_t slot = 0, user = 0, t = 0;
+    int st = kEmpty;
+    bool pending = false;                                          // round 2: the parked draw, to be picked in float64
+    uint32_t res_next = 0, res_end = 0;                            // this wave's reservoir of queue tickets
+    uint64_t row_next = 0, row_end = 0;                            // this wave's reserved raw-log rows
+    uint32_t park_next = 0, park_end = 0;                          // this wave's reserved park_list entries
+    bool exhausted = false;
+    unsigned long long c_org = 0, c_ban = 0, c_clicks = 0, c_ph = 0, c_pick = 0, c_sweeps = 0;
+    uint32_t c_maxt = 0, c_limit = 0;
+
+    for (;;) {
+        // ---- refill the lanes whose user has stopped (or was parked) ----
+        unsigned long long dead = __ballot(st == kEmpty);
+        if (dead && !exhausted && (__popcll(dead) >= 16 || dead == ~0ull)) {
+            for (int pass = 0; pass < 2 && dead; ++pass) {
+                if (res_next == res_end) {
+                    if (exhausted) break;
+                    uint32_t base = 0;
+                    if (lane == 0) base = static_cast<uint32_t>(atomicAdd(&d.counters[kCntWalkTicket], 64ull));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= n_work) { exhausted = true; break; }
+                    res_next = base; res_end = min(base + 64u, n_work);
+                }
+                const uint32_t take = min(static_cast<uint32_t>(__popcll(dead)), res_end - res_next);
+                const uint32_t r = prefix_in_mask(dead);
+                const bool mine = st == kEmpty && r < take;
+                if (mine) {
+                    const uint32_t idx = res_next + r;
+                    uint32_t s2 = idx;
+                    if (round == 2) s2 = d.park_list[idx];
+                    if (s2 != 0xFFFFFFFFu) {
+                        slot = s2;
+                        user = static_cast<uint32_t>(d.first_user + slot);
+                        st = RG_STATE_ORGANIC;                       // every user starts organic; parked users sit at an organic draw
+                        t = round == 2 ? d.park_t[slot] : 0u;
+                        pending = round == 2;
+                        if (round == 2) { d.f64_valid[slot] = 1; c_sweeps += 1; }   // k_exact_sums_u took its sums between the rounds
+                    }
+                }
+                res_next += take;
+                dead = __ballot(st == kEmpty) & ~(__ballot(mine));   // lanes that drew an unused entry wait for the next refill
+                dead = __ballot(st == kEmpty && !mine);
+            }
+        }
+        const unsigned long long live = __ballot(st != kEmpty);
+        if (!live) { if (exhausted) break; else continue; }
+        // ---- one raw-log row per live lane ----
+        const uint32_t nlive = static_cast<uint32_t>(__popcll(live));
+        if (row_next + nlive > row_end) {
+            for (uint64_t r = row_next + lane; r < row_end; r += 64)
+                if (d.log && r < d.log_cap) { rg_event e; e.u = 0; e.t = 0; e.code = kHoleCode; e.ps = 0.0f; d.log[r] = e; }
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&d.counters[kCntTailRows], static_cast<unsigned long long>(chunk_rows));
+            base = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32))) << 32) |
+                   __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
+            row_next = base; row_end = base + chunk_rows;
+        }
+        const uint64_t my_row = row_next + prefix_in_mask(live);
+        row_next += nlive;
+        const bool alive = st != kEmpty;
+        const rg_u32x4 w = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
+        const bool is_org = alive && st == RG_STATE_ORGANIC;
+        bool parked = false;
+        // =========================== organic product draw ===========================
+        const unsigned long long org_mask = __ballot(is_org);
+        if (org_mask && (d.ablate & (1u << 20))) {          // timing experiment: no draw at all
+            if (is_org) {
+                if (d.log && my_row < d.log_cap) { rg_event e; e.u = user; e.t = t; e.code = (user + t) % d.P; e.ps = __builtin_nanf(""); d.log[my_row] = e; }
+                c_org += 1;
+            }
+        } else
+        if (org_mask) {
+            const bool search = is_org && !pending;
+            const size_t row = search ? slot : d.n_cap;
+            // ---- the user's cache row (k_draw_cached phase 1) ----
+            const float4* rp = reinterpret_cast<const float4*>(d.cache_row + row * d.cache_row_f);
+            float W[kMaxSC];
+#pragma unroll
+            for (int i = 0; i < kMaxSC / 4; ++i) {
+                const float4 x = rp[i];
+                W[4 * i] = x.x; W[4 * i + 1] = x.y; W[4 * i + 2] = x.z; W[4 * i + 3] = x.w;
+            }
+            const float4 hdr = rp[8];
+            const float4 of0 = rp[9], of1 = rp[10];
+            {
+                float* o = om_w + lane * K2;
+#pragma unroll
+                for (int k4 = 0; k4 < K2 / 4; ++k4) *reinterpret_cast<float4*>(o + 4 * k4) = rp[11 + k4];
+#pragma unroll
+                for (int k = (K2 / 4) * 4; k < K2; ++k) o[k] = reinterpret_cast<const float*>(rp)[44 + k];
+            }
+            const float Q = hdr.x;
+            const double delta = static_cast<double>(hdr.y);
+            double S = 0.0;
+#pragma unroll
+            for (uint32_t sc = 0; sc < kMaxSC; ++sc) S += static_cast<double>(W[sc]);
+            const double u_org = organic_uniform(d, slot, user, t);
+            const double tau = u_org * S;
+            double pb = 0.0;
+            uint32_t sc_star = d.n_sc - 1;
+            bool found_sc = false;
+            {
+                double run = 0.0;
+#pragma unroll
+                for (uint32_t sc = 0; sc < kMaxSC; ++sc) {
+                    const double Wd = static_cast<double>(W[sc]);
+                    if (sc < d.n_sc && !found_sc && run + Wd > tau) { found_sc = true; sc_star = sc; pb = run; }
+                    if (sc < d.n_sc && !found_sc) run += Wd;
+                }
+            }
+            uint32_t offw;
+            {
+                const uint32_t q = sc_star >> 2;
+                const float4 o4 = q < 4 ? of0 : of1;
+                const float ow = (q & 3) == 0 ? o4.x : (q & 3) == 1 ? o4.y : (q & 3) == 2 ? o4.z : o4.w;
+                offw = (__builtin_bit_cast(uint32_t, ow) >> (8 * (sc_star & 3))) & 0xFFu;
+            }
+            if (offw >= 127u) found_sc = false;
+            const float f_star = found_sc ? __builtin_amdgcn_exp2f(-static_cast<float>(offw)) : 1.0f;
+            // ---- the chunk inside that super-chunk (phase 2) ----
+            uint32_t c_star = 0;
+            bool found_c = false;
+            {
+                const uint32_t c0 = sc_star * d.sc_chunks, c1 = min(c0 + d.sc_chunks, d.n_chunks);
+                const float* cp = d.cache_chunk + row * d.n_chunks;
+                double run = pb;
+                for (uint32_t cb = c0; cb < c1; cb += 16) {
+                    float4 w4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        w4[i] = cb + 4 * i < c1 ? *reinterpret_cast<const float4*>(cp + cb + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float4 q4 = w4[i >> 2];
+                        const float wv = (i & 3) == 0 ? q4.x : (i & 3) == 1 ? q4.y : (i & 3) == 2 ? q4.z : q4.w;
+                        const double Wd = static_cast<double>(wv * f_star);
+                        const uint32_t c = cb + i;
+                        if (c < c1 && !found_c && run + Wd > tau) { found_c = true; c_star = c; pb = run; }
+                        if (c < c1 && !found_c) run += Wd;
+                    }
+                }
+            }
+            found_c = found_c && found_sc;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            // ---- the 32 products of the chosen chunk (phase 3): eight searching users per pass, eight lanes per
+            // user, four products per lane.  A pass is ONE latency chain (user parameters -> 21 coalesced
+            // 16-byte loads -> 80 fma -> 4 exp -> 3-step prefix across the user's lanes -> compare); two users
+            // per pass of 32-lane prefixes cost a chain per pair and made the walk 4x slower ----
+            const int grp = lane >> 3, gl = lane & 7;
+            unsigned long long todo = __ballot(search);
+            if (d.ablate & (1u << 16)) { todo = 0; if (search) { mbox[lane * 3] = 0.0; mbox[lane * 3 + 1] = 0.0; mbox[lane * 3 + 2] = 1e300; } }
+            while (todo) {
+                int src = -1;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const int bit = todo ? __builtin_ctzll(todo) : -1;
+                    if (g == grp) src = bit;
+                    if (todo) todo &= todo - 1;
+                }
+                const bool has = src >= 0;
+                const int s2 = has ? src : 0;
+                const uint32_t cs = static_cast<uint32_t>(__shfl(static_cast<int>(c_star), s2));
+                const float Qs = __shfl(Q, s2);
+                const double pbs = __shfl(pb, s2), taus = __shfl(tau, s2);
+                const float4* gp = reinterpret_cast<const float4*>(d.gamma32t + (static_cast<size_t>(cs) * K2) * 32) + gl;
+                float4 gk[K2];
+#pragma unroll
+                for (int k = 0; k < K2; ++k) gk[k] = gp[k * 8];
+                float4 l = *(reinterpret_cast<const float4*>(d.mu32 + cs * 32) + gl);
+                const float* o = om_w + s2 * K2;
+#pragma unroll
+                for (int k = 0; k < K2; ++k) {
+                    const float wk = o[k];
+                    l.x = fmaf(gk[k].x, wk, l.x); l.y = fmaf(gk[k].y, wk, l.y);
+                    l.z = fmaf(gk[k].z, wk, l.z); l.w = fmaf(gk[k].w, wk, l.w);
+                }
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(l.x, kLog2e, -Qs)), e1 = __builtin_amdgcn_exp2f(fmaf(l.y, kLog2e, -Qs));
+                const float e2 = __builtin_amdgcn_exp2f(fmaf(l.z, kLog2e, -Qs)), e3 = __builtin_amdgcn_exp2f(fmaf(l.w, kLog2e, -Qs));
+                const float q0 = e0, q1 = q0 + e1, q2 = q1 + e2, q3 = q2 + e3;      // prefix inside the lane
+                float inc = q3;                                                     // ... and across the user's 8 lanes
+#pragma unroll
+                for (int o2 = 1; o2 < 8; o2 <<= 1) {
+                    const float y = __shfl_up(inc, o2, 8);
+                    if (gl >= o2) inc += y;
+                }
+                float ex = __shfl_up(inc, 1, 8);                                    // prefix before this lane's products
+                if (gl == 0) ex = 0.0f;
+                const double pxb = pbs + static_cast<double>(ex);
+                const double px0 = pbs + static_cast<double>(ex + q0), px1 = pbs + static_cast<double>(ex + q1);
+                const double px2 = pbs + static_cast<double>(ex + q2), px3 = pbs + static_cast<double>(ex + q3);
+                const int j0 = px0 > taus ? 0 : px1 > taus ? 1 : px2 > taus ? 2 : px3 > taus ? 3 : -1;
+                const unsigned long long hits = __ballot(has && j0 >= 0);
+                const uint32_t gmask = static_cast<uint32_t>(hits >> (8 * grp)) & 0xFFu;
+                if (has) {
+                    if (gmask) {
+                        if (gl == __builtin_ctz(gmask)) {
+                            mbox[src * 3] = static_cast<double>(4 * gl + j0);
+                            mbox[src * 3 + 1] = j0 == 0 ? pxb : j0 == 1 ? px0 : j0 == 2 ? px1 : px2;
+                            mbox[src * 3 + 2] = j0 == 0 ? px0 : j0 == 1 ? px1 : j0 == 2 ? px2 : px3;
+                        }
+                    } else if (gl == 0) { mbox[src * 3] = -1.0; mbox[src * 3 + 1] = pbs; mbox[src * 3 + 2] = pbs; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t v = 0;
+            bool ok = false;
+            if (search) {
+                const int idx = static_cast<int>(mbox[lane * 3]);
+                const double Av = mbox[lane * 3 + 1], Bv = mbox[lane * 3 + 2];
+                v = c_star * 32 + static_cast<uint32_t>(max(idx, 0));
+                ok = found_c && idx >= 0 && v < d.P &&
+                     (v == 0 || Av * (1.0 + delta) < tau * (1.0 - delta)) &&
+                     (v == d.P - 1 || tau * (1.0 + delta) < Bv * (1.0 - delta));
+            }
+            // ---- uncertified: float64 pick from the user's stored sums, or park the user until they exist ----
+            const bool need64 = is_org && !ok;
+            const bool have64 = need64 && d.f64_valid[slot] != 0;
+            parked = need64 && !have64;
+            unsigned long long picks = __ballot(have64);
+            while (picks) {
+                const int L = __builtin_ctzll(picks);
+                picks &= picks - 1;
+                const uint32_t s_slot = static_cast<uint32_t>(__shfl(static_cast<int>(slot), L));
+                const double s_u = __shfl(u_org, L);
+                for (uint32_t k = lane; k < d.K; k += 64) om_d[k] = d.omega[static_cast<size_t>(s_slot) * d.OMS + k];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                const double M = static_cast<double>(d.exact_ref[s_slot]) * 0.69314718055994530942;
+                const uint32_t pv = exact_pick_wave(d, d.exact_sums + static_cast<size_t>(s_slot) * n_cc, om_d, M, s_u, 1u, lane);
+                if (lane == L) { v = pv; c_pick += 1; }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (parked) {
+                d.park_t[slot] = t;
+                d.exact_ref[slot] = Q;
+            }
+            if (is_org && !parked) {
+                if (d.log && my_row < d.log_cap) {
+                    rg_event e;
+                    e.u = user; e.t = t; e.code = v; e.ps = __builtin_nanf("");
+                    d.log[my_row] = e;
+                }
+                if (d.lpv) d.lpv[slot] = v;
+                if (d.hist_cap && !(d.ablate & (1u << 17))) history_add(d, slot, v);
+                c_org += 1;
+                pending = false;
+            }
+        }
+        // ---- park list entries for the users parked in this step ----
+        const unsigned long long pmask = __ballot(parked);
+        if (pmask) {
+            const uint32_t np = static_cast<uint32_t>(__popcll(pmask));
+            if (park_next + np > park_end) {
+                for (uint32_t r = park_next + lane; r < park_end; r += 64) d.park_list[r] = 0xFFFFFFFFu;
+                uint32_t base = 0;
+                if (lane == 0) base = static_cast<uint32_t>(atomicAdd(&d.counters[kCntParkCnt], 64ull));
+                base = __builtin_amdgcn_readfirstlane(base);
+                park_next = base; park_end = base + 64;
+            }
+            if (parked) {
+                d.park_list[park_next + prefix_in_mask(pmask)] = slot;
+                if (d.log && my_row < d.log_cap) { rg_event e; e.u = 0; e.t = 0; e.code = kHoleCode; e.ps = 0.0f; d.log[my_row] = e; }
+                st = kEmpty;
+            }
+            park_next += np;
+        }
+        // =========================== bandit event + transition (k_advance's arithmetic) ===========================
+        if (alive && !parked) {
+            const double u_trans = rg_uniform(w.w[2], w.w[3]);
+            bool click = false;
+            if (!is_org) {
+                double ps = 1.0;
+                const uint32_t a = (d.ablate & (1u << 18)) ? (user + t) % d.P : policy_act(d, slot, user, t, &ps);
+                const double* b = d.beta + static_cast<size_t>(a) * d.K;
+                const double* om = d.omega + static_cast<size_t>(slot) * d.OMS;
+                double x = 0.0;
+                if (!(d.ablate & (1u << 19)))
+                for (uint32_t k0 = 0; k0 < d.K; k0 += 8) {
+                    double wv[8], bv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const uint32_t k = min(k0 + i, d.K - 1);
+                        wv[i] = om[k];
+                        bv[i] = b[k];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (k0 + i < d.K) x += bv[i] * wv[i];
+                }
+                const double ctr = (d.ablate & (1u << 19)) ? 0.01 : ff64(x + d.mu_b[a]);
+                const double p0 = 1.0 - ctr;
+                click = (p0 / (p0 + ctr)) <= rg_uniform(w.w[0], w.w[1]);
+                c_clicks += click;
+                c_ban += 1;
+                if (d.log && my_row < d.log_cap) {
+                    rg_event e;
+                    e.u = user; e.t = t;
+                    e.code = RG_EV_BANDIT | (click ? RG_EV_CLICK : 0u) | a;
+                    e.ps = static_cast<float>(ps);
+                    d.log[my_row] = e;
+                    if (d.aux_ps) d.aux_ps[my_row] = ps;
+                    if (d.aux_pclick) d.aux_pclick[my_row] = ctr;
+                }
+            }
+            const double c0 = is_org ? d.cdf_o0 : d.cdf_b0, c1 = is_org ? d.cdf_o1 : d.cdf_b1;
+            int ns = (c0 <= u_trans) + (c1 <= u_trans);
+            if (click) ns = RG_STATE_ORGANIC;                  // abstract.py:180-181 (sigma_omega == 0: no drift to apply)
+            const bool organic_only = (d.first_user + slot) < d.organic_only_below;
+            if (organic_only && ns != RG_STATE_ORGANIC) {
+                ns = RG_STATE_STOP;
+                d.n_events[slot] = t + 1;
+            } else if (ns == RG_STATE_STOP) {
+                d.n_events[slot] = t + 1;
+                double ps = 1.0;
+                const uint32_t a = policy_act(d, slot, user, t + 1, &ps);
+                rg_event e;
+                e.u = user; e.t = t + 1; e.code = RG_EV_BANDIT | RG_EV_PHANTOM | a;
+                e.ps = static_cast<float>(ps);
+                d.phantom[slot] = e;
+                d.phantom_ps[slot] = ps;
+                d.has_phantom[slot] = 1;
+                c_ph += 1;
+            } else if (t + 2 >= kMaxSteps) {
+                ns = RG_STATE_STOP;
+                d.n_events[slot] = t + 1;
+                c_limit += 1;
+            }
+            if (ns == RG_STATE_STOP) { c_maxt = max(c_maxt, t + 1); st = kEmpty; }
+            else { st = ns; t += 1; }
+        }
+    }
+    // ---- leftovers of the reserved chunks, counters ----
+    for (uint64_t r = row_next + lane; r < row_end; r += 64)
+        if (d.log && r < d.log_cap) { rg_event e; e.u = 0; e.t = 0; e.code = kHoleCode; e.ps = 0.0f; d.log[r] = e; }
+    for (uint32_t r = park_next + lane; r < park_end; r += 64) d.park_list[r] = 0xFFFFFFFFu;
+    for (int o = 32; o > 0; o >>= 1) {
+        c_org += __shfl_xor(c_org, o); c_ban += __shfl_xor(c_ban, o); c_clicks += __shfl_xor(c_clicks, o);
+        c_ph += __shfl_xor(c_ph, o); c_pick += __shfl_xor(c_pick, o); c_sweeps += __shfl_xor(c_sweeps, o);
+        c_maxt = max(c_maxt, static_cast<uint32_t>(__shfl_xor(static_cast<int>(c_maxt), o)));
+        c_limit += static_cast<uint32_t>(__shfl_xor(static_cast<int>(c_limit), o));
+    }
+    if (lane == 0) {
+        if (c_org) atomicAdd(&d.counters[kCntTailOrganic], c_org);
+        if (c_ban) atomicAdd(&d.counters[kCntTailBandit], c_ban);
+        if (c_clicks) atomicAdd(&d.counters[RG_CNT_CLICKS], c_clicks);
+        if (c_ph) atomicAdd(&d.counters[RG_CNT_PHANTOM], c_ph);
+        if (c_pick) atomicAdd(&d.counters[RG_CNT_EXACT_DRAWS], c_pick);
+        if (c_sweeps) atomicAdd(&d.counters[RG_CNT_EXACT_SWEEPS], c_sweeps);
+        if (c_maxt) atomicMax(&d.counters[kCntTailMaxT], static_cast<unsigned long long>(c_maxt));
+        if (c_limit) atomicAdd(&d.counters[kCntTailLimit], static_cast<unsigned long long>(c_limit));
+    }
+}
+
+// closes the books of a walked run: no lock-step step holds events; step 1 exists, is empty and starts after the raw rows
+__global__ void k_walk_finish(DevSim d) {
+    d.step_cnt[0] = 0; d.step_cnt[1] = 0; d.step_cnt[2] = 0; d.step_cnt[3] = 0;
+    d.log_base[0] = 0;
+    d.log_base[1] = d.counters[kCntTailRows];
+}
+
+typedef void (*walk_kernel_t)(DevSim, uint32_t, int, uint32_t);
+walk_kernel_t walk_kernel_for(const DevSim& d) {
+    switch (d.KH) {
+        case 4: return k_walk<4>;
+        case 10: return k_walk<10>;
+        case 16: return k_walk<16>;
+        default: return k_walk<32>;
+    }
+}
+
 // totals that are sums over the per-step counts
 __global__ void k_totals(DevSim d, uint32_t t_now) {
     __shared__ unsigned long long so[kBlock], sb[kBlock];
@@ -3105,6 +3572,7 @@ __global__ void __launch_bounds__(kBlock) k_scatter_rows(DevSim d, uint64_t n_ro
     for (uint64_t r = blockIdx.x * static_cast<uint64_t>(kBlock) + threadIdx.x; r < n_rows;
          r += static_cast<uint64_t>(gridDim.x) * kBlock) {
         const rg_event e = d.log[r];
+        if (e.code == kHoleCode) continue;                           // unused entry of a k_walk row chunk
         const uint64_t dst = static_cast<uint64_t>(off[e.u - d.first_user]) + e.t;
         if (dst < out_cap) out[dst] = e;
     }
@@ -3127,6 +3595,7 @@ __global__ void __launch_bounds__(kBlock) k_scatter_aux(DevSim d, uint64_t n_row
     for (uint64_t r = blockIdx.x * static_cast<uint64_t>(kBlock) + threadIdx.x; r < n_rows;
          r += static_cast<uint64_t>(gridDim.x) * kBlock) {
         const rg_event e = d.log[r];
+        if (e.code == kHoleCode) continue;
         const uint64_t dst = static_cast<uint64_t>(off[e.u - d.first_user]) + e.t;
         if (dst >= out_cap) continue;
         const bool is_b = (e.code & RG_EV_BANDIT) != 0;
@@ -3291,6 +3760,97 @@ int prof_collect(rg_sim* sim) {
     return RG_OK;
 }
 
+// rg_sim_run "to the end" of a sigma_omega == 0 run: sweep (fills the per-user cache) -> k_walk round 1 ->
+// float64 sums of the parked users in one batch -> k_walk round 2.  Five launches and one host read-back.
+int run_walk(rg_sim* sim, hipStream_t st) {
+    const DevSim& d = sim->d;
+    if (!sim->n_cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        sim->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    auto mark = [&](int i) -> int {
+        if (!sim->profiling) return RG_OK;
+        HIP_TRY(hipEventCreate(&ev[i]));
+        HIP_TRY(hipEventRecord(ev[i], st));
+        return RG_OK;
+    };
+    if (int rc = mark(0)) return rc;
+    // 1. every user's first product sweep: only the per-user sums are kept (no search, no rows)
+    {
+        DevSim ds = d;
+        ds.sweep_only = 1;
+        const uint32_t tiles_up = (d.n_users + 127) / 128;
+        uint32_t S = tiles_up >= 1024 ? 1u : 2048u / (tiles_up ? tiles_up : 1u);
+        if (const char* e = getenv("RECOGYM_SLICES")) S = static_cast<uint32_t>(atoi(e));
+        if (S > d.n_sc) S = d.n_sc;
+        if (S < 1) S = 1;
+        hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid_for(static_cast<uint64_t>(tiles_up) * S, 1)), dim3(kBlock), sim->bf16_smem,
+                           st, ds, 0u, S);
+    }
+    if (int rc = mark(1)) return rc;
+    hipLaunchKernelGGL(finalize_kernel_for(d), dim3(grid_for(d.n_users)), dim3(kBlock), 0, st, d);
+    if (int rc = mark(2)) return rc;
+    // 2. round 1: every user from t = 0 to its end or to its first uncertified draw
+    const size_t smem = (kBlock / 64) * (static_cast<size_t>(64) * 2 * d.KH * 4 + ((d.K + 1) & ~1u) * 8 + 64 * 24);
+    auto launch_walk = [&](uint32_t n_work, int round) {
+        const int blocks_cap = sim->n_cus * (d.KH <= 16 ? 2 : 1);
+        int blocks = static_cast<int>((static_cast<uint64_t>(n_work) + kBlock - 1) / kBlock);
+        if (blocks > blocks_cap) blocks = blocks_cap;
+        if (blocks < 1) blocks = 1;
+        // rows are reserved per wave in chunks: ~1/32 of what a wave will emit, within [256, 4096] (unused entries:
+        // < 64 per chunk and the rest of every wave's last chunk — a few percent of the raw log)
+        uint64_t chunk = static_cast<uint64_t>(n_work) * 100 / (static_cast<uint64_t>(blocks) * 4 * 32);
+        chunk = chunk / 64 * 64;
+        if (chunk < 256) chunk = 256;
+        if (chunk > 4096) chunk = 4096;
+        hipLaunchKernelGGL(walk_kernel_for(d), dim3(blocks), dim3(kBlock), smem, st, d, n_work, round, static_cast<uint32_t>(chunk));
+    };
+    launch_walk(d.n_users, 1);
+    if (int rc = mark(3)) return rc;
+    // 3. the users parked at an uncertified draw: float64 sums in one batch, then their round
+    unsigned long long* h64 = reinterpret_cast<unsigned long long*>(sim->h_pinned);
+    HIP_TRY(hipMemcpyAsync(h64, d.counters + kCntParkCnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t n_park = static_cast<uint32_t>(*h64);
+    if (n_park) {
+        exact_u_kernel_t ku = exact_u_kernel_for(d.XKB);
+        if (!ku) return fail(RG_ESTATE, "no user-per-lane float64 kernel for K = %u", d.K);
+        const uint32_t n_chunks = d.PT / 64;
+        const uint64_t groups = (static_cast<uint64_t>(n_park) + 63) / 64;
+        uint32_t S = static_cast<uint32_t>(24576 / groups);
+        if (S > n_chunks) S = n_chunks;
+        if (S < 1) S = 1;
+        int grid = grid_for(groups * S, kBlock / 64);
+        if (grid > 1536) grid = 1536;
+        hipLaunchKernelGGL(ku, dim3(grid), dim3(kBlock), 0, st, d, n_park, 2, 1, S);
+        if (int rc = mark(4)) return rc;
+        HIP_TRY(hipMemsetAsync(d.counters + kCntWalkTicket, 0, sizeof(unsigned long long), st));
+        launch_walk(n_park, 2);
+    } else if (int rc = mark(4)) return rc;
+    if (int rc = mark(5)) return rc;
+    hipLaunchKernelGGL(k_walk_finish, dim3(1), dim3(1), 0, st, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h64, d.counters + kCntTailLimit, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (sim->profiling) {
+        float ms[5];
+        for (int i = 0; i < 5; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+        sim->prof_ms[0] += ms[0]; sim->prof_ms[1] += ms[1]; sim->prof_ms[2] += ms[3];
+        sim->prof_walk_ms[0] += ms[2]; sim->prof_walk_ms[1] += ms[4];
+        sim->prof_tail_ms += ms[2] + ms[4];
+        sim->prof_launches += 1;
+        for (int i = 0; i < 6; ++i) (void)hipEventDestroy(ev[i]);
+    }
+    sim->t = 1;
+    sim->live_upper = 0;
+    if (*h64) return fail(RG_ELIMIT, "more than %u steps", kMaxSteps);
+    return RG_OK;
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -3389,6 +3949,13 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     s->prof_tail_ms = 0.0;
     s->cached_search_old = false;
     if (const char* e = getenv("RECOGYM_CACHED")) s->cached_search_old = !strcmp(e, "search");
+    // user-major walk: wherever the per-user cache exists and the policy acts lane by lane (the frozen LogReg
+    // policy acts wave-cooperatively: lock-step); RECOGYM_WALK=0 keeps the lock-step loop (A/B tests)
+    s->walk = d.use_cache && (d.policy == RG_POLICY_UNIFORM_ENV || d.policy == RG_POLICY_RANDOM_AGENT ||
+                              d.policy == RG_POLICY_ORGANIC_USER_COUNT || d.policy == RG_POLICY_LAST_VIEW_TABLE);
+    if (const char* e = getenv("RECOGYM_WALK")) if (e[0] == '0') s->walk = false;
+    s->n_cus = 0;
+    s->prof_walk_ms[0] = s->prof_walk_ms[1] = 0.0;
     if (const char* e = getenv("RECOGYM_TAIL")) s->tail_below = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_REPACK")) s->repack_every = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_ABLATE")) d.ablate = static_cast<uint32_t>(atoi(e));
@@ -3529,6 +4096,7 @@ int rg_sim_run(rg_sim* sim, uint32_t max_steps, void* stream) {
     if (sim->d.policy == RG_POLICY_EXTERNAL) return fail(RG_ESTATE, "rg_sim_run needs a device policy");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!sim->h_pinned) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sim->h_pinned), 4 * sizeof(uint32_t)));
+    if (sim->walk && sim->t == 0 && max_steps >= kMaxSteps) return run_walk(sim, st);
     uint32_t done_steps = 0;
     const uint32_t chunk = 16;
     while (done_steps < max_steps) {
@@ -3594,6 +4162,7 @@ int rg_sim_set_profiling(rg_sim* sim, int on) {
     sim->prof_used = 0; sim->prof_launches = 0;
     sim->prof_ms[0] = sim->prof_ms[1] = sim->prof_ms[2] = sim->prof_ms[3] = 0.0;
     sim->prof_tail_ms = 0.0;
+    sim->prof_walk_ms[0] = sim->prof_walk_ms[1] = 0.0;
     return RG_OK;
 }
 
@@ -3603,6 +4172,7 @@ int rg_sim_get_profile(rg_sim* sim, double* out) {
     out[0] = sim->prof_ms[0]; out[1] = sim->prof_ms[1]; out[2] = sim->prof_ms[2]; out[3] = sim->prof_ms[3];
     out[4] = static_cast<double>(sim->prof_launches);
     out[5] = sim->prof_tail_ms;
+    out[6] = sim->prof_walk_ms[0]; out[7] = sim->prof_walk_ms[1];
     return RG_OK;
 }
 

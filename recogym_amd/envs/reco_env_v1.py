@@ -307,14 +307,23 @@ class RecoEnv1:
         """All users at once on the GPU -> (counters dict, Simulator).  User ids are
         first_user_id .. ; the first `num_organic_users` ids are organic-only warm-up users."""
         total = num_users + num_organic_users
-        sim = self.make_simulator(total, agent, log=log, device=device)
+        pol = device_policy_of(agent)
+        sim = self.make_simulator(total, agent, log=log, device=device, policy=pol)
         while True:
             sim.reset_users(first_user_id, total,
                             organic_only_below=first_user_id + num_organic_users)
             sim.run()
             cnt = sim.counters()
             if cnt['hist_overflow']:
-                raise _abi.RecoGymHipError('per-user view history overflowed ouc_history_cap')
+                # a user viewed more distinct products than its history row holds (default 255): run again with
+                # rows twice as long, the way a log overflow is retried with a larger buffer
+                cap = 2 * max(int((pol.get('ouc') or {}).get('history_cap', 0) or pol.get('history_cap', 0) or 255), 255) + 1
+                if cap > 4 * self.config.num_products + 512:
+                    raise _abi.RecoGymHipError('per-user view history overflowed ouc_history_cap')
+                sim.close()
+                pol = dict(pol, ouc=dict(pol.get('ouc') or {}, history_cap=cap))
+                sim = self.make_simulator(total, agent, log=log, device=device, policy=pol)
+                continue
             if cnt['log_dropped'] == 0:
                 return cnt, sim
             sim.set_log_capacity(cnt['log_rows'] + cnt['log_dropped'] + 1024)
@@ -370,6 +379,9 @@ class RecoEnv1:
             return (Observation(DefaultContext(self.current_time, self.current_user_id), sessions),
                     None, self.state == stop, info)
         assert (action_id is not None)
+        if not 0 <= int(action_id) < self.config.num_products:
+            # the reference indexes ctr[action] (reco_env_v1.py:113): IndexError; the device would read out of bounds
+            raise IndexError(f'action {action_id} is out of bounds for {self.config.num_products} products')
         row = self._advance(action_id)
         reward = int(row['c'])
         sessions = self.generate_organic_sessions() if self.state == organic \
@@ -403,19 +415,20 @@ class RecoEnv1:
         return action, observation, reward, done, info
 
     # -- generate_logs ----------------------------------------------------------------------------
-    def generate_logs(self, num_offline_users, agent=None, num_organic_offline_users=0):
-        """Logs of `agent` (None = uniform random actions) over the given number of users."""
+    def generate_logs(self, num_offline_users, agent=None, num_organic_offline_users=0, first_user_id=0):
+        """Logs of `agent` (None = uniform random actions) over the given number of users.  `first_user_id`
+        (an extension; the reference always starts at 0) selects which addressed users are simulated."""
         use = agent if agent else self.agent
         pol = device_policy_of(use)
         if pol is not None:
-            cnt, sim = self.simulate(num_offline_users, use, num_organic_offline_users)
+            cnt, sim = self.simulate(num_offline_users, use, num_organic_offline_users, first_user_id=first_user_id)
             cols = sim.log_columns()
             sim.close()
             with_all = bool(getattr(self.config, 'with_ps_all', False)) and use is None
             return columns_to_dataframe(cols, self.config.num_products, with_all)
-        return self._generate_logs_per_user(num_offline_users, use, num_organic_offline_users)
+        return self._generate_logs_per_user(num_offline_users, use, num_organic_offline_users, first_user_id)
 
-    def _generate_logs_per_user(self, num_offline_users, agent, num_organic_offline_users):
+    def _generate_logs_per_user(self, num_offline_users, agent, num_organic_offline_users, first_user_id=0):
         """Any Python agent: the reference's loop (abstract.py:292-316), one user at a time."""
         old_agent, self.agent = self.agent, agent
         cols = {k: [] for k in ('t', 'u', 'z', 'v', 'a', 'c', 'ps', 'ps-a')}
@@ -433,7 +446,7 @@ class RecoEnv1:
                 put(action['t'], action['u'], 'bandit', None, action['a'], reward, action['ps'],
                     action['ps-a'] if 'ps-a' in action else ())
 
-        uid = 0
+        uid = first_user_id
         for _ in range(num_organic_offline_users):
             self.reset(uid)
             uid += 1

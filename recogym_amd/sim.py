@@ -32,7 +32,10 @@ def default_log_capacity(config, n_users):
     """Rows a run emits: each user lives ~Geometric(prob_leave) events plus its phantom row."""
     p_stop = max(float(config.prob_leave_organic), 1e-6)
     mean = 1.0 / p_stop + 1.0
-    return int(n_users * (mean + 1.0) + 8.0 * mean * math.sqrt(n_users) + 4096)
+    rows = n_users * (mean + 1.0) + 8.0 * mean * math.sqrt(n_users) + 4096
+    # the user-major walk (sigma_omega = 0) reserves raw-log rows per wave in chunks and leaves a few percent of
+    # them unused: up to 63 per chunk of >= 256 rows and the rest of every wave's last chunk
+    return int(rows * 1.04 + min(rows * 0.3, 4.0e6) + 65536)
 
 
 def decode_rows(raw, uniform_ps=None, ps64=None, p_click=None):
@@ -201,10 +204,10 @@ class Simulator:
 
     def profile(self):
         """-> dict(draw_mfma_ms, draw_search_ms, draw_exact_ms, advance_ms, steps, tail_ms), HIP events."""
-        out = (C.c_double * 6)()
+        out = (C.c_double * 8)()
         _abi.check(self.lib.rg_sim_get_profile(self._h, out), 'rg_sim_get_profile')
         return dict(draw_mfma_ms=out[0], draw_search_ms=out[1], draw_exact_ms=out[2],
-                    advance_ms=out[3], steps=int(out[4]), tail_ms=out[5])
+                    advance_ms=out[3], steps=int(out[4]), tail_ms=out[5], walk1_ms=out[6], walk2_ms=out[7])
 
     def states(self):
         with torch.cuda.device(self.device):
@@ -297,6 +300,13 @@ class Simulator:
         """log_columns() left on the device (torch tensors), e.g. for
         agents.feature_feed.train_data_from_log_torch."""
         return self.log_columns(on_device=True)
+
+    def raw_log(self):
+        """The raw (unsorted) device log without its unused entries: (rows, 4) int32 tensor.  The user-major
+        walk reserves rows per wave in chunks and marks what it leaves unused (code 0xFFFFFFFF)."""
+        n = min(self.counters()['log_rows'], self.log_capacity)
+        raw = self.log[:n]
+        return raw[raw[:, 2] != -1]
 
     def rows(self):
         """Decoded host rows in the reference's order."""

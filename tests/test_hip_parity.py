@@ -224,7 +224,8 @@ def test_more_than_a_million_users_shard_consistently():
         sim.reset_users(first, n)
         sim.run()
         c = sim.counters()
-        rows = sim.log[:c['log_rows']].to(torch.int64)
+        rows = sim.raw_log().to(torch.int64)
+        assert rows.shape[0] == c['organic'] + c['bandit']
         chk = [(rows[:, i] * (rows[:, 1] + 7)).sum().item() for i in range(3)]
         sim.close()
         return c, chk
@@ -291,7 +292,8 @@ def test_certified_draws_equal_float64_draws_at_scale(shape, monkeypatch):
         sim.reset_users(1000, n)
         sim.run()
         c = sim.counters()
-        rows = sim.log[:c['log_rows']].to(torch.int64)
+        rows = sim.raw_log().to(torch.int64)
+        assert rows.shape[0] == c['organic'] + c['bandit']
         chk = [(rows[:, i] * (rows[:, 1] + 7) * (rows[:, 0] + 13)).sum().item() for i in range(4)]
         sim.close()
         return c, chk
@@ -299,7 +301,7 @@ def test_certified_draws_equal_float64_draws_at_scale(shape, monkeypatch):
     fast_c, fast_chk = run('f16')
     ref_c, ref_chk = run('f64')
     assert 0 < fast_c['exact_draws'] < 0.1 * fast_c['organic'] and ref_c['exact_draws'] == 0
-    for k in ('organic', 'bandit', 'clicks', 'phantom', 'log_rows'):
+    for k in ('organic', 'bandit', 'clicks', 'phantom'):
         assert fast_c[k] == ref_c[k], k
     assert fast_chk == ref_chk
 
@@ -364,14 +366,15 @@ def test_repack_and_tail_kernel_do_not_change_the_log_at_scale(monkeypatch):
         sim.reset_users(0, n)
         sim.run()
         c = sim.counters()
-        rows = sim.log[:c['log_rows']].to(torch.int64)
+        rows = sim.raw_log().to(torch.int64)
+        assert rows.shape[0] == c['organic'] + c['bandit']
         chk = [(rows[:, i] * (rows[:, 1] + 7) * (rows[:, 0] + 13)).sum().item() for i in range(4)]
         sim.close()
         return c, chk
 
     a_c, a_chk = run('16', '4096')
     b_c, b_chk = run('0', '0')
-    for k in ('organic', 'bandit', 'clicks', 'phantom', 'log_rows'):
+    for k in ('organic', 'bandit', 'clicks', 'phantom'):
         assert a_c[k] == b_c[k], k
     assert a_chk == b_chk
 
@@ -392,14 +395,15 @@ def test_fused_and_sliced_draw_forms_agree_at_scale(monkeypatch):
         sim.reset_users(0, n)
         sim.run()
         c = sim.counters()
-        rows = sim.log[:c['log_rows']].to(torch.int64)
+        rows = sim.raw_log().to(torch.int64)
+        assert rows.shape[0] == c['organic'] + c['bandit']
         chk = [(rows[:, i] * (rows[:, 1] + 7) * (rows[:, 0] + 13)).sum().item() for i in range(4)]
         sim.close()
         return c, chk
 
     fused_c, fused_chk = run('1')
     sliced_c, sliced_chk = run('4')
-    for k in ('organic', 'bandit', 'clicks', 'phantom', 'log_rows'):
+    for k in ('organic', 'bandit', 'clicks', 'phantom'):
         assert fused_c[k] == sliced_c[k], k
     assert fused_chk == sliced_chk
     assert fused_c['live'] == 0 and fused_c['hist_overflow'] == 0
@@ -556,7 +560,7 @@ def test_certificate_is_sound_for_uniforms_next_to_cdf_boundaries(mode, shape, m
     assert clear.mean() > 0.95
 
 
-@pytest.mark.parametrize('variant', ['default', 'repack', 'lockstep', 'sliced'])
+@pytest.mark.parametrize('variant', ['default', 'sliced', 'nowalk', 'repack', 'lockstep', 'nowalk_sliced'])
 @pytest.mark.parametrize('shape', [(129, 9, 1500, 40), (2049, 20, 500, 0), (10000, 20, 150, 0), (33, 3, 2500, 0)])
 def test_sigma_omega_zero_sum_cache_matches_the_oracle(shape, variant, monkeypatch):
     """sigma_omega = 0 (BASELINE configs 2 and 3): a user's omega never changes, so the exp-sums of its first
@@ -566,12 +570,16 @@ def test_sigma_omega_zero_sum_cache_matches_the_oracle(shape, variant, monkeypat
     the product-sliced form of the sweep."""
     from oracle import oracle as orc
     P, K, n, n_org = shape
+    # 'default' / 'sliced': the user-major walk (k_walk) after a fused / product-sliced sweep; the others keep the
+    # lock-step loop over the cache (k_draw_cached), which also serves the step-by-step API
+    if variant in ('nowalk', 'repack', 'lockstep', 'nowalk_sliced'):
+        monkeypatch.setenv('RECOGYM_WALK', '0')
     if variant == 'repack':
         monkeypatch.setenv('RECOGYM_REPACK_MIN', '1')
         monkeypatch.setenv('RECOGYM_REPACK', '3')
     if variant == 'lockstep':
         monkeypatch.setenv('RECOGYM_TAIL', '0')
-    if variant == 'sliced':
+    if variant in ('sliced', 'nowalk_sliced'):
         monkeypatch.setenv('RECOGYM_SLICES', '4')
     pol = dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=31, ouc=dict(gu.OUC_DEFAULTS))
     cfg = Configuration({**env_1_args, 'random_seed': 700 + P, 'num_products': P, 'K': K, 'sigma_omega': 0.0})
@@ -599,15 +607,49 @@ def test_sum_cache_does_not_change_the_log_at_scale(monkeypatch):
         sim.reset_users(0, n)
         sim.run()
         c = sim.counters()
-        rows = sim.log[:c['log_rows']].to(torch.int64)
+        rows = sim.raw_log().to(torch.int64)
+        assert rows.shape[0] == c['organic'] + c['bandit']
         chk = [(rows[:, i] * (rows[:, 1] + 7) * (rows[:, 0] + 13)).sum().item() for i in range(4)]
         sim.close()
         return c, chk
 
     on_c, on_chk = run('1')
     off_c, off_chk = run('0')
-    for k in ('organic', 'bandit', 'clicks', 'phantom', 'log_rows'):
+    for k in ('organic', 'bandit', 'clicks', 'phantom'):
         assert on_c[k] == off_c[k], k
     assert on_chk == off_chk
     assert abs(on_c['exact_draws'] - off_c['exact_draws']) < 0.05 * off_c['exact_draws']
     assert off_c['exact_sweeps'] == off_c['exact_draws'] and 0 < on_c['exact_sweeps'] < on_c['exact_draws']
+
+
+def test_user_major_walk_equals_the_lock_step_loop_at_scale(monkeypatch):
+    """sigma_omega = 0, 300 000 users, P = 1 000, OrganicUserEventCounter in the loop: the user-major walk
+    (default: sweep -> k_walk -> batched float64 sums of the parked users -> k_walk) logs exactly the rows of
+    the lock-step loop (RECOGYM_WALK=0) — order-independent checksum of every raw row and the counters; the
+    sorted logs are identical row for row on a prefix of the users."""
+    from recogym_amd.sim import Simulator
+    cfg = Configuration({**env_1_args, 'random_seed': 29, 'num_products': 1000, 'K': 20, 'sigma_omega': 0.0})
+    n = 300_000
+
+    def run(walk):
+        monkeypatch.setenv('RECOGYM_WALK', walk)
+        sim = Simulator(cfg, n, device='cuda:0', policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=5,
+                        ouc=dict(gu.OUC_DEFAULTS))
+        sim.reset_users(7, n)
+        sim.run()
+        c = sim.counters()
+        rows = sim.raw_log().to(torch.int64)
+        assert rows.shape[0] == c['organic'] + c['bandit']
+        chk = [(rows[:, i] * (rows[:, 1] + 7) * (rows[:, 0] + 13)).sum().item() for i in range(4)]
+        srt, off = sim.sorted_log()
+        head = srt[:int(off[2000])].cpu().numpy().copy()
+        sim.close()
+        return c, chk, head
+
+    w_c, w_chk, w_head = run('1')
+    l_c, l_chk, l_head = run('0')
+    for k in ('organic', 'bandit', 'clicks', 'phantom', 'live', 'hist_overflow', 'log_dropped'):
+        assert w_c[k] == l_c[k], k
+    assert w_chk == l_chk
+    assert np.array_equal(w_head, l_head)
+    assert w_c['step'] == l_c['step'] and 0 < w_c['exact_sweeps'] <= w_c['exact_draws']
