@@ -38,12 +38,58 @@ class OrganicUserEventCounterAgent(Agent):
 
     def device_policy(self):
         c = self.config
+        pol = dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=c.random_seed,
+                   ouc=dict(select_randomly=c.select_randomly, epsilon=c.epsilon,
+                            exploit_explore=c.exploit_explore,
+                            reverse_pop=getattr(c, 'reverse_pop', False)))
         if getattr(c, 'with_ps_all', False):
-            return None
-        return dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=c.random_seed,
-                    ouc=dict(select_randomly=c.select_randomly, epsilon=c.epsilon,
-                             exploit_explore=c.exploit_explore,
-                             reverse_pop=getattr(c, 'reverse_pop', False)))
+            # the device logs (a, ps); the whole distribution of every bandit row (`ps-a`, organic_user_count.py:77-94)
+            # is a function of the user's views so far, which the log itself holds: rebuilt at materialisation
+            pol['ps_all'] = self.ps_all_from_log
+        return pol
+
+    def ps_all_from_log(self, df):
+        """`ps-a` of every bandit row of a log this agent produced (with_ps_all=True): the distribution act() sampled
+        from, recomputed from the organic rows that precede the row (same arithmetic as act(); the explore flip is
+        the addressed policy draw of (user, t)).  O(bandit rows x P) on the host, like the reference's own column."""
+        c = self.config
+        P = c.num_products
+        out = np.empty(len(df), dtype=object)
+        views = np.zeros(P, dtype=np.int64)
+        cur = None
+        u_col = df['u'].to_numpy(dtype=np.int64)
+        t_col = df['t'].to_numpy()
+        is_b = (df['z'] == 'bandit').to_numpy()
+        v_col = df['v'].to_numpy(dtype=np.float64, na_value=np.nan)
+        a_col = df['a'].to_numpy(dtype=np.float64, na_value=np.nan)
+        eps = c.epsilon
+        for i in range(len(df)):
+            if u_col[i] != cur:
+                cur = u_col[i]
+                views[:] = 0
+            if not is_b[i]:
+                views[int(v_col[i])] += 1
+                out[i] = None
+                continue
+            f = views.astype(np.float64)
+            if c.exploit_explore:
+                _, u0, _ = rng.policy_uniforms(c.random_seed, int(u_col[i]), int(t_col[i]))
+                if not (eps / (eps + (1 - eps)) <= u0):
+                    f = (views == 0).astype(np.float64)
+                p = f / np.sum(f)
+            else:
+                f = eps + f
+                p = f / np.sum(f)
+                if getattr(c, 'reverse_pop', False):
+                    p = 1 - p
+                    p = p / np.sum(p)
+            if c.select_randomly:
+                out[i] = p
+            else:
+                one = np.zeros(P)
+                one[int(a_col[i])] = 1.0
+                out[i] = one
+        return out
 
     def reset(self):
         self.views[:] = 0

@@ -116,6 +116,7 @@ struct DevSim {
     // split-bf16 kernel geometry: A row = [G1|G2|G3] (3K bf16, zero padded to 16*N1), row stride RS bytes
     uint32_t N1, N2, N3;      // k-steps of the three MFMA groups (B = w1 / w2 / w3)
     uint32_t f16;             // 1: gsplit holds the two-way fp16 split [G1|G2|G1|0..|1] (one group of N1 k-steps)
+    uint32_t wide;            // 1: served by k_draw_f16w (21 < K <= 64: 512-thread blocks, 256 users per table pass)
     uint32_t RS;              // row stride of gsplit / its LDS tile, bytes ((RS/16) odd: conflict-free b128)
     uint32_t TPB;             // products per LDS tile of the bf16 kernel
     unsigned short* gsplit;   // [P_pad][RS/2] bf16 three-way split of fl32(Gamma log2 e), then 1,1,1 in the last 3 columns of 16*N1
@@ -189,6 +190,7 @@ struct rg_sim {
     bool repacked;            // slots no longer equal user indices (since the last reset)
     bool cached_search_old;   // RECOGYM_CACHED=search: the first form of the cached draw (k_draw_search over the cache)
     bool walk;                // rg_sim_run "to the end" walks the run user-major (k_walk) instead of step-major
+    int walk_occ;             // blocks per CU of the walk kernel (RECOGYM_WALK_OCC: 2, 3 or 4)
     int n_cus;                // compute units of the device (grid of the persistent walk kernel)
     double prof_walk_ms[2];   // round 1 / round 2 of k_walk
     uint32_t repack_every;    // steps between repacks (RECOGYM_REPACK, 0 = never)
@@ -197,6 +199,7 @@ struct rg_sim {
     uint32_t* h_pinned;       // 4 x u32 staging for the live-count readback
     size_t mfma_smem, bf16_smem;
     void (*bf16_kernel)(DevSim, uint32_t, uint32_t);
+    uint32_t draw_threads, draw_users;   // block size of that kernel and the users one block sweeps for (256 / 128; wide K: 512 / 256)
     bool profiling;
     std::vector<hipEvent_t> prof_events;   // 5 per profiled step: before draw, after mfma, after search, after exact, after advance
     size_t prof_used;
@@ -254,9 +257,16 @@ Geom geom_of(const rg_config& c) {
             g.F16 = 1;
             g.N1 = (3 * c.K + 1 + 15) / 16; g.N2 = 0; g.N3 = 0;
         }
+        // wide embeddings (21 < K <= 64): the same two-way fp16 split, k_draw_f16w (N1 classes 7 / 10 / 13 k-steps,
+        // tiles of one pair of chunks); RECOGYM_F16W=0 keeps the older choice (bf16 classes / fp32 MFMA)
+        const char* e_w = getenv("RECOGYM_F16W");
+        if (want_f16 && !g.F16 && c.K > 21 && c.K <= 64 && (g.KH == 16 || g.KH == 32) && !(e_w && e_w[0] == '0')) {
+            g.F16 = 2;
+            g.N1 = 3 * c.K + 1 <= 112 ? 7 : (3 * c.K + 1 <= 160 ? 10 : 13); g.N2 = 0; g.N3 = 0;
+        }
         if (g.N1) {
             g.RS = 32 * g.N1 + 16;
-            g.TPB = 128;                            // 4 chunks per tile: the kernel walks pairs of pairs
+            g.TPB = g.F16 == 2 ? 64 : 128;          // 4 chunks per tile: the kernel walks pairs of pairs (wide: one pair)
         }
     }
     g.sc_chunks = (g.n_chunks + kMaxSC - 1) / kMaxSC;
@@ -355,7 +365,8 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->gamma32 = gamma32; d->mu32 = mu32; d->gamma32t = gamma32t; d->stats = stats; d->omega = omega; d->list = list;
         d->gamma_rm = gamma_rm; d->XKB = xkb;
         d->gammaT = gammaT; d->PT = static_cast<uint32_t>(PT); d->exact_ref = exact_ref; d->exact_sums = exact_sums; d->sc_scratch = sc_scratch; d->chunk_scratch = chunk_scratch;
-        d->gsplit = gsplit; d->mu32s = mu32s; d->N1 = g.N1; d->N2 = g.N2; d->N3 = g.N3; d->RS = g.RS; d->TPB = g.TPB; d->f16 = g.F16;
+        d->gsplit = gsplit; d->mu32s = mu32s; d->N1 = g.N1; d->N2 = g.N2; d->N3 = g.N3; d->RS = g.RS; d->TPB = g.TPB;
+        d->f16 = g.F16 ? 1u : 0u; d->wide = g.F16 == 2 ? 1u : 0u;
         d->KH = g.KH; d->KS = g.KS; d->TP = g.TP; d->P_pad = g.P_pad; d->n_chunks = g.n_chunks;
         d->sc_chunks = g.sc_chunks; d->n_sc = g.n_sc; d->use_mfma = g.KH ? 1u : 0u;
         d->step_cnt = step_cnt; d->log_base = log_base; d->exact_list = exact_list;
@@ -2543,6 +2554,251 @@ draw_kernel_t bf16_kernel_for(const DevSim& d) {
     return nullptr;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// k_draw_f16w — the two-way fp16 split sweep for WIDE embeddings (21 < K <= 64: BASELINE config 4's K = 64).
+//
+// Same arithmetic, table and certificate as k_draw_bf16p<.., F16>: A row = [G1 | G2 | G1 | 0.. | 1], B row =
+// [w1 | w1 | w2 | 0.. | -q], N1 = ceil((3K + 1) / 16) k-steps (13 at K = 64) of v_mfma_f32_32x32x16_f16 per
+// 32-product chunk.  What differs is the shape around it:
+//   * the matrix pipe binds here (13 MFMAs = 416 pipe cycles per chunk against ~220 cycles of exp/sum VALU
+//     work), so the A operands are NOT double-buffered per pair in registers (2 x 104 VGPRs at N1 = 13): they
+//     are read from the LDS tile k-step by k-step, next to the MFMA that consumes them;
+//   * a block is 8 waves = 256 users per pass over the table (the split table is 43 MB at P = 10^5: at 128
+//     users per pass the L2 -> LDS stream alone would need ~2/3 of a CU's L2 bandwidth);
+//   * tiles are one PAIR of chunks (64 products, 27 KB at N1 = 13), three LDS buffers, DMA two tiles ahead,
+//     counted vmcnt at the tile barrier (as in k_draw_bf16p).
+// The exp-sums of pair n - 1 sit in the issue slots between the MFMAs of pair n (two independent accumulator
+// chains), order pinned with sched_barrier.
+// ------------------------------------------------------------------------------------------
+template <int KH, int N1>
+__global__ void __launch_bounds__(512, 1) k_draw_f16w(DevSim d, uint32_t t, uint32_t S) {
+    constexpr uint32_t RSc = 32 * N1 + 16, TILE_B = 64 * RSc, NT = TILE_B / 1024;     // 1 KB per wave-wide DMA instruction
+    constexpr int NW = 8;
+    using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* g_buf = smem_raw;                                           // [3][64][RSc]
+    float* mu_buf = reinterpret_cast<float*>(g_buf + 3 * TILE_B);     // [3][64]
+    float* om_stage = mu_buf + 3 * 64;                                // [8 waves][32 users][2KH] omega32
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const uint32_t n_tiles = (n_o + 32 * NW - 1) / (32 * NW);
+    const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const float mumax = d.stats[2 * KH + 1], g2max = d.stats[2 * KH];
+    const uint32_t scps = (d.n_sc + S - 1) / S;                       // super-chunks per slice
+    const uint32_t n_work = n_tiles * S;
+    float* omu = om_stage + (wave * 32 + j) * 2 * KH;                 // this lane's user's omega32
+    // this wave's DMA instructions per tile (they complete in issue order: the tile barrier may leave these in flight)
+    const int my_dma = static_cast<int>((NT - wave + NW - 1) / NW) + (wave == NW - 1 ? 1 : 0);
+
+    for (uint32_t wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
+        const uint32_t tb = wk / S, slice = wk % S;
+        const uint32_t chunk_lo = min(slice * scps * d.sc_chunks, d.n_chunks);
+        const uint32_t chunk_hi = min((slice + 1) * scps * d.sc_chunks, d.n_chunks);
+        if (chunk_lo >= chunk_hi) continue;
+        const uint32_t pt_lo = chunk_lo / 2, pt_hi = (chunk_hi + 1) / 2;      // tiles = pairs of chunks
+        const size_t wslot = (S == 1 ? static_cast<size_t>(blockIdx.x) : static_cast<size_t>(tb)) * NW + wave;
+        float* scr_chunk = d.chunk_scratch + wslot * d.n_chunks * 32;
+        float2* scr = d.sc_scratch + wslot * kMaxSC * 32;
+        const uint32_t pos = tb * (32 * NW) + wave * 32 + j;
+        const bool active = pos < n_o;
+        const uint32_t slot = active ? cur[pos] : 0u;
+        const SumsView view = sums_view(d, scr, scr_chunk, j, active, slot);
+        __syncthreads();           // every wave is done with the LDS buffers and stage (previous work item)
+        const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
+        const rg_v4i rs_g = raw_buffer_rsrc(d.gsplit), rs_m = raw_buffer_rsrc(d.mu32s);
+        const uint32_t g_lds = lds_addr_of(g_buf), mu_lds = lds_addr_of(mu_buf);
+        auto fetch_tile = [&](uint32_t ti) {
+            for (uint32_t off = static_cast<uint32_t>(wave) * 1024u; off < TILE_B; off += NW * 1024u)
+                dma_to_lds_b128(rs_g, g_lds + ((ti - pt_lo) % 3u) * TILE_B + off, lane16, ti * TILE_B + off);
+            if (wave == NW - 1 && lane < 16) dma_to_lds_b128(rs_m, mu_lds + ((ti - pt_lo) % 3u) * 256u, lane16, ti * 256u);
+        };
+        fetch_tile(pt_lo);
+        // ---- omega32 of the user -> LDS stage (also the logit error bound) ----
+        float absdot = 0.0f, sq = 0.0f, absw = 0.0f;
+#pragma unroll
+        for (int s2 = 0; s2 < KH; ++s2) {
+            const uint32_t k = h * KH + s2;
+            float w = 0.0f;
+            if (active && k < d.K) w = static_cast<float>(d.omega[static_cast<size_t>(slot) * d.OMS + k]);
+            omu[k] = w;
+            absdot = fmaf(fabsf(w), d.stats[k], absdot);
+            sq = fmaf(w, w, sq);
+            absw += fabsf(w);
+        }
+        absdot += swap32(absdot);
+        sq += swap32(sq);
+        absw += swap32(absw);
+        const float Ahat = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
+        const double delta_fixed = kDeltaFixedBf16 + f16_extra_delta(d, Ahat, absw);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // ---- B fragments [w1 | w1 | w2 | 0 .. | -q]: lane (j, h) holds elements ke = 16 s + 8 h + e of its user's row ----
+        bf16x8 Bm[N1];
+        {
+            const uint32_t K = d.K;
+#pragma unroll
+            for (int s2 = 0; s2 < N1; ++s2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t ke = 16 * s2 + 8 * h + e;
+                    unsigned short sp[2] = {0, 0};
+                    if (ke < 3 * K) f16_split2(omu[ke % K], sp);
+                    Bm[s2][e] = static_cast<short>(ke < 2 * K ? sp[0] : sp[1]);
+                }
+        }
+        float q = 0.0f;            // reference (log2 units, an integer) the MFMAs being issued subtract
+        auto set_reference = [&](float qn) {
+            qn = fminf(fmaxf(qn, -2047.0f), 2047.0f);       // one fp16 piece: an integer |q| <= 2047 is exact
+            q = qn;
+            if (h == 1) Bm[N1 - 1][7] = static_cast<short>(__builtin_bit_cast(unsigned short, static_cast<_Float16>(-qn)));
+        };
+        auto mm = [](const bf16x8& a, const bf16x8& b, const f32x16& c) -> f32x16 {
+            return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+        };
+        // this lane's operand rows in buffer 0 (chunk 0 of the pair; chunk 1 is 32 rows further)
+        const char* a_lane = g_buf + j * RSc + 16 * h;
+        const char* m_lane = reinterpret_cast<const char*>(mu_buf) + 16 * h;
+        auto load_mu = [&](f32x16& acc, const char* mb, int which) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const float4 m = *reinterpret_cast<const float4*>(mb + 128 * which + 32 * qq);
+                acc[4 * qq] = m.x; acc[4 * qq + 1] = m.y; acc[4 * qq + 2] = m.z; acc[4 * qq + 3] = m.w;
+            }
+        };
+        // ---- bookkeeping of finished pairs (one pair behind the MFMAs) ----
+        double s_sc = 0.0;         // running exp-sum of the super-chunk being summed
+        float wcmax = 0.0f;        // its largest chunk sum
+        int n_resc = 0;
+        float q_next = 0.0f;       // reference to switch to at the next super-chunk start
+        const uint32_t sc_pairs = d.sc_chunks / 2;
+        uint32_t sc_cur = chunk_lo / d.sc_chunks, sc_left = sc_pairs;
+        auto book = [&](uint32_t ti_done, float s0, float s1, float q_used) {   // sums of the pair of tile ti_done
+            s0 += swap32(s0);
+            s1 += swap32(s1);
+            const uint32_t ci = 2 * ti_done;
+            // scratch layout of the 4-chunk tiles the search reads: [tile of 4][user][4 chunks]
+            *reinterpret_cast<float2*>(view.chunk + static_cast<size_t>(ci >> 2) * view.tile_stride + (ci & 3)) = make_float2(s0, s1);
+            wcmax = fmaxf(wcmax, fmaxf(s0, s1));
+            s_sc += static_cast<double>(s0 + s1);
+            if (--sc_left == 0) {
+                view.rec[sc_cur * view.rec_stride] = make_float2(static_cast<float>(s_sc), q_used);
+                s_sc = 0.0;
+                // some logit is >= ~43 above the reference: re-reference from the next super-chunk that has not started
+                if (wcmax > 2.8e14f) q_next = fmaxf(q_next, q_used + floorf(__builtin_amdgcn_logf(wcmax)));
+                wcmax = 0.0f;
+                ++sc_cur;
+                sc_left = sc_pairs;
+            }
+        };
+        RG_DMA_WAIT();
+        __syncthreads();           // tile pt_lo landed
+        if (pt_lo + 1 < pt_hi) fetch_tile(pt_lo + 1);
+        if (pt_lo + 2 < pt_hi) fetch_tile(pt_lo + 2);
+        {   // first chunk with reference 0: its max (an integer after ceil, exact in one fp16 piece) becomes the reference
+            f32x16 y;
+            load_mu(y, m_lane, 0);
+#pragma unroll
+            for (int s2 = 0; s2 < N1; ++s2) y = mm(*reinterpret_cast<const bf16x8*>(a_lane + 32 * s2), Bm[s2], y);
+            float cm = y[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) cm = fmaxf(cm, y[r]);
+            set_reference(fmaxf(ceilf(fmaxf(cm, swap32(cm))), -1.0e30f));
+            q_next = q;
+        }
+        f32x16 p0, p1;             // logits of the previous pair, waiting for their exp-sums
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { p0[r] = 0.0f; p1[r] = 0.0f; }
+        float q_prev = q;          // reference they were taken with
+        uint32_t sc_issue_left = sc_pairs;                      // pairs left in the super-chunk being ISSUED
+        for (uint32_t ti = pt_lo; ti < pt_hi; ++ti) {
+            if (ti > pt_lo) {
+                // tile ti has landed once at most this wave's DMA of tile ti + 1 (issued after it) is still in flight
+                if (ti + 1 >= pt_hi) RG_TILE_BARRIER(0);
+                else if (my_dma == 4) RG_TILE_BARRIER(4);
+                else if (my_dma == 3) RG_TILE_BARRIER(3);
+                else RG_TILE_BARRIER(2);
+                if (ti + 2 < pt_hi) fetch_tile(ti + 2);        // into the buffer of tile ti - 1: every wave is past it
+            }
+            const uint32_t bsel = (ti - pt_lo) % 3u;
+            const char* ab = a_lane + bsel * TILE_B;
+            const char* mb = m_lane + bsel * 256u;
+            if (sc_issue_left == sc_pairs && q_next != q) { set_reference(q_next); n_resc += 1; }   // a super-chunk starts
+            if (--sc_issue_left == 0) sc_issue_left = sc_pairs;
+            f32x16 a0, a1;
+            load_mu(a0, mb, 0);
+            load_mu(a1, mb, 1);
+            f32x2 x0[4], x1[4];
+            const bool have_p = ti > pt_lo;
+            // A operands: a ring three k-steps deep, read two steps ahead of the MFMA that consumes them
+            bf16x8 A0r[3], A1r[3];
+#pragma unroll
+            for (int s2 = 0; s2 < 2 && s2 < N1; ++s2) {
+                A0r[s2] = *reinterpret_cast<const bf16x8*>(ab + 32 * s2);
+                A1r[s2] = *reinterpret_cast<const bf16x8*>(ab + 32 * RSc + 32 * s2);
+            }
+            RG_PIN();
+#pragma unroll
+            for (int s2 = 0; s2 < N1; ++s2) {
+                if (s2 + 2 < N1) {
+                    A0r[(s2 + 2) % 3] = *reinterpret_cast<const bf16x8*>(ab + 32 * (s2 + 2));
+                    A1r[(s2 + 2) % 3] = *reinterpret_cast<const bf16x8*>(ab + 32 * RSc + 32 * (s2 + 2));
+                }
+                a0 = mm(A0r[s2 % 3], Bm[s2], a0);
+                if (s2 < 8) {      // exps of the previous pair's chunk 0, two per slot (pinned: pure ops float otherwise)
+                    asm volatile("" : "+v"(p0));
+                    f32x2 y = {__builtin_amdgcn_exp2f(p0[2 * s2]), __builtin_amdgcn_exp2f(p0[2 * s2 + 1])};
+                    asm volatile("" : "+v"(y));
+                    if (s2 < 4) x0[s2] = y; else x0[s2 & 3] += y;
+                }
+                RG_PIN();
+                a1 = mm(A1r[s2 % 3], Bm[s2], a1);
+                if (s2 < 8) {
+                    asm volatile("" : "+v"(p1));
+                    f32x2 y = {__builtin_amdgcn_exp2f(p1[2 * s2]), __builtin_amdgcn_exp2f(p1[2 * s2 + 1])};
+                    asm volatile("" : "+v"(y));
+                    if (s2 < 4) x1[s2] = y; else x1[s2 & 3] += y;
+                }
+                RG_PIN();
+            }
+            if (N1 < 8) {          // fewer MFMA slots than exp pairs: the rest after the stream
+#pragma unroll
+                for (int s2 = N1; s2 < 8; ++s2) {
+                    f32x2 y0 = {__builtin_amdgcn_exp2f(p0[2 * s2]), __builtin_amdgcn_exp2f(p0[2 * s2 + 1])};
+                    f32x2 y1 = {__builtin_amdgcn_exp2f(p1[2 * s2]), __builtin_amdgcn_exp2f(p1[2 * s2 + 1])};
+                    if (s2 < 4) { x0[s2] = y0; x1[s2] = y1; } else { x0[s2 & 3] += y0; x1[s2 & 3] += y1; }
+                }
+            }
+            if (have_p) {
+                x0[0] += x0[2]; x0[1] += x0[3]; x0[0] += x0[1];
+                x1[0] += x1[2]; x1[1] += x1[3]; x1[0] += x1[1];
+                book(ti - 1, x0[0][0] + x0[0][1], x1[0][0] + x1[0][1], q_prev);
+            }
+            p0 = a0; p1 = a1;
+            q_prev = q;
+        }
+        {   // the last pair's own sums
+            float e0 = 0.0f, e1 = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { e0 += __builtin_amdgcn_exp2f(p0[r]); e1 += __builtin_amdgcn_exp2f(p1[r]); }
+            book(pt_hi - 1, e0, e1, q_prev);
+        }
+        if (sc_left != sc_pairs) view.rec[sc_cur * view.rec_stride] = make_float2(static_cast<float>(s_sc), q_prev);   // partial last super-chunk
+        if (d.use_cache && S == 1 && active && h == 0) d.cache_resc[d.uid[slot]] = static_cast<uint8_t>(min(n_resc, 255));
+        if (S == 1 && !d.sweep_only)
+            search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, delta_fixed, &view);
+    }
+}
+
+draw_kernel_t f16w_kernel_for(const DevSim& d) {
+#define RG_CASE(kh, a) if (d.KH == kh && d.N1 == a) return k_draw_f16w<kh, a>;
+    RG_CASE(16, 7) RG_CASE(32, 7) RG_CASE(32, 10) RG_CASE(32, 13)
+#undef RG_CASE
+    return nullptr;
+}
+
 // RG_POLICY_LOGREG_FROZEN for one user, computed by the whole wave: lane = class (c, c + 64, ...), so the
 // coef_t rows of the viewed products are read as coalesced 512-byte runs instead of one gather per
 // lane and class.  Same arithmetic as policy_act's scalar loop (per class: viewed products ascending,
@@ -3020,8 +3276,8 @@ __global__ void k_tail_finish(DevSim d, uint32_t t0) {
 // Raw log: a wave reserves rows in chunks (one atomic per `chunk_rows` rows, not per row or per step) and
 // marks the entries it does not use (kHoleCode); the sort skips them.
 // ------------------------------------------------------------------------------------------
-template <int KH>
-__global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_walk(DevSim d, uint32_t n_work, int round, uint32_t chunk_rows) {
+template <int KH, int OCC>
+__global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work, int round, uint32_t chunk_rows) {
     constexpr int K2 = 2 * KH;
     constexpr int kEmpty = 3;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -3032,7 +3288,6 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_walk(DevSim d, u
     double* om_d = reinterpret_cast<double*>(wbase + 64 * K2 * 4);
     double* mbox = om_d + ((d.K + 1) & ~1u);                       // [64][3]
     const uint32_t n_cc = d.PT / 64;
-
     uint32_t slot = 0, user = 0, t = 0;
     int st = kEmpty;
     bool pending = false;                                          // round 2: the parked draw, to be picked in float64
@@ -3046,7 +3301,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_walk(DevSim d, u
     for (;;) {
         // ---- refill the lanes whose user has stopped (or was parked) ----
         unsigned long long dead = __ballot(st == kEmpty);
-        if (dead && !exhausted && (__popcll(dead) >= 16 || dead == ~0ull)) {
+        if (dead && !exhausted && (__popcll(dead) >= 8 || dead == ~0ull)) {
             for (int pass = 0; pass < 2 && dead; ++pass) {
                 if (res_next == res_end) {
                     if (exhausted) break;
@@ -3073,12 +3328,14 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_walk(DevSim d, u
                     }
                 }
                 res_next += take;
-                dead = __ballot(st == kEmpty) & ~(__ballot(mine));   // lanes that drew an unused entry wait for the next refill
-                dead = __ballot(st == kEmpty && !mine);
+                dead = __ballot(st == kEmpty && !mine);              // lanes that drew an unused entry wait for the next refill
             }
         }
+        // (sorting the block's users by state through LDS so that waves are all-organic or all-bandit was measured
+        // SLOWER, 352 vs 301 ms on C3: its two barriers per step serialise the block on its organic wave's latency chain)
         const unsigned long long live = __ballot(st != kEmpty);
         if (!live) { if (exhausted) break; else continue; }
+        {
         // ---- one raw-log row per live lane ----
         const uint32_t nlive = static_cast<uint32_t>(__popcll(live));
         if (row_next + nlive > row_end) {
@@ -3129,7 +3386,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_walk(DevSim d, u
             double S = 0.0;
 #pragma unroll
             for (uint32_t sc = 0; sc < kMaxSC; ++sc) S += static_cast<double>(W[sc]);
-            const double u_org = organic_uniform(d, slot, user, t);
+            const double u_org = d.u_override ? d.u_override[slot] : rg_uniform(w.w[0], w.w[1]);
             const double tau = u_org * S;
             double pb = 0.0;
             uint32_t sc_star = d.n_sc - 1;
@@ -3199,16 +3456,20 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_walk(DevSim d, u
                 const float Qs = __shfl(Q, s2);
                 const double pbs = __shfl(pb, s2), taus = __shfl(tau, s2);
                 const float4* gp = reinterpret_cast<const float4*>(d.gamma32t + (static_cast<size_t>(cs) * K2) * 32) + gl;
-                float4 gk[K2];
-#pragma unroll
-                for (int k = 0; k < K2; ++k) gk[k] = gp[k * 8];
                 float4 l = *(reinterpret_cast<const float4*>(d.mu32 + cs * 32) + gl);
                 const float* o = om_w + s2 * K2;
 #pragma unroll
-                for (int k = 0; k < K2; ++k) {
-                    const float wk = o[k];
-                    l.x = fmaf(gk[k].x, wk, l.x); l.y = fmaf(gk[k].y, wk, l.y);
-                    l.z = fmaf(gk[k].z, wk, l.z); l.w = fmaf(gk[k].w, wk, l.w);
+                for (int kh = 0; kh < K2; kh += KH) {          // two halves: KH 16-byte loads in flight, then their fmas
+                    float4 gk[KH];
+#pragma unroll
+                    for (int k = 0; k < KH; ++k) gk[k] = gp[(kh + k) * 8];
+#pragma unroll
+                    for (int k = 0; k < KH; ++k) {
+                        const float wk = o[kh + k];
+                        l.x = fmaf(gk[k].x, wk, l.x); l.y = fmaf(gk[k].y, wk, l.y);
+                        l.z = fmaf(gk[k].z, wk, l.z); l.w = fmaf(gk[k].w, wk, l.w);
+                    }
+                    asm volatile("" : "+v"(l.x), "+v"(l.y), "+v"(l.z), "+v"(l.w));   // keeps the second half's loads behind these
                 }
                 const float e0 = __builtin_amdgcn_exp2f(fmaf(l.x, kLog2e, -Qs)), e1 = __builtin_amdgcn_exp2f(fmaf(l.y, kLog2e, -Qs));
                 const float e2 = __builtin_amdgcn_exp2f(fmaf(l.z, kLog2e, -Qs)), e3 = __builtin_amdgcn_exp2f(fmaf(l.w, kLog2e, -Qs));
@@ -3311,7 +3572,22 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_walk(DevSim d, u
                 const double* b = d.beta + static_cast<size_t>(a) * d.K;
                 const double* om = d.omega + static_cast<size_t>(slot) * d.OMS;
                 double x = 0.0;
-                if (!(d.ablate & (1u << 19)))
+                if (d.ablate & (1u << 19)) {}
+                else if (!(d.K & 1)) {
+                    // rows of K even are 16-byte aligned: half as many (scattered) load requests as 8-byte loads
+                    for (uint32_t k0 = 0; k0 < d.K; k0 += 8) {
+                        double2 wv[4], bv[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t k = min(k0 + 2 * i, d.K - 2);
+                            wv[i] = *reinterpret_cast<const double2*>(om + k);
+                            bv[i] = *reinterpret_cast<const double2*>(b + k);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (k0 + 2 * i < d.K) { x += bv[i].x * wv[i].x; x += bv[i].y * wv[i].y; }
+                    }
+                } else
                 for (uint32_t k0 = 0; k0 < d.K; k0 += 8) {
                     double wv[8], bv[8];
 #pragma unroll
@@ -3365,6 +3641,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_walk(DevSim d, u
             if (ns == RG_STATE_STOP) { c_maxt = max(c_maxt, t + 1); st = kEmpty; }
             else { st = ns; t += 1; }
         }
+        }   // if (live)
     }
     // ---- leftovers of the reserved chunks, counters ----
     for (uint64_t r = row_next + lane; r < row_end; r += 64)
@@ -3396,12 +3673,13 @@ __global__ void k_walk_finish(DevSim d) {
 }
 
 typedef void (*walk_kernel_t)(DevSim, uint32_t, int, uint32_t);
-walk_kernel_t walk_kernel_for(const DevSim& d) {
+// blocks per CU the kernel is compiled for (register budget 512 / OCC per lane): KH <= 16 at 2, 3 or 4, KH = 32 at 1
+walk_kernel_t walk_kernel_for(const DevSim& d, int occ) {
     switch (d.KH) {
-        case 4: return k_walk<4>;
-        case 10: return k_walk<10>;
-        case 16: return k_walk<16>;
-        default: return k_walk<32>;
+        case 4: return occ >= 4 ? k_walk<4, 4> : occ == 3 ? k_walk<4, 3> : k_walk<4, 2>;
+        case 10: return occ >= 4 ? k_walk<10, 4> : occ == 3 ? k_walk<10, 3> : k_walk<10, 2>;
+        case 16: return occ >= 4 ? k_walk<16, 4> : occ == 3 ? k_walk<16, 3> : k_walk<16, 2>;
+        default: return k_walk<32, 1>;
     }
 }
 
@@ -3701,13 +3979,14 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         launch_exact(sim, t, 1, upper / 100 + 16, st);
     } else if (d.use_mfma == 2) {
         // few user tiles: slice the products so that the step's latency is a slice, not a sweep
-        const uint32_t tiles_up = (upper + 127) / 128;
-        uint32_t S = tiles_up >= 1024 ? 1u : 2048u / (tiles_up ? tiles_up : 1u);
+        const uint32_t tiles_up = (upper + sim->draw_users - 1) / sim->draw_users;
+        uint32_t S = tiles_up >= 131072u / sim->draw_users ? 1u : (262144u / sim->draw_users) / (tiles_up ? tiles_up : 1u);
         if (const char* e = getenv("RECOGYM_SLICES")) S = static_cast<uint32_t>(atoi(e));   // tests: force either form
         if (S > d.n_sc) S = d.n_sc;
         if (S < 1) S = 1;
-        const int grid = grid_for(static_cast<uint64_t>(tiles_up) * S, 1);
-        hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid), dim3(kBlock), sim->bf16_smem, st, d, t, S);
+        int grid = grid_for(static_cast<uint64_t>(tiles_up) * S, 1);
+        if (sim->draw_users == 256 && grid > kMaxGrid / 2) grid = kMaxGrid / 2;     // 8 waves per block share the per-wave scratch
+        hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid), dim3(sim->draw_threads), sim->bf16_smem, st, d, t, S);
         if (int rc = prof_mark(sim, st)) return rc;
         if (S > 1)
             hipLaunchKernelGGL(search_kernel_for(d), dim3(grid_for(upper, 128)), dim3(kBlock),
@@ -3783,13 +4062,14 @@ int run_walk(rg_sim* sim, hipStream_t st) {
     {
         DevSim ds = d;
         ds.sweep_only = 1;
-        const uint32_t tiles_up = (d.n_users + 127) / 128;
-        uint32_t S = tiles_up >= 1024 ? 1u : 2048u / (tiles_up ? tiles_up : 1u);
+        const uint32_t tiles_up = (d.n_users + sim->draw_users - 1) / sim->draw_users;
+        uint32_t S = tiles_up >= 131072u / sim->draw_users ? 1u : (262144u / sim->draw_users) / (tiles_up ? tiles_up : 1u);
         if (const char* e = getenv("RECOGYM_SLICES")) S = static_cast<uint32_t>(atoi(e));
         if (S > d.n_sc) S = d.n_sc;
         if (S < 1) S = 1;
-        hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid_for(static_cast<uint64_t>(tiles_up) * S, 1)), dim3(kBlock), sim->bf16_smem,
-                           st, ds, 0u, S);
+        int grid = grid_for(static_cast<uint64_t>(tiles_up) * S, 1);
+        if (sim->draw_users == 256 && grid > kMaxGrid / 2) grid = kMaxGrid / 2;
+        hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid), dim3(sim->draw_threads), sim->bf16_smem, st, ds, 0u, S);
     }
     if (int rc = mark(1)) return rc;
     hipLaunchKernelGGL(finalize_kernel_for(d), dim3(grid_for(d.n_users)), dim3(kBlock), 0, st, d);
@@ -3797,7 +4077,8 @@ int run_walk(rg_sim* sim, hipStream_t st) {
     // 2. round 1: every user from t = 0 to its end or to its first uncertified draw
     const size_t smem = (kBlock / 64) * (static_cast<size_t>(64) * 2 * d.KH * 4 + ((d.K + 1) & ~1u) * 8 + 64 * 24);
     auto launch_walk = [&](uint32_t n_work, int round) {
-        const int blocks_cap = sim->n_cus * (d.KH <= 16 ? 2 : 1);
+        const int occ = d.KH <= 16 ? sim->walk_occ : 1;
+        const int blocks_cap = sim->n_cus * occ;
         int blocks = static_cast<int>((static_cast<uint64_t>(n_work) + kBlock - 1) / kBlock);
         if (blocks > blocks_cap) blocks = blocks_cap;
         if (blocks < 1) blocks = 1;
@@ -3807,7 +4088,7 @@ int run_walk(rg_sim* sim, hipStream_t st) {
         chunk = chunk / 64 * 64;
         if (chunk < 256) chunk = 256;
         if (chunk > 4096) chunk = 4096;
-        hipLaunchKernelGGL(walk_kernel_for(d), dim3(blocks), dim3(kBlock), smem, st, d, n_work, round, static_cast<uint32_t>(chunk));
+        hipLaunchKernelGGL(walk_kernel_for(d, occ), dim3(blocks), dim3(kBlock), smem, st, d, n_work, round, static_cast<uint32_t>(chunk));
     };
     launch_walk(d.n_users, 1);
     if (int rc = mark(3)) return rc;
@@ -3909,6 +4190,7 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     s->mfma_smem = d.use_mfma ? mfma_smem_bytes(geom_of(*cfg)) : 0;
     // kernel choice: split-bf16 MFMA when a class exists for K, else fp32 MFMA; RECOGYM_DRAW=f64|fp32|bf16 overrides
     s->bf16_kernel = nullptr; s->bf16_smem = 0;
+    s->draw_threads = kBlock; s->draw_users = 128;
     if (d.use_mfma && d.N1) {
         s->bf16_kernel = d.f16 ? nullptr : bf16_kernel_for(d);
         // the pipelined form (two chunks in flight, exp-sum and operand loads inside the MFMA stream)
@@ -3918,6 +4200,11 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
             if (static_cast<size_t>(d.P_pad) * d.RS < (1ull << 31))     // its DMA uses 31-bit buffer offsets
                 if (draw_kernel_t kp = bf16p_kernel_for(d)) s->bf16_kernel = kp;
         s->bf16_smem = bf16_smem_bytes(geom_of(*cfg), 2 * d.KH, s->bf16_kernel == bf16p_kernel_for(d) ? 3u : 2u);
+        if (d.wide) {
+            s->bf16_kernel = static_cast<size_t>(d.P_pad) * d.RS < (1ull << 31) ? f16w_kernel_for(d) : nullptr;
+            s->bf16_smem = 3 * (64 * static_cast<size_t>(d.RS) + 256) + 8 * 32 * 2 * static_cast<size_t>(d.KH) * 4;
+            s->draw_threads = 512; s->draw_users = 256;
+        }
         // the larger classes still spill registers; the fp32 kernel is faster there for now
         if (s->bf16_kernel && (d.f16 || (d.N1 <= 4 && d.KH <= 10))) d.use_mfma = 2;
     }
@@ -3928,7 +4215,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     }
     if (const char* e = getenv("RECOGYM_FORCE_EXACT")) if (e[0] == '1') d.use_mfma = 0;   // A/B switch for tests
     // the per-user sum cache is written by the pipelined 16-bit kernel only
-    if (!(d.use_mfma == 2 && s->bf16_kernel && s->bf16_kernel == bf16p_kernel_for(d))) d.use_cache = 0;
+    if (!(d.use_mfma == 2 && s->bf16_kernel &&
+          (s->bf16_kernel == bf16p_kernel_for(d) || (d.wide && s->bf16_kernel == f16w_kernel_for(d))))) d.use_cache = 0;
     if (s->bf16_kernel && s->bf16_smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s->bf16_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->bf16_smem));
@@ -3955,6 +4243,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
                               d.policy == RG_POLICY_ORGANIC_USER_COUNT || d.policy == RG_POLICY_LAST_VIEW_TABLE);
     if (const char* e = getenv("RECOGYM_WALK")) if (e[0] == '0') s->walk = false;
     s->n_cus = 0;
+    s->walk_occ = 3;
+    if (const char* e = getenv("RECOGYM_WALK_OCC")) { const int o = atoi(e); if (o >= 2 && o <= 4) s->walk_occ = o; }
     s->prof_walk_ms[0] = s->prof_walk_ms[1] = 0.0;
     if (const char* e = getenv("RECOGYM_TAIL")) s->tail_below = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_REPACK")) s->repack_every = static_cast<uint32_t>(atoi(e));

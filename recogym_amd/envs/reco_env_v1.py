@@ -87,7 +87,7 @@ def device_policy_of(agent):
     if name == 'RandomAgent':
         return dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=cfg.random_seed, ouc=None)
     if name == 'OrganicUserEventCounterAgent' and \
-            getattr(cfg, 'weight_history_function', None) is None:
+            getattr(cfg, 'weight_history_function', None) is None and not getattr(cfg, 'with_ps_all', False):
         return dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=cfg.random_seed,
                     ouc=dict(select_randomly=cfg.select_randomly, epsilon=cfg.epsilon,
                              exploit_explore=cfg.exploit_explore,
@@ -297,6 +297,7 @@ class RecoEnv1:
         pol = policy if policy is not None else device_policy_of(agent)
         if pol is None:
             raise ValueError(f'{type(agent).__name__} cannot run inside the device step loop')
+        pol = {k: v for k, v in pol.items() if k != 'ps_all'}
         if pol.get('policy_seed') is None:
             pol = dict(pol, policy_seed=self.seed)      # agent=None draws from the ENV stream
         return Simulator(self.config, n_users, epoch=self._epoch, tables=self._tables,
@@ -425,7 +426,10 @@ class RecoEnv1:
             cols = sim.log_columns()
             sim.close()
             with_all = bool(getattr(self.config, 'with_ps_all', False)) and use is None
-            return columns_to_dataframe(cols, self.config.num_products, with_all)
+            df = columns_to_dataframe(cols, self.config.num_products, with_all)
+            if pol.get('ps_all') is not None:              # the agent's whole distribution per bandit row
+                df['ps-a'] = pd.Series(pol['ps_all'](df), dtype=object, copy=False)
+            return df
         return self._generate_logs_per_user(num_offline_users, use, num_organic_offline_users, first_user_id)
 
     def _generate_logs_per_user(self, num_offline_users, agent, num_organic_offline_users, first_user_id=0):

@@ -240,9 +240,24 @@ def test_test_agent_and_verify_agents_quantiles():
         s, f = c['clicks'], c['bandit'] + c['phantom'] - c['clicks']
         assert df['0.500'][i] == beta.ppf(0.5, s + 1, f + 1)
         assert df['0.025'][i] == beta.ppf(0.025, s + 1, f + 1)
+        # test_agent evaluates on the users AFTER its 10 offline users (fresh draws, as the reference's stream gives)
+        o2 = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **agent.device_policy())
+        o2.generate_logs(n, first_user_id=10)
+        c2 = o2.counters()
+        s2, f2 = c2['clicks'], c2['bandit'] + c2['phantom'] - c2['clicks']
         q = recogym.test_agent(env, agent, 10, n)
-        assert q == (beta.ppf(0.5, s + 1, f + 1), beta.ppf(0.025, s + 1, f + 1),
-                     beta.ppf(0.975, s + 1, f + 1))
+        assert q == (beta.ppf(0.5, s2 + 1, f2 + 1), beta.ppf(0.025, s2 + 1, f2 + 1),
+                     beta.ppf(0.975, s2 + 1, f2 + 1))
+        if i == 0:
+            # two epochs without a random reset continue the id sequence: not the first epoch's counts doubled
+            o3 = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **agent.device_policy())
+            o3.generate_logs(n, first_user_id=10 + (10 + n))
+            c3 = o3.counters()
+            s3, f3 = s2 + c3['clicks'], f2 + c3['bandit'] + c3['phantom'] - c3['clicks']
+            q2 = recogym.test_agent(env, agent, 10, n, num_epochs=2)
+            assert q2 == (beta.ppf(0.5, s3 + 1, f3 + 1), beta.ppf(0.025, s3 + 1, f3 + 1), beta.ppf(0.975, s3 + 1, f3 + 1))
+            assert q2 != (beta.ppf(0.5, 2 * s2 + 1, 2 * f2 + 1), beta.ppf(0.025, 2 * s2 + 1, 2 * f2 + 1),
+                          beta.ppf(0.975, 2 * s2 + 1, 2 * f2 + 1))
     # the organic-count policy beats random on this environment (sanity)
     assert df['0.500'][1] > df['0.500'][0]
     # epochs re-key the env stream
@@ -330,3 +345,31 @@ def test_training_feed_on_device_equals_host_feed():
     assert np.array_equal(t['val'].cpu().numpy(), F.data)
     assert np.array_equal(t['actions'].cpu().numpy(), A) and np.array_equal(t['deltas'].cpu().numpy(), D)
     np.testing.assert_array_equal(t['pss'].cpu().numpy(), S)
+
+
+def test_with_ps_all_for_the_organic_count_agent_on_the_device_path():
+    """with_ps_all=True (organic_user_count.py:77-94): the batched device path logs (a, ps) and rebuilds the whole
+    distribution of every bandit row from the log; it must equal the per-user path, where the agent's Python
+    act() returns the vector itself.  Also: an action outside [0, P) raises IndexError like the reference."""
+    over = dict(random_seed=11, num_products=30, K=8)
+    cfgs = [dict(gu.OUC_DEFAULTS), dict(gu.OUC_DEFAULTS, epsilon=0.3), dict(gu.OUC_DEFAULTS, select_randomly=False),
+            dict(gu.OUC_DEFAULTS, exploit_explore=False, epsilon=0.5, reverse_pop=True)]
+    for oc in cfgs:
+        def agent():
+            return OrganicUserEventCounterAgent(Configuration({**oc, 'weight_history_function': None, 'num_products': 30,
+                                                               'random_seed': 3, 'with_ps_all': True}))
+        df_dev = make_env(over).generate_logs(40, agent())
+        df_seq = make_env(over)._generate_logs_per_user(40, agent(), 0)
+        assert len(df_dev) == len(df_seq)
+        for k in ('t', 'u', 'a', 'c'):
+            assert np.array_equal(df_dev[k].to_numpy(dtype=np.float64, na_value=np.nan),
+                                  df_seq[k].to_numpy(dtype=np.float64, na_value=np.nan), equal_nan=True), k
+        is_b = (df_dev['z'] == 'bandit').to_numpy()
+        for i in np.flatnonzero(is_b):
+            np.testing.assert_allclose(df_dev['ps-a'][i], df_seq['ps-a'][i], rtol=1e-15, atol=0)
+            assert len(df_dev['ps-a'][i]) == 30
+    env = make_env(over)
+    env.reset(0)
+    env.step(None)
+    with pytest.raises(IndexError):
+        env.step(30)
