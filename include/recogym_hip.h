@@ -117,6 +117,9 @@ typedef struct rg_event {
 #define RG_CNT_HIST_OVERFLOW 9  /* OrganicUserEventCounter views that did not fit ouc_history_cap */
 #define RG_CNT_EXACT_SWEEPS 10  /* float64 product sweeps those draws needed (== EXACT_DRAWS unless sigma_omega = 0,
                                    where a user's float64 sums are taken once and reused) */
+#define RG_CNT_EXACT_OVERFLOW 11 /* uncertified draws beyond what the float64 resolve scratch covers in a step (25 % of the
+                                   live users): the run is incomplete and must be reported — never reached by the
+                                   reference's parameter ranges */
 #define RG_CNT_N 24             /* out[] of rg_sim_read_counters; slots past the named ones are internal */
 
 typedef struct rg_sim rg_sim;

@@ -26,6 +26,46 @@ def make(env_id):
 register(id='reco-gym-v1', entry_point='recogym_amd.envs.reco_env_v1:RecoEnv1')
 
 
+def register_with_gym(env_id='reco-gym-v1', force=False):
+    """Where OpenAI `gym` is importable, make `gym.make('reco-gym-v1')` resolve to this package's environment the
+    way the reference registers its own (recogym/__init__.py:37-45).  Not done on import: the reference package, if it
+    is installed too, owns that id until the caller asks (force=True replaces its registration).  Returns True when
+    the id now points here."""
+    try:
+        from gym.envs.registration import register as gym_register
+        import gym.envs.registration as reg
+    except Exception:
+        return False
+    registry = getattr(reg, 'registry', None)
+    specs = getattr(registry, 'env_specs', registry)
+    try:
+        known = specs is not None and env_id in specs
+    except TypeError:
+        known = False
+    if known:
+        if not force:
+            return False
+        try:
+            del specs[env_id]
+        except Exception:
+            return False
+    gym_register(id=env_id, entry_point=_REGISTRY[env_id])
+    return True
+
+
+def _auto_register():
+    # `import recogym_amd as recogym; gym.make('reco-gym-v1')` — the reference's usage — works when gym is there
+    import importlib.util
+    try:
+        if importlib.util.find_spec('gym') is not None:
+            register_with_gym()
+    except Exception:
+        pass
+
+
+_auto_register()
+
+
 def __getattr__(name):
     # torch-dependent pieces load lazily so that `import recogym_amd` works everywhere
     if name in ('env_1_args', 'env_args', 'RecoEnv1'):

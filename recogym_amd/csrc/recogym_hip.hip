@@ -100,7 +100,12 @@ struct DevSim {
     double* gamma_rm;         // [PT][4 XKB + 4] row-major float64 Gamma, k zero-padded to 4 XKB, then mu_o (-inf beyond P):
     uint32_t XKB;             // one row = what one product costs the user-per-lane float64 kernel in scalar loads; 0 = K > 64
     float* exact_ref;         // [n_users] log2-scaled reference of a draw handed to the float64 kernel
-    double* exact_sums;       // [n_users][PT/64] float64 exp-sum of every 64-product chunk
+    double* exact_sums;       // [exact_rows][PT/64] float64 exp-sum of every 64-product chunk
+    uint32_t exact_rows;      // rows of exact_sums: n_cap where they are per-user constants (sigma_omega = 0 cache) or every
+                              // draw goes through float64; else max(4096, n_cap / 8) — a step's uncertified draws (a few percent
+                              // of its organic users) are resolved in batches of that many list entries
+    uint32_t exact_base;      // first exact_list entry of the batch being resolved
+    uint32_t exact_last;      // this is the last batch launched for the step
     float2* sc_scratch;       // [kMaxGrid*4 waves][kMaxSC][32] {sum, reference} of the MFMA draw kernel
     float* chunk_scratch;     // [kMaxGrid*4 waves][n_chunks][32] exp-sum of every 32-product chunk
     float* stats;             // [2*KH] max_p |Gamma[p][k]|, then max_p ||Gamma[p]||_2, max_p |mu_o[p]|
@@ -282,6 +287,16 @@ bool cache_wanted(const rg_config& c, const Geom& g) {
     return c.sigma_omega == 0.0 && g.N1 != 0 && !(e && e[0] == '0');
 }
 
+// rows of the float64 chunk-sum scratch (see DevSim::exact_rows)
+size_t exact_rows_of(const rg_config& c, const Geom& g, uint64_t n) {
+    const char* e = getenv("RECOGYM_DRAW");
+    const char* f = getenv("RECOGYM_FORCE_EXACT");
+    const bool all_f64 = !g.KH || (e && !strcmp(e, "f64")) || (f && f[0] == '1');
+    if (cache_wanted(c, g) || all_f64) return n;
+    const uint64_t r = n / 8;
+    return r < 4096 ? (n < 4096 ? n : 4096) : r;
+}
+
 size_t bf16_smem_bytes(const Geom& g, uint32_t K, uint32_t buffers) {
     // split tiles + mu tiles (2 buffers: lean kernel, 3: pipelined kernel) + the per-wave omega32 stage [4][32][K]
     return buffers * (static_cast<size_t>(g.TPB) * g.RS + g.TPB * 4) + 4 * 32 * static_cast<size_t>(K) * 4 + 256;
@@ -320,7 +335,8 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     const uint32_t xkb = exact_kb_of(c.K);
     double* gamma_rm = w.take<double>(xkb ? PT * (4 * static_cast<size_t>(xkb) + 4) : 1);
     float* exact_ref = w.take<float>(n);
-    double* exact_sums = w.take<double>(n * (PT / 64));
+    const size_t exact_rows = exact_rows_of(c, g, n);
+    double* exact_sums = w.take<double>(exact_rows * (PT / 64));
     unsigned short* gsplit = w.take<unsigned short>(g.N1 ? static_cast<size_t>(g.P_pad) * (g.RS / 2) : 1);
     float* mu32s = w.take<float>(g.N1 ? g.P_pad : 1);
     float2* sc_scratch = w.take<float2>(g.KH ? static_cast<size_t>(kMaxGrid) * 4 * kMaxSC * 32 : 1);
@@ -364,6 +380,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->lpv_alt = lpv_alt; d->uid_alt = uid_alt;
         d->gamma32 = gamma32; d->mu32 = mu32; d->gamma32t = gamma32t; d->stats = stats; d->omega = omega; d->list = list;
         d->gamma_rm = gamma_rm; d->XKB = xkb;
+        d->exact_rows = static_cast<uint32_t>(exact_rows); d->exact_base = 0;
         d->gammaT = gammaT; d->PT = static_cast<uint32_t>(PT); d->exact_ref = exact_ref; d->exact_sums = exact_sums; d->sc_scratch = sc_scratch; d->chunk_scratch = chunk_scratch;
         d->gsplit = gsplit; d->mu32s = mu32s; d->N1 = g.N1; d->N2 = g.N2; d->N3 = g.N3; d->RS = g.RS; d->TPB = g.TPB;
         d->f16 = g.F16 ? 1u : 0u; d->wide = g.F16 == 2 ? 1u : 0u;
@@ -616,6 +633,10 @@ __device__ __forceinline__ bool cdf_exceeds(double acc, double last, double u) {
 //   RandomAgent      random_agent.py:22-33      uniform over P from the agent's stream
 //   OrganicUserEventCounter  organic_user_count.py:45-96 on the user's own view counts
 // ------------------------------------------------------------------------------------------
+// DENSE = false leaves out the O(P) forms of the OrganicUserEventCounter policy (explore flip, epsilon smoothing,
+// reverse_pop: BASELINE configs use epsilon = 0) — ~40 % of this function's code, which the walk kernel would
+// otherwise carry through its instruction cache on every step; the host picks the instantiation.
+template <bool DENSE = true>
 __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, uint32_t t,
                                double* ps_out) {
     if (d.policy == RG_POLICY_LAST_VIEW_TABLE) {
@@ -719,6 +740,7 @@ __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, ui
         *ps_out = 1.0;
         return best;
     }
+    if (!DENSE) { *ps_out = 1.0; return 0u; }       // (not reached: the host selects DENSE = true for these configurations)
     const uint32_t nd = h_cnt(hr[0]);
     // Dense cases (explore flip, epsilon smoothing, reverse_pop): every product has mass, the
     // float64 running sums are order-dependent, so walk all P products like numpy does.
@@ -968,9 +990,12 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums(DevSim d, uint32_t t, int
     double* mu_tile = g_tile + static_cast<size_t>(d.K) * 64;
     double* om_all = mu_tile + 64;
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
-    const uint32_t n = from_list ? d.exact_cnt[t] : n_o;
+    const bool batched = from_list == 1 && !d.use_cache;
+    const uint32_t base = batched ? d.exact_base : 0u;
+    uint32_t n = from_list ? d.exact_cnt[t] : n_o;
+    if (batched) n = min(n, base + d.exact_rows);
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
-    const uint32_t n_groups = (n + kExactUsers - 1) / kExactUsers;
+    const uint32_t n_groups = n > base ? (n - base + kExactUsers - 1) / kExactUsers : 0u;
     const uint32_t cps = ((n_cc + S - 1) / S) * 8;             // chunks per slice (whole coarse chunks)
     const uint32_t n_work = n_groups * S;
 
@@ -978,7 +1003,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums(DevSim d, uint32_t t, int
         const uint32_t grp = wk / S, slice = wk % S;
         const uint32_t c0 = slice * cps, c1 = min(c0 + cps, n_chunks);
         if (c0 >= c1) continue;
-        uint32_t w_idx[kUPW];
+        uint32_t w_idx[kUPW], srow[kUPW];
         bool act[kUPW];
         double M[kUPW], part[kUPW];
 #pragma unroll
@@ -987,11 +1012,12 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums(DevSim d, uint32_t t, int
         double* om = om_all + static_cast<size_t>(wave * kUPW) * d.K;
 #pragma unroll
         for (int u = 0; u < kUPW; ++u) {
-            w_idx[u] = grp * kExactUsers + wave * kUPW + u;
+            w_idx[u] = base + grp * kExactUsers + wave * kUPW + u;
             act[u] = w_idx[u] < n;
             const uint32_t pos = act[u] ? (from_list ? d.exact_list[w_idx[u]] : w_idx[u]) : 0u;
             const uint32_t slot = act[u] ? cur[pos] : 0u;
-            if (from_list && d.use_cache && act[u]) w_idx[u] = d.uid[slot];    // sums / reference rows are per user in this mode
+            srow[u] = w_idx[u] - base;                                         // row of this batch's scratch
+            if (from_list && d.use_cache && act[u]) { w_idx[u] = d.uid[slot]; srow[u] = w_idx[u]; }   // per-user rows in this mode
             // any shift gives the same float64 decision up to 1e-16: a draw handed over by the
             // MFMA kernel reuses that kernel's reference, pure float64 mode uses k_exact_ref's
             M[u] = (mode == 1 && act[u]) ? static_cast<double>(d.exact_ref[w_idx[u]]) * 0.69314718055994530942 : 0.0;
@@ -1059,7 +1085,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums(DevSim d, uint32_t t, int
 #pragma unroll
                 for (int u = 0; u < kUPW; ++u) {
                     const double r = mode == 0 ? wave_max(part[u]) : wave_sum(part[u]);
-                    if (lane == 0 && act[u]) d.exact_sums[static_cast<size_t>(w_idx[u]) * n_cc + (c >> 3)] = r;
+                    if (lane == 0 && act[u]) d.exact_sums[static_cast<size_t>(srow[u]) * n_cc + (c >> 3)] = r;
                     part[u] = 0.0;
                 }
             }
@@ -1087,9 +1113,13 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_u(DevSim d, uint32_t t, i
     const uint32_t n_cc = d.PT / 64;                           // one stored sum per 64-product chunk
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
     // from_list == 2: the users k_walk parked (park_list, `t` = its length; entries 0xFFFFFFFF are unused)
-    const uint32_t n = from_list == 2 ? t : (from_list ? d.exact_cnt[t] : n_o);
+    // from_list == 1 without the per-user cache: the batch [exact_base, exact_base + exact_rows) of the step's list
+    const bool batched = from_list == 1 && !d.use_cache;
+    const uint32_t base = batched ? d.exact_base : 0u;
+    uint32_t n = from_list == 2 ? t : (from_list ? d.exact_cnt[t] : n_o);
+    if (batched) n = min(n, base + d.exact_rows);
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
-    const uint32_t n_groups = (n + 63) / 64;
+    const uint32_t n_groups = n > base ? (n - base + 63) / 64 : 0u;
     const uint32_t ccps = (n_cc + S - 1) / S;                  // chunks per slice
     const uint32_t n_work = n_groups * S;
     constexpr uint32_t RSd = 4 * KB + 4;
@@ -1097,7 +1127,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_u(DevSim d, uint32_t t, i
         const uint32_t grp = wk / S, slice = wk % S;
         const uint32_t cc0 = slice * ccps, cc1 = min(cc0 + ccps, n_cc);
         if (cc0 >= cc1) continue;
-        uint32_t w_idx = grp * 64 + lane;
+        uint32_t w_idx = base + grp * 64 + lane;
         bool act = w_idx < n;
         uint32_t slot;
         if (from_list == 2) {
@@ -1129,7 +1159,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_u(DevSim d, uint32_t t, i
                 l += row[4 * KB];                              // -inf for products >= P: exp gives exactly 0
                 acc = mode == 0 ? fmax(acc, l) : acc + exp64t(l - M, exp_tab);
             }
-            if (act) d.exact_sums[static_cast<size_t>(w_idx) * n_cc + cc] = acc;
+            if (act) d.exact_sums[static_cast<size_t>(w_idx - (batched ? base : 0u)) * n_cc + cc] = acc;
         }
     }
 }
@@ -1218,18 +1248,24 @@ __global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int
     const uint32_t n_cc = (d.PT / 64 + G - 1) / G;
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
     const bool cached = from_list && d.use_cache;
-    const uint32_t n_a = from_list ? d.exact_cnt[t] : n_o;              // draws whose sums the previous kernel took
+    const bool batched = from_list == 1 && !d.use_cache;
+    const uint32_t base = batched ? d.exact_base : 0u;
+    const uint32_t n_all = from_list ? d.exact_cnt[t] : n_o;
+    const uint32_t n_a = batched ? min(n_all, base + d.exact_rows) : n_all;   // draws whose sums the previous kernel took
     const uint32_t n = n_a + (cached ? d.exact_cnt_b[t] : 0u);          // + draws of users whose sums were there already
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
     const uint32_t waves_total = gridDim.x * (kBlock / 64);
-    for (uint32_t w = blockIdx.x * (kBlock / 64) + wave; w < n; w += waves_total) {
+    // more uncertified draws than the batches cover: reported, never silently dropped
+    if (batched && d.exact_last && n_all > n_a && blockIdx.x == 0 && threadIdx.x == 0)
+        atomicAdd(&d.counters[RG_CNT_EXACT_OVERFLOW], static_cast<unsigned long long>(n_all - n_a));
+    for (uint32_t w = base + blockIdx.x * (kBlock / 64) + wave; w < n; w += waves_total) {
         const uint32_t pos = from_list ? d.exact_list[w < n_a ? w : d.n_cap - 1u - (w - n_a)] : w;
         const uint32_t slot = cur[pos];
         const uint32_t uidx = d.uid[slot];
         const uint32_t user = static_cast<uint32_t>(d.first_user + uidx);
         const uint32_t row = cached ? uidx : w;
         const double M = static_cast<double>(d.exact_ref[row]) * 0.69314718055994530942;
-        const double* sums = d.exact_sums + static_cast<size_t>(row) * n_cc;
+        const double* sums = d.exact_sums + static_cast<size_t>(row - base) * n_cc;
         for (uint32_t k = lane; k < d.K; k += 64) om[k] = d.omega[static_cast<size_t>(slot) * d.OMS + k];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -1242,8 +1278,8 @@ __global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int
         __builtin_amdgcn_wave_barrier();
     }
     if (from_list == 1 && blockIdx.x == 0 && threadIdx.x == 0) {
-        atomicAdd(&d.counters[RG_CNT_EXACT_DRAWS], static_cast<unsigned long long>(n));
-        atomicAdd(&d.counters[RG_CNT_EXACT_SWEEPS], static_cast<unsigned long long>(n_a));
+        atomicAdd(&d.counters[RG_CNT_EXACT_DRAWS], static_cast<unsigned long long>(n > base ? n - base : 0u));
+        atomicAdd(&d.counters[RG_CNT_EXACT_SWEEPS], static_cast<unsigned long long>(n_a > base ? n_a - base : 0u));
     }
 }
 
@@ -2571,25 +2607,26 @@ draw_kernel_t bf16_kernel_for(const DevSim& d) {
 // The exp-sums of pair n - 1 sit in the issue slots between the MFMAs of pair n (two independent accumulator
 // chains), order pinned with sched_barrier.
 // ------------------------------------------------------------------------------------------
-template <int KH, int N1>
-__global__ void __launch_bounds__(512, 1) k_draw_f16w(DevSim d, uint32_t t, uint32_t S) {
+template <int KH, int N1, int UG>
+__global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t, uint32_t S) {
     constexpr uint32_t RSc = 32 * N1 + 16, TILE_B = 64 * RSc, NT = TILE_B / 1024;     // 1 KB per wave-wide DMA instruction
-    constexpr int NW = 8;
+    // UG groups of 32 users per wave, 8 / UG waves per block (256 users either way).  UG = 2: every A fragment read
+    // from LDS feeds two MFMAs (half the LDS traffic) but one wave per SIMD; UG = 1: two waves per SIMD
+    constexpr int NW = 8 / UG;
     using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
     using f32x2 = __attribute__((ext_vector_type(2))) float;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* g_buf = smem_raw;                                           // [3][64][RSc]
     float* mu_buf = reinterpret_cast<float*>(g_buf + 3 * TILE_B);     // [3][64]
-    float* om_stage = mu_buf + 3 * 64;                                // [8 waves][32 users][2KH] omega32
+    float* om_stage = mu_buf + 3 * 64;                                // [8 groups][32 users][2KH] omega32
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const int j = lane & 31, h = lane >> 5;
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
-    const uint32_t n_tiles = (n_o + 32 * NW - 1) / (32 * NW);
+    const uint32_t n_tiles = (n_o + 255) / 256;
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
     const float mumax = d.stats[2 * KH + 1], g2max = d.stats[2 * KH];
     const uint32_t scps = (d.n_sc + S - 1) / S;                       // super-chunks per slice
     const uint32_t n_work = n_tiles * S;
-    float* omu = om_stage + (wave * 32 + j) * 2 * KH;                 // this lane's user's omega32
     // this wave's DMA instructions per tile (they complete in issue order: the tile barrier may leave these in flight)
     const int my_dma = static_cast<int>((NT - wave + NW - 1) / NW) + (wave == NW - 1 ? 1 : 0);
 
@@ -2599,13 +2636,23 @@ __global__ void __launch_bounds__(512, 1) k_draw_f16w(DevSim d, uint32_t t, uint
         const uint32_t chunk_hi = min((slice + 1) * scps * d.sc_chunks, d.n_chunks);
         if (chunk_lo >= chunk_hi) continue;
         const uint32_t pt_lo = chunk_lo / 2, pt_hi = (chunk_hi + 1) / 2;      // tiles = pairs of chunks
-        const size_t wslot = (S == 1 ? static_cast<size_t>(blockIdx.x) : static_cast<size_t>(tb)) * NW + wave;
-        float* scr_chunk = d.chunk_scratch + wslot * d.n_chunks * 32;
-        float2* scr = d.sc_scratch + wslot * kMaxSC * 32;
-        const uint32_t pos = tb * (32 * NW) + wave * 32 + j;
-        const bool active = pos < n_o;
-        const uint32_t slot = active ? cur[pos] : 0u;
-        const SumsView view = sums_view(d, scr, scr_chunk, j, active, slot);
+        uint32_t pos[UG], slot[UG];
+        bool active[UG];
+        SumsView view[UG];
+        float* omu[UG];
+        float2* scr[UG];
+        float* scr_chunk[UG];
+#pragma unroll
+        for (int g = 0; g < UG; ++g) {
+            const size_t wslot = (S == 1 ? static_cast<size_t>(blockIdx.x) : static_cast<size_t>(tb)) * (NW * UG) + wave * UG + g;
+            scr_chunk[g] = d.chunk_scratch + wslot * d.n_chunks * 32;
+            scr[g] = d.sc_scratch + wslot * kMaxSC * 32;
+            pos[g] = tb * 256 + (wave * UG + g) * 32 + j;
+            active[g] = pos[g] < n_o;
+            slot[g] = active[g] ? cur[pos[g]] : 0u;
+            view[g] = sums_view(d, scr[g], scr_chunk[g], j, active[g], slot[g]);
+            omu[g] = om_stage + ((wave * UG + g) * 32 + j) * 2 * KH;      // this lane's user's omega32
+        }
         __syncthreads();           // every wave is done with the LDS buffers and stage (previous work item)
         const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
         const rg_v4i rs_g = raw_buffer_rsrc(d.gsplit), rs_m = raw_buffer_rsrc(d.mu32s);
@@ -2616,44 +2663,53 @@ __global__ void __launch_bounds__(512, 1) k_draw_f16w(DevSim d, uint32_t t, uint
             if (wave == NW - 1 && lane < 16) dma_to_lds_b128(rs_m, mu_lds + ((ti - pt_lo) % 3u) * 256u, lane16, ti * 256u);
         };
         fetch_tile(pt_lo);
-        // ---- omega32 of the user -> LDS stage (also the logit error bound) ----
-        float absdot = 0.0f, sq = 0.0f, absw = 0.0f;
+        // ---- omega32 of the users -> LDS stage (also the logit error bound) ----
+        float Ahat[UG];
+        double delta_fixed[UG];
 #pragma unroll
-        for (int s2 = 0; s2 < KH; ++s2) {
-            const uint32_t k = h * KH + s2;
-            float w = 0.0f;
-            if (active && k < d.K) w = static_cast<float>(d.omega[static_cast<size_t>(slot) * d.OMS + k]);
-            omu[k] = w;
-            absdot = fmaf(fabsf(w), d.stats[k], absdot);
-            sq = fmaf(w, w, sq);
-            absw += fabsf(w);
+        for (int g = 0; g < UG; ++g) {
+            float absdot = 0.0f, sq = 0.0f, absw = 0.0f;
+#pragma unroll
+            for (int s2 = 0; s2 < KH; ++s2) {
+                const uint32_t k = h * KH + s2;
+                float w = 0.0f;
+                if (active[g] && k < d.K) w = static_cast<float>(d.omega[static_cast<size_t>(slot[g]) * d.OMS + k]);
+                omu[g][k] = w;
+                absdot = fmaf(fabsf(w), d.stats[k], absdot);
+                sq = fmaf(w, w, sq);
+                absw += fabsf(w);
+            }
+            absdot += swap32(absdot);
+            sq += swap32(sq);
+            absw += swap32(absw);
+            Ahat[g] = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
+            delta_fixed[g] = kDeltaFixedBf16 + f16_extra_delta(d, Ahat[g], absw);
         }
-        absdot += swap32(absdot);
-        sq += swap32(sq);
-        absw += swap32(absw);
-        const float Ahat = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
-        const double delta_fixed = kDeltaFixedBf16 + f16_extra_delta(d, Ahat, absw);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         // ---- B fragments [w1 | w1 | w2 | 0 .. | -q]: lane (j, h) holds elements ke = 16 s + 8 h + e of its user's row ----
-        bf16x8 Bm[N1];
+        bf16x8 Bm[UG][N1];
         {
             const uint32_t K = d.K;
 #pragma unroll
-            for (int s2 = 0; s2 < N1; ++s2)
+            for (int g = 0; g < UG; ++g)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const uint32_t ke = 16 * s2 + 8 * h + e;
-                    unsigned short sp[2] = {0, 0};
-                    if (ke < 3 * K) f16_split2(omu[ke % K], sp);
-                    Bm[s2][e] = static_cast<short>(ke < 2 * K ? sp[0] : sp[1]);
-                }
+                for (int s2 = 0; s2 < N1; ++s2)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t ke = 16 * s2 + 8 * h + e;
+                        unsigned short sp[2] = {0, 0};
+                        if (ke < 3 * K) f16_split2(omu[g][ke % K], sp);
+                        Bm[g][s2][e] = static_cast<short>(ke < 2 * K ? sp[0] : sp[1]);
+                    }
         }
-        float q = 0.0f;            // reference (log2 units, an integer) the MFMAs being issued subtract
-        auto set_reference = [&](float qn) {
+        float q[UG];               // reference (log2 units, an integer) the MFMAs being issued subtract
+#pragma unroll
+        for (int g = 0; g < UG; ++g) q[g] = 0.0f;
+        auto set_reference = [&](int g, float qn) {
             qn = fminf(fmaxf(qn, -2047.0f), 2047.0f);       // one fp16 piece: an integer |q| <= 2047 is exact
-            q = qn;
-            if (h == 1) Bm[N1 - 1][7] = static_cast<short>(__builtin_bit_cast(unsigned short, static_cast<_Float16>(-qn)));
+            q[g] = qn;
+            if (h == 1) Bm[g][N1 - 1][7] = static_cast<short>(__builtin_bit_cast(unsigned short, static_cast<_Float16>(-qn)));
         };
         auto mm = [](const bf16x8& a, const bf16x8& b, const f32x16& c) -> f32x16 {
             return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -2668,55 +2724,64 @@ __global__ void __launch_bounds__(512, 1) k_draw_f16w(DevSim d, uint32_t t, uint
                 acc[4 * qq] = m.x; acc[4 * qq + 1] = m.y; acc[4 * qq + 2] = m.z; acc[4 * qq + 3] = m.w;
             }
         };
-        // ---- bookkeeping of finished pairs (one pair behind the MFMAs) ----
-        double s_sc = 0.0;         // running exp-sum of the super-chunk being summed
-        float wcmax = 0.0f;        // its largest chunk sum
-        int n_resc = 0;
-        float q_next = 0.0f;       // reference to switch to at the next super-chunk start
+        // ---- bookkeeping of finished pairs (one pair behind the MFMAs), per user group ----
+        double s_sc[UG];           // running exp-sum of the super-chunk being summed
+        float wcmax[UG];           // its largest chunk sum
+        int n_resc[UG];
+        float q_next[UG];          // reference to switch to at the next super-chunk start
+#pragma unroll
+        for (int g = 0; g < UG; ++g) { s_sc[g] = 0.0; wcmax[g] = 0.0f; n_resc[g] = 0; q_next[g] = 0.0f; }
         const uint32_t sc_pairs = d.sc_chunks / 2;
         uint32_t sc_cur = chunk_lo / d.sc_chunks, sc_left = sc_pairs;
-        auto book = [&](uint32_t ti_done, float s0, float s1, float q_used) {   // sums of the pair of tile ti_done
+        auto book = [&](int g, uint32_t ti_done, float s0, float s1, float q_used, bool flush) {   // sums of the pair of tile ti_done
             s0 += swap32(s0);
             s1 += swap32(s1);
             const uint32_t ci = 2 * ti_done;
             // scratch layout of the 4-chunk tiles the search reads: [tile of 4][user][4 chunks]
-            *reinterpret_cast<float2*>(view.chunk + static_cast<size_t>(ci >> 2) * view.tile_stride + (ci & 3)) = make_float2(s0, s1);
-            wcmax = fmaxf(wcmax, fmaxf(s0, s1));
-            s_sc += static_cast<double>(s0 + s1);
-            if (--sc_left == 0) {
-                view.rec[sc_cur * view.rec_stride] = make_float2(static_cast<float>(s_sc), q_used);
-                s_sc = 0.0;
+            *reinterpret_cast<float2*>(view[g].chunk + static_cast<size_t>(ci >> 2) * view[g].tile_stride + (ci & 3)) = make_float2(s0, s1);
+            wcmax[g] = fmaxf(wcmax[g], fmaxf(s0, s1));
+            s_sc[g] += static_cast<double>(s0 + s1);
+            if (flush) {
+                view[g].rec[sc_cur * view[g].rec_stride] = make_float2(static_cast<float>(s_sc[g]), q_used);
+                s_sc[g] = 0.0;
                 // some logit is >= ~43 above the reference: re-reference from the next super-chunk that has not started
-                if (wcmax > 2.8e14f) q_next = fmaxf(q_next, q_used + floorf(__builtin_amdgcn_logf(wcmax)));
-                wcmax = 0.0f;
-                ++sc_cur;
-                sc_left = sc_pairs;
+                if (wcmax[g] > 2.8e14f) q_next[g] = fmaxf(q_next[g], q_used + floorf(__builtin_amdgcn_logf(wcmax[g])));
+                wcmax[g] = 0.0f;
             }
         };
         RG_DMA_WAIT();
         __syncthreads();           // tile pt_lo landed
         if (pt_lo + 1 < pt_hi) fetch_tile(pt_lo + 1);
         if (pt_lo + 2 < pt_hi) fetch_tile(pt_lo + 2);
-        {   // first chunk with reference 0: its max (an integer after ceil, exact in one fp16 piece) becomes the reference
+#pragma unroll
+        for (int g = 0; g < UG; ++g) {   // first chunk with reference 0: its max (an integer after ceil, exact in one fp16 piece) becomes the reference
             f32x16 y;
             load_mu(y, m_lane, 0);
 #pragma unroll
-            for (int s2 = 0; s2 < N1; ++s2) y = mm(*reinterpret_cast<const bf16x8*>(a_lane + 32 * s2), Bm[s2], y);
+            for (int s2 = 0; s2 < N1; ++s2) y = mm(*reinterpret_cast<const bf16x8*>(a_lane + 32 * s2), Bm[g][s2], y);
             float cm = y[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) cm = fmaxf(cm, y[r]);
-            set_reference(fmaxf(ceilf(fmaxf(cm, swap32(cm))), -1.0e30f));
-            q_next = q;
+            set_reference(g, fmaxf(ceilf(fmaxf(cm, swap32(cm))), -1.0e30f));
+            q_next[g] = q[g];
         }
-        f32x16 p0, p1;             // logits of the previous pair, waiting for their exp-sums
+        f32x16 p[UG][2];           // logits of the previous pair (per group: chunk 0, chunk 1), waiting for their exp-sums
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { p0[r] = 0.0f; p1[r] = 0.0f; }
-        float q_prev = q;          // reference they were taken with
+        for (int g = 0; g < UG; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p[g][0][r] = 0.0f; p[g][1][r] = 0.0f; }
+        float q_prev[UG];          // references they were taken with
+#pragma unroll
+        for (int g = 0; g < UG; ++g) q_prev[g] = q[g];
         uint32_t sc_issue_left = sc_pairs;                      // pairs left in the super-chunk being ISSUED
         for (uint32_t ti = pt_lo; ti < pt_hi; ++ti) {
             if (ti > pt_lo) {
                 // tile ti has landed once at most this wave's DMA of tile ti + 1 (issued after it) is still in flight
                 if (ti + 1 >= pt_hi) RG_TILE_BARRIER(0);
+                else if (my_dma >= 8) RG_TILE_BARRIER(8);
+                else if (my_dma == 7) RG_TILE_BARRIER(7);
+                else if (my_dma == 6) RG_TILE_BARRIER(6);
+                else if (my_dma == 5) RG_TILE_BARRIER(5);
                 else if (my_dma == 4) RG_TILE_BARRIER(4);
                 else if (my_dma == 3) RG_TILE_BARRIER(3);
                 else RG_TILE_BARRIER(2);
@@ -2725,75 +2790,108 @@ __global__ void __launch_bounds__(512, 1) k_draw_f16w(DevSim d, uint32_t t, uint
             const uint32_t bsel = (ti - pt_lo) % 3u;
             const char* ab = a_lane + bsel * TILE_B;
             const char* mb = m_lane + bsel * 256u;
-            if (sc_issue_left == sc_pairs && q_next != q) { set_reference(q_next); n_resc += 1; }   // a super-chunk starts
-            if (--sc_issue_left == 0) sc_issue_left = sc_pairs;
-            f32x16 a0, a1;
-            load_mu(a0, mb, 0);
-            load_mu(a1, mb, 1);
-            f32x2 x0[4], x1[4];
-            const bool have_p = ti > pt_lo;
-            // A operands: a ring three k-steps deep, read two steps ahead of the MFMA that consumes them
-            bf16x8 A0r[3], A1r[3];
+            if (sc_issue_left == sc_pairs) {                    // a super-chunk starts
 #pragma unroll
-            for (int s2 = 0; s2 < 2 && s2 < N1; ++s2) {
+                for (int g = 0; g < UG; ++g) if (q_next[g] != q[g]) { set_reference(g, q_next[g]); n_resc[g] += 1; }
+            }
+            if (--sc_issue_left == 0) sc_issue_left = sc_pairs;
+            f32x16 a[UG][2];
+#pragma unroll
+            for (int g = 0; g < UG; ++g) { load_mu(a[g][0], mb, 0); load_mu(a[g][1], mb, 1); }
+            f32x2 x[UG][2][4];
+            const bool have_p = ti > pt_lo;
+            // A operands: a ring RD k-steps deep, read RD - 1 steps ahead of the MFMAs that consume them (one wave per
+            // SIMD has nobody to hide an LDS round trip behind: deeper there)
+            constexpr int RD = UG == 2 ? 5 : 3;
+            bf16x8 A0r[RD], A1r[RD];
+#pragma unroll
+            for (int s2 = 0; s2 < RD - 1 && s2 < N1; ++s2) {
                 A0r[s2] = *reinterpret_cast<const bf16x8*>(ab + 32 * s2);
                 A1r[s2] = *reinterpret_cast<const bf16x8*>(ab + 32 * RSc + 32 * s2);
             }
             RG_PIN();
+            // the exps of the previous tile (2 UG accumulators x 16) spread over the 2 UG N1 MFMA slots of this one
+            constexpr int NSLOT = 2 * UG * N1, NEP = 16 * UG, EPS = (NEP + NSLOT - 1) / NSLOT;      // exp PAIRS (per slot)
+            auto exps = [&](int slot_i) {
+#pragma unroll
+                for (int e = slot_i * EPS; e < (slot_i + 1) * EPS && e < NEP; ++e) {
+                    const int g = e >> 4, c = (e >> 3) & 1, r = e & 7;       // accumulator (g, c), register pair r
+                    asm volatile("" : "+v"(p[g][c]));
+                    f32x2 y = {__builtin_amdgcn_exp2f(p[g][c][2 * r]), __builtin_amdgcn_exp2f(p[g][c][2 * r + 1])};
+                    asm volatile("" : "+v"(y));
+                    if (r < 4) x[g][c][r] = y; else x[g][c][r & 3] += y;
+                }
+            };
 #pragma unroll
             for (int s2 = 0; s2 < N1; ++s2) {
-                if (s2 + 2 < N1) {
-                    A0r[(s2 + 2) % 3] = *reinterpret_cast<const bf16x8*>(ab + 32 * (s2 + 2));
-                    A1r[(s2 + 2) % 3] = *reinterpret_cast<const bf16x8*>(ab + 32 * RSc + 32 * (s2 + 2));
+                if (s2 + RD - 1 < N1) {
+                    A0r[(s2 + RD - 1) % RD] = *reinterpret_cast<const bf16x8*>(ab + 32 * (s2 + RD - 1));
+                    A1r[(s2 + RD - 1) % RD] = *reinterpret_cast<const bf16x8*>(ab + 32 * RSc + 32 * (s2 + RD - 1));
                 }
-                a0 = mm(A0r[s2 % 3], Bm[s2], a0);
-                if (s2 < 8) {      // exps of the previous pair's chunk 0, two per slot (pinned: pure ops float otherwise)
-                    asm volatile("" : "+v"(p0));
-                    f32x2 y = {__builtin_amdgcn_exp2f(p0[2 * s2]), __builtin_amdgcn_exp2f(p0[2 * s2 + 1])};
-                    asm volatile("" : "+v"(y));
-                    if (s2 < 4) x0[s2] = y; else x0[s2 & 3] += y;
-                }
-                RG_PIN();
-                a1 = mm(A1r[s2 % 3], Bm[s2], a1);
-                if (s2 < 8) {
-                    asm volatile("" : "+v"(p1));
-                    f32x2 y = {__builtin_amdgcn_exp2f(p1[2 * s2]), __builtin_amdgcn_exp2f(p1[2 * s2 + 1])};
-                    asm volatile("" : "+v"(y));
-                    if (s2 < 4) x1[s2] = y; else x1[s2 & 3] += y;
-                }
-                RG_PIN();
-            }
-            if (N1 < 8) {          // fewer MFMA slots than exp pairs: the rest after the stream
 #pragma unroll
-                for (int s2 = N1; s2 < 8; ++s2) {
-                    f32x2 y0 = {__builtin_amdgcn_exp2f(p0[2 * s2]), __builtin_amdgcn_exp2f(p0[2 * s2 + 1])};
-                    f32x2 y1 = {__builtin_amdgcn_exp2f(p1[2 * s2]), __builtin_amdgcn_exp2f(p1[2 * s2 + 1])};
-                    if (s2 < 4) { x0[s2] = y0; x1[s2] = y1; } else { x0[s2 & 3] += y0; x1[s2 & 3] += y1; }
+                for (int g = 0; g < UG; ++g) {
+                    a[g][0] = mm(A0r[s2 % RD], Bm[g][s2], a[g][0]);
+                    exps((2 * s2) * UG + g);
+                    RG_PIN();
+                }
+#pragma unroll
+                for (int g = 0; g < UG; ++g) {
+                    a[g][1] = mm(A1r[s2 % RD], Bm[g][s2], a[g][1]);
+                    exps((2 * s2 + 1) * UG + g);
+                    RG_PIN();
                 }
             }
+            const bool flush = have_p && sc_left == 1;
             if (have_p) {
-                x0[0] += x0[2]; x0[1] += x0[3]; x0[0] += x0[1];
-                x1[0] += x1[2]; x1[1] += x1[3]; x1[0] += x1[1];
-                book(ti - 1, x0[0][0] + x0[0][1], x1[0][0] + x1[0][1], q_prev);
+#pragma unroll
+                for (int g = 0; g < UG; ++g) {
+                    float sm[2];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        x[g][c][0] += x[g][c][2]; x[g][c][1] += x[g][c][3]; x[g][c][0] += x[g][c][1];
+                        sm[c] = x[g][c][0][0] + x[g][c][0][1];
+                    }
+                    book(g, ti - 1, sm[0], sm[1], q_prev[g], flush);
+                }
+                if (flush) { ++sc_cur; sc_left = sc_pairs; } else --sc_left;
             }
-            p0 = a0; p1 = a1;
-            q_prev = q;
+#pragma unroll
+            for (int g = 0; g < UG; ++g) { p[g][0] = a[g][0]; p[g][1] = a[g][1]; q_prev[g] = q[g]; }
         }
         {   // the last pair's own sums
-            float e0 = 0.0f, e1 = 0.0f;
+            const bool flush = sc_left == 1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { e0 += __builtin_amdgcn_exp2f(p0[r]); e1 += __builtin_amdgcn_exp2f(p1[r]); }
-            book(pt_hi - 1, e0, e1, q_prev);
+            for (int g = 0; g < UG; ++g) {
+                float e0 = 0.0f, e1 = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { e0 += __builtin_amdgcn_exp2f(p[g][0][r]); e1 += __builtin_amdgcn_exp2f(p[g][1][r]); }
+                book(g, pt_hi - 1, e0, e1, q_prev[g], flush);
+            }
+            if (flush) { ++sc_cur; sc_left = sc_pairs; } else --sc_left;
         }
-        if (sc_left != sc_pairs) view.rec[sc_cur * view.rec_stride] = make_float2(static_cast<float>(s_sc), q_prev);   // partial last super-chunk
-        if (d.use_cache && S == 1 && active && h == 0) d.cache_resc[d.uid[slot]] = static_cast<uint8_t>(min(n_resc, 255));
-        if (S == 1 && !d.sweep_only)
-            search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, delta_fixed, &view);
+#pragma unroll
+        for (int g = 0; g < UG; ++g) {
+            if (sc_left != sc_pairs)       // partial last super-chunk
+                view[g].rec[sc_cur * view[g].rec_stride] = make_float2(static_cast<float>(s_sc[g]), q_prev[g]);
+            if (d.use_cache && S == 1 && active[g] && h == 0) d.cache_resc[d.uid[slot[g]]] = static_cast<uint8_t>(min(n_resc[g], 255));
+        }
+        if (S == 1 && !d.sweep_only) {
+#pragma unroll
+            for (int g = 0; g < UG; ++g)
+                search_and_emit<KH>(d, t, scr[g], scr_chunk[g], omu[g], Ahat[g], n_resc[g], active[g], pos[g], slot[g], j, h, true,
+                                    delta_fixed[g], &view[g]);
+        }
     }
 }
 
+// user groups per wave of the wide kernel (RECOGYM_F16W_UG: 1 = 8 waves x 32 users, 2 = 4 waves x 64 users)
+inline int f16w_ug() {
+    const char* e = getenv("RECOGYM_F16W_UG");
+    return (e && e[0] == '2') ? 2 : 1;
+}
 draw_kernel_t f16w_kernel_for(const DevSim& d) {
-#define RG_CASE(kh, a) if (d.KH == kh && d.N1 == a) return k_draw_f16w<kh, a>;
+    const int ug = f16w_ug();
+#define RG_CASE(kh, a) if (d.KH == kh && d.N1 == a) return ug == 2 ? k_draw_f16w<kh, a, 2> : k_draw_f16w<kh, a, 1>;
     RG_CASE(16, 7) RG_CASE(32, 7) RG_CASE(32, 10) RG_CASE(32, 13)
 #undef RG_CASE
     return nullptr;
@@ -3276,10 +3374,14 @@ __global__ void k_tail_finish(DevSim d, uint32_t t0) {
 // Raw log: a wave reserves rows in chunks (one atomic per `chunk_rows` rows, not per row or per step) and
 // marks the entries it does not use (kHoleCode); the sort skips them.
 // ------------------------------------------------------------------------------------------
-template <int KH, int OCC>
+template <int KH, int OCC, bool DENSE>
 __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work, int round, uint32_t chunk_rows) {
     constexpr int K2 = 2 * KH;
     constexpr int kEmpty = 3;
+    // a user that stops still owes its phantom row (one more policy act, abstract.py:311-316): it takes it on its lane's
+    // NEXT step, through the one policy_act call site of the loop (a second inlined copy of the policy cost ~15 % of
+    // the kernel's instructions and was executed on half of the steps)
+    constexpr int kPhantom = 4;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
     // per wave: omega32 stage [64][K2] floats | float64 omega of the user being picked [K rounded to 2] | mailbox [64] {idx, A, B}
@@ -3313,7 +3415,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
                 }
                 const uint32_t take = min(static_cast<uint32_t>(__popcll(dead)), res_end - res_next);
                 const uint32_t r = prefix_in_mask(dead);
-                const bool mine = st == kEmpty && r < take;
+                const bool mine = ((dead >> lane) & 1ull) != 0 && r < take;   // (a lane that drew an unused entry in pass 1 is not in `dead`)
                 if (mine) {
                     const uint32_t idx = res_next + r;
                     uint32_t s2 = idx;
@@ -3336,8 +3438,9 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
         const unsigned long long live = __ballot(st != kEmpty);
         if (!live) { if (exhausted) break; else continue; }
         {
-        // ---- one raw-log row per live lane ----
-        const uint32_t nlive = static_cast<uint32_t>(__popcll(live));
+        // ---- one raw-log row per lane that emits an event (not for the pending phantom rows: they have their own array) ----
+        const unsigned long long rowm = __ballot(st == RG_STATE_ORGANIC || st == RG_STATE_BANDIT);
+        const uint32_t nlive = static_cast<uint32_t>(__popcll(rowm));
         if (row_next + nlive > row_end) {
             for (uint64_t r = row_next + lane; r < row_end; r += 64)
                 if (d.log && r < d.log_cap) { rg_event e; e.u = 0; e.t = 0; e.code = kHoleCode; e.ps = 0.0f; d.log[r] = e; }
@@ -3347,9 +3450,9 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
                    __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
             row_next = base; row_end = base + chunk_rows;
         }
-        const uint64_t my_row = row_next + prefix_in_mask(live);
+        const uint64_t my_row = row_next + prefix_in_mask(rowm);
         row_next += nlive;
-        const bool alive = st != kEmpty;
+        const bool alive = st == RG_STATE_ORGANIC || st == RG_STATE_BANDIT;
         const rg_u32x4 w = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
         const bool is_org = alive && st == RG_STATE_ORGANIC;
         bool parked = false;
@@ -3563,12 +3666,24 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
             park_next += np;
         }
         // =========================== bandit event + transition (k_advance's arithmetic) ===========================
+        const bool is_ban = st == RG_STATE_BANDIT, is_ph = st == kPhantom;
+        double ps = 1.0;
+        uint32_t a = 0;
+        if (is_ban || is_ph) a = (d.ablate & (1u << 18)) ? (user + t) % d.P : policy_act<DENSE>(d, slot, user, t, &ps);
+        if (is_ph) {       // final step_offline(done = True): the act above, reward 0 (abstract.py:223-233,311-316); t is already the row's time
+            rg_event e;
+            e.u = user; e.t = t; e.code = RG_EV_BANDIT | RG_EV_PHANTOM | a;
+            e.ps = static_cast<float>(ps);
+            d.phantom[slot] = e;
+            d.phantom_ps[slot] = ps;
+            d.has_phantom[slot] = 1;
+            c_ph += 1;
+            st = kEmpty;
+        }
         if (alive && !parked) {
             const double u_trans = rg_uniform(w.w[2], w.w[3]);
             bool click = false;
-            if (!is_org) {
-                double ps = 1.0;
-                const uint32_t a = (d.ablate & (1u << 18)) ? (user + t) % d.P : policy_act(d, slot, user, t, &ps);
+            if (is_ban) {
                 const double* b = d.beta + static_cast<size_t>(a) * d.K;
                 const double* om = d.omega + static_cast<size_t>(slot) * d.OMS;
                 double x = 0.0;
@@ -3624,21 +3739,14 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
                 d.n_events[slot] = t + 1;
             } else if (ns == RG_STATE_STOP) {
                 d.n_events[slot] = t + 1;
-                double ps = 1.0;
-                const uint32_t a = policy_act(d, slot, user, t + 1, &ps);
-                rg_event e;
-                e.u = user; e.t = t + 1; e.code = RG_EV_BANDIT | RG_EV_PHANTOM | a;
-                e.ps = static_cast<float>(ps);
-                d.phantom[slot] = e;
-                d.phantom_ps[slot] = ps;
-                d.has_phantom[slot] = 1;
-                c_ph += 1;
+                ns = kPhantom;                                 // the phantom row's act: this lane's next step
             } else if (t + 2 >= kMaxSteps) {
                 ns = RG_STATE_STOP;
                 d.n_events[slot] = t + 1;
                 c_limit += 1;
             }
-            if (ns == RG_STATE_STOP) { c_maxt = max(c_maxt, t + 1); st = kEmpty; }
+            if (ns == RG_STATE_STOP || ns == kPhantom) c_maxt = max(c_maxt, t + 1);
+            if (ns == RG_STATE_STOP) st = kEmpty;
             else { st = ns; t += 1; }
         }
         }   // if (live)
@@ -3675,12 +3783,16 @@ __global__ void k_walk_finish(DevSim d) {
 typedef void (*walk_kernel_t)(DevSim, uint32_t, int, uint32_t);
 // blocks per CU the kernel is compiled for (register budget 512 / OCC per lane): KH <= 16 at 2, 3 or 4, KH = 32 at 1
 walk_kernel_t walk_kernel_for(const DevSim& d, int occ) {
+    // the O(P) forms of the OrganicUserEventCounter policy are compiled in only where the configuration can reach them
+    const bool dense = d.policy == RG_POLICY_ORGANIC_USER_COUNT && !(d.ouc_exploit_explore && d.ouc_epsilon == 0.0);
+#define RG_W(kh, o) (dense ? k_walk<kh, o, true> : k_walk<kh, o, false>)
     switch (d.KH) {
-        case 4: return occ >= 4 ? k_walk<4, 4> : occ == 3 ? k_walk<4, 3> : k_walk<4, 2>;
-        case 10: return occ >= 4 ? k_walk<10, 4> : occ == 3 ? k_walk<10, 3> : k_walk<10, 2>;
-        case 16: return occ >= 4 ? k_walk<16, 4> : occ == 3 ? k_walk<16, 3> : k_walk<16, 2>;
-        default: return k_walk<32, 1>;
+        case 4: return occ >= 4 ? RG_W(4, 4) : occ == 3 ? RG_W(4, 3) : RG_W(4, 2);
+        case 10: return occ >= 4 ? RG_W(10, 4) : occ == 3 ? RG_W(10, 3) : RG_W(10, 2);
+        case 16: return occ >= 4 ? RG_W(16, 4) : occ == 3 ? RG_W(16, 3) : RG_W(16, 2);
+        default: return RG_W(32, 1);
     }
+#undef RG_W
 }
 
 // totals that are sums over the per-step counts
@@ -3914,40 +4026,73 @@ int prof_mark(rg_sim* sim, hipStream_t st) {
 // float64 draw of this step: from_list = 1 resolves the users the MFMA kernel could not certify
 // (est = expected count), from_list = 0 serves every organic user (pure float64 mode)
 void launch_exact(rg_sim* sim, uint32_t t, int from_list, uint64_t est, hipStream_t st) {
-    const DevSim& d = sim->d;
-    const uint32_t n_chunks = d.PT / 64;
-    if (exact_u_kernel_t ku = (getenv("RECOGYM_EXACT_TILE") ? nullptr : exact_u_kernel_for(d.XKB))) {
-        const uint64_t groups = (est + 63) / 64;
-        // The kernel's stall is the scalar-load latency of a Gamma row (the table streams through
-        // L2), hidden only by other waves: fill every SIMD to the kernel's occupancy (6 waves) and
-        // cut the work ~4x finer than that so the grid-stride loop balances.
-        uint32_t S = static_cast<uint32_t>(24576 / (groups ? groups : 1));
-        if (S > n_chunks) S = n_chunks;
-        if (S < 1) S = 1;
-        int grid = grid_for(groups * S, kBlock / 64);
-        if (grid > 1536) grid = 1536;
-        if (!from_list) {
-            hipLaunchKernelGGL(ku, dim3(grid), dim3(kBlock), 0, st, d, t, 0, 0, S);
-            hipLaunchKernelGGL(k_exact_ref, dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t, 1u);
+    const uint32_t n_chunks = sim->d.PT / 64;
+    // Without the per-user cache the float64 chunk sums of a step's uncertified draws go through a scratch of
+    // exact_rows rows: one batch where the step cannot have more draws than that, else two (covers 25 % of the live
+    // users uncertified; beyond that the run reports RG_CNT_EXACT_OVERFLOW instead of dropping draws)
+    const bool batched = from_list == 1 && !sim->d.use_cache;
+    const int n_batches = (batched && sim->live_upper > sim->d.exact_rows) ? 2 : 1;
+    for (int b = 0; b < n_batches; ++b) {
+        DevSim d = sim->d;
+        d.exact_base = batched ? static_cast<uint32_t>(b) * d.exact_rows : 0u;
+        d.exact_last = b + 1 == n_batches ? 1u : 0u;
+        if (batched && est > d.exact_rows) est = d.exact_rows;
+        if (exact_u_kernel_t ku = (getenv("RECOGYM_EXACT_TILE") ? nullptr : exact_u_kernel_for(d.XKB))) {
+            const uint64_t groups = (est + 63) / 64;
+            // The kernel's stall is the scalar-load latency of a Gamma row (the table streams through
+            // L2), hidden only by other waves: fill every SIMD to the kernel's occupancy (6 waves) and
+            // cut the work ~4x finer than that so the grid-stride loop balances.
+            uint32_t S = static_cast<uint32_t>(24576 / (groups ? groups : 1));
+            if (S > n_chunks) S = n_chunks;
+            if (S < 1) S = 1;
+            int grid = grid_for(groups * S, kBlock / 64);
+            if (grid > 1536) grid = 1536;
+            if (!from_list) {
+                hipLaunchKernelGGL(ku, dim3(grid), dim3(kBlock), 0, st, d, t, 0, 0, S);
+                hipLaunchKernelGGL(k_exact_ref, dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t, 1u);
+            }
+            hipLaunchKernelGGL(ku, dim3(grid), dim3(kBlock), 0, st, d, t, from_list, 1, S);
+            hipLaunchKernelGGL(k_exact_pick, dim3(grid_for(est, kBlock / 64)), dim3(kBlock),
+                               sizeof(double) * d.K * (kBlock / 64), st, d, t, from_list, 1u);
+            continue;
         }
-        hipLaunchKernelGGL(ku, dim3(grid), dim3(kBlock), 0, st, d, t, from_list, 1, S);
+        const uint64_t groups = (est + kExactUsers - 1) / kExactUsers;
+        uint32_t S = static_cast<uint32_t>(2048 / (groups ? groups : 1));
+        if (S > (n_chunks + 7) / 8) S = (n_chunks + 7) / 8;
+        if (S < 1) S = 1;
+        const int grid = grid_for(groups * S, 1);
+        const size_t smem = sizeof(double) * (static_cast<size_t>(d.K) * 64 + 64 + kExactUsers * d.K);
+        if (!from_list) {
+            hipLaunchKernelGGL(k_exact_sums, dim3(grid), dim3(kBlock), smem, st, d, t, 0, 0, S);
+            hipLaunchKernelGGL(k_exact_ref, dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t, 8u);
+        }
+        hipLaunchKernelGGL(k_exact_sums, dim3(grid), dim3(kBlock), smem, st, d, t, from_list, 1, S);
         hipLaunchKernelGGL(k_exact_pick, dim3(grid_for(est, kBlock / 64)), dim3(kBlock),
-                           sizeof(double) * d.K * (kBlock / 64), st, d, t, from_list, 1u);
-        return;
+                           sizeof(double) * d.K * (kBlock / 64), st, d, t, from_list, 8u);
     }
-    const uint64_t groups = (est + kExactUsers - 1) / kExactUsers;
-    uint32_t S = static_cast<uint32_t>(2048 / (groups ? groups : 1));
-    if (S > (n_chunks + 7) / 8) S = (n_chunks + 7) / 8;
-    if (S < 1) S = 1;
-    const int grid = grid_for(groups * S, 1);
-    const size_t smem = sizeof(double) * (static_cast<size_t>(d.K) * 64 + 64 + kExactUsers * d.K);
-    if (!from_list) {
-        hipLaunchKernelGGL(k_exact_sums, dim3(grid), dim3(kBlock), smem, st, d, t, 0, 0, S);
-        hipLaunchKernelGGL(k_exact_ref, dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t, 8u);
+}
+
+int device_cus(rg_sim* sim) {
+    if (!sim->n_cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            sim->n_cus = prop.multiProcessorCount;
+        else sim->n_cus = 256;
     }
-    hipLaunchKernelGGL(k_exact_sums, dim3(grid), dim3(kBlock), smem, st, d, t, from_list, 1, S);
-    hipLaunchKernelGGL(k_exact_pick, dim3(grid_for(est, kBlock / 64)), dim3(kBlock),
-                       sizeof(double) * d.K * (kBlock / 64), st, d, t, from_list, 8u);
+    return sim->n_cus;
+}
+
+// The sweep kernels keep per-wave scratch (chunk sums + super-chunk records, ~40 KB per wave at C3) indexed by
+// BLOCK in the fused form: a grid of exactly the blocks the device holds at once (2 per CU, register-bound) makes
+// that scratch a ~80 MB working set that lives in the Infinity Cache instead of ~650 MB that streams through
+// HBM (round 1: 2.7 KB of HBM traffic per draw against 192 B algorithmic); the blocks stride over the user tiles.
+int sweep_grid(rg_sim* sim, uint64_t work_items, uint32_t S) {
+    int grid = grid_for(work_items, 1);
+    const int resident = device_cus(sim) * (sim->draw_users == 256 ? 1 : 2);
+    if (S == 1 && grid > resident && !getenv("RECOGYM_FULL_GRID")) grid = resident;
+    if (sim->draw_users == 256 && grid > kMaxGrid / 2) grid = kMaxGrid / 2;     // 8 groups per block share the per-wave scratch
+    return grid;
 }
 
 int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
@@ -3984,8 +4129,7 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         if (const char* e = getenv("RECOGYM_SLICES")) S = static_cast<uint32_t>(atoi(e));   // tests: force either form
         if (S > d.n_sc) S = d.n_sc;
         if (S < 1) S = 1;
-        int grid = grid_for(static_cast<uint64_t>(tiles_up) * S, 1);
-        if (sim->draw_users == 256 && grid > kMaxGrid / 2) grid = kMaxGrid / 2;     // 8 waves per block share the per-wave scratch
+        const int grid = sweep_grid(sim, static_cast<uint64_t>(tiles_up) * S, S);
         hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid), dim3(sim->draw_threads), sim->bf16_smem, st, d, t, S);
         if (int rc = prof_mark(sim, st)) return rc;
         if (S > 1)
@@ -4043,13 +4187,7 @@ int prof_collect(rg_sim* sim) {
 // float64 sums of the parked users in one batch -> k_walk round 2.  Five launches and one host read-back.
 int run_walk(rg_sim* sim, hipStream_t st) {
     const DevSim& d = sim->d;
-    if (!sim->n_cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipGetDeviceProperties(&prop, dev));
-        sim->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    (void)device_cus(sim);
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     auto mark = [&](int i) -> int {
         if (!sim->profiling) return RG_OK;
@@ -4067,8 +4205,7 @@ int run_walk(rg_sim* sim, hipStream_t st) {
         if (const char* e = getenv("RECOGYM_SLICES")) S = static_cast<uint32_t>(atoi(e));
         if (S > d.n_sc) S = d.n_sc;
         if (S < 1) S = 1;
-        int grid = grid_for(static_cast<uint64_t>(tiles_up) * S, 1);
-        if (sim->draw_users == 256 && grid > kMaxGrid / 2) grid = kMaxGrid / 2;
+        const int grid = sweep_grid(sim, static_cast<uint64_t>(tiles_up) * S, S);
         hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid), dim3(sim->draw_threads), sim->bf16_smem, st, ds, 0u, S);
     }
     if (int rc = mark(1)) return rc;
@@ -4203,7 +4340,7 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
         if (d.wide) {
             s->bf16_kernel = static_cast<size_t>(d.P_pad) * d.RS < (1ull << 31) ? f16w_kernel_for(d) : nullptr;
             s->bf16_smem = 3 * (64 * static_cast<size_t>(d.RS) + 256) + 8 * 32 * 2 * static_cast<size_t>(d.KH) * 4;
-            s->draw_threads = 512; s->draw_users = 256;
+            s->draw_threads = 512 / f16w_ug(); s->draw_users = 256;
         }
         // the larger classes still spill registers; the fp32 kernel is faster there for now
         if (s->bf16_kernel && (d.f16 || (d.N1 <= 4 && d.KH <= 10))) d.use_mfma = 2;

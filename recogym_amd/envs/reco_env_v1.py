@@ -315,6 +315,8 @@ class RecoEnv1:
                             organic_only_below=first_user_id + num_organic_users)
             sim.run()
             cnt = sim.counters()
+            if cnt['exact_overflow']:
+                raise _abi.RecoGymHipError(f"{cnt['exact_overflow']} organic draws exceeded the float64 resolve scratch")
             if cnt['hist_overflow']:
                 # a user viewed more distinct products than its history row holds (default 255): run again with
                 # rows twice as long, the way a log overflow is retried with a larger buffer

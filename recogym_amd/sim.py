@@ -196,7 +196,7 @@ class Simulator:
             _abi.check(self.lib.rg_sim_read_counters(self._h, out, self._stream()),
                        'rg_sim_read_counters')
         names = ['organic', 'bandit', 'clicks', 'phantom', 'live', 'step', 'log_rows',
-                 'log_dropped', 'exact_draws', 'hist_overflow', 'exact_sweeps']
+                 'log_dropped', 'exact_draws', 'hist_overflow', 'exact_sweeps', 'exact_overflow']
         return {k: int(out[i]) for i, k in enumerate(names)}
 
     def set_profiling(self, on=True):
@@ -306,7 +306,11 @@ class Simulator:
         walk reserves rows per wave in chunks and marks what it leaves unused (code 0xFFFFFFFF)."""
         n = min(self.counters()['log_rows'], self.log_capacity)
         raw = self.log[:n]
-        return raw[raw[:, 2] != -1]
+        if not bool((raw[:, 2] == -1).any()):
+            return raw                                  # lock-step runs leave no unused entries: a view, no copy
+        # piecewise: torch's masked select mis-indexes results beyond 2^31 bytes on this stack
+        step = 1 << 24
+        return torch.cat([raw[i:i + step][raw[i:i + step, 2] != -1] for i in range(0, n, step)])
 
     def rows(self):
         """Decoded host rows in the reference's order."""

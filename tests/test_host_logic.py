@@ -265,3 +265,29 @@ def test_bench_workloads_and_cli_are_consistent():
     shards = [parallel.shard_range(10_000_000, r, 8) for r in range(8)]
     assert sum(c for _, c in shards) == 10_000_000 and shards[0][0] == 0
     assert all(shards[i][0] + shards[i][1] == shards[i + 1][0] for i in range(7))
+
+
+def test_gym_registration_hook(tmp_path, monkeypatch):
+    """recogym_amd.register_with_gym() registers 'reco-gym-v1' with an importable `gym` (here: a stand-in with the
+    registration surface the reference uses, recogym/__init__.py:35-45) and leaves an existing registration alone
+    unless forced; without gym it reports False."""
+    import recogym_amd
+    pkg = tmp_path / 'gym'
+    (pkg / 'envs').mkdir(parents=True)
+    (pkg / '__init__.py').write_text('from .envs import registration\n')
+    (pkg / 'envs' / '__init__.py').write_text('from . import registration\n')
+    (pkg / 'envs' / 'registration.py').write_text(
+        'registry = {}\n'
+        'def register(id, entry_point, **kw):\n'
+        '    if id in registry: raise ValueError("Cannot re-register id: " + id)\n'
+        '    registry[id] = entry_point\n')
+    for m in [k for k in sys.modules if k == 'gym' or k.startswith('gym.')]:
+        monkeypatch.delitem(sys.modules, m)
+    monkeypatch.syspath_prepend(str(tmp_path))
+    assert recogym_amd.register_with_gym() is True
+    import gym.envs.registration as reg
+    assert reg.registry['reco-gym-v1'] == 'recogym_amd.envs.reco_env_v1:RecoEnv1'
+    reg.registry['reco-gym-v1'] = 'recogym.envs.reco_env_v1:RecoEnv1'        # the reference got there first
+    assert recogym_amd.register_with_gym() is False
+    assert recogym_amd.register_with_gym(force=True) is True
+    assert reg.registry['reco-gym-v1'] == 'recogym_amd.envs.reco_env_v1:RecoEnv1'
