@@ -137,9 +137,31 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
                                  ms=round(prof['draw_mfma_ms'], 2), units=int(swept), unit_name='swept draws',
                                  achieved=round(tf, 2), peak=peak, unit='TFLOP/s', frac=round(tf / peak, 4),
                                  executed_mfma_tflops=round(tf * (64.0 if f16_split else 144.0) / K, 1) if K <= 21 else None)
-    # cached draw (sigma_omega = 0, t >= 1): per draw the user's 32 super-chunk sums (128 B), the chosen
+    walked = prof.get('walk1_ms', 0.0) > 0
+    # the user-major walk (sigma_omega = 0, run to the end): SURVEY.md 8d bytes per event — bandit: omega 4K + state 8 +
+    # row 16 + action 3 (+35 history with the OUC agent in the loop); organic: state 8 + the cached draw's 128 B of
+    # super-chunk sums, 48 B of chunk sums, omega32 (4K) and the 16-byte row
+    if walked:
+        b_b = 4 * K + 8 + 16 + 3 + (35 if pol == 'ouc' else 0)
+        b_o = 8 + 128 + 48 + 4 * K + 16
+        by = b_b * c['bandit'] + b_o * c['organic']
+        ms = prof['walk1_ms'] + prof['walk2_ms']
+        gbps = by / (ms * 1e-3) / 1e9
+        out['walk'] = dict(kernel='k_walk', bound='hbm', ms=round(ms, 2), round1_ms=round(prof['walk1_ms'], 2),
+                           round2_ms=round(prof['walk2_ms'], 2), units=int(c['bandit'] + c['organic']), unit_name='events',
+                           bytes_per_unit=round(by / max(c['bandit'] + c['organic'], 1), 1), achieved=round(gbps, 1),
+                           peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(gbps / HBM_PEAK_GBPS, 4),
+                           note='VALU-issue / latency bound on per-user state that lives in L2 and the Infinity Cache '
+                                '(DESIGN.md 4), not on HBM bandwidth')
+        if prof['draw_search_ms'] > 0:
+            out['cache_finalize'] = dict(kernel='k_cache_finalize', bound='hbm', ms=round(prof['draw_search_ms'], 2), units=int(users),
+                                         unit_name='users', bytes_per_unit=256 + 8 * K + 256,
+                                         achieved=round((512 + 8 * K) * users / (prof['draw_search_ms'] * 1e-3) / 1e9, 1),
+                                         peak=HBM_PEAK_GBPS, unit='GB/s',
+                                         frac=round((512 + 8 * K) * users / (prof['draw_search_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4))
+    # cached draw (sigma_omega = 0, t >= 1, lock-step form): per draw the user's 32 super-chunk sums (128 B), the chosen
     # super-chunk's chunk sums (48 B), omega32 (4K) and the 16-byte row: HBM gather
-    if cached and prof['draw_search_ms'] > 0:
+    if cached and not walked and prof['draw_search_ms'] > 0:
         n = c['organic'] - users
         by = 128 + 48 + 4 * K + 16
         gbps = by * n / (prof['draw_search_ms'] * 1e-3) / 1e9
@@ -282,7 +304,11 @@ def main():
                                        f'{launches} launches; bound by scattered per-user gathers, not by streaming bandwidth')
         roofline['launches'] = launches
         roofline['avg_launch_ms'] = round(roofline['ms'] / launches, 4)
-        pmc = measured_traffic(roofline['kernel'].split(' ')[0])
+        pmc = measured_traffic(roofline['kernel'].split(' ')[0]) if args.workload in ('c3', 'c4shard') else None
+        if dom == 'walk':
+            launches = 2 if prof['walk2_ms'] > 0 else 1          # round 1 + round 2 of one run
+            roofline['launches'] = launches
+            roofline['avg_launch_ms'] = round(roofline['ms'] / launches, 4)
         roofline['traffic'] = None if pmc is None else pmc['hbm_bytes_per_unit'] * roofline['units'] / launches
         roofline['traffic_source'] = None if pmc is None else pmc['source']
         roofline['tail_ms'] = round(prof['tail_ms'], 2)

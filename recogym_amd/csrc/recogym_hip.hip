@@ -618,6 +618,17 @@ __device__ __forceinline__ void hist_load_line(const hent_t* row, hent_t e[kHist
     }
 }
 
+// count / sum, correctly rounded, from y = RN(1 / sum) (one true division per act instead of one per viewed product):
+// q = RN(c y); r = c - sum q (exact in one fma); RN(q + r y) is the correctly rounded quotient whenever y is the
+// correctly rounded reciprocal and the significand of `sum` is not all ones (Markstein 1990; Cornea, Harrison & Tang,
+// "Scientific Computing on Itanium", Thm 8.5) — `sum` is an integer below 2^32 here, so it never is.  Checked
+// exhaustively / on random operands against exact rational arithmetic in tests/test_host_logic.py.
+__device__ __forceinline__ double div_by_reciprocal(double c, double sum, double y) {
+    const double q = c * y;
+    const double r = fma(-sum, q, c);
+    return fma(r, y, q);
+}
+
 // !(acc / last <= u) exactly as float64 evaluates it, without the division where the answer is clear:
 // acc < fl(u last)(1 - 2^-50) implies fl(acc / last) <= u, acc > fl(u last)(1 + 2^-50) implies fl(acc / last) > u
 __device__ __forceinline__ bool cdf_exceeds(double acc, double last, double u) {
@@ -690,10 +701,11 @@ __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, ui
             // the whole history is in registers: p_i once, then the cdf walk without touching memory again
             double pr[kHistRegs - 1];
             double last = 0.0;
+            const double y = 1.0 / sum;
 #pragma unroll
             for (int i = 1; i < kHistRegs; ++i) {
                 pr[i - 1] = 0.0;
-                if (static_cast<uint32_t>(i) <= nd) { pr[i - 1] = static_cast<double>(h_cnt(e[i])) / sum; last += pr[i - 1]; }
+                if (static_cast<uint32_t>(i) <= nd) { pr[i - 1] = div_by_reciprocal(static_cast<double>(h_cnt(e[i])), sum, y); last += pr[i - 1]; }
             }
             if (d.ouc_select_randomly) {
                 double acc = 0.0, pa = 0.0;
@@ -2142,12 +2154,13 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             if (!(pe & 1)) { wlo = make_float2(s0, s1); return; }
             const uint32_t ti = pt_lo + (pe >> 1);
             const float4 w4 = make_float4(wlo.x, wlo.y, s0, s1);
-            // scratch layout [tile][user][4 chunks]; both lanes of the user hold the same sums: no branch
-            if (!(d.ablate & 16u)) *reinterpret_cast<float4*>(view.chunk + static_cast<size_t>(ti) * view.tile_stride) = w4;
+            // scratch layout [tile][user][4 chunks]; both lanes of the user hold the same sums: one of them stores
+            // (unpredicated, the duplicate store doubled the kernel's write traffic: 3.1 KB per draw, profiles/r2)
+            if (h == 0 && !(d.ablate & 16u)) *reinterpret_cast<float4*>(view.chunk + static_cast<size_t>(ti) * view.tile_stride) = w4;
             wcmax = fmaxf(fmaxf(wcmax, fmaxf(w4.x, w4.y)), fmaxf(w4.z, w4.w));
             s_sc += static_cast<double>((w4.x + w4.y) + (w4.z + w4.w));
             if (--sc_left == 0) {
-                view.rec[sc_cur * view.rec_stride] = make_float2(static_cast<float>(s_sc), q_done);
+                if (h == 0) view.rec[sc_cur * view.rec_stride] = make_float2(static_cast<float>(s_sc), q_done);
                 s_sc = 0.0;
                 // some logit is >= ~43 above the reference: re-reference from the next super-chunk
                 // that has not started (its MFMAs are a pair ahead of these sums)
@@ -2234,7 +2247,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             q_done = q;
             book(pi, tree(p0), tree(p1));
         }
-        if (sc_left != d.sc_chunks / 4) {                      // partial last super-chunk
+        if (sc_left != d.sc_chunks / 4 && h == 0) {            // partial last super-chunk
             view.rec[sc_cur * view.rec_stride] = make_float2(static_cast<float>(s_sc), q_done);
         }
         if (d.use_cache && S == 1 && active && h == 0) d.cache_resc[d.uid[slot]] = static_cast<uint8_t>(min(n_resc, 255));
@@ -2738,11 +2751,11 @@ __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t,
             s1 += swap32(s1);
             const uint32_t ci = 2 * ti_done;
             // scratch layout of the 4-chunk tiles the search reads: [tile of 4][user][4 chunks]
-            *reinterpret_cast<float2*>(view[g].chunk + static_cast<size_t>(ci >> 2) * view[g].tile_stride + (ci & 3)) = make_float2(s0, s1);
+            if (h == 0) *reinterpret_cast<float2*>(view[g].chunk + static_cast<size_t>(ci >> 2) * view[g].tile_stride + (ci & 3)) = make_float2(s0, s1);
             wcmax[g] = fmaxf(wcmax[g], fmaxf(s0, s1));
             s_sc[g] += static_cast<double>(s0 + s1);
             if (flush) {
-                view[g].rec[sc_cur * view[g].rec_stride] = make_float2(static_cast<float>(s_sc[g]), q_used);
+                if (h == 0) view[g].rec[sc_cur * view[g].rec_stride] = make_float2(static_cast<float>(s_sc[g]), q_used);
                 s_sc[g] = 0.0;
                 // some logit is >= ~43 above the reference: re-reference from the next super-chunk that has not started
                 if (wcmax[g] > 2.8e14f) q_next[g] = fmaxf(q_next[g], q_used + floorf(__builtin_amdgcn_logf(wcmax[g])));
@@ -2871,7 +2884,7 @@ __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t,
         }
 #pragma unroll
         for (int g = 0; g < UG; ++g) {
-            if (sc_left != sc_pairs)       // partial last super-chunk
+            if (sc_left != sc_pairs && h == 0)       // partial last super-chunk
                 view[g].rec[sc_cur * view[g].rec_stride] = make_float2(static_cast<float>(s_sc[g]), q_prev[g]);
             if (d.use_cache && S == 1 && active[g] && h == 0) d.cache_resc[d.uid[slot[g]]] = static_cast<uint8_t>(min(n_resc[g], 255));
         }
@@ -4083,14 +4096,14 @@ int device_cus(rg_sim* sim) {
     return sim->n_cus;
 }
 
-// The sweep kernels keep per-wave scratch (chunk sums + super-chunk records, ~40 KB per wave at C3) indexed by
-// BLOCK in the fused form: a grid of exactly the blocks the device holds at once (2 per CU, register-bound) makes
-// that scratch a ~80 MB working set that lives in the Infinity Cache instead of ~650 MB that streams through
-// HBM (round 1: 2.7 KB of HBM traffic per draw against 192 B algorithmic); the blocks stride over the user tiles.
+// Grid of a sweep kernel.  The per-wave scratch (chunk sums + super-chunk records, ~40 KB per wave at C3) is indexed
+// by BLOCK in the fused form.  Capping the grid at the blocks the device holds at once (RECOGYM_RESIDENT_GRID=1) keeps
+// that scratch an ~80 MB working set instead of ~650 MB, but the memory-side counters (FETCH_SIZE / WRITE_SIZE sit at
+// the L2 <-> fabric boundary and include Infinity-Cache hits) were identical and the kernel 3 % slower: not the default.
 int sweep_grid(rg_sim* sim, uint64_t work_items, uint32_t S) {
     int grid = grid_for(work_items, 1);
     const int resident = device_cus(sim) * (sim->draw_users == 256 ? 1 : 2);
-    if (S == 1 && grid > resident && !getenv("RECOGYM_FULL_GRID")) grid = resident;
+    if (S == 1 && grid > resident && getenv("RECOGYM_RESIDENT_GRID")) grid = resident;
     if (sim->draw_users == 256 && grid > kMaxGrid / 2) grid = kMaxGrid / 2;     // 8 groups per block share the per-wave scratch
     return grid;
 }

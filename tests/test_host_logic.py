@@ -291,3 +291,31 @@ def test_gym_registration_hook(tmp_path, monkeypatch):
     assert recogym_amd.register_with_gym() is False
     assert recogym_amd.register_with_gym(force=True) is True
     assert reg.registry['reco-gym-v1'] == 'recogym_amd.envs.reco_env_v1:RecoEnv1'
+
+
+def test_division_by_reciprocal_is_correctly_rounded():
+    """The device computes count / sum of the organic-count policy as q = RN(c y), r = c - sum q (one fma),
+    RN(q + r y) with y = RN(1 / sum) — one true division per act.  That equals IEEE division for the operands the
+    policy has (positive integers below 2^32): checked against exact rational arithmetic, exhaustively for small
+    operands and on random large ones."""
+    from fractions import Fraction
+    import random
+
+    def rn(fr):                     # nearest double of an exact rational (Python rounds int/int division correctly)
+        return fr.numerator / fr.denominator
+
+    def dev(c, s):
+        y = 1.0 / s
+        q = c * y
+        r = rn(Fraction(c) - Fraction(s) * Fraction(q))          # fma(-s, q, c): exact, then rounded once
+        assert Fraction(r) == Fraction(c) - Fraction(s) * Fraction(q)      # ... and in fact representable
+        return rn(Fraction(q) + Fraction(r) * Fraction(y))       # fma(r, y, q)
+
+    for s in range(1, 400):
+        for c in range(1, s + 1):
+            assert dev(float(c), float(s)) == c / s, (c, s)
+    rnd = random.Random(7)
+    for _ in range(40000):
+        s = rnd.randrange(1, 1 << rnd.randrange(1, 33))
+        c = rnd.randrange(1, s + 1)
+        assert dev(float(c), float(s)) == c / s, (c, s)

@@ -1,0 +1,49 @@
+# Round-2 profile evidence: kernel-trace stats of the bench command per workload, and PMC passes (each in its own run,
+# --kernel-trace only) for the dominant kernels.  Outputs under gpurun_out/r2_prof/ (copied to profiles/r2/ by hand).
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r2_prof
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+stats() { # name, bench args
+  name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -o run -- python $R/bench.py "$@" > $O/$name.bench.log 2> $O/$name.err
+  f=$(find $O/$name -name '*kernel_stats.csv' | head -1); cp $f $O/${name}_kernel_stats.csv; rm -rf $O/$name
+  grep '"metric"' $O/$name.bench.log > $O/${name}_bench_line.json
+}
+pmc() { # name, counters, bench args
+  name=$1; cnt=$2; shift; shift
+  rocprofv3 --kernel-trace --pmc $cnt --output-format csv -d $O/$name -o run -- python $R/bench.py "$@" > $O/$name.out 2> $O/$name.err
+  f=$(find $O/$name -name '*counter_collection.csv' | head -1)
+  python - "$f" "$O/${name}_counters.csv" <<'PY'
+import csv, sys, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter(); dur = collections.Counter()
+seen = set()
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r['Kernel_Name']
+    agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+    if (k, r['Dispatch_Id']) not in seen:
+        seen.add((k, r['Dispatch_Id'])); n[k] += 1; dur[k] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+with open(sys.argv[2], 'w') as f:
+    f.write('kernel,dispatches,total_ns,counter,value\n')
+    for k in sorted(agg, key=lambda k: -dur[k]):
+        for c, v in sorted(agg[k].items()):
+            f.write(f'"{k[:90]}",{n[k]},{dur[k]},{c},{v:.6g}\n')
+PY
+  rm -rf $O/$name
+}
+stats c3 --workload c3 --steps 2 --warmup 1
+stats c4shard --workload c4shard --steps 1 --warmup 1 --no-cpu-baseline
+stats c2 --workload c2 --steps 3 --warmup 1 --no-cpu-baseline --no-drift-line
+A="--users 2000000 --steps 1 --warmup 0 --no-cpu-baseline --no-drift-line"
+pmc pmc_c3_fetch FETCH_SIZE --workload c3 $A
+pmc pmc_c3_write WRITE_SIZE --workload c3 $A
+pmc pmc_c3_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE" --workload c3 $A
+pmc pmc_c3drift_fetch FETCH_SIZE --workload c3drift $A
+pmc pmc_c3drift_write WRITE_SIZE --workload c3drift $A
+RECOGYM_RESIDENT_GRID=1 pmc pmc_c3drift_residentgrid_write WRITE_SIZE --workload c3drift $A
+pmc pmc_c3drift_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" --workload c3drift $A
+B="--users 300000 --steps 1 --warmup 0 --no-cpu-baseline"
+pmc pmc_c4_fetch FETCH_SIZE --workload c4shard $B
+pmc pmc_c4_write WRITE_SIZE --workload c4shard $B
+pmc pmc_c4_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" --workload c4shard $B
+ls -la $O | head -40
