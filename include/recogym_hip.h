@@ -82,6 +82,13 @@ typedef struct rg_config {
     uint32_t ouc_reverse_pop;
     uint32_t ouc_history_cap;       /* max organic views kept per user on the device (0 = default) */
     double ouc_epsilon;
+    /* time generator (envs/features/time/): 0 = DefaultTimeGenerator (t = event index, default_time_generator.py:10-13);
+     * 1 = NormalTimeGenerator (normal_time_generator.py:23-26): event n of a user happens at T_n = sum_{i<n} |mu + sigma z_i|,
+     * and the drift that follows it is scaled by T_{n+1} - T_n (reco_env_v1.py:89-98).  Lock-step execution only. */
+    uint32_t time_mode;
+    uint32_t reserved0;
+    double time_mu;                 /* config.normal_time_mu (default 0) */
+    double time_sigma;              /* config.normal_time_sigma (default 1) */
 } rg_config;
 
 /*
@@ -171,6 +178,10 @@ int rg_sim_set_log(rg_sim* sim, rg_event* d_log, uint64_t capacity);
  * (reco_env_v1.py:104-116).  Entries of organic rows are not written.  rg_sim_set_log detaches them. */
 int rg_sim_set_log_aux(rg_sim* sim, double* d_ps, double* d_p_click);
 
+/* NormalTimeGenerator only: d_time[row] receives the (float64) time of raw-log row `row`, every row (the 16-byte row's
+ * `t` stays the per-user event index, which orders the log).  `capacity` doubles, like the log.  rg_sim_set_log detaches it. */
+int rg_sim_set_log_time(rg_sim* sim, double* d_time);
+
 /* RecoEnv1.reset + AbstractEnv.reset (reco_env_v1.py:78-82, abstract.py:90-103) for `n` users
  * with ids first_user_id .. first_user_id+n-1 at once: state <- organic, t <- 0,
  * omega <- sigma_omega_initial * Z(K).  Users with id < organic_only_below are the
@@ -230,6 +241,12 @@ int rg_sim_sort_log(rg_sim* sim, int64_t* d_row_offsets, int64_t* d_scratch, rg_
  * by it): NaN on organic rows, and for p_click on the phantom row (never drawn).  Either output may be NULL. */
 int rg_sim_sort_log_aux(rg_sim* sim, const int64_t* d_row_offsets, double* d_sorted_ps,
                         double* d_sorted_p_click, uint64_t sorted_capacity, void* stream);
+
+/* The time column in the row order of rg_sim_sort_log (phantom rows: the time their act would have had). */
+int rg_sim_sort_log_time(rg_sim* sim, const int64_t* d_row_offsets, double* d_sorted_time, uint64_t sorted_capacity,
+                         void* stream);
+/* Current time of every user of the reset range (n float64; = its event index with the default generator). */
+int rg_sim_export_time(rg_sim* sim, double* d_time, void* stream);
 
 /* ---- test hooks (the parity suite's adversarial certificate test; not part of the reference surface) ----
  * rg_sim_debug_set_omega: overwrite omega of the reset range, (n, K) float64 user-major, right after

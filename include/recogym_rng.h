@@ -23,6 +23,7 @@
  *   purpose RG_DRAW_DRIFT  (slot j): Box-Muller pair -> z[2j], z[2j+1] of the omega drift that
  *                                    follows event t (reco_env_v1.py:96)
  *   purpose RG_DRAW_RESET  (slot j, t = 0): z[2j], z[2j+1] of omega_0 (reco_env_v1.py:80)
+ *   purpose RG_DRAW_TIME   (slot 0): z0 -> the time increment after event t (NormalTimeGenerator only)
  *
  * seed64 is `random_seed + epoch` (abstract.py:62) for env draws and the agent's own
  * `random_seed` for RG_DRAW_POLICY draws of an agent (with agent=None the policy draw comes
@@ -51,6 +52,8 @@
 #define RG_DRAW_POLICY 1u
 #define RG_DRAW_DRIFT 2u
 #define RG_DRAW_RESET 3u
+#define RG_DRAW_TIME 4u    /* NormalTimeGenerator (normal_time_generator.py:23-26): slot 0, z0 of the Box-Muller pair -> the
+                              increment |mu + sigma z| that follows event t */
 
 #define RG_TWO_PI 6.283185307179586476925286766559
 

@@ -19,7 +19,7 @@ RNG_PHILOX, RNG_MT = 0, 1
 
 ROW_DTYPE = np.dtype([('u', np.uint32), ('t', np.uint32), ('z', np.int32), ('v', np.int32),
                       ('a', np.int32), ('c', np.int32), ('phantom', np.int32),
-                      ('pad', np.int32), ('ps', np.float64), ('p_click', np.float64)])
+                      ('pad', np.int32), ('ps', np.float64), ('p_click', np.float64), ('time', np.float64)])
 
 
 def build(force=False):
@@ -56,6 +56,8 @@ def lib():
                                    C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
         L.rgo_env_time.restype = C.c_uint32
         L.rgo_env_time.argtypes = [C.c_void_p]
+        L.rgo_env_clock.restype = C.c_double
+        L.rgo_env_clock.argtypes = [C.c_void_p]
         L.rgo_env_state.restype = C.c_int
         L.rgo_env_state.argtypes = [C.c_void_p]
         L.rgo_env_omega.argtypes = [C.c_void_p, C.c_void_p]
@@ -139,6 +141,10 @@ class OracleEnv:
     @property
     def time(self):
         return lib().rgo_env_time(self._h)
+
+    @property
+    def clock(self):
+        return lib().rgo_env_clock(self._h)
 
     @property
     def state(self):

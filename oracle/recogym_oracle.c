@@ -52,6 +52,7 @@ typedef struct rgo_row {
     int32_t pad;
     double ps;        /* NaN on organic rows */
     double p_click;   /* ff(beta[a].omega + mu_b[a]) on real bandit rows, NaN otherwise */
+    double time;      /* the time generator's clock at the row (== t with DefaultTimeGenerator) */
 } rgo_row;
 
 /* ------------------------------------------------------------------------------------------
@@ -152,7 +153,8 @@ typedef struct rgo_env {
     int state;                /* self.state */
     int first_step;           /* self.first_step */
     uint32_t user;            /* self.current_user_id */
-    uint32_t time;            /* self.current_time (DefaultTimeGenerator) */
+    uint32_t time;            /* event index of the current user == self.current_time with DefaultTimeGenerator */
+    double clock;             /* self.current_time with NormalTimeGenerator (normal_time_generator.py:23-26) */
     double* omega;            /* (K) */
     double last_p_click;
     /* draw sources */
@@ -250,6 +252,7 @@ void rgo_env_reset(rgo_env* e, uint32_t user_id) {
     e->first_step = 1;
     e->state = RG_STATE_ORGANIC;
     e->time = 0;                       /* time_generator.reset(); new_time() -> 0 */
+    e->clock = 0.0;
     e->user = user_id;
     memset(e->views, 0, sizeof(int32_t) * e->cfg.num_products);   /* agent.reset() */
     double* z = e->zbuf;
@@ -300,12 +303,23 @@ static void update_state(rgo_env* e) {
     const uint32_t t_event = e->time;
     e->state = ns;
     e->time += 1;
+    /* time_delta = new_time() - old_time; omega_k = 1 if time_delta == 0 else time_delta (reco_env_v1.py:89-92).
+     * DefaultTimeGenerator: always 1.  NormalTimeGenerator (Philox mode only): the increment that follows event t is
+     * |mu + sigma z|, z = the RG_DRAW_TIME draw of (user, t) */
+    double omega_k = 1.0;
+    if (e->cfg.time_mode == 1) {
+        const rg_u32x4 w = rg_draw(e->cfg.seed, e->user, t_event, 0, RG_DRAW_TIME);
+        const double z0 = sqrt(-2.0 * log(1.0 - rg_uniform(w.w[0], w.w[1]))) * cos(RG_TWO_PI * rg_uniform(w.w[2], w.w[3]));
+        const double dt = fabs(e->cfg.time_mu + e->cfg.time_sigma * z0);
+        e->clock = e->clock + dt;
+        omega_k = dt == 0.0 ? 1.0 : dt;
+    } else e->clock = (double)e->time;
     if (e->cfg.change_omega_for_bandits || e->state == RG_STATE_ORGANIC) {
         double* z = e->zbuf;
         /* the draws are consumed even when sigma_omega == 0 (MT mode must advance) */
         draw_normals(e, RG_DRAW_DRIFT, t_event, z);
         for (uint32_t k = 0; k < e->cfg.K; ++k)
-            e->omega[k] = e->omega[k] + (e->cfg.sigma_omega * 1.0) * z[k];
+            e->omega[k] = e->omega[k] + (e->cfg.sigma_omega * omega_k) * z[k];
     }
 }
 
@@ -347,7 +361,7 @@ static void generate_organic_sessions(rgo_env* e, rgo_session* out) {
         const int32_t v = update_product_view(e);
         rgo_row r;
         memset(&r, 0, sizeof(r));
-        r.u = e->user; r.t = e->time; r.z = 0; r.v = v; r.a = -1; r.c = -1;
+        r.u = e->user; r.t = e->time; r.time = e->clock; r.z = 0; r.v = v; r.a = -1; r.c = -1;
         r.ps = NAN; r.p_click = NAN;
         push_row(out, &r);
         e->views[v] += 1;
@@ -380,6 +394,7 @@ int rgo_env_step(rgo_env* e, int32_t action, rgo_row* rows, uint64_t cap, uint64
 }
 
 uint32_t rgo_env_time(const rgo_env* e) { return e->time; }
+double rgo_env_clock(const rgo_env* e) { return e->clock; }
 int rgo_env_state(const rgo_env* e) { return e->state; }
 void rgo_env_omega(const rgo_env* e, double* out) {
     memcpy(out, e->omega, sizeof(double) * e->cfg.K);
@@ -496,7 +511,7 @@ int64_t rgo_env_generate_logs(rgo_env* e, uint64_t first_user_id, uint64_t n_use
             /* step_offline: act, then step(action) */
             rgo_row r;
             memset(&r, 0, sizeof(r));
-            r.u = e->user; r.t = e->time; r.z = 1; r.v = -1;
+            r.u = e->user; r.t = e->time; r.time = e->clock; r.z = 1; r.v = -1;
             r.a = rgo_env_policy_act(e, &r.ps);
             r.c = draw_click(e, r.a);
             r.p_click = e->last_p_click;
@@ -513,7 +528,7 @@ int64_t rgo_env_generate_logs(rgo_env* e, uint64_t first_user_id, uint64_t n_use
         /* final step_offline(done=True): one more act, reward forced to 0 (abstract.py:223-233) */
         rgo_row r;
         memset(&r, 0, sizeof(r));
-        r.u = e->user; r.t = e->time; r.z = 1; r.v = -1; r.c = 0; r.phantom = 1;
+        r.u = e->user; r.t = e->time; r.time = e->clock; r.z = 1; r.v = -1; r.c = 0; r.phantom = 1;
         r.a = rgo_env_policy_act(e, &r.ps);
         r.p_click = NAN;
         push_row(&s, &r);

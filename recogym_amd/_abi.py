@@ -48,6 +48,10 @@ class RgConfig(C.Structure):
         ('ouc_reverse_pop', C.c_uint32),
         ('ouc_history_cap', C.c_uint32),
         ('ouc_epsilon', C.c_double),
+        ('time_mode', C.c_uint32),
+        ('reserved0', C.c_uint32),
+        ('time_mu', C.c_double),
+        ('time_sigma', C.c_double),
     ]
 
 
@@ -85,6 +89,9 @@ SYMBOLS = {
     'rg_sim_set_log_aux': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_sort_log_aux': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
                                       C.c_void_p]),
+    'rg_sim_set_log_time': (C.c_int, [_SIM, C.c_void_p]),
+    'rg_sim_sort_log_time': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    'rg_sim_export_time': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_debug_set_omega': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_debug_set_uniforms': (C.c_int, [_SIM, C.c_void_p]),
     'rg_sim_debug_uncertified': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),

@@ -99,7 +99,7 @@ class OrganicUserEventCounterAgent(Agent):
         for s in observation.sessions():
             self.views[int(s['v'])] += 1
         ctx = observation.context()
-        _, u0, u1 = rng.policy_uniforms(c.random_seed, ctx.user(), ctx.time())
+        _, u0, u1 = rng.policy_uniforms(c.random_seed, *(ctx.draw_key() if hasattr(ctx, 'draw_key') else (ctx.user(), ctx.time())))
         eps = c.epsilon
         f = self.views.astype(np.float64)
         explore = False

@@ -25,7 +25,8 @@ class RandomAgent(Agent):
     def act(self, observation, reward, done):
         P = self.config.num_products
         ctx = observation.context()
-        w = rng.draw(self.config.random_seed, ctx.user(), ctx.time(), 0, rng.DRAW_POLICY)
+        user, t = ctx.draw_key() if hasattr(ctx, 'draw_key') else (ctx.user(), ctx.time())
+        w = rng.draw(self.config.random_seed, user, t, 0, rng.DRAW_POLICY)
         return {
             **super().act(observation, reward, done),
             'a': rng.bounded(w[0], w[1], P),

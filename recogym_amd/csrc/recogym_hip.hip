@@ -180,6 +180,12 @@ struct DevSim {
     double* phantom_ps;       // [n_users] float64 propensity of the phantom row
     // test hooks (rg_sim_debug_*): per-user-index uniforms replacing the organic draw's u at the next step
     const double* u_override;
+    // NormalTimeGenerator (time_mode = 1, normal_time_generator.py:23-26; lock-step only)
+    uint32_t time_mode;
+    double time_mu, time_sigma;
+    double* utime;            // [n_cap] current time of every user (index = user index)
+    double* phantom_time;     // [n_cap] time of the phantom row
+    double* aux_time;         // optional side array of the log: time of every raw row
 };
 
 }  // namespace
@@ -356,6 +362,8 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     unsigned long long* counters = w.take<unsigned long long>(RG_CNT_N);
     uint32_t* uid = w.take<uint32_t>(n);
     double* phantom_ps = w.take<double>(n);
+    double* utime = w.take<double>(c.time_mode ? n : 1);
+    double* phantom_time = w.take<double>(c.time_mode ? n : 1);
     const bool cache = cache_wanted(c, g);
     float2* cache_rec = w.take<float2>(cache ? (n + 1) * kMaxSC : 1);
     float* cache_chunk = w.take<float>(cache ? (n + 1) * static_cast<size_t>(g.n_chunks) : 1);
@@ -372,7 +380,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint32_t* lpv_alt = w.take<uint32_t>(rp && c.policy == RG_POLICY_LAST_VIEW_TABLE ? n : 1);
     uint32_t* uid_alt = w.take<uint32_t>(rp ? n : 1);
     if (d) {
-        d->phantom_ps = phantom_ps;
+        d->phantom_ps = phantom_ps; d->utime = utime; d->phantom_time = phantom_time;
         d->use_cache = cache ? 1u : 0u; d->cache_rec = cache_rec; d->cache_chunk = cache_chunk; d->cache_resc = cache_resc;
         d->f64_valid = f64_valid; d->exact_cnt_b = exact_cnt_b; d->cache_row = cache_row; d->cache_row_f = cache_row_f;
         d->park_list = park_list; d->park_t = park_t; d->sweep_only = 0;
@@ -406,6 +414,8 @@ int validate(const rg_config* c, uint64_t n) {
         return fail(RG_EINVAL, "K %u exceeds the float64 draw kernel's LDS budget", c->K);
     if (n == 0 || n >= (1ull << 31)) return fail(RG_EINVAL, "n_users %llu out of range", (unsigned long long)n);
     if (c->policy > RG_POLICY_LOGREG_FROZEN) return fail(RG_EINVAL, "unknown policy %u", c->policy);
+    if (c->time_mode > 1) return fail(RG_EINVAL, "unknown time_mode %u", c->time_mode);
+    if (c->time_mode == 1 && !(c->time_sigma >= 0.0)) return fail(RG_EINVAL, "normal_time_sigma must be >= 0");
     for (int s = 0; s < 2; ++s)
         if (!(c->trans_cdf[s][0] >= 0.0 && c->trans_cdf[s][0] <= c->trans_cdf[s][1] &&
               c->trans_cdf[s][1] <= 1.0))
@@ -476,6 +486,7 @@ __global__ void __launch_bounds__(kBlock) k_reset_users(DevSim d) {
         d.uid[i] = i;
         d.n_events[i] = 0;
         d.has_phantom[i] = 0;
+        if (d.time_mode) d.utime[i] = 0.0;
         if (d.hist_cap) d.hist[static_cast<size_t>(i) * d.hist_cap] = 0ull;
         if (d.use_cache) { d.f64_valid[i] = 0; d.cache_resc[i] = 0; }
     }
@@ -884,6 +895,7 @@ __device__ __forceinline__ void write_organic_row(const DevSim& d, uint32_t t, u
         rg_event e;
         e.u = user; e.t = t; e.code = v; e.ps = __builtin_nanf("");
         d.log[row] = e;
+        if (d.aux_time) d.aux_time[row] = d.utime[d.uid[slot]];     // the draw kernels run before k_advance moves the clock
     }
     if (d.lpv) d.lpv[slot] = v;   // BanditMFSquare.update_lpv, bandit_mf.py:60-65
 }
@@ -3076,18 +3088,30 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                     d.log[row] = e;
                     if (d.aux_ps) d.aux_ps[row] = ps;
                     if (d.aux_pclick) d.aux_pclick[row] = ctr;
+                    if (d.aux_time) d.aux_time[row] = d.utime[uidx];
                 }
             }
             // update_state (reco_env_v1.py:85-100)
             const double c0 = is_org ? d.cdf_o0 : d.cdf_b0, c1 = is_org ? d.cdf_o1 : d.cdf_b1;
             ns = (c0 <= u_trans) + (c1 <= u_trans);
+            // NormalTimeGenerator: the clock advances by |mu + sigma z| (normal_time_generator.py:25) and the drift's
+            // standard deviation is scaled by that time delta (1 when it is exactly 0; reco_env_v1.py:91-92)
+            double omega_k = 1.0;
+            if (d.time_mode) {
+                double z0, z1;
+                normal_pair(d.seed, user, t, 0, RG_DRAW_TIME, &z0, &z1);
+                const double dt = fabs(d.time_mu + d.time_sigma * z0);
+                d.utime[uidx] = d.utime[uidx] + dt;
+                omega_k = dt == 0.0 ? 1.0 : dt;
+            }
+            const double sig = d.sigma_omega * omega_k;
             if (d.sigma_omega != 0.0 && (d.change_omega_for_bandits || ns == RG_STATE_ORGANIC)) {
                 for (uint32_t j = 0; 2 * j < d.K; ++j) {
                     double z0, z1;
                     normal_pair(d.seed, user, t, j, RG_DRAW_DRIFT, &z0, &z1);
                     double* o0 = d.omega + static_cast<size_t>(slot) * d.OMS + 2 * j;
-                    *o0 = *o0 + d.sigma_omega * z0;
-                    if (2 * j + 1 < d.K) { double* o1 = o0 + 1; *o1 = *o1 + d.sigma_omega * z1; }
+                    *o0 = *o0 + sig * z0;
+                    if (2 * j + 1 < d.K) { double* o1 = o0 + 1; *o1 = *o1 + sig * z1; }
                 }
             }
             if (click) ns = RG_STATE_ORGANIC;          // abstract.py:180-181
@@ -3106,6 +3130,7 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                     e.ps = static_cast<float>(ps);
                     d.phantom[uidx] = e;
                     d.phantom_ps[uidx] = ps;
+                    if (d.time_mode) d.phantom_time[uidx] = d.utime[uidx];       // (already advanced past the last event)
                     d.has_phantom[uidx] = 1;
                     phantoms += 1;
                 }
@@ -4018,6 +4043,27 @@ __global__ void __launch_bounds__(kBlock) k_scatter_aux_phantom(DevSim d, const 
     }
 }
 
+__global__ void __launch_bounds__(kBlock) k_scatter_time(DevSim d, uint64_t n_rows, const int64_t* off, double* out, uint64_t out_cap) {
+    for (uint64_t r = blockIdx.x * static_cast<uint64_t>(kBlock) + threadIdx.x; r < n_rows;
+         r += static_cast<uint64_t>(gridDim.x) * kBlock) {
+        const rg_event e = d.log[r];
+        if (e.code == kHoleCode) continue;
+        const uint64_t dst = static_cast<uint64_t>(off[e.u - d.first_user]) + e.t;
+        if (dst < out_cap) out[dst] = d.aux_time ? d.aux_time[r] : static_cast<double>(e.t);
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_scatter_time_phantom(DevSim d, const int64_t* off, double* out, uint64_t out_cap) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) {
+        if (!d.has_phantom[i]) continue;
+        const uint64_t dst = static_cast<uint64_t>(off[i]) + d.n_events[i];
+        if (dst < out_cap) out[dst] = d.time_mode ? d.phantom_time[i] : static_cast<double>(d.n_events[i]);
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_export_time(DevSim d, uint32_t t, double* out) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock)
+        out[i] = d.time_mode ? d.utime[i] : static_cast<double>(d.n_events[i] ? d.n_events[i] : t);
+}
+
 inline int grid_for(uint64_t n, int per_block = kBlock) {
     uint64_t g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -4333,6 +4379,7 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     d.ouc_exploit_explore = cfg->ouc_exploit_explore;
     d.ouc_reverse_pop = cfg->ouc_reverse_pop;
     d.ouc_epsilon = cfg->ouc_epsilon;
+    d.time_mode = cfg->time_mode; d.time_mu = cfg->time_mu; d.time_sigma = cfg->time_sigma;
     d.n_users = d.n_cap = static_cast<uint32_t>(n_users);
     s->h_pinned = nullptr;
     s->profiling = false; s->prof_used = 0; s->prof_launches = 0;
@@ -4392,6 +4439,7 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     s->walk = d.use_cache && (d.policy == RG_POLICY_UNIFORM_ENV || d.policy == RG_POLICY_RANDOM_AGENT ||
                               d.policy == RG_POLICY_ORGANIC_USER_COUNT || d.policy == RG_POLICY_LAST_VIEW_TABLE);
     if (const char* e = getenv("RECOGYM_WALK")) if (e[0] == '0') s->walk = false;
+    if (d.time_mode) { s->walk = false; s->tail_below = 0; }      // per-user clocks: the lock-step kernels only
     s->n_cus = 0;
     s->walk_occ = 3;
     if (const char* e = getenv("RECOGYM_WALK_OCC")) { const int o = atoi(e); if (o >= 2 && o <= 4) s->walk_occ = o; }
@@ -4475,7 +4523,7 @@ int rg_sim_set_log(rg_sim* sim, rg_event* d_log, uint64_t capacity) {
     if (!sim) return fail(RG_EINVAL, "sim is NULL");
     sim->d.log = capacity ? d_log : nullptr;
     sim->d.log_cap = d_log ? capacity : 0;
-    sim->d.aux_ps = nullptr; sim->d.aux_pclick = nullptr;     // side arrays are sized with the log: re-attach
+    sim->d.aux_ps = nullptr; sim->d.aux_pclick = nullptr; sim->d.aux_time = nullptr;     // side arrays are sized with the log: re-attach
     return RG_OK;
 }
 
@@ -4635,6 +4683,36 @@ int rg_sim_export_omega(rg_sim* sim, double* d_omega, void* stream) {
     } else
         hipLaunchKernelGGL(k_export_omega, dim3(grid_for(static_cast<uint64_t>(sim->d.n_users) * sim->d.K)),
                            dim3(kBlock), 0, st, sim->d, d_omega);
+    HIP_TRY(hipGetLastError());
+    return RG_OK;
+}
+
+int rg_sim_set_log_time(rg_sim* sim, double* d_time) {
+    if (!sim) return fail(RG_EINVAL, "sim is NULL");
+    if (d_time && !sim->d.log) return fail(RG_ESTATE, "attach a log buffer first (rg_sim_set_log)");
+    sim->d.aux_time = d_time;
+    return RG_OK;
+}
+
+int rg_sim_sort_log_time(rg_sim* sim, const int64_t* d_row_offsets, double* d_sorted_time, uint64_t sorted_capacity, void* stream) {
+    if (!sim || !d_row_offsets || !d_sorted_time) return fail(RG_EINVAL, "NULL argument");
+    if (!sim->d.log) return fail(RG_ESTATE, "no log buffer is attached");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const DevSim& d = sim->d;
+    uint64_t n_rows = 0;
+    HIP_TRY(hipMemcpyAsync(&n_rows, d.log_base + sim->t, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (n_rows > d.log_cap) return fail(RG_ELIMIT, "log overflow: %llu rows emitted, capacity %llu",
+                                        (unsigned long long)n_rows, (unsigned long long)d.log_cap);
+    hipLaunchKernelGGL(k_scatter_time, dim3(grid_for(n_rows)), dim3(kBlock), 0, st, d, n_rows, d_row_offsets, d_sorted_time, sorted_capacity);
+    hipLaunchKernelGGL(k_scatter_time_phantom, dim3(grid_for(d.n_users)), dim3(kBlock), 0, st, d, d_row_offsets, d_sorted_time, sorted_capacity);
+    HIP_TRY(hipGetLastError());
+    return RG_OK;
+}
+
+int rg_sim_export_time(rg_sim* sim, double* d_time, void* stream) {
+    if (!sim || !d_time) return fail(RG_EINVAL, "NULL argument");
+    hipLaunchKernelGGL(k_export_time, dim3(grid_for(sim->d.n_users)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), sim->d, sim->t, d_time);
     HIP_TRY(hipGetLastError());
     return RG_OK;
 }

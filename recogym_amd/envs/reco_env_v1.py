@@ -27,7 +27,8 @@ from .. import _abi, rng
 from ..sim import Simulator, decode_rows
 from .configuration import Configuration
 from .context import DefaultContext
-from .features.time import DefaultTimeGenerator
+from .features.time import DefaultTimeGenerator, NormalTimeGenerator
+from .static_params import time_generator_params
 from .observation import Observation
 from .session import OrganicSessions
 from .static_params import draw_tables
@@ -229,18 +230,17 @@ class RecoEnv1:
         self._tables = None
         self._seq = None          # 1-user simulator behind reset()/step()
         self._device = None
+        self._time_mode = 0       # 1: NormalTimeGenerator (the device keeps the clocks)
+        self._event_index = 0
 
     # -- construction -------------------------------------------------------------------------
     def init_gym(self, args):
         self.config = Configuration(args)
         self.action_space = Discrete(self.config.num_products)
-        if 'time_generator' in args and not isinstance(args['time_generator'],
-                                                       DefaultTimeGenerator) \
-                and type(args['time_generator']).__name__ != 'DefaultTimeGenerator':
-            raise NotImplementedError(
-                'only DefaultTimeGenerator (t = event index) is supported by the device step '
-                'loop; NormalTimeGenerator is listed as next in SURVEY.md §8f')
-        self.time_generator = DefaultTimeGenerator(self.config)
+        # abstract.py:72-76: the default generator unless one is passed in.  A NormalTimeGenerator (this package's or the
+        # reference's own object) only contributes mu / sigma: the device keeps the per-user clocks
+        self._time_mode = time_generator_params(self.config)[0]
+        self.time_generator = args['time_generator'] if 'time_generator' in args else DefaultTimeGenerator(self.config)
         self.agent = args['agent'] if 'agent' in args else None
         self.reset_random_seed()
         self._tables = draw_tables(self.config)      # set_static_params, bit-identical draws
@@ -280,7 +280,9 @@ class RecoEnv1:
         other = RecoEnv1()
         other.config = self.config
         other.action_space = getattr(self, 'action_space', None)
-        other.time_generator = DefaultTimeGenerator(self.config) if self.config else None
+        other.time_generator = (DefaultTimeGenerator(self.config) if not getattr(self, '_time_mode', 0)
+                                else self.time_generator) if self.config else None
+        other._time_mode = getattr(self, '_time_mode', 0)
         other.agent = deepcopy(self.agent, memo)
         other._epoch = self._epoch
         other._tables = self._tables               # read-only
@@ -345,7 +347,8 @@ class RecoEnv1:
         self.time_generator.reset()
         if self.agent:
             self.agent.reset()
-        self.current_time = self.time_generator.new_time()
+        self.current_time = 0 if self._time_mode else self.time_generator.new_time()
+        self._event_index = 0
         self.current_user_id = user_id
         sim = self._seq_sim()
         sim.reseed(self.seed, self.seed)
@@ -362,15 +365,19 @@ class RecoEnv1:
         self._rows_read += 1
         row = decode_rows(raw)[0]
         self.state = int(sim.states()[0].item())
-        self.current_time = self.time_generator.new_time()
+        self._event_index += 1
+        self.current_time = float(sim.user_times()[0].item()) if self._time_mode else self.time_generator.new_time()
         return row
+
+    def _context(self, t, u, n):
+        return DefaultContext(t, u, n if self._time_mode else None)
 
     def generate_organic_sessions(self):
         session = OrganicSessions()
         while self.state == organic:
-            t, u = self.current_time, self.current_user_id
+            t, u, n = self.current_time, self.current_user_id, self._event_index
             row = self._advance()
-            session.next(DefaultContext(t, u), int(row['v']))
+            session.next(self._context(t, u, n), int(row['v']))
         return session
 
     def step(self, action_id):
@@ -379,7 +386,7 @@ class RecoEnv1:
             assert (action_id is None)
             self.first_step = False
             sessions = self.generate_organic_sessions()
-            return (Observation(DefaultContext(self.current_time, self.current_user_id), sessions),
+            return (Observation(self._context(self.current_time, self.current_user_id, self._event_index), sessions),
                     None, self.state == stop, info)
         assert (action_id is not None)
         if not 0 <= int(action_id) < self.config.num_products:
@@ -389,7 +396,7 @@ class RecoEnv1:
         reward = int(row['c'])
         sessions = self.generate_organic_sessions() if self.state == organic \
             else self.empty_sessions
-        return (Observation(DefaultContext(self.current_time, self.current_user_id), sessions),
+        return (Observation(self._context(self.current_time, self.current_user_id, self._event_index), sessions),
                 reward, self.state == stop, info)
 
     def step_offline(self, observation, reward, done):
@@ -403,7 +410,7 @@ class RecoEnv1:
             else:
                 P = self.config.num_products
                 ctx = observation.context()
-                w = rng.draw(self.seed, ctx.user(), ctx.time(), 0, rng.DRAW_POLICY)
+                w = rng.draw(self.seed, *ctx.draw_key(), 0, rng.DRAW_POLICY)
                 action = {
                     't': ctx.time(), 'u': ctx.user(), 'a': rng.bounded(w[0], w[1], P),
                     'ps': 1.0 / P,
@@ -411,7 +418,7 @@ class RecoEnv1:
                 }
         if done:
             return (action,
-                    Observation(DefaultContext(self.current_time, self.current_user_id),
+                    Observation(self._context(self.current_time, self.current_user_id, self._event_index),
                                 self.empty_sessions),
                     0, done, None)
         observation, reward, done, info = self.step(action['a'] if action is not None else None)

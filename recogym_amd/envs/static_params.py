@@ -101,4 +101,18 @@ def make_rg_config(config, seed, policy=_abi.RG_POLICY_UNIFORM_ENV, policy_seed=
     cfg.ouc_reverse_pop = int(bool(ouc.get('reverse_pop', False)))
     cfg.ouc_history_cap = int(ouc.get('history_cap', 0))
     cfg.ouc_epsilon = float(ouc.get('epsilon', 0.0))
+    mode, mu, sigma = time_generator_params(config)
+    cfg.time_mode, cfg.time_mu, cfg.time_sigma = mode, mu, sigma
     return cfg
+
+
+def time_generator_params(config):
+    """-> (time_mode, mu, sigma) of `config.time_generator` (abstract.py:72-76): 0 for the default generator (or none),
+    1 for a NormalTimeGenerator — this package's or the reference's own class, recognised by name."""
+    tg = getattr(config, 'time_generator', None)
+    if tg is None or type(tg).__name__ == 'DefaultTimeGenerator':
+        return 0, 0.0, 1.0
+    if type(tg).__name__ == 'NormalTimeGenerator':
+        return (1, float(getattr(tg, 'normal_time_mu', getattr(config, 'normal_time_mu', 0))),
+                float(getattr(tg, 'normal_time_sigma', getattr(config, 'normal_time_sigma', 1))))
+    raise NotImplementedError(f'time generator {type(tg).__name__} is not supported by the device step loop')

@@ -86,6 +86,7 @@ class Simulator:
         self.rg_config = make_rg_config(config, config.random_seed + epoch, policy, policy_seed,
                                         ouc)
         self.policy = policy
+        self.time_mode = int(self.rg_config.time_mode)
         self.ps_float64 = (policy in (_abi.RG_POLICY_ORGANIC_USER_COUNT, _abi.RG_POLICY_LAST_VIEW_TABLE)
                            if ps_float64 is None else bool(ps_float64))
         self.keep_p_click = bool(p_click)
@@ -138,6 +139,11 @@ class Simulator:
                         if rows else None)
         _abi.check(self.lib.rg_sim_set_log(self._h, self.log.data_ptr() if rows else None,
                                            self.log_capacity), 'rg_sim_set_log')
+        self.aux_time = None
+        if rows and self.time_mode:
+            with torch.cuda.device(self.device):
+                self.aux_time = torch.empty(self.log_capacity, dtype=torch.float64, device=self.device)
+            _abi.check(self.lib.rg_sim_set_log_time(self._h, self.aux_time.data_ptr()), 'rg_sim_set_log_time')
         self.aux_ps = self.aux_p_click = None
         if rows and (self.ps_float64 or self.keep_p_click):
             with torch.cuda.device(self.device):
@@ -245,6 +251,21 @@ class Simulator:
                        'rg_sim_sort_log')
         return out, offsets
 
+    def sorted_time(self, offsets, total):
+        """The time column in the order of sorted_log() (float64): the clock of a NormalTimeGenerator, else the event index."""
+        with torch.cuda.device(self.device):
+            out = torch.empty(total, dtype=torch.float64, device=self.device)
+            _abi.check(self.lib.rg_sim_sort_log_time(self._h, offsets.data_ptr(), out.data_ptr(), total, self._stream()),
+                       'rg_sim_sort_log_time')
+        return out
+
+    def user_times(self):
+        """Current clock of every user of the reset range (float64 device tensor)."""
+        with torch.cuda.device(self.device):
+            out = torch.empty(self.n_active, dtype=torch.float64, device=self.device)
+            _abi.check(self.lib.rg_sim_export_time(self._h, out.data_ptr(), self._stream()), 'rg_sim_export_time')
+        return out
+
     def sorted_aux(self, offsets, total):
         """The float64 side arrays (ps, p_click) in the order of sorted_log(); None where not kept."""
         with torch.cuda.device(self.device):
@@ -286,7 +307,7 @@ class Simulator:
             else:
                 ps_b = out[:, 3].contiguous().view(torch.float32).to(torch.float64)
             cols = dict(
-                t=out[:, 1].to(torch.float32),
+                t=(self.sorted_time(offsets, out.shape[0]) if self.time_mode else out[:, 1]).to(torch.float32),
                 u=out[:, 0].contiguous(),
                 is_bandit=is_b,
                 v=torch.where(is_b, zero, idx),
@@ -319,5 +340,9 @@ class Simulator:
         uniform = None
         if self.policy in (_abi.RG_POLICY_UNIFORM_ENV, _abi.RG_POLICY_RANDOM_AGENT):
             uniform = 1.0 / float(self.config.num_products)
-        return decode_rows(out.cpu().numpy(), uniform, None if ps64 is None else ps64.cpu().numpy(),
+        rows = decode_rows(out.cpu().numpy(), uniform, None if ps64 is None else ps64.cpu().numpy(),
                            None if pc is None else pc.cpu().numpy())
+        if self.time_mode:         # 't' stays the event index; 'time' = the generator's clock
+            import numpy.lib.recfunctions as rfn
+            rows = rfn.append_fields(rows, 'time', self.sorted_time(offsets, out.shape[0]).cpu().numpy(), usemask=False)
+        return rows

@@ -49,7 +49,12 @@ def policy_args(meta, cols=None):
 
 
 def env_config(meta):
-    return Configuration(meta['env_args'])
+    args = dict(meta['env_args'])
+    if meta.get('normal_time'):       # fixtures of the reference's NormalTimeGenerator: rebuild this package's descriptor
+        from recogym_amd.envs.features.time import NormalTimeGenerator
+        nt = meta['normal_time']
+        args['time_generator'] = NormalTimeGenerator(Configuration({'normal_time_mu': nt['mu'], 'normal_time_sigma': nt['sigma']}))
+    return Configuration(args)
 
 
 def assert_rows_equal(rows, cols, ps_rtol=1e-12, what=''):
@@ -63,6 +68,8 @@ def assert_rows_equal(rows, cols, ps_rtol=1e-12, what=''):
                                f'{bad[0]}: got {got[bad[0]]} want {want[bad[0]]}')
     np.testing.assert_allclose(rows['ps'], cols['ps'], rtol=ps_rtol, atol=0, equal_nan=True,
                                err_msg=f'{what}: ps')
+    if 'time' in cols and 'time' in rows.dtype.names:       # the generator's clock (float32 in the reference's DataFrame)
+        np.testing.assert_allclose(rows['time'], cols['time'], rtol=2e-7, atol=0, err_msg=f'{what}: time')
     if 'p_click' in cols and 'p_click' in rows.dtype.names:
         np.testing.assert_allclose(rows['p_click'], cols['p_click'], rtol=1e-12, atol=0,
                                    equal_nan=True, err_msg=f'{what}: p_click')

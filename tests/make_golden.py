@@ -56,7 +56,7 @@ def save(name, arrays, meta):
     for k, v in arrays.items():
         if k in ('z', 'c'):
             small[k] = v.astype(np.int8)
-        elif k in ('ps', 'p_click') or k.startswith('bmf_'):
+        elif k in ('ps', 'p_click', 'time') or k.startswith('bmf_'):
             small[k] = v
         else:
             small[k] = v.astype(np.int32)
@@ -66,8 +66,14 @@ def save(name, arrays, meta):
 
 
 def run_case(name, env_over, n_users, n_organic=0, agent_kind=None, agent_args=None,
-             injected=False):
+             injected=False, normal_time=None):
     args = {**BASE, **env_over}
+    if normal_time is not None:       # {'mu':, 'sigma':}: the reference's NormalTimeGenerator, passed the way init_gym takes it
+        rh.import_reference()
+        from recogym import Configuration
+        from recogym.envs.features.time import NormalTimeGenerator
+        args = {**args, 'time_generator': NormalTimeGenerator(Configuration(
+            {'random_seed': args['random_seed'], 'normal_time_mu': normal_time['mu'], 'normal_time_sigma': normal_time['sigma']}))}
     env = rh.make_reference_env(args)
     agent = None
     agent_args = dict(agent_args or {})
@@ -78,7 +84,14 @@ def run_case(name, env_over, n_users, n_organic=0, agent_kind=None, agent_args=N
     if injected:
         rng = rh.inject_counter_rng(env, None if agent_kind == 'bmf' else agent, agent_args.get('random_seed'))
     df = env.generate_logs(n_users, agent, n_organic)
+    times = None
+    if normal_time is not None:       # 't' holds the generator's clock: keep it as `time`, and the event index as t
+        times = df['t'].to_numpy(dtype=np.float64)
+        df = df.copy()
+        df['t'] = df.groupby(df['u'].astype('int64')).cumcount().astype(np.float32)
     arrays = rh.log_to_arrays(df)
+    if times is not None:
+        arrays['time'] = times
     if injected:
         # p_click of every REAL bandit row, in row order (phantom rows are never drawn)
         pc = np.full(len(df), np.nan)
@@ -89,12 +102,23 @@ def run_case(name, env_over, n_users, n_organic=0, agent_kind=None, agent_args=N
         assert real.sum() == len(rng.p_click_log), (real.sum(), len(rng.p_click_log))
         pc[real] = rng.p_click_log
         arrays['p_click'] = pc
-    meta = dict(env_args=args, n_users=n_users, n_organic=n_organic, agent=agent_kind,
-                agent_args=agent_args, rng='philox' if injected else 'mt')
+    meta = dict(env_args={k: v for k, v in args.items() if k != 'time_generator'}, n_users=n_users, n_organic=n_organic,
+                agent=agent_kind, agent_args=agent_args, rng='philox' if injected else 'mt')
+    if normal_time is not None:
+        meta['normal_time'] = normal_time
     if agent_kind == 'bmf':      # the (untrained) embeddings the frozen device policy is built from
         arrays['bmf_product_embedding'] = agent.product_embedding.weight.detach().numpy().astype(np.float64)
         arrays['bmf_user_embedding'] = agent.user_embedding.weight.detach().numpy().astype(np.float64)
     save(name, arrays, meta)
+
+
+def normal_time_goldens():
+    """The reference with its NormalTimeGenerator (float clock, drift scaled by the time delta, reco_env_v1.py:89-98)."""
+    S = dict(random_seed=42)
+    run_case('philox_normal_time', {**S, 'num_products': 30, 'K': 6, 'sigma_omega': 0.2}, 150, n_organic=5, injected=True,
+             normal_time=dict(mu=0.3, sigma=1.2))
+    run_case('philox_normal_time_ouc', {**S, 'num_products': 40, 'K': 8, 'sigma_omega': 0.1, 'change_omega_for_bandits': True}, 120,
+             agent_kind='ouc', agent_args=dict(random_seed=9), injected=True, normal_time=dict(mu=0.0, sigma=1.0))
 
 
 def notebook_goldens():
@@ -298,6 +322,10 @@ def main():
         # BASELINE config 3's table shape with its agent in the loop
         run_case('philox_ouc_p10000', {**S, 'num_products': 10000, 'K': 20, 'sigma_omega': 0.0}, 40,
                  agent_kind='ouc', agent_args=dict(random_seed=11), injected=True)
+        normal_time_goldens()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'normal_time':
+        normal_time_goldens()
         return
     notebook_goldens()
     S = dict(random_seed=42)
@@ -344,6 +372,7 @@ def main():
              injected=True)
     run_case('philox_ouc_p10000', {**S, 'num_products': 10000, 'K': 20, 'sigma_omega': 0.0}, 40,
              agent_kind='ouc', agent_args=dict(random_seed=11), injected=True)
+    normal_time_goldens()
     for fx in ('philox_ouc', 'mt_random_agent'):
         train_feed_golden(fx)
     run_logreg_case('philox_logreg', {**S, 'num_products': 30, 'K': 8}, 1500, 200)

@@ -39,7 +39,7 @@ def import_reference():
 # numpy restatement of include/recogym_rng.h (python ints: exact)
 # ------------------------------------------------------------------------------------------
 M32 = 0xFFFFFFFF
-DRAW_EVENT, DRAW_POLICY, DRAW_DRIFT, DRAW_RESET = 0, 1, 2, 3
+DRAW_EVENT, DRAW_POLICY, DRAW_DRIFT, DRAW_RESET, DRAW_TIME = 0, 1, 2, 3, 4
 
 
 def philox4x32_10(c, k):
@@ -148,6 +148,22 @@ class InjectedEnvRng:
         return numpy_choice_with_p(a, p, uniform(w[0], w[1]))
 
 
+class InjectedTimeRng:
+    """Duck-typed `env.time_generator.rng` of the reference's NormalTimeGenerator (normal_time_generator.py:21,25):
+    its k-th `normal(mu, sigma)` call after a reset serves the RG_DRAW_TIME draw of (user, k) — call 0 is made by
+    reset() (the increment that follows event 0), call k + 1 by the update_state of event k."""
+
+    def __init__(self, env_rng):
+        self.env_rng = env_rng
+        self.calls = 0
+
+    def normal(self, loc=0.0, scale=1.0, size=None):
+        assert size is None
+        z = normals(self.env_rng.seed, self.env_rng.user, self.calls, DRAW_TIME, 1)[0]
+        self.calls += 1
+        return loc + scale * z
+
+
 class InjectedAgentRng:
     """Duck-typed `agent.rng` / `agent.model.rng` serving RG_DRAW_POLICY draws.
 
@@ -185,9 +201,15 @@ def inject_counter_rng(env, agent=None, agent_seed=None):
                          policy_seed=env.config.random_seed)
     env.rng = rng
     original_reset = env.reset
+    trng = None
+    if type(env.time_generator).__name__ == 'NormalTimeGenerator':
+        trng = InjectedTimeRng(rng)
+        env.time_generator.rng = trng
 
     def reset(user_id=0):
         rng.start_user(user_id)
+        if trng is not None:
+            trng.calls = 0
         original_reset(user_id)
     env.reset = reset
     if agent is not None:

@@ -33,8 +33,8 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_config_struct_layout_matches_header(lib):
-    # sizeof(rg_config): 2*4 + 2*8 + 6*8 + 2*8 + 2*4 + 4*4 + 8
-    assert C.sizeof(_abi.RgConfig) == 120
+    # sizeof(rg_config): 2*4 + 2*8 + 6*8 + 2*8 + 2*4 + 4*4 + 8 + (2*4 + 2*8: time generator)
+    assert C.sizeof(_abi.RgConfig) == 144
     assert C.sizeof(_abi.RgEvent) == 16
 
 

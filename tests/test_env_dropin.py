@@ -373,3 +373,34 @@ def test_with_ps_all_for_the_organic_count_agent_on_the_device_path():
     env.step(None)
     with pytest.raises(IndexError):
         env.step(30)
+
+
+@pytest.mark.parametrize('name', ['philox_normal_time', 'philox_normal_time_ouc'])
+def test_normal_time_generator_matches_the_reference(name):
+    """NormalTimeGenerator (normal_time_generator.py:7-31): `t` is a float clock that advances by |N(mu, sigma)| per event
+    and the omega drift after an event is scaled by that time delta (reco_env_v1.py:89-98).  The batched device path and
+    the reset / step_offline path both reproduce the reference's own log — indices exactly, the clock at float32 resolution
+    (the dtype of the reference's `t` column)."""
+    from recogym_amd.envs.features.time import NormalTimeGenerator
+    meta, want = gu.load(name)
+    nt = meta['normal_time']
+
+    def env():
+        tg = NormalTimeGenerator(Configuration({'normal_time_mu': nt['mu'], 'normal_time_sigma': nt['sigma']}))
+        return make_env({**meta['env_args'], 'time_generator': tg})
+
+    df = env().generate_logs(meta['n_users'], make_agent(meta), meta['n_organic'])
+    assert str(df['t'].dtype) == 'float32'
+    np.testing.assert_allclose(df['t'].to_numpy(dtype=np.float64), want['time'], rtol=2e-7, atol=0)
+    cols = frame_to_cols(df)
+    for k in ('u', 'z', 'v', 'a', 'c'):
+        assert np.array_equal(cols[k], want[k].astype(np.int64)), k
+    np.testing.assert_allclose(cols['ps'], want['ps'], rtol=1e-12, equal_nan=True)
+    # the per-user gym path (one transition per call, clock read back from the device)
+    n = 12
+    df_seq = env()._generate_logs_per_user(n, make_agent(meta), meta['n_organic'])
+    keep = want['u'] < n + meta['n_organic']
+    np.testing.assert_allclose(df_seq['t'].to_numpy(dtype=np.float64), want['time'][keep], rtol=2e-7, atol=0)
+    cs = frame_to_cols(df_seq)
+    for k in ('u', 'z', 'v', 'a', 'c'):
+        assert np.array_equal(cs[k], want[k][keep].astype(np.int64)), k
