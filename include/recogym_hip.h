@@ -168,6 +168,14 @@ int rg_sim_set_policy_table(rg_sim* sim, const int32_t* d_action, const float* d
 int rg_sim_set_logreg(rg_sim* sim, const double* d_coef_t, const double* d_intercept,
                       const int32_t* d_classes, uint32_t n_classes);
 
+/* Optional fast path of RG_POLICY_LOGREG_FROZEN (after rg_sim_set_logreg): fp32 copies of coef^T [num_products][n_classes]
+ * and intercept [n_classes] (each value rounded to nearest), d_wmax[p] >= max_c |coef_t[p][c]| and bmax >= max_c |intercept[c]|.
+ * The policy's act is computed when a user's view history has changed (not once per event); with these arrays the class
+ * scores are first taken in fp32 and accepted when the best one leads by more than twice the rounding bound
+ * (views + 3) 2^-24 (bmax + sum_p views_p wmax[p]); everything else goes through the float64 walk of rg_sim_set_logreg's
+ * arrays, so the logged action is sklearn's predict() bit for bit either way.  All NULL / 0 = float64 only. */
+int rg_sim_set_logreg_fp32(rg_sim* sim, const float* d_coef32_t, const float* d_intercept32, const float* d_wmax, float bmax);
+
 /* Where rows go.  d_log == NULL (or capacity 0) disables logging: only counters are kept. */
 int rg_sim_set_log(rg_sim* sim, rg_event* d_log, uint64_t capacity);
 

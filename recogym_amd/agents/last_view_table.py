@@ -26,9 +26,17 @@ class LastViewTableAgent(Agent):
         # float32 like the reference's torch forward (bandit_mf.py:44-52)
         Ep = np.asarray(product_embedding, dtype=np.float32)
         Eu = np.asarray(user_embedding, dtype=np.float32)
-        logits = (Eu[:, None, :] * Ep[None, :, :]).sum(axis=2)      # [last viewed product][action]
-        table = logits.argmax(axis=1)
-        return cls(config, table, logits[np.arange(len(table)), table])
+        # [last viewed product][action] logits, a block of rows at a time: the full P x P x E broadcast is 2 GB at
+        # P = 10^4 (BASELINE config 5) and impossible at 10^5.  Every row keeps numpy's own float32 summation over E.
+        P, E = Ep.shape
+        table = np.empty(P, dtype=np.int64)
+        win = np.empty(P, dtype=np.float32)
+        rows = max(1, min(P, (64 << 20) // max(1, P * E * 4)))
+        for lo in range(0, P, rows):
+            logits = (Eu[lo:lo + rows, None, :] * Ep[None, :, :]).sum(axis=2)
+            table[lo:lo + rows] = logits.argmax(axis=1)
+            win[lo:lo + rows] = logits[np.arange(logits.shape[0]), table[lo:lo + rows]]
+        return cls(config, table, win)
 
     def device_policy(self):
         if getattr(self.config, 'with_ps_all', False):

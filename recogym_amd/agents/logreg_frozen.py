@@ -11,15 +11,19 @@ CSR x dense product (viewed products ascending, multiply then add, intercept las
 is sklearn's predict() bit for bit — on the device, in the oracle and in `act` below."""
 import numpy as np
 
-from .. import _abi
+from .. import _abi, rng
 from .abstract import Agent
 
 
 class LogregFrozenAgent(Agent):
     def __init__(self, config, coef, intercept, classes):
         """coef (n_classes, P) / intercept (n_classes,) / classes (n_classes,) as sklearn stores them;
-        a two-class model (coef of one row) is expanded to two rows (zero first row)."""
+        a two-class model (coef of one row) is expanded to two rows (zero first row).
+        config.select_randomly = True (logreg_ips.py:61-66): the action is sampled from predict_proba — softmax of the
+        same scores, one addressed policy draw — on the per-user path (no device form; needs every product as a class,
+        like the reference's rng.choice(num_products, p=proba))."""
         super().__init__(config)
+        self.select_randomly = bool(getattr(config, 'select_randomly', False))
         coef = np.atleast_2d(np.asarray(coef, dtype=np.float64))
         intercept = np.atleast_1d(np.asarray(intercept, dtype=np.float64))
         classes = np.asarray(classes, dtype=np.int32)
@@ -37,7 +41,7 @@ class LogregFrozenAgent(Agent):
         return cls(config, logreg.coef_, logreg.intercept_, logreg.classes_)
 
     def device_policy(self):
-        if getattr(self.config, 'with_ps_all', False):
+        if getattr(self.config, 'with_ps_all', False) or self.select_randomly:
             return None
         return dict(policy=_abi.RG_POLICY_LOGREG_FROZEN, policy_seed=0, ouc=None,
                     logreg=dict(coef_t=self.coef_t, intercept=self.intercept, classes=self.classes))
@@ -52,5 +56,18 @@ class LogregFrozenAgent(Agent):
         for p in np.flatnonzero(self.views):                 # ascending, multiply then add
             score = score + np.float64(self.views[p]) * self.coef_t[p]
         score = score + self.intercept
+        if self.select_randomly:
+            # sklearn's multinomial predict_proba: softmax(decision_function) (sklearn.utils.extmath.softmax)
+            e = np.exp(score - score.max())
+            proba = e / e.sum()
+            assert len(proba) == self.config.num_products, 'select_randomly needs every product as a class'
+            ctx = observation.context()
+            key = ctx.draw_key() if hasattr(ctx, 'draw_key') else (ctx.user(), ctx.time())
+            _, _, u1 = rng.policy_uniforms(self.config.random_seed, *key)
+            cdf = proba.cumsum()
+            cdf /= cdf[-1]
+            a = int(cdf.searchsorted(u1, side='right'))
+            return {**super().act(observation, reward, done), 'a': a, 'ps': float(proba[a]),
+                    'ps-a': proba if getattr(self.config, 'with_ps_all', False) else ()}
         return {**super().act(observation, reward, done), 'a': int(self.classes[int(np.argmax(score))]),
                 'ps': 1.0, 'ps-a': ()}

@@ -39,8 +39,6 @@ class LogregMulticlassIpsAgent(Agent):
 
     def __init__(self, config=Configuration(logreg_multiclass_ips_args)):
         super().__init__(config)
-        if getattr(config, 'select_randomly', False):
-            raise NotImplementedError('select_randomly=True (sampling from predict_proba) is not supported')
         self._rows = {k: [] for k in ('u', 'is_bandit', 'v', 'a', 'c', 'ps')}
         self._log = None
         self.logreg = None

@@ -171,6 +171,13 @@ struct DevSim {
     double* omega_alt; unsigned long long* hist_alt; uint32_t* lpv_alt; uint32_t* uid_alt;
     const int32_t* pol_table; const float* pol_ps;   // caller-owned per-product tables of that policy
     const double* lr_coef_t; const double* lr_intercept; const int32_t* lr_classes; uint32_t lr_n;   // RG_POLICY_LOGREG_FROZEN
+    // the policy's act depends on the view history only: it is computed when the history has changed since the last act
+    // (lr_dirty, set by history_add) and kept per user; k_logreg_select / k_logreg_acts run before k_advance
+    const float* lr_coef32_t; const float* lr_intercept32; const float* lr_wmax; float lr_bmax;   // fp32 copies + max_c |coef[p][c]|, max |b|
+    uint32_t* lr_action;      // [n_cap] by user index: action of the user's current history
+    uint8_t* lr_dirty;        // [n_cap] by user index
+    uint32_t* lr_list;        // [n_cap] slots whose act is to be computed this step
+    uint32_t* lr_cnt;         // [kMaxSteps + 2]
     unsigned long long* counters;   // [RG_CNT_N]
     // log
     rg_event* log; uint64_t log_cap;
@@ -372,6 +379,11 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     float* cache_row = w.take<float>(cache ? (n + 1) * static_cast<size_t>(cache_row_f) : 1);
     uint8_t* f64_valid = w.take<uint8_t>(cache ? n : 1);
     uint32_t* exact_cnt_b = w.take<uint32_t>(kMaxSteps + 2);
+    const bool lr = c.policy == RG_POLICY_LOGREG_FROZEN;
+    uint32_t* lr_action = w.take<uint32_t>(lr ? n : 1);
+    uint8_t* lr_dirty = w.take<uint8_t>(lr ? n : 1);
+    uint32_t* lr_list = w.take<uint32_t>(lr ? n : 1);
+    uint32_t* lr_cnt = w.take<uint32_t>(lr ? kMaxSteps + 2 : 1);
     uint32_t* park_list = w.take<uint32_t>(cache ? n + 64 + 64 * 8192 : 1);
     uint32_t* park_t = w.take<uint32_t>(cache ? n : 1);
     const bool rp = n >= repack_min_users();      // small runs never repack: no second copy
@@ -384,6 +396,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->use_cache = cache ? 1u : 0u; d->cache_rec = cache_rec; d->cache_chunk = cache_chunk; d->cache_resc = cache_resc;
         d->f64_valid = f64_valid; d->exact_cnt_b = exact_cnt_b; d->cache_row = cache_row; d->cache_row_f = cache_row_f;
         d->park_list = park_list; d->park_t = park_t; d->sweep_only = 0;
+        d->lr_action = lr_action; d->lr_dirty = lr ? lr_dirty : nullptr; d->lr_list = lr_list; d->lr_cnt = lr_cnt;
         d->uid = uid; d->omega_alt = omega_alt; d->hist_alt = hist_alt;
         d->lpv_alt = lpv_alt; d->uid_alt = uid_alt;
         d->gamma32 = gamma32; d->mu32 = mu32; d->gamma32t = gamma32t; d->stats = stats; d->omega = omega; d->list = list;
@@ -487,6 +500,7 @@ __global__ void __launch_bounds__(kBlock) k_reset_users(DevSim d) {
         d.n_events[i] = 0;
         d.has_phantom[i] = 0;
         if (d.time_mode) d.utime[i] = 0.0;
+        if (d.lr_dirty) d.lr_dirty[i] = 1;
         if (d.hist_cap) d.hist[static_cast<size_t>(i) * d.hist_cap] = 0ull;
         if (d.use_cache) { d.f64_valid[i] = 0; d.cache_resc[i] = 0; }
     }
@@ -820,6 +834,7 @@ __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, ui
 // ViewsFeaturesProvider.observe (agents/abstract.py:347-358): count one organic view, keeping the
 // user's (product, count) history sorted by product id.
 __device__ void history_add(const DevSim& d, uint32_t slot, uint32_t v) {
+    if (d.lr_dirty) d.lr_dirty[d.uid[slot]] = 1;           // the frozen LogReg policy's cached act is stale now
     hent_t* hr = hist_row(d, slot);
     hent_t e[kHistRegs];
     hist_load_line(hr, e);
@@ -2974,6 +2989,113 @@ __device__ uint32_t logreg_act_wave(const DevSim& d, uint32_t slot, int lane) {
     return static_cast<uint32_t>(d.lr_classes[best_c]);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Frozen LogregMulticlassIps at scale (BASELINE config 5: 10^4 classes).  a = classes[argmax_c (b_c + sum_p views_p W[p][c])]
+// depends on the view history only, so it is computed when the history has changed (5-6 times per user, not once per
+// event) and kept per user:
+//   k_logreg_select  (lane per live user) the users that need an act at this step — bandit users whose history changed
+//                    since their last act, organic users that stop at this step (their phantom row) — into lr_list;
+//   k_logreg_acts    (wave per listed user, lane = class) scores in fp32 from the fp32 copy of coef^T (half the bytes,
+//                    twice the fma rate of the float64 walk): |s~_c - s_c| <= (nd + 3) 2^-24 (max|b| + sum_p views_p
+//                    max_c |W[p][c]|) for every class, so when the best fp32 score leads the second best by more than
+//                    twice that bound it IS sklearn's argmax; otherwise (near-ties, exact ties) the float64 walk in
+//                    scipy's summation order (logreg_act_wave) decides — predict() bit for bit either way.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_logreg_select(DevSim d, uint32_t t) {
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC], n_b = d.step_cnt[2 * t + RG_STATE_BANDIT], n = n_o + n_b;
+    const uint32_t* cur_o = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const uint32_t* cur_b = list_ptr(d, t & 1, RG_STATE_BANDIT);
+    const uint32_t n_iter = (n + kBlock - 1) / kBlock;
+    for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+        const uint32_t i = it * kBlock + threadIdx.x;
+        bool need = false;
+        uint32_t slot = 0;
+        if (i < n) {
+            const bool is_org = i < n_o;
+            slot = is_org ? cur_o[i] : cur_b[i - n_o];
+            const uint32_t uidx = d.uid[slot];
+            need = d.lr_dirty[uidx] != 0;
+            if (need && is_org) {
+                // an organic user needs an act only for its phantom row: when this step's transition stops it
+                const uint32_t user = static_cast<uint32_t>(d.first_user + uidx);
+                const rg_u32x4 w = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
+                const double u_trans = rg_uniform(w.w[2], w.w[3]);
+                const int ns = (d.cdf_o0 <= u_trans) + (d.cdf_o1 <= u_trans);
+                need = ns == RG_STATE_STOP && !((d.first_user + uidx) < d.organic_only_below);
+            }
+        }
+        const unsigned long long m = __ballot(need);
+        uint32_t base = 0;
+        if (m && lane_id() == 0) base = atomicAdd(&d.lr_cnt[t], static_cast<uint32_t>(__popcll(m)));
+        base = __shfl(static_cast<int>(base), 0);
+        if (need) d.lr_list[base + prefix_in_mask(m)] = slot;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_logreg_acts(DevSim d, uint32_t t) {
+    const int lane = lane_id();
+    const uint32_t n = d.lr_cnt[t];
+    const uint32_t waves_total = gridDim.x * (kBlock / 64);
+    for (uint32_t w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < n; w += waves_total) {
+        const uint32_t slot = d.lr_list[w];
+        const uint32_t uidx = d.uid[slot];
+        uint32_t action = 0;
+        bool done = false;
+        const hent_t* hr = hist_row(d, slot) + 1;
+        const uint32_t nd = h_cnt(hr[-1]);
+        if (d.lr_coef32_t && nd <= 32 && nd > 0) {
+            // history entries in registers of the first nd lanes, broadcast by readlane
+            const hent_t mine = static_cast<uint32_t>(lane) < nd ? hr[lane] : 0ull;
+            float Ahat = d.lr_bmax;
+            for (uint32_t i = 0; i < nd; ++i) {
+                const hent_t x = __shfl(mine, static_cast<int>(i));
+                Ahat = fmaf(static_cast<float>(h_cnt(x)), d.lr_wmax[h_prod(x)], Ahat);
+            }
+            float best = -INFINITY, second = -INFINITY;
+            uint32_t best_c = 0;
+            for (uint32_t c0 = 0; c0 < d.lr_n; c0 += 256) {
+                float sc[4];
+                uint32_t cc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    cc[q] = min(c0 + 64u * q + lane, d.lr_n - 1);                  // clamped: masked below
+                    sc[q] = d.lr_intercept32[cc[q]];
+                }
+                for (uint32_t i = 0; i < nd; ++i) {
+                    const hent_t x = __shfl(mine, static_cast<int>(i));
+                    const float cnt = static_cast<float>(h_cnt(x));
+                    const float* row = d.lr_coef32_t + static_cast<size_t>(h_prod(x)) * d.lr_n;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sc[q] = fmaf(cnt, row[cc[q]], sc[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t c = c0 + 64u * q + lane;
+                    if (c < d.lr_n) {
+                        if (sc[q] > best) { second = best; best = sc[q]; best_c = c; }
+                        else if (sc[q] > second) second = sc[q];
+                    }
+                }
+            }
+            // wave top-2 over disjoint class sets: the best score with its class, and the best of everything else
+            // (equal best scores leave a margin of 0: not certified, the float64 walk breaks the tie like numpy)
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(best, o), os = __shfl_xor(second, o);
+                const uint32_t oc = __shfl_xor(best_c, o);
+                const float ns = fmaxf(fminf(best, ob), fmaxf(second, os));
+                if (ob > best) best_c = oc;
+                best = fmaxf(best, ob);
+                second = ns;
+            }
+            const float bound = static_cast<float>(nd + 3) * 5.9604644775390625e-08f * Ahat * 1.01f;
+            if (d.lr_n == 1 || best - second > 2.0f * bound) { action = static_cast<uint32_t>(d.lr_classes[best_c]); done = true; }
+        }
+        if (!done) action = logreg_act_wave(d, slot, lane);             // float64, scipy's summation order
+        if (lane == 0) { d.lr_action[uidx] = action; d.lr_dirty[uidx] = 0; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // k_advance — one Markov transition for every live user (lane per user).
 // ------------------------------------------------------------------------------------------
@@ -3004,19 +3126,10 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
         int ns = RG_STATE_STOP;       // inactive lanes look dead
         uint32_t slot = 0;
         uint32_t lr_a = 0;            // RG_POLICY_LOGREG_FROZEN: this user's action for its current view history
-        if (d.policy == RG_POLICY_LOGREG_FROZEN) {
-            // the policy reads only the history, which this kernel does not change: one act per live user serves
-            // its bandit event AND its phantom row.  Computed user by user by the whole wave (lane = class).
-            uint32_t my_slot = 0;
-            if (i < n) my_slot = i < n_o ? cur_o[i] : cur_b[i - n_o];
-            unsigned long long todo = __ballot(i < n);
-            while (todo) {
-                const int L = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                const uint32_t a_L = logreg_act_wave(d, static_cast<uint32_t>(__shfl(static_cast<int>(my_slot), L)), lane);
-                if (lane == L) lr_a = a_L;
-            }
-        }
+        if (d.policy == RG_POLICY_LOGREG_FROZEN && i < n)
+            // the policy reads only the view history: its act was computed by k_logreg_acts when the history last changed
+            // and serves the bandit event and the phantom row alike
+            lr_a = d.lr_action[d.uid[i < n_o ? cur_o[i] : cur_b[i - n_o]]];
         if (i < n) {
             const bool is_org = i < n_o;
             slot = is_org ? cur_o[i] : cur_b[i - n_o];
@@ -4218,6 +4331,11 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         launch_exact(sim, t, 0, upper, st);
     }
     if (int rc = prof_mark(sim, st)) return rc;
+    if (d.policy == RG_POLICY_LOGREG_FROZEN) {
+        // acts of the users whose view history changed since their last one (frozen LogReg at scale)
+        hipLaunchKernelGGL(k_logreg_select, dim3(grid_for(upper)), dim3(kBlock), 0, st, d, t);
+        hipLaunchKernelGGL(k_logreg_acts, dim3(grid_for(static_cast<uint64_t>(upper) / 4 + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
+    }
     // 2. click draws, transitions, drift, next lists, bandit + phantom rows
     hipLaunchKernelGGL(k_advance, dim3(grid_for(upper, kAdvBlock)), dim3(kAdvBlock), 0, st, d, t, d_actions);
     HIP_TRY(hipGetLastError());
@@ -4519,6 +4637,16 @@ int rg_sim_set_logreg(rg_sim* sim, const double* d_coef_t, const double* d_inter
     return RG_OK;
 }
 
+int rg_sim_set_logreg_fp32(rg_sim* sim, const float* d_coef32_t, const float* d_intercept32, const float* d_wmax, float bmax) {
+    if (!sim) return fail(RG_EINVAL, "sim is NULL");
+    if (sim->d.policy != RG_POLICY_LOGREG_FROZEN) return fail(RG_ESTATE, "policy is not RG_POLICY_LOGREG_FROZEN");
+    if (!sim->d.lr_coef_t) return fail(RG_ESTATE, "rg_sim_set_logreg must be called first");
+    if ((d_coef32_t || d_intercept32 || d_wmax) && !(d_coef32_t && d_intercept32 && d_wmax)) return fail(RG_EINVAL, "all three arrays or none");
+    if (!(bmax >= 0.0f)) return fail(RG_EINVAL, "bmax must be >= 0");
+    sim->d.lr_coef32_t = d_coef32_t; sim->d.lr_intercept32 = d_intercept32; sim->d.lr_wmax = d_wmax; sim->d.lr_bmax = bmax;
+    return RG_OK;
+}
+
 int rg_sim_set_log(rg_sim* sim, rg_event* d_log, uint64_t capacity) {
     if (!sim) return fail(RG_EINVAL, "sim is NULL");
     sim->d.log = capacity ? d_log : nullptr;
@@ -4561,6 +4689,7 @@ int rg_sim_reset_users(rg_sim* sim, uint64_t first_user_id, uint64_t n, uint64_t
     HIP_TRY(hipMemsetAsync(d.step_cnt, 0, sizeof(uint32_t) * 2 * (kMaxSteps + 2), st));
     HIP_TRY(hipMemsetAsync(d.exact_cnt, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
     HIP_TRY(hipMemsetAsync(d.exact_cnt_b, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
+    if (d.lr_dirty) HIP_TRY(hipMemsetAsync(d.lr_cnt, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
     HIP_TRY(hipMemsetAsync(d.counters, 0, sizeof(unsigned long long) * RG_CNT_N, st));
     hipLaunchKernelGGL(k_reset_users, dim3(grid_for(n)), dim3(kBlock), 0, st, d);
     HIP_TRY(hipGetLastError());

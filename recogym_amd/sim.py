@@ -123,6 +123,15 @@ class Simulator:
                 _abi.check(self.lib.rg_sim_set_logreg(self._h, self.logreg[0].data_ptr(), self.logreg[1].data_ptr(),
                                                       self.logreg[2].data_ptr(), self.logreg[2].numel()),
                            'rg_sim_set_logreg')
+                if logreg.get('fp32', True):
+                    # fp32 copies for the certified fast scores (the float64 arrays stay the arbiter); bounds rounded up
+                    w32 = self.logreg[0].to(torch.float32)
+                    b32 = self.logreg[1].to(torch.float32)
+                    wmax = (self.logreg[0].abs().amax(dim=1) * (1.0 + 1e-6)).to(torch.float32) * (1.0 + 1e-6)
+                    bmax = float(self.logreg[1].abs().max().item()) * (1.0 + 1e-6)
+                    self.logreg32 = (w32.contiguous(), b32.contiguous(), wmax.contiguous())
+                    _abi.check(self.lib.rg_sim_set_logreg_fp32(self._h, self.logreg32[0].data_ptr(), self.logreg32[1].data_ptr(),
+                                                               self.logreg32[2].data_ptr(), C.c_float(bmax)), 'rg_sim_set_logreg_fp32')
             if log_capacity is None:
                 log_capacity = default_log_capacity(config, self.n_users)
             self.log = None

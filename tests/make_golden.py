@@ -181,7 +181,7 @@ def notebook_goldens():
     assert same7 and same9
 
 
-def run_logreg_case(name, env_over, n_train, n_users, injected=True):
+def run_logreg_case(name, env_over, n_train, n_users, injected=True, select_randomly=False):
     """LogregMulticlassIpsAgent of the UNMODIFIED reference (agents/logreg_ips.py): trained by the
     reference's own build() (train_data + sklearn fit) on a uniform-policy log of n_train users that the
     reference generated, then run through generate_logs with the counter RNG injected into the env (the
@@ -194,7 +194,7 @@ def run_logreg_case(name, env_over, n_train, n_users, injected=True):
     train_log = train_env.generate_logs(n_train)
     agent = LogregMulticlassIpsAgent(Configuration({**logreg_multiclass_ips_args,
                                                     'num_products': args['num_products'],
-                                                    'random_seed': 7, 'select_randomly': False}))
+                                                    'random_seed': 7, 'select_randomly': select_randomly}))
     d = agent.model_builder.data
     for _, r in train_log.iterrows():                       # ModelBuilder.train's bookkeeping, row by row
         bandit = r['z'] == 'bandit'
@@ -204,8 +204,9 @@ def run_logreg_case(name, env_over, n_train, n_users, injected=True):
         d['c'].append(int(r['c']) if bandit else None)
         d['ps'].append(float(r['ps']) if bandit else None)
     env = rh.make_reference_env(args)
-    if injected:
-        rh.inject_counter_rng(env, None, None)              # else: the reference exactly as shipped (MT19937)
+    if injected:                                            # else: the reference exactly as shipped (MT19937)
+        # select_randomly = False draws nothing; True samples from predict_proba with the model's own rng (seed 7)
+        rh.inject_counter_rng(env, agent if select_randomly else None, 7 if select_randomly else None)
     df = env.generate_logs(n_users, agent)                  # first act() builds the model
     lr = agent.model.logreg
     arrays = rh.log_to_arrays(df)
@@ -213,7 +214,8 @@ def run_logreg_case(name, env_over, n_train, n_users, injected=True):
     arrays['logreg_intercept'] = np.asarray(lr.intercept_, dtype=np.float64)
     arrays['logreg_classes'] = np.asarray(lr.classes_, dtype=np.int64)
     meta = dict(env_args=args, n_users=n_users, n_organic=0, agent='logreg',
-                agent_args=dict(n_train=n_train, clicks_in_training=int(np.nansum(train_log['c'].to_numpy(dtype=float)))),
+                agent_args=dict(n_train=n_train, clicks_in_training=int(np.nansum(train_log['c'].to_numpy(dtype=float))),
+                                select_randomly=bool(select_randomly), random_seed=7),
                 rng='philox' if injected else 'mt')
     small = {}
     for k, v in arrays.items():
@@ -324,6 +326,9 @@ def main():
                  agent_kind='ouc', agent_args=dict(random_seed=11), injected=True)
         normal_time_goldens()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'logreg_random':
+        run_logreg_case('hostpath_logreg_random', {'random_seed': 42, 'num_products': 10, 'K': 5}, 800, 100, select_randomly=True)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'normal_time':
         normal_time_goldens()
         return
@@ -377,6 +382,7 @@ def main():
         train_feed_golden(fx)
     run_logreg_case('philox_logreg', {**S, 'num_products': 30, 'K': 8}, 1500, 200)
     run_logreg_case('mt_logreg', {**S, 'num_products': 30, 'K': 8}, 1500, 120, injected=False)
+    run_logreg_case('hostpath_logreg_random', {**S, 'num_products': 10, 'K': 5}, 800, 100, select_randomly=True)
     bandit_mf_training_golden('mt_random_agent')
 
 

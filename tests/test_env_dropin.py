@@ -404,3 +404,23 @@ def test_normal_time_generator_matches_the_reference(name):
     cs = frame_to_cols(df_seq)
     for k in ('u', 'z', 'v', 'a', 'c'):
         assert np.array_equal(cs[k], want[k][keep].astype(np.int64)), k
+
+
+def test_logreg_select_randomly_samples_like_the_reference():
+    """LogregMulticlassIpsAgent with select_randomly=True (logreg_ips.py:61-66): the action is sampled from
+    predict_proba with the model's own rng.  Host form only (per-user path, HIP kernels underneath): reproduces the
+    log of the unmodified reference (its fitted model travels with the fixture, its draw injected as the addressed
+    policy draw) — actions exactly, `ps` = the sampled class's probability to 1e-12."""
+    from recogym_amd.agents import LogregFrozenAgent
+    meta, want = gu.load('hostpath_logreg_random')
+    cfg = Configuration({'num_products': meta['env_args']['num_products'], 'random_seed': meta['agent_args']['random_seed'],
+                         'select_randomly': True, 'with_ps_all': False})
+    agent = LogregFrozenAgent(cfg, want['logreg_coef'], want['logreg_intercept'], want['logreg_classes'])
+    assert agent.device_policy() is None
+    n = 30
+    df = make_env(meta['env_args']).generate_logs(n, agent)
+    keep = want['u'] < n
+    cols = frame_to_cols(df)
+    for k in ('t', 'u', 'z', 'v', 'a', 'c'):
+        assert np.array_equal(cols[k], want[k][keep].astype(np.int64)), k
+    np.testing.assert_allclose(cols['ps'], want['ps'][keep], rtol=1e-12, equal_nan=True)

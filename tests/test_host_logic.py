@@ -319,3 +319,18 @@ def test_division_by_reciprocal_is_correctly_rounded():
         s = rnd.randrange(1, 1 << rnd.randrange(1, 33))
         c = rnd.randrange(1, s + 1)
         assert dev(float(c), float(s)) == c / s, (c, s)
+
+
+def test_bandit_mf_table_is_built_in_row_blocks():
+    """LastViewTableAgent.from_bandit_mf: the P x P logit matrix is taken a block of rows at a time (2 GB as one
+    broadcast at P = 10^4); blocks of any size give the table and winning logits of the one-shot form."""
+    from recogym_amd.agents import LastViewTableAgent
+    rng = np.random.RandomState(4)
+    P, E = 700, 5
+    Ep, Eu = rng.randn(P, E), rng.randn(P, E)
+    ag = LastViewTableAgent.from_bandit_mf(Configuration({'num_products': P}), Ep, Eu)
+    full = (Eu.astype(np.float32)[:, None, :] * Ep.astype(np.float32)[None, :, :]).sum(axis=2)
+    assert np.array_equal(ag.table, full.argmax(axis=1))
+    assert np.array_equal(ag.ps, full.max(axis=1).astype(np.float64))
+    big = LastViewTableAgent.from_bandit_mf(Configuration({'num_products': 6000}), rng.randn(6000, 5), rng.randn(6000, 5))
+    assert big.table.shape == (6000,) and big.table.max() < 6000
