@@ -256,7 +256,9 @@ Geom geom_of(const rg_config& c) {
     g.KS = 2 * g.KH;
     while (g.KS % 4 != 2) ++g.KS;
     g.TP = 256;
-    while (g.TP > 32 && static_cast<size_t>(g.TP) * g.KS * 4 > 24 * 1024) g.TP /= 2;
+    // (never below 64 products: k_draw_mfma consumes the tile in PAIRS of 32-product chunks.  KH = 64 takes 2 x 33 KB
+    // of tile + 64 KB of omega stage = 133 KB of the CU's 160 KB)
+    while (g.TP > 64 && static_cast<size_t>(g.TP) * g.KS * 4 > 24 * 1024) g.TP /= 2;
     g.P_pad = static_cast<uint32_t>(align_up(c.num_products, 256)) + 256;
     g.n_chunks = (c.num_products + 31) / 32;
     g.n_chunks = (g.n_chunks + 3) & ~3u;            // chunks are processed in pairs of pairs
@@ -1234,11 +1236,28 @@ __device__ __forceinline__ uint32_t exact_pick_wave(const DevSim& d, const doubl
                                                     double u, uint32_t G, int lane) {
     const uint32_t n_chunks = d.PT / 64;
     const uint32_t n_cc = (n_chunks + G - 1) / G;
-    // total over the coarse-chunk sums, in the same association the prefix below uses
+    // One scan per block of 64 stored sums, kept in registers (up to 4 blocks = 256 sums = P <= 16 384 at G = 1; a
+    // second pass over memory otherwise): the total and the search use the same partial sums — the same association.
+    constexpr int RB = 4;
+    double x[RB], incl[RB];
+    const bool in_regs = n_cc <= 64u * RB;
     double total = 0.0;
-    for (uint32_t c0 = 0; c0 < n_cc; c0 += 64) {
-        const uint32_t c = c0 + lane;
-        total += __shfl(wave_scan(c < n_cc ? sums[c] : 0.0, lane), 63);
+    if (in_regs) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const uint32_t c = 64u * r + lane;
+            x[r] = c < n_cc ? sums[c] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            if (64u * r < n_cc) { incl[r] = wave_scan(x[r], lane); total += __shfl(incl[r], 63); }
+            else incl[r] = 0.0;
+        }
+    } else {
+        for (uint32_t c0 = 0; c0 < n_cc; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            total += __shfl(wave_scan(c < n_cc ? sums[c] : 0.0, lane), 63);
+        }
     }
     // The reference normalises p = e / sum(e) before its cumsum and divides by cdf[-1];
     // dividing every term by the same positive constants moves the decision only at the
@@ -1248,17 +1267,33 @@ __device__ __forceinline__ uint32_t exact_pick_wave(const DevSim& d, const doubl
     uint32_t ccstar = n_cc - 1;
     double before = 0.0, run = 0.0;
     bool found = false;
-    for (uint32_t c0 = 0; c0 < n_cc && !found; c0 += 64) {
-        const uint32_t c = c0 + lane;
-        const double x = c < n_cc ? sums[c] : 0.0;
-        const double incl = wave_scan(x, lane);
-        const unsigned long long hit = __ballot(c < n_cc && run + incl > target);
-        if (hit) {
-            const int L = __builtin_ctzll(hit);
-            ccstar = c0 + L;
-            before = run + __shfl(incl - x, L);
-            found = true;
-        } else run += __shfl(incl, 63);
+    if (in_regs) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            if (64u * r < n_cc && !found) {
+                const uint32_t c = 64u * r + lane;
+                const unsigned long long hit = __ballot(c < n_cc && run + incl[r] > target);
+                if (hit) {
+                    const int L = __builtin_ctzll(hit);
+                    ccstar = 64u * r + L;
+                    before = run + __shfl(incl[r] - x[r], L);
+                    found = true;
+                } else run += __shfl(incl[r], 63);
+            }
+        }
+    } else {
+        for (uint32_t c0 = 0; c0 < n_cc && !found; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            const double xv = c < n_cc ? sums[c] : 0.0;
+            const double inc = wave_scan(xv, lane);
+            const unsigned long long hit = __ballot(c < n_cc && run + inc > target);
+            if (hit) {
+                const int L = __builtin_ctzll(hit);
+                ccstar = c0 + L;
+                before = run + __shfl(inc - xv, L);
+                found = true;
+            } else run += __shfl(inc, 63);
+        }
     }
     if (!found) before = run - sums[n_cc - 1];          // u * total rounded up to total
     __builtin_amdgcn_wave_barrier();
@@ -1268,14 +1303,21 @@ __device__ __forceinline__ uint32_t exact_pick_wave(const DevSim& d, const doubl
     for (uint32_t i = 0; i < G; ++i) {
         const uint32_t p = (ccstar * G + i) * 64 + lane;
         if (ccstar * G + i >= n_chunks) break;
-        double lg = 0.0;
         const double* g = d.gammaT + p;                  // PT columns: always in range
-        for (uint32_t k = 0; k < d.K; ++k) lg += g[static_cast<size_t>(k) * d.PT] * om[k];
+        double lg = 0.0;
+        // same association as the oracle (k ascending); the loads of eight k are issued together
+        for (uint32_t k0 = 0; k0 < d.K; k0 += 8) {
+            double gv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gv[j] = g[static_cast<size_t>(min(k0 + j, d.K - 1)) * d.PT];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (k0 + j < d.K) lg += gv[j] * om[k0 + j];
+        }
         lg = p < d.P ? lg + d.mu_o[p] : -INFINITY;
-        const double incl = wave_scan(exp64(lg - M), lane);
-        const unsigned long long hit = __ballot(p < d.P && acc + incl > target);
+        const double inc = wave_scan(exp64(lg - M), lane);
+        const unsigned long long hit = __ballot(p < d.P && acc + inc > target);
         if (hit) { v = (ccstar * G + i) * 64 + static_cast<uint32_t>(__builtin_ctzll(hit)); break; }
-        acc += __shfl(incl, 63);
+        acc += __shfl(inc, 63);
     }
     return v;
 }

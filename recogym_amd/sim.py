@@ -6,6 +6,7 @@ CPU fallback — constructing a Simulator without a HIP device raises.
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -99,7 +100,7 @@ class Simulator:
             if need == 0:
                 raise _abi.RecoGymHipError('rg_sim_workspace_bytes: ' +
                                            self.lib.rg_last_error().decode())
-            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.workspace = self._poison(torch.empty(need, dtype=torch.uint8, device=self.device))
             self._h = C.c_void_p()
             _abi.check(self.lib.rg_sim_create(C.byref(self._h), C.byref(self.rg_config),
                                               self.n_users, self.workspace.data_ptr(), need),
@@ -138,28 +139,36 @@ class Simulator:
             self.set_log_capacity(log_capacity)
 
     # -- plumbing ---------------------------------------------------------------------------
+    @staticmethod
+    def _poison(t):
+        """RECOGYM_POISON=1 (a debugging aid): fill every buffer handed to the library with 0xA5 bytes, so that a
+        kernel reading memory nothing initialised fails every time instead of when the allocator recycles a block."""
+        if os.environ.get('RECOGYM_POISON'):
+            t.view(torch.uint8).fill_(0xA5)
+        return t
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def set_log_capacity(self, rows):
         self.log_capacity = int(rows)
         with torch.cuda.device(self.device):
-            self.log = (torch.empty((self.log_capacity, 4), dtype=torch.int32, device=self.device)
+            self.log = (self._poison(torch.empty((self.log_capacity, 4), dtype=torch.int32, device=self.device))
                         if rows else None)
         _abi.check(self.lib.rg_sim_set_log(self._h, self.log.data_ptr() if rows else None,
                                            self.log_capacity), 'rg_sim_set_log')
         self.aux_time = None
         if rows and self.time_mode:
             with torch.cuda.device(self.device):
-                self.aux_time = torch.empty(self.log_capacity, dtype=torch.float64, device=self.device)
+                self.aux_time = self._poison(torch.empty(self.log_capacity, dtype=torch.float64, device=self.device))
             _abi.check(self.lib.rg_sim_set_log_time(self._h, self.aux_time.data_ptr()), 'rg_sim_set_log_time')
         self.aux_ps = self.aux_p_click = None
         if rows and (self.ps_float64 or self.keep_p_click):
             with torch.cuda.device(self.device):
                 if self.ps_float64:
-                    self.aux_ps = torch.empty(self.log_capacity, dtype=torch.float64, device=self.device)
+                    self.aux_ps = self._poison(torch.empty(self.log_capacity, dtype=torch.float64, device=self.device))
                 if self.keep_p_click:
-                    self.aux_p_click = torch.empty(self.log_capacity, dtype=torch.float64, device=self.device)
+                    self.aux_p_click = self._poison(torch.empty(self.log_capacity, dtype=torch.float64, device=self.device))
             _abi.check(self.lib.rg_sim_set_log_aux(
                 self._h, None if self.aux_ps is None else self.aux_ps.data_ptr(),
                 None if self.aux_p_click is None else self.aux_p_click.data_ptr()), 'rg_sim_set_log_aux')

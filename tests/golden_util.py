@@ -65,7 +65,8 @@ def assert_rows_equal(rows, cols, ps_rtol=1e-12, what=''):
         want = cols[k].astype(np.int64)
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, (f'{what}: column {k}: {bad.size} mismatches, first at row '
-                               f'{bad[0]}: got {got[bad[0]]} want {want[bad[0]]}')
+                               f'{bad[0]}: got {got[bad[0]]} want {want[bad[0]]}; (u, t, got, want) of the first: '
+                               f'{[(int(rows["u"][i]), int(rows["t"][i]), int(got[i]), int(want[i])) for i in bad[:12]]}')
     np.testing.assert_allclose(rows['ps'], cols['ps'], rtol=ps_rtol, atol=0, equal_nan=True,
                                err_msg=f'{what}: ps')
     if 'time' in cols and 'time' in rows.dtype.names:       # the generator's clock (float32 in the reference's DataFrame)
