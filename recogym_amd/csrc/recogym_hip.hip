@@ -104,6 +104,7 @@ struct DevSim {
     uint32_t exact_rows;      // rows of exact_sums: n_cap where they are per-user constants (sigma_omega = 0 cache) or every
                               // draw goes through float64; else max(4096, n_cap / 8) — a step's uncertified draws (a few percent
                               // of its organic users) are resolved in batches of that many list entries
+    uint32_t walk_bias;       // k_walk: 0 = both event kinds every iteration; else one kind, organic when n_org * walk_bias >= n_bandit * 4
     uint32_t exact_base;      // first exact_list entry of the batch being resolved
     uint32_t exact_last;      // this is the last batch launched for the step
     float2* sc_scratch;       // [kMaxGrid*4 waves][kMaxSC][32] {sum, reference} of the MFMA draw kernel
@@ -134,6 +135,9 @@ struct DevSim {
     uint32_t use_cache;
     float2* cache_rec;        // [n_cap + 1][kMaxSC] {sum, reference} of every super-chunk
     float* cache_chunk;       // [n_cap + 1][n_chunks] exp-sum of every 32-product chunk
+    float* beta32;            // [P][KB4] fp32 copy of beta (rows padded with zeros to KB4 = K rounded up to 4): k_walk's click fast path
+    uint32_t KB4;
+    float* cache_sub;         // [n_cap + 1][n_chunks][4] exp-sums of the four 8-product groups of every chunk (k_walk's recompute unit), or null
     uint8_t* cache_resc;      // [n_cap + 1] re-references of the sweep (certificate budget)
     // what every later draw of a user starts from, one contiguous row per user (k_cache_finalize builds it from the
     // records above right after step 0): [0,32) super-chunk sums scaled to the common reference | 32: that reference,
@@ -302,6 +306,19 @@ bool cache_wanted(const rg_config& c, const Geom& g) {
     return c.sigma_omega == 0.0 && g.N1 != 0 && !(e && e[0] == '0');
 }
 
+// Sums of 8-product groups next to the chunk sums: where the run will be walked user by user (k_walk), the recompute
+// that turns a chunk into a product streams the chunk's Gamma rows through the CU's L1 — the walk's bound — and a
+// group is a quarter of that.  16 bytes per chunk and user, written by the SUB instantiation of the fp16 sweep.
+// OPT-IN (RECOGYM_SUB=1).  Measured (profiles/r2): the walk's L1 requests per event drop 2.3x and its time does not
+// move (C3: 266 -> 267 ms; C2: 17.9 -> 16.1 ms) while the sweep that writes 4x the sums goes 29 -> 45 ms on C3 —
+// the walk is bound by its chains of dependent loads, not by L1 bytes.
+bool sub_wanted(const rg_config& c, const Geom& g) {
+    const char* e = getenv("RECOGYM_SUB");
+    const bool walks = c.policy == RG_POLICY_UNIFORM_ENV || c.policy == RG_POLICY_RANDOM_AGENT ||
+                       c.policy == RG_POLICY_ORGANIC_USER_COUNT || c.policy == RG_POLICY_LAST_VIEW_TABLE;
+    return cache_wanted(c, g) && g.F16 == 1 && g.KH <= 16 && walks && !c.time_mode && e && e[0] == '1';
+}
+
 // rows of the float64 chunk-sum scratch (see DevSim::exact_rows)
 size_t exact_rows_of(const rg_config& c, const Geom& g, uint64_t n) {
     const char* e = getenv("RECOGYM_DRAW");
@@ -330,9 +347,9 @@ uint32_t exact_kb_of(uint32_t K) {
 
 uint32_t hist_cap_of(const rg_config& c) {
     if (c.policy != RG_POLICY_ORGANIC_USER_COUNT && c.policy != RG_POLICY_LOGREG_FROZEN) return 0;
-    // entries per row: the header + the distinct products kept, rounded up to whole 16-byte pairs
-    const uint32_t hc = ((c.ouc_history_cap ? c.ouc_history_cap : kDefaultHistoryCap - 1u) + 2u) & ~1u;
-    return hc < 16u ? 16u : hc;                  // at least the one line the register paths load
+    // entries per row: the header + the distinct products kept, rounded up to whole 128-byte lines of 16 entries (what
+    // the register paths load at a time)
+    return ((c.ouc_history_cap ? c.ouc_history_cap : kDefaultHistoryCap - 1u) + 1u + 15u) & ~15u;
 }
 
 size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
@@ -377,6 +394,10 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     float2* cache_rec = w.take<float2>(cache ? (n + 1) * kMaxSC : 1);
     float* cache_chunk = w.take<float>(cache ? (n + 1) * static_cast<size_t>(g.n_chunks) : 1);
     uint8_t* cache_resc = w.take<uint8_t>(cache ? n + 1 : 1);
+    const bool sub = sub_wanted(c, g);
+    const size_t KB4 = (K + 3) & ~static_cast<size_t>(3);
+    float* beta32 = w.take<float>(cache ? P * KB4 : 4);
+    float* cache_sub = w.take<float>(sub ? (n + 1) * static_cast<size_t>(g.n_chunks) * 4 : 4);
     const uint32_t cache_row_f = (44u + 2u * g.KH + 31u) & ~31u;
     float* cache_row = w.take<float>(cache ? (n + 1) * static_cast<size_t>(cache_row_f) : 1);
     uint8_t* f64_valid = w.take<uint8_t>(cache ? n : 1);
@@ -396,6 +417,8 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     if (d) {
         d->phantom_ps = phantom_ps; d->utime = utime; d->phantom_time = phantom_time;
         d->use_cache = cache ? 1u : 0u; d->cache_rec = cache_rec; d->cache_chunk = cache_chunk; d->cache_resc = cache_resc;
+        d->cache_sub = sub ? cache_sub : nullptr;
+        d->beta32 = cache ? beta32 : nullptr; d->KB4 = static_cast<uint32_t>(KB4);
         d->f64_valid = f64_valid; d->exact_cnt_b = exact_cnt_b; d->cache_row = cache_row; d->cache_row_f = cache_row_f;
         d->park_list = park_list; d->park_t = park_t; d->sweep_only = 0;
         d->lr_action = lr_action; d->lr_dirty = lr ? lr_dirty : nullptr; d->lr_list = lr_list; d->lr_cnt = lr_cnt;
@@ -590,6 +613,15 @@ __global__ void __launch_bounds__(kBlock) k_make_gammaT(DevSim d) {
     }
 }
 
+__global__ void __launch_bounds__(kBlock) k_make_beta32(DevSim d) {
+    const size_t n = static_cast<size_t>(d.P) * d.KB4;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const size_t p = i / d.KB4, k = i % d.KB4;
+        d.beta32[i] = k < d.K ? static_cast<float>(d.beta[p * d.K + k]) : 0.0f;
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) k_make_gamma_rm(DevSim d) {
     const uint32_t rs = 4 * d.XKB + 4;
     const size_t n = static_cast<size_t>(d.PT) * rs;
@@ -710,7 +742,7 @@ __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, ui
     const hent_t* hr = hist_row(d, slot);
     const double eps = d.ouc_epsilon;
     bool explore = false;
-    if (d.ouc_exploit_explore) {
+    if (d.ouc_exploit_explore && eps != 0.0) {            // (eps == 0: 0 / 1 <= u0 for every u0 — never explores)
         const double u0 = rg_uniform(w.w[0], w.w[1]);
         const double c0 = eps, c1 = eps + (1.0 - eps);
         explore = !(c0 / c1 <= u0);
@@ -724,6 +756,39 @@ __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, ui
         hist_load_line(hr, e);
         const uint32_t nd = h_cnt(e[0]);
         const double sum = static_cast<double>(h_prod(e[0]));
+        if (d.ouc_select_randomly) {
+            // The float64 walk below compares RN(acc_i / last) with u1, where acc_i is the running sum of the
+            // correctly rounded count_j / sum and last their total: it equals the exact ratio C_i / sum
+            // (C_i = count_1 + .. + count_i, integers) up to (4 nd + 2) roundings — < 1e-12 relative for any history
+            // that fits a row.  So wherever C_i and u1 * sum are further apart than 2^-36 relative the answer is decided
+            // by integers — one add, one conversion and two compares per viewed product, a line of 16 entries at a
+            // time, instead of a division and a float64 sum per product — and the walk in float64 is only taken by a
+            // lane that lands inside that band (~1e-10 of the acts).
+            const double T = u1 * sum;
+            const double T_hi = T * (1.0 + 0x1p-36), T_lo = T * (1.0 - 0x1p-36);
+            uint32_t C = 0, a_f = 0, c_f = 0;
+            bool found = false, amb = false;
+            hent_t f[kHistRegs];
+#pragma unroll
+            for (int i = 0; i < kHistRegs; ++i) f[i] = e[i];
+            for (uint32_t base = 0; base <= nd && !found; base += kHistRegs) {
+                if (base) hist_load_line(hr + base, f);            // (rows are whole 16-entry lines: hist_cap is even and >= 16)
+#pragma unroll
+                for (int i = 0; i < kHistRegs; ++i) {
+                    const uint32_t idx = base + i;
+                    if (idx >= 1 && idx <= nd && !found) {
+                        C += h_cnt(f[i]);
+                        const double Cd = static_cast<double>(C);
+                        if (Cd > T_hi) { found = true; a_f = h_prod(f[i]); c_f = h_cnt(f[i]); }
+                        else if (!(Cd < T_lo)) amb = true;
+                    }
+                }
+            }
+            if (found && !amb) {
+                *ps_out = (1.0 - eps) * (static_cast<double>(c_f) / sum);
+                return a_f;
+            }
+        }
         if (nd < kHistRegs) {
             // the whole history is in registers: p_i once, then the cdf walk without touching memory again
             double pr[kHistRegs - 1];
@@ -874,16 +939,42 @@ __device__ void history_add(const DevSim& d, uint32_t slot, uint32_t v) {
                 reinterpret_cast<ulonglong2*>(hr)[i] = make_ulonglong2(i == 0 ? f[0] : f[2 * i], f[2 * i + 1]);
         return;
     }
-    uint32_t i = 1;
-    while (i <= nd && hr[i] < key) ++i;
-    if (i <= nd && h_prod(hr[i]) == v) {
-        hr[i] += 1ull;
+    // longer histories: the position a line of 16 entries at a time (8 independent loads and 16 compares instead of a
+    // dependent load per entry), the shift four entries at a time from the top
+    uint32_t pos = 1;                           // first entry with product >= v (nd + 1 if none)
+    hent_t at = 0ull;                           // the entry there
+    bool past = false;
+    for (uint32_t base = 0; base <= nd && !past; base += kHistRegs) {
+        hent_t f[kHistRegs];
+        if (base) hist_load_line(hr + base, f);
+        else {
+#pragma unroll
+            for (int i = 0; i < kHistRegs; ++i) f[i] = e[i];
+        }
+#pragma unroll
+        for (int i = 0; i < kHistRegs; ++i) {
+            const uint32_t idx = base + i;
+            if (idx >= 1 && idx <= nd && !past) {
+                if (f[i] < key) pos = idx + 1;
+                else { past = true; at = f[i]; }
+            }
+        }
+    }
+    if (past && h_prod(at) == v) {
+        hr[pos] = at + 1ull;
         hr[0] = e[0] + (1ull << 32);
         return;
     }
     if (nd + 1 >= d.hist_cap) { atomicAdd(&d.counters[RG_CNT_HIST_OVERFLOW], 1ull); return; }
-    for (uint32_t j = nd + 1; j > i; --j) hr[j] = hr[j - 1];
-    hr[i] = key | 1ull;
+    uint32_t j = nd + 1;                        // entries [pos, j) move up by one, highest first
+    while (j > pos) {
+        if (j >= pos + 4) {
+            const hent_t a0 = hr[j - 4], a1 = hr[j - 3], a2 = hr[j - 2], a3 = hr[j - 1];
+            hr[j - 3] = a0; hr[j - 2] = a1; hr[j - 1] = a2; hr[j] = a3;
+            j -= 4;
+        } else { hr[j] = hr[j - 1]; --j; }
+    }
+    hr[pos] = key | 1ull;
     hr[0] = e[0] + (1ull << 32) + 1ull;
 }
 
@@ -1232,8 +1323,10 @@ __global__ void __launch_bounds__(kBlock) k_exact_ref(DevSim d, uint32_t t, uint
 // The float64 pick of one user, by a whole wave (every argument wave-uniform): prefix over the stored chunk sums ->
 // the chunk that holds u * total -> its products walked in product order.  `om` = the user's omega in LDS.
 // G = 64-product chunks per stored sum (8: tile kernel's coarse chunks, 1: user-per-lane kernel)
+// om[k * om_stride]: the user's float64 omega (contiguous in k_exact_pick, one column of the wave's [K][64] LDS block
+// in k_walk)
 __device__ __forceinline__ uint32_t exact_pick_wave(const DevSim& d, const double* sums, const double* om, double M,
-                                                    double u, uint32_t G, int lane) {
+                                                    double u, uint32_t G, int lane, uint32_t om_stride = 1) {
     const uint32_t n_chunks = d.PT / 64;
     const uint32_t n_cc = (n_chunks + G - 1) / G;
     // One scan per block of 64 stored sums, kept in registers (up to 4 blocks = 256 sums = P <= 16 384 at G = 1; a
@@ -1311,7 +1404,7 @@ __device__ __forceinline__ uint32_t exact_pick_wave(const DevSim& d, const doubl
 #pragma unroll
             for (int j = 0; j < 8; ++j) gv[j] = g[static_cast<size_t>(min(k0 + j, d.K - 1)) * d.PT];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if (k0 + j < d.K) lg += gv[j] * om[k0 + j];
+            for (int j = 0; j < 8; ++j) if (k0 + j < d.K) lg += gv[j] * om[(k0 + j) * om_stride];
         }
         lg = p < d.P ? lg + d.mu_o[p] : -INFINITY;
         const double inc = wave_scan(exp64(lg - M), lane);
@@ -1437,7 +1530,7 @@ __device__ __forceinline__ float swap32(float x) {
 // Where a lane finds / leaves its user's sums: record of super-chunk sc at rec[sc * rec_stride], the four chunk
 // sums of product tile ti (16 bytes) at chunk[ti * tile_stride].  Per-wave scratch (users interleaved, one sweep's
 // lifetime) or the per-user cache of the sigma_omega == 0 mode.
-struct SumsView { float2* rec; uint32_t rec_stride; float* chunk; uint32_t tile_stride; };
+struct SumsView { float2* rec; uint32_t rec_stride; float* chunk; uint32_t tile_stride; float* sub; };
 
 __device__ __forceinline__ SumsView sums_view(const DevSim& d, float2* scr, float* scr_chunk, int j, bool active, uint32_t slot) {
     SumsView v;
@@ -1445,7 +1538,9 @@ __device__ __forceinline__ SumsView sums_view(const DevSim& d, float2* scr, floa
         const size_t row = active ? d.uid[slot] : d.n_cap;          // inactive lanes: the dummy row
         v.rec = d.cache_rec + row * kMaxSC; v.rec_stride = 1;
         v.chunk = d.cache_chunk + row * d.n_chunks; v.tile_stride = 4;
+        v.sub = d.cache_sub ? d.cache_sub + row * d.n_chunks * 4 : nullptr;
     } else {
+        v.sub = nullptr;
         v.rec = scr + j; v.rec_stride = 32;
         v.chunk = scr_chunk + 4 * j; v.tile_stride = 128;
     }
@@ -2015,7 +2110,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* generic_ptr) {
         asm volatile("" ::: "memory");                                         \
     } while (0)
 
-template <int KH, int N1, int N2, int N3, bool F16>
+template <int KH, int N1, int N2, int N3, bool F16, bool SUB = false>
 __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, uint32_t S) {
     constexpr int NM = F16 ? N1 : N1 + N2 + N3;   // MFMAs per chunk (fp16 two-way split: one group)
     // MFMA slots that carry the exps (and the A loads); the rest carry the mu loads.  The fp16 form is VALU-bound:
@@ -2149,6 +2244,9 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         // (s0, s1) | A rows of pair pi_next -> nxt, its mu -> (p0, p1) once their exps are done.
         // The exps feed four running packed sums per chunk as they are produced (slots < EXS), so
         // the logit registers are free for the mu quads fetched in the last slots.
+        using f32x4 = __attribute__((ext_vector_type(4))) float;
+        constexpr bool sub = SUB;                            // also the sums of the chunk's four 8-product groups (view.sub)
+        f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
         auto stream = [&](const PairOps& co, PairOps& no, uint32_t pi_next, f32x16& a0, f32x16& a1,
                           f32x16& p0, f32x16& p1, float& s0, float& s1) {
             f32x2 x0[4], x1[4];
@@ -2166,7 +2264,10 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
                     for (int e = (m * 8 / EXS) * 2; e < ((m + 1) * 8 / EXS) * 2; e += 2) {       // exps in pairs
                         f32x2 y = {__builtin_amdgcn_exp2f(p0[e]), __builtin_amdgcn_exp2f(p0[e + 1])};
                         asm volatile("" : "+v"(y));                     // with the pin on p0 above: keeps these pure ops in this slot
-                        if (e < 8) x0[e / 2] = y; else x0[(e / 2) & 3] += y;
+                        // (SUB: x0[q] = accumulator rows 4q..4q+3 = products 8q..8q+7 with the other half-wave; else four
+                        // independent running sums)
+                        if (sub) { if ((e & 3) == 0) x0[e / 4] = y; else x0[e / 4] += y; }
+                        else { if (e < 8) x0[e / 2] = y; else x0[(e / 2) & 3] += y; }
                     }
                 } else {
 #pragma unroll
@@ -2182,7 +2283,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
                     for (int e = (m * 8 / EXS) * 2; e < ((m + 1) * 8 / EXS) * 2; e += 2) {
                         f32x2 y = {__builtin_amdgcn_exp2f(p1[e]), __builtin_amdgcn_exp2f(p1[e + 1])};
                         asm volatile("" : "+v"(y));                     // with the pin on p1 above: keeps these pure ops in this slot
-                        if (e < 8) x1[e / 2] = y; else x1[(e / 2) & 3] += y;
+                        if (sub) { if ((e & 3) == 0) x1[e / 4] = y; else x1[e / 4] += y; }
+                        else { if (e < 8) x1[e / 2] = y; else x1[(e / 2) & 3] += y; }
                     }
                 } else {
 #pragma unroll
@@ -2194,11 +2296,24 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) { load_mu(p0, mb, 0, qq); load_mu(p1, mb, 1, qq); }
             }
-            x0[0] += x0[2]; x0[1] += x0[3]; x0[0] += x0[1];
-            x1[0] += x1[2]; x1[1] += x1[3]; x1[0] += x1[1];
-            s0 = x0[0][0] + x0[0][1];
-            s1 = x1[0][0] + x1[0][1];
+            if (sub) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) { g0[q4] = x0[q4][0] + x0[q4][1]; g1[q4] = x1[q4][0] + x1[q4][1]; }
+                s0 = (g0[0] + g0[1]) + (g0[2] + g0[3]);
+                s1 = (g1[0] + g1[1]) + (g1[2] + g1[3]);
+            } else {
+                x0[0] += x0[2]; x0[1] += x0[3]; x0[0] += x0[1];
+                x1[0] += x1[2]; x1[1] += x1[3]; x1[0] += x1[1];
+                s0 = x0[0][0] + x0[0][1];
+                s1 = x1[0][0] + x1[0][1];
+            }
             RG_PIN();
+        };
+        auto tree4 = [](const f32x16& y) -> f32x4 {
+            f32x4 r;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) r[q4] = (y[4 * q4] + y[4 * q4 + 1]) + (y[4 * q4 + 2] + y[4 * q4 + 3]);
+            return r;
         };
         auto tree = [](const f32x16& y) -> float {
             f32x2 x0 = {y[0], y[1]}, x1 = {y[2], y[3]}, x2 = {y[4], y[5]}, x3 = {y[6], y[7]};
@@ -2220,6 +2335,15 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             if (d.ablate & 256u) { wcmax += s0 + s1; return; }
             s0 += swap32(s0);
             s1 += swap32(s1);
+            if (sub) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) { g0[q4] += swap32(g0[q4]); g1[q4] += swap32(g1[q4]); }
+                if (h == 0) {
+                    float4* sp = reinterpret_cast<float4*>(view.sub + (static_cast<size_t>(pt_lo) * 4 + 2 * pe) * 4);
+                    sp[0] = make_float4(g0[0], g0[1], g0[2], g0[3]);
+                    sp[1] = make_float4(g1[0], g1[1], g1[2], g1[3]);
+                }
+            }
             if (!(pe & 1)) { wlo = make_float2(s0, s1); return; }
             const uint32_t ti = pt_lo + (pe >> 1);
             const float4 w4 = make_float4(wlo.x, wlo.y, s0, s1);
@@ -2291,6 +2415,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             // the scratch stores of the tiles finished since (0, 1, then always 2) -> those may stay in flight ----
             if (T + 2 >= pt_hi) RG_TILE_BARRIER(0);            // nothing was issued behind tile T + 1 but stores
             else if (pi == 1) RG_TILE_BARRIER(4);               // DMA(T + 2)
+            else if (sub) { if (pi == 3) RG_TILE_BARRIER(9); else RG_TILE_BARRIER(14); }   // (five stores per tile with the group sums)
             else if (pi == 3) RG_TILE_BARRIER(5);               // + one store
             else RG_TILE_BARRIER(6);                            // + two stores
             if (T + 3 < pt_hi && !(d.ablate & 32u)) fetch_tile(T + 3);
@@ -2314,7 +2439,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) { p0[r] = __builtin_amdgcn_exp2f(p0[r]); p1[r] = __builtin_amdgcn_exp2f(p1[r]); }
             q_done = q;
-            book(pi, tree(p0), tree(p1));
+            if (sub) { g0 = tree4(p0); g1 = tree4(p1); book(pi, (g0[0] + g0[1]) + (g0[2] + g0[3]), (g1[0] + g1[1]) + (g1[2] + g1[3])); }
+            else book(pi, tree(p0), tree(p1));
         }
         if (sc_left != d.sc_chunks / 4 && h == 0) {            // partial last super-chunk
             view.rec[sc_cur * view.rec_stride] = make_float2(static_cast<float>(s_sc), q_done);
@@ -2654,7 +2780,7 @@ search_kernel_t search_kernel_for(const DevSim& d) {
 }
 draw_kernel_t bf16p_kernel_for(const DevSim& d) {
     if (d.f16) {
-#define RG_CASE(kh, a) if (d.KH == kh && d.N1 == a) return k_draw_bf16p<kh, a, 0, 0, true>;
+#define RG_CASE(kh, a) if (d.KH == kh && d.N1 == a) return d.cache_sub ? k_draw_bf16p<kh, a, 0, 0, true, true> : k_draw_bf16p<kh, a, 0, 0, true>;
         RG_CASE(4, 1) RG_CASE(4, 2) RG_CASE(10, 2) RG_CASE(10, 3) RG_CASE(10, 4) RG_CASE(16, 4)
 #undef RG_CASE
         return nullptr;
@@ -3567,6 +3693,14 @@ __global__ void k_tail_finish(DevSim d, uint32_t t0) {
 // Raw log: a wave reserves rows in chunks (one atomic per `chunk_rows` rows, not per row or per step) and
 // marks the entries it does not use (kHoleCode); the sort skips them.
 // ------------------------------------------------------------------------------------------
+// users a lane of k_walk holds at a time
+#ifndef RG_WALK_USERS
+#define RG_WALK_USERS 1
+#endif
+constexpr int kWalkUsers = RG_WALK_USERS;
+// LDS of one wave of k_walk: omega32 of its 2 x 64 users [entry][2 KH][64] + the mailbox + the rank table
+__host__ __device__ inline size_t walk_wave_lds(uint32_t KH) { return static_cast<size_t>(kWalkUsers) * 2 * KH * 64 * 4 + 64 * 24 + 64 * 4; }
+
 template <int KH, int OCC, bool DENSE>
 __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work, int round, uint32_t chunk_rows) {
     constexpr int K2 = 2 * KH;
@@ -3577,15 +3711,21 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
     constexpr int kPhantom = 4;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    // per wave: omega32 stage [64][K2] floats | float64 omega of the user being picked [K rounded to 2] | mailbox [64] {idx, A, B}
-    char* wbase = smem_raw + static_cast<size_t>(wave) * (64 * K2 * 4 + ((d.K + 1) & ~1u) * 8 + 64 * 24);
-    float* om_w = reinterpret_cast<float*>(wbase);
-    double* om_d = reinterpret_cast<double*>(wbase + 64 * K2 * 4);
-    double* mbox = om_d + ((d.K + 1) & ~1u);                       // [64][3]
+    // A lane holds kWalkUsers users and, each iteration, advances the first of them that is in the state the wave
+    // processes (see below): with one user per lane ~45 % of the lanes had nothing to do in an iteration.
+    constexpr int kIdle = 5;                                       // this iteration: none of the lane's users takes part
+    // per wave: omega32 of the lanes' users [entry][K2][64] (k-major: conflict-free; a lane keeps a user to its end, so
+    // omega is fetched once per USER; the recompute and the fp32 click decision read it) | mailbox [64] {idx, A, B}
+    char* wbase = smem_raw + static_cast<size_t>(wave) * walk_wave_lds(KH);
+    float* om32 = reinterpret_cast<float*>(wbase);
+    double* mbox = reinterpret_cast<double*>(om32 + kWalkUsers * K2 * 64);   // [64][3]
+    uint32_t* slots = reinterpret_cast<uint32_t*>(mbox + 64 * 3);  // [64] lanes of the searching users, by rank
     const uint32_t n_cc = d.PT / 64;
-    uint32_t slot = 0, user = 0, t = 0;
-    int st = kEmpty;
-    bool pending = false;                                          // round 2: the parked draw, to be picked in float64
+    uint32_t slotA[kWalkUsers], tA[kWalkUsers];
+    int stA[kWalkUsers];
+    bool pendA[kWalkUsers];                                        // round 2: the parked draw, to be picked in float64
+#pragma unroll
+    for (int e = 0; e < kWalkUsers; ++e) { slotA[e] = 0; tA[e] = 0; stA[e] = kEmpty; pendA[e] = false; }
     uint32_t res_next = 0, res_end = 0;                            // this wave's reservoir of queue tickets
     uint64_t row_next = 0, row_end = 0;                            // this wave's reserved raw-log rows
     uint32_t park_next = 0, park_end = 0;                          // this wave's reserved park_list entries
@@ -3594,8 +3734,10 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
     uint32_t c_maxt = 0, c_limit = 0;
 
     for (;;) {
-        // ---- refill the lanes whose user has stopped (or was parked) ----
-        unsigned long long dead = __ballot(st == kEmpty);
+        // ---- refill the entries whose user has stopped (or was parked) ----
+#pragma unroll
+        for (int e = 0; e < kWalkUsers; ++e) {
+        unsigned long long dead = __ballot(stA[e] == kEmpty);
         if (dead && !exhausted && (__popcll(dead) >= 8 || dead == ~0ull)) {
             for (int pass = 0; pass < 2 && dead; ++pass) {
                 if (res_next == res_end) {
@@ -3614,25 +3756,66 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
                     uint32_t s2 = idx;
                     if (round == 2) s2 = d.park_list[idx];
                     if (s2 != 0xFFFFFFFFu) {
-                        slot = s2;
-                        user = static_cast<uint32_t>(d.first_user + slot);
-                        st = RG_STATE_ORGANIC;                       // every user starts organic; parked users sit at an organic draw
-                        t = round == 2 ? d.park_t[slot] : 0u;
-                        pending = round == 2;
-                        if (round == 2) { d.f64_valid[slot] = 1; c_sweeps += 1; }   // k_exact_sums_u took its sums between the rounds
+                        slotA[e] = s2;
+                        stA[e] = RG_STATE_ORGANIC;                   // every user starts organic; parked users sit at an organic draw
+                        tA[e] = round == 2 ? d.park_t[s2] : 0u;
+                        pendA[e] = round == 2;
+                        if (round == 2) { d.f64_valid[s2] = 1; c_sweeps += 1; }   // k_exact_sums_u took its sums between the rounds
+                        // omega32 = float(omega), as k_cache_finalize left it in the user's cache row (floats 44 .. 44 + K2)
+                        const float4* rp = reinterpret_cast<const float4*>(d.cache_row + static_cast<size_t>(s2) * d.cache_row_f);
+                        float* o = om32 + e * (K2 * 64) + lane;
+#pragma unroll
+                        for (int k4 = 0; k4 < K2 / 4; ++k4) {
+                            const float4 x = rp[11 + k4];
+                            o[(4 * k4) * 64] = x.x; o[(4 * k4 + 1) * 64] = x.y; o[(4 * k4 + 2) * 64] = x.z; o[(4 * k4 + 3) * 64] = x.w;
+                        }
+#pragma unroll
+                        for (int k = (K2 / 4) * 4; k < K2; ++k) o[k * 64] = reinterpret_cast<const float*>(rp)[44 + k];
                     }
                 }
                 res_next += take;
-                dead = __ballot(st == kEmpty && !mine);              // lanes that drew an unused entry wait for the next refill
+                dead = __ballot(stA[e] == kEmpty && !mine);          // lanes that drew an unused entry wait for the next refill
             }
+        }
         }
         // (sorting the block's users by state through LDS so that waves are all-organic or all-bandit was measured
         // SLOWER, 352 vs 301 ms on C3: its two barriers per step serialise the block on its organic wave's latency chain)
-        const unsigned long long live = __ballot(st != kEmpty);
+        bool any_user = false, has_org = false, has_ban = false;
+#pragma unroll
+        for (int e = 0; e < kWalkUsers; ++e) {
+            any_user = any_user || stA[e] != kEmpty;
+            has_org = has_org || stA[e] == RG_STATE_ORGANIC;
+            has_ban = has_ban || stA[e] == RG_STATE_BANDIT || stA[e] == kPhantom;
+        }
+        const unsigned long long live = __ballot(any_user);
         if (!live) { if (exhausted) break; else continue; }
         {
+        // ---- ONE kind of event per iteration: the organic draw and the bandit event are different code, and a wave whose
+        // lanes are in both states executes both for every step at ~25 active lanes each.  The users are independent and
+        // every draw is addressed by (user, t), so the lanes in the minority state simply wait an iteration: the wave runs
+        // the path more of its lanes are ready for (organic weighted by walk_bias / 4: its path is the longer one). ----
+        bool run_org = true, run_ban = true;
+        if (d.walk_bias) {
+            const uint32_t n_ro = static_cast<uint32_t>(__popcll(__ballot(has_org)));
+            const uint32_t n_rb = static_cast<uint32_t>(__popcll(__ballot(has_ban)));
+            run_org = n_ro != 0 && n_ro * d.walk_bias >= n_rb * 4u;
+            run_ban = !run_org;
+        }
+        // this iteration's user of the lane: its first one in a state that is processed
+        int sel = -1;
+#pragma unroll
+        for (int e = kWalkUsers - 1; e >= 0; --e)
+            if ((run_org && stA[e] == RG_STATE_ORGANIC) || (run_ban && (stA[e] == RG_STATE_BANDIT || stA[e] == kPhantom))) sel = e;
+        uint32_t slot = slotA[0], t = tA[0];
+        int st = sel == 0 ? stA[0] : kIdle;
+        bool pending = pendA[0];
+#pragma unroll
+        for (int e = 1; e < kWalkUsers; ++e)
+            if (sel == e) { slot = slotA[e]; t = tA[e]; st = stA[e]; pending = pendA[e]; }
+        const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
+        const float* om_sel = om32 + max(sel, 0) * (K2 * 64);     // [K2][64]
         // ---- one raw-log row per lane that emits an event (not for the pending phantom rows: they have their own array) ----
-        const unsigned long long rowm = __ballot(st == RG_STATE_ORGANIC || st == RG_STATE_BANDIT);
+        const unsigned long long rowm = __ballot((run_org && st == RG_STATE_ORGANIC) || (run_ban && st == RG_STATE_BANDIT));
         const uint32_t nlive = static_cast<uint32_t>(__popcll(rowm));
         if (row_next + nlive > row_end) {
             for (uint64_t r = row_next + lane; r < row_end; r += 64)
@@ -3645,7 +3828,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
         }
         const uint64_t my_row = row_next + prefix_in_mask(rowm);
         row_next += nlive;
-        const bool alive = st == RG_STATE_ORGANIC || st == RG_STATE_BANDIT;
+        const bool alive = (run_org && st == RG_STATE_ORGANIC) || (run_ban && st == RG_STATE_BANDIT);
         const rg_u32x4 w = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
         const bool is_org = alive && st == RG_STATE_ORGANIC;
         bool parked = false;
@@ -3670,13 +3853,6 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
             }
             const float4 hdr = rp[8];
             const float4 of0 = rp[9], of1 = rp[10];
-            {
-                float* o = om_w + lane * K2;
-#pragma unroll
-                for (int k4 = 0; k4 < K2 / 4; ++k4) *reinterpret_cast<float4*>(o + 4 * k4) = rp[11 + k4];
-#pragma unroll
-                for (int k = (K2 / 4) * 4; k < K2; ++k) o[k] = reinterpret_cast<const float*>(rp)[44 + k];
-            }
             const float Q = hdr.x;
             const double delta = static_cast<double>(hdr.y);
             double S = 0.0;
@@ -3729,8 +3905,75 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
                 }
             }
             found_c = found_c && found_sc;
+            // ---- the 8-product group inside the chunk, where the sweep kept the group sums ----
+            uint32_t g_star = 3;
+            if (d.cache_sub) {
+                const float4 g4 = *reinterpret_cast<const float4*>(d.cache_sub + (row * d.n_chunks + c_star) * 4);
+                const double G0 = static_cast<double>(g4.x * f_star), G1 = static_cast<double>(g4.y * f_star),
+                             G2 = static_cast<double>(g4.z * f_star);
+                if (pb + G0 > tau) g_star = 0;
+                else if (pb + G0 + G1 > tau) { g_star = 1; pb = pb + G0; }
+                else if (pb + G0 + G1 + G2 > tau) { g_star = 2; pb = pb + G0 + G1; }
+                else pb = pb + G0 + G1 + G2;
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
+            if (d.cache_sub) {
+                // ---- the 8 products of the group (phase 3): 32 searching users per pass, two lanes per user, four
+                // products per lane — a quarter of the Gamma bytes of a whole chunk through the L1, and one latency
+                // chain for all the searching users of the step ----
+                const unsigned long long todo = __ballot(search);
+                const uint32_t n_todo = static_cast<uint32_t>(__popcll(todo));
+                if (search) slots[prefix_in_mask(todo)] = static_cast<uint32_t>(lane);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                const int grp = lane >> 1, gl = lane & 1;
+                for (uint32_t base = (d.ablate & (1u << 16)) ? n_todo : 0u; base < n_todo; base += 32) {
+                    const bool has = base + grp < n_todo;
+                    const int src = has ? static_cast<int>(slots[base + grp]) : 0;
+                    const uint32_t cs = static_cast<uint32_t>(__shfl(static_cast<int>(c_star), src));
+                    const uint32_t gs = static_cast<uint32_t>(__shfl(static_cast<int>(g_star), src));
+                    const float Qs = __shfl(Q, src);
+                    const double pbs = __shfl(pb, src), taus = __shfl(tau, src);
+                    const float4* gp = reinterpret_cast<const float4*>(d.gamma32t + (static_cast<size_t>(cs) * K2) * 32) + gs * 2 + gl;
+                    float4 l = *(reinterpret_cast<const float4*>(d.mu32 + cs * 32) + gs * 2 + gl);
+                    const float* o = om32 + __shfl(max(sel, 0), src) * (K2 * 64) + src;
+#pragma unroll
+                    for (int kh = 0; kh < K2; kh += KH) {
+                        float4 gk[KH];
+#pragma unroll
+                        for (int k = 0; k < KH; ++k) gk[k] = gp[(kh + k) * 8];
+#pragma unroll
+                        for (int k = 0; k < KH; ++k) {
+                            const float wk = o[(kh + k) * 64];
+                            l.x = fmaf(gk[k].x, wk, l.x); l.y = fmaf(gk[k].y, wk, l.y);
+                            l.z = fmaf(gk[k].z, wk, l.z); l.w = fmaf(gk[k].w, wk, l.w);
+                        }
+                        asm volatile("" : "+v"(l.x), "+v"(l.y), "+v"(l.z), "+v"(l.w));
+                    }
+                    const float e0 = __builtin_amdgcn_exp2f(fmaf(l.x, kLog2e, -Qs)), e1 = __builtin_amdgcn_exp2f(fmaf(l.y, kLog2e, -Qs));
+                    const float e2 = __builtin_amdgcn_exp2f(fmaf(l.z, kLog2e, -Qs)), e3 = __builtin_amdgcn_exp2f(fmaf(l.w, kLog2e, -Qs));
+                    const float q0 = e0, q1 = q0 + e1, q2 = q1 + e2, q3 = q2 + e3;      // prefix inside the lane
+                    float ex = __shfl_up(q3, 1, 2);                                     // ... and after the user's first lane
+                    if (gl == 0) ex = 0.0f;
+                    const double pxb = pbs + static_cast<double>(ex);
+                    const double px0 = pbs + static_cast<double>(ex + q0), px1 = pbs + static_cast<double>(ex + q1);
+                    const double px2 = pbs + static_cast<double>(ex + q2), px3 = pbs + static_cast<double>(ex + q3);
+                    const int j0 = px0 > taus ? 0 : px1 > taus ? 1 : px2 > taus ? 2 : px3 > taus ? 3 : -1;
+                    const unsigned long long hits = __ballot(has && j0 >= 0);
+                    const uint32_t gmask = static_cast<uint32_t>(hits >> (2 * grp)) & 3u;
+                    if (has) {
+                        if (gmask) {
+                            if (gl == __builtin_ctz(gmask)) {
+                                mbox[src * 3] = static_cast<double>(4 * gl + j0);
+                                mbox[src * 3 + 1] = j0 == 0 ? pxb : j0 == 1 ? px0 : j0 == 2 ? px1 : px2;
+                                mbox[src * 3 + 2] = j0 == 0 ? px0 : j0 == 1 ? px1 : j0 == 2 ? px2 : px3;
+                            }
+                        } else if (gl == 0) { mbox[src * 3] = -1.0; mbox[src * 3 + 1] = pbs; mbox[src * 3 + 2] = pbs; }
+                    }
+                }
+                if ((d.ablate & (1u << 16)) && search) { mbox[lane * 3] = 0.0; mbox[lane * 3 + 1] = 0.0; mbox[lane * 3 + 2] = 1e300; }
+            } else {
             // ---- the 32 products of the chosen chunk (phase 3): eight searching users per pass, eight lanes per
             // user, four products per lane.  A pass is ONE latency chain (user parameters -> 21 coalesced
             // 16-byte loads -> 80 fma -> 4 exp -> 3-step prefix across the user's lanes -> compare); two users
@@ -3753,7 +3996,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
                 const double pbs = __shfl(pb, s2), taus = __shfl(tau, s2);
                 const float4* gp = reinterpret_cast<const float4*>(d.gamma32t + (static_cast<size_t>(cs) * K2) * 32) + gl;
                 float4 l = *(reinterpret_cast<const float4*>(d.mu32 + cs * 32) + gl);
-                const float* o = om_w + s2 * K2;
+                const float* o = om32 + __shfl(max(sel, 0), s2) * (K2 * 64) + s2;
 #pragma unroll
                 for (int kh = 0; kh < K2; kh += KH) {          // two halves: KH 16-byte loads in flight, then their fmas
                     float4 gk[KH];
@@ -3761,7 +4004,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
                     for (int k = 0; k < KH; ++k) gk[k] = gp[(kh + k) * 8];
 #pragma unroll
                     for (int k = 0; k < KH; ++k) {
-                        const float wk = o[kh + k];
+                        const float wk = o[(kh + k) * 64];
                         l.x = fmaf(gk[k].x, wk, l.x); l.y = fmaf(gk[k].y, wk, l.y);
                         l.z = fmaf(gk[k].z, wk, l.z); l.w = fmaf(gk[k].w, wk, l.w);
                     }
@@ -3794,6 +4037,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
                     } else if (gl == 0) { mbox[src * 3] = -1.0; mbox[src * 3 + 1] = pbs; mbox[src * 3 + 2] = pbs; }
                 }
             }
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             uint32_t v = 0;
@@ -3801,7 +4045,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
             if (search) {
                 const int idx = static_cast<int>(mbox[lane * 3]);
                 const double Av = mbox[lane * 3 + 1], Bv = mbox[lane * 3 + 2];
-                v = c_star * 32 + static_cast<uint32_t>(max(idx, 0));
+                v = c_star * 32 + (d.cache_sub ? g_star * 8 : 0u) + static_cast<uint32_t>(max(idx, 0));
                 ok = found_c && idx >= 0 && v < d.P &&
                      (v == 0 || Av * (1.0 + delta) < tau * (1.0 - delta)) &&
                      (v == d.P - 1 || tau * (1.0 + delta) < Bv * (1.0 - delta));
@@ -3816,11 +4060,9 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
                 picks &= picks - 1;
                 const uint32_t s_slot = static_cast<uint32_t>(__shfl(static_cast<int>(slot), L));
                 const double s_u = __shfl(u_org, L);
-                for (uint32_t k = lane; k < d.K; k += 64) om_d[k] = d.omega[static_cast<size_t>(s_slot) * d.OMS + k];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
                 const double M = static_cast<double>(d.exact_ref[s_slot]) * 0.69314718055994530942;
-                const uint32_t pv = exact_pick_wave(d, d.exact_sums + static_cast<size_t>(s_slot) * n_cc, om_d, M, s_u, 1u, lane);
+                const uint32_t pv = exact_pick_wave(d, d.exact_sums + static_cast<size_t>(s_slot) * n_cc,
+                                                    d.omega + static_cast<size_t>(s_slot) * d.OMS, M, s_u, 1u, lane);
                 if (lane == L) { v = pv; c_pick += 1; }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -3859,7 +4101,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
             park_next += np;
         }
         // =========================== bandit event + transition (k_advance's arithmetic) ===========================
-        const bool is_ban = st == RG_STATE_BANDIT, is_ph = st == kPhantom;
+        const bool is_ban = run_ban && st == RG_STATE_BANDIT, is_ph = run_ban && st == kPhantom;
         double ps = 1.0;
         uint32_t a = 0;
         if (is_ban || is_ph) a = (d.ablate & (1u << 18)) ? (user + t) % d.P : policy_act<DENSE>(d, slot, user, t, &ps);
@@ -3876,7 +4118,49 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
         if (alive && !parked) {
             const double u_trans = rg_uniform(w.w[2], w.w[3]);
             bool click = false;
-            if (is_ban) {
+            // The click is a Bernoulli draw against ff(beta[a].omega + mu_b[a]) (three nested sigmoids: three float64
+            // exps and four divisions).  Its outcome is decided in fp32 wherever the fp32 value of 1 - ff is further from
+            // the uniform than the fp32 error bound (fp32 dot: (K + 2) 2^-24 sum|beta_k omega_k|, damped by the chain's
+            // slope <= 0.05; three v_exp / v_rcp at ~1e-6); the float64 evaluation below is for the lanes inside that
+            // band (~4e-5 of the acts) and for runs that export the click probability.
+            bool click_known = false;
+            if (is_ban && !d.aux_pclick && !(d.ablate & (1u << 21))) {
+                const float4* b4 = reinterpret_cast<const float4*>(d.beta32 + static_cast<size_t>(a) * d.KB4);
+                const float* om = om_sel + lane;
+                float x = 0.0f, ax = 0.0f;
+                for (uint32_t k0 = 0; k0 < d.KB4; k0 += 8) {
+                    const float4 v0 = b4[k0 / 4], v1 = k0 + 4 < d.KB4 ? b4[k0 / 4 + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float bb[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (k0 + i < d.K) {
+                            const float wk = om[(k0 + i) * 64];
+                            x = fmaf(bb[i], wk, x);
+                            ax = fmaf(fabsf(bb[i]), fabsf(wk), ax);
+                        }
+                }
+                const float mb = static_cast<float>(d.mu_b[a]);
+                auto sig32 = [](float z) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * z)); };
+                const float ctr32 = sig32(5.0f * sig32(2.0f * sig32(0.3f * (x + mb)) - 2.0f) - 6.0f);
+                const float margin = 2.0e-5f + 1.0e-6f * (ax + fabsf(mb));
+                const float p0 = 1.0f - ctr32;
+                const float uf = static_cast<float>(rg_uniform(w.w[0], w.w[1]));
+                if (p0 < uf - margin) { click = true; click_known = true; }
+                else if (p0 > uf + margin) { click = false; click_known = true; }
+            }
+            if (is_ban && click_known) {
+                c_clicks += click;
+                c_ban += 1;
+                if (d.log && my_row < d.log_cap) {
+                    rg_event e;
+                    e.u = user; e.t = t;
+                    e.code = RG_EV_BANDIT | (click ? RG_EV_CLICK : 0u) | a;
+                    e.ps = static_cast<float>(ps);
+                    d.log[my_row] = e;
+                    if (d.aux_ps) d.aux_ps[my_row] = ps;
+                }
+            }
+            if (is_ban && !click_known) {
                 const double* b = d.beta + static_cast<size_t>(a) * d.K;
                 const double* om = d.omega + static_cast<size_t>(slot) * d.OMS;
                 double x = 0.0;
@@ -3942,6 +4226,9 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
             if (ns == RG_STATE_STOP) st = kEmpty;
             else { st = ns; t += 1; }
         }
+#pragma unroll
+        for (int e = 0; e < kWalkUsers; ++e)
+            if (sel == e) { stA[e] = st; tA[e] = t; pendA[e] = pending; }
         }   // if (live)
     }
     // ---- leftovers of the reserved chunks, counters ----
@@ -4431,7 +4718,7 @@ int run_walk(rg_sim* sim, hipStream_t st) {
     hipLaunchKernelGGL(finalize_kernel_for(d), dim3(grid_for(d.n_users)), dim3(kBlock), 0, st, d);
     if (int rc = mark(2)) return rc;
     // 2. round 1: every user from t = 0 to its end or to its first uncertified draw
-    const size_t smem = (kBlock / 64) * (static_cast<size_t>(64) * 2 * d.KH * 4 + ((d.K + 1) & ~1u) * 8 + 64 * 24);
+    const size_t smem = (kBlock / 64) * walk_wave_lds(d.KH);
     auto launch_walk = [&](uint32_t n_work, int round) {
         const int occ = d.KH <= 16 ? sim->walk_occ : 1;
         const int blocks_cap = sim->n_cus * occ;
@@ -4444,6 +4731,9 @@ int run_walk(rg_sim* sim, hipStream_t st) {
         chunk = chunk / 64 * 64;
         if (chunk < 256) chunk = 256;
         if (chunk > 4096) chunk = 4096;
+        if (smem > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(walk_kernel_for(d, occ)), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      static_cast<int>(smem));
         hipLaunchKernelGGL(walk_kernel_for(d, occ), dim3(blocks), dim3(kBlock), smem, st, d, n_work, round, static_cast<uint32_t>(chunk));
     };
     launch_walk(d.n_users, 1);
@@ -4574,6 +4864,11 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     // the per-user sum cache is written by the pipelined 16-bit kernel only
     if (!(d.use_mfma == 2 && s->bf16_kernel &&
           (s->bf16_kernel == bf16p_kernel_for(d) || (d.wide && s->bf16_kernel == f16w_kernel_for(d))))) d.use_cache = 0;
+    if (!d.use_cache && d.cache_sub) {          // no cache, no group sums: back to the plain instantiation of the sweep
+        const bool was_p = s->bf16_kernel == bf16p_kernel_for(d);
+        d.cache_sub = nullptr;
+        if (was_p) s->bf16_kernel = bf16p_kernel_for(d);
+    }
     if (s->bf16_kernel && s->bf16_smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s->bf16_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->bf16_smem));
@@ -4602,6 +4897,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     if (d.time_mode) { s->walk = false; s->tail_below = 0; }      // per-user clocks: the lock-step kernels only
     s->n_cus = 0;
     s->walk_occ = 3;
+    d.walk_bias = 8;
+    if (const char* e = getenv("RECOGYM_WALK_BIAS")) d.walk_bias = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_OCC")) { const int o = atoi(e); if (o >= 2 && o <= 4) s->walk_occ = o; }
     s->prof_walk_ms[0] = s->prof_walk_ms[1] = 0.0;
     if (const char* e = getenv("RECOGYM_TAIL")) s->tail_below = static_cast<uint32_t>(atoi(e));
@@ -4644,6 +4941,9 @@ int rg_sim_set_tables(rg_sim* sim, const double* d_gamma, const double* d_mu_org
                        static_cast<hipStream_t>(stream), sim->d);
     if (sim->d.XKB)
         hipLaunchKernelGGL(k_make_gamma_rm, dim3(grid_for(static_cast<size_t>(sim->d.PT) * (4 * sim->d.XKB + 4))), dim3(kBlock), 0,
+                           static_cast<hipStream_t>(stream), sim->d);
+    if (sim->d.beta32)
+        hipLaunchKernelGGL(k_make_beta32, dim3(grid_for(static_cast<size_t>(sim->d.P) * sim->d.KB4)), dim3(kBlock), 0,
                            static_cast<hipStream_t>(stream), sim->d);
     if (sim->d.use_mfma) {
         const size_t n = static_cast<size_t>(sim->d.P_pad) * sim->d.KS;

@@ -563,7 +563,7 @@ def test_certificate_is_sound_for_uniforms_next_to_cdf_boundaries(mode, shape, m
     assert clear.mean() > 0.95
 
 
-@pytest.mark.parametrize('variant', ['default', 'sliced', 'nowalk', 'repack', 'lockstep', 'nowalk_sliced'])
+@pytest.mark.parametrize('variant', ['default', 'fastclick', 'sub', 'sliced', 'nowalk', 'repack', 'lockstep', 'nowalk_sliced'])
 @pytest.mark.parametrize('shape', [(129, 9, 1500, 40), (2049, 20, 500, 0), (10000, 20, 150, 0), (33, 3, 2500, 0)])
 def test_sigma_omega_zero_sum_cache_matches_the_oracle(shape, variant, monkeypatch):
     """sigma_omega = 0 (BASELINE configs 2 and 3): a user's omega never changes, so the exp-sums of its first
@@ -584,12 +584,16 @@ def test_sigma_omega_zero_sum_cache_matches_the_oracle(shape, variant, monkeypat
         monkeypatch.setenv('RECOGYM_TAIL', '0')
     if variant in ('sliced', 'nowalk_sliced'):
         monkeypatch.setenv('RECOGYM_SLICES', '4')
+    if variant == 'sub':             # opt-in: the sweep also keeps 8-product group sums, the walk recomputes a group
+        monkeypatch.setenv('RECOGYM_SUB', '1')
     pol = dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=31, ouc=dict(gu.OUC_DEFAULTS))
     cfg = Configuration({**env_1_args, 'random_seed': 700 + P, 'num_products': P, 'K': K, 'sigma_omega': 0.0})
     want_env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol)
     want = want_env.generate_logs(n, n_org)
-    rows, cnt = run_sim(cfg, n, n_org, **pol)
-    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps', 'p_click')},
+    # 'fastclick': without the click-probability export the walk decides the clicks in fp32 wherever that is certain
+    rows, cnt = run_sim(cfg, n, n_org, **pol, **(dict(p_click=False) if variant == 'fastclick' else {}))
+    cols = ('u', 't', 'z', 'v', 'a', 'c', 'ps') + (() if variant == 'fastclick' else ('p_click',))
+    gu.assert_rows_equal(rows, {k: want[k] for k in cols},
                          ps_rtol=1e-12, what=f'sigma0 cache {shape} {variant}')
     assert (rows['phantom'] == want['phantom']).all()
     assert cnt['exact_sweeps'] <= cnt['exact_draws'] and cnt['live'] == 0
