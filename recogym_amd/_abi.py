@@ -103,7 +103,8 @@ _lib = None
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', LIB_NAME)
+    # RECOGYM_HIP_LIB: another build of the same source (A/B measurements of compile-time switches)
+    return os.environ.get('RECOGYM_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', LIB_NAME)
 
 
 class RecoGymHipError(RuntimeError):

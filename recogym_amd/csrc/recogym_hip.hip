@@ -765,22 +765,24 @@ __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, ui
             // time, instead of a division and a float64 sum per product — and the walk in float64 is only taken by a
             // lane that lands inside that band (~1e-10 of the acts).
             const double T = u1 * sum;
-            const double T_hi = T * (1.0 + 0x1p-36), T_lo = T * (1.0 - 0x1p-36);
+            // C integer: C > T_hi <=> C > floor(T_hi), !(C < T_lo) <=> C >= ceil(T_lo) — the loop compares integers
+            const uint32_t Thi = static_cast<uint32_t>(fmin(floor(T * (1.0 + 0x1p-36)), 4294967295.0));
+            const uint32_t Tlo = static_cast<uint32_t>(fmin(ceil(T * (1.0 - 0x1p-36)), 4294967295.0));
             uint32_t C = 0, a_f = 0, c_f = 0;
             bool found = false, amb = false;
             hent_t f[kHistRegs];
 #pragma unroll
             for (int i = 0; i < kHistRegs; ++i) f[i] = e[i];
             for (uint32_t base = 0; base <= nd && !found; base += kHistRegs) {
-                if (base) hist_load_line(hr + base, f);            // (rows are whole 16-entry lines: hist_cap is even and >= 16)
+                if (base && (d.ablate & (1u << 22))) { found = true; a_f = 0; c_f = 1; break; }   // timing experiment: first line only
+                if (base) hist_load_line(hr + base, f);            // (rows are whole 16-entry lines)
 #pragma unroll
                 for (int i = 0; i < kHistRegs; ++i) {
                     const uint32_t idx = base + i;
                     if (idx >= 1 && idx <= nd && !found) {
                         C += h_cnt(f[i]);
-                        const double Cd = static_cast<double>(C);
-                        if (Cd > T_hi) { found = true; a_f = h_prod(f[i]); c_f = h_cnt(f[i]); }
-                        else if (!(Cd < T_lo)) amb = true;
+                        if (C > Thi) { found = true; a_f = h_prod(f[i]); c_f = h_cnt(f[i]); }
+                        else if (C >= Tlo) amb = true;
                     }
                 }
             }
@@ -941,6 +943,7 @@ __device__ void history_add(const DevSim& d, uint32_t slot, uint32_t v) {
     }
     // longer histories: the position a line of 16 entries at a time (8 independent loads and 16 compares instead of a
     // dependent load per entry), the shift four entries at a time from the top
+    if (d.ablate & (1u << 22)) return;          // timing experiment: histories stop growing at one line
     uint32_t pos = 1;                           // first entry with product >= v (nd + 1 if none)
     hent_t at = 0ull;                           // the entry there
     bool past = false;
@@ -3702,7 +3705,15 @@ constexpr int kWalkUsers = RG_WALK_USERS;
 __host__ __device__ inline size_t walk_wave_lds(uint32_t KH) { return static_cast<size_t>(kWalkUsers) * 2 * KH * 64 * 4 + 64 * 24 + 64 * 4; }
 
 template <int KH, int OCC, bool DENSE>
-__global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work, int round, uint32_t chunk_rows) {
+__global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_work, int round, uint32_t chunk_rows) {
+    // The ~60 fields of DevSim this kernel uses do not fit the scalar registers next to its own state: kept live across
+    // the loop they were spilled into VGPR lanes (v_writelane / v_readlane: ~10 % of the kernel's VALU instructions, the
+    // unit that bounds it).  They are read from the kernel-argument segment instead — scalar loads, at the point of use:
+    // the pointer is laundered once per iteration so that the loads are not hoisted out of the loop again.
+    (void)d_arg;
+    const __attribute__((address_space(4))) char* kargs =
+        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    const DevSim& d = *(const DevSim*)kargs;
     constexpr int K2 = 2 * KH;
     constexpr int kEmpty = 3;
     // a user that stops still owes its phantom row (one more policy act, abstract.py:311-316): it takes it on its lane's
@@ -3734,6 +3745,8 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d, uint32_t n_work,
     uint32_t c_maxt = 0, c_limit = 0;
 
     for (;;) {
+        asm volatile("" : "+s"(kargs));
+        const DevSim& d = *(const DevSim*)kargs;
         // ---- refill the entries whose user has stopped (or was parked) ----
 #pragma unroll
         for (int e = 0; e < kWalkUsers; ++e) {
@@ -4743,6 +4756,11 @@ int run_walk(rg_sim* sim, hipStream_t st) {
     HIP_TRY(hipMemcpyAsync(h64, d.counters + kCntParkCnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const uint32_t n_park = static_cast<uint32_t>(*h64);
+    if (getenv("RECOGYM_DEBUG")) {
+        unsigned long long ev2[2] = {0, 0};
+        HIP_TRY(hipMemcpy(ev2, d.counters + kCntTailOrganic, sizeof(ev2), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[recogym] walk round 1: %llu organic + %llu bandit events, %u users parked of %u\n", ev2[0], ev2[1], n_park, d.n_users);
+    }
     if (n_park) {
         exact_u_kernel_t ku = exact_u_kernel_for(d.XKB);
         if (!ku) return fail(RG_ESTATE, "no user-per-lane float64 kernel for K = %u", d.K);
