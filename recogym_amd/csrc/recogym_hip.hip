@@ -1238,8 +1238,14 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums(DevSim d, uint32_t t, int
 // Work item = (64 users of the list, one slice of the 64-product chunks); one sum per chunk.
 typedef const __attribute__((address_space(4))) double kdouble;   // constant address space: uniform loads become s_load
 
+// users per lane of k_exact_sums_u: two for K <= 20 (every Gamma row fetched through the scalar cache then feeds two
+// independent chains of K dependent FMAs — the row's load latency was exposed once per product and chain), one beyond
+// (omega alone is 2 x 4 KB registers per user)
+__host__ __device__ constexpr int exact_upl_of(uint32_t kb) { return kb <= 5 ? 2 : 1; }
+
 template <int KB>
 __global__ void __launch_bounds__(kBlock) k_exact_sums_u(DevSim d, uint32_t t, int from_list, int mode, uint32_t S) {
+    constexpr int UPL = exact_upl_of(KB);
     __shared__ double exp_tab[32];
     if (threadIdx.x < 32) exp_tab[threadIdx.x] = kExp2Tab32[threadIdx.x];
     __syncthreads();
@@ -1254,7 +1260,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_u(DevSim d, uint32_t t, i
     uint32_t n = from_list == 2 ? t : (from_list ? d.exact_cnt[t] : n_o);
     if (batched) n = min(n, base + d.exact_rows);
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
-    const uint32_t n_groups = n > base ? (n - base + 63) / 64 : 0u;
+    const uint32_t n_groups = n > base ? (n - base + 64 * UPL - 1) / (64 * UPL) : 0u;
     const uint32_t ccps = (n_cc + S - 1) / S;                  // chunks per slice
     const uint32_t n_work = n_groups * S;
     constexpr uint32_t RSd = 4 * KB + 4;
@@ -1262,39 +1268,69 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_u(DevSim d, uint32_t t, i
         const uint32_t grp = wk / S, slice = wk % S;
         const uint32_t cc0 = slice * ccps, cc1 = min(cc0 + ccps, n_cc);
         if (cc0 >= cc1) continue;
-        uint32_t w_idx = base + grp * 64 + lane;
-        bool act = w_idx < n;
-        uint32_t slot;
-        if (from_list == 2) {
-            slot = act ? d.park_list[w_idx] : 0xFFFFFFFFu;
-            act = slot != 0xFFFFFFFFu;
-            if (!act) slot = 0u;
-            w_idx = slot;                                                  // slot == user index: nothing was repacked
-        } else {
-            const uint32_t pos = act ? (from_list ? d.exact_list[w_idx] : w_idx) : 0u;
-            slot = act ? cur[pos] : 0u;
-            if (from_list && d.use_cache && act) w_idx = d.uid[slot];         // sums / reference rows are per user in this mode
-        }
-        double om[4 * KB];
+        uint32_t w_idx[UPL];
+        bool act[UPL];
+        double om[UPL][4 * KB], M[UPL];
 #pragma unroll
-        for (int k = 0; k < 4 * KB; ++k)
-            om[k] = (act && static_cast<uint32_t>(k) < d.K) ? d.omega[static_cast<size_t>(slot) * d.OMS + k] : 0.0;
-        const double M = (mode == 1 && act) ? static_cast<double>(d.exact_ref[w_idx]) * 0.69314718055994530942 : 0.0;
-        for (uint32_t cc = cc0; cc < cc1; ++cc) {
-            double acc = mode == 0 ? -INFINITY : 0.0;
-            const uint32_t p1 = cc * 64 + 64;                  // PT is a multiple of 64
-#pragma unroll 2
-            for (uint32_t p = cc * 64; p < p1; ++p) {
-                kdouble* row = (kdouble*)(d.gamma_rm) + static_cast<size_t>(p) * RSd;   // C-style: address-space cast
-                // same association as the oracle / numpy: (sum_k Gamma[p][k] omega[k]) + mu[p], k ascending
-                // (the zero-padded k leave the sum unchanged)
-                double l = 0.0;
-#pragma unroll
-                for (int k = 0; k < 4 * KB; ++k) l += row[k] * om[k];
-                l += row[4 * KB];                              // -inf for products >= P: exp gives exactly 0
-                acc = mode == 0 ? fmax(acc, l) : acc + exp64t(l - M, exp_tab);
+        for (int j = 0; j < UPL; ++j) {
+            w_idx[j] = base + grp * (64 * UPL) + j * 64 + lane;
+            act[j] = w_idx[j] < n;
+            uint32_t slot;
+            if (from_list == 2) {
+                slot = act[j] ? d.park_list[w_idx[j]] : 0xFFFFFFFFu;
+                act[j] = slot != 0xFFFFFFFFu;
+                if (!act[j]) slot = 0u;
+                w_idx[j] = slot;                                               // slot == user index: nothing was repacked
+            } else {
+                const uint32_t pos = act[j] ? (from_list ? d.exact_list[w_idx[j]] : w_idx[j]) : 0u;
+                slot = act[j] ? cur[pos] : 0u;
+                if (from_list && d.use_cache && act[j]) w_idx[j] = d.uid[slot];   // sums / reference rows are per user in this mode
             }
-            if (act) d.exact_sums[static_cast<size_t>(w_idx - (batched ? base : 0u)) * n_cc + cc] = acc;
+#pragma unroll
+            for (int k = 0; k < 4 * KB; ++k)
+                om[j][k] = (act[j] && static_cast<uint32_t>(k) < d.K) ? d.omega[static_cast<size_t>(slot) * d.OMS + k] : 0.0;
+            M[j] = (mode == 1 && act[j]) ? static_cast<double>(d.exact_ref[w_idx[j]]) * 0.69314718055994530942 : 0.0;
+        }
+        for (uint32_t cc = cc0; cc < cc1; ++cc) {
+            double acc[UPL];
+            const uint32_t p1 = cc * 64 + 64;                  // PT is a multiple of 64
+            // same association as the oracle / numpy: (sum_k Gamma[p][k] omega[k]) + mu[p], k ascending (the zero-padded
+            // k leave the sum unchanged); mu = -inf for products >= P: exp gives exactly 0
+            if (mode == 0) {
+#pragma unroll
+                for (int j = 0; j < UPL; ++j) acc[j] = -INFINITY;
+                for (uint32_t p = cc * 64; p < p1; ++p) {
+                    kdouble* row = (kdouble*)(d.gamma_rm) + static_cast<size_t>(p) * RSd;   // C-style: address-space cast
+#pragma unroll
+                    for (int j = 0; j < UPL; ++j) {
+                        double l = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 4 * KB; ++k) l += row[k] * om[j][k];
+                        acc[j] = fmax(acc[j], l + row[4 * KB]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < UPL; ++j) acc[j] = 0.0;
+#pragma unroll 2
+                for (uint32_t p = cc * 64; p < p1; ++p) {
+                    kdouble* row = (kdouble*)(d.gamma_rm) + static_cast<size_t>(p) * RSd;
+                    double l[UPL];
+#pragma unroll
+                    for (int j = 0; j < UPL; ++j) l[j] = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 4 * KB; ++k) {
+                        const double g = row[k];
+#pragma unroll
+                        for (int j = 0; j < UPL; ++j) l[j] += g * om[j][k];
+                    }
+#pragma unroll
+                    for (int j = 0; j < UPL; ++j) acc[j] += exp64t(l[j] + row[4 * KB] - M[j], exp_tab);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < UPL; ++j)
+                if (act[j]) d.exact_sums[static_cast<size_t>(w_idx[j] - (batched ? base : 0u)) * n_cc + cc] = acc[j];
         }
     }
 }
@@ -4552,7 +4588,8 @@ void launch_exact(rg_sim* sim, uint32_t t, int from_list, uint64_t est, hipStrea
         d.exact_last = b + 1 == n_batches ? 1u : 0u;
         if (batched && est > d.exact_rows) est = d.exact_rows;
         if (exact_u_kernel_t ku = (getenv("RECOGYM_EXACT_TILE") ? nullptr : exact_u_kernel_for(d.XKB))) {
-            const uint64_t groups = (est + 63) / 64;
+            const uint64_t upl = 64ull * exact_upl_of(d.XKB);
+            const uint64_t groups = (est + upl - 1) / upl;
             // The kernel's stall is the scalar-load latency of a Gamma row (the table streams through
             // L2), hidden only by other waves: fill every SIMD to the kernel's occupancy (6 waves) and
             // cut the work ~4x finer than that so the grid-stride loop balances.
@@ -4765,7 +4802,8 @@ int run_walk(rg_sim* sim, hipStream_t st) {
         exact_u_kernel_t ku = exact_u_kernel_for(d.XKB);
         if (!ku) return fail(RG_ESTATE, "no user-per-lane float64 kernel for K = %u", d.K);
         const uint32_t n_chunks = d.PT / 64;
-        const uint64_t groups = (static_cast<uint64_t>(n_park) + 63) / 64;
+        const uint64_t upl = 64ull * exact_upl_of(d.XKB);
+        const uint64_t groups = (static_cast<uint64_t>(n_park) + upl - 1) / upl;
         uint32_t S = static_cast<uint32_t>(24576 / groups);
         if (S > n_chunks) S = n_chunks;
         if (S < 1) S = 1;
