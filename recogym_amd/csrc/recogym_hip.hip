@@ -104,6 +104,7 @@ struct DevSim {
     uint32_t exact_rows;      // rows of exact_sums: n_cap where they are per-user constants (sigma_omega = 0 cache) or every
                               // draw goes through float64; else max(4096, n_cap / 8) — a step's uncertified draws (a few percent
                               // of its organic users) are resolved in batches of that many list entries
+    uint32_t walk_refill;     // k_walk: free lanes of a wave at which it takes new users from the queue
     uint32_t walk_bias;       // k_walk: 0 = both event kinds every iteration; else one kind, organic when n_org * walk_bias >= n_bandit * 4
     uint32_t exact_base;      // first exact_list entry of the batch being resolved
     uint32_t exact_last;      // this is the last batch launched for the step
@@ -1333,6 +1334,171 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_u(DevSim d, uint32_t t, i
                 if (act[j]) d.exact_sums[static_cast<size_t>(w_idx[j] - (batched ? base : 0u)) * n_cc + cc] = acc[j];
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_exact_sums_m — the float64 chunk sums on the float64 MATRIX cores (v_mfma_f64_16x16x4_f64).
+//
+// Same job and output as k_exact_sums_u (exp-sum, or maximum in mode 0, of every 64-product chunk, per user).  There
+// a lane owns a user and every product costs K dependent v_fma_f64 fed by scalar loads of the Gamma row plus ~18
+// VALU instructions of exp — all on the vector ALU (44-47 % of its float64 peak at K = 20, 16 % at K = 64 where omega
+// alone is 128 registers).  Here the dot products move to the matrix pipe, which runs beside the VALU:
+//   D[product i][user j] += Gamma[i][4s..4s+3] . omega_j[4s..4s+3]        16 products x 16 users x 4 k per MFMA
+// A = the Gamma rows of a 64-product chunk staged in LDS by the block (a straight copy of gamma_rm, mu in the last
+// column), B = omega of 16 users (register resident for the work item), 4 (K <= 32) or 2 groups of 16 users per wave
+// so that every A fragment read from LDS feeds 4 / 2 MFMAs; the VALU only adds mu, subtracts the reference and takes
+// the exp of the 4 logits a lane gets per group and tile.  The matrix unit's accumulation order differs from the
+// k-ascending chain (as the oracle's differs from OpenBLAS'): a 1e-16-level difference, decisions unchanged.
+// C/D layout of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * reg.
+// ------------------------------------------------------------------------------------------
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+__host__ __device__ constexpr int exact_m_groups(uint32_t kb) { return kb <= 8 ? 4 : 2; }
+__host__ __device__ constexpr uint32_t exact_m_lds(uint32_t kb) { return (2u * 64u * (4u * kb + 4u) + 32u) * 8u; }
+
+template <int KB>
+__global__ void __launch_bounds__(kBlock) k_exact_sums_m(DevSim d, uint32_t t, int from_list, int mode, uint32_t S) {
+    constexpr int G = exact_m_groups(KB);
+    constexpr uint32_t UPW = 16 * G, UPB = (kBlock / 64) * UPW;      // users per wave / per block
+    constexpr uint32_t RSd = 4 * KB + 4, TILE = 64 * RSd;            // doubles per staged chunk
+    constexpr int NLD = (TILE / 2 + kBlock - 1) / kBlock;            // 16-byte pieces of a chunk per thread
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* tiles = reinterpret_cast<double*>(smem_raw);             // [2][TILE]
+    double* exp_tab = tiles + 2 * TILE;
+    if (threadIdx.x < 32) exp_tab[threadIdx.x] = kExp2Tab32[threadIdx.x];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int q = lane >> 4, jl = lane & 15;
+    const uint32_t n_cc = d.PT / 64;
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const bool batched = from_list == 1 && !d.use_cache;
+    const uint32_t base = batched ? d.exact_base : 0u;
+    uint32_t n = from_list == 2 ? t : (from_list ? d.exact_cnt[t] : n_o);
+    if (batched) n = min(n, base + d.exact_rows);
+    const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const uint32_t n_groups = n > base ? (n - base + UPB - 1) / UPB : 0u;
+    const uint32_t ccps = (n_cc + S - 1) / S;                        // chunks per slice
+    const uint32_t n_work = n_groups * S;
+    for (uint32_t wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
+        const uint32_t grp = wk / S, slice = wk % S;
+        const uint32_t cc0 = slice * ccps, cc1 = min(cc0 + ccps, n_cc);
+        if (cc0 >= cc1) continue;
+        // ---- this lane's users: group g, column jl (the four lane quarters hold the same users, other rows) ----
+        uint32_t row[G];
+        bool act[G];
+        double b[G][KB], M[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            uint32_t w_idx = base + grp * UPB + wave * UPW + g * 16 + jl;
+            act[g] = w_idx < n;
+            uint32_t slot;
+            if (from_list == 2) {
+                slot = act[g] ? d.park_list[w_idx] : 0xFFFFFFFFu;
+                act[g] = slot != 0xFFFFFFFFu;
+                if (!act[g]) slot = 0u;
+                w_idx = slot;
+            } else {
+                const uint32_t pos = act[g] ? (from_list ? d.exact_list[w_idx] : w_idx) : 0u;
+                slot = act[g] ? cur[pos] : 0u;
+                if (from_list && d.use_cache && act[g]) w_idx = d.uid[slot];
+            }
+            row[g] = w_idx - (batched ? base : 0u);
+#pragma unroll
+            for (int s2 = 0; s2 < KB; ++s2) {
+                const uint32_t k = 4 * s2 + q;
+                b[g][s2] = (act[g] && k < d.K) ? d.omega[static_cast<size_t>(slot) * d.OMS + k] : 0.0;
+            }
+            M[g] = (mode == 1 && act[g]) ? static_cast<double>(d.exact_ref[w_idx]) * 0.69314718055994530942 : 0.0;
+        }
+        // ---- chunks of the slice: the next one is fetched into registers while this one is used ----
+        double2 pf[NLD];
+        auto fetch = [&](uint32_t cc) {
+            const double2* src = reinterpret_cast<const double2*>(d.gamma_rm + static_cast<size_t>(cc) * TILE);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const uint32_t idx = threadIdx.x + i * kBlock;
+                if (idx < TILE / 2) pf[i] = src[idx];
+            }
+        };
+        auto stash = [&](uint32_t buf) {
+            double2* dst = reinterpret_cast<double2*>(tiles + buf * TILE);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const uint32_t idx = threadIdx.x + i * kBlock;
+                if (idx < TILE / 2) dst[idx] = pf[i];
+            }
+        };
+        __syncthreads();                       // the previous work item is done with both buffers
+        fetch(cc0);
+        stash(0);
+        for (uint32_t cc = cc0; cc < cc1; ++cc) {
+            __syncthreads();                   // chunk cc is in its buffer; the other one is free
+            const bool more = cc + 1 < cc1;
+            if (more) fetch(cc + 1);
+            const double* A = tiles + ((cc - cc0) & 1u) * TILE;
+            double sum[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) sum[g] = mode == 0 ? -INFINITY : 0.0;
+#pragma unroll 1
+            for (int tt = 0; tt < 4; ++tt) {
+                f64x4 acc[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g] = f64x4{0.0, 0.0, 0.0, 0.0};
+                const double* arow = A + static_cast<size_t>(tt * 16 + jl) * RSd + q;
+#pragma unroll
+                for (int s2 = 0; s2 < KB; ++s2) {
+                    const double a = arow[4 * s2];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[g][s2], acc[g], 0, 0, 0);
+                }
+                double mu[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mu[r] = A[static_cast<size_t>(tt * 16 + q + 4 * r) * RSd + 4 * KB];   // -inf for products >= P
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double l = acc[g][r] + mu[r];
+                        sum[g] = mode == 0 ? fmax(sum[g], l) : sum[g] + exp64t(l - M[g], exp_tab);
+                    }
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                double x = sum[g];
+                const double y = __shfl_xor(x, 16);
+                x = mode == 0 ? fmax(x, y) : x + y;
+                const double z = __shfl_xor(x, 32);
+                x = mode == 0 ? fmax(x, z) : x + z;
+                if (q == (g & 3) && act[g]) d.exact_sums[static_cast<size_t>(row[g]) * n_cc + cc] = x;
+            }
+            if (more) stash(((cc - cc0) & 1u) ^ 1u);
+        }
+    }
+}
+
+typedef void (*exact_m_kernel_t)(DevSim, uint32_t, int, int, uint32_t);
+exact_m_kernel_t exact_m_kernel_for(uint32_t kb) {
+    if (const char* e = getenv("RECOGYM_EXACT")) if (!strcmp(e, "valu")) return nullptr;     // A/B: the vector-ALU kernel
+    switch (kb) {
+        case 1: return k_exact_sums_m<1>;   case 2: return k_exact_sums_m<2>;   case 3: return k_exact_sums_m<3>;
+        case 4: return k_exact_sums_m<4>;   case 5: return k_exact_sums_m<5>;   case 6: return k_exact_sums_m<6>;
+        case 8: return k_exact_sums_m<8>;   case 12: return k_exact_sums_m<12>; case 16: return k_exact_sums_m<16>;
+        default: return nullptr;
+    }
+}
+// launch shape of k_exact_sums_m for `est` users: blocks of 64 / 128 / 256 users x S product slices
+void launch_exact_m(exact_m_kernel_t km, const DevSim& d, uint32_t t, int from_list, int mode, uint64_t est, hipStream_t st) {
+    const uint32_t upb = (kBlock / 64) * 16 * exact_m_groups(d.XKB);
+    const uint64_t groups = (est + upb - 1) / upb;
+    const uint32_t n_chunks = d.PT / 64;
+    uint32_t S = static_cast<uint32_t>(4096 / (groups ? groups : 1));      // ~16 work items per CU when users are few
+    if (S > n_chunks) S = n_chunks;
+    if (S < 1) S = 1;
+    uint64_t grid = groups * S;
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    const size_t smem = exact_m_lds(d.XKB);
+    if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(km), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
+    hipLaunchKernelGGL(km, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), smem, st, d, t, from_list, mode, S);
 }
 
 typedef void (*exact_u_kernel_t)(DevSim, uint32_t, int, int, uint32_t);
@@ -3787,7 +3953,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
 #pragma unroll
         for (int e = 0; e < kWalkUsers; ++e) {
         unsigned long long dead = __ballot(stA[e] == kEmpty);
-        if (dead && !exhausted && (__popcll(dead) >= 8 || dead == ~0ull)) {
+        if (dead && !exhausted && (static_cast<uint32_t>(__popcll(dead)) >= d.walk_refill || dead == ~0ull)) {
             for (int pass = 0; pass < 2 && dead; ++pass) {
                 if (res_next == res_end) {
                     if (exhausted) break;
@@ -4587,6 +4753,16 @@ void launch_exact(rg_sim* sim, uint32_t t, int from_list, uint64_t est, hipStrea
         d.exact_base = batched ? static_cast<uint32_t>(b) * d.exact_rows : 0u;
         d.exact_last = b + 1 == n_batches ? 1u : 0u;
         if (batched && est > d.exact_rows) est = d.exact_rows;
+        if (exact_m_kernel_t km = (getenv("RECOGYM_EXACT_TILE") ? nullptr : exact_m_kernel_for(d.XKB))) {
+            if (!from_list) {
+                launch_exact_m(km, d, t, 0, 0, est, st);
+                hipLaunchKernelGGL(k_exact_ref, dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t, 1u);
+            }
+            launch_exact_m(km, d, t, from_list, 1, est, st);
+            hipLaunchKernelGGL(k_exact_pick, dim3(grid_for(est, kBlock / 64)), dim3(kBlock),
+                               sizeof(double) * d.K * (kBlock / 64), st, d, t, from_list, 1u);
+            continue;
+        }
         if (exact_u_kernel_t ku = (getenv("RECOGYM_EXACT_TILE") ? nullptr : exact_u_kernel_for(d.XKB))) {
             const uint64_t upl = 64ull * exact_upl_of(d.XKB);
             const uint64_t groups = (est + upl - 1) / upl;
@@ -4799,6 +4975,13 @@ int run_walk(rg_sim* sim, hipStream_t st) {
         fprintf(stderr, "[recogym] walk round 1: %llu organic + %llu bandit events, %u users parked of %u\n", ev2[0], ev2[1], n_park, d.n_users);
     }
     if (n_park) {
+        if (exact_m_kernel_t km = exact_m_kernel_for(d.XKB)) {
+            launch_exact_m(km, d, n_park, 2, 1, n_park, st);
+            if (int rc = mark(4)) return rc;
+            HIP_TRY(hipMemsetAsync(d.counters + kCntWalkTicket, 0, sizeof(unsigned long long), st));
+            launch_walk(n_park, 2);
+            goto walked;
+        }
         exact_u_kernel_t ku = exact_u_kernel_for(d.XKB);
         if (!ku) return fail(RG_ESTATE, "no user-per-lane float64 kernel for K = %u", d.K);
         const uint32_t n_chunks = d.PT / 64;
@@ -4814,6 +4997,7 @@ int run_walk(rg_sim* sim, hipStream_t st) {
         HIP_TRY(hipMemsetAsync(d.counters + kCntWalkTicket, 0, sizeof(unsigned long long), st));
         launch_walk(n_park, 2);
     } else if (int rc = mark(4)) return rc;
+walked:
     if (int rc = mark(5)) return rc;
     hipLaunchKernelGGL(k_walk_finish, dim3(1), dim3(1), 0, st, d);
     HIP_TRY(hipGetLastError());
@@ -4954,6 +5138,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     s->n_cus = 0;
     s->walk_occ = 3;
     d.walk_bias = 8;
+    d.walk_refill = 8;
+    if (const char* e = getenv("RECOGYM_WALK_REFILL")) d.walk_refill = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_BIAS")) d.walk_bias = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_OCC")) { const int o = atoi(e); if (o >= 2 && o <= 4) s->walk_occ = o; }
     s->prof_walk_ms[0] = s->prof_walk_ms[1] = 0.0;
