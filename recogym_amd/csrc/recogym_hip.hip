@@ -104,6 +104,7 @@ struct DevSim {
     uint32_t exact_rows;      // rows of exact_sums: n_cap where they are per-user constants (sigma_omega = 0 cache) or every
                               // draw goes through float64; else max(4096, n_cap / 8) — a step's uncertified draws (a few percent
                               // of its organic users) are resolved in batches of that many list entries
+    uint32_t walk_handover;   // k_walk: live lanes at which a wave whose queue is empty passes its users to the next round (0: never)
     uint32_t walk_refill;     // k_walk: free lanes of a wave at which it takes new users from the queue
     uint32_t walk_bias;       // k_walk: 0 = both event kinds every iteration; else one kind, organic when n_org * walk_bias >= n_bandit * 4
     uint32_t exact_base;      // first exact_list entry of the batch being resolved
@@ -408,7 +409,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint8_t* lr_dirty = w.take<uint8_t>(lr ? n : 1);
     uint32_t* lr_list = w.take<uint32_t>(lr ? n : 1);
     uint32_t* lr_cnt = w.take<uint32_t>(lr ? kMaxSteps + 2 : 1);
-    uint32_t* park_list = w.take<uint32_t>(cache ? n + 64 + 64 * 8192 : 1);
+    uint32_t* park_list = w.take<uint32_t>(cache ? n + 64 + 64 * 16384 : 1);   // round 1's list, then round 2's hand-overs, 64-entry blocks per wave
     uint32_t* park_t = w.take<uint32_t>(cache ? n : 1);
     const bool rp = n >= repack_min_users();      // small runs never repack: no second copy
     double* omega_alt = w.take<double>(rp ? ((K + 1) & ~static_cast<size_t>(1)) * n_pad : 1);
@@ -3907,7 +3908,8 @@ constexpr int kWalkUsers = RG_WALK_USERS;
 __host__ __device__ inline size_t walk_wave_lds(uint32_t KH) { return static_cast<size_t>(kWalkUsers) * 2 * KH * 64 * 4 + 64 * 24 + 64 * 4; }
 
 template <int KH, int OCC, bool DENSE>
-__global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_work, int round, uint32_t chunk_rows) {
+__global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_work, int round, uint32_t chunk_rows,
+                                                       uint32_t in_base, uint32_t out_base) {
     // The ~60 fields of DevSim this kernel uses do not fit the scalar registers next to its own state: kept live across
     // the loop they were spilled into VGPR lanes (v_writelane / v_readlane: ~10 % of the kernel's VALU instructions, the
     // unit that bounds it).  They are read from the kernel-argument segment instead — scalar loads, at the point of use:
@@ -3969,13 +3971,18 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
                 if (mine) {
                     const uint32_t idx = res_next + r;
                     uint32_t s2 = idx;
-                    if (round == 2) s2 = d.park_list[idx];
+                    if (round >= 2) s2 = d.park_list[in_base + idx];
                     if (s2 != 0xFFFFFFFFu) {
                         slotA[e] = s2;
-                        stA[e] = RG_STATE_ORGANIC;                   // every user starts organic; parked users sit at an organic draw
-                        tA[e] = round == 2 ? d.park_t[s2] : 0u;
-                        pendA[e] = round == 2;
-                        if (round == 2) { d.f64_valid[s2] = 1; c_sweeps += 1; }   // k_exact_sums_u took its sums between the rounds
+                        stA[e] = RG_STATE_ORGANIC;                   // every user starts organic
+                        tA[e] = 0u;
+                        pendA[e] = false;
+                        if (round >= 2) {
+                            // a parked user sits at an organic draw to be picked in float64; a handed-over one anywhere
+                            const uint32_t pt = d.park_t[s2];
+                            tA[e] = pt & 0xFFFFFFu; stA[e] = static_cast<int>((pt >> 24) & 7u); pendA[e] = (pt >> 27) & 1u;
+                            if (round == 2) { d.f64_valid[s2] = 1; c_sweeps += pendA[e] ? 1 : 0; }   // the batch between the rounds took its sums (counted for the parked)
+                        }
                         // omega32 = float(omega), as k_cache_finalize left it in the user's cache row (floats 44 .. 44 + K2)
                         const float4* rp = reinterpret_cast<const float4*>(d.cache_row + static_cast<size_t>(s2) * d.cache_row_f);
                         float* o = om32 + e * (K2 * 64) + lane;
@@ -4004,6 +4011,36 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
         }
         const unsigned long long live = __ballot(any_user);
         if (!live) { if (exhausted) break; else continue; }
+        // ---- hand-over: once the queue is empty a wave would drain for several user lifetimes with ever fewer live
+        // lanes (an iteration costs the same whatever their number).  With few left it passes its users on — they are
+        // appended to the list the next round reads, with their time, state and pending-pick flag — and ends; the
+        // last round walks everyone to the end. ----
+        if (exhausted && round < 3 && d.walk_handover && static_cast<uint32_t>(__popcll(live)) <= d.walk_handover) {
+#pragma unroll
+            for (int e = 0; e < kWalkUsers; ++e) {
+                const bool give = stA[e] != kEmpty;
+                const unsigned long long gm = __ballot(give);
+                if (!gm) continue;
+                const uint32_t np = static_cast<uint32_t>(__popcll(gm));
+                if (park_next + np > park_end) {
+                    for (uint32_t r = park_next + lane; r < park_end; r += 64) d.park_list[out_base + r] = 0xFFFFFFFFu;
+                    uint32_t base = 0;
+                    if (lane == 0) base = static_cast<uint32_t>(atomicAdd(&d.counters[kCntParkCnt], 64ull));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    park_next = base; park_end = base + 64;
+                }
+                if (give) {
+                    d.park_list[out_base + park_next + prefix_in_mask(gm)] = slotA[e];
+                    d.park_t[slotA[e]] = tA[e] | (static_cast<uint32_t>(stA[e]) << 24) | (pendA[e] ? 1u << 27 : 0u);
+                    // round 1: the float64 batch takes the sums of every listed user with the reference found here — the
+                    // user's common reference, as a parked draw would have left it (float 32 of its cache row)
+                    if (round == 1) d.exact_ref[slotA[e]] = d.cache_row[static_cast<size_t>(slotA[e]) * d.cache_row_f + 32];
+                    stA[e] = kEmpty;
+                }
+                park_next += np;
+            }
+            break;
+        }
         {
         // ---- ONE kind of event per iteration: the organic draw and the bandit event are different code, and a wave whose
         // lanes are in both states executes both for every step at ~25 active lanes each.  The users are independent and
@@ -4282,7 +4319,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
                 __builtin_amdgcn_wave_barrier();
             }
             if (parked) {
-                d.park_t[slot] = t;
+                d.park_t[slot] = t | (static_cast<uint32_t>(RG_STATE_ORGANIC) << 24) | (1u << 27);
                 d.exact_ref[slot] = Q;
             }
             if (is_org && !parked) {
@@ -4302,14 +4339,14 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
         if (pmask) {
             const uint32_t np = static_cast<uint32_t>(__popcll(pmask));
             if (park_next + np > park_end) {
-                for (uint32_t r = park_next + lane; r < park_end; r += 64) d.park_list[r] = 0xFFFFFFFFu;
+                for (uint32_t r = park_next + lane; r < park_end; r += 64) d.park_list[out_base + r] = 0xFFFFFFFFu;
                 uint32_t base = 0;
                 if (lane == 0) base = static_cast<uint32_t>(atomicAdd(&d.counters[kCntParkCnt], 64ull));
                 base = __builtin_amdgcn_readfirstlane(base);
                 park_next = base; park_end = base + 64;
             }
             if (parked) {
-                d.park_list[park_next + prefix_in_mask(pmask)] = slot;
+                d.park_list[out_base + park_next + prefix_in_mask(pmask)] = slot;
                 if (d.log && my_row < d.log_cap) { rg_event e; e.u = 0; e.t = 0; e.code = kHoleCode; e.ps = 0.0f; d.log[my_row] = e; }
                 st = kEmpty;
             }
@@ -4449,7 +4486,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
     // ---- leftovers of the reserved chunks, counters ----
     for (uint64_t r = row_next + lane; r < row_end; r += 64)
         if (d.log && r < d.log_cap) { rg_event e; e.u = 0; e.t = 0; e.code = kHoleCode; e.ps = 0.0f; d.log[r] = e; }
-    for (uint32_t r = park_next + lane; r < park_end; r += 64) d.park_list[r] = 0xFFFFFFFFu;
+    for (uint32_t r = park_next + lane; r < park_end; r += 64) d.park_list[out_base + r] = 0xFFFFFFFFu;
     for (int o = 32; o > 0; o >>= 1) {
         c_org += __shfl_xor(c_org, o); c_ban += __shfl_xor(c_ban, o); c_clicks += __shfl_xor(c_clicks, o);
         c_ph += __shfl_xor(c_ph, o); c_pick += __shfl_xor(c_pick, o); c_sweeps += __shfl_xor(c_sweeps, o);
@@ -4475,7 +4512,7 @@ __global__ void k_walk_finish(DevSim d) {
     d.log_base[1] = d.counters[kCntTailRows];
 }
 
-typedef void (*walk_kernel_t)(DevSim, uint32_t, int, uint32_t);
+typedef void (*walk_kernel_t)(DevSim, uint32_t, int, uint32_t, uint32_t, uint32_t);
 // blocks per CU the kernel is compiled for (register budget 512 / OCC per lane): KH <= 16 at 2, 3 or 4, KH = 32 at 1
 walk_kernel_t walk_kernel_for(const DevSim& d, int occ) {
     // the O(P) forms of the OrganicUserEventCounter policy are compiled in only where the configuration can reach them
@@ -4945,7 +4982,7 @@ int run_walk(rg_sim* sim, hipStream_t st) {
     if (int rc = mark(2)) return rc;
     // 2. round 1: every user from t = 0 to its end or to its first uncertified draw
     const size_t smem = (kBlock / 64) * walk_wave_lds(d.KH);
-    auto launch_walk = [&](uint32_t n_work, int round) {
+    auto launch_walk = [&](uint32_t n_work, int round, uint32_t in_base, uint32_t out_base) {
         const int occ = d.KH <= 16 ? sim->walk_occ : 1;
         const int blocks_cap = sim->n_cus * occ;
         int blocks = static_cast<int>((static_cast<uint64_t>(n_work) + kBlock - 1) / kBlock);
@@ -4960,9 +4997,10 @@ int run_walk(rg_sim* sim, hipStream_t st) {
         if (smem > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(walk_kernel_for(d, occ)), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       static_cast<int>(smem));
-        hipLaunchKernelGGL(walk_kernel_for(d, occ), dim3(blocks), dim3(kBlock), smem, st, d, n_work, round, static_cast<uint32_t>(chunk));
+        hipLaunchKernelGGL(walk_kernel_for(d, occ), dim3(blocks), dim3(kBlock), smem, st, d, n_work, round, static_cast<uint32_t>(chunk),
+                           in_base, out_base);
     };
-    launch_walk(d.n_users, 1);
+    launch_walk(d.n_users, 1, 0u, 0u);
     if (int rc = mark(3)) return rc;
     // 3. the users parked at an uncertified draw: float64 sums in one batch, then their round
     unsigned long long* h64 = reinterpret_cast<unsigned long long*>(sim->h_pinned);
@@ -4974,12 +5012,27 @@ int run_walk(rg_sim* sim, hipStream_t st) {
         HIP_TRY(hipMemcpy(ev2, d.counters + kCntTailOrganic, sizeof(ev2), hipMemcpyDeviceToHost));
         fprintf(stderr, "[recogym] walk round 1: %llu organic + %llu bandit events, %u users parked of %u\n", ev2[0], ev2[1], n_park, d.n_users);
     }
+    // round 2 over the parked (and handed-over) users; what IT hands over is appended behind them for round 3
+    auto later_rounds = [&](uint32_t n_list) -> int {
+        const uint32_t base3 = (n_list + 63u) & ~63u;
+        HIP_TRY(hipMemsetAsync(d.counters + kCntWalkTicket, 0, sizeof(unsigned long long), st));
+        HIP_TRY(hipMemsetAsync(d.counters + kCntParkCnt, 0, sizeof(unsigned long long), st));
+        launch_walk(n_list, 2, 0u, base3);
+        if (!d.walk_handover) return RG_OK;
+        HIP_TRY(hipMemcpyAsync(h64, d.counters + kCntParkCnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const uint32_t n_left = static_cast<uint32_t>(*h64);
+        if (n_left) {
+            HIP_TRY(hipMemsetAsync(d.counters + kCntWalkTicket, 0, sizeof(unsigned long long), st));
+            launch_walk(n_left, 3, base3, base3);
+        }
+        return RG_OK;
+    };
     if (n_park) {
         if (exact_m_kernel_t km = exact_m_kernel_for(d.XKB)) {
             launch_exact_m(km, d, n_park, 2, 1, n_park, st);
             if (int rc = mark(4)) return rc;
-            HIP_TRY(hipMemsetAsync(d.counters + kCntWalkTicket, 0, sizeof(unsigned long long), st));
-            launch_walk(n_park, 2);
+            if (int rc = later_rounds(n_park)) return rc;
             goto walked;
         }
         exact_u_kernel_t ku = exact_u_kernel_for(d.XKB);
@@ -4994,8 +5047,7 @@ int run_walk(rg_sim* sim, hipStream_t st) {
         if (grid > 1536) grid = 1536;
         hipLaunchKernelGGL(ku, dim3(grid), dim3(kBlock), 0, st, d, n_park, 2, 1, S);
         if (int rc = mark(4)) return rc;
-        HIP_TRY(hipMemsetAsync(d.counters + kCntWalkTicket, 0, sizeof(unsigned long long), st));
-        launch_walk(n_park, 2);
+        if (int rc = later_rounds(n_park)) return rc;
     } else if (int rc = mark(4)) return rc;
 walked:
     if (int rc = mark(5)) return rc;
@@ -5139,6 +5191,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     s->walk_occ = 3;
     d.walk_bias = 8;
     d.walk_refill = 8;
+    d.walk_handover = 16;
+    if (const char* e = getenv("RECOGYM_WALK_HANDOVER")) d.walk_handover = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_REFILL")) d.walk_refill = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_BIAS")) d.walk_bias = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_OCC")) { const int o = atoi(e); if (o >= 2 && o <= 4) s->walk_occ = o; }
