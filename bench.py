@@ -171,7 +171,7 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
     # float64 resolve: per sweep P * (2K + ~16) float64 flop-equivalents on the VALU
     if prof['draw_exact_ms'] > 0 and c['exact_sweeps'] > 0:
         tf = c['exact_sweeps'] * float(P) * (2 * K + 16) / (prof['draw_exact_ms'] * 1e-3) / 1e12
-        out['draw_exact_f64'] = dict(kernel='k_exact_sums_u + k_exact_pick', bound='f64 valu', ms=round(prof['draw_exact_ms'], 2),
+        out['draw_exact_f64'] = dict(kernel='k_exact_sums_m + k_exact_pick', bound='f64 mfma + valu', ms=round(prof['draw_exact_ms'], 2),
                                      units=int(c['exact_sweeps']), unit_name='float64 sweeps', achieved=round(tf, 2),
                                      peak=F64_VALU_PEAK_TFLOPS, unit='TFLOP/s', frac=round(tf / F64_VALU_PEAK_TFLOPS, 4),
                                      resolved_draws=int(c['exact_draws']))

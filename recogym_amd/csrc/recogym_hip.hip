@@ -10,8 +10,12 @@
 //                     certified against float64 (search_and_emit); k_draw_bf16 = its
 //                     one-accumulator form, k_draw_mfma = fp32 MFMA (K classes without a 16-bit
 //                     instantiation), k_draw_search = the search of the product-sliced form
-//   k_exact_sums_u / k_exact_pick (k_exact_sums: K > 64)
-//                     the same draw in float64 for the draws the fast path cannot certify
+//   k_exact_sums_m / k_exact_pick (k_exact_sums_u: its vector-ALU form; k_exact_sums: K > 64)
+//                     the same draw in float64 for the draws the fast path cannot certify (dot products on the
+//                     float64 matrix cores)
+//   k_cache_finalize, k_walk (sigma_omega == 0)
+//                     the whole run user-major from a per-user cache of exp-sums: draw, policy act, click,
+//                     transition and row of every event of a user on one lane
 //   k_advance         AbstractEnv.step / step_offline, RecoEnv1.draw_click / update_state, the
 //                     policy's act (policy_act / logreg_act_wave) and the log rows of generate_logs
 //                                                                 abstract.py:123-239,267-316
