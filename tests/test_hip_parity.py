@@ -103,6 +103,25 @@ def test_hip_matches_oracle(case):
         (oc['organic'], oc['bandit'], oc['clicks'], oc['phantom'])
 
 
+@pytest.mark.parametrize('lockstep', [False, True])
+@pytest.mark.parametrize('case', [0, 5, 6, 7, 8, 9, 15])
+def test_fp32_decided_clicks_match_the_oracle(case, lockstep, monkeypatch):
+    """Without the click-probability export k_walk decides a click from an fp32 evaluation of
+    ff(beta[a].omega + mu_b[a]) wherever its error margin allows and falls back to float64 inside the margin (measured
+    in k_advance too: no gain there, not kept): the logged clicks must be the oracle's, walked or in lock-step."""
+    from oracle import oracle as orc
+    over, n_users, n_org, pol = CASES[case]
+    if lockstep:
+        monkeypatch.setenv('RECOGYM_WALK', '0')
+        monkeypatch.setenv('RECOGYM_TAIL', '0')
+    cfg = Configuration({**env_1_args, **over})
+    want = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol).generate_logs(n_users, n_org)
+    rows, cnt = run_sim(cfg, n_users, n_org, p_click=False, **pol)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps')}, ps_rtol=1e-12,
+                         what=f'fp32 clicks, case {case}, lockstep {lockstep}')
+    assert cnt['clicks'] == int((want['c'] == 1).sum()) > 0
+
+
 @pytest.mark.parametrize('case', [0, 4, 7, 9, 10])
 def test_repacked_state_matches_oracle(case, monkeypatch):
     """The state repack (live users' omega / view history / user ids copied into list order every
