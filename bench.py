@@ -304,9 +304,13 @@ def main():
                                        f'{launches} launches; bound by scattered per-user gathers, not by streaming bandwidth')
         roofline['launches'] = launches
         roofline['avg_launch_ms'] = round(roofline['ms'] / launches, 4)
+        if dom == 'walk':
+            roofline['achieved_is'] = ('algorithmic bytes (SURVEY.md 8d figure per event x events) / total kernel time of the run\'s '
+                                       'walk launches (rounds of unequal size: per-launch figures are the run\'s divided by their number)')
         pmc = measured_traffic(roofline['kernel'].split(' ')[0]) if args.workload in ('c3', 'c4shard') else None
         if dom == 'walk':
-            launches = 2 if prof['walk2_ms'] > 0 else 1          # round 1 + round 2 of one run
+            # rounds of one run: 1, the parked users' round 2, and round 3 for what draining waves handed over
+            launches = (3 if os.environ.get('RECOGYM_WALK_HANDOVER', '16') != '0' else 2) if prof['walk2_ms'] > 0 else 1
             roofline['launches'] = launches
             roofline['avg_launch_ms'] = round(roofline['ms'] / launches, 4)
         roofline['traffic'] = None if pmc is None else pmc['hbm_bytes_per_unit'] * roofline['units'] / launches
