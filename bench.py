@@ -262,11 +262,15 @@ def main():
         torch.cuda.synchronize(device)
 
     def timed(s, steps, warmup):
+        # (the warm-up also runs the few torch ops of the timed loop once: their kernels are loaded lazily, ~20 ms the
+        # first time, which is 2 ms per step of a 10-step run and more than a whole step of the C2 workload)
+        totals = torch.zeros(4, dtype=torch.int64, device=device)
         for _ in range(warmup):
-            one_step(s)
+            _, vec = one_step(s)
+            totals += vec
+        totals.zero_()
         sync()
         t0 = time.perf_counter()
-        totals = torch.zeros(4, dtype=torch.int64, device=device)
         last = None
         for _ in range(steps):
             last, vec = one_step(s)
