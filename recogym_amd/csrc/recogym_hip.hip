@@ -254,6 +254,8 @@ struct Carve {
 
 constexpr uint32_t kMaxSC = 32;           // stored partial sums per user in the MFMA draw kernel
 constexpr uint32_t kHoleCode = 0xFFFFFFFFu;   // rg_event.code of an unused raw-log entry (no real row has every bit set: P < 2^29)
+constexpr int kCntTailRows = 16, kCntTailOrganic = 17, kCntTailBandit = 18, kCntTailMaxT = 19, kCntTailTicket = 20,
+              kCntTailLimit = 21, kCntWalkTicket = 22, kCntParkCnt = 23;   // internal slots of counters[] (RG_CNT_N = 24)
 
 struct Geom { uint32_t KH, KS, TP, P_pad, n_chunks, sc_chunks, n_sc, N1, N2, N3, RS, TPB, F16; };
 
@@ -1476,6 +1478,167 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_m(DevSim d, uint32_t t, i
             }
             if (more) stash(((cc - cc0) & 1u) ^ 1u);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_exact_sums_h — the parked users' batch of k_walk on BOTH float64 pipes at once.
+//
+// At K <= 20 the matrix form (k_exact_sums_m: the MFMA pipe binds, the VALU is half idle) and the vector form
+// (k_exact_sums_u: the VALU binds, the matrix pipe idles) take the same time.  Here a block takes the next group of 256
+// listed users from a ticket counter and runs `mfma_of_8` groups of every 8 in the matrix form, the others in the
+// vector form (a lane per user, Gamma rows through the scalar cache), so that the waves resident on a SIMD are a mix
+// of both and the two pipes work side by side.  Exp-sums only (mode 1), whole table per user (no product slices).
+// ------------------------------------------------------------------------------------------
+template <int KB>
+__global__ void __launch_bounds__(kBlock) k_exact_sums_h(DevSim d, uint32_t n, uint32_t mfma_of_8) {
+    constexpr int G = exact_m_groups(KB);
+    constexpr uint32_t UPW = 16 * G, UPB = (kBlock / 64) * UPW;      // 256 users per group at K <= 32
+    constexpr uint32_t RSd = 4 * KB + 4, TILE = 64 * RSd;
+    constexpr int NLD = (TILE / 2 + kBlock - 1) / kBlock;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* tiles = reinterpret_cast<double*>(smem_raw);             // [2][TILE]
+    double* exp_tab = tiles + 2 * TILE;
+    __shared__ uint32_t s_grp;
+    if (threadIdx.x < 32) exp_tab[threadIdx.x] = kExp2Tab32[threadIdx.x];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int q = lane >> 4, jl = lane & 15;
+    const uint32_t n_cc = d.PT / 64;
+    const uint32_t n_groups = (n + UPB - 1) / UPB;
+    for (;;) {
+        __syncthreads();                       // s_grp and the LDS tiles of the previous group are free
+        if (threadIdx.x == 0) s_grp = static_cast<uint32_t>(atomicAdd(&d.counters[kCntWalkTicket], 1ull));
+        __syncthreads();
+        const uint32_t grp = s_grp;
+        if (grp >= n_groups) break;
+        if ((grp & 7u) < mfma_of_8) {
+            // ================= matrix form (k_exact_sums_m's body, from_list == 2, one slice) =================
+            uint32_t row[G];
+            bool act[G];
+            double b[G][KB], M[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const uint32_t w_idx = grp * UPB + wave * UPW + g * 16 + jl;
+                uint32_t slot = w_idx < n ? d.park_list[w_idx] : 0xFFFFFFFFu;
+                act[g] = slot != 0xFFFFFFFFu;
+                if (!act[g]) slot = 0u;
+                row[g] = slot;
+#pragma unroll
+                for (int s2 = 0; s2 < KB; ++s2) {
+                    const uint32_t k = 4 * s2 + q;
+                    b[g][s2] = (act[g] && k < d.K) ? d.omega[static_cast<size_t>(slot) * d.OMS + k] : 0.0;
+                }
+                M[g] = act[g] ? static_cast<double>(d.exact_ref[slot]) * 0.69314718055994530942 : 0.0;
+            }
+            double2 pf[NLD];
+            auto fetch = [&](uint32_t cc) {
+                const double2* src = reinterpret_cast<const double2*>(d.gamma_rm + static_cast<size_t>(cc) * TILE);
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    const uint32_t idx = threadIdx.x + i * kBlock;
+                    if (idx < TILE / 2) pf[i] = src[idx];
+                }
+            };
+            auto stash = [&](uint32_t buf) {
+                double2* dst = reinterpret_cast<double2*>(tiles + buf * TILE);
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    const uint32_t idx = threadIdx.x + i * kBlock;
+                    if (idx < TILE / 2) dst[idx] = pf[i];
+                }
+            };
+            fetch(0);
+            stash(0);
+            for (uint32_t cc = 0; cc < n_cc; ++cc) {
+                __syncthreads();
+                const bool more = cc + 1 < n_cc;
+                if (more) fetch(cc + 1);
+                const double* A = tiles + (cc & 1u) * TILE;
+                double sum[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) sum[g] = 0.0;
+#pragma unroll 1
+                for (int tt = 0; tt < 4; ++tt) {
+                    f64x4 acc[G];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) acc[g] = f64x4{0.0, 0.0, 0.0, 0.0};
+                    const double* arow = A + static_cast<size_t>(tt * 16 + jl) * RSd + q;
+#pragma unroll
+                    for (int s2 = 0; s2 < KB; ++s2) {
+                        const double a = arow[4 * s2];
+#pragma unroll
+                        for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[g][s2], acc[g], 0, 0, 0);
+                    }
+                    double mu[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mu[r] = A[static_cast<size_t>(tt * 16 + q + 4 * r) * RSd + 4 * KB];
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sum[g] += exp64t(acc[g][r] + mu[r] - M[g], exp_tab);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    double x = sum[g];
+                    x += __shfl_xor(x, 16);
+                    x += __shfl_xor(x, 32);
+                    if (q == (g & 3) && act[g]) d.exact_sums[static_cast<size_t>(row[g]) * n_cc + cc] = x;
+                }
+                if (more) stash((cc & 1u) ^ 1u);
+            }
+        } else {
+            // ================= vector form (k_exact_sums_u's body): wave = 64 users of the group =================
+            constexpr int UPL = UPB / (kBlock / 64) / 64;          // users per lane: 1 (256-user groups)
+            uint32_t w_row[UPL];
+            bool act[UPL];
+            double om[UPL][4 * KB], M[UPL];
+#pragma unroll
+            for (int j = 0; j < UPL; ++j) {
+                const uint32_t w_idx = grp * UPB + wave * 64 * UPL + j * 64 + lane;
+                uint32_t slot = w_idx < n ? d.park_list[w_idx] : 0xFFFFFFFFu;
+                act[j] = slot != 0xFFFFFFFFu;
+                if (!act[j]) slot = 0u;
+                w_row[j] = slot;
+#pragma unroll
+                for (int k = 0; k < 4 * KB; ++k)
+                    om[j][k] = (act[j] && static_cast<uint32_t>(k) < d.K) ? d.omega[static_cast<size_t>(slot) * d.OMS + k] : 0.0;
+                M[j] = act[j] ? static_cast<double>(d.exact_ref[slot]) * 0.69314718055994530942 : 0.0;
+            }
+            for (uint32_t cc = 0; cc < n_cc; ++cc) {
+                double acc[UPL];
+#pragma unroll
+                for (int j = 0; j < UPL; ++j) acc[j] = 0.0;
+                const uint32_t p1 = cc * 64 + 64;
+#pragma unroll 2
+                for (uint32_t p = cc * 64; p < p1; ++p) {
+                    kdouble* row = (kdouble*)(d.gamma_rm) + static_cast<size_t>(p) * RSd;
+                    double l[UPL];
+#pragma unroll
+                    for (int j = 0; j < UPL; ++j) l[j] = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 4 * KB; ++k) {
+                        const double g = row[k];
+#pragma unroll
+                        for (int j = 0; j < UPL; ++j) l[j] += g * om[j][k];
+                    }
+#pragma unroll
+                    for (int j = 0; j < UPL; ++j) acc[j] += exp64t(l[j] + row[4 * KB] - M[j], exp_tab);
+                }
+#pragma unroll
+                for (int j = 0; j < UPL; ++j)
+                    if (act[j]) d.exact_sums[static_cast<size_t>(w_row[j]) * n_cc + cc] = acc[j];
+            }
+        }
+    }
+}
+
+typedef void (*exact_h_kernel_t)(DevSim, uint32_t, uint32_t);
+exact_h_kernel_t exact_h_kernel_for(uint32_t kb) {
+    switch (kb) {                               // K <= 32: 256-user groups in both forms
+        case 1: return k_exact_sums_h<1>;   case 2: return k_exact_sums_h<2>;   case 3: return k_exact_sums_h<3>;
+        case 4: return k_exact_sums_h<4>;   case 5: return k_exact_sums_h<5>;   case 6: return k_exact_sums_h<6>;
+        case 8: return k_exact_sums_h<8>;
+        default: return nullptr;
     }
 }
 
@@ -3682,8 +3845,6 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
 // log rows log_base[t0] + ticket (the sorted log does not depend on raw positions); events of
 // steps > t0 are counted in the kCntTail* counters (step t0's are in step_cnt[t0]).
 // ------------------------------------------------------------------------------------------
-constexpr int kCntTailRows = 16, kCntTailOrganic = 17, kCntTailBandit = 18, kCntTailMaxT = 19, kCntTailTicket = 20,
-              kCntTailLimit = 21, kCntWalkTicket = 22, kCntParkCnt = 23;   // internal slots of counters[] (RG_CNT_N = 24)
 
 __global__ void __launch_bounds__(kBlock) k_tail(DevSim d, uint32_t t0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -5033,6 +5194,18 @@ int run_walk(rg_sim* sim, hipStream_t st) {
         return RG_OK;
     };
     if (n_park) {
+        uint32_t mfma_of_8 = 5;                 // groups of every 8 that take the matrix form (RECOGYM_EXACT_MIX; 8 = all)
+        if (const char* e = getenv("RECOGYM_EXACT_MIX")) mfma_of_8 = static_cast<uint32_t>(atoi(e));
+        exact_h_kernel_t kh = (mfma_of_8 < 8 && !getenv("RECOGYM_EXACT")) ? exact_h_kernel_for(d.XKB) : nullptr;
+        if (kh) {
+            HIP_TRY(hipMemsetAsync(d.counters + kCntWalkTicket, 0, sizeof(unsigned long long), st));
+            const uint32_t groups = (n_park + 255u) / 256u;
+            const uint32_t grid = groups < 1024u ? groups : 1024u;
+            hipLaunchKernelGGL(kh, dim3(grid), dim3(kBlock), exact_m_lds(d.XKB), st, d, n_park, mfma_of_8);
+            if (int rc = mark(4)) return rc;
+            if (int rc = later_rounds(n_park)) return rc;
+            goto walked;
+        }
         if (exact_m_kernel_t km = exact_m_kernel_for(d.XKB)) {
             launch_exact_m(km, d, n_park, 2, 1, n_park, st);
             if (int rc = mark(4)) return rc;
