@@ -1,7 +1,1 @@
-mkdir -p gpurun_out/r2_h
-timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -q -x -k "sigma_omega_zero or walk or sum_cache or fixture or fp32_decided" 2>&1 | tail -2
-for mix in 5 8 4 6 3; do
-RECOGYM_EXACT_MIX=$mix timeout 300 python bench.py --workload c3 --steps 3 --warmup 1 --no-cpu-baseline --no-drift-line 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('mix $mix', round(d['value']/1e6,1), round(d['ms_per_step'],2), {k:v['ms'] for k,v in d['kernels'].items()})"
-done
+timeout 1200 python -m pytest tests -m gpu -q -x 2>&1 | tail -4
