@@ -1,0 +1,18 @@
+"""Is the wide-K sweep bound by streaming its split table?  Same K = 64 / drift workload at two table sizes."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from recogym_amd import Configuration, env_1_args
+from recogym_amd.sim import Simulator, default_log_capacity
+
+for P, users in ((12800, 1_250_000), (100_000, 1_250_000)):
+    cfg = Configuration({**env_1_args, 'random_seed': 42, 'num_products': P, 'K': 64, 'sigma_omega': 0.1})
+    sim = Simulator(cfg, users, device='cuda:0', log_capacity=default_log_capacity(cfg, users))
+    for rep in range(2):
+        sim.set_profiling(rep == 1)
+        sim.reset_users(0, users); sim.run()
+    prof = sim.profile(); c = sim.counters()
+    draws = c['organic']
+    print(f'P={P}: sweep {prof["draw_mfma_ms"]:.1f} ms for {draws/1e6:.1f} M draws -> {prof["draw_mfma_ms"]*1e6/(draws*P/64):.3f} ns per (draw x 64-product tile); '
+          f'exact {prof["draw_exact_ms"]:.1f} ms, advance {prof["advance_ms"]:.1f} ms, exact draws {c["exact_draws"]}')
+    sim.close(); del sim; torch.cuda.empty_cache()
