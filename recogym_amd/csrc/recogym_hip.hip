@@ -3188,6 +3188,14 @@ draw_kernel_t bf16_kernel_for(const DevSim& d) {
 // The exp-sums of pair n - 1 sit in the issue slots between the MFMAs of pair n (two independent accumulator
 // chains), order pinned with sched_barrier.
 // ------------------------------------------------------------------------------------------
+#ifdef RG_F16W_TIMING
+// -DRG_F16W_TIMING: s_memtime per section of the tile loop, summed over wave 0 of every block (tools/wide_probe.py)
+__device__ unsigned long long g_f16w_t[8];
+#define RG_TSEC(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define RG_TSEC(i) do {} while (0)
+#endif
+
 template <int KH, int N1, int UG>
 __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t, uint32_t S) {
     constexpr uint32_t RSc = 32 * N1 + 16, TILE_B = 64 * RSc, NT = TILE_B / 1024;     // 1 KB per wave-wide DMA instruction
@@ -3355,7 +3363,11 @@ __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t,
 #pragma unroll
         for (int g = 0; g < UG; ++g) q_prev[g] = q[g];
         uint32_t sc_issue_left = sc_pairs;                      // pairs left in the super-chunk being ISSUED
+#ifdef RG_F16W_TIMING
+        unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
         for (uint32_t ti = pt_lo; ti < pt_hi; ++ti) {
+            RG_TSEC(4);
             if (ti > pt_lo) {
                 // tile ti has landed once at most this wave's DMA of tile ti + 1 (issued after it) is still in flight
                 if (ti + 1 >= pt_hi) RG_TILE_BARRIER(0);
@@ -3366,8 +3378,10 @@ __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t,
                 else if (my_dma == 4) RG_TILE_BARRIER(4);
                 else if (my_dma == 3) RG_TILE_BARRIER(3);
                 else RG_TILE_BARRIER(2);
+                RG_TSEC(0);
                 if (ti + 2 < pt_hi) fetch_tile(ti + 2);        // into the buffer of tile ti - 1: every wave is past it
             }
+            RG_TSEC(5);
             const uint32_t bsel = (ti - pt_lo) % 3u;
             const char* ab = a_lane + bsel * TILE_B;
             const char* mb = m_lane + bsel * 256u;
@@ -3391,6 +3405,7 @@ __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t,
                 A1r[s2] = *reinterpret_cast<const bf16x8*>(ab + 32 * RSc + 32 * s2);
             }
             RG_PIN();
+            RG_TSEC(1);
             // the exps of the previous tile (2 UG accumulators x 16) spread over the 2 UG N1 MFMA slots of this one
             constexpr int NSLOT = 2 * UG * N1, NEP = 16 * UG, EPS = (NEP + NSLOT - 1) / NSLOT;      // exp PAIRS (per slot)
             auto exps = [&](int slot_i) {
@@ -3422,6 +3437,7 @@ __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t,
                     RG_PIN();
                 }
             }
+            RG_TSEC(2);
             const bool flush = have_p && sc_left == 1;
             if (have_p) {
 #pragma unroll
@@ -3438,7 +3454,14 @@ __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t,
             }
 #pragma unroll
             for (int g = 0; g < UG; ++g) { p[g][0] = a[g][0]; p[g][1] = a[g][1]; q_prev[g] = q[g]; }
+            RG_TSEC(3);
         }
+#ifdef RG_F16W_TIMING
+        if (wave == 0 && lane == 0) {
+            for (int i = 0; i < 6; ++i) atomicAdd(&g_f16w_t[i], tacc[i]);
+            atomicAdd(&g_f16w_t[6], static_cast<unsigned long long>(pt_hi - pt_lo));
+        }
+#endif
         {   // the last pair's own sums
             const bool flush = sc_left == 1;
 #pragma unroll
@@ -5514,6 +5537,13 @@ int rg_sim_reset_users(rg_sim* sim, uint64_t first_user_id, uint64_t n, uint64_t
     sim->repacked = false;
     return RG_OK;
 }
+
+#ifdef RG_F16W_TIMING
+void rg_debug_f16w_timing(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f16w_t), sizeof(unsigned long long) * 8);
+}
+#endif
 
 int rg_sim_step(rg_sim* sim, const int32_t* d_actions, void* stream) {
     if (!sim) return fail(RG_EINVAL, "sim is NULL");
