@@ -3198,6 +3198,12 @@ __device__ unsigned long long g_f16w_t[8];
 
 template <int KH, int N1, int UG>
 __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t, uint32_t S) {
+    // Nothing that lives across the tile loop may be spilled: a reload inside the loop is followed by `s_waitcnt
+    // vmcnt(0)`, which also waits for the tile DMA in flight (the asm DMA is invisible to the compiler's counter
+    // model) — a memory round trip per tile and wave.  The mu tile's buffer descriptor and this lane's LDS address
+    // were two such values (measured: 3/4 of the kernel's time); they are rebuilt where they are used, the first from
+    // the kernel-argument segment.
+    const __attribute__((address_space(4))) char* kargs = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr uint32_t RSc = 32 * N1 + 16, TILE_B = 64 * RSc, NT = TILE_B / 1024;     // 1 KB per wave-wide DMA instruction
     // UG groups of 32 users per wave, 8 / UG waves per block (256 users either way).  UG = 2: every A fragment read
     // from LDS feeds two MFMAs (half the LDS traffic) but one wave per SIMD; UG = 1: two waves per SIMD
@@ -3244,12 +3250,16 @@ __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t,
         }
         __syncthreads();           // every wave is done with the LDS buffers and stage (previous work item)
         const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
-        const rg_v4i rs_g = raw_buffer_rsrc(d.gsplit), rs_m = raw_buffer_rsrc(d.mu32s);
+        const rg_v4i rs_g = raw_buffer_rsrc(d.gsplit);
         const uint32_t g_lds = lds_addr_of(g_buf), mu_lds = lds_addr_of(mu_buf);
         auto fetch_tile = [&](uint32_t ti) {
             for (uint32_t off = static_cast<uint32_t>(wave) * 1024u; off < TILE_B; off += NW * 1024u)
                 dma_to_lds_b128(rs_g, g_lds + ((ti - pt_lo) % 3u) * TILE_B + off, lane16, ti * TILE_B + off);
-            if (wave == NW - 1 && lane < 16) dma_to_lds_b128(rs_m, mu_lds + ((ti - pt_lo) % 3u) * 256u, lane16, ti * 256u);
+            if (wave == NW - 1) {
+                asm volatile("" : "+s"(kargs));
+                const rg_v4i rs_m = raw_buffer_rsrc(((const DevSim*)kargs)->mu32s);
+                if (lane < 16) dma_to_lds_b128(rs_m, mu_lds + ((ti - pt_lo) % 3u) * 256u, lane16, ti * 256u);
+            }
         };
         fetch_tile(pt_lo);
         // ---- omega32 of the users -> LDS stage (also the logit error bound) ----
@@ -3383,8 +3393,10 @@ __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t,
             }
             RG_TSEC(5);
             const uint32_t bsel = (ti - pt_lo) % 3u;
-            const char* ab = a_lane + bsel * TILE_B;
-            const char* mb = m_lane + bsel * 256u;
+            int hl = lane >> 5, jl = lane & 31;
+            asm volatile("" : "+v"(hl), "+v"(jl));                 // (rebuilt here: see the note on spills at the top)
+            const char* ab = g_buf + jl * RSc + 16 * hl + bsel * TILE_B;
+            const char* mb = reinterpret_cast<const char*>(mu_buf) + 16 * hl + bsel * 256u;
             if (sc_issue_left == sc_pairs) {                    // a super-chunk starts
 #pragma unroll
                 for (int g = 0; g < UG; ++g) if (q_next[g] != q[g]) { set_reference(g, q_next[g]); n_resc[g] += 1; }
