@@ -3188,6 +3188,13 @@ draw_kernel_t bf16_kernel_for(const DevSim& d) {
 // The exp-sums of pair n - 1 sit in the issue slots between the MFMAs of pair n (two independent accumulator
 // chains), order pinned with sched_barrier.
 // ------------------------------------------------------------------------------------------
+// timing experiments of the tile loop (RECOGYM_ABLATE bits 8-14: no book-keeping / exps / table stream / second operand
+// read / tile barrier / mu reads / MFMAs) exist in the -DRG_F16W_TIMING build only: the tests alone cost the loop 20 %
+#ifdef RG_F16W_TIMING
+#define RG_F16W_ABL(bit) (d.ablate & (bit))
+#else
+#define RG_F16W_ABL(bit) (false)
+#endif
 #ifdef RG_F16W_TIMING
 // -DRG_F16W_TIMING: s_memtime per section of the tile loop, summed over wave 0 of every block (tools/wide_probe.py)
 __device__ unsigned long long g_f16w_t[8];
@@ -3253,6 +3260,7 @@ __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t,
         const rg_v4i rs_g = raw_buffer_rsrc(d.gsplit);
         const uint32_t g_lds = lds_addr_of(g_buf), mu_lds = lds_addr_of(mu_buf);
         auto fetch_tile = [&](uint32_t ti) {
+            if (RG_F16W_ABL(1024u) && ti > pt_lo + 2) return;        // timing experiment: no table stream (stale tiles)
             for (uint32_t off = static_cast<uint32_t>(wave) * 1024u; off < TILE_B; off += NW * 1024u)
                 dma_to_lds_b128(rs_g, g_lds + ((ti - pt_lo) % 3u) * TILE_B + off, lane16, ti * TILE_B + off);
             if (wave == NW - 1) {
@@ -3333,6 +3341,7 @@ __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t,
         const uint32_t sc_pairs = d.sc_chunks / 2;
         uint32_t sc_cur = chunk_lo / d.sc_chunks, sc_left = sc_pairs;
         auto book = [&](int g, uint32_t ti_done, float s0, float s1, float q_used, bool flush) {   // sums of the pair of tile ti_done
+            if RG_F16W_ABL(256u) { wcmax[g] += s0 + s1; return; }   // timing experiment: no reduction across lanes, no stores
             s0 += swap32(s0);
             s1 += swap32(s1);
             const uint32_t ci = 2 * ti_done;
@@ -3378,7 +3387,7 @@ __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t,
 #endif
         for (uint32_t ti = pt_lo; ti < pt_hi; ++ti) {
             RG_TSEC(4);
-            if (ti > pt_lo) {
+            if (ti > pt_lo && !RG_F16W_ABL(4096u)) {                 // (4096: timing experiment without the tile barrier)
                 // tile ti has landed once at most this wave's DMA of tile ti + 1 (issued after it) is still in flight
                 if (ti + 1 >= pt_hi) RG_TILE_BARRIER(0);
                 else if (my_dma >= 8) RG_TILE_BARRIER(8);
@@ -3404,7 +3413,12 @@ __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t,
             if (--sc_issue_left == 0) sc_issue_left = sc_pairs;
             f32x16 a[UG][2];
 #pragma unroll
-            for (int g = 0; g < UG; ++g) { load_mu(a[g][0], mb, 0); load_mu(a[g][1], mb, 1); }
+            for (int g = 0; g < UG; ++g) {
+                if RG_F16W_ABL(8192u) {                                // timing experiment: no mu tile reads
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { a[g][0][r] = 0.0f; a[g][1][r] = 0.0f; }
+                } else { load_mu(a[g][0], mb, 0); load_mu(a[g][1], mb, 1); }
+            }
             f32x2 x[UG][2][4];
             const bool have_p = ti > pt_lo;
             // A operands: a ring RD k-steps deep, read RD - 1 steps ahead of the MFMAs that consume them (one wave per
@@ -3421,6 +3435,7 @@ __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t,
             // the exps of the previous tile (2 UG accumulators x 16) spread over the 2 UG N1 MFMA slots of this one
             constexpr int NSLOT = 2 * UG * N1, NEP = 16 * UG, EPS = (NEP + NSLOT - 1) / NSLOT;      // exp PAIRS (per slot)
             auto exps = [&](int slot_i) {
+                if RG_F16W_ABL(512u) return;                          // timing experiment: MFMA stream only
 #pragma unroll
                 for (int e = slot_i * EPS; e < (slot_i + 1) * EPS && e < NEP; ++e) {
                     const int g = e >> 4, c = (e >> 3) & 1, r = e & 7;       // accumulator (g, c), register pair r
@@ -3434,17 +3449,18 @@ __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t,
             for (int s2 = 0; s2 < N1; ++s2) {
                 if (s2 + RD - 1 < N1) {
                     A0r[(s2 + RD - 1) % RD] = *reinterpret_cast<const bf16x8*>(ab + 32 * (s2 + RD - 1));
-                    A1r[(s2 + RD - 1) % RD] = *reinterpret_cast<const bf16x8*>(ab + 32 * RSc + 32 * (s2 + RD - 1));
+                    if RG_F16W_ABL(2048u) A1r[(s2 + RD - 1) % RD] = A0r[(s2 + RD - 1) % RD];      // timing experiment: half the LDS operand reads
+                    else A1r[(s2 + RD - 1) % RD] = *reinterpret_cast<const bf16x8*>(ab + 32 * RSc + 32 * (s2 + RD - 1));
                 }
 #pragma unroll
                 for (int g = 0; g < UG; ++g) {
-                    a[g][0] = mm(A0r[s2 % RD], Bm[g][s2], a[g][0]);
+                    if (!RG_F16W_ABL(16384u)) a[g][0] = mm(A0r[s2 % RD], Bm[g][s2], a[g][0]);   // (16384: timing experiment without the MFMAs)
                     exps((2 * s2) * UG + g);
                     RG_PIN();
                 }
 #pragma unroll
                 for (int g = 0; g < UG; ++g) {
-                    a[g][1] = mm(A1r[s2 % RD], Bm[g][s2], a[g][1]);
+                    if (!RG_F16W_ABL(16384u)) a[g][1] = mm(A1r[s2 % RD], Bm[g][s2], a[g][1]);
                     exps((2 * s2 + 1) * UG + g);
                     RG_PIN();
                 }
