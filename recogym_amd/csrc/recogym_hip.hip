@@ -2483,6 +2483,14 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* generic_ptr) {
         asm volatile("" ::: "memory");                                         \
     } while (0)
 
+// timing experiments of the sweep's tile loop (RECOGYM_ABLATE bits 4, 5, 7, 8) exist in -DRG_SWEEP_TIMING builds only: the
+// same kind of test cost the wide kernel's loop 20 %
+#ifdef RG_SWEEP_TIMING
+#define RG_SWEEP_ABL(bit) (d.ablate & (bit))
+#else
+#define RG_SWEEP_ABL(bit) (false)
+#endif
+
 template <int KH, int N1, int N2, int N3, bool F16, bool SUB = false>
 __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, uint32_t S) {
     constexpr int NM = F16 ? N1 : N1 + N2 + N3;   // MFMAs per chunk (fp16 two-way split: one group)
@@ -2705,7 +2713,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         uint32_t sc_left = d.sc_chunks / 4;                    // tiles left in it
         float2 wlo = make_float2(0.f, 0.f);
         auto book = [&](uint32_t pe, float s0, float s1) {    // sums of pair pe (chunks 2pe, 2pe+1 of the work item)
-            if (d.ablate & 256u) { wcmax += s0 + s1; return; }
+            if RG_SWEEP_ABL(256u) { wcmax += s0 + s1; return; }
             s0 += swap32(s0);
             s1 += swap32(s1);
             if (sub) {
@@ -2722,7 +2730,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             const float4 w4 = make_float4(wlo.x, wlo.y, s0, s1);
             // scratch layout [tile][user][4 chunks]; both lanes of the user hold the same sums: one of them stores
             // (unpredicated, the duplicate store doubled the kernel's write traffic: 3.1 KB per draw, profiles/r2)
-            if (h == 0 && !(d.ablate & 16u)) *reinterpret_cast<float4*>(view.chunk + static_cast<size_t>(ti) * view.tile_stride) = w4;
+            if (h == 0 && !RG_SWEEP_ABL(16u)) *reinterpret_cast<float4*>(view.chunk + static_cast<size_t>(ti) * view.tile_stride) = w4;
             wcmax = fmaxf(fmaxf(wcmax, fmaxf(w4.x, w4.y)), fmaxf(w4.z, w4.w));
             s_sc += static_cast<double>((w4.x + w4.y) + (w4.z + w4.w));
             if (--sc_left == 0) {
@@ -2791,7 +2799,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             else if (sub) { if (pi == 3) RG_TILE_BARRIER(9); else RG_TILE_BARRIER(14); }   // (five stores per tile with the group sums)
             else if (pi == 3) RG_TILE_BARRIER(5);               // + one store
             else RG_TILE_BARRIER(6);                            // + two stores
-            if (T + 3 < pt_hi && !(d.ablate & 32u)) fetch_tile(T + 3);
+            if (T + 3 < pt_hi && !RG_SWEEP_ABL(32u)) fetch_tile(T + 3);
             stream(ob, oa, pi + 1, p0, p1, a0, a1, s0, s1);                  // MFMAs of pair pi | sums of pair pi - 1
             book(pi - 1, s0, s1);
             if (--sc_issue_left == 0) sc_issue_left = d.sc_chunks / 4;
@@ -2819,7 +2827,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             view.rec[sc_cur * view.rec_stride] = make_float2(static_cast<float>(s_sc), q_done);
         }
         if (d.use_cache && S == 1 && active && h == 0) d.cache_resc[d.uid[slot]] = static_cast<uint8_t>(min(n_resc, 255));
-        if (S == 1 && !(d.ablate & 128u) && !d.sweep_only) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, delta_fixed, &view);
+        if (S == 1 && !RG_SWEEP_ABL(128u) && !d.sweep_only) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, delta_fixed, &view);
     }
 }
 
