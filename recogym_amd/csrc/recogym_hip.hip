@@ -254,6 +254,13 @@ struct Carve {
 
 constexpr uint32_t kMaxSC = 32;           // stored partial sums per user in the MFMA draw kernel
 constexpr uint32_t kHoleCode = 0xFFFFFFFFu;   // rg_event.code of an unused raw-log entry (no real row has every bit set: P < 2^29)
+// timing experiments of the walk (RECOGYM_ABLATE bits 16-22: see DESIGN.md) exist in -DRG_WALK_TIMING builds only
+#ifdef RG_WALK_TIMING
+#define RG_WALK_ABL(bit) (d.ablate & (1u << (bit)))
+#else
+#define RG_WALK_ABL(bit) (false)
+#endif
+
 constexpr int kCntTailRows = 16, kCntTailOrganic = 17, kCntTailBandit = 18, kCntTailMaxT = 19, kCntTailTicket = 20,
               kCntTailLimit = 21, kCntWalkTicket = 22, kCntParkCnt = 23;   // internal slots of counters[] (RG_CNT_N = 24)
 
@@ -782,7 +789,7 @@ __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, ui
 #pragma unroll
             for (int i = 0; i < kHistRegs; ++i) f[i] = e[i];
             for (uint32_t base = 0; base <= nd && !found; base += kHistRegs) {
-                if (base && (d.ablate & (1u << 22))) { found = true; a_f = 0; c_f = 1; break; }   // timing experiment: first line only
+                if (base && RG_WALK_ABL(22)) { found = true; a_f = 0; c_f = 1; break; }   // timing experiment: first line only
                 if (base) hist_load_line(hr + base, f);            // (rows are whole 16-entry lines)
 #pragma unroll
                 for (int i = 0; i < kHistRegs; ++i) {
@@ -951,7 +958,7 @@ __device__ void history_add(const DevSim& d, uint32_t slot, uint32_t v) {
     }
     // longer histories: the position a line of 16 entries at a time (8 independent loads and 16 compares instead of a
     // dependent load per entry), the shift four entries at a time from the top
-    if (d.ablate & (1u << 22)) return;          // timing experiment: histories stop growing at one line
+    if RG_WALK_ABL(22) return;          // timing experiment: histories stop growing at one line
     uint32_t pos = 1;                           // first entry with product >= v (nd + 1 if none)
     hent_t at = 0ull;                           // the entry there
     bool past = false;
@@ -4310,7 +4317,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
         bool parked = false;
         // =========================== organic product draw ===========================
         const unsigned long long org_mask = __ballot(is_org);
-        if (org_mask && (d.ablate & (1u << 20))) {          // timing experiment: no draw at all
+        if (org_mask && RG_WALK_ABL(20)) {          // timing experiment: no draw at all
             if (is_org) {
                 if (d.log && my_row < d.log_cap) { rg_event e; e.u = user; e.t = t; e.code = (user + t) % d.P; e.ps = __builtin_nanf(""); d.log[my_row] = e; }
                 c_org += 1;
@@ -4404,7 +4411,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 const int grp = lane >> 1, gl = lane & 1;
-                for (uint32_t base = (d.ablate & (1u << 16)) ? n_todo : 0u; base < n_todo; base += 32) {
+                for (uint32_t base = RG_WALK_ABL(16) ? n_todo : 0u; base < n_todo; base += 32) {
                     const bool has = base + grp < n_todo;
                     const int src = has ? static_cast<int>(slots[base + grp]) : 0;
                     const uint32_t cs = static_cast<uint32_t>(__shfl(static_cast<int>(c_star), src));
@@ -4448,7 +4455,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
                         } else if (gl == 0) { mbox[src * 3] = -1.0; mbox[src * 3 + 1] = pbs; mbox[src * 3 + 2] = pbs; }
                     }
                 }
-                if ((d.ablate & (1u << 16)) && search) { mbox[lane * 3] = 0.0; mbox[lane * 3 + 1] = 0.0; mbox[lane * 3 + 2] = 1e300; }
+                if (RG_WALK_ABL(16) && search) { mbox[lane * 3] = 0.0; mbox[lane * 3 + 1] = 0.0; mbox[lane * 3 + 2] = 1e300; }
             } else {
             // ---- the 32 products of the chosen chunk (phase 3): eight searching users per pass, eight lanes per
             // user, four products per lane.  A pass is ONE latency chain (user parameters -> 21 coalesced
@@ -4456,7 +4463,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
             // per pass of 32-lane prefixes cost a chain per pair and made the walk 4x slower ----
             const int grp = lane >> 3, gl = lane & 7;
             unsigned long long todo = __ballot(search);
-            if (d.ablate & (1u << 16)) { todo = 0; if (search) { mbox[lane * 3] = 0.0; mbox[lane * 3 + 1] = 0.0; mbox[lane * 3 + 2] = 1e300; } }
+            if RG_WALK_ABL(16) { todo = 0; if (search) { mbox[lane * 3] = 0.0; mbox[lane * 3 + 1] = 0.0; mbox[lane * 3 + 2] = 1e300; } }
             while (todo) {
                 int src = -1;
 #pragma unroll
@@ -4553,7 +4560,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
                     d.log[my_row] = e;
                 }
                 if (d.lpv) d.lpv[slot] = v;
-                if (d.hist_cap && !(d.ablate & (1u << 17))) history_add(d, slot, v);
+                if (d.hist_cap && !RG_WALK_ABL(17)) history_add(d, slot, v);
                 c_org += 1;
                 pending = false;
             }
@@ -4580,7 +4587,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
         const bool is_ban = run_ban && st == RG_STATE_BANDIT, is_ph = run_ban && st == kPhantom;
         double ps = 1.0;
         uint32_t a = 0;
-        if (is_ban || is_ph) a = (d.ablate & (1u << 18)) ? (user + t) % d.P : policy_act<DENSE>(d, slot, user, t, &ps);
+        if (is_ban || is_ph) a = RG_WALK_ABL(18) ? (user + t) % d.P : policy_act<DENSE>(d, slot, user, t, &ps);
         if (is_ph) {       // final step_offline(done = True): the act above, reward 0 (abstract.py:223-233,311-316); t is already the row's time
             rg_event e;
             e.u = user; e.t = t; e.code = RG_EV_BANDIT | RG_EV_PHANTOM | a;
@@ -4600,7 +4607,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
             // slope <= 0.05; three v_exp / v_rcp at ~1e-6); the float64 evaluation below is for the lanes inside that
             // band (~4e-5 of the acts) and for runs that export the click probability.
             bool click_known = false;
-            if (is_ban && !d.aux_pclick && !(d.ablate & (1u << 21))) {
+            if (is_ban && !d.aux_pclick && !RG_WALK_ABL(21)) {
                 const float4* b4 = reinterpret_cast<const float4*>(d.beta32 + static_cast<size_t>(a) * d.KB4);
                 const float* om = om_sel + lane;
                 float x = 0.0f, ax = 0.0f;
@@ -4640,7 +4647,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
                 const double* b = d.beta + static_cast<size_t>(a) * d.K;
                 const double* om = d.omega + static_cast<size_t>(slot) * d.OMS;
                 double x = 0.0;
-                if (d.ablate & (1u << 19)) {}
+                if RG_WALK_ABL(19) {}
                 else if (!(d.K & 1)) {
                     // rows of K even are 16-byte aligned: half as many (scattered) load requests as 8-byte loads
                     for (uint32_t k0 = 0; k0 < d.K; k0 += 8) {
@@ -4668,7 +4675,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
                     for (int i = 0; i < 8; ++i)
                         if (k0 + i < d.K) x += bv[i] * wv[i];
                 }
-                const double ctr = (d.ablate & (1u << 19)) ? 0.01 : ff64(x + d.mu_b[a]);
+                const double ctr = RG_WALK_ABL(19) ? 0.01 : ff64(x + d.mu_b[a]);
                 const double p0 = 1.0 - ctr;
                 click = (p0 / (p0 + ctr)) <= rg_uniform(w.w[0], w.w[1]);
                 c_clicks += click;
