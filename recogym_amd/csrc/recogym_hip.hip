@@ -48,7 +48,18 @@
 #include "../../include/recogym_hip.h"
 #include "../../include/recogym_rng.h"
 
-namespace {
+// Translation-unit parts.  The file compiles as ONE translation unit (RG_PART undefined) or, in parallel, as seven
+// (-DRG_PART=1..7, linked into one library by __graft_entry__.build()): part 1 holds the host code and the small
+// kernels; every large kernel family lives in a part of its own (2 float64 resolve, 3 fp32 / lean bf16 sweeps, 4 the
+// pipelined sweep + per-user cache kernels, 5 the wide-K sweep, 6 advance / tail / frozen LogReg, 7 the user-major
+// walk) and hands its kernels to the host code through the *_kernel_for functions.  Types and device helpers are
+// shared by all parts (namespace rgk, identical in every unit).
+#ifndef RG_PART
+#define RG_PART 0
+#endif
+#define RG_HAS(p) (RG_PART == 0 || RG_PART == (p))
+
+namespace rgk {
 
 constexpr uint32_t kMaxSteps = 1u << 16;       // P(a user survives that long) ~ exp(-650)
 constexpr int kBlock = 256;                    // 4 waves of 64
@@ -60,9 +71,9 @@ inline uint64_t repack_min_users() {
     return e ? static_cast<uint64_t>(strtoull(e, nullptr, 10)) : (1ull << 18);
 }
 
-thread_local char g_err[512] = "";
+inline thread_local char g_err[512] = "";
 
-int fail(int code, const char* fmt, ...) {
+inline int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -205,7 +216,8 @@ struct DevSim {
     double* aux_time;         // optional side array of the log: time of every raw row
 };
 
-}  // namespace
+}  // namespace rgk
+using namespace rgk;
 
 struct rg_sim {
     rg_config cfg;
@@ -235,7 +247,38 @@ struct rg_sim {
     uint64_t prof_launches;
 };
 
-namespace {
+namespace rgk {
+
+// kernels of the other parts, as the host code (part 1) gets them
+typedef void (*exact_h_kernel_t)(DevSim, uint32_t, uint32_t);
+typedef void (*exact_m_kernel_t)(DevSim, uint32_t, int, int, uint32_t);
+typedef void (*exact_u_kernel_t)(DevSim, uint32_t, int, int, uint32_t);
+typedef void (*exact_pick_kernel_t)(DevSim, uint32_t, int, uint32_t);
+typedef void (*finalize_kernel_t)(DevSim);
+typedef void (*cached_kernel_t)(DevSim, uint32_t);
+typedef void (*draw_kernel_t)(DevSim, uint32_t, uint32_t);
+typedef void (*search_kernel_t)(DevSim, uint32_t);
+typedef void (*mfma_kernel_t)(DevSim, uint32_t);
+typedef void (*advance_kernel_t)(DevSim, uint32_t, const int32_t*);
+typedef void (*walk_kernel_t)(DevSim, uint32_t, int, uint32_t, uint32_t, uint32_t);
+exact_h_kernel_t exact_h_kernel_for(uint32_t kb);          // part 2
+exact_m_kernel_t exact_m_kernel_for(uint32_t kb);
+exact_u_kernel_t exact_u_kernel_for(uint32_t kb);
+exact_m_kernel_t exact_tile_kernel();                      // k_exact_sums
+exact_h_kernel_t exact_ref_kernel();                       // k_exact_ref
+exact_pick_kernel_t exact_pick_kernel();                   // k_exact_pick
+search_kernel_t search_kernel_for(const DevSim& d);        // part 3
+draw_kernel_t bf16_kernel_for(const DevSim& d);
+mfma_kernel_t mfma_kernel_for(uint32_t KH);
+finalize_kernel_t finalize_kernel_for(const DevSim& d);    // part 4
+cached_kernel_t cached_kernel_for(const DevSim& d);
+draw_kernel_t bf16p_kernel_for(const DevSim& d);
+draw_kernel_t f16w_kernel_for(const DevSim& d);            // part 5
+search_kernel_t logreg_select_kernel();                    // part 6
+search_kernel_t logreg_acts_kernel();
+advance_kernel_t advance_kernel();
+search_kernel_t tail_kernel();
+walk_kernel_t walk_kernel_for(const DevSim& d, int occ);   // part 7
 
 // ------------------------------------------------------------------------------------------
 // workspace carving (host)
@@ -266,7 +309,7 @@ constexpr int kCntTailRows = 16, kCntTailOrganic = 17, kCntTailBandit = 18, kCnt
 
 struct Geom { uint32_t KH, KS, TP, P_pad, n_chunks, sc_chunks, n_sc, N1, N2, N3, RS, TPB, F16; };
 
-Geom geom_of(const rg_config& c) {
+inline Geom geom_of(const rg_config& c) {
     Geom g{};
     const uint32_t need = (c.K + 1) / 2;
     const uint32_t opts[] = {4, 10, 16, 32, 64};
@@ -316,7 +359,7 @@ Geom geom_of(const rg_config& c) {
 
 // the per-user sum cache exists where omega cannot change (sigma_omega == 0) and a 16-bit MFMA kernel class serves K
 // (RECOGYM_CACHE=0: A/B tests)
-bool cache_wanted(const rg_config& c, const Geom& g) {
+inline bool cache_wanted(const rg_config& c, const Geom& g) {
     const char* e = getenv("RECOGYM_CACHE");
     return c.sigma_omega == 0.0 && g.N1 != 0 && !(e && e[0] == '0');
 }
@@ -327,7 +370,7 @@ bool cache_wanted(const rg_config& c, const Geom& g) {
 // OPT-IN (RECOGYM_SUB=1).  Measured (profiles/r2): the walk's L1 requests per event drop 2.3x and its time does not
 // move (C3: 266 -> 267 ms; C2: 17.9 -> 16.1 ms) while the sweep that writes 4x the sums goes 29 -> 45 ms on C3 —
 // the walk is bound by its chains of dependent loads, not by L1 bytes.
-bool sub_wanted(const rg_config& c, const Geom& g) {
+inline bool sub_wanted(const rg_config& c, const Geom& g) {
     const char* e = getenv("RECOGYM_SUB");
     const bool walks = c.policy == RG_POLICY_UNIFORM_ENV || c.policy == RG_POLICY_RANDOM_AGENT ||
                        c.policy == RG_POLICY_ORGANIC_USER_COUNT || c.policy == RG_POLICY_LAST_VIEW_TABLE;
@@ -335,7 +378,7 @@ bool sub_wanted(const rg_config& c, const Geom& g) {
 }
 
 // rows of the float64 chunk-sum scratch (see DevSim::exact_rows)
-size_t exact_rows_of(const rg_config& c, const Geom& g, uint64_t n) {
+inline size_t exact_rows_of(const rg_config& c, const Geom& g, uint64_t n) {
     const char* e = getenv("RECOGYM_DRAW");
     const char* f = getenv("RECOGYM_FORCE_EXACT");
     const bool all_f64 = !g.KH || (e && !strcmp(e, "f64")) || (f && f[0] == '1');
@@ -344,30 +387,30 @@ size_t exact_rows_of(const rg_config& c, const Geom& g, uint64_t n) {
     return r < 4096 ? (n < 4096 ? n : 4096) : r;
 }
 
-size_t bf16_smem_bytes(const Geom& g, uint32_t K, uint32_t buffers) {
+inline size_t bf16_smem_bytes(const Geom& g, uint32_t K, uint32_t buffers) {
     // split tiles + mu tiles (2 buffers: lean kernel, 3: pipelined kernel) + the per-wave omega32 stage [4][32][K]
     return buffers * (static_cast<size_t>(g.TPB) * g.RS + g.TPB * 4) + 4 * 32 * static_cast<size_t>(K) * 4 + 256;
 }
 
-size_t mfma_smem_bytes(const Geom& g) {
+inline size_t mfma_smem_bytes(const Geom& g) {
     return sizeof(float) * (2 * (static_cast<size_t>(g.TP) * g.KS + g.TP) + 64 + 4 * 32 * 2 * g.KH);   // tiles + omega stage
 }
 
 // K classes of the user-per-lane float64 kernel (omega lives in 8 XKB registers per lane)
-uint32_t exact_kb_of(uint32_t K) {
+inline uint32_t exact_kb_of(uint32_t K) {
     const uint32_t opts[] = {1, 2, 3, 4, 5, 6, 8, 12, 16};
     for (uint32_t o : opts) if (K <= 4 * o) return o;
     return 0;
 }
 
-uint32_t hist_cap_of(const rg_config& c) {
+inline uint32_t hist_cap_of(const rg_config& c) {
     if (c.policy != RG_POLICY_ORGANIC_USER_COUNT && c.policy != RG_POLICY_LOGREG_FROZEN) return 0;
     // entries per row: the header + the distinct products kept, rounded up to whole 128-byte lines of 16 entries (what
     // the register paths load at a time)
     return ((c.ouc_history_cap ? c.ouc_history_cap : kDefaultHistoryCap - 1u) + 1u + 15u) & ~15u;
 }
 
-size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
+inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     Carve w(base);
     const size_t n_pad = align_up(n, 64);
     const size_t P = c.num_products, K = c.K;
@@ -458,7 +501,7 @@ size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     return align_up(w.off, 256);
 }
 
-int validate(const rg_config* c, uint64_t n) {
+inline int validate(const rg_config* c, uint64_t n) {
     if (!c) return fail(RG_EINVAL, "config is NULL");
     if (c->num_products == 0 || c->num_products > RG_EV_INDEX_MASK)
         return fail(RG_EINVAL, "num_products %u out of range [1, 2^29)", c->num_products);
@@ -521,6 +564,7 @@ __device__ __forceinline__ uint32_t* list_ptr(const DevSim& d, uint32_t parity, 
 // ------------------------------------------------------------------------------------------
 // k_reset_users
 // ------------------------------------------------------------------------------------------
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_reset_users(DevSim d) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         d.step_cnt[0] = d.n_users;   // everyone starts organic (abstract.py:93)
@@ -545,9 +589,11 @@ __global__ void __launch_bounds__(kBlock) k_reset_users(DevSim d) {
         if (d.use_cache) { d.f64_valid[i] = 0; d.cache_resc[i] = 0; }
     }
 }
+#endif
 
 // fp32 copies of Gamma / mu_organic for the MFMA path: gamma32 [P_pad][KS] (columns >= K and rows
 // >= P are zero), mu32 [P_pad] (-inf beyond P, so padded products get probability exactly 0).
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_make_fp32_tables(DevSim d) {
     const size_t n = static_cast<size_t>(d.P_pad) * d.KS;
     for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
@@ -565,6 +611,7 @@ __global__ void __launch_bounds__(kBlock) k_make_fp32_tables(DevSim d) {
         }
     }
 }
+#endif
 
 __device__ __forceinline__ unsigned short bf16_rne(float x) {
     unsigned u = __builtin_bit_cast(unsigned, x);
@@ -594,6 +641,7 @@ __device__ __forceinline__ void bf16_split3(float x, unsigned short* sp) {
 // gsplit[p] = [G1(K) | G2(K) | G3(K) | 0 ... 0 | 1 1 1] (bf16), the A operand rows of the split-bf16
 // kernel, G = fl32(Gamma log2 e): the MFMA then yields logits in log2 units, and the three ones
 // multiply the three bf16 pieces of -reference that sit in the user's B row.
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_make_split_table(DevSim d) {
     const size_t rs2 = d.RS / 2;
     const size_t n = static_cast<size_t>(d.P_pad) * rs2;
@@ -617,8 +665,10 @@ __global__ void __launch_bounds__(kBlock) k_make_split_table(DevSim d) {
         if (i < d.P_pad) d.mu32s[i] = i < d.P ? static_cast<float>(d.mu_o[i] * log2e) : -INFINITY;
     }
 }
+#endif
 
 // float64 transpose of Gamma for the float64 draw kernel: lane-per-product reads coalesce
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_make_gammaT(DevSim d) {
     const size_t n = static_cast<size_t>(d.K) * d.PT;
     for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
@@ -627,7 +677,9 @@ __global__ void __launch_bounds__(kBlock) k_make_gammaT(DevSim d) {
         d.gammaT[i] = p < d.P ? d.gamma[p * d.K + k] : 0.0;
     }
 }
+#endif
 
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_make_beta32(DevSim d) {
     const size_t n = static_cast<size_t>(d.P) * d.KB4;
     for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
@@ -636,7 +688,9 @@ __global__ void __launch_bounds__(kBlock) k_make_beta32(DevSim d) {
         d.beta32[i] = k < d.K ? static_cast<float>(d.beta[p * d.K + k]) : 0.0f;
     }
 }
+#endif
 
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_make_gamma_rm(DevSim d) {
     const uint32_t rs = 4 * d.XKB + 4;
     const size_t n = static_cast<size_t>(d.PT) * rs;
@@ -649,10 +703,12 @@ __global__ void __launch_bounds__(kBlock) k_make_gamma_rm(DevSim d) {
         d.gamma_rm[i] = v;
     }
 }
+#endif
 
 // Table statistics for the logit error bound of the MFMA path (one block per statistic):
 //   block k < 2KH : max_p |Gamma[p][k]|      block 2KH : max_p ||Gamma[p]||_2
 //   block 2KH+1   : max_p |mu_o[p]|
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_table_stats(DevSim d) {
     __shared__ double red[kBlock];
     const uint32_t which = blockIdx.x;
@@ -676,6 +732,7 @@ __global__ void __launch_bounds__(kBlock) k_table_stats(DevSim d) {
     // round up: the bound must dominate the float64 value
     if (threadIdx.x == 0) d.stats[which] = static_cast<float>(red[0] * (1.0 + 1e-6));
 }
+#endif
 
 typedef unsigned long long hent_t;
 __device__ __forceinline__ hent_t* hist_row(const DevSim& d, uint32_t slot) { return d.hist + static_cast<size_t>(slot) * d.hist_cap; }
@@ -1056,7 +1113,7 @@ __device__ __forceinline__ double exp64(double x) {
 // n = rint(x * 32/ln 2) = 32 e + j and |r| <= ln 2 / 64, so a degree-6 polynomial is enough
 // (remainder r^7/5040 < 4e-18) — ~15 float64 instructions instead of ~35.  T[j] = 2^(j/32),
 // correctly rounded; `tab` is the block's LDS copy (32 doubles, one bank pair each: conflict-free).
-__device__ const double kExp2Tab32[32] = {
+static __device__ const double kExp2Tab32[32] = {
     0x1.0000000000000p+0, 0x1.059b0d3158574p+0, 0x1.0b5586cf9890fp+0, 0x1.11301d0125b51p+0,
     0x1.172b83c7d517bp+0, 0x1.1d4873168b9aap+0, 0x1.2387a6e756238p+0, 0x1.29e9df51fdee1p+0,
     0x1.306fe0a31b715p+0, 0x1.371a7373aa9cbp+0, 0x1.3dea64c123422p+0, 0x1.44e086061892dp+0,
@@ -1130,6 +1187,7 @@ __device__ __forceinline__ void logit64x4(const DevSim& d, const double* om, uin
 constexpr int kUPW = 4;                      // users per wave
 constexpr int kExactUsers = 4 * kUPW;        // users per block
 
+#if RG_HAS(2)
 __global__ void __launch_bounds__(kBlock) k_exact_sums(DevSim d, uint32_t t, int from_list, int mode, uint32_t S) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -1242,6 +1300,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums(DevSim d, uint32_t t, int
         }
     }
 }
+#endif
 
 // User-per-lane variant of k_exact_sums for K <= 64 (the one that runs; the tile kernel above
 // remains for larger K).  With a product per lane every FMA needs an omega value broadcast from
@@ -1258,6 +1317,7 @@ typedef const __attribute__((address_space(4))) double kdouble;   // constant ad
 // (omega alone is 2 x 4 KB registers per user)
 __host__ __device__ constexpr int exact_upl_of(uint32_t kb) { return kb <= 5 ? 2 : 1; }
 
+#if RG_HAS(2)
 template <int KB>
 __global__ void __launch_bounds__(kBlock) k_exact_sums_u(DevSim d, uint32_t t, int from_list, int mode, uint32_t S) {
     constexpr int UPL = exact_upl_of(KB);
@@ -1349,6 +1409,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_u(DevSim d, uint32_t t, i
         }
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // k_exact_sums_m — the float64 chunk sums on the float64 MATRIX cores (v_mfma_f64_16x16x4_f64).
@@ -1369,6 +1430,7 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 __host__ __device__ constexpr int exact_m_groups(uint32_t kb) { return kb <= 8 ? 4 : 2; }
 __host__ __device__ constexpr uint32_t exact_m_lds(uint32_t kb) { return (2u * 64u * (4u * kb + 4u) + 32u) * 8u; }
 
+#if RG_HAS(2)
 template <int KB>
 __global__ void __launch_bounds__(kBlock) k_exact_sums_m(DevSim d, uint32_t t, int from_list, int mode, uint32_t S) {
     constexpr int G = exact_m_groups(KB);
@@ -1487,6 +1549,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_m(DevSim d, uint32_t t, i
         }
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // k_exact_sums_h — the parked users' batch of k_walk on BOTH float64 pipes at once.
@@ -1497,6 +1560,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_m(DevSim d, uint32_t t, i
 // vector form (a lane per user, Gamma rows through the scalar cache), so that the waves resident on a SIMD are a mix
 // of both and the two pipes work side by side.  Exp-sums only (mode 1), whole table per user (no product slices).
 // ------------------------------------------------------------------------------------------
+#if RG_HAS(2)
 template <int KB>
 __global__ void __launch_bounds__(kBlock) k_exact_sums_h(DevSim d, uint32_t n, uint32_t mfma_of_8) {
     constexpr int G = exact_m_groups(KB);
@@ -1638,8 +1702,9 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_h(DevSim d, uint32_t n, u
         }
     }
 }
+#endif
 
-typedef void (*exact_h_kernel_t)(DevSim, uint32_t, uint32_t);
+#if RG_HAS(2)
 exact_h_kernel_t exact_h_kernel_for(uint32_t kb) {
     switch (kb) {                               // K <= 32: 256-user groups in both forms
         case 1: return k_exact_sums_h<1>;   case 2: return k_exact_sums_h<2>;   case 3: return k_exact_sums_h<3>;
@@ -1649,7 +1714,6 @@ exact_h_kernel_t exact_h_kernel_for(uint32_t kb) {
     }
 }
 
-typedef void (*exact_m_kernel_t)(DevSim, uint32_t, int, int, uint32_t);
 exact_m_kernel_t exact_m_kernel_for(uint32_t kb) {
     if (const char* e = getenv("RECOGYM_EXACT")) if (!strcmp(e, "valu")) return nullptr;     // A/B: the vector-ALU kernel
     switch (kb) {
@@ -1659,8 +1723,9 @@ exact_m_kernel_t exact_m_kernel_for(uint32_t kb) {
         default: return nullptr;
     }
 }
+#endif
 // launch shape of k_exact_sums_m for `est` users: blocks of 64 / 128 / 256 users x S product slices
-void launch_exact_m(exact_m_kernel_t km, const DevSim& d, uint32_t t, int from_list, int mode, uint64_t est, hipStream_t st) {
+inline void launch_exact_m(exact_m_kernel_t km, const DevSim& d, uint32_t t, int from_list, int mode, uint64_t est, hipStream_t st) {
     const uint32_t upb = (kBlock / 64) * 16 * exact_m_groups(d.XKB);
     const uint64_t groups = (est + upb - 1) / upb;
     const uint32_t n_chunks = d.PT / 64;
@@ -1676,7 +1741,7 @@ void launch_exact_m(exact_m_kernel_t km, const DevSim& d, uint32_t t, int from_l
     hipLaunchKernelGGL(km, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), smem, st, d, t, from_list, mode, S);
 }
 
-typedef void (*exact_u_kernel_t)(DevSim, uint32_t, int, int, uint32_t);
+#if RG_HAS(2)
 exact_u_kernel_t exact_u_kernel_for(uint32_t kb) {
     switch (kb) {
         case 1: return k_exact_sums_u<1>;   case 2: return k_exact_sums_u<2>;   case 3: return k_exact_sums_u<3>;
@@ -1685,8 +1750,10 @@ exact_u_kernel_t exact_u_kernel_for(uint32_t kb) {
         default: return nullptr;
     }
 }
+#endif
 
 // pure float64 mode: the reference of every user = its max logit (reco_env_v1.py:121)
+#if RG_HAS(2)
 __global__ void __launch_bounds__(kBlock) k_exact_ref(DevSim d, uint32_t t, uint32_t G) {
     const int lane = lane_id();
     const uint32_t n_cc = (d.PT / 64 + G - 1) / G;
@@ -1699,6 +1766,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_ref(DevSim d, uint32_t t, uint
         if (lane == 0) d.exact_ref[w] = static_cast<float>(m * 1.4426950408889634074);
     }
 }
+#endif
 
 // The float64 pick of one user, by a whole wave (every argument wave-uniform): prefix over the stored chunk sums ->
 // the chunk that holds u * total -> its products walked in product order.  `om` = the user's omega in LDS.
@@ -1795,6 +1863,7 @@ __device__ __forceinline__ uint32_t exact_pick_wave(const DevSim& d, const doubl
     return v;
 }
 
+#if RG_HAS(2)
 __global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int from_list, uint32_t G) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -1836,6 +1905,10 @@ __global__ void __launch_bounds__(kBlock) k_exact_pick(DevSim d, uint32_t t, int
         atomicAdd(&d.counters[RG_CNT_EXACT_SWEEPS], static_cast<unsigned long long>(n_a > base ? n_a - base : 0u));
     }
 }
+exact_m_kernel_t exact_tile_kernel() { return k_exact_sums; }
+exact_h_kernel_t exact_ref_kernel() { return k_exact_ref; }
+exact_pick_kernel_t exact_pick_kernel() { return k_exact_pick; }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // k_draw_mfma — the organic product draw on the fp32 matrix cores, with a certified margin.
@@ -2083,6 +2156,7 @@ __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, con
         }
 }
 
+#if RG_HAS(3)
 template <int KH>
 __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_draw_mfma(DevSim d, uint32_t t) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -2226,6 +2300,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_draw_mfma(DevSim
                             active, pos, slot, j, h, false, kDeltaFixed);
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // k_draw_bf16 — the same draw on the bf16 matrix cores with fp32-class accuracy.
@@ -2249,6 +2324,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_draw_mfma(DevSim
 // ------------------------------------------------------------------------------------------
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
 
+#if RG_HAS(3)
 template <int KH, int N1, int N2, int N3>
 __global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 3 : 1)) k_draw_bf16(DevSim d, uint32_t t, uint32_t S) {
     // Register-lean form: ONE chunk (one accumulator) in flight per wave and no software pipeline,
@@ -2425,6 +2501,7 @@ __global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 3 : 1)) k_draw_bf16(DevSim 
         if (S == 1) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, kDeltaFixedBf16);
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // k_draw_bf16p — the same computation as k_draw_bf16 with the instruction stream arranged for
@@ -2498,6 +2575,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* generic_ptr) {
 #define RG_SWEEP_ABL(bit) (false)
 #endif
 
+#if RG_HAS(4)
 template <int KH, int N1, int N2, int N3, bool F16, bool SUB = false>
 __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, uint32_t S) {
     constexpr int NM = F16 ? N1 : N1 + N2 + N3;   // MFMAs per chunk (fp16 two-way split: one group)
@@ -2837,8 +2915,10 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         if (S == 1 && !RG_SWEEP_ABL(128u) && !d.sweep_only) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, delta_fixed, &view);
     }
 }
+#endif
 
 // second kernel of the sliced mode: the search over the sums all slices of a user tile left
+#if RG_HAS(3)
 template <int KH>
 __global__ void __launch_bounds__(kBlock) k_draw_search(DevSim d, uint32_t t) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -2879,6 +2959,7 @@ __global__ void __launch_bounds__(kBlock) k_draw_search(DevSim d, uint32_t t) {
         __builtin_amdgcn_wave_barrier();
     }
 }
+#endif
 
 
 // ------------------------------------------------------------------------------------------
@@ -2896,6 +2977,7 @@ __global__ void __launch_bounds__(kBlock) k_draw_search(DevSim d, uint32_t t) {
 // resolve are done a lane per user again.
 // ------------------------------------------------------------------------------------------
 // after step 0 (slot == user index: nothing has been repacked yet), a lane per user
+#if RG_HAS(4)
 template <int KH>
 __global__ void __launch_bounds__(kBlock) k_cache_finalize(DevSim d) {
     constexpr int K2 = 2 * KH;
@@ -2967,7 +3049,9 @@ __global__ void __launch_bounds__(kBlock) k_cache_finalize(DevSim d) {
         for (int k = (K2 / 4) * 4; k < K2; ++k) reinterpret_cast<float*>(row4)[44 + k] = om[k];
     }
 }
+#endif
 
+#if RG_HAS(4)
 template <int KH>
 __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 3 : 2)) k_draw_cached(DevSim d, uint32_t t) {
     constexpr int K2 = 2 * KH;
@@ -3134,8 +3218,9 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 3 : 2)) k_draw_cached(DevS
         __builtin_amdgcn_wave_barrier();                                 // the omega32 stage is reused by the next group
     }
 }
+#endif
 
-typedef void (*finalize_kernel_t)(DevSim);
+#if RG_HAS(4)
 finalize_kernel_t finalize_kernel_for(const DevSim& d) {
     switch (d.KH) {
         case 4: return k_cache_finalize<4>;
@@ -3144,7 +3229,6 @@ finalize_kernel_t finalize_kernel_for(const DevSim& d) {
         default: return k_cache_finalize<32>;
     }
 }
-typedef void (*cached_kernel_t)(DevSim, uint32_t);
 cached_kernel_t cached_kernel_for(const DevSim& d) {
     switch (d.KH) {
         case 4: return k_draw_cached<4>;
@@ -3153,10 +3237,10 @@ cached_kernel_t cached_kernel_for(const DevSim& d) {
         default: return k_draw_cached<32>;
     }
 }
+#endif
 
 // kernel selection by (KH, N1, N2, N3)
-typedef void (*draw_kernel_t)(DevSim, uint32_t, uint32_t);
-typedef void (*search_kernel_t)(DevSim, uint32_t);
+#if RG_HAS(3)
 search_kernel_t search_kernel_for(const DevSim& d) {
     switch (d.KH) {
         case 4: return k_draw_search<4>;
@@ -3166,6 +3250,8 @@ search_kernel_t search_kernel_for(const DevSim& d) {
         default: return k_draw_search<64>;
     }
 }
+#endif
+#if RG_HAS(4)
 draw_kernel_t bf16p_kernel_for(const DevSim& d) {
     if (d.f16) {
 #define RG_CASE(kh, a) if (d.KH == kh && d.N1 == a) return d.cache_sub ? k_draw_bf16p<kh, a, 0, 0, true, true> : k_draw_bf16p<kh, a, 0, 0, true>;
@@ -3178,6 +3264,8 @@ draw_kernel_t bf16p_kernel_for(const DevSim& d) {
 #undef RG_CASE
     return nullptr;
 }
+#endif
+#if RG_HAS(3)
 draw_kernel_t bf16_kernel_for(const DevSim& d) {
 #define RG_CASE(kh, a, b, c) if (d.KH == kh && d.N1 == a && d.N2 == b && d.N3 == c) return k_draw_bf16<kh, a, b, c>;
     RG_CASE(4, 1, 1, 1) RG_CASE(4, 2, 1, 1) RG_CASE(10, 3, 2, 1) RG_CASE(10, 4, 3, 2)
@@ -3185,6 +3273,16 @@ draw_kernel_t bf16_kernel_for(const DevSim& d) {
 #undef RG_CASE
     return nullptr;
 }
+mfma_kernel_t mfma_kernel_for(uint32_t KH) {
+    switch (KH) {
+        case 4: return k_draw_mfma<4>;
+        case 10: return k_draw_mfma<10>;
+        case 16: return k_draw_mfma<16>;
+        case 32: return k_draw_mfma<32>;
+        default: return k_draw_mfma<64>;
+    }
+}
+#endif
 
 
 // ------------------------------------------------------------------------------------------
@@ -3212,12 +3310,13 @@ draw_kernel_t bf16_kernel_for(const DevSim& d) {
 #endif
 #ifdef RG_F16W_TIMING
 // -DRG_F16W_TIMING: s_memtime per section of the tile loop, summed over wave 0 of every block (tools/wide_probe.py)
-__device__ unsigned long long g_f16w_t[8];
+static __device__ unsigned long long g_f16w_t[8];
 #define RG_TSEC(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
 #else
 #define RG_TSEC(i) do {} while (0)
 #endif
 
+#if RG_HAS(5)
 template <int KH, int N1, int UG>
 __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t, uint32_t S) {
     // Nothing that lives across the tile loop may be spilled: a reload inside the loop is followed by `s_waitcnt
@@ -3530,12 +3629,14 @@ __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t,
         }
     }
 }
+#endif
 
 // user groups per wave of the wide kernel (RECOGYM_F16W_UG: 1 = 8 waves x 32 users, 2 = 4 waves x 64 users)
 inline int f16w_ug() {
     const char* e = getenv("RECOGYM_F16W_UG");
     return (e && e[0] == '2') ? 2 : 1;
 }
+#if RG_HAS(5)
 draw_kernel_t f16w_kernel_for(const DevSim& d) {
     const int ug = f16w_ug();
 #define RG_CASE(kh, a) if (d.KH == kh && d.N1 == a) return ug == 2 ? k_draw_f16w<kh, a, 2> : k_draw_f16w<kh, a, 1>;
@@ -3543,6 +3644,7 @@ draw_kernel_t f16w_kernel_for(const DevSim& d) {
 #undef RG_CASE
     return nullptr;
 }
+#endif
 
 // RG_POLICY_LOGREG_FROZEN for one user, computed by the whole wave: lane = class (c, c + 64, ...), so the
 // coef_t rows of the viewed products are read as coalesced 512-byte runs instead of one gather per
@@ -3609,6 +3711,7 @@ __device__ uint32_t logreg_act_wave(const DevSim& d, uint32_t slot, int lane) {
 //                    twice that bound it IS sklearn's argmax; otherwise (near-ties, exact ties) the float64 walk in
 //                    scipy's summation order (logreg_act_wave) decides — predict() bit for bit either way.
 // ------------------------------------------------------------------------------------------
+#if RG_HAS(6)
 __global__ void __launch_bounds__(kBlock) k_logreg_select(DevSim d, uint32_t t) {
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC], n_b = d.step_cnt[2 * t + RG_STATE_BANDIT], n = n_o + n_b;
     const uint32_t* cur_o = list_ptr(d, t & 1, RG_STATE_ORGANIC);
@@ -3639,7 +3742,9 @@ __global__ void __launch_bounds__(kBlock) k_logreg_select(DevSim d, uint32_t t) 
         if (need) d.lr_list[base + prefix_in_mask(m)] = slot;
     }
 }
+#endif
 
+#if RG_HAS(6)
 __global__ void __launch_bounds__(kBlock) k_logreg_acts(DevSim d, uint32_t t) {
     const int lane = lane_id();
     const uint32_t n = d.lr_cnt[t];
@@ -3702,11 +3807,13 @@ __global__ void __launch_bounds__(kBlock) k_logreg_acts(DevSim d, uint32_t t) {
         if (lane == 0) { d.lr_action[uidx] = action; d.lr_dirty[uidx] = 0; }
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // k_advance — one Markov transition for every live user (lane per user).
 // ------------------------------------------------------------------------------------------
 constexpr int kAdvBlock = 256;
+#if RG_HAS(6)
 __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, const int32_t* actions) {
     constexpr int kSub = 1;                     // block iterations that share one reservation
     __shared__ uint32_t s_cnt_o[kSub][kAdvBlock / 64], s_cnt_b[kSub][kAdvBlock / 64], s_base_o, s_base_b;
@@ -3898,6 +4005,7 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
         if (phantoms) atomicAdd(&d.counters[RG_CNT_PHANTOM], static_cast<unsigned long long>(phantoms));
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // k_tail — the end of a run, user by user instead of step by step.
@@ -3912,6 +4020,7 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
 // steps > t0 are counted in the kCntTail* counters (step t0's are in step_cnt[t0]).
 // ------------------------------------------------------------------------------------------
 
+#if RG_HAS(6)
 __global__ void __launch_bounds__(kBlock) k_tail(DevSim d, uint32_t t0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* om = reinterpret_cast<double*>(smem_raw);                       // [K rounded up to 2]
@@ -4099,13 +4208,20 @@ __global__ void __launch_bounds__(kBlock) k_tail(DevSim d, uint32_t t0) {
         if (c_maxt) atomicMax(&d.counters[kCntTailMaxT], static_cast<unsigned long long>(c_maxt));
     }
 }
+search_kernel_t logreg_select_kernel() { return k_logreg_select; }
+search_kernel_t logreg_acts_kernel() { return k_logreg_acts; }
+advance_kernel_t advance_kernel() { return k_advance; }
+search_kernel_t tail_kernel() { return k_tail; }
+#endif
 
 // closes the books of the tail: step t0 + 1 exists, is empty, and starts after the tail's rows
+#if RG_HAS(1)
 __global__ void k_tail_finish(DevSim d, uint32_t t0) {
     d.log_base[t0 + 1] = d.log_base[t0] + d.counters[kCntTailRows];
     d.step_cnt[2 * (t0 + 1)] = 0;
     d.step_cnt[2 * (t0 + 1) + 1] = 0;
 }
+#endif
 
 
 // ------------------------------------------------------------------------------------------
@@ -4138,6 +4254,7 @@ constexpr int kWalkUsers = RG_WALK_USERS;
 // LDS of one wave of k_walk: omega32 of its 2 x 64 users [entry][2 KH][64] + the mailbox + the rank table
 __host__ __device__ inline size_t walk_wave_lds(uint32_t KH) { return static_cast<size_t>(kWalkUsers) * 2 * KH * 64 * 4 + 64 * 24 + 64 * 4; }
 
+#if RG_HAS(7)
 template <int KH, int OCC, bool DENSE>
 __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_work, int round, uint32_t chunk_rows,
                                                        uint32_t in_base, uint32_t out_base) {
@@ -4735,15 +4852,18 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
         if (c_limit) atomicAdd(&d.counters[kCntTailLimit], static_cast<unsigned long long>(c_limit));
     }
 }
+#endif
 
 // closes the books of a walked run: no lock-step step holds events; step 1 exists, is empty and starts after the raw rows
+#if RG_HAS(1)
 __global__ void k_walk_finish(DevSim d) {
     d.step_cnt[0] = 0; d.step_cnt[1] = 0; d.step_cnt[2] = 0; d.step_cnt[3] = 0;
     d.log_base[0] = 0;
     d.log_base[1] = d.counters[kCntTailRows];
 }
+#endif
 
-typedef void (*walk_kernel_t)(DevSim, uint32_t, int, uint32_t, uint32_t, uint32_t);
+#if RG_HAS(7)
 // blocks per CU the kernel is compiled for (register budget 512 / OCC per lane): KH <= 16 at 2, 3 or 4, KH = 32 at 1
 walk_kernel_t walk_kernel_for(const DevSim& d, int occ) {
     // the O(P) forms of the OrganicUserEventCounter policy are compiled in only where the configuration can reach them
@@ -4757,8 +4877,10 @@ walk_kernel_t walk_kernel_for(const DevSim& d, int occ) {
     }
 #undef RG_W
 }
+#endif
 
 // totals that are sums over the per-step counts
+#if RG_HAS(1)
 __global__ void k_totals(DevSim d, uint32_t t_now) {
     __shared__ unsigned long long so[kBlock], sb[kBlock];
     unsigned long long o = 0, b = 0;
@@ -4779,7 +4901,9 @@ __global__ void k_totals(DevSim d, uint32_t t_now) {
         d.counters[RG_CNT_LOG_DROPPED] = d.log ? (rows > d.log_cap ? rows - d.log_cap : 0ull) : 0ull;
     }
 }
+#endif
 
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_export_state(DevSim d, uint32_t t, int8_t* state) {
     const uint32_t n_o = d.step_cnt[2 * t], n_b = d.step_cnt[2 * t + 1];
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_o + n_b; i += gridDim.x * kBlock) {
@@ -4787,7 +4911,9 @@ __global__ void __launch_bounds__(kBlock) k_export_state(DevSim d, uint32_t t, i
         else state[d.uid[list_ptr(d, t & 1, 1)[i - n_o]]] = RG_STATE_BANDIT;
     }
 }
+#endif
 
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_export_omega(DevSim d, double* out) {
     const size_t n = static_cast<size_t>(d.n_users) * d.K;
     for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
@@ -4796,8 +4922,10 @@ __global__ void __launch_bounds__(kBlock) k_export_omega(DevSim d, double* out) 
         out[i] = d.omega[u * d.OMS + k];
     }
 }
+#endif
 
 // test hooks
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_debug_set_omega(DevSim d, const double* in) {
     const size_t n = static_cast<size_t>(d.n_users) * d.K;
     for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < n;
@@ -4806,14 +4934,18 @@ __global__ void __launch_bounds__(kBlock) k_debug_set_omega(DevSim d, const doub
         d.omega[u * d.OMS + k] = in[i];
     }
 }
+#endif
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_debug_uncertified(DevSim d, uint32_t t_prev, uint8_t* flags) {
     const uint32_t n_a = d.exact_cnt[t_prev], n = n_a + (d.use_cache ? d.exact_cnt_b[t_prev] : 0u);
     const uint32_t* lst = list_ptr(d, t_prev & 1, RG_STATE_ORGANIC);
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
         flags[d.uid[lst[d.exact_list[i < n_a ? i : d.n_cap - 1u - (i - n_a)]]]] = 1;
 }
+#endif
 
 // live users only (after a repack the slots of users that left are gone); `out` is zero-filled first
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_export_omega_live(DevSim d, uint32_t t, double* out) {
     const uint32_t n_o = d.step_cnt[2 * t], n_b = d.step_cnt[2 * t + 1];
     const size_t n = static_cast<size_t>(n_o + n_b) * d.K;
@@ -4824,6 +4956,7 @@ __global__ void __launch_bounds__(kBlock) k_export_omega_live(DevSim d, uint32_t
         out[static_cast<size_t>(d.uid[slot]) * d.K + k] = d.omega[static_cast<size_t>(slot) * d.OMS + k];
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // repack: the live lists lose their order step by step (the block that reserves first writes
@@ -4833,6 +4966,7 @@ __global__ void __launch_bounds__(kBlock) k_export_omega_live(DevSim d, uint32_t
 // therefore copied into the second buffer in list order — new slot = position in [organic |
 // bandit] — and the lists become the identity.  Pure relabelling: user ids travel in uid[].
 // ------------------------------------------------------------------------------------------
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_repack_copy(DevSim d, uint32_t t) {
     const uint32_t n_o = d.step_cnt[2 * t], n_b = d.step_cnt[2 * t + 1], n = n_o + n_b;
     const uint32_t* cur_o = list_ptr(d, t & 1, RG_STATE_ORGANIC);
@@ -4855,7 +4989,9 @@ __global__ void __launch_bounds__(kBlock) k_repack_copy(DevSim d, uint32_t t) {
         }
     }
 }
+#endif
 
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_repack_lists(DevSim d, uint32_t t) {
     const uint32_t n_o = d.step_cnt[2 * t], n_b = d.step_cnt[2 * t + 1];
     uint32_t* cur_o = list_ptr(d, t & 1, RG_STATE_ORGANIC);
@@ -4865,16 +5001,20 @@ __global__ void __launch_bounds__(kBlock) k_repack_lists(DevSim d, uint32_t t) {
         else cur_b[i - n_o] = i;
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // log reordering: rows of user u occupy [off[u], off[u] + n_events[u] + has_phantom[u])
 // ------------------------------------------------------------------------------------------
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_rows_per_user(DevSim d, int64_t* rows) {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock)
         rows[i] = static_cast<int64_t>(d.n_events[i]) + d.has_phantom[i];
 }
+#endif
 
 // exclusive scan, three phases (block sums -> scan of sums by one block -> add)
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_scan_block(const int64_t* in, int64_t* out, int64_t* block_sums, uint32_t n) {
     __shared__ int64_t s[kBlock];
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -4890,7 +5030,9 @@ __global__ void __launch_bounds__(kBlock) k_scan_block(const int64_t* in, int64_
     if (i < n) out[i] = s[threadIdx.x] - x;
     if (threadIdx.x == kBlock - 1) block_sums[blockIdx.x] = s[threadIdx.x];
 }
+#endif
 
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_scan_sums(int64_t* block_sums, uint32_t nb, int64_t* total) {
     __shared__ int64_t s[kBlock];
     __shared__ int64_t carry;
@@ -4914,12 +5056,16 @@ __global__ void __launch_bounds__(kBlock) k_scan_sums(int64_t* block_sums, uint3
     }
     if (threadIdx.x == 0) *total = carry;
 }
+#endif
 
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_scan_add(int64_t* out, const int64_t* block_sums, uint32_t n) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < n) out[i] += block_sums[blockIdx.x];
 }
+#endif
 
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_scatter_rows(DevSim d, uint64_t n_rows, const int64_t* off,
                                                        rg_event* out, uint64_t out_cap) {
     for (uint64_t r = blockIdx.x * static_cast<uint64_t>(kBlock) + threadIdx.x; r < n_rows;
@@ -4930,7 +5076,9 @@ __global__ void __launch_bounds__(kBlock) k_scatter_rows(DevSim d, uint64_t n_ro
         if (dst < out_cap) out[dst] = e;
     }
 }
+#endif
 
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_scatter_phantom(DevSim d, const int64_t* off, rg_event* out,
                                                           uint64_t out_cap) {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) {
@@ -4939,9 +5087,11 @@ __global__ void __launch_bounds__(kBlock) k_scatter_phantom(DevSim d, const int6
         if (dst < out_cap) out[dst] = d.phantom[i];
     }
 }
+#endif
 
 // the float64 side arrays in the same order: NaN where the reference's column is NaN (organic rows; p_click of
 // the phantom row, which is never drawn)
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_scatter_aux(DevSim d, uint64_t n_rows, const int64_t* off,
                                                       double* out_ps, double* out_pc, uint64_t out_cap) {
     const double nan = __builtin_nan("");
@@ -4956,7 +5106,9 @@ __global__ void __launch_bounds__(kBlock) k_scatter_aux(DevSim d, uint64_t n_row
         if (out_pc) out_pc[dst] = (is_b && d.aux_pclick) ? d.aux_pclick[r] : nan;
     }
 }
+#endif
 
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_scatter_aux_phantom(DevSim d, const int64_t* off, double* out_ps,
                                                               double* out_pc, uint64_t out_cap) {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) {
@@ -4967,7 +5119,9 @@ __global__ void __launch_bounds__(kBlock) k_scatter_aux_phantom(DevSim d, const 
         if (out_pc) out_pc[dst] = __builtin_nan("");
     }
 }
+#endif
 
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_scatter_time(DevSim d, uint64_t n_rows, const int64_t* off, double* out, uint64_t out_cap) {
     for (uint64_t r = blockIdx.x * static_cast<uint64_t>(kBlock) + threadIdx.x; r < n_rows;
          r += static_cast<uint64_t>(gridDim.x) * kBlock) {
@@ -4977,6 +5131,8 @@ __global__ void __launch_bounds__(kBlock) k_scatter_time(DevSim d, uint64_t n_ro
         if (dst < out_cap) out[dst] = d.aux_time ? d.aux_time[r] : static_cast<double>(e.t);
     }
 }
+#endif
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_scatter_time_phantom(DevSim d, const int64_t* off, double* out, uint64_t out_cap) {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) {
         if (!d.has_phantom[i]) continue;
@@ -4984,11 +5140,15 @@ __global__ void __launch_bounds__(kBlock) k_scatter_time_phantom(DevSim d, const
         if (dst < out_cap) out[dst] = d.time_mode ? d.phantom_time[i] : static_cast<double>(d.n_events[i]);
     }
 }
+#endif
+#if RG_HAS(1)
 __global__ void __launch_bounds__(kBlock) k_export_time(DevSim d, uint32_t t, double* out) {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock)
         out[i] = d.time_mode ? d.utime[i] : static_cast<double>(d.n_events[i] ? d.n_events[i] : t);
 }
+#endif
 
+#if RG_HAS(1)   // host code (to the end of the namespace)
 inline int grid_for(uint64_t n, int per_block = kBlock) {
     uint64_t g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -5024,10 +5184,10 @@ void launch_exact(rg_sim* sim, uint32_t t, int from_list, uint64_t est, hipStrea
         if (exact_m_kernel_t km = (getenv("RECOGYM_EXACT_TILE") ? nullptr : exact_m_kernel_for(d.XKB))) {
             if (!from_list) {
                 launch_exact_m(km, d, t, 0, 0, est, st);
-                hipLaunchKernelGGL(k_exact_ref, dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t, 1u);
+                hipLaunchKernelGGL(exact_ref_kernel(), dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t, 1u);
             }
             launch_exact_m(km, d, t, from_list, 1, est, st);
-            hipLaunchKernelGGL(k_exact_pick, dim3(grid_for(est, kBlock / 64)), dim3(kBlock),
+            hipLaunchKernelGGL(exact_pick_kernel(), dim3(grid_for(est, kBlock / 64)), dim3(kBlock),
                                sizeof(double) * d.K * (kBlock / 64), st, d, t, from_list, 1u);
             continue;
         }
@@ -5044,10 +5204,10 @@ void launch_exact(rg_sim* sim, uint32_t t, int from_list, uint64_t est, hipStrea
             if (grid > 1536) grid = 1536;
             if (!from_list) {
                 hipLaunchKernelGGL(ku, dim3(grid), dim3(kBlock), 0, st, d, t, 0, 0, S);
-                hipLaunchKernelGGL(k_exact_ref, dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t, 1u);
+                hipLaunchKernelGGL(exact_ref_kernel(), dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t, 1u);
             }
             hipLaunchKernelGGL(ku, dim3(grid), dim3(kBlock), 0, st, d, t, from_list, 1, S);
-            hipLaunchKernelGGL(k_exact_pick, dim3(grid_for(est, kBlock / 64)), dim3(kBlock),
+            hipLaunchKernelGGL(exact_pick_kernel(), dim3(grid_for(est, kBlock / 64)), dim3(kBlock),
                                sizeof(double) * d.K * (kBlock / 64), st, d, t, from_list, 1u);
             continue;
         }
@@ -5058,11 +5218,11 @@ void launch_exact(rg_sim* sim, uint32_t t, int from_list, uint64_t est, hipStrea
         const int grid = grid_for(groups * S, 1);
         const size_t smem = sizeof(double) * (static_cast<size_t>(d.K) * 64 + 64 + kExactUsers * d.K);
         if (!from_list) {
-            hipLaunchKernelGGL(k_exact_sums, dim3(grid), dim3(kBlock), smem, st, d, t, 0, 0, S);
-            hipLaunchKernelGGL(k_exact_ref, dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t, 8u);
+            hipLaunchKernelGGL(exact_tile_kernel(), dim3(grid), dim3(kBlock), smem, st, d, t, 0, 0, S);
+            hipLaunchKernelGGL(exact_ref_kernel(), dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t, 8u);
         }
-        hipLaunchKernelGGL(k_exact_sums, dim3(grid), dim3(kBlock), smem, st, d, t, from_list, 1, S);
-        hipLaunchKernelGGL(k_exact_pick, dim3(grid_for(est, kBlock / 64)), dim3(kBlock),
+        hipLaunchKernelGGL(exact_tile_kernel(), dim3(grid), dim3(kBlock), smem, st, d, t, from_list, 1, S);
+        hipLaunchKernelGGL(exact_pick_kernel(), dim3(grid_for(est, kBlock / 64)), dim3(kBlock),
                            sizeof(double) * d.K * (kBlock / 64), st, d, t, from_list, 8u);
     }
 }
@@ -5137,13 +5297,7 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     } else if (d.use_mfma) {
         const int grid = grid_for(upper, 128);
         const size_t smem = sim->mfma_smem;
-        switch (d.KH) {
-            case 4: hipLaunchKernelGGL(k_draw_mfma<4>, dim3(grid), dim3(kBlock), smem, st, d, t); break;
-            case 10: hipLaunchKernelGGL(k_draw_mfma<10>, dim3(grid), dim3(kBlock), smem, st, d, t); break;
-            case 16: hipLaunchKernelGGL(k_draw_mfma<16>, dim3(grid), dim3(kBlock), smem, st, d, t); break;
-            case 32: hipLaunchKernelGGL(k_draw_mfma<32>, dim3(grid), dim3(kBlock), smem, st, d, t); break;
-            default: hipLaunchKernelGGL(k_draw_mfma<64>, dim3(grid), dim3(kBlock), smem, st, d, t); break;
-        }
+        hipLaunchKernelGGL(mfma_kernel_for(d.KH), dim3(grid), dim3(kBlock), smem, st, d, t);
         if (int rc = prof_mark(sim, st)) return rc;
         if (int rc = prof_mark(sim, st)) return rc;
         // draws the fp32 path could not certify -> float64 (a few percent of the organic users)
@@ -5156,11 +5310,11 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     if (int rc = prof_mark(sim, st)) return rc;
     if (d.policy == RG_POLICY_LOGREG_FROZEN) {
         // acts of the users whose view history changed since their last one (frozen LogReg at scale)
-        hipLaunchKernelGGL(k_logreg_select, dim3(grid_for(upper)), dim3(kBlock), 0, st, d, t);
-        hipLaunchKernelGGL(k_logreg_acts, dim3(grid_for(static_cast<uint64_t>(upper) / 4 + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
+        hipLaunchKernelGGL(logreg_select_kernel(), dim3(grid_for(upper)), dim3(kBlock), 0, st, d, t);
+        hipLaunchKernelGGL(logreg_acts_kernel(), dim3(grid_for(static_cast<uint64_t>(upper) / 4 + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
     }
     // 2. click draws, transitions, drift, next lists, bandit + phantom rows
-    hipLaunchKernelGGL(k_advance, dim3(grid_for(upper, kAdvBlock)), dim3(kAdvBlock), 0, st, d, t, d_actions);
+    hipLaunchKernelGGL(advance_kernel(), dim3(grid_for(upper, kAdvBlock)), dim3(kAdvBlock), 0, st, d, t, d_actions);
     HIP_TRY(hipGetLastError());
     if (int rc = prof_mark(sim, st)) return rc;
     sim->t = t + 1;
@@ -5313,8 +5467,10 @@ walked:
     return RG_OK;
 }
 
-}  // namespace
+#endif  // RG_HAS(1): host code
+}  // namespace rgk
 
+#if RG_HAS(1)
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
@@ -5446,17 +5602,14 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     if (const char* e = getenv("RECOGYM_LDS_PAD")) s->mfma_smem += static_cast<size_t>(atoi(e));
     if (getenv("RECOGYM_DEBUG") && d.use_mfma && rg_device_count() > 0) {
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_draw_mfma<10>), kBlock, s->mfma_smem);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(mfma_kernel_for(10)), kBlock, s->mfma_smem);
         fprintf(stderr, "[recogym] k_draw_mfma<10>: dynamic LDS %zu B, occupancy API %d blocks/CU\n", s->mfma_smem, nb);
     }
     if (s->mfma_smem > 64 * 1024) {
         // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel instantiation
         const int bytes = static_cast<int>(s->mfma_smem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_draw_mfma<4>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_draw_mfma<10>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_draw_mfma<16>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_draw_mfma<32>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_draw_mfma<64>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        for (uint32_t kh : {4u, 10u, 16u, 32u, 64u})
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_kernel_for(kh)), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     }
     *out = s;
     return RG_OK;
@@ -5625,7 +5778,7 @@ int rg_sim_run(rg_sim* sim, uint32_t max_steps, void* stream) {
                 HIP_TRY(hipEventRecord(ev[0], st));
             }
             const int grid = static_cast<int>(live < 2048 ? live : 2048);
-            hipLaunchKernelGGL(k_tail, dim3(grid), dim3(kBlock), tail_smem, st, sim->d, sim->t);
+            hipLaunchKernelGGL(tail_kernel(), dim3(grid), dim3(kBlock), tail_smem, st, sim->d, sim->t);
             hipLaunchKernelGGL(k_tail_finish, dim3(1), dim3(1), 0, st, sim->d, sim->t);
             HIP_TRY(hipGetLastError());
             if (sim->profiling) HIP_TRY(hipEventRecord(ev[1], st));
@@ -5809,3 +5962,4 @@ int rg_sim_sort_log_aux(rg_sim* sim, const int64_t* d_row_offsets, double* d_sor
 }
 
 }  // extern "C"
+#endif  // RG_HAS(1): C ABI
