@@ -14,6 +14,10 @@ data-path collective; one RCCL all-reduce of the click/impression counters close
 `--scaling weak` (default) keeps the per-GPU users fixed as N grows, `--scaling strong` keeps the TOTAL fixed
 (10 M users over N GPUs, the way north_star states the target).
 
+Other workloads (`--workload`): c2 / c4shard = BASELINE configs 2 / one rank's share of 4; c3drift = config 3 with
+the reference's default drift; c5 = BASELINE config 5 on one rank's share: the `verify_agents` A/B loop with a frozen
+BanditMFSquare table arm and a frozen 10^4-class LogregMulticlassIps arm over the SAME users (a step = both arms).
+
 Prints ONE JSON line (rank 0).  `value` counts real rows (organic + bandit; the per-user phantom row is
 excluded) over all ranks / max-over-ranks wall time.
 """
@@ -32,13 +36,18 @@ WORKLOADS = {
     'c3drift': (dict(num_products=10000, K=20, sigma_omega=0.1), 10_000_000, 10_000_000, 'ouc'),
     'c2': (dict(num_products=1000, K=20, sigma_omega=0.0), 1_000_000, 1_000_000, 'random'),
     'c4shard': (dict(num_products=100000, K=64, sigma_omega=0.1), 1_250_000, 10_000_000, 'none'),
+    # verify_agents(env, users, {BanditMFSquare, LogregMulticlassIps}) with the env's defaults (sigma_omega = 0.1)
+    'c5': (dict(num_products=10000, K=20), 1_250_000, 10_000_000, 'c5'),
     'tiny': (dict(num_products=100, K=20, sigma_omega=0.0), 20_000, 20_000, 'ouc'),
+    'tiny5': (dict(num_products=300, K=20), 20_000, 20_000, 'c5'),
 }
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 F16_MFMA_PEAK_TFLOPS = 2516.6      # v_mfma_f32_32x32x16_f16 / bf16, dense (256 CUs x 4 SIMDs x 1024 flop/cycle x 2.4 GHz)
 F64_VALU_PEAK_TFLOPS = 78.6
 HBM_PEAK_GBPS = 8000.0
+EXP_PEAK_PER_S = 1024 * 4 * 2.4e9  # v_exp_f32: quarter rate, 4 lanes per cycle and SIMD (MI355X_MICROARCH.md: transcendentals)
+PROFILE_ROUNDS = ('r3', 'r2')      # profiles/<round>/pmc_traffic.json, newest first
 
 
 def policy_kwargs(pol):
@@ -51,6 +60,27 @@ def policy_kwargs(pol):
     return {}
 
 
+def arms_of(workload, cfg):
+    """[(arm name, Simulator policy kwargs)].  Every workload but c5 has one arm.  c5: the two frozen policies of BASELINE
+    config 5 — a BanditMFSquare inference table (last viewed product -> action, its logit as `ps`) and a
+    LogregMulticlassIps model with one class per product.  The models are random (training is the reference's host
+    code, SURVEY.md §2: a random table and N(0, 0.1) coefficients), seeded, the same on every rank."""
+    pol = WORKLOADS[workload][3]
+    if pol != 'c5':
+        return [(pol, policy_kwargs(pol))]
+    import numpy as np
+    from recogym_amd import _abi
+    P = cfg.num_products
+    rng = np.random.RandomState(0)
+    table = rng.randint(0, P, size=P).astype(np.int32)
+    ps = rng.rand(P)
+    coef_t = (rng.standard_normal((P, P)) * 0.1)
+    intercept = rng.standard_normal(P) * 0.1
+    return [('bandit_mf_frozen', dict(policy=_abi.RG_POLICY_LAST_VIEW_TABLE, policy_seed=0, policy_table=table, policy_ps=ps)),
+            ('logreg_ips_frozen', dict(policy=_abi.RG_POLICY_LOGREG_FROZEN, policy_seed=0,
+                                       logreg=dict(coef_t=coef_t, intercept=intercept, classes=np.arange(P, dtype=np.int32))))]
+
+
 def make_config(workload):
     from recogym_amd.envs.configuration import Configuration
     from recogym_amd.envs.reco_env_v1 import env_1_args
@@ -58,21 +88,23 @@ def make_config(workload):
 
 
 def make_sim(workload, users, device, log_rows):
+    """(config, simulator) of a one-arm workload (tools use this)."""
     from recogym_amd.sim import Simulator
     cfg = make_config(workload)
-    return cfg, Simulator(cfg, users, device=device, log_capacity=log_rows, **policy_kwargs(WORKLOADS[workload][3]))
+    return cfg, Simulator(cfg, users, device=device, log_capacity=log_rows, **arms_of(workload, cfg)[0][1])
 
 
 def cpu_baseline(workload, seconds_target=12.0):
-    """The oracle (plain-C float64 port of the reference loop, oracle/recogym_oracle.c) on a bounded sample of the
-    same workload on ALL host cores: trajectories are keyed by (seed, user id), so every thread replays its own id
-    range with its own oracle instance (ctypes releases the GIL; no allocation inside the loop).  Test
-    infrastructure used as the reported CPU baseline only.  The unmodified NumPy reference cannot run on the GPU
-    box (no /root/reference there): its events/s measured in the build container is quoted beside it."""
+    """The CPU leg.  `reference_numpy`: the unmodified NumPy reference — it cannot travel to the GPU box (no
+    /root/reference there), so its events/s are the ones tools/time_reference.py measured in the build container,
+    quoted with that provenance.  `value` (kind "port"): the oracle (plain-C float64 restatement of the reference loop,
+    oracle/recogym_oracle.c) timed LIVE on this box's host cores on a bounded sample of the same workload: trajectories
+    are keyed by (seed, user id), so every thread replays its own id range with its own oracle instance (ctypes
+    releases the GIL; no allocation inside the loop).  Test infrastructure used as the reported baseline only."""
     import threading
     from oracle import oracle as orc
     cfg = make_config(workload)
-    kw = policy_kwargs(WORKLOADS[workload][3])
+    kw = arms_of(workload, cfg)[0][1]
     cores = max(1, min(os.cpu_count() or 1, 64))
     orc.lib()                                   # build / load once, before the threads start
 
@@ -99,16 +131,10 @@ def cpu_baseline(workload, seconds_target=12.0):
         wall = time.perf_counter() - t0
         return sum(r[0] for r in results), sum(r[1] for r in results), wall
 
-    u1, e1, w1 = measure(1, 3.0)
-    users, events, wall = measure(cores, seconds_target)
-    out = dict(value=events / wall, unit='events/s', cores=cores, kind='port',
-               per_core=events / wall / cores, one_thread=e1 / w1,
-               sample=f'{users} users / {events} events of the same workload in {wall:.1f} s on {cores} threads '
-                      f'(oracle/recogym_oracle.c, float64, one oracle instance per thread); one thread alone: '
-                      f'{e1 / w1:.0f} events/s')
+    out = {}
     try:      # the NumPy reference itself, measured where /root/reference exists (tools/time_reference.py)
         ref = json.load(open(os.path.join(ROOT, 'profiles', 'r2', 'numpy_reference_cpu.json')))
-        case = {'c3': 'c3', 'c3drift': 'c3', 'c2': 'c2', 'c4shard': 'c4_capped', 'tiny': 'c1'}[workload]
+        case = {'c3': 'c3', 'c3drift': 'c3', 'c2': 'c2', 'c4shard': 'c4_capped', 'tiny': 'c1', 'c5': 'c3', 'tiny5': 'c1'}[workload]
         rc = ref['cases'][case]
         out['reference_numpy'] = dict(
             one_core_events_per_s=rc['one_core_events_per_s'], all_core_events_per_s=rc['all_core_events_per_s'],
@@ -118,7 +144,23 @@ def cpu_baseline(workload, seconds_target=12.0):
                        f"profiles/r2/numpy_reference_cpu.json")
     except Exception:
         out['reference_numpy'] = None
+    u1, e1, w1 = measure(1, 3.0)
+    users, events, wall = measure(cores, seconds_target)
+    out.update(value=events / wall, unit='events/s', cores=cores, kind='port',
+               per_core=events / wall / cores, one_thread=e1 / w1,
+               sample=f'{users} users / {events} events of the same workload in {wall:.1f} s on {cores} threads '
+                      f'(oracle/recogym_oracle.c, float64, one oracle instance per thread); one thread alone: '
+                      f'{e1 / w1:.0f} events/s')
     return out
+
+
+def survey_bytes_per_event(cfg, pol):
+    """fp32 state per event — omega 4K + (state, t) 8 + packed row 16 + action 3 (0.78 x 4 B), + 35 B of
+    view history with the OrganicUserEventCounter agent in the loop, + 0.2 x 4K omega write where omega drifts."""
+    b = 4 * cfg.K + 8 + 16 + 3 + (35 if pol == 'ouc' else 0)
+    if cfg.sigma_omega != 0:
+        b += round(0.8 * cfg.K)
+    return b
 
 
 def kernel_rooflines(cfg, prof, c, users, cached, pol):
@@ -126,6 +168,7 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
     (rg_sim_set_profiling).  Algorithmic units follow SURVEY.md §8d (stated in DESIGN.md §6)."""
     P, K = cfg.num_products, cfg.K
     f16_split = (3 * K + 1) <= 64
+    events = c['bandit'] + c['organic']
     out = {}
     # organic product sweeps on the matrix pipe: 2*P*K flop per swept draw.  With sigma_omega = 0 only a user's
     # first draw sweeps (the rest search the per-user cache); otherwise every lock-step organic draw does.
@@ -133,32 +176,37 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
     if prof['draw_mfma_ms'] > 0:
         tf = 2.0 * P * K * swept / (prof['draw_mfma_ms'] * 1e-3) / 1e12
         peak = F16_MFMA_PEAK_TFLOPS if K <= 64 else FP32_MFMA_PEAK_TFLOPS
+        exp_ms = 1e3 * float(P) * swept / EXP_PEAK_PER_S
         out['draw_sweep'] = dict(kernel='k_draw_bf16p' if K <= 21 else 'k_draw_* (K class)', bound='mfma',
                                  ms=round(prof['draw_mfma_ms'], 2), units=int(swept), unit_name='swept draws',
                                  achieved=round(tf, 2), peak=peak, unit='TFLOP/s', frac=round(tf / peak, 4),
-                                 executed_mfma_tflops=round(tf * (64.0 if f16_split else 144.0) / K, 1) if K <= 21 else None)
+                                 executed_mfma_tflops=round(tf * (64.0 if f16_split else 144.0) / K, 1) if K <= 21 else None,
+                                 # one v_exp_f32 per logit at a quarter of the fp32 lane rate: the kernel's real ceiling
+                                 exp_bound_ms=round(exp_ms, 2), frac_of_exp_bound=round(exp_ms / prof['draw_mfma_ms'], 4))
     walked = prof.get('walk1_ms', 0.0) > 0
-    # the user-major walk (sigma_omega = 0, run to the end): SURVEY.md 8d bytes per event — bandit: omega 4K + state 8 +
-    # row 16 + action 3 (+35 history with the OUC agent in the loop); organic: state 8 + the cached draw's 128 B of
-    # super-chunk sums, 48 B of chunk sums, omega32 (4K) and the 16-byte row
+    b_survey = survey_bytes_per_event(cfg, pol)
+    # the user-major walk (sigma_omega = 0, run to the end).  `bytes_per_unit` is SURVEY.md 8d's figure; what this
+    # implementation's cached organic draw moves on top of it (128 B of super-chunk prefixes, 48 B of chunk sums) is
+    # reported as implementation_bytes_per_unit
     if walked:
         b_b = 4 * K + 8 + 16 + 3 + (35 if pol == 'ouc' else 0)
         b_o = 8 + 128 + 48 + 4 * K + 16
-        by = b_b * c['bandit'] + b_o * c['organic']
+        by_impl = b_b * c['bandit'] + b_o * c['organic']
         ms = prof['walk1_ms'] + prof['walk2_ms']
-        gbps = by / (ms * 1e-3) / 1e9
+        gbps = b_survey * events / (ms * 1e-3) / 1e9
         out['walk'] = dict(kernel='k_walk', bound='hbm', ms=round(ms, 2), round1_ms=round(prof['walk1_ms'], 2),
-                           round2_ms=round(prof['walk2_ms'], 2), units=int(c['bandit'] + c['organic']), unit_name='events',
-                           bytes_per_unit=round(by / max(c['bandit'] + c['organic'], 1), 1), achieved=round(gbps, 1),
-                           peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(gbps / HBM_PEAK_GBPS, 4),
-                           note='VALU-issue / latency bound on per-user state that lives in L2 and the Infinity Cache '
-                                '(DESIGN.md 4), not on HBM bandwidth')
+                           later_rounds_ms=round(prof['walk2_ms'], 2), units=int(events), unit_name='events',
+                           bytes_per_unit=b_survey, implementation_bytes_per_unit=round(by_impl / max(events, 1), 1),
+                           achieved=round(gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(gbps / HBM_PEAK_GBPS, 4),
+                           note='latency bound on per-user state that lives in L2 and the Infinity Cache (DESIGN.md 4), not on '
+                                'HBM bandwidth')
         if prof['draw_search_ms'] > 0:
+            by = 512 + 8 * K
             out['cache_finalize'] = dict(kernel='k_cache_finalize', bound='hbm', ms=round(prof['draw_search_ms'], 2), units=int(users),
-                                         unit_name='users', bytes_per_unit=256 + 8 * K + 256,
-                                         achieved=round((512 + 8 * K) * users / (prof['draw_search_ms'] * 1e-3) / 1e9, 1),
+                                         unit_name='users', bytes_per_unit=by,
+                                         achieved=round(by * users / (prof['draw_search_ms'] * 1e-3) / 1e9, 1),
                                          peak=HBM_PEAK_GBPS, unit='GB/s',
-                                         frac=round((512 + 8 * K) * users / (prof['draw_search_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4))
+                                         frac=round(by * users / (prof['draw_search_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4))
     # cached draw (sigma_omega = 0, t >= 1, lock-step form): per draw the user's 32 super-chunk sums (128 B), the chosen
     # super-chunk's chunk sums (48 B), omega32 (4K) and the 16-byte row: HBM gather
     if cached and not walked and prof['draw_search_ms'] > 0:
@@ -168,35 +216,48 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
         out['draw_cached'] = dict(kernel='k_draw_cached', bound='hbm', ms=round(prof['draw_search_ms'], 2), units=int(n),
                                   unit_name='cached draws', bytes_per_unit=by, achieved=round(gbps, 1),
                                   peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(gbps / HBM_PEAK_GBPS, 4))
-    # float64 resolve: per sweep P * (2K + ~16) float64 flop-equivalents on the VALU
+    # float64 resolve: per sweep P * (2K + ~16) float64 flop-equivalents
     if prof['draw_exact_ms'] > 0 and c['exact_sweeps'] > 0:
         tf = c['exact_sweeps'] * float(P) * (2 * K + 16) / (prof['draw_exact_ms'] * 1e-3) / 1e12
-        out['draw_exact_f64'] = dict(kernel='k_exact_sums_m + k_exact_pick', bound='f64 mfma + valu', ms=round(prof['draw_exact_ms'], 2),
+        out['draw_exact_f64'] = dict(kernel='k_exact_sums_* + k_exact_pick', bound='f64 mfma + valu', ms=round(prof['draw_exact_ms'], 2),
                                      units=int(c['exact_sweeps']), unit_name='float64 sweeps', achieved=round(tf, 2),
                                      peak=F64_VALU_PEAK_TFLOPS, unit='TFLOP/s', frac=round(tf / F64_VALU_PEAK_TFLOPS, 4),
                                      resolved_draws=int(c['exact_draws']))
-    # advance: SURVEY.md 8d bytes per event — bandit: omega 4K + state 8 + row 16 + action 3 (+35 history with the
-    # OUC agent in the loop); organic: state 8 (+ omega write 4K when it drifts)
+    # frozen LogReg acts: the act of a user is recomputed when its view history changed; per act the coef^T rows of its
+    # viewed products over all classes (fp32 fast path: 4 B per weight) — the table (P x classes) is larger than the
+    # Infinity Cache at 10^4 classes, the rows stream from HBM
+    if prof.get('logreg_ms', 0.0) > 0 and c.get('lr_acts', 0) > 0:
+        n_classes = P
+        by = 4.0 * n_classes * c['lr_rows']
+        gbps = by / (prof['logreg_ms'] * 1e-3) / 1e9
+        out['logreg_acts'] = dict(kernel='k_logreg_select + k_logreg_acts', bound='hbm', ms=round(prof['logreg_ms'], 2),
+                                  units=int(c['lr_acts']), unit_name='acts', bytes_per_unit=round(by / c['lr_acts'], 1),
+                                  rows_per_act=round(c['lr_rows'] / c['lr_acts'], 2), float64_acts=int(c.get('lr_exact', 0)),
+                                  achieved=round(gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(gbps / HBM_PEAK_GBPS, 4))
+    # advance: SURVEY.md 8d bytes per event
     if prof['advance_ms'] > 0:
-        b_b = 4 * K + 8 + 16 + 3 + (35 if pol == 'ouc' else 0)
-        b_o = 8 + (4 * K if cfg.sigma_omega != 0 else 0)
-        by = b_b * c['bandit'] + b_o * c['organic']
-        gbps = by / (prof['advance_ms'] * 1e-3) / 1e9
+        gbps = b_survey * events / (prof['advance_ms'] * 1e-3) / 1e9
         out['advance'] = dict(kernel='k_advance', bound='hbm', ms=round(prof['advance_ms'], 2),
-                              units=int(c['bandit'] + c['organic']), unit_name='events',
-                              bytes_per_unit=round(by / max(c['bandit'] + c['organic'], 1), 1),
+                              units=int(events), unit_name='events', bytes_per_unit=b_survey,
                               achieved=round(gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(gbps / HBM_PEAK_GBPS, 4))
     return out
 
 
-def measured_traffic(name):
-    """HBM bytes per unit of a kernel from the committed rocprofv3 --pmc passes (profiles/r2/pmc_traffic.json;
-    PMC counters cannot be read from inside this process) — None when that kernel was not profiled."""
-    try:
-        pt = json.load(open(os.path.join(ROOT, 'profiles', 'r2', 'pmc_traffic.json')))
-        return pt['kernels'][name]
-    except Exception:
-        return None
+def measured_traffic(workload, name):
+    """HBM bytes per unit of a kernel from the committed rocprofv3 --pmc passes (profiles/<round>/pmc_traffic.json; PMC
+    counters cannot be read from inside this process) — None when that kernel was not profiled on this workload."""
+    for rnd in PROFILE_ROUNDS:
+        try:
+            pt = json.load(open(os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic.json')))
+        except Exception:
+            continue
+        e = pt.get('kernels', {}).get(name)
+        if e is None:
+            continue
+        wl = e.get('workload')
+        if wl == workload or (wl is None and workload in ('c3', 'c4shard')):
+            return e
+    return None
 
 
 def main():
@@ -210,7 +271,16 @@ def main():
     ap.add_argument('--no-log', action='store_true', help='counters only (no 16 B/row log writes)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-drift-line', action='store_true', help='skip the sigma_omega > 0 companion measurement')
+    ap.add_argument('--no-materialise', action='store_true', help='skip the sort_log / log_columns timings')
+    ap.add_argument('--single-run', action='store_true',
+                    help='exactly ONE simulation per arm in the process (the HIP-event profile is taken on the timed run): what '
+                         'the rocprofv3 --pmc passes run, so that a counter summed over the trace belongs to one run')
+    ap.add_argument('--shard', default='', help='R/W: with --gpus 1, simulate rank R\'s id range of a W-rank strongly scaled job')
+    ap.add_argument('--digest', action='store_true', help='add the order-independent checksum of the last run\'s log rows')
     args = ap.parse_args()
+    if args.single_run:
+        args.steps, args.warmup = 1, 0
+        args.no_cpu_baseline = args.no_drift_line = args.no_materialise = True
 
     from recogym_amd import parallel
     rc = parallel.self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:])
@@ -229,9 +299,16 @@ def main():
     if dist:
         dist.barrier()
 
-    from recogym_amd.sim import default_log_capacity
+    from recogym_amd.sim import Simulator, default_log_capacity
     _, per_gpu, total, pol = WORKLOADS[args.workload]
-    if args.scaling == 'weak':
+    shard_note = None
+    if args.shard:
+        assert world == 1, '--shard emulates a rank on ONE GPU'
+        r, w = (int(x) for x in args.shard.split('/'))
+        users_total = args.users or total
+        first_user, users = parallel.shard_range(users_total, r, w)
+        shard_note = f'rank {r} of {w} (strong scaling of {users_total} users), on one GPU'
+    elif args.scaling == 'weak':
         users = args.users or per_gpu
         first_user = rank * users       # disjoint id ranges: identical to one big run
         users_total = users * world
@@ -240,40 +317,47 @@ def main():
         first_user, users = parallel.shard_range(users_total, rank, world)
 
     def build(workload, n):
-        log_rows = 0 if args.no_log else default_log_capacity(make_config(workload), n)
-        return make_sim(workload, n, device, log_rows)
+        cfg = make_config(workload)
+        log_rows = 0 if args.no_log else default_log_capacity(cfg, n)
+        return cfg, [(name, Simulator(cfg, n, device=device, log_capacity=log_rows, **kw)) for name, kw in arms_of(workload, cfg)]
 
-    cfg, sim = build(args.workload, users)
+    cfg, arms = build(args.workload, users)
 
-    def one_step(s=None):
-        s = s or sim
-        s.reset_users(first_user, users)
-        s.run()
-        c = s.counters()
-        vec = torch.tensor([c['organic'], c['bandit'], c['clicks'], c['phantom']],
-                           dtype=torch.int64, device=device)
-        if dist:
-            dist.all_reduce(vec)        # the CTR reduction of test_agent / verify_agents
-        return c, vec
+    def one_step(arm_list, profiled=False):
+        """every arm over the same users; -> (last counters per arm, summed [organic, bandit, clicks, phantom])"""
+        vec = torch.zeros(4, dtype=torch.int64, device=device)
+        per_arm = []
+        for _, s in arm_list:
+            if profiled:
+                s.set_profiling(True)
+            s.reset_users(first_user, users)
+            s.run()
+            c = s.counters()
+            per_arm.append(c)
+            v = torch.tensor([c['organic'], c['bandit'], c['clicks'], c['phantom']], dtype=torch.int64, device=device)
+            if dist:
+                dist.all_reduce(v)      # the CTR reduction of test_agent / verify_agents, once per agent
+            vec += v
+        return per_arm, vec
 
     def sync():
         if dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    def timed(s, steps, warmup):
+    def timed(arm_list, steps, warmup, profiled=False):
         # (the warm-up also runs the few torch ops of the timed loop once: their kernels are loaded lazily, ~20 ms the
         # first time, which is 2 ms per step of a 10-step run and more than a whole step of the C2 workload)
         totals = torch.zeros(4, dtype=torch.int64, device=device)
         for _ in range(warmup):
-            _, vec = one_step(s)
+            _, vec = one_step(arm_list)
             totals += vec
         totals.zero_()
         sync()
         t0 = time.perf_counter()
         last = None
         for _ in range(steps):
-            last, vec = one_step(s)
+            last, vec = one_step(arm_list, profiled)
             totals += vec
         sync()
         elapsed = time.perf_counter() - t0
@@ -282,65 +366,128 @@ def main():
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el.item()), totals.cpu().numpy(), last
 
-    elapsed, totals, last = timed(sim, args.steps, args.warmup)
+    elapsed, totals, last = timed(arms, args.steps, args.warmup, profiled=args.single_run)
     events = int(totals[0] + totals[1])
-    assert last['hist_overflow'] == 0 and last['log_dropped'] == 0 and last['live'] == 0, last
+    for c in last:
+        assert c['hist_overflow'] == 0 and c['log_dropped'] == 0 and c['live'] == 0 and c['exact_overflow'] == 0, c
 
-    def profile(s, config):
-        s.set_profiling(True)
-        s.reset_users(first_user, users)
-        s.run()
-        prof = s.profile()
-        c = s.counters()
-        s.set_profiling(False)
-        cached = config.sigma_omega == 0 and os.environ.get('RECOGYM_CACHE', '1') != '0' and config.K <= 63
-        return prof, c, kernel_rooflines(config, prof, c, users, cached, pol)
+    def is_cached(config):
+        return config.sigma_omega == 0 and os.environ.get('RECOGYM_CACHE', '1') != '0' and config.K <= 63
+
+    def profile(arm_list, config, already=False):
+        """HIP-event profile of one more run of every arm (or of the timed run itself: --single-run)"""
+        out = {}
+        counters = []
+        for (name, s), c_timed in zip(arm_list, last if already else [None] * len(arm_list)):
+            if already:
+                c = c_timed
+            else:
+                s.set_profiling(True)
+                s.reset_users(first_user, users)
+                s.run()
+                c = s.counters()
+            prof = s.profile()
+            s.set_profiling(False)
+            counters.append((c, prof))
+            arm_pol = name if name in ('ouc', 'random', 'none') else name
+            for k, v in kernel_rooflines(config, prof, c, users, is_cached(config), arm_pol).items():
+                out[k if len(arm_list) == 1 else f'{name}.{k}'] = dict(v, arm=name) if len(arm_list) > 1 else v
+        return counters, out
 
     # --- per-kernel rooflines, HIP events on the launch stream; `roofline` = the kernel with the most time ---
     roofline = kernels = None
+    materialise = None
     if rank == 0:
-        prof, c, kernels = profile(sim, cfg)
+        counters, kernels = profile(arms, cfg, already=args.single_run)
         dom = max((k for k in kernels if kernels[k]['bound'] in ('hbm', 'mfma')), key=lambda k: kernels[k]['ms'])
         roofline = dict(kernels[dom])
+        c, prof = counters[0] if len(counters) == 1 else counters[[n for n, _ in arms].index(roofline['arm'])]
         launches = max(prof['steps'], 1)
-        if roofline['unit'] == 'GB/s':
-            roofline['achieved_is'] = ('algorithmic bytes (SURVEY.md 8d figure per unit x units) / total kernel time over '
-                                       f'{launches} launches; bound by scattered per-user gathers, not by streaming bandwidth')
-        roofline['launches'] = launches
-        roofline['avg_launch_ms'] = round(roofline['ms'] / launches, 4)
-        if dom == 'walk':
-            roofline['achieved_is'] = ('algorithmic bytes (SURVEY.md 8d figure per event x events) / total kernel time of the run\'s '
-                                       'walk launches (rounds of unequal size: per-launch figures are the run\'s divided by their number)')
-        pmc = measured_traffic(roofline['kernel'].split(' ')[0]) if args.workload in ('c3', 'c4shard') else None
-        if dom == 'walk':
+        roofline['dominant'] = dom
+        if roofline['kernel'] == 'k_walk':
             # rounds of one run: 1, the parked users' round 2, and round 3 for what draining waves handed over
             launches = (3 if os.environ.get('RECOGYM_WALK_HANDOVER', '16') != '0' else 2) if prof['walk2_ms'] > 0 else 1
-            roofline['launches'] = launches
-            roofline['avg_launch_ms'] = round(roofline['ms'] / launches, 4)
-        roofline['traffic'] = None if pmc is None else pmc['hbm_bytes_per_unit'] * roofline['units'] / launches
-        roofline['traffic_source'] = None if pmc is None else pmc['source']
+            roofline['achieved_is'] = ('SURVEY.md 8d bytes per event x events of the run / total time of the run\'s walk launches '
+                                       '(rounds of unequal size: avg_launch_ms is the run\'s time divided by their number)')
+        elif roofline['unit'] == 'GB/s':
+            roofline['achieved_is'] = (f'algorithmic bytes per unit x units of the run / total kernel time over {launches} launches')
+        roofline['launches'] = launches
+        roofline['avg_launch_ms'] = round(roofline['ms'] / launches, 4)
+        pmc = measured_traffic(args.workload, roofline['kernel'].split(' ')[0])
+        if pmc is not None and roofline['unit'] == 'GB/s':
+            # HBM bytes of ONE run's launches of this kernel (FETCH_SIZE doubled as the microarchitecture guide prescribes
+            # for gfx950, + WRITE_SIZE; per-unit figure of the profiled run x this run's units)
+            roofline['traffic'] = pmc['hbm_bytes_per_unit'] * roofline['units']
+            roofline['traffic_per_launch'] = roofline['traffic'] / launches
+            roofline['traffic_bytes_per_unit'] = round(pmc['hbm_bytes_per_unit'], 1)
+            roofline['wasted_traffic_ratio'] = round(pmc['hbm_bytes_per_unit'] / roofline['bytes_per_unit'], 2)
+            roofline['traffic_source'] = pmc['source']
+        else:
+            roofline['traffic'] = None
+            roofline['traffic_source'] = None if pmc is None else pmc['source']
+            if pmc is not None:
+                roofline['traffic_bytes_per_unit'] = round(pmc['hbm_bytes_per_unit'], 1)
         roofline['tail_ms'] = round(prof['tail_ms'], 2)
         roofline['exact_fraction'] = round(c['exact_draws'] / max(c['organic'], 1), 5)
-        roofline['whole_job_hbm_algorithmic_GBps'] = round(
-            (events / args.steps / world) * (4 * cfg.K + 8 + 16 + 3 + (35 if pol == 'ouc' else 0)) / 1e9 / (elapsed / args.steps), 1)
-    sim.close()
-    del sim
+        b_ev = survey_bytes_per_event(cfg, pol)
+        roofline['whole_job_hbm_algorithmic_GBps'] = round((events / args.steps / world) * b_ev / 1e9 / (elapsed / args.steps), 1)
+        roofline['whole_job_frac'] = round(roofline['whole_job_hbm_algorithmic_GBps'] / HBM_PEAK_GBPS, 4)
+
+        # --- what the reference's row order costs (abstract.py:299-327 is part of generate_logs): rg_sim_sort_log on the
+        # whole log of the last run; decoding into the reference's columns on a 200 k-user run of the same workload ---
+        if not args.no_materialise and not args.no_log:
+            s0 = arms[0][1]
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            srt, off = s0.sorted_log()
+            torch.cuda.synchronize(device)
+            sort_ms = 1e3 * (time.perf_counter() - t0)
+            n_rows = int(srt.shape[0])
+            del srt, off
+            torch.cuda.empty_cache()
+            n_small = min(users, 200_000)
+            small = Simulator(cfg, n_small, device=device, **arms_of(args.workload, cfg)[0][1])
+            small.reset_users(first_user, n_small)
+            small.run()
+            small.log_columns()                     # (loads the torch kernels it uses)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            cols = small.log_columns()
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            materialise = dict(sort_log_ms=round(sort_ms, 2), sort_log_rows=n_rows,
+                               sort_log_rows_per_s=round(n_rows / (sort_ms * 1e-3), 0),
+                               log_columns_rows_per_s=round(len(cols['t']) / dt, 0), log_columns_sample_rows=int(len(cols['t'])),
+                               note='outside the timed region: rg_sim_sort_log on the whole log of one run (reference row order), '
+                                    'Simulator.log_columns (sort + decode to the reference\'s columns, to the host) on a '
+                                    f'{n_small}-user run of the same workload')
+            small.close()
+            del small, cols
+            torch.cuda.empty_cache()
+    digest = None
+    if args.digest:
+        digest = [arm.log_digest() for _, arm in arms]
+    for _, s in arms:
+        s.close()
+    del arms
     torch.cuda.empty_cache()
 
     # --- the sigma_omega > 0 companion of the headline workload: no per-user cache is possible there, every
     # organic draw sweeps all P products on the matrix pipe — the line that shows the sweep kernel's quality ---
     drift = None
     if args.workload == 'c3' and not args.no_drift_line:
-        dcfg, dsim = build('c3drift', users)
-        d_el, d_tot, d_last = timed(dsim, 1, 1)
+        dcfg, darms = build('c3drift', users)
+        d_el, d_tot, d_last = timed(darms, 1, 1)
         if rank == 0:
-            d_prof, d_c, d_k = profile(dsim, dcfg)
+            d_counters, d_k = profile(darms, dcfg)
+            d_c = d_counters[0][0]
             drift = dict(workload='c3drift: the same with sigma_omega=0.1 (omega drifts at every organic transition)',
                          value=float(d_tot[0] + d_tot[1]) / d_el, unit='events/s', ms_per_step=1e3 * d_el,
                          steps=1, warmup=1, kernels=d_k,
                          exact_fraction=round(d_c['exact_draws'] / max(d_c['organic'], 1), 5))
-        dsim.close()
-        del dsim
+        for _, s in darms:
+            s.close()
+        del darms
         torch.cuda.empty_cache()
 
     cpu = None
@@ -364,16 +511,24 @@ def main():
                      'of fp32 operands (fp32 accumulate), every index certified against f64',
             'data': 'synthetic',
             'config': {'workload': f'{args.workload}: reco-gym-v1 P={cfg.num_products} K={cfg.K} '
-                                   f'sigma_omega={cfg.sigma_omega} policy={pol}',
-                       'users_per_gpu': users, 'users_total': users_total,
+                                   f'sigma_omega={cfg.sigma_omega} policy={pol}'
+                                   + (' (verify_agents: frozen BanditMFSquare table arm + frozen LogregMulticlassIps arm, same users)'
+                                      if pol == 'c5' else ''),
+                       'users_per_gpu': users, 'users_total': users_total, 'first_user': first_user,
                        'events_per_step': events // args.steps,
                        'log': 'off' if args.no_log else '16 B/row device log + float64 ps side array',
                        'ctr': float(totals[2]) / max(float(totals[1] + totals[3]), 1.0)},
             'roofline': roofline,
             'kernels': kernels,
+            'materialise': materialise,
             'sigma_omega_gt0': drift,
             'cpu_baseline': cpu,
         }
+        if shard_note:
+            out['config']['shard'] = shard_note
+        if digest is not None:
+            out['digest'] = digest
+            out['totals'] = dict(organic=int(totals[0]), bandit=int(totals[1]), clicks=int(totals[2]), phantom=int(totals[3]))
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()

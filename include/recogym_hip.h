@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION 2
+#define RG_ABI_VERSION 3
 
 /* error codes */
 #define RG_OK 0
@@ -127,6 +127,9 @@ typedef struct rg_event {
 #define RG_CNT_EXACT_OVERFLOW 11 /* uncertified draws beyond what the float64 resolve scratch covers in a step (25 % of the
                                    live users): the run is incomplete and must be reported — never reached by the
                                    reference's parameter ranges */
+#define RG_CNT_LR_ACTS 12       /* RG_POLICY_LOGREG_FROZEN: acts computed (one per change of a user's view history that an event needed) */
+#define RG_CNT_LR_ROWS 13       /* ... and the coef^T rows (viewed products) those acts read */
+#define RG_CNT_LR_EXACT 14      /* ... acts the fp32 scores could not certify (decided by float64 scores) */
 #define RG_CNT_N 24             /* out[] of rg_sim_read_counters; slots past the named ones are internal */
 
 typedef struct rg_sim rg_sim;
@@ -212,7 +215,8 @@ int rg_sim_step(rg_sim* sim, const int32_t* d_actions, void* stream);
  * reached `stop` or max_steps transitions were made.  Synchronises `stream`.  With max_steps >=
  * 65536 ("to the end") the last users of the run (<= 4096 alive at a 16-step poll, fewer for tables larger than 10^4 x 20; RECOGYM_TAIL overrides) are walked
  * to their end one user per workgroup instead of step by step; rows, counters and the sorted
- * log are the same, RG_CNT_STEP then reports the longest trajectory. */
+ * log are the same, RG_CNT_STEP then reports the longest trajectory.  Fails with RG_ELIMIT when the run is incomplete
+ * (RG_CNT_EXACT_OVERFLOW != 0, or a user reached the step limit). */
 int rg_sim_run(rg_sim* sim, uint32_t max_steps, void* stream);
 
 /* Synchronises `stream` and copies RG_CNT_N counters to the host. */
@@ -224,7 +228,8 @@ int rg_sim_read_counters(rg_sim* sim, int64_t* out, void* stream);
  * (sliced mode only), in the float64 resolve kernels and in the advance kernel; out[4] =
  * profiled steps; out[5] = milliseconds in the tail kernel (rg_sim_run finishes the last users
  * of a run user by user instead of step by step, or — sigma_omega = 0 — the whole run user-major: k_walk);
- * out[6], out[7] = milliseconds in round 1 / round 2 of k_walk.  `out` must hold 8 doubles.  Off by default. */
+ * out[6], out[7] = milliseconds in round 1 / the later rounds of k_walk; out[8] = milliseconds in the frozen-LogReg act
+ * kernels (k_logreg_select + k_logreg_acts; not part of out[3]); out[9] reserved.  `out` must hold 10 doubles.  Off by default. */
 int rg_sim_set_profiling(rg_sim* sim, int on);
 int rg_sim_get_profile(rg_sim* sim, double* out);
 
@@ -265,6 +270,22 @@ int rg_sim_export_time(rg_sim* sim, double* d_time, void* stream);
 int rg_sim_debug_set_omega(rg_sim* sim, const double* d_omega, void* stream);
 int rg_sim_debug_set_uniforms(rg_sim* sim, const double* d_u);
 int rg_sim_debug_uncertified(rg_sim* sim, uint8_t* d_flags, void* stream);
+
+/* ---- test hooks of the two "decide cheaply, float64 inside a band" paths of the user-major walk ----
+ * rg_sim_debug_click_decisions: for user index i of the reset range, the click decision of a bandit event with action
+ * d_actions[i] and uniform d_u[i] on the user's current omega (reco_env_v1.py:104-116), by the walk's fp32 form and in
+ * float64: d_out[i] bit 0 = the fp32 form decided (outside its error margin), bit 1 = its decision, bit 2 = the
+ * float64 decision.  Needs sigma_omega == 0 (where the walk runs).
+ * rg_sim_debug_set_history: overwrite the view histories (ViewsFeaturesProvider, agents/abstract.py:347-358) of the reset
+ * range right after rg_sim_reset_users: user index i has d_nd[i] distinct products d_products[i * stride + j]
+ * (ascending) with d_counts[i * stride + j] views each.
+ * rg_sim_debug_ouc_acts: OrganicUserEventCounterModel.act (organic_user_count.py:45-96) of every user index on its
+ * current history with d_u1[i] as the uniform of the action draw: d_action / d_ps (float64) as logged, d_flags[i] = 1
+ * iff the action was decided by the integer prefix walk (outside its 2^-36 band), 0 = float64 cdf walk. */
+int rg_sim_debug_click_decisions(rg_sim* sim, const int32_t* d_actions, const double* d_u, uint8_t* d_out, void* stream);
+int rg_sim_debug_set_history(rg_sim* sim, const uint32_t* d_nd, const uint32_t* d_products, const uint32_t* d_counts,
+                             uint32_t stride, void* stream);
+int rg_sim_debug_ouc_acts(rg_sim* sim, const double* d_u1, int32_t* d_action, double* d_ps, uint8_t* d_flags, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@
  *                    by importing the reference here (tests/golden/, made by
  *                    tests/make_golden.py).
  *   RGO_RNG_PHILOX — the counter RNG of include/recogym_rng.h.  In this mode it is the oracle
- *                    the HIP path must match bit-exactly on (t, u, z, v, a, c) and to 1e-9 on
+ *                    the HIP path must match bit-exactly on (t, u, z, v, a, c) and to 1e-12 (relative) on
  *                    ps / p_click; it is itself pinned against the reference's arithmetic by
  *                    running the unmodified reference with the same draws injected through
  *                    `env.rng` (tests/ref_harness.py -> tests/golden/philox_*.npz).

@@ -28,9 +28,11 @@ register(id='reco-gym-v1', entry_point='recogym_amd.envs.reco_env_v1:RecoEnv1')
 
 def register_with_gym(env_id='reco-gym-v1', force=False):
     """Where OpenAI `gym` is importable, make `gym.make('reco-gym-v1')` resolve to this package's environment the
-    way the reference registers its own (recogym/__init__.py:37-45).  Not done on import: the reference package, if it
-    is installed too, owns that id until the caller asks (force=True replaces its registration).  Returns True when
-    the id now points here."""
+    way the reference registers its own (recogym/__init__.py:37-45).  Called once on import (like the reference's
+    package does) when gym is installed and the id is still free; an id that is already registered — e.g. by the
+    reference package imported earlier — is left alone unless force=True.  `gym.make` on a gym that wraps environments
+    in checkers expects a gym.Env subclass: RecoEnv1 mirrors the reference's duck-typed surface (reset / step /
+    step_offline / generate_logs), use recogym_amd.make for it.  Returns True when the id now points here."""
     try:
         from gym.envs.registration import register as gym_register
         import gym.envs.registration as reg

@@ -7,7 +7,7 @@ infrastructure and is never imported from this package.)
 import ctypes as C
 import os
 
-RG_ABI_VERSION = 2
+RG_ABI_VERSION = 3
 
 RG_STATE_ORGANIC, RG_STATE_BANDIT, RG_STATE_STOP = 0, 1, 2
 
@@ -25,7 +25,7 @@ RG_EV_INDEX_MASK = 0x1FFFFFFF
 
 (RG_CNT_ORGANIC, RG_CNT_BANDIT, RG_CNT_CLICKS, RG_CNT_PHANTOM, RG_CNT_LIVE, RG_CNT_STEP,
  RG_CNT_LOG_ROWS, RG_CNT_LOG_DROPPED, RG_CNT_EXACT_DRAWS, RG_CNT_HIST_OVERFLOW,
- RG_CNT_EXACT_SWEEPS, RG_CNT_EXACT_OVERFLOW) = range(12)
+ RG_CNT_EXACT_SWEEPS, RG_CNT_EXACT_OVERFLOW, RG_CNT_LR_ACTS, RG_CNT_LR_ROWS, RG_CNT_LR_EXACT) = range(15)
 RG_CNT_N = 24
 
 RG_ERRORS = {-1: 'RG_EINVAL', -2: 'RG_ENODEV', -3: 'RG_ENOMEM', -4: 'RG_ESTATE', -5: 'RG_ELIMIT'}
@@ -96,6 +96,9 @@ SYMBOLS = {
     'rg_sim_debug_set_omega': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_debug_set_uniforms': (C.c_int, [_SIM, C.c_void_p]),
     'rg_sim_debug_uncertified': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
+    'rg_sim_debug_click_decisions': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'rg_sim_debug_set_history': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    'rg_sim_debug_ouc_acts': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 LIB_NAME = 'librecogym_hip.so'

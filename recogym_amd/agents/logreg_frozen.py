@@ -69,5 +69,9 @@ class LogregFrozenAgent(Agent):
             a = int(cdf.searchsorted(u1, side='right'))
             return {**super().act(observation, reward, done), 'a': a, 'ps': float(proba[a]),
                     'ps-a': proba if getattr(self.config, 'with_ps_all', False) else ()}
-        return {**super().act(observation, reward, done), 'a': int(self.classes[int(np.argmax(score))]),
-                'ps': 1.0, 'ps-a': ()}
+        a = int(self.classes[int(np.argmax(score))])
+        ps_all = ()
+        if getattr(self.config, 'with_ps_all', False):       # logreg_ips.py:73-80: a one-hot vector over the products
+            ps_all = np.zeros(self.config.num_products)
+            ps_all[a] = 1.0
+        return {**super().act(observation, reward, done), 'a': a, 'ps': 1.0, 'ps-a': ps_all}

@@ -58,22 +58,28 @@ class OrganicUserEventCounterAgent(Agent):
         views = np.zeros(P, dtype=np.int64)
         cur = None
         u_col = df['u'].to_numpy(dtype=np.int64)
-        t_col = df['t'].to_numpy()
         is_b = (df['z'] == 'bandit').to_numpy()
         v_col = df['v'].to_numpy(dtype=np.float64, na_value=np.nan)
         a_col = df['a'].to_numpy(dtype=np.float64, na_value=np.nan)
         eps = c.epsilon
+        idx = 0
         for i in range(len(df)):
             if u_col[i] != cur:
                 cur = u_col[i]
                 views[:] = 0
+                idx = 0
+            # the policy draw is keyed by the user's EVENT INDEX (= the row's position within the user; the phantom row
+            # takes the index after the last real event), not by the `t` column: with a NormalTimeGenerator `t` is the
+            # float clock, and the device / act() key the draw by the index (DefaultContext.draw_key)
+            ev = idx
+            idx += 1
             if not is_b[i]:
                 views[int(v_col[i])] += 1
                 out[i] = None
                 continue
             f = views.astype(np.float64)
             if c.exploit_explore:
-                _, u0, _ = rng.policy_uniforms(c.random_seed, int(u_col[i]), int(t_col[i]))
+                _, u0, _ = rng.policy_uniforms(c.random_seed, int(u_col[i]), ev)
                 if not (eps / (eps + (1 - eps)) <= u0):
                     f = (views == 0).astype(np.float64)
                 p = f / np.sum(f)

@@ -76,6 +76,12 @@ def test_agent(env, agent, num_offline_users=1000, num_online_users=100,
     # [base, base + organic + offline) for training and the next `num_online_users` ids for evaluation; without
     # epoch_with_random_reset the next epoch starts where this one ended (with it, the epoch re-keys the draws
     # and ids restart at 0, as the reference's reset_random_seed(epoch) restarts its stream).
+    if with_cache:
+        # the reference's with_cache pickles the offline log under the working directory and re-reads it on the next call
+        # (bench_agents.py:50-63): out of scope here — the log is regenerated on the device every time
+        import warnings
+        warnings.warn('test_agent(with_cache=True): the offline-log pickle cache is not implemented; the training log is '
+                      'regenerated on the device (same rows for the same seed)', RuntimeWarning, stacklevel=2)
     successes = failures = 0
     per_epoch = num_organic_offline_users + num_offline_users + num_online_users
     for epoch in range(num_epochs):

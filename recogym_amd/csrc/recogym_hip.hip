@@ -241,9 +241,9 @@ struct rg_sim {
     void (*bf16_kernel)(DevSim, uint32_t, uint32_t);
     uint32_t draw_threads, draw_users;   // block size of that kernel and the users one block sweeps for (256 / 128; wide K: 512 / 256)
     bool profiling;
-    std::vector<hipEvent_t> prof_events;   // 5 per profiled step: before draw, after mfma, after search, after exact, after advance
+    std::vector<hipEvent_t> prof_events;   // 6 per profiled step: before draw, after mfma, after search, after exact, after the frozen LogReg acts, after advance
     size_t prof_used;
-    double prof_ms[4];
+    double prof_ms[5];                     // sweep, search, float64 resolve, LogReg acts, advance
     uint64_t prof_launches;
 };
 
@@ -536,6 +536,41 @@ __device__ __forceinline__ double ff64(double x) {
     return sigmoid64(5.0 * sigmoid64(2.0 * sigmoid64(0.3 * x) - 2.0) - 6.0);
 }
 
+// The click of a bandit event, click = [u >= 1 - ff(beta[a].omega + mu_b[a])] (reco_env_v1.py:104-116), decided in fp32
+// wherever that is provably the float64 decision.  `b_row` = beta32[a] (KB4 floats, zero padded), om[k * OM_STRIDE] =
+// float(omega_k), mb = float(mu_b[a]).  Returns 1 / 0 = click / no click, -1 = undecided (the caller evaluates float64).
+// Error budget (derivation): with e = 2^-24, x~ = fl32 dot of the rounded operands + fl32(mu_b),
+//   |x~ - x| <= (K + 3) e (sum_k |beta_k omega_k| + |mu_b|)         (operand rounding 2e, K fma roundings, one add)
+//   |ff'| <= 0.0285 * 5 * 0.25 * 2 * 0.25 * 0.3 = 5.4e-3             (range of the three nested sigmoids)
+// so the dot contributes <= 7.5e-9 (ax + |mu_b|) at K = 20; the three v_exp_f32 / v_rcp_f32 sigmoids (1 ulp each) add
+// <= 6e-8 to ctr, 1 - ctr and float(u) another 2^-24 + 2^-25: < 2e-7 in all.  The margin taken is 100x that:
+// 2e-5 + 1e-6 (ax + |mu_b|); ~4e-5 of the acts land inside it.  Tested adversarially through
+// rg_sim_debug_click_decisions (uniforms placed at 1 - ctr +- eps).
+template <int OM_STRIDE>
+__device__ __forceinline__ int click_decide32(const float* b_row, const float* om, uint32_t K, uint32_t KB4, float mb, double u) {
+    const float4* b4 = reinterpret_cast<const float4*>(b_row);
+    float x = 0.0f, ax = 0.0f;
+    for (uint32_t k0 = 0; k0 < KB4; k0 += 8) {
+        const float4 v0 = b4[k0 / 4], v1 = k0 + 4 < KB4 ? b4[k0 / 4 + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float bb[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (k0 + i < K) {
+                const float wk = om[(k0 + i) * OM_STRIDE];
+                x = fmaf(bb[i], wk, x);
+                ax = fmaf(fabsf(bb[i]), fabsf(wk), ax);
+            }
+    }
+    auto sig32 = [](float z) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * z)); };
+    const float ctr32 = sig32(5.0f * sig32(2.0f * sig32(0.3f * (x + mb)) - 2.0f) - 6.0f);
+    const float margin = 2.0e-5f + 1.0e-6f * (ax + fabsf(mb));
+    const float p0 = 1.0f - ctr32;
+    const float uf = static_cast<float>(u);
+    if (p0 < uf - margin) return 1;
+    if (p0 > uf + margin) return 0;
+    return -1;
+}
+
 // Box-Muller pair j of the K normals addressed by (user, t, purpose)
 __device__ __forceinline__ void normal_pair(uint64_t seed, uint32_t user, uint32_t t, uint32_t j,
                                             uint32_t purpose, double* z0, double* z1) {
@@ -778,9 +813,11 @@ __device__ __forceinline__ bool cdf_exceeds(double acc, double last, double u) {
 // DENSE = false leaves out the O(P) forms of the OrganicUserEventCounter policy (explore flip, epsilon smoothing,
 // reverse_pop: BASELINE configs use epsilon = 0) — ~40 % of this function's code, which the walk kernel would
 // otherwise carry through its instruction cache on every step; the host picks the instantiation.
-template <bool DENSE = true>
+// HOOK = true (rg_sim_debug_ouc_acts only): the OrganicUserEventCounter draw takes `u1_hook` for its second uniform
+// and *flag_hook tells whether the act was decided by the integer prefix walk (1) or by the float64 cdf walk (0).
+template <bool DENSE = true, bool HOOK = false>
 __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, uint32_t t,
-                               double* ps_out) {
+                               double* ps_out, double u1_hook = 0.0, int* flag_hook = nullptr) {
     if (d.policy == RG_POLICY_LAST_VIEW_TABLE) {
         const uint32_t p = d.lpv[slot];
         *ps_out = d.pol_ps ? static_cast<double>(d.pol_ps[p]) : 1.0;
@@ -819,7 +856,8 @@ __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, ui
         const double c0 = eps, c1 = eps + (1.0 - eps);
         explore = !(c0 / c1 <= u0);
     }
-    const double u1 = rg_uniform(w.w[2], w.w[3]);
+    const double u1 = HOOK ? u1_hook : rg_uniform(w.w[2], w.w[3]);
+    if (HOOK) *flag_hook = 0;
     if (d.ouc_exploit_explore && !explore) {
         // p_i = count_i / sum(counts): zero entries add exactly 0.0 to the running cdf, so the
         // sequential float64 cumsum over all P products equals the one over the viewed ones.
@@ -860,6 +898,7 @@ __device__ uint32_t policy_act(const DevSim& d, uint32_t slot, uint32_t user, ui
             }
             if (found && !amb) {
                 *ps_out = (1.0 - eps) * (static_cast<double>(c_f) / sum);
+                if (HOOK) *flag_hook = 1;
                 return a_f;
             }
         }
@@ -3749,6 +3788,7 @@ __global__ void __launch_bounds__(kBlock) k_logreg_acts(DevSim d, uint32_t t) {
     const int lane = lane_id();
     const uint32_t n = d.lr_cnt[t];
     const uint32_t waves_total = gridDim.x * (kBlock / 64);
+    unsigned long long c_acts = 0, c_rows = 0, c_exact = 0;
     for (uint32_t w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < n; w += waves_total) {
         const uint32_t slot = d.lr_list[w];
         const uint32_t uidx = d.uid[slot];
@@ -3756,6 +3796,7 @@ __global__ void __launch_bounds__(kBlock) k_logreg_acts(DevSim d, uint32_t t) {
         bool done = false;
         const hent_t* hr = hist_row(d, slot) + 1;
         const uint32_t nd = h_cnt(hr[-1]);
+        c_acts += 1; c_rows += nd;
         if (d.lr_coef32_t && nd <= 32 && nd > 0) {
             // history entries in registers of the first nd lanes, broadcast by readlane
             const hent_t mine = static_cast<uint32_t>(lane) < nd ? hr[lane] : 0ull;
@@ -3803,8 +3844,13 @@ __global__ void __launch_bounds__(kBlock) k_logreg_acts(DevSim d, uint32_t t) {
             const float bound = static_cast<float>(nd + 3) * 5.9604644775390625e-08f * Ahat * 1.01f;
             if (d.lr_n == 1 || best - second > 2.0f * bound) { action = static_cast<uint32_t>(d.lr_classes[best_c]); done = true; }
         }
-        if (!done) action = logreg_act_wave(d, slot, lane);             // float64, scipy's summation order
+        if (!done) { action = logreg_act_wave(d, slot, lane); c_exact += 1; }   // float64, scipy's summation order
         if (lane == 0) { d.lr_action[uidx] = action; d.lr_dirty[uidx] = 0; }
+    }
+    if (lane == 0 && c_acts) {
+        atomicAdd(&d.counters[RG_CNT_LR_ACTS], c_acts);
+        atomicAdd(&d.counters[RG_CNT_LR_ROWS], c_rows);
+        if (c_exact) atomicAdd(&d.counters[RG_CNT_LR_EXACT], c_exact);
     }
 }
 #endif
@@ -4725,28 +4771,9 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
             // band (~4e-5 of the acts) and for runs that export the click probability.
             bool click_known = false;
             if (is_ban && !d.aux_pclick && !RG_WALK_ABL(21)) {
-                const float4* b4 = reinterpret_cast<const float4*>(d.beta32 + static_cast<size_t>(a) * d.KB4);
-                const float* om = om_sel + lane;
-                float x = 0.0f, ax = 0.0f;
-                for (uint32_t k0 = 0; k0 < d.KB4; k0 += 8) {
-                    const float4 v0 = b4[k0 / 4], v1 = k0 + 4 < d.KB4 ? b4[k0 / 4 + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float bb[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (k0 + i < d.K) {
-                            const float wk = om[(k0 + i) * 64];
-                            x = fmaf(bb[i], wk, x);
-                            ax = fmaf(fabsf(bb[i]), fabsf(wk), ax);
-                        }
-                }
-                const float mb = static_cast<float>(d.mu_b[a]);
-                auto sig32 = [](float z) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * z)); };
-                const float ctr32 = sig32(5.0f * sig32(2.0f * sig32(0.3f * (x + mb)) - 2.0f) - 6.0f);
-                const float margin = 2.0e-5f + 1.0e-6f * (ax + fabsf(mb));
-                const float p0 = 1.0f - ctr32;
-                const float uf = static_cast<float>(rg_uniform(w.w[0], w.w[1]));
-                if (p0 < uf - margin) { click = true; click_known = true; }
-                else if (p0 > uf + margin) { click = false; click_known = true; }
+                const int dec = click_decide32<64>(d.beta32 + static_cast<size_t>(a) * d.KB4, om_sel + lane, d.K, d.KB4,
+                                                   static_cast<float>(d.mu_b[a]), rg_uniform(w.w[0], w.w[1]));
+                if (dec >= 0) { click = dec != 0; click_known = true; }
             }
             if (is_ban && click_known) {
                 c_clicks += click;
@@ -4936,6 +4963,46 @@ __global__ void __launch_bounds__(kBlock) k_debug_set_omega(DevSim d, const doub
 }
 #endif
 #if RG_HAS(1)
+// rg_sim_debug_click_decisions: click_decide32 (k_walk's fp32 decision) beside the float64 decision, per user index
+__global__ void __launch_bounds__(kBlock) k_debug_click(DevSim d, const int32_t* actions, const double* u, uint8_t* out) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) {
+        const uint32_t a = static_cast<uint32_t>(actions[i]);
+        const double* om = d.omega + static_cast<size_t>(i) * d.OMS;
+        float om32[64];
+        for (uint32_t k = 0; k < d.K && k < 64; ++k) om32[k] = static_cast<float>(om[k]);
+        const int dec = click_decide32<1>(d.beta32 + static_cast<size_t>(a) * d.KB4, om32, d.K, d.KB4, static_cast<float>(d.mu_b[a]), u[i]);
+        const double* b = d.beta + static_cast<size_t>(a) * d.K;
+        double x = 0.0;
+        for (uint32_t k = 0; k < d.K; ++k) x += b[k] * om[k];
+        const double ctr = ff64(x + d.mu_b[a]);
+        const double p0 = 1.0 - ctr;
+        const bool click64 = (p0 / (p0 + ctr)) <= u[i];
+        out[i] = static_cast<uint8_t>((dec >= 0 ? 1u : 0u) | (dec == 1 ? 2u : 0u) | (click64 ? 4u : 0u));
+    }
+}
+// rg_sim_debug_set_history: view histories of the reset range from (distinct count, products ascending, counts)
+__global__ void __launch_bounds__(kBlock) k_debug_set_history(DevSim d, const uint32_t* nd, const uint32_t* prod, const uint32_t* cnt,
+                                                               uint32_t stride) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) {
+        hent_t* hr = hist_row(d, i);
+        unsigned long long views = 0;
+        for (uint32_t j = 0; j < nd[i]; ++j) {
+            const uint32_t c = cnt[static_cast<size_t>(i) * stride + j];
+            hr[1 + j] = (static_cast<hent_t>(prod[static_cast<size_t>(i) * stride + j]) << 32) | c;
+            views += c;
+        }
+        hr[0] = (views << 32) | nd[i];
+    }
+}
+// rg_sim_debug_ouc_acts: policy_act (OrganicUserEventCounter) with a caller-chosen second uniform, per user index
+__global__ void __launch_bounds__(kBlock) k_debug_ouc_acts(DevSim d, const double* u1, int32_t* action, double* ps, uint8_t* flags) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) {
+        double p = 0.0;
+        int fl = 0;
+        const uint32_t a = policy_act<true, true>(d, i, static_cast<uint32_t>(d.first_user + i), 0u, &p, u1[i], &fl);
+        action[i] = static_cast<int32_t>(a); ps[i] = p; flags[i] = static_cast<uint8_t>(fl);
+    }
+}
 __global__ void __launch_bounds__(kBlock) k_debug_uncertified(DevSim d, uint32_t t_prev, uint8_t* flags) {
     const uint32_t n_a = d.exact_cnt[t_prev], n = n_a + (d.use_cache ? d.exact_cnt_b[t_prev] : 0u);
     const uint32_t* lst = list_ptr(d, t_prev & 1, RG_STATE_ORGANIC);
@@ -5313,6 +5380,7 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         hipLaunchKernelGGL(logreg_select_kernel(), dim3(grid_for(upper)), dim3(kBlock), 0, st, d, t);
         hipLaunchKernelGGL(logreg_acts_kernel(), dim3(grid_for(static_cast<uint64_t>(upper) / 4 + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
     }
+    if (int rc = prof_mark(sim, st)) return rc;
     // 2. click draws, transitions, drift, next lists, bandit + phantom rows
     hipLaunchKernelGGL(advance_kernel(), dim3(grid_for(upper, kAdvBlock)), dim3(kAdvBlock), 0, st, d, t, d_actions);
     HIP_TRY(hipGetLastError());
@@ -5325,8 +5393,8 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
 int prof_collect(rg_sim* sim) {
     if (!sim->prof_used) return RG_OK;
     HIP_TRY(hipEventSynchronize(sim->prof_events[sim->prof_used - 1]));
-    for (size_t i = 0; i + 4 < sim->prof_used; i += 5) {
-        for (int k = 0; k < 4; ++k) {
+    for (size_t i = 0; i + 5 < sim->prof_used; i += 6) {
+        for (int k = 0; k < 5; ++k) {
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, sim->prof_events[i + k], sim->prof_events[i + k + 1]));
             sim->prof_ms[k] += ms;
@@ -5524,7 +5592,7 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     d.n_users = d.n_cap = static_cast<uint32_t>(n_users);
     s->h_pinned = nullptr;
     s->profiling = false; s->prof_used = 0; s->prof_launches = 0;
-    s->prof_ms[0] = s->prof_ms[1] = s->prof_ms[2] = s->prof_ms[3] = 0.0;
+    s->prof_ms[0] = s->prof_ms[1] = s->prof_ms[2] = s->prof_ms[3] = s->prof_ms[4] = 0.0;
     s->mfma_smem = d.use_mfma ? mfma_smem_bytes(geom_of(*cfg)) : 0;
     // kernel choice: split-bf16 MFMA when a class exists for K, else fp32 MFMA; RECOGYM_DRAW=f64|fp32|bf16 overrides
     s->bf16_kernel = nullptr; s->bf16_smem = 0;
@@ -5797,6 +5865,12 @@ int rg_sim_run(rg_sim* sim, uint32_t max_steps, void* stream) {
             break;
         }
     }
+    {   // an incomplete run is an error, not a counter to remember to look at
+        unsigned long long* h64 = reinterpret_cast<unsigned long long*>(sim->h_pinned);
+        HIP_TRY(hipMemcpyAsync(h64, sim->d.counters + RG_CNT_EXACT_OVERFLOW, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (*h64) return fail(RG_ELIMIT, "%llu uncertified organic draws exceeded the float64 resolve scratch: the run is incomplete", *h64);
+    }
     return RG_OK;
 }
 
@@ -5818,7 +5892,7 @@ int rg_sim_set_profiling(rg_sim* sim, int on) {
     if (!sim) return fail(RG_EINVAL, "sim is NULL");
     sim->profiling = on != 0;
     sim->prof_used = 0; sim->prof_launches = 0;
-    sim->prof_ms[0] = sim->prof_ms[1] = sim->prof_ms[2] = sim->prof_ms[3] = 0.0;
+    sim->prof_ms[0] = sim->prof_ms[1] = sim->prof_ms[2] = sim->prof_ms[3] = sim->prof_ms[4] = 0.0;
     sim->prof_tail_ms = 0.0;
     sim->prof_walk_ms[0] = sim->prof_walk_ms[1] = 0.0;
     return RG_OK;
@@ -5827,10 +5901,11 @@ int rg_sim_set_profiling(rg_sim* sim, int on) {
 int rg_sim_get_profile(rg_sim* sim, double* out) {
     if (!sim || !out) return fail(RG_EINVAL, "NULL argument");
     if (int rc = prof_collect(sim)) return rc;
-    out[0] = sim->prof_ms[0]; out[1] = sim->prof_ms[1]; out[2] = sim->prof_ms[2]; out[3] = sim->prof_ms[3];
+    out[0] = sim->prof_ms[0]; out[1] = sim->prof_ms[1]; out[2] = sim->prof_ms[2]; out[3] = sim->prof_ms[4];
     out[4] = static_cast<double>(sim->prof_launches);
     out[5] = sim->prof_tail_ms;
     out[6] = sim->prof_walk_ms[0]; out[7] = sim->prof_walk_ms[1];
+    out[8] = sim->prof_ms[3]; out[9] = 0.0;
     return RG_OK;
 }
 
@@ -5898,6 +5973,39 @@ int rg_sim_debug_set_omega(rg_sim* sim, const double* d_omega, void* stream) {
     if (!sim->users_reset || sim->t != 0) return fail(RG_ESTATE, "only right after rg_sim_reset_users");
     hipLaunchKernelGGL(k_debug_set_omega, dim3(grid_for(static_cast<uint64_t>(sim->d.n_users) * sim->d.K)), dim3(kBlock), 0,
                        static_cast<hipStream_t>(stream), sim->d, d_omega);
+    HIP_TRY(hipGetLastError());
+    return RG_OK;
+}
+
+int rg_sim_debug_click_decisions(rg_sim* sim, const int32_t* d_actions, const double* d_u, uint8_t* d_out, void* stream) {
+    if (!sim || !d_actions || !d_u || !d_out) return fail(RG_EINVAL, "NULL argument");
+    if (!sim->users_reset || !sim->tables_set) return fail(RG_ESTATE, "needs tables and a reset range");
+    if (!sim->d.beta32) return fail(RG_ESTATE, "the fp32 click decision exists where k_walk runs (sigma_omega == 0 with the per-user cache)");
+    if (sim->d.K > 64) return fail(RG_EINVAL, "K > 64");
+    hipLaunchKernelGGL(k_debug_click, dim3(grid_for(sim->d.n_users)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), sim->d,
+                       d_actions, d_u, d_out);
+    HIP_TRY(hipGetLastError());
+    return RG_OK;
+}
+
+int rg_sim_debug_set_history(rg_sim* sim, const uint32_t* d_nd, const uint32_t* d_products, const uint32_t* d_counts,
+                             uint32_t stride, void* stream) {
+    if (!sim || !d_nd || !d_products || !d_counts) return fail(RG_EINVAL, "NULL argument");
+    if (!sim->users_reset || sim->t != 0) return fail(RG_ESTATE, "only right after rg_sim_reset_users");
+    if (!sim->d.hist_cap) return fail(RG_ESTATE, "the policy keeps no view history");
+    if (stride + 1 > sim->d.hist_cap) return fail(RG_EINVAL, "stride %u exceeds the history capacity %u", stride, sim->d.hist_cap - 1);
+    hipLaunchKernelGGL(k_debug_set_history, dim3(grid_for(sim->d.n_users)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), sim->d,
+                       d_nd, d_products, d_counts, stride);
+    HIP_TRY(hipGetLastError());
+    return RG_OK;
+}
+
+int rg_sim_debug_ouc_acts(rg_sim* sim, const double* d_u1, int32_t* d_action, double* d_ps, uint8_t* d_flags, void* stream) {
+    if (!sim || !d_u1 || !d_action || !d_ps || !d_flags) return fail(RG_EINVAL, "NULL argument");
+    if (sim->d.policy != RG_POLICY_ORGANIC_USER_COUNT) return fail(RG_ESTATE, "policy is not OrganicUserEventCounter");
+    if (!sim->users_reset) return fail(RG_ESTATE, "no reset range");
+    hipLaunchKernelGGL(k_debug_ouc_acts, dim3(grid_for(sim->d.n_users)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), sim->d,
+                       d_u1, d_action, d_ps, d_flags);
     HIP_TRY(hipGetLastError());
     return RG_OK;
 }

@@ -312,6 +312,7 @@ class RecoEnv1:
         total = num_users + num_organic_users
         pol = device_policy_of(agent)
         sim = self.make_simulator(total, agent, log=log, device=device, policy=pol)
+        log_retries = 0
         while True:
             sim.reset_users(first_user_id, total,
                             organic_only_below=first_user_id + num_organic_users)
@@ -331,7 +332,15 @@ class RecoEnv1:
                 continue
             if cnt['log_dropped'] == 0:
                 return cnt, sim
-            sim.set_log_capacity(cnt['log_rows'] + cnt['log_dropped'] + 1024)
+            # the walk reserves rows per wave in chunks and leaves holes whose number depends on the scheduling: retry
+            # with a proportional margin, not with the last run's exact need; a bounded number of times
+            log_retries += 1
+            if log_retries > 3:
+                raise _abi.RecoGymHipError(f"the log overflowed {log_retries} times ({cnt['log_dropped']} rows dropped at "
+                                           f"capacity {cnt['log_rows']})")
+            from ..sim import default_log_capacity
+            need = cnt['log_rows'] + cnt['log_dropped']
+            sim.set_log_capacity(max(default_log_capacity(self.config, total), int(1.10 * need) + 65536 * log_retries))
 
     # -- gym.Env episode API (one user at a time; batch of 1 on the device) -----------------------
     def _seq_sim(self):

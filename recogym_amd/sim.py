@@ -211,6 +211,7 @@ class Simulator:
             _abi.check(self.lib.rg_sim_step(self._h, ptr, self._stream()), 'rg_sim_step')
 
     def run(self, max_steps=1 << 16):
+        """rg_sim_run; raises when the run is incomplete (uncertified draws beyond the float64 resolve scratch)."""
         with torch.cuda.device(self.device):
             _abi.check(self.lib.rg_sim_run(self._h, max_steps, self._stream()), 'rg_sim_run')
 
@@ -220,7 +221,8 @@ class Simulator:
             _abi.check(self.lib.rg_sim_read_counters(self._h, out, self._stream()),
                        'rg_sim_read_counters')
         names = ['organic', 'bandit', 'clicks', 'phantom', 'live', 'step', 'log_rows',
-                 'log_dropped', 'exact_draws', 'hist_overflow', 'exact_sweeps', 'exact_overflow']
+                 'log_dropped', 'exact_draws', 'hist_overflow', 'exact_sweeps', 'exact_overflow', 'lr_acts', 'lr_rows',
+                 'lr_exact']
         return {k: int(out[i]) for i, k in enumerate(names)}
 
     def set_profiling(self, on=True):
@@ -228,10 +230,11 @@ class Simulator:
 
     def profile(self):
         """-> dict(draw_mfma_ms, draw_search_ms, draw_exact_ms, advance_ms, steps, tail_ms), HIP events."""
-        out = (C.c_double * 8)()
+        out = (C.c_double * 10)()
         _abi.check(self.lib.rg_sim_get_profile(self._h, out), 'rg_sim_get_profile')
         return dict(draw_mfma_ms=out[0], draw_search_ms=out[1], draw_exact_ms=out[2],
-                    advance_ms=out[3], steps=int(out[4]), tail_ms=out[5], walk1_ms=out[6], walk2_ms=out[7])
+                    advance_ms=out[3], steps=int(out[4]), tail_ms=out[5], walk1_ms=out[6], walk2_ms=out[7],
+                    logreg_ms=out[8])
 
     def states(self):
         with torch.cuda.device(self.device):
@@ -350,6 +353,21 @@ class Simulator:
         # piecewise: torch's masked select mis-indexes results beyond 2^31 bytes on this stack
         step = 1 << 24
         return torch.cat([raw[i:i + step][raw[i:i + step, 2] != -1] for i in range(0, n, step)])
+
+    def log_digest(self):
+        """Order-independent checksum of every real row of the raw device log (unused entries of a walked run skipped):
+        one sum per column of the 16-byte row (u, t, code, ps bits), each row weighted by (t + 7) (u + 13), modulo
+        2^64.  Equal digests of two runs = the same multiset of rows, whatever order the execution form emitted them
+        in; digests of disjoint user shards add up (mod 2^64) to the digest of the whole run."""
+        n = min(self.counters()['log_rows'], self.log_capacity)
+        chk = [0, 0, 0, 0]
+        step = 1 << 25
+        for lo in range(0, n, step):
+            rows = self.log[lo:min(lo + step, n)].to(torch.int64)
+            w = (rows[:, 1] + 7) * (rows[:, 0] + 13) * (rows[:, 2] != -1).to(torch.int64)
+            for i in range(4):
+                chk[i] = (chk[i] + int((rows[:, i] * w).sum().item())) % (1 << 64)
+        return chk
 
     def rows(self):
         """Decoded host rows in the reference's order."""

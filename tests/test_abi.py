@@ -38,6 +38,27 @@ def test_config_struct_layout_matches_header(lib):
     assert C.sizeof(_abi.RgEvent) == 16
 
 
+def test_integration_stub_declares_the_current_config_struct():
+    """The ctypes stub INTEGRATION.md shows a reference maintainer must declare struct rg_config exactly as the header
+    (and the package's own mirror) does: same fields, same order, same types, 144 bytes — a short struct would have
+    the library read time_mode past its end."""
+    md = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    block = md[md.index('class RgConfig(C.Structure)'):]
+    block = block[:block.index('lib = C.CDLL')]
+    ns = {'C': C}
+    exec(block, ns)
+    stub = ns['RgConfig']
+    assert C.sizeof(stub) == C.sizeof(_abi.RgConfig) == 144
+    assert [(n, C.sizeof(t)) for n, t in stub._fields_] == [(n, C.sizeof(t)) for n, t in _abi.RgConfig._fields_]
+    assert [getattr(stub, n).offset for n, _ in stub._fields_] == [getattr(_abi.RgConfig, n).offset for n, _ in _abi.RgConfig._fields_]
+    header = open(os.path.join(ROOT, 'include', 'recogym_hip.h')).read()
+    struct = header[header.index('typedef struct rg_config {'):header.index('} rg_config;')]
+    names = re.findall(r'^\s*(?:uint32_t|uint64_t|double)\s+([a-zA-Z_0-9]+)(?:\[\d+\])*;', struct, flags=re.M)
+    assert names == [n for n, _ in stub._fields_], names
+    m = re.search(r'rg_abi_version\(\) == (\d+)', md)
+    assert m and int(m.group(1)) == _abi.RG_ABI_VERSION
+
+
 def test_workspace_and_validation(lib):
     cfg = make_rg_config(Configuration({**env_1_args, 'random_seed': 1}), 1)
     n = lib.rg_sim_workspace_bytes(C.byref(cfg), 1000)

@@ -406,6 +406,39 @@ def test_normal_time_generator_matches_the_reference(name):
         assert np.array_equal(cs[k], want[k][keep].astype(np.int64)), k
 
 
+def test_with_ps_all_under_the_normal_time_generator_uses_the_event_index():
+    """OrganicUserEventCounter with with_ps_all, exploit_explore and epsilon > 0 under a NormalTimeGenerator: the `t`
+    column is the float clock, but the explore flip of a bandit row is the policy draw of the user's EVENT INDEX (what
+    the device and act() key it by).  The `ps-a` column rebuilt from the batched device log must be the distribution the
+    logged (a, ps) came from: equal to the per-user path's vectors, and ps == ps-a[a] * (eps or 1 - eps)."""
+    from recogym_amd.envs.features.time import NormalTimeGenerator
+    over = dict(random_seed=17, num_products=30, K=8)
+    oc = dict(gu.OUC_DEFAULTS, epsilon=0.3)
+
+    def env():
+        tg = NormalTimeGenerator(Configuration({'normal_time_mu': 0.0, 'normal_time_sigma': 1.0}))
+        return make_env({**over, 'time_generator': tg})
+
+    def agent():
+        return OrganicUserEventCounterAgent(Configuration({**oc, 'weight_history_function': None, 'num_products': 30,
+                                                           'random_seed': 5, 'with_ps_all': True}))
+    df_dev = env().generate_logs(60, agent())
+    df_seq = env()._generate_logs_per_user(60, agent(), 0)
+    assert len(df_dev) == len(df_seq)
+    for k in ('u', 'a', 'c'):
+        assert np.array_equal(df_dev[k].to_numpy(dtype=np.float64, na_value=np.nan),
+                              df_seq[k].to_numpy(dtype=np.float64, na_value=np.nan), equal_nan=True), k
+    is_b = (df_dev['z'] == 'bandit').to_numpy()
+    explored = 0
+    for i in np.flatnonzero(is_b):
+        np.testing.assert_allclose(df_dev['ps-a'][i], df_seq['ps-a'][i], rtol=1e-15, atol=0)
+        pa = df_dev['ps-a'][i][int(df_dev['a'][i])]
+        ps = float(df_dev['ps'][i])
+        assert np.isclose(ps, 0.7 * pa, rtol=1e-12) or np.isclose(ps, 0.3 * pa, rtol=1e-12)
+        explored += int(np.isclose(ps, 0.3 * pa, rtol=1e-12) and not np.isclose(ps, 0.7 * pa, rtol=1e-12))
+    assert explored > 10          # the flips are exercised
+
+
 def test_logreg_select_randomly_samples_like_the_reference():
     """LogregMulticlassIpsAgent with select_randomly=True (logreg_ips.py:61-66): the action is sampled from
     predict_proba with the model's own rng.  Host form only (per-user path, HIP kernels underneath): reproduces the

@@ -1,34 +1,52 @@
-"""BASELINE config 3 at full size, twice: certified fp16-split MFMA draws vs float64-only draws
-(the oracle's arithmetic).  Prints counters and an order-independent checksum of every log row."""
+"""Row-level parity at full size of what the headline actually runs.
+
+For each workload the DEFAULT path (sigma_omega = 0: sweep -> k_walk with the fp32-decided clicks, the integer-decided
+OrganicUserEventCounter act and the float64 sums of the parked users on both float64 pipes; sigma_omega > 0: certified
+fp16-split MFMA sweeps) is compared with the float64-only lock-step path — RECOGYM_DRAW=f64 RECOGYM_WALK=0 with the
+click-probability export on, which forces every click through float64 — on the counters and on an order-independent
+checksum of EVERY log row (Simulator.log_digest).  The float64-only path is the oracle's arithmetic on the device
+(tests/test_hip_parity.py pins it on the oracle and on the reference's logs at small sizes).
+
+    python tools/full_scale_check.py [c3 c2 c4shard] [--users N]      -> one JSON line per run + a verdict line
+"""
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from recogym_amd import _abi
-from recogym_amd.envs.configuration import Configuration
-from recogym_amd.envs.reco_env_v1 import env_1_args
+import bench
 from recogym_amd.sim import Simulator, default_log_capacity
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-cfg = Configuration({**env_1_args, 'random_seed': 42, 'num_products': 10000, 'K': 20, 'sigma_omega': 0.0})
-out = {}
-for mode in ('f16', 'f64'):
-    os.environ['RECOGYM_DRAW'] = mode
-    sim = Simulator(cfg, n, device='cuda:0', log_capacity=default_log_capacity(cfg, n),
-                    policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=42,
-                    ouc=dict(select_randomly=True, epsilon=0.0, exploit_explore=True, reverse_pop=False))
-    sim.reset_users(0, n)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    sim.run()
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    c = sim.counters()
-    chk = [0, 0, 0, 0]
-    step = 1 << 26
-    for lo in range(0, c['log_rows'], step):
-        rows = sim.log[lo:min(lo + step, c['log_rows'])].to(torch.int64)
-        for i in range(4):
-            chk[i] = (chk[i] + int((rows[:, i] * (rows[:, 1] + 7) * (rows[:, 0] + 13)).sum().item())) % (1 << 64)
-    out[mode] = dict(seconds=round(dt, 2), counters={k: c[k] for k in ('organic', 'bandit', 'clicks', 'phantom', 'log_rows', 'exact_draws')}, checksum=chk)
-    print(mode, json.dumps(out[mode]), flush=True)
-    sim.close(); del sim; torch.cuda.empty_cache()
-same = out['f16']['checksum'] == out['f64']['checksum'] and all(
-    out['f16']['counters'][k] == out['f64']['counters'][k] for k in ('organic', 'bandit', 'clicks', 'phantom', 'log_rows'))
-print('IDENTICAL LOGS' if same else 'MISMATCH')
+
+args = [a for a in sys.argv[1:] if not a.startswith('--')]
+users_override = int(sys.argv[sys.argv.index('--users') + 1]) if '--users' in sys.argv else 0
+workloads = args or ['c3', 'c2', 'c4shard']
+FAST = {}                                                           # the default path
+EXACT = {'RECOGYM_DRAW': 'f64', 'RECOGYM_WALK': '0'}                 # float64 draws, lock-step, float64 clicks
+ok_all = True
+for wl in workloads:
+    _, per_gpu, _, pol = bench.WORKLOADS[wl]
+    n = users_override or per_gpu
+    cfg = bench.make_config(wl)
+    out = {}
+    for name, env, p_click in (('default', FAST, False), ('float64', EXACT, True)):
+        for k in ('RECOGYM_DRAW', 'RECOGYM_WALK'):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        sim = Simulator(cfg, n, device='cuda:0', log_capacity=default_log_capacity(cfg, n), p_click=p_click,
+                        **bench.policy_kwargs(pol))
+        sim.reset_users(0, n)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        sim.run()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        c = sim.counters()
+        out[name] = dict(workload=wl, path=name, env=env, p_click_export=p_click, users=n, seconds=round(dt, 3),
+                         counters={k: c[k] for k in ('organic', 'bandit', 'clicks', 'phantom', 'exact_draws', 'exact_sweeps',
+                                                     'exact_overflow', 'hist_overflow', 'log_dropped', 'live')},
+                         digest=sim.log_digest())
+        print(json.dumps(out[name]), flush=True)
+        sim.close(); del sim; torch.cuda.empty_cache()
+    same = out['default']['digest'] == out['float64']['digest'] and all(
+        out['default']['counters'][k] == out['float64']['counters'][k] for k in ('organic', 'bandit', 'clicks', 'phantom')) and all(
+        out[p]['counters'][k] == 0 for p in out for k in ('exact_overflow', 'hist_overflow', 'log_dropped', 'live'))
+    ok_all = ok_all and same
+    print(json.dumps(dict(workload=wl, users=n, rows=out['default']['counters']['organic'] + out['default']['counters']['bandit'],
+                          verdict='IDENTICAL LOGS' if same else 'MISMATCH')), flush=True)
+sys.exit(0 if ok_all else 1)
