@@ -130,6 +130,7 @@ typedef struct rg_event {
 #define RG_CNT_LR_ACTS 12       /* RG_POLICY_LOGREG_FROZEN: acts computed (one per change of a user's view history that an event needed) */
 #define RG_CNT_LR_ROWS 13       /* ... and the coef^T rows (viewed products) those acts read */
 #define RG_CNT_LR_EXACT 14      /* ... acts the fp32 scores could not certify (decided by float64 scores) */
+#define RG_CNT_MEMO_HITS 15     /* sigma_omega = 0, user-major walk: organic draws answered by the user's memo of certified draws */
 #define RG_CNT_N 24             /* out[] of rg_sim_read_counters; slots past the named ones are internal */
 
 typedef struct rg_sim rg_sim;

@@ -161,6 +161,9 @@ struct DevSim {
     // 33: the certificate's delta (rounded up), 34-35: - | [36,44) 32 int8: reference offset of every super-chunk
     // (scale of its chunk sums) | [44, 44 + 2 KH) omega32.  256 bytes at K <= 20: two lines instead of six
     float* cache_row; uint32_t cache_row_f;   // row stride in floats (multiple of 32)
+    // k_walk2: [n_cap + 1][32] hot row {S, delta, Q, n_hot | 9 x {product, u_lo, u_hi}} and [n_cap + 1][32] fp32 prefix at the end of
+    // every super-chunk (cache_chunk holds the chunk-level prefixes once k_cache_prefix ran)
+    float* walk_hot; float* walk_scp;
     // user-major walk of the sigma_omega == 0 mode (k_walk): users parked at their first uncertified draw
     uint32_t sweep_only;      // the step-0 sweep only fills the cache (no search, no rows): k_walk draws t = 0 too
     uint32_t* park_list;      // [n_cap + 64] user indices, reserved in chunks of 64 (0xFFFFFFFF = unused entry)
@@ -231,6 +234,7 @@ struct rg_sim {
     bool cached_search_old;   // RECOGYM_CACHED=search: the first form of the cached draw (k_draw_search over the cache)
     bool walk;                // rg_sim_run "to the end" walks the run user-major (k_walk) instead of step-major
     int walk_occ;             // blocks per CU of the walk kernel (RECOGYM_WALK_OCC: 2, 3 or 4)
+    bool walk2;               // the walk is k_walk2 (prefix sums + memo; RECOGYM_WALK=1 keeps k_walk)
     int n_cus;                // compute units of the device (grid of the persistent walk kernel)
     double prof_walk_ms[2];   // round 1 / round 2 of k_walk
     uint32_t repack_every;    // steps between repacks (RECOGYM_REPACK, 0 = never)
@@ -279,6 +283,8 @@ search_kernel_t logreg_acts_kernel();
 advance_kernel_t advance_kernel();
 search_kernel_t tail_kernel();
 walk_kernel_t walk_kernel_for(const DevSim& d, int occ);   // part 7
+walk_kernel_t walk2_kernel_for(const DevSim& d, int occ);  // (nullptr: this configuration keeps k_walk)
+void (*cache_prefix_kernel())(DevSim);
 
 // ------------------------------------------------------------------------------------------
 // workspace carving (host)
@@ -306,6 +312,7 @@ constexpr uint32_t kHoleCode = 0xFFFFFFFFu;   // rg_event.code of an unused raw-
 
 constexpr int kCntTailRows = 16, kCntTailOrganic = 17, kCntTailBandit = 18, kCntTailMaxT = 19, kCntTailTicket = 20,
               kCntTailLimit = 21, kCntWalkTicket = 22, kCntParkCnt = 23;   // internal slots of counters[] (RG_CNT_N = 24)
+constexpr int kCntWalkHits = RG_CNT_MEMO_HITS;
 
 struct Geom { uint32_t KH, KS, TP, P_pad, n_chunks, sc_chunks, n_sc, N1, N2, N3, RS, TPB, F16; };
 
@@ -458,6 +465,8 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     float* cache_sub = w.take<float>(sub ? (n + 1) * static_cast<size_t>(g.n_chunks) * 4 : 4);
     const uint32_t cache_row_f = (44u + 2u * g.KH + 31u) & ~31u;
     float* cache_row = w.take<float>(cache ? (n + 1) * static_cast<size_t>(cache_row_f) : 1);
+    float* walk_hot = w.take<float>(cache ? (n + 1) * 32 : 1);
+    float* walk_scp = w.take<float>(cache ? (n + 1) * static_cast<size_t>(kMaxSC) : 1);
     uint8_t* f64_valid = w.take<uint8_t>(cache ? n : 1);
     uint32_t* exact_cnt_b = w.take<uint32_t>(kMaxSteps + 2);
     const bool lr = c.policy == RG_POLICY_LOGREG_FROZEN;
@@ -479,6 +488,7 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->beta32 = cache ? beta32 : nullptr; d->KB4 = static_cast<uint32_t>(KB4);
         d->f64_valid = f64_valid; d->exact_cnt_b = exact_cnt_b; d->cache_row = cache_row; d->cache_row_f = cache_row_f;
         d->park_list = park_list; d->park_t = park_t; d->sweep_only = 0;
+        d->walk_hot = cache ? walk_hot : nullptr; d->walk_scp = walk_scp;
         d->lr_action = lr_action; d->lr_dirty = lr ? lr_dirty : nullptr; d->lr_list = lr_list; d->lr_cnt = lr_cnt;
         d->uid = uid; d->omega_alt = omega_alt; d->hist_alt = hist_alt;
         d->lpv_alt = lpv_alt; d->uid_alt = uid_alt;
@@ -537,7 +547,7 @@ __device__ __forceinline__ double ff64(double x) {
 }
 
 // The click of a bandit event, click = [u >= 1 - ff(beta[a].omega + mu_b[a])] (reco_env_v1.py:104-116), decided in fp32
-// wherever that is provably the float64 decision.  `b_row` = beta32[a] (KB4 floats, zero padded), om[k * OM_STRIDE] =
+// wherever that is provably the float64 decision.  `b_row` = beta32[a] (KB4 floats, zero padded), om_at(k) =
 // float(omega_k), mb = float(mu_b[a]).  Returns 1 / 0 = click / no click, -1 = undecided (the caller evaluates float64).
 // Error budget (derivation): with e = 2^-24, x~ = fl32 dot of the rounded operands + fl32(mu_b),
 //   |x~ - x| <= (K + 3) e (sum_k |beta_k omega_k| + |mu_b|)         (operand rounding 2e, K fma roundings, one add)
@@ -546,20 +556,24 @@ __device__ __forceinline__ double ff64(double x) {
 // <= 6e-8 to ctr, 1 - ctr and float(u) another 2^-24 + 2^-25: < 2e-7 in all.  The margin taken is 100x that:
 // 2e-5 + 1e-6 (ax + |mu_b|); ~4e-5 of the acts land inside it.  Tested adversarially through
 // rg_sim_debug_click_decisions (uniforms placed at 1 - ctr +- eps).
-template <int OM_STRIDE>
-__device__ __forceinline__ int click_decide32(const float* b_row, const float* om, uint32_t K, uint32_t KB4, float mb, double u) {
+// `om_at(k)` = float(omega_k) (k < KMAX compile-time unrolled: LDS, memory or a register array), KMAX >= KB4 a multiple of 4.
+template <int KMAX, class OmAt>
+__device__ __forceinline__ int click_decide32(const float* b_row, OmAt om_at, uint32_t K, uint32_t KB4, float mb, double u) {
     const float4* b4 = reinterpret_cast<const float4*>(b_row);
     float x = 0.0f, ax = 0.0f;
-    for (uint32_t k0 = 0; k0 < KB4; k0 += 8) {
-        const float4 v0 = b4[k0 / 4], v1 = k0 + 4 < KB4 ? b4[k0 / 4 + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float bb[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (k0 + i < K) {
-                const float wk = om[(k0 + i) * OM_STRIDE];
-                x = fmaf(bb[i], wk, x);
-                ax = fmaf(fabsf(bb[i]), fabsf(wk), ax);
-            }
+    for (int k4 = 0; k4 < KMAX / 4; ++k4) {
+        if (static_cast<uint32_t>(4 * k4) < KB4) {
+            const float4 v = b4[k4];
+            const float bb[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (static_cast<uint32_t>(4 * k4 + i) < K) {
+                    const float wk = om_at(4 * k4 + i);
+                    x = fmaf(bb[i], wk, x);
+                    ax = fmaf(fabsf(bb[i]), fabsf(wk), ax);
+                }
+        }
     }
     auto sig32 = [](float z) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * z)); };
     const float ctr32 = sig32(5.0f * sig32(2.0f * sig32(0.3f * (x + mb)) - 2.0f) - 6.0f);
@@ -4771,8 +4785,9 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
             // band (~4e-5 of the acts) and for runs that export the click probability.
             bool click_known = false;
             if (is_ban && !d.aux_pclick && !RG_WALK_ABL(21)) {
-                const int dec = click_decide32<64>(d.beta32 + static_cast<size_t>(a) * d.KB4, om_sel + lane, d.K, d.KB4,
-                                                   static_cast<float>(d.mu_b[a]), rg_uniform(w.w[0], w.w[1]));
+                const float* om_l = om_sel + lane;
+                const int dec = click_decide32<((K2 + 3) / 4) * 4>(d.beta32 + static_cast<size_t>(a) * d.KB4, [&](int k) { return om_l[k * 64]; },
+                                                                   d.K, d.KB4, static_cast<float>(d.mu_b[a]), rg_uniform(w.w[0], w.w[1]));
                 if (dec >= 0) { click = dec != 0; click_known = true; }
             }
             if (is_ban && click_known) {
@@ -4881,6 +4896,678 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
 }
 #endif
 
+// ------------------------------------------------------------------------------------------
+// k_walk2 — the user-major walk, second form (the default where it applies; k_walk above remains for the other
+// configurations and as RECOGYM_WALK=1).  Same contract, lists, rounds, parking and hand-over as k_walk; what changed is
+// what an event costs in DEPENDENT memory round trips, the thing that bound k_walk (61 % of its wave cycles in
+// s_waitcnt at three waves per SIMD):
+//   * prefix form of the per-user sums (k_cache_prefix, once per run): the 32 super-chunk sums and the chunk sums of a user
+//     become fp32 prefix sums on the user's common reference, so the two search levels are "count the prefixes <= u S"
+//     (one compare per element, no float64 running sum, no per-super-chunk scale);
+//   * a per-user MEMO of certified draws: the first time the search certifies product v for a user, the u-interval that
+//     is certified for v — [C~[v-1](1+d)/(S~(1-d)), C~[v](1-d)/(S~(1+d))] rounded inwards — joins the user's hot row
+//     (9 entries in one 128-byte line).  A user's softmax never changes (sigma_omega = 0) and is peaked (its top product
+//     holds 46 % of the mass on C3, the top 8 hold 82 %), so most later draws of the user land in a memoised interval:
+//     one load, no search.  A memo hit IS a certificate (the same inequality), so the logged index is float64's either way;
+//   * three event kinds per wave iteration instead of two: organic draws answered by the memo, organic draws that need the
+//     search (they wait until >= 16 lanes of the wave do: the search's passes then run full), bandit events;
+//   * the user's view history (header + 15 products: most users' whole history) lives in LDS for the user's stay on the
+//     lane (write-through to its row in HBM): the OrganicUserEventCounter act and the view insertion touch no memory;
+//   * omega32 of the lane's user in 2 KH registers (the chunk recompute fetches the searching users' by ds_bpermute),
+//     counters in scalar registers: <= 128 VGPRs, four waves per SIMD.
+// ------------------------------------------------------------------------------------------
+constexpr int kHotEntries = 9;          // memo entries of a user: floats [4 + 3 j, 7 + 3 j) of its hot row = {product, u_lo, u_hi}
+constexpr int kWSlow = 6;               // lane state: organic draw that missed the memo (RG_STATE_* = 0..2, empty 3, phantom 4)
+__host__ __device__ inline size_t walk2_wave_lds(int hist) { return (hist ? 16 * 64 * 8 : 0) + 64 * 24; }
+#if RG_HAS(7)
+
+// The prefix form.  Eight lanes per user, 32 chunks per pass (one 128-byte line of the user's chunk sums): scaled to the
+// user's common reference Q (exact powers of two), summed in float64 in chunk order, stored back in place as fp32
+// prefixes; the prefix at the end of every super-chunk also goes to the user's scp row, the total into its hot row.
+__global__ void __launch_bounds__(kBlock) k_cache_prefix(DevSim d) {
+    const int lane = lane_id(), grp = lane >> 3, gl = lane & 7;
+    const uint32_t n_groups = (d.n_users + 7) / 8;
+    const uint32_t waves = gridDim.x * (kBlock / 64);
+    for (uint32_t ug = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); ug < n_groups; ug += waves) {
+        const uint32_t i = ug * 8 + grp;
+        const bool act = i < d.n_users;
+        const size_t row = act ? i : d.n_cap;
+        const float4* r4 = reinterpret_cast<const float4*>(d.cache_row + row * d.cache_row_f);
+        const float4 hdr = r4[8], of0 = r4[9], of1 = r4[10];
+        float* cp = d.cache_chunk + row * d.n_chunks;
+        float* scp = d.walk_scp + row * kMaxSC;
+        double run = 0.0;
+        for (uint32_t c0 = 0; c0 < d.n_chunks; c0 += 32) {
+            const uint32_t c = c0 + 4 * gl;
+            const bool in = c < d.n_chunks;
+            const float4 w = in ? *reinterpret_cast<const float4*>(cp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint32_t sc = min(c / d.sc_chunks, kMaxSC - 1u);       // (sc_chunks % 4 == 0: one super-chunk per float4)
+            const uint32_t q = sc >> 2;
+            const float4 o4 = q < 4 ? of0 : of1;
+            const float ow = (q & 3) == 0 ? o4.x : (q & 3) == 1 ? o4.y : (q & 3) == 2 ? o4.z : o4.w;
+            const uint32_t off = (__builtin_bit_cast(uint32_t, ow) >> (8 * (sc & 3))) & 0xFFu;
+            const float f = off >= 127u ? 0.0f : __builtin_amdgcn_exp2f(-static_cast<float>(off));
+            const double p0 = static_cast<double>(w.x * f), p1 = p0 + static_cast<double>(w.y * f);
+            const double p2 = p1 + static_cast<double>(w.z * f), p3 = p2 + static_cast<double>(w.w * f);
+            double inc = p3;
+#pragma unroll
+            for (int o2 = 1; o2 < 8; o2 <<= 1) {
+                const double y = __shfl_up(inc, o2, 8);
+                if (gl >= o2) inc += y;
+            }
+            const double base = run + (inc - p3);
+            const float4 out = make_float4(static_cast<float>(base + p0), static_cast<float>(base + p1),
+                                           static_cast<float>(base + p2), static_cast<float>(base + p3));
+            if (in && act) {
+                *reinterpret_cast<float4*>(cp + c) = out;
+                if ((c + 4) % d.sc_chunks == 0 || c + 4 == d.n_chunks) scp[sc] = out.w;
+            }
+            run += __shfl(inc, (grp << 3) | 7);
+        }
+        if (act) {
+            for (uint32_t sc = d.n_sc + gl; sc < kMaxSC; sc += 8) scp[sc] = INFINITY;     // never counted
+            if (gl == 0) {
+                // S~ as the search sees it (the last prefix), the certificate's delta + the roundings of the stored prefixes
+                // (2^-24 each, relative to the prefix: the same kind of error the budget is made of), Q, an empty memo
+                float4* hot = reinterpret_cast<float4*>(d.walk_hot + row * 32);
+                hot[0] = make_float4(static_cast<float>(run), hdr.y * 1.000001f + 2.4e-7f, hdr.x, __builtin_bit_cast(float, 0u));
+            }
+        }
+    }
+}
+
+// next float above / below (finite x; the roundings of the memo's interval bounds and of the uniform go INWARDS)
+__device__ __forceinline__ float f32_up(float x) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, x);
+    return x == 0.0f ? __builtin_bit_cast(float, 1u) : __builtin_bit_cast(float, x > 0.0f ? b + 1u : b - 1u);
+}
+__device__ __forceinline__ float f32_down(float x) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, x);
+    return x == 0.0f ? __builtin_bit_cast(float, 0x80000001u) : __builtin_bit_cast(float, x > 0.0f ? b - 1u : b + 1u);
+}
+
+template <int KH, int HIST, int OCC>
+__global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_work, int round, uint32_t chunk_rows,
+                                                        uint32_t in_base, uint32_t out_base) {
+    (void)d_arg;       // read from the kernel-argument segment at the point of use (see k_walk)
+    const __attribute__((address_space(4))) char* kargs =
+        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int K2 = 2 * KH;
+    constexpr int KC = ((K2 + 3) / 4) * 4;
+    constexpr int kEmpty = 3, kPhantom = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    char* wbase = smem_raw + static_cast<size_t>(wave) * walk2_wave_lds(HIST);
+    hent_t* hl = reinterpret_cast<hent_t*>(wbase) + lane;               // HIST: [16][64] entry-major: hl[i * 64]
+    double* mbox = reinterpret_cast<double*>(wbase + (HIST ? 16 * 64 * 8 : 0));   // [64][3]
+    uint32_t slot = 0, t = 0;
+    int st = kEmpty;
+    bool pend = false;                                                 // rounds >= 2: the parked draw, to be picked in float64
+    float om[KC];                                                      // omega32 of the lane's user
+#pragma unroll
+    for (int k = 0; k < KC; ++k) om[k] = 0.0f;
+    uint32_t res_next = 0, res_end = 0;
+    uint64_t row_next = 0, row_end = 0;
+    uint32_t park_next = 0, park_end = 0;
+    bool exhausted = false;
+    // wave-uniform tallies (scalar registers): events are counted by ballots
+    uint32_t c_org = 0, c_ban = 0, c_clicks = 0, c_ph = 0, c_pick = 0, c_sweeps = 0, c_maxt = 0, c_limit = 0, c_hit = 0;
+
+    for (;;) {
+        asm volatile("" : "+s"(kargs));
+        const DevSim& d = *(const DevSim*)kargs;
+        const uint32_t n_cc = d.PT / 64;
+        // ---- refill the lanes whose user has stopped (or was parked) ----
+        {
+            unsigned long long dead = __ballot(st == kEmpty);
+            if (dead && !exhausted && (static_cast<uint32_t>(__popcll(dead)) >= d.walk_refill || dead == ~0ull)) {
+                for (int pass = 0; pass < 2 && dead; ++pass) {
+                    if (res_next == res_end) {
+                        if (exhausted) break;
+                        uint32_t base = 0;
+                        if (lane == 0) base = static_cast<uint32_t>(atomicAdd(&d.counters[kCntWalkTicket], 64ull));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (base >= n_work) { exhausted = true; break; }
+                        res_next = base; res_end = min(base + 64u, n_work);
+                    }
+                    const uint32_t take = min(static_cast<uint32_t>(__popcll(dead)), res_end - res_next);
+                    const uint32_t r = prefix_in_mask(dead);
+                    const bool mine = ((dead >> lane) & 1ull) != 0 && r < take;
+                    if (mine) {
+                        const uint32_t idx = res_next + r;
+                        uint32_t s2 = idx;
+                        if (round >= 2) s2 = d.park_list[in_base + idx];
+                        if (s2 != 0xFFFFFFFFu) {
+                            slot = s2; st = RG_STATE_ORGANIC; t = 0u; pend = false;
+                            if (round >= 2) {
+                                const uint32_t pt = d.park_t[s2];
+                                t = pt & 0xFFFFFFu; st = static_cast<int>((pt >> 24) & 7u); pend = (pt >> 27) & 1u;
+                                if (round == 2) d.f64_valid[s2] = 1;         // the batch between the rounds took its sums
+                                if (pend) st = kWSlow;                       // its draw goes straight to the float64 pick
+                            }
+                            const float4* rp = reinterpret_cast<const float4*>(d.cache_row + static_cast<size_t>(s2) * d.cache_row_f);
+#pragma unroll
+                            for (int k4 = 0; k4 < K2 / 4; ++k4) {
+                                const float4 x = rp[11 + k4];
+                                om[4 * k4] = x.x; om[4 * k4 + 1] = x.y; om[4 * k4 + 2] = x.z; om[4 * k4 + 3] = x.w;
+                            }
+#pragma unroll
+                            for (int k = (K2 / 4) * 4; k < K2; ++k) om[k] = reinterpret_cast<const float*>(rp)[44 + k];
+                            if (HIST) {
+                                const ulonglong2* hr2 = reinterpret_cast<const ulonglong2*>(hist_row(d, s2));
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    const ulonglong2 x = hr2[i];
+                                    hl[(2 * i) * 64] = x.x; hl[(2 * i + 1) * 64] = x.y;
+                                }
+                            }
+                        }
+                    }
+                    // (the float64 batch between the rounds swept for every parked user: counted where round 2 takes them)
+                    if (round == 2) c_sweeps += static_cast<uint32_t>(__popcll(__ballot(mine && st != kEmpty && pend)));
+                    res_next += take;
+                    dead = __ballot(st == kEmpty && !mine);
+                }
+            }
+        }
+        const unsigned long long live = __ballot(st != kEmpty);
+        if (!live) { if (exhausted) break; else continue; }
+        // ---- hand-over (see k_walk) ----
+        if (exhausted && round < 3 && d.walk_handover && static_cast<uint32_t>(__popcll(live)) <= d.walk_handover) {
+            const bool give = st != kEmpty;
+            const unsigned long long gm = __ballot(give);
+            const uint32_t np = static_cast<uint32_t>(__popcll(gm));
+            if (park_next + np > park_end) {
+                for (uint32_t r = park_next + lane; r < park_end; r += 64) d.park_list[out_base + r] = 0xFFFFFFFFu;
+                uint32_t base = 0;
+                if (lane == 0) base = static_cast<uint32_t>(atomicAdd(&d.counters[kCntParkCnt], 64ull));
+                base = __builtin_amdgcn_readfirstlane(base);
+                park_next = base; park_end = base + 64;
+            }
+            if (give) {
+                d.park_list[out_base + park_next + prefix_in_mask(gm)] = slot;
+                const int st_out = st == kWSlow ? RG_STATE_ORGANIC : st;     // (a searching draw restarts at the memo check)
+                d.park_t[slot] = t | (static_cast<uint32_t>(st_out) << 24) | (pend ? 1u << 27 : 0u);
+                if (round == 1) d.exact_ref[slot] = d.cache_row[static_cast<size_t>(slot) * d.cache_row_f + 32];
+                st = kEmpty;
+            }
+            park_next += np;
+            break;
+        }
+        // ---- ONE kind of event per iteration: memo-answered organic draws, searching organic draws, bandit events ----
+        const uint32_t n_o = static_cast<uint32_t>(__popcll(__ballot(st == RG_STATE_ORGANIC)));
+        const uint32_t n_s = static_cast<uint32_t>(__popcll(__ballot(st == kWSlow)));
+        const uint32_t n_b = static_cast<uint32_t>(__popcll(__ballot(st == RG_STATE_BANDIT || st == kPhantom)));
+        int kind;                                  // 0 = memo check, 1 = search, 2 = bandit
+        if (n_s >= 16u || (n_s && !n_o && !n_b)) kind = 1;
+        else if (n_o && (n_o * d.walk_bias >= n_b * 4u)) kind = 0;
+        else if (n_b) kind = 2;
+        else kind = n_o ? 0 : 1;
+        const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
+        const rg_u32x4 w = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
+        bool have_v = false, parked = false;
+        uint32_t v = 0;
+        if (kind == 0) {
+            // =========================== organic draw, answered by the user's memo ===========================
+            const bool is_o = st == RG_STATE_ORGANIC;
+            const size_t row = is_o ? slot : d.n_cap;
+            const float4* hp = reinterpret_cast<const float4*>(d.walk_hot + row * 32);
+            const float4 h0 = hp[0];
+            const uint32_t n_hot = __builtin_bit_cast(uint32_t, h0.w);
+            const double u_org = d.u_override ? d.u_override[slot] : rg_uniform(w.w[0], w.w[1]);
+            float uf = static_cast<float>(u_org), u_dn = uf, u_up = uf;
+            if (static_cast<double>(uf) > u_org) u_dn = f32_down(uf);
+            if (static_cast<double>(uf) < u_org) u_up = f32_up(uf);
+            bool hit = false;
+            if (n_hot) {
+                float e[28];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) {
+                    const float4 x = hp[i];
+                    e[4 * i - 4] = x.x; e[4 * i - 3] = x.y; e[4 * i - 2] = x.z; e[4 * i - 1] = x.w;
+                }
+#pragma unroll
+                for (int j = 0; j < kHotEntries; ++j)
+                    if (static_cast<uint32_t>(j) < n_hot && e[3 * j + 1] < u_dn && u_up < e[3 * j + 2]) {
+                        hit = true; v = __builtin_bit_cast(uint32_t, e[3 * j]);
+                    }
+            }
+            have_v = is_o && hit;
+            if (is_o && !hit) st = kWSlow;
+            c_hit += static_cast<uint32_t>(__popcll(__ballot(have_v)));
+        } else if (kind == 1) {
+            // =========================== organic draw by the search over the user's prefix sums ===========================
+            const bool is_s = st == kWSlow;
+            const bool search = is_s && !pend;
+            const size_t row = search ? slot : d.n_cap;
+            const float4* hp = reinterpret_cast<const float4*>(d.walk_hot + row * 32);
+            const float4 h0 = hp[0];
+            const double S = static_cast<double>(h0.x), delta = static_cast<double>(h0.y);
+            const float Q = h0.z;
+            const uint32_t n_hot = __builtin_bit_cast(uint32_t, h0.w);
+            const double u_org = d.u_override ? d.u_override[slot] : rg_uniform(w.w[0], w.w[1]);
+            const double tau = u_org * S;
+            const float tauf = static_cast<float>(tau);
+            // ---- super-chunk: the prefixes <= tau (an unused entry is +inf) ----
+            uint32_t sc_star = 0;
+            float pbf = 0.0f;
+            {
+                const float4* sp = reinterpret_cast<const float4*>(d.walk_scp + row * kMaxSC);
+#pragma unroll
+                for (int i = 0; i < kMaxSC / 4; ++i) {
+                    const float4 x = sp[i];
+                    const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (xs[q] <= tauf) { sc_star += 1; pbf = fmaxf(pbf, xs[q]); }
+                }
+            }
+            bool found = sc_star < d.n_sc;
+            sc_star = min(sc_star, d.n_sc - 1);
+            // ---- chunk inside it ----
+            uint32_t c_star;
+            {
+                const uint32_t c0 = sc_star * d.sc_chunks, c1 = min(c0 + d.sc_chunks, d.n_chunks);
+                const float* cp = d.cache_chunk + row * d.n_chunks;
+                uint32_t cnt = 0;
+                for (uint32_t cb = c0; cb < c1; cb += 16) {
+                    float4 w4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        w4[i] = cb + 4 * i < c1 ? *reinterpret_cast<const float4*>(cp + cb + 4 * i) : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float xs[4] = {w4[i].x, w4[i].y, w4[i].z, w4[i].w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (xs[q] <= tauf) { cnt += 1; pbf = fmaxf(pbf, xs[q]); }
+                    }
+                }
+                found = found && cnt < c1 - c0;
+                c_star = min(c0 + cnt, c1 - 1);
+            }
+            const double pb = static_cast<double>(pbf);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            // ---- the 32 products of the chunk: eight searching users per pass, eight lanes per user, four products per lane ----
+            {
+                const int grp = lane >> 3, gl = lane & 7;
+                unsigned long long todo = __ballot(search);
+                while (todo) {
+                    int src = -1;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const int bit = todo ? __builtin_ctzll(todo) : -1;
+                        if (g == grp) src = bit;
+                        if (todo) todo &= todo - 1;
+                    }
+                    const bool has = src >= 0;
+                    const int s2 = has ? src : 0;
+                    const uint32_t cs = static_cast<uint32_t>(__shfl(static_cast<int>(c_star), s2));
+                    const float Qs = __shfl(Q, s2);
+                    const double pbs = __shfl(pb, s2), taus = __shfl(tau, s2);
+                    const float4* gp = reinterpret_cast<const float4*>(d.gamma32t + (static_cast<size_t>(cs) * K2) * 32) + gl;
+                    float4 l = *(reinterpret_cast<const float4*>(d.mu32 + cs * 32) + gl);
+#pragma unroll
+                    for (int kh = 0; kh < K2; kh += KH) {
+                        float4 gk[KH];
+#pragma unroll
+                        for (int k = 0; k < KH; ++k) gk[k] = gp[(kh + k) * 8];
+#pragma unroll
+                        for (int k = 0; k < KH; ++k) {
+                            const float wk = __shfl(om[kh + k], s2);
+                            l.x = fmaf(gk[k].x, wk, l.x); l.y = fmaf(gk[k].y, wk, l.y);
+                            l.z = fmaf(gk[k].z, wk, l.z); l.w = fmaf(gk[k].w, wk, l.w);
+                        }
+                        asm volatile("" : "+v"(l.x), "+v"(l.y), "+v"(l.z), "+v"(l.w));
+                    }
+                    const float e0 = __builtin_amdgcn_exp2f(fmaf(l.x, kLog2e, -Qs)), e1 = __builtin_amdgcn_exp2f(fmaf(l.y, kLog2e, -Qs));
+                    const float e2 = __builtin_amdgcn_exp2f(fmaf(l.z, kLog2e, -Qs)), e3 = __builtin_amdgcn_exp2f(fmaf(l.w, kLog2e, -Qs));
+                    const float q0 = e0, q1 = q0 + e1, q2 = q1 + e2, q3 = q2 + e3;
+                    float inc = q3;
+#pragma unroll
+                    for (int o2 = 1; o2 < 8; o2 <<= 1) {
+                        const float y = __shfl_up(inc, o2, 8);
+                        if (gl >= o2) inc += y;
+                    }
+                    float ex = __shfl_up(inc, 1, 8);
+                    if (gl == 0) ex = 0.0f;
+                    const double pxb = pbs + static_cast<double>(ex);
+                    const double px0 = pbs + static_cast<double>(ex + q0), px1 = pbs + static_cast<double>(ex + q1);
+                    const double px2 = pbs + static_cast<double>(ex + q2), px3 = pbs + static_cast<double>(ex + q3);
+                    const int j0 = px0 > taus ? 0 : px1 > taus ? 1 : px2 > taus ? 2 : px3 > taus ? 3 : -1;
+                    const unsigned long long hits = __ballot(has && j0 >= 0);
+                    const uint32_t gmask = static_cast<uint32_t>(hits >> (8 * grp)) & 0xFFu;
+                    if (has) {
+                        if (gmask) {
+                            if (gl == __builtin_ctz(gmask)) {
+                                mbox[src * 3] = static_cast<double>(4 * gl + j0);
+                                mbox[src * 3 + 1] = j0 == 0 ? pxb : j0 == 1 ? px0 : j0 == 2 ? px1 : px2;
+                                mbox[src * 3 + 2] = j0 == 0 ? px0 : j0 == 1 ? px1 : j0 == 2 ? px2 : px3;
+                            }
+                        } else if (gl == 0) { mbox[src * 3] = -1.0; mbox[src * 3 + 1] = pbs; mbox[src * 3 + 2] = pbs; }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            bool ok = false;
+            if (search) {
+                const int idx = static_cast<int>(mbox[lane * 3]);
+                const double Av = mbox[lane * 3 + 1], Bv = mbox[lane * 3 + 2];
+                v = c_star * 32 + static_cast<uint32_t>(max(idx, 0));
+                const bool lo_ok = v == 0 || Av * (1.0 + delta) < tau * (1.0 - delta);
+                const bool hi_ok = v == d.P - 1 || tau * (1.0 + delta) < Bv * (1.0 - delta);
+                ok = found && idx >= 0 && v < d.P && lo_ok && hi_ok;
+                if (ok && n_hot < static_cast<uint32_t>(kHotEntries) && !d.u_override) {
+                    // memoise the certified u-interval of v, rounded inwards (and a hair more for the float64 roundings of
+                    // the inequality above): u in (lo, hi) implies both conditions, whatever u
+                    float lo = -1.0f, hi = 2.0f;
+                    if (v != 0) {
+                        const double x = Av * (1.0 + delta) / ((1.0 - delta) * S) * (1.0 + 1e-14);
+                        lo = static_cast<float>(x);
+                        if (static_cast<double>(lo) < x) lo = f32_up(lo);
+                    }
+                    if (v != d.P - 1) {
+                        const double x = Bv * (1.0 - delta) / ((1.0 + delta) * S) * (1.0 - 1e-14);
+                        hi = static_cast<float>(x);
+                        if (static_cast<double>(hi) > x) hi = f32_down(hi);
+                    }
+                    float* hf = d.walk_hot + static_cast<size_t>(slot) * 32;
+                    hf[4 + 3 * n_hot] = __builtin_bit_cast(float, v);
+                    hf[5 + 3 * n_hot] = lo;
+                    hf[6 + 3 * n_hot] = hi;
+                    reinterpret_cast<uint32_t*>(hf)[3] = n_hot + 1u;
+                }
+            }
+            // ---- uncertified: float64 pick from the user's stored sums, or park the user until they exist ----
+            const bool need64 = is_s && !ok;
+            const bool have64 = need64 && d.f64_valid[slot] != 0;
+            parked = need64 && !have64;
+            unsigned long long picks = __ballot(have64);
+            c_pick += static_cast<uint32_t>(__popcll(picks));
+            while (picks) {
+                const int L = __builtin_ctzll(picks);
+                picks &= picks - 1;
+                const uint32_t s_slot = static_cast<uint32_t>(__shfl(static_cast<int>(slot), L));
+                const double s_u = __shfl(u_org, L);
+                const double M = static_cast<double>(d.exact_ref[s_slot]) * 0.69314718055994530942;
+                const uint32_t pv = exact_pick_wave(d, d.exact_sums + static_cast<size_t>(s_slot) * n_cc,
+                                                    d.omega + static_cast<size_t>(s_slot) * d.OMS, M, s_u, 1u, lane);
+                if (lane == L) v = pv;
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (parked) {
+                d.park_t[slot] = t | (static_cast<uint32_t>(RG_STATE_ORGANIC) << 24) | (1u << 27);
+                d.exact_ref[slot] = Q;
+            }
+            have_v = is_s && !parked;
+            if (have_v) pend = false;
+        }
+        // ---- park list entries for the users parked in this step ----
+        const unsigned long long pmask = __ballot(parked);
+        if (pmask) {
+            const uint32_t np = static_cast<uint32_t>(__popcll(pmask));
+            if (park_next + np > park_end) {
+                for (uint32_t r = park_next + lane; r < park_end; r += 64) d.park_list[out_base + r] = 0xFFFFFFFFu;
+                uint32_t base = 0;
+                if (lane == 0) base = static_cast<uint32_t>(atomicAdd(&d.counters[kCntParkCnt], 64ull));
+                base = __builtin_amdgcn_readfirstlane(base);
+                park_next = base; park_end = base + 64;
+            }
+            if (parked) { d.park_list[out_base + park_next + prefix_in_mask(pmask)] = slot; st = kEmpty; }
+            park_next += np;
+        }
+        // =========================== bandit event: the policy's act and the click ===========================
+        const bool is_ban = kind == 2 && st == RG_STATE_BANDIT, is_ph = kind == 2 && st == kPhantom;
+        double ps = 1.0;
+        uint32_t a = 0;
+        bool click = false, click_known = false;
+        double ctr = 0.0;
+        if (kind == 2) {
+            if (is_ban || is_ph) {
+                if (HIST) {
+                    // OrganicUserEventCounterModel.act (organic_user_count.py:45-96; exploit_explore, epsilon = 0,
+                    // select_randomly: the host instantiates HIST = 1 for this form only) on the history line in LDS: decided
+                    // by integer prefix counts outside a 2^-36 band (see policy_act), by the float64 cdf walk inside it
+                    const rg_u32x4 pw = rg_draw(d.policy_seed, user, t, 0, RG_DRAW_POLICY);
+                    const double u1 = rg_uniform(pw.w[2], pw.w[3]);
+                    const hent_t h0 = hl[0];
+                    const uint32_t nd = h_cnt(h0);
+                    const double sum = static_cast<double>(h_prod(h0));
+                    const hent_t* hr = hist_row(d, slot);
+                    const double T = u1 * sum;
+                    const uint32_t Thi = static_cast<uint32_t>(fmin(floor(T * (1.0 + 0x1p-36)), 4294967295.0));
+                    const uint32_t Tlo = static_cast<uint32_t>(fmin(ceil(T * (1.0 - 0x1p-36)), 4294967295.0));
+                    uint32_t C = 0, c_f = 0;
+                    bool found = false, amb = false;
+#pragma unroll
+                    for (int i = 1; i < 16; ++i)
+                        if (static_cast<uint32_t>(i) <= nd && !found) {
+                            const hent_t x = hl[i * 64];
+                            C += h_cnt(x);
+                            if (C > Thi) { found = true; a = h_prod(x); c_f = h_cnt(x); }
+                            else if (C >= Tlo) amb = true;
+                        }
+                    for (uint32_t base = 16; base <= nd && !found; base += kHistRegs) {      // longer histories: from the row
+                        hent_t f[kHistRegs];
+                        hist_load_line(hr + base, f);
+#pragma unroll
+                        for (int i = 0; i < kHistRegs; ++i)
+                            if (base + i <= nd && !found) {
+                                C += h_cnt(f[i]);
+                                if (C > Thi) { found = true; a = h_prod(f[i]); c_f = h_cnt(f[i]); }
+                                else if (C >= Tlo) amb = true;
+                            }
+                    }
+                    if (found && !amb) ps = static_cast<double>(c_f) / sum;
+                    else {
+                        // inside the band (~1e-10 of the acts): numpy's arithmetic — p_i = count_i / sum, cdf = cumsum(p) / last,
+                        // first index with cdf > u1 — over the viewed products (zero entries add exactly 0.0)
+                        double last = 0.0;
+                        for (uint32_t i = 1; i <= nd; ++i) last += static_cast<double>(h_cnt(i < 16 ? hl[i * 64] : hr[i])) / sum;
+                        double acc = 0.0, pa = 0.0;
+                        a = d.P - 1;
+                        bool fnd = false;
+                        for (uint32_t i = 1; i <= nd && !fnd; ++i) {
+                            const hent_t x = i < 16 ? hl[i * 64] : hr[i];
+                            const double p = static_cast<double>(h_cnt(x)) / sum;
+                            acc += p;
+                            if (!(acc / last <= u1)) { a = h_prod(x); pa = p; fnd = true; }
+                        }
+                        ps = pa;
+                    }
+                } else if (d.policy == RG_POLICY_LAST_VIEW_TABLE) {
+                    const uint32_t p = d.lpv[slot];
+                    ps = d.pol_ps ? static_cast<double>(d.pol_ps[p]) : 1.0;
+                    a = static_cast<uint32_t>(d.pol_table[p]);
+                } else {        // agent = None / RandomAgent: uniform over P from the env / the agent stream
+                    const rg_u32x4 pw = rg_draw(d.policy_seed, user, t, 0, RG_DRAW_POLICY);
+                    ps = 1.0 / static_cast<double>(d.P);
+                    a = rg_bounded(pw.w[0], pw.w[1], d.P);
+                }
+            }
+            if (is_ph) {       // final step_offline(done = True): the act above, reward 0 (abstract.py:223-233,311-316)
+                rg_event e;
+                e.u = user; e.t = t; e.code = RG_EV_BANDIT | RG_EV_PHANTOM | a;
+                e.ps = static_cast<float>(ps);
+                d.phantom[slot] = e;
+                d.phantom_ps[slot] = ps;
+                d.has_phantom[slot] = 1;
+                st = kEmpty;
+            }
+            c_ph += static_cast<uint32_t>(__popcll(__ballot(is_ph)));
+            if (is_ban && !d.aux_pclick) {
+                const int dec = click_decide32<KC>(d.beta32 + static_cast<size_t>(a) * d.KB4, [&](int k) { return om[k]; }, d.K, d.KB4,
+                                                   static_cast<float>(d.mu_b[a]), rg_uniform(w.w[0], w.w[1]));
+                if (dec >= 0) { click = dec != 0; click_known = true; }
+            }
+            if (is_ban && !click_known) {
+                const double* b = d.beta + static_cast<size_t>(a) * d.K;
+                const double* omd = d.omega + static_cast<size_t>(slot) * d.OMS;
+                double x = 0.0;
+                for (uint32_t k0 = 0; k0 < d.K; k0 += 8) {
+                    double wv[8], bv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const uint32_t k = min(k0 + i, d.K - 1);
+                        wv[i] = omd[k];
+                        bv[i] = b[k];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (k0 + i < d.K) x += bv[i] * wv[i];
+                }
+                ctr = ff64(x + d.mu_b[a]);
+                const double p0 = 1.0 - ctr;
+                click = (p0 / (p0 + ctr)) <= rg_uniform(w.w[0], w.w[1]);
+            }
+        }
+        // =========================== the event's row, the view, the transition ===========================
+        const bool ev = have_v || is_ban;
+        const unsigned long long rowm = __ballot(ev);
+        if (rowm) {
+            const uint32_t nrow = static_cast<uint32_t>(__popcll(rowm));
+            if (row_next + nrow > row_end) {
+                for (uint64_t r = row_next + lane; r < row_end; r += 64)
+                    if (d.log && r < d.log_cap) { rg_event e; e.u = 0; e.t = 0; e.code = kHoleCode; e.ps = 0.0f; d.log[r] = e; }
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&d.counters[kCntTailRows], static_cast<unsigned long long>(chunk_rows));
+                base = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32))) << 32) |
+                       __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
+                row_next = base; row_end = base + chunk_rows;
+            }
+            const uint64_t my_row = row_next + prefix_in_mask(rowm);
+            row_next += nrow;
+            if (ev && d.log && my_row < d.log_cap) {
+                rg_event e;
+                e.u = user; e.t = t;
+                e.code = have_v ? v : (RG_EV_BANDIT | (click ? RG_EV_CLICK : 0u) | a);
+                e.ps = have_v ? __builtin_nanf("") : static_cast<float>(ps);
+                d.log[my_row] = e;
+                if (is_ban && d.aux_ps) d.aux_ps[my_row] = ps;
+                if (is_ban && d.aux_pclick) d.aux_pclick[my_row] = ctr;
+            }
+            c_org += static_cast<uint32_t>(__popcll(__ballot(have_v)));
+            c_ban += static_cast<uint32_t>(__popcll(__ballot(is_ban)));
+            c_clicks += static_cast<uint32_t>(__popcll(__ballot(is_ban && click)));
+            if (have_v) {
+                if (d.lpv) d.lpv[slot] = v;
+                if (HIST) {
+                    // ViewsFeaturesProvider.observe (agents/abstract.py:347-358) on the line in LDS, written through to the row
+                    hent_t* hr = hist_row(d, slot);
+                    const hent_t h0 = hl[0];
+                    const uint32_t nd = h_cnt(h0);
+                    const hent_t key = static_cast<hent_t>(v) << 32;
+                    if (nd < 15u) {
+                        uint32_t pos = 1;
+                        bool hit = false;
+                        hent_t at = 0ull;
+#pragma unroll
+                        for (int i = 1; i < 16; ++i)
+                            if (static_cast<uint32_t>(i) <= nd) {
+                                const hent_t x = hl[i * 64];
+                                pos += x < key ? 1u : 0u;
+                                if (h_prod(x) == v) { hit = true; at = x; }
+                            }
+                        if (hit) {
+                            hl[pos * 64] = at + 1ull; hr[pos] = at + 1ull;
+                            hl[0] = h0 + (1ull << 32); hr[0] = h0 + (1ull << 32);
+                        } else if (nd + 1 >= d.hist_cap) atomicAdd(&d.counters[RG_CNT_HIST_OVERFLOW], 1ull);
+                        else {
+                            // entries [pos, nd] move up by one, highest first (nd + 1 <= 15: all inside the line)
+                            for (uint32_t i = nd; i >= pos; --i) { const hent_t x = hl[i * 64]; hl[(i + 1) * 64] = x; hr[i + 1] = x; }
+                            hl[pos * 64] = key | 1ull; hr[pos] = key | 1ull;
+                            hl[0] = h0 + (1ull << 32) + 1ull; hr[0] = h0 + (1ull << 32) + 1ull;
+                        }
+                    } else {
+                        // the line is full (or the history longer): the general insertion on the row, then the line again
+                        history_add(d, slot, v);
+                        const ulonglong2* hr2 = reinterpret_cast<const ulonglong2*>(hr);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const ulonglong2 x = hr2[i];
+                            hl[(2 * i) * 64] = x.x; hl[(2 * i + 1) * 64] = x.y;
+                        }
+                    }
+                }
+            }
+            if (ev) {
+                const double u_trans = rg_uniform(w.w[2], w.w[3]);
+                const double c0 = have_v ? d.cdf_o0 : d.cdf_b0, c1 = have_v ? d.cdf_o1 : d.cdf_b1;
+                int ns = (c0 <= u_trans) + (c1 <= u_trans);
+                if (click) ns = RG_STATE_ORGANIC;                  // abstract.py:180-181 (sigma_omega == 0: no drift to apply)
+                const bool organic_only = (d.first_user + slot) < d.organic_only_below;
+                bool limit = false;
+                if (organic_only && ns != RG_STATE_ORGANIC) {
+                    ns = RG_STATE_STOP;
+                    d.n_events[slot] = t + 1;
+                } else if (ns == RG_STATE_STOP) {
+                    d.n_events[slot] = t + 1;
+                    ns = kPhantom;                                 // the phantom row's act: this lane's next bandit iteration
+                } else if (t + 2 >= kMaxSteps) {
+                    ns = RG_STATE_STOP;
+                    d.n_events[slot] = t + 1;
+                    limit = true;
+                }
+                const unsigned long long endm = __ballot(ns == RG_STATE_STOP || ns == kPhantom);
+                (void)endm;
+                if (ns == RG_STATE_STOP || ns == kPhantom) {
+                    // (maximum over the wave taken once at the end: a per-lane maximum in one register)
+                    c_maxt = max(c_maxt, t + 1);
+                }
+                if (limit) c_limit += 1;
+                if (ns == RG_STATE_STOP) st = kEmpty;
+                else { st = ns; t += 1; }
+            }
+        }
+    }
+    // ---- leftovers of the reserved chunks, counters ----
+    {
+        const DevSim& d = *(const DevSim*)kargs;
+        for (uint64_t r = row_next + lane; r < row_end; r += 64)
+            if (d.log && r < d.log_cap) { rg_event e; e.u = 0; e.t = 0; e.code = kHoleCode; e.ps = 0.0f; d.log[r] = e; }
+        for (uint32_t r = park_next + lane; r < park_end; r += 64) d.park_list[out_base + r] = 0xFFFFFFFFu;
+        for (int o = 32; o > 0; o >>= 1) {
+            c_maxt = max(c_maxt, static_cast<uint32_t>(__shfl_xor(static_cast<int>(c_maxt), o)));
+            c_limit += static_cast<uint32_t>(__shfl_xor(static_cast<int>(c_limit), o));
+        }
+        if (lane == 0) {
+            if (c_org) atomicAdd(&d.counters[kCntTailOrganic], static_cast<unsigned long long>(c_org));
+            if (c_ban) atomicAdd(&d.counters[kCntTailBandit], static_cast<unsigned long long>(c_ban));
+            if (c_clicks) atomicAdd(&d.counters[RG_CNT_CLICKS], static_cast<unsigned long long>(c_clicks));
+            if (c_ph) atomicAdd(&d.counters[RG_CNT_PHANTOM], static_cast<unsigned long long>(c_ph));
+            if (c_pick) atomicAdd(&d.counters[RG_CNT_EXACT_DRAWS], static_cast<unsigned long long>(c_pick));
+            if (c_sweeps) atomicAdd(&d.counters[RG_CNT_EXACT_SWEEPS], static_cast<unsigned long long>(c_sweeps));
+            if (c_hit) atomicAdd(&d.counters[kCntWalkHits], static_cast<unsigned long long>(c_hit));
+            if (c_maxt) atomicMax(&d.counters[kCntTailMaxT], static_cast<unsigned long long>(c_maxt));
+            if (c_limit) atomicAdd(&d.counters[kCntTailLimit], static_cast<unsigned long long>(c_limit));
+        }
+    }
+}
+
+walk_kernel_t walk2_kernel_for(const DevSim& d, int occ) {
+    // the forms k_walk2 is instantiated for: K <= 32, no group sums, the policies without a view history or the
+    // OrganicUserEventCounter default (exploit_explore, epsilon = 0, select_randomly)
+    const bool ouc = d.policy == RG_POLICY_ORGANIC_USER_COUNT;
+    if (d.KH > 16 || d.cache_sub || !d.walk_hot) return nullptr;
+    if (ouc && !(d.ouc_exploit_explore && d.ouc_epsilon == 0.0 && d.ouc_select_randomly)) return nullptr;
+    if (d.policy != RG_POLICY_UNIFORM_ENV && d.policy != RG_POLICY_RANDOM_AGENT && d.policy != RG_POLICY_LAST_VIEW_TABLE && !ouc) return nullptr;
+#ifdef RG_W2_ONLY     // kernel work: one instantiation, seconds to compile (never a shipped build)
+    return k_walk2<10, 1, RG_W2_ONLY>;
+#else
+#define RG_W2(kh) (ouc ? (occ >= 4 ? k_walk2<kh, 1, 4> : k_walk2<kh, 1, 3>) : (occ >= 4 ? k_walk2<kh, 0, 4> : k_walk2<kh, 0, 3>))
+    switch (d.KH) {
+        case 4: return RG_W2(4);
+        case 10: return RG_W2(10);
+        default: return RG_W2(16);
+    }
+#undef RG_W2
+#endif
+}
+void (*cache_prefix_kernel())(DevSim) { return k_cache_prefix; }
+#endif
+
 // closes the books of a walked run: no lock-step step holds events; step 1 exists, is empty and starts after the raw rows
 #if RG_HAS(1)
 __global__ void k_walk_finish(DevSim d) {
@@ -4893,6 +5580,9 @@ __global__ void k_walk_finish(DevSim d) {
 #if RG_HAS(7)
 // blocks per CU the kernel is compiled for (register budget 512 / OCC per lane): KH <= 16 at 2, 3 or 4, KH = 32 at 1
 walk_kernel_t walk_kernel_for(const DevSim& d, int occ) {
+#ifdef RG_W2_ONLY
+    return nullptr;
+#else
     // the O(P) forms of the OrganicUserEventCounter policy are compiled in only where the configuration can reach them
     const bool dense = d.policy == RG_POLICY_ORGANIC_USER_COUNT && !(d.ouc_exploit_explore && d.ouc_epsilon == 0.0);
 #define RG_W(kh, o) (dense ? k_walk<kh, o, true> : k_walk<kh, o, false>)
@@ -4903,6 +5593,7 @@ walk_kernel_t walk_kernel_for(const DevSim& d, int occ) {
         default: return RG_W(32, 1);
     }
 #undef RG_W
+#endif
 }
 #endif
 
@@ -4968,9 +5659,8 @@ __global__ void __launch_bounds__(kBlock) k_debug_click(DevSim d, const int32_t*
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) {
         const uint32_t a = static_cast<uint32_t>(actions[i]);
         const double* om = d.omega + static_cast<size_t>(i) * d.OMS;
-        float om32[64];
-        for (uint32_t k = 0; k < d.K && k < 64; ++k) om32[k] = static_cast<float>(om[k]);
-        const int dec = click_decide32<1>(d.beta32 + static_cast<size_t>(a) * d.KB4, om32, d.K, d.KB4, static_cast<float>(d.mu_b[a]), u[i]);
+        const int dec = click_decide32<64>(d.beta32 + static_cast<size_t>(a) * d.KB4, [&](int k) { return static_cast<float>(om[k]); },
+                                           d.K, d.KB4, static_cast<float>(d.mu_b[a]), u[i]);
         const double* b = d.beta + static_cast<size_t>(a) * d.K;
         double x = 0.0;
         for (uint32_t k = 0; k < d.K; ++k) x += b[k] * om[k];
@@ -5432,9 +6122,13 @@ int run_walk(rg_sim* sim, hipStream_t st) {
     }
     if (int rc = mark(1)) return rc;
     hipLaunchKernelGGL(finalize_kernel_for(d), dim3(grid_for(d.n_users)), dim3(kBlock), 0, st, d);
+    if (sim->walk2)      // the sums in prefix form, the memo rows emptied
+        hipLaunchKernelGGL(cache_prefix_kernel(), dim3(grid_for((static_cast<uint64_t>(d.n_users) + 7) / 8, kBlock / 64)), dim3(kBlock), 0, st, d);
     if (int rc = mark(2)) return rc;
     // 2. round 1: every user from t = 0 to its end or to its first uncertified draw
-    const size_t smem = (kBlock / 64) * walk_wave_lds(d.KH);
+    const size_t smem = sim->walk2 ? (kBlock / 64) * walk2_wave_lds(d.policy == RG_POLICY_ORGANIC_USER_COUNT)
+                                   : (kBlock / 64) * walk_wave_lds(d.KH);
+    const walk_kernel_t wk = sim->walk2 ? walk2_kernel_for(d, sim->walk_occ) : walk_kernel_for(d, d.KH <= 16 ? sim->walk_occ : 1);
     auto launch_walk = [&](uint32_t n_work, int round, uint32_t in_base, uint32_t out_base) {
         const int occ = d.KH <= 16 ? sim->walk_occ : 1;
         const int blocks_cap = sim->n_cus * occ;
@@ -5448,10 +6142,8 @@ int run_walk(rg_sim* sim, hipStream_t st) {
         if (chunk < 256) chunk = 256;
         if (chunk > 4096) chunk = 4096;
         if (smem > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(walk_kernel_for(d, occ)), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      static_cast<int>(smem));
-        hipLaunchKernelGGL(walk_kernel_for(d, occ), dim3(blocks), dim3(kBlock), smem, st, d, n_work, round, static_cast<uint32_t>(chunk),
-                           in_base, out_base);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
+        hipLaunchKernelGGL(wk, dim3(blocks), dim3(kBlock), smem, st, d, n_work, round, static_cast<uint32_t>(chunk), in_base, out_base);
     };
     launch_walk(d.n_users, 1, 0u, 0u);
     if (int rc = mark(3)) return rc;
@@ -5662,7 +6354,13 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     if (const char* e = getenv("RECOGYM_WALK_HANDOVER")) d.walk_handover = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_REFILL")) d.walk_refill = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_BIAS")) d.walk_bias = static_cast<uint32_t>(atoi(e));
+    // k_walk2 where it is instantiated for the configuration (RECOGYM_WALK=1: k_walk), four blocks per CU at K <= 20
+    s->walk2 = s->walk && walk2_kernel_for(d, 4) != nullptr;
+    if (const char* e = getenv("RECOGYM_WALK")) if (e[0] == '1') s->walk2 = false;
+    if (s->walk2) { s->walk_occ = d.KH <= 10 ? 4 : 3; d.walk_bias = 8; }
+    if (const char* e = getenv("RECOGYM_WALK_BIAS")) d.walk_bias = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_OCC")) { const int o = atoi(e); if (o >= 2 && o <= 4) s->walk_occ = o; }
+    if (s->walk2 && s->walk_occ < 3) s->walk_occ = 3;
     s->prof_walk_ms[0] = s->prof_walk_ms[1] = 0.0;
     if (const char* e = getenv("RECOGYM_TAIL")) s->tail_below = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_REPACK")) s->repack_every = static_cast<uint32_t>(atoi(e));

@@ -222,7 +222,7 @@ class Simulator:
                        'rg_sim_read_counters')
         names = ['organic', 'bandit', 'clicks', 'phantom', 'live', 'step', 'log_rows',
                  'log_dropped', 'exact_draws', 'hist_overflow', 'exact_sweeps', 'exact_overflow', 'lr_acts', 'lr_rows',
-                 'lr_exact']
+                 'lr_exact', 'memo_hits']
         return {k: int(out[i]) for i, k in enumerate(names)}
 
     def set_profiling(self, on=True):
