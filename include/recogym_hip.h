@@ -180,6 +180,14 @@ int rg_sim_set_logreg(rg_sim* sim, const double* d_coef_t, const double* d_inter
  * arrays, so the logged action is sklearn's predict() bit for bit either way.  All NULL / 0 = float64 only. */
 int rg_sim_set_logreg_fp32(rg_sim* sim, const float* d_coef32_t, const float* d_intercept32, const float* d_wmax, float bmax);
 
+/* Optional screening pass on top of rg_sim_set_logreg_fp32 (its intercept32 / wmax / bmax are used): d_coef16_t = coef^T
+ * [num_products][n_classes] rounded to nearest IEEE half (every |value| <= 65504; n_classes % 8 == 0).  An act then takes
+ * all class scores from the half table (half the bytes of the fp32 one: at 10^4 classes the act is bound by streaming the
+ * rows of the viewed products), keeps the classes whose score is within twice the rounding bound
+ * sum_p views_p (2^-11 wmax[p] + 2^-25) + (views + 3) 2^-24 (bmax + sum_p views_p wmax[p]) of the best one, and decides among
+ * them by float64 scores in scipy's order (rg_sim_set_logreg's arrays): sklearn's predict() bit for bit.  NULL = off. */
+int rg_sim_set_logreg_fp16(rg_sim* sim, const uint16_t* d_coef16_t);
+
 /* Where rows go.  d_log == NULL (or capacity 0) disables logging: only counters are kept. */
 int rg_sim_set_log(rg_sim* sim, rg_event* d_log, uint64_t capacity);
 

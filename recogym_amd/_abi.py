@@ -75,6 +75,7 @@ SYMBOLS = {
     'rg_sim_set_policy_table': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_set_logreg': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     'rg_sim_set_logreg_fp32': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]),
+    'rg_sim_set_logreg_fp16': (C.c_int, [_SIM, C.c_void_p]),
     'rg_sim_set_log': (C.c_int, [_SIM, C.c_void_p, C.c_uint64]),
     'rg_sim_reset_users': (C.c_int, [_SIM, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     'rg_sim_reseed': (C.c_int, [_SIM, C.c_uint64, C.c_uint64]),

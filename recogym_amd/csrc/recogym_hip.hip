@@ -198,6 +198,7 @@ struct DevSim {
     // the policy's act depends on the view history only: it is computed when the history has changed since the last act
     // (lr_dirty, set by history_add) and kept per user; k_logreg_select / k_logreg_acts run before k_advance
     const float* lr_coef32_t; const float* lr_intercept32; const float* lr_wmax; float lr_bmax;   // fp32 copies + max_c |coef[p][c]|, max |b|
+    const unsigned short* lr_coef16_t;   // fp16 copy of coef^T (screening pass of k_logreg_acts16), or null
     uint32_t* lr_action;      // [n_cap] by user index: action of the user's current history
     uint8_t* lr_dirty;        // [n_cap] by user index
     uint32_t* lr_list;        // [n_cap] slots whose act is to be computed this step
@@ -280,6 +281,7 @@ draw_kernel_t bf16p_kernel_for(const DevSim& d);
 draw_kernel_t f16w_kernel_for(const DevSim& d);            // part 5
 search_kernel_t logreg_select_kernel();                    // part 6
 search_kernel_t logreg_acts_kernel();
+search_kernel_t logreg_acts16_kernel();
 advance_kernel_t advance_kernel();
 search_kernel_t tail_kernel();
 walk_kernel_t walk_kernel_for(const DevSim& d, int occ);   // part 7
@@ -3870,6 +3872,143 @@ __global__ void __launch_bounds__(kBlock) k_logreg_acts(DevSim d, uint32_t t) {
 #endif
 
 // ------------------------------------------------------------------------------------------
+// k_logreg_acts16 — the frozen LogReg act by SCREEN AND REFINE (BASELINE config 5: 10^4 classes, where an act streams the
+// coef^T rows of the user's viewed products: 40 KB per row in fp32, a 400 MB table that no cache holds).
+//   screen   every class score in fp32 from an fp16 copy of coef^T (20 KB per row; the 200 MB table fits the Infinity
+//            Cache): |s~_c - s_c| <= B for every class, B = sum_p views_p (2^-11 wmax_p + 2^-25)   (fp16 rounding, subnormals)
+//                                                      + (nd + 3) 2^-24 (max|b| + sum_p views_p wmax_p)   (fp32 accumulation).
+//            The argmax of the true scores is then among the CANDIDATES {c : s~_c >= max s~ - 2B}; they are collected while
+//            the classes stream by (against the running maximum: a superset), 64 at most;
+//   refine   more than one candidate (near-ties, exact ties): their scores in float64 in scipy's csr_matvecs order
+//            (products ascending, multiply then add, intercept last), a lane per candidate — nd scattered 8-byte reads
+//            each instead of a second pass over whole rows; first maximum wins, like numpy's argmax.
+// sklearn's predict() bit for bit, as before; more than 64 candidates (degenerate models): the float64 walk over all classes.
+// Needs n_classes % 8 == 0 (16-byte loads of 8 halves); the host keeps the fp32 kernel otherwise.
+// ------------------------------------------------------------------------------------------
+#if RG_HAS(6)
+__global__ void __launch_bounds__(kBlock) k_logreg_acts16(DevSim d, uint32_t t) {
+    __shared__ uint32_t s_cand[kBlock / 64][64];
+    __shared__ float s_cval[kBlock / 64][64];
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t n = d.lr_cnt[t];
+    const uint32_t C = d.lr_n;
+    const uint32_t waves_total = gridDim.x * (kBlock / 64);
+    unsigned long long c_acts = 0, c_rows = 0, c_exact = 0;
+    for (uint32_t w = blockIdx.x * (kBlock / 64) + wave; w < n; w += waves_total) {
+        const uint32_t slot = d.lr_list[w];
+        const uint32_t uidx = d.uid[slot];
+        const hent_t* hr = hist_row(d, slot) + 1;
+        const uint32_t nd = h_cnt(hr[-1]);
+        c_acts += 1; c_rows += nd;
+        // ---- the error bound of this history ----
+        float A = 0.0f, V = 0.0f;
+        for (uint32_t i = lane; i < nd; i += 64) {
+            const hent_t x = hr[i];
+            const float cnt = static_cast<float>(h_cnt(x));
+            A = fmaf(cnt, d.lr_wmax[h_prod(x)], A);
+            V += cnt;
+        }
+        for (int o = 32; o > 0; o >>= 1) { A += __shfl_xor(A, o); V += __shfl_xor(V, o); }
+        const float B = (A * 4.8828125e-4f + V * 2.98023224e-8f + static_cast<float>(nd + 3) * 5.9604644775390625e-08f * (d.lr_bmax + A)) * 1.02f;
+        const float thr = 2.0f * B * 1.01f + 1e-30f;
+        // ---- screen ----
+        float rb = -INFINITY;
+        uint32_t n_cand = 0;
+        bool overflow = false;
+        for (uint32_t c0 = 0; c0 < C; c0 += 512) {
+            const uint32_t c = c0 + 8u * static_cast<uint32_t>(lane);
+            const bool in = c < C;                                   // (C % 8 == 0: a lane's 8 classes are all in or all out)
+            const uint32_t cl = in ? c : 0u;
+            float acc[8];
+            {
+                const float4 b0 = *reinterpret_cast<const float4*>(d.lr_intercept32 + cl);
+                const float4 b1 = *reinterpret_cast<const float4*>(d.lr_intercept32 + cl + 4);
+                acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+            }
+            for (uint32_t i0 = 0; i0 < nd; i0 += 4) {
+                half8 hv[4];
+                float cn[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const hent_t x = hr[min(i0 + e, nd - 1)];
+                    cn[e] = i0 + e < nd ? static_cast<float>(h_cnt(x)) : 0.0f;
+                    hv[e] = *reinterpret_cast<const half8*>(d.lr_coef16_t + static_cast<size_t>(h_prod(x)) * C + cl);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (i0 + e < nd) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] = fmaf(cn[e], static_cast<float>(hv[e][j]), acc[j]);
+                    }
+            }
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = fmaxf(m, acc[j]);
+            if (!in) m = -INFINITY;
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            rb = fmaxf(rb, m);
+            const float cut = rb - thr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool pass = in && acc[j] >= cut;
+                const unsigned long long pm = __ballot(pass);
+                if (pm) {
+                    const uint32_t np = static_cast<uint32_t>(__popcll(pm));
+                    if (n_cand + np > 64u) overflow = true;
+                    else if (pass) {
+                        const uint32_t k = n_cand + prefix_in_mask(pm);
+                        s_cand[wave][k] = c + j; s_cval[wave][k] = acc[j];
+                    }
+                    if (!overflow) n_cand += np;
+                }
+            }
+            if (overflow) break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t action;
+        if (overflow) { action = logreg_act_wave(d, slot, lane); c_exact += 1; }
+        else {
+            // ---- the candidates that survive the final maximum; one: certified; more: float64, scipy's order ----
+            const bool mine = static_cast<uint32_t>(lane) < n_cand;
+            const uint32_t cc = mine ? s_cand[wave][lane] : 0u;
+            const bool keep = mine && s_cval[wave][lane] >= rb - thr;
+            const unsigned long long km = __ballot(keep);
+            uint32_t best_c = 0xFFFFFFFFu;
+            if (__popcll(km) == 1) best_c = static_cast<uint32_t>(__shfl(static_cast<int>(cc), __builtin_ctzll(km)));
+            else {
+                double sc = -INFINITY;
+                if (keep) {
+                    sc = 0.0;
+                    for (uint32_t i = 0; i < nd; ++i) {
+                        const hent_t x = hr[i];
+                        sc = __dadd_rn(sc, __dmul_rn(static_cast<double>(h_cnt(x)), d.lr_coef_t[static_cast<size_t>(h_prod(x)) * C + cc]));
+                    }
+                    sc = __dadd_rn(sc, d.lr_intercept[cc]);
+                    best_c = cc;
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double os = __shfl_xor(sc, o);
+                    const uint32_t oc = __shfl_xor(best_c, o);
+                    if (oc != 0xFFFFFFFFu && (best_c == 0xFFFFFFFFu || os > sc || (os == sc && oc < best_c))) { sc = os; best_c = oc; }
+                }
+                c_exact += 1;
+            }
+            action = static_cast<uint32_t>(d.lr_classes[best_c]);
+        }
+        if (lane == 0) { d.lr_action[uidx] = action; d.lr_dirty[uidx] = 0; }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0 && c_acts) {
+        atomicAdd(&d.counters[RG_CNT_LR_ACTS], c_acts);
+        atomicAdd(&d.counters[RG_CNT_LR_ROWS], c_rows);
+        if (c_exact) atomicAdd(&d.counters[RG_CNT_LR_EXACT], c_exact);
+    }
+}
+#endif
+
+// ------------------------------------------------------------------------------------------
 // k_advance — one Markov transition for every live user (lane per user).
 // ------------------------------------------------------------------------------------------
 constexpr int kAdvBlock = 256;
@@ -4270,6 +4409,7 @@ __global__ void __launch_bounds__(kBlock) k_tail(DevSim d, uint32_t t0) {
 }
 search_kernel_t logreg_select_kernel() { return k_logreg_select; }
 search_kernel_t logreg_acts_kernel() { return k_logreg_acts; }
+search_kernel_t logreg_acts16_kernel() { return k_logreg_acts16; }
 advance_kernel_t advance_kernel() { return k_advance; }
 search_kernel_t tail_kernel() { return k_tail; }
 #endif
@@ -6068,7 +6208,8 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     if (d.policy == RG_POLICY_LOGREG_FROZEN) {
         // acts of the users whose view history changed since their last one (frozen LogReg at scale)
         hipLaunchKernelGGL(logreg_select_kernel(), dim3(grid_for(upper)), dim3(kBlock), 0, st, d, t);
-        hipLaunchKernelGGL(logreg_acts_kernel(), dim3(grid_for(static_cast<uint64_t>(upper) / 4 + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
+        hipLaunchKernelGGL(d.lr_coef16_t ? logreg_acts16_kernel() : logreg_acts_kernel(),
+                           dim3(grid_for(static_cast<uint64_t>(upper) / 4 + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
     }
     if (int rc = prof_mark(sim, st)) return rc;
     // 2. click draws, transitions, drift, next lists, bandit + phantom rows
@@ -6444,6 +6585,15 @@ int rg_sim_set_logreg_fp32(rg_sim* sim, const float* d_coef32_t, const float* d_
     if ((d_coef32_t || d_intercept32 || d_wmax) && !(d_coef32_t && d_intercept32 && d_wmax)) return fail(RG_EINVAL, "all three arrays or none");
     if (!(bmax >= 0.0f)) return fail(RG_EINVAL, "bmax must be >= 0");
     sim->d.lr_coef32_t = d_coef32_t; sim->d.lr_intercept32 = d_intercept32; sim->d.lr_wmax = d_wmax; sim->d.lr_bmax = bmax;
+    return RG_OK;
+}
+
+int rg_sim_set_logreg_fp16(rg_sim* sim, const uint16_t* d_coef16_t) {
+    if (!sim) return fail(RG_EINVAL, "sim is NULL");
+    if (sim->d.policy != RG_POLICY_LOGREG_FROZEN) return fail(RG_ESTATE, "policy is not RG_POLICY_LOGREG_FROZEN");
+    if (d_coef16_t && !sim->d.lr_coef32_t) return fail(RG_ESTATE, "rg_sim_set_logreg_fp32 must be called first (intercept32, wmax, bmax)");
+    if (d_coef16_t && sim->d.lr_n % 8u) return fail(RG_EINVAL, "the fp16 screening pass needs n_classes %% 8 == 0 (have %u)", sim->d.lr_n);
+    sim->d.lr_coef16_t = d_coef16_t;
     return RG_OK;
 }
 

@@ -133,6 +133,13 @@ class Simulator:
                     self.logreg32 = (w32.contiguous(), b32.contiguous(), wmax.contiguous())
                     _abi.check(self.lib.rg_sim_set_logreg_fp32(self._h, self.logreg32[0].data_ptr(), self.logreg32[1].data_ptr(),
                                                                self.logreg32[2].data_ptr(), C.c_float(bmax)), 'rg_sim_set_logreg_fp32')
+                    # screening pass from a half copy of coef^T (half the row bytes; float64 decides among the candidates):
+                    # RECOGYM_LOGREG=fp32 keeps the fp32 scores only (A/B)
+                    n_cls = int(self.logreg[2].numel())
+                    if (logreg.get('fp16', True) and n_cls % 8 == 0 and os.environ.get('RECOGYM_LOGREG', 'fp16') != 'fp32'
+                            and float(self.logreg[0].abs().max().item()) < 6.0e4):
+                        self.logreg16 = self.logreg[0].to(torch.float16).contiguous()
+                        _abi.check(self.lib.rg_sim_set_logreg_fp16(self._h, self.logreg16.data_ptr()), 'rg_sim_set_logreg_fp16')
             if log_capacity is None:
                 log_capacity = default_log_capacity(config, self.n_users)
             self.log = None

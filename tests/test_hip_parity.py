@@ -507,6 +507,37 @@ def test_frozen_logreg_with_more_than_256_classes_matches_the_oracle():
     assert (used >= classes[256]).any() and (used >= classes[512]).any()     # later class blocks do win
 
 
+@pytest.mark.parametrize('screen', ['fp16', 'fp32'])
+def test_frozen_logreg_at_config_5_scale_matches_the_oracle(screen, monkeypatch):
+    """BASELINE config 5's policy shape: one class per product, 4 096 products.  The act screens every class score from
+    the half copy of coef^T (RECOGYM_LOGREG=fp32: from the fp32 copy), keeps the classes within twice the rounding
+    bound of the best and lets float64 scores in scipy's order decide among them.  Small coefficients (N(0, 0.1)) make
+    near-ties common; classes duplicated exactly (first maximum wins) and almost exactly (1e-9 apart: far inside the
+    fp16 bound, decided by float64) must come out as the oracle's argmax."""
+    from oracle import oracle as orc
+    monkeypatch.setenv('RECOGYM_LOGREG', screen)
+    P = C = 4096
+    rng = np.random.RandomState(5)
+    coef_t = rng.standard_normal((P, C)) * 0.1
+    intercept = rng.standard_normal(C) * 0.1
+    for a, b in ((10, 3000), (511, 512), (77, 4095)):           # exact duplicates: the smaller class index wins
+        coef_t[:, b] = coef_t[:, a]; intercept[b] = intercept[a]
+    for a, b in ((20, 2000), (1023, 1024)):                     # near duplicates, the LATER class a hair better
+        coef_t[:, b] = coef_t[:, a]; intercept[b] = intercept[a] + 1e-9
+    intercept[[10, 3000, 511, 512, 77, 4095, 20, 2000, 1023, 1024]] += 0.6      # ... and often the best
+    pol = dict(policy=_abi.RG_POLICY_LOGREG_FROZEN, policy_seed=0,
+               logreg=dict(coef_t=coef_t, intercept=intercept, classes=np.arange(C, dtype=np.int32)))
+    cfg = Configuration({**env_1_args, 'random_seed': 55, 'num_products': P, 'K': 10})
+    want_env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol)
+    want = want_env.generate_logs(120)
+    rows, cnt = run_sim(cfg, 120, **pol)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps', 'p_click')},
+                         ps_rtol=1e-12, what=f'logreg 4096 classes, {screen} screen')
+    used = set(np.unique(rows['a'][rows['z'] == 1]).tolist())
+    assert used & {10, 511, 77} and used & {2000, 1024} and not used & {3000, 512, 4095}
+    assert cnt['lr_acts'] > 300 and cnt['lr_exact'] > 0 and cnt['lr_rows'] >= cnt['lr_acts']
+
+
 @pytest.mark.parametrize('mode', ['f16', 'bf16', 'fp32'])
 @pytest.mark.parametrize('shape', [(10000, 20), (3000, 20), (1500, 40)])
 def test_certificate_is_sound_for_uniforms_next_to_cdf_boundaries(mode, shape, monkeypatch):
