@@ -5058,7 +5058,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
 // ------------------------------------------------------------------------------------------
 constexpr int kHotEntries = 9;          // memo entries of a user: floats [4 + 3 j, 7 + 3 j) of its hot row = {product, u_lo, u_hi}
 constexpr int kWSlow = 6;               // lane state: organic draw that missed the memo (RG_STATE_* = 0..2, empty 3, phantom 4)
-__host__ __device__ inline size_t walk2_wave_lds(int hist) { return (hist ? 16 * 64 * 8 : 0) + 64 * 24; }
+__host__ __device__ inline size_t walk2_wave_lds(int hist) { return (hist ? 16 * 64 * 8 : 0) + 64 * 12; }
 #if RG_HAS(7)
 
 // The prefix form.  Eight lanes per user, 32 chunks per pass (one 128-byte line of the user's chunk sums): scaled to the
@@ -5126,7 +5126,16 @@ __device__ __forceinline__ float f32_down(float x) {
     return x == 0.0f ? __builtin_bit_cast(float, 0x80000001u) : __builtin_bit_cast(float, x > 0.0f ? b - 1u : b + 1u);
 }
 
-template <int KH, int HIST, int OCC>
+// OMREG: omega32 of the lane's user stays in registers for its whole stay (2 KH VGPRs; the chunk recompute fetches the
+// searching users' by ds_bpermute); else it is read from the user's cache row where needed (five 16-byte loads issued
+// at the top of a bandit / search iteration, off the critical chain): fewer registers, more waves.
+// the float64 pick as a CALL: k_walk2 reaches it for ~3 % of the organic draws, inlined it cost the whole loop its registers
+__device__ __attribute__((noinline)) uint32_t exact_pick_call(const DevSim& d, const double* sums, const double* om, double M,
+                                                             double u, int lane) {
+    return exact_pick_wave(d, sums, om, M, u, 1u, lane);
+}
+
+template <int KH, int HIST, int OCC, bool OMREG = (OCC < 4)>
 __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_work, int round, uint32_t chunk_rows,
                                                         uint32_t in_base, uint32_t out_base) {
     (void)d_arg;       // read from the kernel-argument segment at the point of use (see k_walk)
@@ -5139,13 +5148,26 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
     const int wave = threadIdx.x >> 6, lane = lane_id();
     char* wbase = smem_raw + static_cast<size_t>(wave) * walk2_wave_lds(HIST);
     hent_t* hl = reinterpret_cast<hent_t*>(wbase) + lane;               // HIST: [16][64] entry-major: hl[i * 64]
-    double* mbox = reinterpret_cast<double*>(wbase + (HIST ? 16 * 64 * 8 : 0));   // [64][3]
+    float* mboxf = reinterpret_cast<float*>(wbase + (HIST ? 16 * 64 * 8 : 0));   // [64][3]: the search's result per lane
     uint32_t slot = 0, t = 0;
     int st = kEmpty;
     bool pend = false;                                                 // rounds >= 2: the parked draw, to be picked in float64
-    float om[KC];                                                      // omega32 of the lane's user
+    float om[OMREG ? KC : 1];                                          // omega32 of the lane's user
 #pragma unroll
-    for (int k = 0; k < KC; ++k) om[k] = 0.0f;
+    for (int k = 0; k < (OMREG ? KC : 1); ++k) om[k] = 0.0f;
+    // omega32 of user `s2` from its cache row (floats 44 ..), as k_cache_finalize left it
+    auto load_omega = [&](const DevSim& d, uint32_t s2, float (&o)[KC]) {
+        const float4* rp = reinterpret_cast<const float4*>(d.cache_row + static_cast<size_t>(s2) * d.cache_row_f);
+#pragma unroll
+        for (int k4 = 0; k4 < K2 / 4; ++k4) {
+            const float4 x = rp[11 + k4];
+            o[4 * k4] = x.x; o[4 * k4 + 1] = x.y; o[4 * k4 + 2] = x.z; o[4 * k4 + 3] = x.w;
+        }
+#pragma unroll
+        for (int k = (K2 / 4) * 4; k < K2; ++k) o[k] = reinterpret_cast<const float*>(rp)[44 + k];
+#pragma unroll
+        for (int k = K2; k < KC; ++k) o[k] = 0.0f;
+    };
     uint32_t res_next = 0, res_end = 0;
     uint64_t row_next = 0, row_end = 0;
     uint32_t park_next = 0, park_end = 0;
@@ -5185,14 +5207,12 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
                                 if (round == 2) d.f64_valid[s2] = 1;         // the batch between the rounds took its sums
                                 if (pend) st = kWSlow;                       // its draw goes straight to the float64 pick
                             }
-                            const float4* rp = reinterpret_cast<const float4*>(d.cache_row + static_cast<size_t>(s2) * d.cache_row_f);
+                            if constexpr (OMREG) {
+                                float o[KC];
+                                load_omega(d, s2, o);
 #pragma unroll
-                            for (int k4 = 0; k4 < K2 / 4; ++k4) {
-                                const float4 x = rp[11 + k4];
-                                om[4 * k4] = x.x; om[4 * k4 + 1] = x.y; om[4 * k4 + 2] = x.z; om[4 * k4 + 3] = x.w;
+                                for (int k = 0; k < KC; ++k) om[k] = o[k];
                             }
-#pragma unroll
-                            for (int k = (K2 / 4) * 4; k < K2; ++k) om[k] = reinterpret_cast<const float*>(rp)[44 + k];
                             if (HIST) {
                                 const ulonglong2* hr2 = reinterpret_cast<const ulonglong2*>(hist_row(d, s2));
 #pragma unroll
@@ -5327,6 +5347,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
                 c_star = min(c0 + cnt, c1 - 1);
             }
             const double pb = static_cast<double>(pbf);
+            const float rem = static_cast<float>(tau - pb);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             // ---- the 32 products of the chunk: eight searching users per pass, eight lanes per user, four products per lane ----
@@ -5345,17 +5366,21 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
                     const int s2 = has ? src : 0;
                     const uint32_t cs = static_cast<uint32_t>(__shfl(static_cast<int>(c_star), s2));
                     const float Qs = __shfl(Q, s2);
-                    const double pbs = __shfl(pb, s2), taus = __shfl(tau, s2);
+                    const float rems = __shfl(rem, s2);                  // what is left of u S~ at the chunk's start
                     const float4* gp = reinterpret_cast<const float4*>(d.gamma32t + (static_cast<size_t>(cs) * K2) * 32) + gl;
                     float4 l = *(reinterpret_cast<const float4*>(d.mu32 + cs * 32) + gl);
+                    float osrc[KC];
+                    if constexpr (!OMREG) load_omega(d, static_cast<uint32_t>(__shfl(static_cast<int>(slot), s2)), osrc);
+                    constexpr int GB = (OCC >= 4 && KH % 2 == 0) ? KH / 2 : KH;      // Gamma rows in flight per batch (registers)
 #pragma unroll
-                    for (int kh = 0; kh < K2; kh += KH) {
-                        float4 gk[KH];
+                    for (int kh = 0; kh < K2; kh += GB) {
+                        float4 gk[GB];
 #pragma unroll
-                        for (int k = 0; k < KH; ++k) gk[k] = gp[(kh + k) * 8];
+                        for (int k = 0; k < GB; ++k) gk[k] = gp[(kh + k) * 8];
 #pragma unroll
-                        for (int k = 0; k < KH; ++k) {
-                            const float wk = __shfl(om[kh + k], s2);
+                        for (int k = 0; k < GB; ++k) {
+                            float wk;
+                            if constexpr (OMREG) wk = __shfl(om[kh + k], s2); else wk = osrc[kh + k];
                             l.x = fmaf(gk[k].x, wk, l.x); l.y = fmaf(gk[k].y, wk, l.y);
                             l.z = fmaf(gk[k].z, wk, l.z); l.w = fmaf(gk[k].w, wk, l.w);
                         }
@@ -5372,20 +5397,20 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
                     }
                     float ex = __shfl_up(inc, 1, 8);
                     if (gl == 0) ex = 0.0f;
-                    const double pxb = pbs + static_cast<double>(ex);
-                    const double px0 = pbs + static_cast<double>(ex + q0), px1 = pbs + static_cast<double>(ex + q1);
-                    const double px2 = pbs + static_cast<double>(ex + q2), px3 = pbs + static_cast<double>(ex + q3);
-                    const int j0 = px0 > taus ? 0 : px1 > taus ? 1 : px2 > taus ? 2 : px3 > taus ? 3 : -1;
+                    // the product in fp32 (which product is only a proposal: the certificate below is taken in float64 from
+                    // the two prefixes around it and rejects a wrong one)
+                    const float x0 = ex + q0, x1 = ex + q1, x2 = ex + q2, x3 = ex + q3;
+                    const int j0 = x0 > rems ? 0 : x1 > rems ? 1 : x2 > rems ? 2 : x3 > rems ? 3 : -1;
                     const unsigned long long hits = __ballot(has && j0 >= 0);
                     const uint32_t gmask = static_cast<uint32_t>(hits >> (8 * grp)) & 0xFFu;
                     if (has) {
                         if (gmask) {
                             if (gl == __builtin_ctz(gmask)) {
-                                mbox[src * 3] = static_cast<double>(4 * gl + j0);
-                                mbox[src * 3 + 1] = j0 == 0 ? pxb : j0 == 1 ? px0 : j0 == 2 ? px1 : px2;
-                                mbox[src * 3 + 2] = j0 == 0 ? px0 : j0 == 1 ? px1 : j0 == 2 ? px2 : px3;
+                                mboxf[src * 3] = static_cast<float>(4 * gl + j0);
+                                mboxf[src * 3 + 1] = j0 == 0 ? ex : j0 == 1 ? x0 : j0 == 2 ? x1 : x2;
+                                mboxf[src * 3 + 2] = j0 == 0 ? x0 : j0 == 1 ? x1 : j0 == 2 ? x2 : x3;
                             }
-                        } else if (gl == 0) { mbox[src * 3] = -1.0; mbox[src * 3 + 1] = pbs; mbox[src * 3 + 2] = pbs; }
+                        } else if (gl == 0) { mboxf[src * 3] = -1.0f; mboxf[src * 3 + 1] = 0.0f; mboxf[src * 3 + 2] = 0.0f; }
                     }
                 }
             }
@@ -5393,8 +5418,8 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
             __builtin_amdgcn_wave_barrier();
             bool ok = false;
             if (search) {
-                const int idx = static_cast<int>(mbox[lane * 3]);
-                const double Av = mbox[lane * 3 + 1], Bv = mbox[lane * 3 + 2];
+                const int idx = static_cast<int>(mboxf[lane * 3]);
+                const double Av = pb + static_cast<double>(mboxf[lane * 3 + 1]), Bv = pb + static_cast<double>(mboxf[lane * 3 + 2]);
                 v = c_star * 32 + static_cast<uint32_t>(max(idx, 0));
                 const bool lo_ok = v == 0 || Av * (1.0 + delta) < tau * (1.0 - delta);
                 const bool hi_ok = v == d.P - 1 || tau * (1.0 + delta) < Bv * (1.0 - delta);
@@ -5432,8 +5457,8 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
                 const uint32_t s_slot = static_cast<uint32_t>(__shfl(static_cast<int>(slot), L));
                 const double s_u = __shfl(u_org, L);
                 const double M = static_cast<double>(d.exact_ref[s_slot]) * 0.69314718055994530942;
-                const uint32_t pv = exact_pick_wave(d, d.exact_sums + static_cast<size_t>(s_slot) * n_cc,
-                                                    d.omega + static_cast<size_t>(s_slot) * d.OMS, M, s_u, 1u, lane);
+                const uint32_t pv = exact_pick_call(d, d.exact_sums + static_cast<size_t>(s_slot) * n_cc,
+                                                    d.omega + static_cast<size_t>(s_slot) * d.OMS, M, s_u, lane);
                 if (lane == L) v = pv;
                 __builtin_amdgcn_wave_barrier();
             }
@@ -5465,6 +5490,8 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
         bool click = false, click_known = false;
         double ctr = 0.0;
         if (kind == 2) {
+            float omb[KC];                          // !OMREG: this user's omega32, requested before the policy walks the history
+            if constexpr (!OMREG) { if (is_ban && !d.aux_pclick) load_omega(d, slot, omb); }
             if (is_ban || is_ph) {
                 if (HIST) {
                     // OrganicUserEventCounterModel.act (organic_user_count.py:45-96; exploit_explore, epsilon = 0,
@@ -5538,8 +5565,13 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
             }
             c_ph += static_cast<uint32_t>(__popcll(__ballot(is_ph)));
             if (is_ban && !d.aux_pclick) {
-                const int dec = click_decide32<KC>(d.beta32 + static_cast<size_t>(a) * d.KB4, [&](int k) { return om[k]; }, d.K, d.KB4,
-                                                   static_cast<float>(d.mu_b[a]), rg_uniform(w.w[0], w.w[1]));
+                int dec;
+                if constexpr (OMREG)
+                    dec = click_decide32<KC>(d.beta32 + static_cast<size_t>(a) * d.KB4, [&](int k) { return om[k]; }, d.K, d.KB4,
+                                             static_cast<float>(d.mu_b[a]), rg_uniform(w.w[0], w.w[1]));
+                else
+                    dec = click_decide32<KC>(d.beta32 + static_cast<size_t>(a) * d.KB4, [&](int k) { return omb[k]; }, d.K, d.KB4,
+                                             static_cast<float>(d.mu_b[a]), rg_uniform(w.w[0], w.w[1]));
                 if (dec >= 0) { click = dec != 0; click_known = true; }
             }
             if (is_ban && !click_known) {
