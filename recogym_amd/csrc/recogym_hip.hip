@@ -5279,7 +5279,8 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
             if (static_cast<double>(uf) > u_org) u_dn = f32_down(uf);
             if (static_cast<double>(uf) < u_org) u_up = f32_up(uf);
             bool hit = false;
-            if (n_hot) {
+            {
+                // the whole line in one round trip (the entries behind n_hot are not looked at), selects only
                 float e[28];
 #pragma unroll
                 for (int i = 1; i < 8; ++i) {
@@ -5287,10 +5288,11 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
                     e[4 * i - 4] = x.x; e[4 * i - 3] = x.y; e[4 * i - 2] = x.z; e[4 * i - 1] = x.w;
                 }
 #pragma unroll
-                for (int j = 0; j < kHotEntries; ++j)
-                    if (static_cast<uint32_t>(j) < n_hot && e[3 * j + 1] < u_dn && u_up < e[3 * j + 2]) {
-                        hit = true; v = __builtin_bit_cast(uint32_t, e[3 * j]);
-                    }
+                for (int j = 0; j < kHotEntries; ++j) {
+                    const bool in = static_cast<uint32_t>(j) < n_hot && e[3 * j + 1] < u_dn && u_up < e[3 * j + 2];
+                    hit = hit || in;
+                    v = in ? __builtin_bit_cast(uint32_t, e[3 * j]) : v;
+                }
             }
             have_v = is_o && hit;
             if (is_o && !hit) st = kWSlow;
@@ -5508,14 +5510,24 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
                     const uint32_t Tlo = static_cast<uint32_t>(fmin(ceil(T * (1.0 - 0x1p-36)), 4294967295.0));
                     uint32_t C = 0, c_f = 0;
                     bool found = false, amb = false;
+                    {
+                        // the 15 entries of the line at once (one LDS round trip), then selects only: an entry-by-entry loop
+                        // with its two exits compiled to 15 dependent round trips and 30 branches
+                        hent_t e[16];
 #pragma unroll
-                    for (int i = 1; i < 16; ++i)
-                        if (static_cast<uint32_t>(i) <= nd && !found) {
-                            const hent_t x = hl[i * 64];
-                            C += h_cnt(x);
-                            if (C > Thi) { found = true; a = h_prod(x); c_f = h_cnt(x); }
-                            else if (C >= Tlo) amb = true;
+                        for (int i = 1; i < 16; ++i) e[i] = hl[i * 64];
+#pragma unroll
+                        for (int i = 1; i < 16; ++i) {
+                            const bool in = static_cast<uint32_t>(i) <= nd;
+                            const uint32_t cnt = in ? h_cnt(e[i]) : 0u;
+                            C += cnt;
+                            const bool take = in && !found && C > Thi;
+                            amb = amb || (in && !found && !take && C >= Tlo);
+                            a = take ? h_prod(e[i]) : a;
+                            c_f = take ? cnt : c_f;
+                            found = found || take;
                         }
+                    }
                     for (uint32_t base = 16; base <= nd && !found; base += kHistRegs) {      // longer histories: from the row
                         hent_t f[kHistRegs];
                         hist_load_line(hr + base, f);
@@ -5632,26 +5644,36 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
                     const uint32_t nd = h_cnt(h0);
                     const hent_t key = static_cast<hent_t>(v) << 32;
                     if (nd < 15u) {
-                        uint32_t pos = 1;
-                        bool hit = false;
-                        hent_t at = 0ull;
+                        // the whole line in registers (one LDS round trip), the new line by selects, written back whole —
+                        // to LDS and, as eight 16-byte stores, to the row: no data-dependent branch, no dependent loads
+                        hent_t e[17];
+                        e[0] = h0; e[16] = 0ull;
 #pragma unroll
-                        for (int i = 1; i < 16; ++i)
-                            if (static_cast<uint32_t>(i) <= nd) {
-                                const hent_t x = hl[i * 64];
-                                pos += x < key ? 1u : 0u;
-                                if (h_prod(x) == v) { hit = true; at = x; }
-                            }
-                        if (hit) {
-                            hl[pos * 64] = at + 1ull; hr[pos] = at + 1ull;
-                            hl[0] = h0 + (1ull << 32); hr[0] = h0 + (1ull << 32);
-                        } else if (nd + 1 >= d.hist_cap) atomicAdd(&d.counters[RG_CNT_HIST_OVERFLOW], 1ull);
-                        else {
-                            // entries [pos, nd] move up by one, highest first (nd + 1 <= 15: all inside the line)
-                            for (uint32_t i = nd; i >= pos; --i) { const hent_t x = hl[i * 64]; hl[(i + 1) * 64] = x; hr[i + 1] = x; }
-                            hl[pos * 64] = key | 1ull; hr[pos] = key | 1ull;
-                            hl[0] = h0 + (1ull << 32) + 1ull; hr[0] = h0 + (1ull << 32) + 1ull;
+                        for (int i = 1; i < 16; ++i) e[i] = hl[i * 64];
+                        uint32_t pos = 1;                       // first entry with product >= v (nd + 1 if none)
+                        bool hit = false;
+#pragma unroll
+                        for (int i = 1; i < 16; ++i) {
+                            const bool in = static_cast<uint32_t>(i) <= nd;
+                            pos += (in && e[i] < key) ? 1u : 0u;
+                            hit = hit || (in && h_prod(e[i]) == v);
                         }
+                        const bool full = !hit && nd + 1 >= d.hist_cap;
+                        if (full) atomicAdd(&d.counters[RG_CNT_HIST_OVERFLOW], 1ull);
+                        hent_t f[16];
+                        f[0] = full ? h0 : h0 + (1ull << 32) + (hit ? 0ull : 1ull);
+#pragma unroll
+                        for (int i = 1; i < 16; ++i) {
+                            const uint32_t ui = static_cast<uint32_t>(i);
+                            const hent_t shifted = ui < pos ? e[i] : (ui == pos ? (key | 1ull) : e[i - 1]);
+                            const hent_t bumped = ui == pos ? e[i] + 1ull : e[i];
+                            f[i] = full ? e[i] : (hit ? bumped : shifted);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) hl[i * 64] = f[i];
+                        ulonglong2* hw = reinterpret_cast<ulonglong2*>(hr);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) hw[i] = make_ulonglong2(f[2 * i], f[2 * i + 1]);
                     } else {
                         // the line is full (or the history longer): the general insertion on the row, then the line again
                         history_add(d, slot, v);
