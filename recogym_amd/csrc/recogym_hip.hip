@@ -236,6 +236,7 @@ struct rg_sim {
     bool walk;                // rg_sim_run "to the end" walks the run user-major (k_walk) instead of step-major
     int walk_occ;             // blocks per CU of the walk kernel (RECOGYM_WALK_OCC: 2, 3 or 4)
     bool walk2;               // the walk is k_walk2 (prefix sums + memo; RECOGYM_WALK=1 keeps k_walk)
+    bool walk_solo;           // its last round is k_walk_solo (RECOGYM_WALK_SOLO=0: k_walk2's)
     int n_cus;                // compute units of the device (grid of the persistent walk kernel)
     double prof_walk_ms[2];   // round 1 / round 2 of k_walk
     uint32_t repack_every;    // steps between repacks (RECOGYM_REPACK, 0 = never)
@@ -286,6 +287,8 @@ advance_kernel_t advance_kernel();
 search_kernel_t tail_kernel();
 walk_kernel_t walk_kernel_for(const DevSim& d, int occ);   // part 7
 walk_kernel_t walk2_kernel_for(const DevSim& d, int occ);  // (nullptr: this configuration keeps k_walk)
+typedef void (*solo_kernel_t)(DevSim, uint32_t, uint32_t, uint32_t);
+solo_kernel_t solo_kernel_for(const DevSim& d);            // (nullptr: the last round is k_walk2's too)
 void (*cache_prefix_kernel())(DevSim);
 
 // ------------------------------------------------------------------------------------------
@@ -5740,6 +5743,454 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
     }
 }
 
+#endif
+// ------------------------------------------------------------------------------------------
+// k_walk_solo — the LAST round of the user-major walk: a WAVE per user, a LANE per consecutive event.
+//
+// What is left for the last round are the users the draining waves of the earlier rounds handed over: few (some 10^4 of
+// 10^7) and long-lived (the longest trajectory of a 10 M-user run has ~1 600 events).  Walked a lane per user, an event per
+// wave iteration, their round costs (events of the longest user) x (latency of an iteration, ~7 us) whatever the GPU could
+// do meanwhile — a third of the walk on a 2 M-user shard.  But between two organic events nothing a user does depends on
+// its own earlier events of the RUN it is in:
+//   * organic run: the state chain of organic events is decided by their transition uniforms alone (addressed draws), so
+//     the run's length is known up front and its product draws (memo / search / float64 pick) are independent;
+//   * bandit run: omega and the view history are fixed, so the policy's act, the click and the transition of the next 64
+//     events are evaluated at once and committed up to the first one that leaves the run (a click, a transition).
+// A lane takes event t + lane of the user's current run; the wave commits the run's prefix, moves the user past it and
+// goes on: ~11 iterations per 100 events instead of 100.  Rows, counters, view history, phantom row: as k_walk2 (the sorted
+// log cannot tell the difference; the raw order differs, like between any two forms).  Every listed user has its float64
+// sums (the batch between rounds 1 and 2 took them).  Needs hist_cap <= 256 (the user's whole history lives in LDS).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kSoloHist = 256;
+
+// k_walk_solo's view history: the user's whole row in LDS (hs[0] header, hs[1 ..] the entries), every lane an event.
+// The OrganicUserEventCounter act of ONE lane's event (its own uniform u1) on the wave's shared history — the integer
+// prefix walk of policy_act, the float64 cdf walk inside the 2^-36 band.
+__device__ __forceinline__ uint32_t solo_ouc_act(const DevSim& d, const hent_t* hs, double u1, double* ps_out) {
+    const hent_t h0 = hs[0];
+    const uint32_t nd = h_cnt(h0);
+    const double sum = static_cast<double>(h_prod(h0));
+    const double T = u1 * sum;
+    const uint32_t Thi = static_cast<uint32_t>(fmin(floor(T * (1.0 + 0x1p-36)), 4294967295.0));
+    const uint32_t Tlo = static_cast<uint32_t>(fmin(ceil(T * (1.0 - 0x1p-36)), 4294967295.0));
+    uint32_t C = 0, a = 0, c_f = 0;
+    bool found = false, amb = false;
+    for (uint32_t i = 1; i <= nd; ++i) {                 // (wave-uniform trip count, broadcast reads)
+        const hent_t x = hs[i];
+        C += h_cnt(x);
+        const bool take = !found && C > Thi;
+        amb = amb || (!found && !take && C >= Tlo);
+        a = take ? h_prod(x) : a;
+        c_f = take ? h_cnt(x) : c_f;
+        found = found || take;
+    }
+    if (found && !amb) { *ps_out = static_cast<double>(c_f) / sum; return a; }
+    double last = 0.0;
+    for (uint32_t i = 1; i <= nd; ++i) last += static_cast<double>(h_cnt(hs[i])) / sum;
+    double acc = 0.0, pa = 0.0;
+    a = d.P - 1;
+    bool fnd = false;
+    for (uint32_t i = 1; i <= nd && !fnd; ++i) {
+        const hent_t x = hs[i];
+        const double p = static_cast<double>(h_cnt(x)) / sum;
+        acc += p;
+        if (!(acc / last <= u1)) { a = h_prod(x); pa = p; fnd = true; }
+    }
+    *ps_out = pa;
+    return a;
+}
+// ViewsFeaturesProvider.observe (agents/abstract.py:347-358) by the whole wave on the history in LDS, written through to
+// the row: position and hit by ballots over the entries (four per lane: nd < 256), the shift by every lane moving its own.
+__device__ __forceinline__ void solo_hist_add(const DevSim& d, hent_t* hs, hent_t* hr, uint32_t v, int lane) {
+    const hent_t h0 = hs[0];
+    const uint32_t nd = h_cnt(h0);
+    const hent_t key = static_cast<hent_t>(v) << 32;
+    hent_t mine[4];
+    uint32_t below = 0;
+    bool hit = false;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const uint32_t j = 1u + static_cast<uint32_t>(lane) + 64u * b;
+        mine[b] = j <= nd ? hs[j] : ~0ull;
+        below += static_cast<uint32_t>(__popcll(__ballot(j <= nd && mine[b] < key)));
+        hit = hit || __ballot(j <= nd && h_prod(mine[b]) == v) != 0ull;
+    }
+    const uint32_t pos = 1u + below;                      // first entry with product >= v (nd + 1 if none)
+    __builtin_amdgcn_wave_barrier();
+    if (hit) {
+        if (lane == 0) {
+            const hent_t x = hs[pos] + 1ull;
+            hs[pos] = x; hr[pos] = x;
+            hs[0] = h0 + (1ull << 32); hr[0] = h0 + (1ull << 32);
+        }
+    } else if (nd + 1 >= d.hist_cap || nd + 2 > kSoloHist) {
+        if (lane == 0) atomicAdd(&d.counters[RG_CNT_HIST_OVERFLOW], 1ull);
+    } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t j = 1u + static_cast<uint32_t>(lane) + 64u * b;
+            if (j >= pos && j <= nd) { hs[j + 1] = mine[b]; hr[j + 1] = mine[b]; }
+        }
+        if (lane == 0) {
+            hs[pos] = key | 1ull; hr[pos] = key | 1ull;
+            hs[0] = h0 + (1ull << 32) + 1ull; hr[0] = h0 + (1ull << 32) + 1ull;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+#if RG_HAS(7)
+template <int KH, int HIST>
+__global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_work, uint32_t chunk_rows, uint32_t in_base) {
+    (void)d_arg;       // read where it lies, in the kernel-argument segment (the float64 pick is a call that takes its address)
+    const DevSim& d = *(const DevSim*)(const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int K2 = 2 * KH;
+    constexpr int KC = ((K2 + 3) / 4) * 4;
+    constexpr int kEmpty = 3, kPhantom = 4;
+    __shared__ hent_t s_hist[kBlock / 64][HIST ? kSoloHist : 1];      // the user's history row: [0] header, then the entries
+    __shared__ float s_mbox[kBlock / 64][64 * 3];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    hent_t* hs = s_hist[wave];
+    float* mboxf = s_mbox[wave];
+    const uint32_t n_cc = d.PT / 64;
+    uint64_t row_next = 0, row_end = 0;
+    uint32_t c_org = 0, c_ban = 0, c_clicks = 0, c_ph = 0, c_pick = 0, c_maxt = 0, c_limit = 0, c_hit = 0;
+    for (;;) {
+        uint32_t idx = 0;
+        if (lane == 0) idx = static_cast<uint32_t>(atomicAdd(&d.counters[kCntWalkTicket], 1ull));
+        idx = __builtin_amdgcn_readfirstlane(idx);
+        if (idx >= n_work) break;
+        const uint32_t slot = __builtin_amdgcn_readfirstlane(d.park_list[in_base + idx]);
+        if (slot == 0xFFFFFFFFu) continue;
+        const uint32_t pt = __builtin_amdgcn_readfirstlane(d.park_t[slot]);
+        uint32_t t = pt & 0xFFFFFFu;
+        int st = static_cast<int>((pt >> 24) & 7u);
+        bool pend = (pt >> 27) & 1u;
+        const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
+        const bool organic_only = (d.first_user + slot) < d.organic_only_below;
+        float om[KC];
+        {
+            const float4* rp = reinterpret_cast<const float4*>(d.cache_row + static_cast<size_t>(slot) * d.cache_row_f);
+#pragma unroll
+            for (int k4 = 0; k4 < K2 / 4; ++k4) {
+                const float4 x = rp[11 + k4];
+                om[4 * k4] = x.x; om[4 * k4 + 1] = x.y; om[4 * k4 + 2] = x.z; om[4 * k4 + 3] = x.w;
+            }
+#pragma unroll
+            for (int k = (K2 / 4) * 4; k < K2; ++k) om[k] = reinterpret_cast<const float*>(rp)[44 + k];
+#pragma unroll
+            for (int k = K2; k < KC; ++k) om[k] = 0.0f;
+        }
+        hent_t* hr = HIST ? hist_row(d, slot) : nullptr;
+        if (HIST) {
+            const uint32_t nd0 = h_cnt(hr[0]);
+            for (uint32_t j = lane; j <= nd0; j += 64) hs[j] = hr[j];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+        uint32_t lastv = d.lpv ? d.lpv[slot] : 0u;
+        // hot row of the user (no memo entries are added here: the lanes of a run would race for the row)
+        const float4* hp = reinterpret_cast<const float4*>(d.walk_hot + static_cast<size_t>(slot) * 32);
+        while (st != kEmpty) {
+            const uint32_t te = t + static_cast<uint32_t>(lane);             // this lane's event
+            const rg_u32x4 w = rg_draw(d.seed, user, te, 0, RG_DRAW_EVENT);
+            const double u_trans = rg_uniform(w.w[2], w.w[3]);
+            if (st == kPhantom) {
+                // final step_offline(done = True): one more act, reward 0 (abstract.py:223-233,311-316) — lane 0's
+                double ps = 1.0;
+                uint32_t a = 0;
+                if (HIST) {
+                    const rg_u32x4 pw = rg_draw(d.policy_seed, user, t, 0, RG_DRAW_POLICY);
+                    a = solo_ouc_act(d, hs, rg_uniform(pw.w[2], pw.w[3]), &ps);
+                } else if (d.policy == RG_POLICY_LAST_VIEW_TABLE) {
+                    ps = d.pol_ps ? static_cast<double>(d.pol_ps[lastv]) : 1.0;
+                    a = static_cast<uint32_t>(d.pol_table[lastv]);
+                } else {
+                    const rg_u32x4 pw = rg_draw(d.policy_seed, user, t, 0, RG_DRAW_POLICY);
+                    ps = 1.0 / static_cast<double>(d.P);
+                    a = rg_bounded(pw.w[0], pw.w[1], d.P);
+                }
+                if (lane == 0) {
+                    rg_event e;
+                    e.u = user; e.t = t; e.code = RG_EV_BANDIT | RG_EV_PHANTOM | a;
+                    e.ps = static_cast<float>(ps);
+                    d.phantom[slot] = e;
+                    d.phantom_ps[slot] = ps;
+                    d.has_phantom[slot] = 1;
+                }
+                c_ph += 1;
+                st = kEmpty;
+                break;
+            }
+            const bool org = st == RG_STATE_ORGANIC;
+            // ---- bandit run: act and click of every lane's event (they decide where the run ends) ----
+            double ps = 1.0, ctr = 0.0;
+            uint32_t a = 0;
+            bool click = false;
+            if (!org) {
+                if (HIST) {
+                    const rg_u32x4 pw = rg_draw(d.policy_seed, user, te, 0, RG_DRAW_POLICY);
+                    a = solo_ouc_act(d, hs, rg_uniform(pw.w[2], pw.w[3]), &ps);
+                } else if (d.policy == RG_POLICY_LAST_VIEW_TABLE) {
+                    ps = d.pol_ps ? static_cast<double>(d.pol_ps[lastv]) : 1.0;
+                    a = static_cast<uint32_t>(d.pol_table[lastv]);
+                } else {
+                    const rg_u32x4 pw = rg_draw(d.policy_seed, user, te, 0, RG_DRAW_POLICY);
+                    ps = 1.0 / static_cast<double>(d.P);
+                    a = rg_bounded(pw.w[0], pw.w[1], d.P);
+                }
+                int dec = -1;
+                if (!d.aux_pclick)
+                    dec = click_decide32<KC>(d.beta32 + static_cast<size_t>(a) * d.KB4, [&](int k) { return om[k]; }, d.K, d.KB4,
+                                             static_cast<float>(d.mu_b[a]), rg_uniform(w.w[0], w.w[1]));
+                if (dec >= 0) click = dec != 0;
+                else {
+                    const double* b = d.beta + static_cast<size_t>(a) * d.K;
+                    const double* omd = d.omega + static_cast<size_t>(slot) * d.OMS;
+                    double x = 0.0;
+                    for (uint32_t k = 0; k < d.K; ++k) x += b[k] * omd[k];
+                    ctr = ff64(x + d.mu_b[a]);
+                    const double p0 = 1.0 - ctr;
+                    click = (p0 / (p0 + ctr)) <= rg_uniform(w.w[0], w.w[1]);
+                }
+            }
+            // ---- the state after every lane's event, had the run reached it (abstract.py:123-197) ----
+            const double c0 = org ? d.cdf_o0 : d.cdf_b0, c1 = org ? d.cdf_o1 : d.cdf_b1;
+            int ns = (c0 <= u_trans) + (c1 <= u_trans);
+            if (click) ns = RG_STATE_ORGANIC;
+            bool limit = false;
+            if (organic_only && ns != RG_STATE_ORGANIC) ns = RG_STATE_STOP;
+            else if (ns == RG_STATE_STOP) ns = kPhantom;
+            else if (te + 2 >= kMaxSteps) { ns = RG_STATE_STOP; limit = true; }
+            const unsigned long long leave = __ballot(ns != st);
+            const int last = leave ? __builtin_ctzll(leave) : 63;            // the run's events of this pass: lanes 0 .. last
+            const bool mine = lane <= last;
+            const int ns_last = __shfl(ns, last);
+            // ---- organic run: the product of every event of the run ----
+            uint32_t v = 0;
+            if (org) {
+                const float4 h0 = hp[0];
+                const double S = static_cast<double>(h0.x), delta = static_cast<double>(h0.y);
+                const float Q = h0.z;
+                const uint32_t n_hot = __builtin_bit_cast(uint32_t, h0.w);
+                const double u_org = rg_uniform(w.w[0], w.w[1]);
+                float uf = static_cast<float>(u_org), u_dn = uf, u_up = uf;
+                if (static_cast<double>(uf) > u_org) u_dn = f32_down(uf);
+                if (static_cast<double>(uf) < u_org) u_up = f32_up(uf);
+                bool hit = false;
+                {
+                    float e[28];
+#pragma unroll
+                    for (int i = 1; i < 8; ++i) {
+                        const float4 x = hp[i];
+                        e[4 * i - 4] = x.x; e[4 * i - 3] = x.y; e[4 * i - 2] = x.z; e[4 * i - 1] = x.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < kHotEntries; ++j) {
+                        const bool in = static_cast<uint32_t>(j) < n_hot && e[3 * j + 1] < u_dn && u_up < e[3 * j + 2];
+                        hit = hit || in;
+                        v = in ? __builtin_bit_cast(uint32_t, e[3 * j]) : v;
+                    }
+                }
+                const bool first_pend = pend && lane == 0;                   // the parked draw: float64, whatever the memo says
+                hit = hit && !first_pend;
+                c_hit += static_cast<uint32_t>(__popcll(__ballot(mine && hit)));
+                const bool search = mine && !hit && !first_pend;
+                bool ok = false;
+                if (__ballot(search)) {
+                    const double tau = u_org * S;
+                    const float tauf = static_cast<float>(tau);
+                    uint32_t sc_star = 0;
+                    float pbf = 0.0f;
+                    {
+                        const float4* sp = reinterpret_cast<const float4*>(d.walk_scp + static_cast<size_t>(slot) * kMaxSC);
+#pragma unroll
+                        for (int i = 0; i < kMaxSC / 4; ++i) {
+                            const float4 x = sp[i];
+                            const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (xs[q] <= tauf) { sc_star += 1; pbf = fmaxf(pbf, xs[q]); }
+                        }
+                    }
+                    bool found = sc_star < d.n_sc;
+                    sc_star = min(sc_star, d.n_sc - 1);
+                    uint32_t c_star;
+                    {
+                        const uint32_t cc0 = sc_star * d.sc_chunks, cc1 = min(cc0 + d.sc_chunks, d.n_chunks);
+                        const float* cp = d.cache_chunk + static_cast<size_t>(slot) * d.n_chunks;
+                        uint32_t cnt = 0;
+                        for (uint32_t cb = cc0; cb < cc1; cb += 16) {
+                            float4 w4[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                w4[i] = cb + 4 * i < cc1 ? *reinterpret_cast<const float4*>(cp + cb + 4 * i) : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float xs[4] = {w4[i].x, w4[i].y, w4[i].z, w4[i].w};
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    if (xs[q] <= tauf) { cnt += 1; pbf = fmaxf(pbf, xs[q]); }
+                            }
+                        }
+                        found = found && cnt < cc1 - cc0;
+                        c_star = min(cc0 + cnt, cc1 - 1);
+                    }
+                    const double pb = static_cast<double>(pbf);
+                    const float rem = static_cast<float>(tau - pb);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    {
+                        const int grp = lane >> 3, gl = lane & 7;
+                        unsigned long long todo = __ballot(search);
+                        while (todo) {
+                            int src = -1;
+#pragma unroll
+                            for (int g = 0; g < 8; ++g) {
+                                const int bit = todo ? __builtin_ctzll(todo) : -1;
+                                if (g == grp) src = bit;
+                                if (todo) todo &= todo - 1;
+                            }
+                            const bool has = src >= 0;
+                            const int s2 = has ? src : 0;
+                            const uint32_t cs = static_cast<uint32_t>(__shfl(static_cast<int>(c_star), s2));
+                            const float rems = __shfl(rem, s2);
+                            const float4* gp = reinterpret_cast<const float4*>(d.gamma32t + (static_cast<size_t>(cs) * K2) * 32) + gl;
+                            float4 l = *(reinterpret_cast<const float4*>(d.mu32 + cs * 32) + gl);
+#pragma unroll
+                            for (int kh = 0; kh < K2; kh += KH) {
+                                float4 gk[KH];
+#pragma unroll
+                                for (int k = 0; k < KH; ++k) gk[k] = gp[(kh + k) * 8];
+#pragma unroll
+                                for (int k = 0; k < KH; ++k) {
+                                    const float wk = om[kh + k];                 // (every lane holds THE user's omega32)
+                                    l.x = fmaf(gk[k].x, wk, l.x); l.y = fmaf(gk[k].y, wk, l.y);
+                                    l.z = fmaf(gk[k].z, wk, l.z); l.w = fmaf(gk[k].w, wk, l.w);
+                                }
+                                asm volatile("" : "+v"(l.x), "+v"(l.y), "+v"(l.z), "+v"(l.w));
+                            }
+                            const float e0 = __builtin_amdgcn_exp2f(fmaf(l.x, kLog2e, -Q)), e1 = __builtin_amdgcn_exp2f(fmaf(l.y, kLog2e, -Q));
+                            const float e2 = __builtin_amdgcn_exp2f(fmaf(l.z, kLog2e, -Q)), e3 = __builtin_amdgcn_exp2f(fmaf(l.w, kLog2e, -Q));
+                            const float q0 = e0, q1 = q0 + e1, q2 = q1 + e2, q3 = q2 + e3;
+                            float inc = q3;
+#pragma unroll
+                            for (int o2 = 1; o2 < 8; o2 <<= 1) {
+                                const float y = __shfl_up(inc, o2, 8);
+                                if (gl >= o2) inc += y;
+                            }
+                            float ex = __shfl_up(inc, 1, 8);
+                            if (gl == 0) ex = 0.0f;
+                            const float x0 = ex + q0, x1 = ex + q1, x2 = ex + q2, x3 = ex + q3;
+                            const int j0 = x0 > rems ? 0 : x1 > rems ? 1 : x2 > rems ? 2 : x3 > rems ? 3 : -1;
+                            const unsigned long long hits = __ballot(has && j0 >= 0);
+                            const uint32_t gmask = static_cast<uint32_t>(hits >> (8 * grp)) & 0xFFu;
+                            if (has) {
+                                if (gmask) {
+                                    if (gl == __builtin_ctz(gmask)) {
+                                        mboxf[src * 3] = static_cast<float>(4 * gl + j0);
+                                        mboxf[src * 3 + 1] = j0 == 0 ? ex : j0 == 1 ? x0 : j0 == 2 ? x1 : x2;
+                                        mboxf[src * 3 + 2] = j0 == 0 ? x0 : j0 == 1 ? x1 : j0 == 2 ? x2 : x3;
+                                    }
+                                } else if (gl == 0) { mboxf[src * 3] = -1.0f; mboxf[src * 3 + 1] = 0.0f; mboxf[src * 3 + 2] = 0.0f; }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    if (search) {
+                        const int ix = static_cast<int>(mboxf[lane * 3]);
+                        const double Av = pb + static_cast<double>(mboxf[lane * 3 + 1]), Bv = pb + static_cast<double>(mboxf[lane * 3 + 2]);
+                        v = c_star * 32 + static_cast<uint32_t>(max(ix, 0));
+                        const bool lo_ok = v == 0 || Av * (1.0 + delta) < tau * (1.0 - delta);
+                        const bool hi_ok = v == d.P - 1 || tau * (1.0 + delta) < Bv * (1.0 - delta);
+                        ok = found && ix >= 0 && v < d.P && lo_ok && hi_ok;
+                    }
+                }
+                // uncertified draws (and the parked one): float64 picks from the user's stored sums, one after the other
+                unsigned long long picks = __ballot(mine && !hit && !ok);
+                c_pick += static_cast<uint32_t>(__popcll(picks));
+                while (picks) {
+                    const int L = __builtin_ctzll(picks);
+                    picks &= picks - 1;
+                    const double s_u = __shfl(u_org, L);
+                    const double M = static_cast<double>(d.exact_ref[slot]) * 0.69314718055994530942;
+                    const uint32_t pv = exact_pick_call(d, d.exact_sums + static_cast<size_t>(slot) * n_cc,
+                                                        d.omega + static_cast<size_t>(slot) * d.OMS, M, s_u, lane);
+                    if (lane == L) v = pv;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                pend = false;
+            }
+            // ---- rows of the run's events ----
+            const uint32_t n_ev = static_cast<uint32_t>(last) + 1u;
+            if (row_next + n_ev > row_end) {
+                for (uint64_t r = row_next + lane; r < row_end; r += 64)
+                    if (d.log && r < d.log_cap) { rg_event e; e.u = 0; e.t = 0; e.code = kHoleCode; e.ps = 0.0f; d.log[r] = e; }
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&d.counters[kCntTailRows], static_cast<unsigned long long>(chunk_rows));
+                base = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32))) << 32) |
+                       __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
+                row_next = base; row_end = base + chunk_rows;
+            }
+            const uint64_t my_row = row_next + static_cast<uint32_t>(lane);
+            row_next += n_ev;
+            if (mine && d.log && my_row < d.log_cap) {
+                rg_event e;
+                e.u = user; e.t = te;
+                e.code = org ? v : (RG_EV_BANDIT | (click ? RG_EV_CLICK : 0u) | a);
+                e.ps = org ? __builtin_nanf("") : static_cast<float>(ps);
+                d.log[my_row] = e;
+                if (!org && d.aux_ps) d.aux_ps[my_row] = ps;
+                if (!org && d.aux_pclick) d.aux_pclick[my_row] = ctr;
+            }
+            if (org) {
+                c_org += n_ev;
+                lastv = static_cast<uint32_t>(__shfl(static_cast<int>(v), last));
+                if (d.lpv && lane == 0) d.lpv[slot] = lastv;
+                if (HIST)
+                    for (int i = 0; i <= last; ++i) solo_hist_add(d, hs, hr, static_cast<uint32_t>(__shfl(static_cast<int>(v), i)), lane);
+            } else {
+                c_ban += n_ev;
+                c_clicks += static_cast<uint32_t>(__popcll(__ballot(mine && click)));
+            }
+            // ---- the user after the run ----
+            t += n_ev;
+            if (ns_last == RG_STATE_STOP || ns_last == kPhantom) {
+                if (lane == 0) d.n_events[slot] = t;
+                c_maxt = max(c_maxt, t);
+                c_limit += static_cast<uint32_t>(__shfl(static_cast<int>(limit), last));
+            }
+            st = ns_last == RG_STATE_STOP ? kEmpty : ns_last;
+        }
+    }
+    for (uint64_t r = row_next + lane; r < row_end; r += 64)
+        if (d.log && r < d.log_cap) { rg_event e; e.u = 0; e.t = 0; e.code = kHoleCode; e.ps = 0.0f; d.log[r] = e; }
+    if (lane == 0) {
+        if (c_org) atomicAdd(&d.counters[kCntTailOrganic], static_cast<unsigned long long>(c_org));
+        if (c_ban) atomicAdd(&d.counters[kCntTailBandit], static_cast<unsigned long long>(c_ban));
+        if (c_clicks) atomicAdd(&d.counters[RG_CNT_CLICKS], static_cast<unsigned long long>(c_clicks));
+        if (c_ph) atomicAdd(&d.counters[RG_CNT_PHANTOM], static_cast<unsigned long long>(c_ph));
+        if (c_pick) atomicAdd(&d.counters[RG_CNT_EXACT_DRAWS], static_cast<unsigned long long>(c_pick));
+        if (c_hit) atomicAdd(&d.counters[kCntWalkHits], static_cast<unsigned long long>(c_hit));
+        if (c_maxt) atomicMax(&d.counters[kCntTailMaxT], static_cast<unsigned long long>(c_maxt));
+        if (c_limit) atomicAdd(&d.counters[kCntTailLimit], static_cast<unsigned long long>(c_limit));
+    }
+}
+solo_kernel_t solo_kernel_for(const DevSim& d) {
+    const bool ouc = d.policy == RG_POLICY_ORGANIC_USER_COUNT;
+    if (walk2_kernel_for(d, 3) == nullptr || (ouc && d.hist_cap > kSoloHist)) return nullptr;
+#ifdef RG_W2_ONLY
+    return k_walk_solo<10, 1>;
+#else
+    switch (d.KH) {
+        case 4: return ouc ? k_walk_solo<4, 1> : k_walk_solo<4, 0>;
+        case 10: return ouc ? k_walk_solo<10, 1> : k_walk_solo<10, 0>;
+        default: return ouc ? k_walk_solo<16, 1> : k_walk_solo<16, 0>;
+    }
+#endif
+}
 walk_kernel_t walk2_kernel_for(const DevSim& d, int occ) {
     // the forms k_walk2 is instantiated for: K <= 32, no group sums, the policies without a view history or the
     // OrganicUserEventCounter default (exploit_explore, epsilon = 0, select_randomly)
@@ -5750,13 +6201,18 @@ walk_kernel_t walk2_kernel_for(const DevSim& d, int occ) {
 #ifdef RG_W2_ONLY     // kernel work: one instantiation, seconds to compile (never a shipped build)
     return k_walk2<10, 1, RG_W2_ONLY>;
 #else
-#define RG_W2(kh) (ouc ? (occ >= 4 ? k_walk2<kh, 1, 4> : k_walk2<kh, 1, 3>) : (occ >= 4 ? k_walk2<kh, 0, 4> : k_walk2<kh, 0, 3>))
+    // (RECOGYM_WALK_OMREG=0: omega32 from the cache row instead of registers at four blocks per CU — measured, not the default)
+    const char* e_om = getenv("RECOGYM_WALK_OMREG");
+    const bool omreg = !(e_om && e_om[0] == '0');
+#define RG_W2H(kh, h) (occ >= 4 ? (omreg ? k_walk2<kh, h, 4, true> : k_walk2<kh, h, 4, false>) : k_walk2<kh, h, 3, true>)
+#define RG_W2(kh) (ouc ? RG_W2H(kh, 1) : RG_W2H(kh, 0))
     switch (d.KH) {
         case 4: return RG_W2(4);
         case 10: return RG_W2(10);
         default: return RG_W2(16);
     }
 #undef RG_W2
+#undef RG_W2H
 #endif
 }
 void (*cache_prefix_kernel())(DevSim) { return k_cache_prefix; }
@@ -6364,7 +6820,13 @@ int run_walk(rg_sim* sim, hipStream_t st) {
         const uint32_t n_left = static_cast<uint32_t>(*h64);
         if (n_left) {
             HIP_TRY(hipMemsetAsync(d.counters + kCntWalkTicket, 0, sizeof(unsigned long long), st));
-            launch_walk(n_left, 3, base3, base3);
+            const solo_kernel_t sk = (sim->walk2 && sim->walk_solo) ? solo_kernel_for(d) : nullptr;
+            if (sk) {      // a wave per user, a lane per consecutive event
+                uint32_t blocks = (n_left + 3u) / 4u;
+                const uint32_t cap = static_cast<uint32_t>(sim->n_cus) * 8u;
+                if (blocks > cap) blocks = cap;
+                hipLaunchKernelGGL(sk, dim3(blocks), dim3(kBlock), 0, st, d, n_left, 256u, base3);
+            } else launch_walk(n_left, 3, base3, base3);
         }
         return RG_OK;
     };
@@ -6556,6 +7018,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     if (const char* e = getenv("RECOGYM_WALK_BIAS")) d.walk_bias = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_OCC")) { const int o = atoi(e); if (o >= 2 && o <= 4) s->walk_occ = o; }
     if (s->walk2 && s->walk_occ < 3) s->walk_occ = 3;
+    s->walk_solo = true;
+    if (const char* e = getenv("RECOGYM_WALK_SOLO")) s->walk_solo = e[0] != '0';
     s->prof_walk_ms[0] = s->prof_walk_ms[1] = 0.0;
     if (const char* e = getenv("RECOGYM_TAIL")) s->tail_below = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_REPACK")) s->repack_every = static_cast<uint32_t>(atoi(e));
