@@ -5129,17 +5129,19 @@ __device__ __forceinline__ float f32_down(float x) {
     return x == 0.0f ? __builtin_bit_cast(float, 0x80000001u) : __builtin_bit_cast(float, x > 0.0f ? b - 1u : b + 1u);
 }
 
-// OMREG: omega32 of the lane's user stays in registers for its whole stay (2 KH VGPRs; the chunk recompute fetches the
-// searching users' by ds_bpermute); else it is read from the user's cache row where needed (five 16-byte loads issued
-// at the top of a bandit / search iteration, off the critical chain): fewer registers, more waves.
-// the float64 pick as a CALL: k_walk2 reaches it for ~3 % of the organic draws, inlined it cost the whole loop its registers
-__device__ __attribute__((noinline)) uint32_t exact_pick_call(const DevSim& d, const double* sums, const double* om, double M,
-                                                             double u, int lane) {
+// (the float64 pick as a noinline CALL freed ~40 registers of the walk's loop, but at four blocks per CU — 128 VGPRs, the loop
+// spilling around the call — the kernel no longer reproduced the oracle: measured, dropped; inlined at three blocks per CU
+// the loop holds everything in 168 registers)
+__device__ __forceinline__ uint32_t exact_pick_call(const DevSim& d, const double* sums, const double* om, double M,
+                                                   double u, int lane) {
     return exact_pick_wave(d, sums, om, M, u, 1u, lane);
 }
 
-template <int KH, int HIST, int OCC, bool OMREG = (OCC < 4)>
-__global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_work, int round, uint32_t chunk_rows,
+// Three blocks per CU (168 VGPRs, no spills).  Four (128 VGPRs) were measured in two forms — omega32 re-read from the cache
+// row instead of held in registers, and the Gamma rows of the chunk pass in two batches — and did not pay: the extra loads and
+// spills cost what the fourth wave brought (C3 walk 130.9 vs 133.8 ms, C2 13.2 vs 12.1 ms: profiles/r3/ab_walk_call3.jsonl).
+template <int KH, int HIST>
+__global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_arg, uint32_t n_work, int round, uint32_t chunk_rows,
                                                         uint32_t in_base, uint32_t out_base) {
     (void)d_arg;       // read from the kernel-argument segment at the point of use (see k_walk)
     const __attribute__((address_space(4))) char* kargs =
@@ -5155,22 +5157,9 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
     uint32_t slot = 0, t = 0;
     int st = kEmpty;
     bool pend = false;                                                 // rounds >= 2: the parked draw, to be picked in float64
-    float om[OMREG ? KC : 1];                                          // omega32 of the lane's user
+    float om[KC];                                                      // omega32 of the lane's user
 #pragma unroll
-    for (int k = 0; k < (OMREG ? KC : 1); ++k) om[k] = 0.0f;
-    // omega32 of user `s2` from its cache row (floats 44 ..), as k_cache_finalize left it
-    auto load_omega = [&](const DevSim& d, uint32_t s2, float (&o)[KC]) {
-        const float4* rp = reinterpret_cast<const float4*>(d.cache_row + static_cast<size_t>(s2) * d.cache_row_f);
-#pragma unroll
-        for (int k4 = 0; k4 < K2 / 4; ++k4) {
-            const float4 x = rp[11 + k4];
-            o[4 * k4] = x.x; o[4 * k4 + 1] = x.y; o[4 * k4 + 2] = x.z; o[4 * k4 + 3] = x.w;
-        }
-#pragma unroll
-        for (int k = (K2 / 4) * 4; k < K2; ++k) o[k] = reinterpret_cast<const float*>(rp)[44 + k];
-#pragma unroll
-        for (int k = K2; k < KC; ++k) o[k] = 0.0f;
-    };
+    for (int k = 0; k < KC; ++k) om[k] = 0.0f;
     uint32_t res_next = 0, res_end = 0;
     uint64_t row_next = 0, row_end = 0;
     uint32_t park_next = 0, park_end = 0;
@@ -5210,11 +5199,15 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
                                 if (round == 2) d.f64_valid[s2] = 1;         // the batch between the rounds took its sums
                                 if (pend) st = kWSlow;                       // its draw goes straight to the float64 pick
                             }
-                            if constexpr (OMREG) {
-                                float o[KC];
-                                load_omega(d, s2, o);
+                            {   // omega32 = float(omega), as k_cache_finalize left it in the user's cache row (floats 44 ..)
+                                const float4* rp = reinterpret_cast<const float4*>(d.cache_row + static_cast<size_t>(s2) * d.cache_row_f);
 #pragma unroll
-                                for (int k = 0; k < KC; ++k) om[k] = o[k];
+                                for (int k4 = 0; k4 < K2 / 4; ++k4) {
+                                    const float4 x = rp[11 + k4];
+                                    om[4 * k4] = x.x; om[4 * k4 + 1] = x.y; om[4 * k4 + 2] = x.z; om[4 * k4 + 3] = x.w;
+                                }
+#pragma unroll
+                                for (int k = (K2 / 4) * 4; k < K2; ++k) om[k] = reinterpret_cast<const float*>(rp)[44 + k];
                             }
                             if (HIST) {
                                 const ulonglong2* hr2 = reinterpret_cast<const ulonglong2*>(hist_row(d, s2));
@@ -5374,18 +5367,14 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
                     const float rems = __shfl(rem, s2);                  // what is left of u S~ at the chunk's start
                     const float4* gp = reinterpret_cast<const float4*>(d.gamma32t + (static_cast<size_t>(cs) * K2) * 32) + gl;
                     float4 l = *(reinterpret_cast<const float4*>(d.mu32 + cs * 32) + gl);
-                    float osrc[KC];
-                    if constexpr (!OMREG) load_omega(d, static_cast<uint32_t>(__shfl(static_cast<int>(slot), s2)), osrc);
-                    constexpr int GB = (OCC >= 4 && KH % 2 == 0) ? KH / 2 : KH;      // Gamma rows in flight per batch (registers)
 #pragma unroll
-                    for (int kh = 0; kh < K2; kh += GB) {
-                        float4 gk[GB];
+                    for (int kh = 0; kh < K2; kh += KH) {
+                        float4 gk[KH];
 #pragma unroll
-                        for (int k = 0; k < GB; ++k) gk[k] = gp[(kh + k) * 8];
+                        for (int k = 0; k < KH; ++k) gk[k] = gp[(kh + k) * 8];
 #pragma unroll
-                        for (int k = 0; k < GB; ++k) {
-                            float wk;
-                            if constexpr (OMREG) wk = __shfl(om[kh + k], s2); else wk = osrc[kh + k];
+                        for (int k = 0; k < KH; ++k) {
+                            const float wk = __shfl(om[kh + k], s2);
                             l.x = fmaf(gk[k].x, wk, l.x); l.y = fmaf(gk[k].y, wk, l.y);
                             l.z = fmaf(gk[k].z, wk, l.z); l.w = fmaf(gk[k].w, wk, l.w);
                         }
@@ -5495,8 +5484,6 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
         bool click = false, click_known = false;
         double ctr = 0.0;
         if (kind == 2) {
-            float omb[KC];                          // !OMREG: this user's omega32, requested before the policy walks the history
-            if constexpr (!OMREG) { if (is_ban && !d.aux_pclick) load_omega(d, slot, omb); }
             if (is_ban || is_ph) {
                 if (HIST) {
                     // OrganicUserEventCounterModel.act (organic_user_count.py:45-96; exploit_explore, epsilon = 0,
@@ -5580,13 +5567,8 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk2(DevSim d_arg, uint32_t n_
             }
             c_ph += static_cast<uint32_t>(__popcll(__ballot(is_ph)));
             if (is_ban && !d.aux_pclick) {
-                int dec;
-                if constexpr (OMREG)
-                    dec = click_decide32<KC>(d.beta32 + static_cast<size_t>(a) * d.KB4, [&](int k) { return om[k]; }, d.K, d.KB4,
-                                             static_cast<float>(d.mu_b[a]), rg_uniform(w.w[0], w.w[1]));
-                else
-                    dec = click_decide32<KC>(d.beta32 + static_cast<size_t>(a) * d.KB4, [&](int k) { return omb[k]; }, d.K, d.KB4,
-                                             static_cast<float>(d.mu_b[a]), rg_uniform(w.w[0], w.w[1]));
+                const int dec = click_decide32<KC>(d.beta32 + static_cast<size_t>(a) * d.KB4, [&](int k) { return om[k]; }, d.K, d.KB4,
+                                                   static_cast<float>(d.mu_b[a]), rg_uniform(w.w[0], w.w[1]));
                 if (dec >= 0) { click = dec != 0; click_known = true; }
             }
             if (is_ban && !click_known) {
@@ -6199,20 +6181,14 @@ walk_kernel_t walk2_kernel_for(const DevSim& d, int occ) {
     if (ouc && !(d.ouc_exploit_explore && d.ouc_epsilon == 0.0 && d.ouc_select_randomly)) return nullptr;
     if (d.policy != RG_POLICY_UNIFORM_ENV && d.policy != RG_POLICY_RANDOM_AGENT && d.policy != RG_POLICY_LAST_VIEW_TABLE && !ouc) return nullptr;
 #ifdef RG_W2_ONLY     // kernel work: one instantiation, seconds to compile (never a shipped build)
-    return k_walk2<10, 1, RG_W2_ONLY>;
+    return k_walk2<10, 1>;
 #else
-    // (RECOGYM_WALK_OMREG=0: omega32 from the cache row instead of registers at four blocks per CU — measured, not the default)
-    const char* e_om = getenv("RECOGYM_WALK_OMREG");
-    const bool omreg = !(e_om && e_om[0] == '0');
-#define RG_W2H(kh, h) (occ >= 4 ? (omreg ? k_walk2<kh, h, 4, true> : k_walk2<kh, h, 4, false>) : k_walk2<kh, h, 3, true>)
-#define RG_W2(kh) (ouc ? RG_W2H(kh, 1) : RG_W2H(kh, 0))
+    (void)occ;
     switch (d.KH) {
-        case 4: return RG_W2(4);
-        case 10: return RG_W2(10);
-        default: return RG_W2(16);
+        case 4: return ouc ? k_walk2<4, 1> : k_walk2<4, 0>;
+        case 10: return ouc ? k_walk2<10, 1> : k_walk2<10, 0>;
+        default: return ouc ? k_walk2<16, 1> : k_walk2<16, 0>;
     }
-#undef RG_W2
-#undef RG_W2H
 #endif
 }
 void (*cache_prefix_kernel())(DevSim) { return k_cache_prefix; }
@@ -7014,10 +6990,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     // k_walk2 where it is instantiated for the configuration (RECOGYM_WALK=1: k_walk), four blocks per CU at K <= 20
     s->walk2 = s->walk && walk2_kernel_for(d, 4) != nullptr;
     if (const char* e = getenv("RECOGYM_WALK")) if (e[0] == '1') s->walk2 = false;
-    if (s->walk2) { s->walk_occ = d.KH <= 10 ? 4 : 3; d.walk_bias = 8; }
-    if (const char* e = getenv("RECOGYM_WALK_BIAS")) d.walk_bias = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_OCC")) { const int o = atoi(e); if (o >= 2 && o <= 4) s->walk_occ = o; }
-    if (s->walk2 && s->walk_occ < 3) s->walk_occ = 3;
+    if (s->walk2) s->walk_occ = d.KH <= 10 ? 3 : 2;     // (what k_walk2 is compiled for: K <= 20 three blocks per CU, K <= 32 two)
     s->walk_solo = true;
     if (const char* e = getenv("RECOGYM_WALK_SOLO")) s->walk_solo = e[0] != '0';
     s->prof_walk_ms[0] = s->prof_walk_ms[1] = 0.0;

@@ -17,7 +17,7 @@ run c3_nosolo RECOGYM_WALK_SOLO=0
 run c3_solo_h16 RECOGYM_WALK_HANDOVER=16
 run c3_solo_h32 RECOGYM_WALK_HANDOVER=32
 run c3_solo_h48 RECOGYM_WALK_HANDOVER=48
-run c3_solo_h32_occ4 RECOGYM_WALK_HANDOVER=32 RECOGYM_WALK_OCC=4
+run c3_solo_h24 RECOGYM_WALK_HANDOVER=24
 WL="--workload c3 --users 1250000"
 run c3s_nosolo RECOGYM_WALK_SOLO=0
 run c3s_solo_h16 RECOGYM_WALK_HANDOVER=16
