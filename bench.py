@@ -224,16 +224,21 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
                                      peak=F64_VALU_PEAK_TFLOPS, unit='TFLOP/s', frac=round(tf / F64_VALU_PEAK_TFLOPS, 4),
                                      resolved_draws=int(c['exact_draws']))
     # frozen LogReg acts: the act of a user is recomputed when its view history changed; per act the coef^T rows of its
-    # viewed products over all classes (fp32 fast path: 4 B per weight) — the table (P x classes) is larger than the
-    # Infinity Cache at 10^4 classes, the rows stream from HBM
+    # viewed products over all classes at the precision the screening pass stores them in (fp16: 2 B per weight, the
+    # default; RECOGYM_LOGREG=fp32: 4 B) — what the kernel has to read (the float64 refine touches a few values per act)
     if prof.get('logreg_ms', 0.0) > 0 and c.get('lr_acts', 0) > 0:
         n_classes = P
-        by = 4.0 * n_classes * c['lr_rows']
+        wbytes = 4.0 if os.environ.get('RECOGYM_LOGREG', 'fp16') == 'fp32' or n_classes % 8 else 2.0
+        by = wbytes * n_classes * c['lr_rows']
         gbps = by / (prof['logreg_ms'] * 1e-3) / 1e9
-        out['logreg_acts'] = dict(kernel='k_logreg_select + k_logreg_acts', bound='hbm', ms=round(prof['logreg_ms'], 2),
+        out['logreg_acts'] = dict(kernel='k_logreg_select + k_logreg_screen + k_logreg_decide' if wbytes == 2.0 else 'k_logreg_select + k_logreg_acts',
+                                  bound='hbm', ms=round(prof['logreg_ms'], 2),
                                   units=int(c['lr_acts']), unit_name='acts', bytes_per_unit=round(by / c['lr_acts'], 1),
-                                  rows_per_act=round(c['lr_rows'] / c['lr_acts'], 2), float64_acts=int(c.get('lr_exact', 0)),
-                                  achieved=round(gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(gbps / HBM_PEAK_GBPS, 4))
+                                  rows_per_act=round(c['lr_rows'] / c['lr_acts'], 2), float64_refined_acts=int(c.get('lr_exact', 0)),
+                                  launches=int(prof['steps']), us_per_launch=round(1e3 * prof['logreg_ms'] / max(prof['steps'], 1), 1),
+                                  achieved=round(gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(gbps / HBM_PEAK_GBPS, 4),
+                                  note='a lock-step step has few acts (about one per wave slot): the time of a step\'s act kernels is the '
+                                       'latency of one act, not throughput')
     # advance: SURVEY.md 8d bytes per event
     if prof['advance_ms'] > 0:
         gbps = b_survey * events / (prof['advance_ms'] * 1e-3) / 1e9

@@ -203,6 +203,7 @@ struct DevSim {
     uint8_t* lr_dirty;        // [n_cap] by user index
     uint32_t* lr_list;        // [n_cap] slots whose act is to be computed this step
     uint32_t* lr_cnt;         // [kMaxSteps + 2]
+    uint32_t* lr_part;        // [n_cap][kLrSplit][kLrPartWords]: the screen's result per listed act and class range
     unsigned long long* counters;   // [RG_CNT_N]
     // log
     rg_event* log; uint64_t log_cap;
@@ -282,7 +283,8 @@ draw_kernel_t bf16p_kernel_for(const DevSim& d);
 draw_kernel_t f16w_kernel_for(const DevSim& d);            // part 5
 search_kernel_t logreg_select_kernel();                    // part 6
 search_kernel_t logreg_acts_kernel();
-search_kernel_t logreg_acts16_kernel();
+search_kernel_t logreg_screen_kernel();
+search_kernel_t logreg_decide_kernel();
 advance_kernel_t advance_kernel();
 search_kernel_t tail_kernel();
 walk_kernel_t walk_kernel_for(const DevSim& d, int occ);   // part 7
@@ -307,6 +309,7 @@ struct Carve {
 };
 
 constexpr uint32_t kMaxSC = 32;           // stored partial sums per user in the MFMA draw kernel
+constexpr uint32_t kAhatGrid = 64;        // stats[2 KH + 2 + i] = max_p (|mu_p| + ||Gamma_p||_2 (i + 1) / 4): the logit bound, jointly over p
 constexpr uint32_t kHoleCode = 0xFFFFFFFFu;   // rg_event.code of an unused raw-log entry (no real row has every bit set: P < 2^29)
 // timing experiments of the walk (RECOGYM_ABLATE bits 16-22: see DESIGN.md) exist in -DRG_WALK_TIMING builds only
 #ifdef RG_WALK_TIMING
@@ -431,7 +434,7 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     float* gamma32 = w.take<float>(static_cast<size_t>(g.P_pad) * (g.KS ? g.KS : 1));
     float* mu32 = w.take<float>(g.P_pad ? g.P_pad : 1);
     float* gamma32t = w.take<float>(cache_wanted(c, g) ? static_cast<size_t>(g.n_chunks) * 2 * g.KH * 32 : 1);
-    float* stats = w.take<float>(2 * g.KH + 2);
+    float* stats = w.take<float>(2 * g.KH + 2 + kAhatGrid);
     const size_t PT = align_up(P, 64);
     double* gammaT = w.take<double>(K * PT);
     const uint32_t xkb = exact_kb_of(c.K);
@@ -479,6 +482,7 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint8_t* lr_dirty = w.take<uint8_t>(lr ? n : 1);
     uint32_t* lr_list = w.take<uint32_t>(lr ? n : 1);
     uint32_t* lr_cnt = w.take<uint32_t>(lr ? kMaxSteps + 2 : 1);
+    uint32_t* lr_part = w.take<uint32_t>(lr ? n * static_cast<size_t>(8 * (4 + 2 * 8)) : 1);
     uint32_t* park_list = w.take<uint32_t>(cache ? n + 64 + 64 * 16384 : 1);   // round 1's list, then round 2's hand-overs, 64-entry blocks per wave
     uint32_t* park_t = w.take<uint32_t>(cache ? n : 1);
     const bool rp = n >= repack_min_users();      // small runs never repack: no second copy
@@ -494,7 +498,7 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->f64_valid = f64_valid; d->exact_cnt_b = exact_cnt_b; d->cache_row = cache_row; d->cache_row_f = cache_row_f;
         d->park_list = park_list; d->park_t = park_t; d->sweep_only = 0;
         d->walk_hot = cache ? walk_hot : nullptr; d->walk_scp = walk_scp;
-        d->lr_action = lr_action; d->lr_dirty = lr ? lr_dirty : nullptr; d->lr_list = lr_list; d->lr_cnt = lr_cnt;
+        d->lr_action = lr_action; d->lr_dirty = lr ? lr_dirty : nullptr; d->lr_list = lr_list; d->lr_cnt = lr_cnt; d->lr_part = lr_part;
         d->uid = uid; d->omega_alt = omega_alt; d->hist_alt = hist_alt;
         d->lpv_alt = lpv_alt; d->uid_alt = uid_alt;
         d->gamma32 = gamma32; d->mu32 = mu32; d->gamma32t = gamma32t; d->stats = stats; d->omega = omega; d->list = list;
@@ -770,10 +774,12 @@ __global__ void __launch_bounds__(kBlock) k_table_stats(DevSim d) {
     for (uint32_t p = threadIdx.x; p < d.P; p += kBlock) {
         double x;
         if (which < 2 * d.KH) x = which < d.K ? fabs(d.gamma[static_cast<size_t>(p) * d.K + which]) : 0.0;
-        else if (which == 2 * d.KH) {
+        else if (which == 2 * d.KH || which >= 2 * d.KH + 2) {
             double q = 0.0;
             for (uint32_t k = 0; k < d.K; ++k) { const double g = d.gamma[static_cast<size_t>(p) * d.K + k]; q += g * g; }
             x = sqrt(q);
+            // the grid of the joint bound: |mu_p| + ||Gamma_p||_2 r at r = (i + 1) / 4 (ahat_of)
+            if (which >= 2 * d.KH + 2) x = fabs(d.mu_o[p]) + x * (static_cast<double>(which - (2 * d.KH + 2) + 1) * 0.25);
         } else x = fabs(d.mu_o[p]);
         m = fmax(m, x);
     }
@@ -1999,6 +2005,20 @@ constexpr double kDeltaPerRescale = 6.0e-6;
 // summation trees (~20 roundings) and the recompute's own fma/constant roundings remain: < 5e-6
 constexpr double kDeltaFixedBf16 = 1.0e-5;
 
+// Ahat: the bound on |mu_p + sum_{k <= j} Gamma_pk omega_k| over the products p and the partial sums j that the certificate's
+// accumulation budget (K + 5) 2^-24 Ahat is proportional to.  Three bounds, the smallest taken: per coordinate
+// (max|mu| + sum_k |omega_k| max_p |Gamma_pk| = mumax + absdot), Cauchy-Schwarz with the two maxima taken separately
+// (max|mu| + max_p ||Gamma_p|| r, r = ||omega||_2), and Cauchy-Schwarz JOINTLY over the products, max_p (|mu_p| + ||Gamma_p|| r)
+// — the product with the largest |mu| is not the one with the largest norm — read off a grid of r (k_table_stats; the
+// bound is nondecreasing in r: the grid point at or above r is taken).  C3: 42 -> ~33, i.e. delta -19 %.
+__device__ __forceinline__ float ahat_of(const DevSim& d, float mumax, float g2max, float absdot, float sq) {
+    const float r = sqrtf(sq) * 1.000001f;
+    float joint = mumax + g2max * r;
+    const float gi = fmaxf(ceilf(r * 4.0f), 1.0f);
+    if (gi <= static_cast<float>(kAhatGrid)) joint = fminf(joint, d.stats[2 * d.KH + 2 + static_cast<uint32_t>(gi) - 1u]);
+    return fminf(mumax + absdot, joint) * 1.00001f;
+}
+
 __device__ __forceinline__ float wave_scan_f32(float x, int lane) {
     for (int o = 1; o < 64; o <<= 1) {
         const float y = __shfl_up(x, o);
@@ -2255,7 +2275,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 2 : 1)) k_draw_mfma(DevSim
         }
         absdot += swap32(absdot);
         sq += swap32(sq);
-        const float Ahat = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
+        const float Ahat = ahat_of(d, mumax, g2max, absdot, sq);
 
         // ---- pass 1: MFMA logits of chunk c overlap the exp-sum of chunk c-1 (software pipeline) ----
         float q = -1.0e30f;        // per-USER reference in log2 units, constant within a super-chunk
@@ -2440,7 +2460,7 @@ __global__ void __launch_bounds__(kBlock, (N1 <= 6 ? 3 : 1)) k_draw_bf16(DevSim 
         }
         absdot += swap32(absdot);
         sq += swap32(sq);
-        const float Ahat = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
+        const float Ahat = ahat_of(d, mumax, g2max, absdot, sq);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         // ---- B fragments: lane (j, h) holds elements ke = 16 s + 8 h + e of its user's B rows ----
@@ -2699,7 +2719,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         absdot += swap32(absdot);
         sq += swap32(sq);
         absw += swap32(absw);
-        const float Ahat = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
+        const float Ahat = ahat_of(d, mumax, g2max, absdot, sq);
         const double delta_fixed = kDeltaFixedBf16 + (F16 ? f16_extra_delta(d, Ahat, absw) : 0.0);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -3007,7 +3027,7 @@ __global__ void __launch_bounds__(kBlock) k_draw_search(DevSim d, uint32_t t) {
         absdot += swap32(absdot);
         sq += swap32(sq);
         absw += swap32(absw);
-        const float Ahat = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
+        const float Ahat = ahat_of(d, mumax, g2max, absdot, sq);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         const SumsView view = sums_view(d, d.sc_scratch + wslot * kMaxSC * 32, d.chunk_scratch + wslot * d.n_chunks * 32, j, active, slot);
@@ -3064,7 +3084,7 @@ __global__ void __launch_bounds__(kBlock) k_cache_finalize(DevSim d) {
                 absw += fabsf(om[k]);
             }
         }
-        const float Ahat = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
+        const float Ahat = ahat_of(d, mumax, g2max, absdot, sq);
         double delta = static_cast<double>(d.K + 5) * 5.9604644775390625e-08 * static_cast<double>(Ahat) + kDeltaFixedBf16 +
                        kDeltaPerRescale * static_cast<double>(d.cache_resc[i]);
         if (d.f16) delta += 12.0 * 5.9604644775390625e-08 * static_cast<double>(Ahat) +
@@ -3461,7 +3481,7 @@ __global__ void __launch_bounds__(512 / UG, 1) k_draw_f16w(DevSim d, uint32_t t,
             absdot += swap32(absdot);
             sq += swap32(sq);
             absw += swap32(absw);
-            Ahat[g] = (mumax + fminf(absdot, g2max * sqrtf(sq))) * 1.00001f;
+            Ahat[g] = ahat_of(d, mumax, g2max, absdot, sq);
             delta_fixed[g] = kDeltaFixedBf16 + f16_extra_delta(d, Ahat[g], absw);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -3875,35 +3895,41 @@ __global__ void __launch_bounds__(kBlock) k_logreg_acts(DevSim d, uint32_t t) {
 #endif
 
 // ------------------------------------------------------------------------------------------
-// k_logreg_acts16 — the frozen LogReg act by SCREEN AND REFINE (BASELINE config 5: 10^4 classes, where an act streams the
-// coef^T rows of the user's viewed products: 40 KB per row in fp32, a 400 MB table that no cache holds).
+// k_logreg_screen + k_logreg_decide — the frozen LogReg act by SCREEN AND REFINE (BASELINE config 5: 10^4 classes, where an
+// act streams the coef^T rows of the user's viewed products: 40 KB per row in fp32, a 400 MB table that no cache holds).
 //   screen   every class score in fp32 from an fp16 copy of coef^T (20 KB per row; the 200 MB table fits the Infinity
 //            Cache): |s~_c - s_c| <= B for every class, B = sum_p views_p (2^-11 wmax_p + 2^-25)   (fp16 rounding, subnormals)
 //                                                      + (nd + 3) 2^-24 (max|b| + sum_p views_p wmax_p)   (fp32 accumulation).
-//            The argmax of the true scores is then among the CANDIDATES {c : s~_c >= max s~ - 2B}; they are collected while
-//            the classes stream by (against the running maximum: a superset), 64 at most;
-//   refine   more than one candidate (near-ties, exact ties): their scores in float64 in scipy's csr_matvecs order
-//            (products ascending, multiply then add, intercept last), a lane per candidate — nd scattered 8-byte reads
-//            each instead of a second pass over whole rows; first maximum wins, like numpy's argmax.
-// sklearn's predict() bit for bit, as before; more than 64 candidates (degenerate models): the float64 walk over all classes.
-// Needs n_classes % 8 == 0 (16-byte loads of 8 halves); the host keeps the fp32 kernel otherwise.
+//            The argmax of the true scores is then among the CANDIDATES {c : s~_c >= max s~ - 2B}.  A step of the lock-step
+//            loop has few acts (a few 10^3: about one per wave slot of the GPU), so its time is the latency of ONE act —
+//            20 class blocks of 512, each a round trip for the rows — not throughput: the classes of an act are split
+//            into kLrSplit RANGES, a wave per (act, range): it keeps the range's maximum and the classes within 2B of the
+//            running maximum (a superset of the range's candidates; at most kLrCand survive the range's final maximum);
+//   decide   a wave per act: the maximum over the ranges, the candidates within 2B of it (<= 64); one: certified; more (near-ties,
+//            exact ties): their scores in float64 in scipy's csr_matvecs order (products ascending, multiply then add,
+//            intercept last), a lane per candidate — nd scattered 8-byte reads each instead of a second pass over whole
+//            rows; first maximum wins, like numpy's argmax.
+// sklearn's predict() bit for bit, as before; a range with more than kLrCand candidates (degenerate models): the float64
+// walk over all classes.  Needs n_classes % 8 == 0 (16-byte loads of 8 halves); the host keeps the fp32 kernel otherwise.
 // ------------------------------------------------------------------------------------------
+constexpr uint32_t kLrSplit = 8, kLrCand = 8;
+// per act and range: {range maximum, candidates (0xFFFFFFFF: too many), 2B, -} then kLrCand x {class, score}
+constexpr uint32_t kLrPartWords = 4 + 2 * kLrCand;
 #if RG_HAS(6)
-__global__ void __launch_bounds__(kBlock) k_logreg_acts16(DevSim d, uint32_t t) {
-    __shared__ uint32_t s_cand[kBlock / 64][64];
-    __shared__ float s_cval[kBlock / 64][64];
+__global__ void __launch_bounds__(kBlock) k_logreg_screen(DevSim d, uint32_t t) {
+    __shared__ uint32_t s_cand[kBlock / 64][32];
+    __shared__ float s_cval[kBlock / 64][32];
     typedef _Float16 half8 __attribute__((ext_vector_type(8)));
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t n = d.lr_cnt[t];
     const uint32_t C = d.lr_n;
+    const uint32_t RC = ((C + kLrSplit - 1) / kLrSplit + 7u) & ~7u;       // classes per range (a multiple of 8)
     const uint32_t waves_total = gridDim.x * (kBlock / 64);
-    unsigned long long c_acts = 0, c_rows = 0, c_exact = 0;
-    for (uint32_t w = blockIdx.x * (kBlock / 64) + wave; w < n; w += waves_total) {
+    for (uint32_t item = blockIdx.x * (kBlock / 64) + wave; item < n * kLrSplit; item += waves_total) {
+        const uint32_t w = item / kLrSplit, r = item % kLrSplit;
         const uint32_t slot = d.lr_list[w];
-        const uint32_t uidx = d.uid[slot];
         const hent_t* hr = hist_row(d, slot) + 1;
         const uint32_t nd = h_cnt(hr[-1]);
-        c_acts += 1; c_rows += nd;
         // ---- the error bound of this history ----
         float A = 0.0f, V = 0.0f;
         for (uint32_t i = lane; i < nd; i += 64) {
@@ -3915,31 +3941,31 @@ __global__ void __launch_bounds__(kBlock) k_logreg_acts16(DevSim d, uint32_t t) 
         for (int o = 32; o > 0; o >>= 1) { A += __shfl_xor(A, o); V += __shfl_xor(V, o); }
         const float B = (A * 4.8828125e-4f + V * 2.98023224e-8f + static_cast<float>(nd + 3) * 5.9604644775390625e-08f * (d.lr_bmax + A)) * 1.02f;
         const float thr = 2.0f * B * 1.01f + 1e-30f;
-        // ---- screen ----
+        const uint32_t c_lo = r * RC, c_hi = min(c_lo + RC, C);
         float rb = -INFINITY;
         uint32_t n_cand = 0;
         bool overflow = false;
-        for (uint32_t c0 = 0; c0 < C; c0 += 512) {
+        for (uint32_t c0 = c_lo; c0 < c_hi && !overflow; c0 += 512) {
             const uint32_t c = c0 + 8u * static_cast<uint32_t>(lane);
-            const bool in = c < C;                                   // (C % 8 == 0: a lane's 8 classes are all in or all out)
-            const uint32_t cl = in ? c : 0u;
+            const bool in = c < c_hi;                                // (a lane's 8 classes are all in or all out)
+            const uint32_t cl = in ? c : c_lo;
             float acc[8];
             {
                 const float4 b0 = *reinterpret_cast<const float4*>(d.lr_intercept32 + cl);
                 const float4 b1 = *reinterpret_cast<const float4*>(d.lr_intercept32 + cl + 4);
                 acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
             }
-            for (uint32_t i0 = 0; i0 < nd; i0 += 4) {
-                half8 hv[4];
-                float cn[4];
+            for (uint32_t i0 = 0; i0 < nd; i0 += 8) {                // eight rows in flight
+                half8 hv[8];
+                float cn[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 8; ++e) {
                     const hent_t x = hr[min(i0 + e, nd - 1)];
                     cn[e] = i0 + e < nd ? static_cast<float>(h_cnt(x)) : 0.0f;
                     hv[e] = *reinterpret_cast<const half8*>(d.lr_coef16_t + static_cast<size_t>(h_prod(x)) * C + cl);
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 8; ++e)
                     if (i0 + e < nd) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) acc[j] = fmaf(cn[e], static_cast<float>(hv[e][j]), acc[j]);
@@ -3956,27 +3982,64 @@ __global__ void __launch_bounds__(kBlock) k_logreg_acts16(DevSim d, uint32_t t) 
             for (int j = 0; j < 8; ++j) {
                 const bool pass = in && acc[j] >= cut;
                 const unsigned long long pm = __ballot(pass);
-                if (pm) {
+                if (pm && !overflow) {
                     const uint32_t np = static_cast<uint32_t>(__popcll(pm));
-                    if (n_cand + np > 64u) overflow = true;
-                    else if (pass) {
-                        const uint32_t k = n_cand + prefix_in_mask(pm);
-                        s_cand[wave][k] = c + j; s_cval[wave][k] = acc[j];
+                    if (n_cand + np > 32u) overflow = true;
+                    else {
+                        if (pass) { const uint32_t k = n_cand + prefix_in_mask(pm); s_cand[wave][k] = c + j; s_cval[wave][k] = acc[j]; }
+                        n_cand += np;
                     }
-                    if (!overflow) n_cand += np;
                 }
             }
-            if (overflow) break;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        // ---- what survives the range's final maximum ----
+        uint32_t* part = d.lr_part + (static_cast<size_t>(w) * kLrSplit + r) * kLrPartWords;
+        const bool mine = !overflow && static_cast<uint32_t>(lane) < n_cand;
+        const bool keep = mine && s_cval[wave][mine ? lane : 0] >= rb - thr;
+        const unsigned long long km = __ballot(keep);
+        uint32_t n_keep = static_cast<uint32_t>(__popcll(km));
+        if (overflow || n_keep > kLrCand) n_keep = 0xFFFFFFFFu;
+        else if (keep) {
+            const uint32_t k = prefix_in_mask(km);
+            part[4 + 2 * k] = s_cand[wave][lane];
+            part[5 + 2 * k] = __builtin_bit_cast(uint32_t, s_cval[wave][lane]);
+        }
+        if (lane == 0) { part[0] = __builtin_bit_cast(uint32_t, rb); part[1] = n_keep; part[2] = __builtin_bit_cast(uint32_t, thr); part[3] = nd; }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_logreg_decide(DevSim d, uint32_t t) {
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t n = d.lr_cnt[t];
+    const uint32_t C = d.lr_n;
+    const uint32_t waves_total = gridDim.x * (kBlock / 64);
+    unsigned long long c_acts = 0, c_rows = 0, c_exact = 0;
+    for (uint32_t w = blockIdx.x * (kBlock / 64) + wave; w < n; w += waves_total) {
+        const uint32_t slot = d.lr_list[w];
+        const uint32_t uidx = d.uid[slot];
+        const hent_t* hr = hist_row(d, slot) + 1;
+        const uint32_t* part = d.lr_part + static_cast<size_t>(w) * kLrSplit * kLrPartWords;
+        // lane = (range, candidate index)
+        const uint32_t r = static_cast<uint32_t>(lane) / kLrCand, k = static_cast<uint32_t>(lane) % kLrCand;
+        const uint32_t* pr = part + r * kLrPartWords;
+        const float rmax = __builtin_bit_cast(float, pr[0]);
+        const uint32_t nk = pr[1];
+        const float thr = __builtin_bit_cast(float, part[2]);
+        const uint32_t nd = part[3];
+        c_acts += 1; c_rows += nd;
+        float gmax = rmax;
+        for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
+        const bool overflow = __ballot(nk == 0xFFFFFFFFu) != 0ull;
         uint32_t action;
         if (overflow) { action = logreg_act_wave(d, slot, lane); c_exact += 1; }
         else {
-            // ---- the candidates that survive the final maximum; one: certified; more: float64, scipy's order ----
-            const bool mine = static_cast<uint32_t>(lane) < n_cand;
-            const uint32_t cc = mine ? s_cand[wave][lane] : 0u;
-            const bool keep = mine && s_cval[wave][lane] >= rb - thr;
+            const bool have = k < nk;
+            const uint32_t cc = have ? pr[4 + 2 * k] : 0u;
+            const float cv = have ? __builtin_bit_cast(float, pr[5 + 2 * k]) : -INFINITY;
+            const bool keep = have && cv >= gmax - thr;
             const unsigned long long km = __ballot(keep);
             uint32_t best_c = 0xFFFFFFFFu;
             if (__popcll(km) == 1) best_c = static_cast<uint32_t>(__shfl(static_cast<int>(cc), __builtin_ctzll(km)));
@@ -4001,7 +4064,6 @@ __global__ void __launch_bounds__(kBlock) k_logreg_acts16(DevSim d, uint32_t t) 
             action = static_cast<uint32_t>(d.lr_classes[best_c]);
         }
         if (lane == 0) { d.lr_action[uidx] = action; d.lr_dirty[uidx] = 0; }
-        __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0 && c_acts) {
         atomicAdd(&d.counters[RG_CNT_LR_ACTS], c_acts);
@@ -4412,7 +4474,8 @@ __global__ void __launch_bounds__(kBlock) k_tail(DevSim d, uint32_t t0) {
 }
 search_kernel_t logreg_select_kernel() { return k_logreg_select; }
 search_kernel_t logreg_acts_kernel() { return k_logreg_acts; }
-search_kernel_t logreg_acts16_kernel() { return k_logreg_acts16; }
+search_kernel_t logreg_screen_kernel() { return k_logreg_screen; }
+search_kernel_t logreg_decide_kernel() { return k_logreg_decide; }
 advance_kernel_t advance_kernel() { return k_advance; }
 search_kernel_t tail_kernel() { return k_tail; }
 #endif
@@ -6694,8 +6757,12 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     if (d.policy == RG_POLICY_LOGREG_FROZEN) {
         // acts of the users whose view history changed since their last one (frozen LogReg at scale)
         hipLaunchKernelGGL(logreg_select_kernel(), dim3(grid_for(upper)), dim3(kBlock), 0, st, d, t);
-        hipLaunchKernelGGL(d.lr_coef16_t ? logreg_acts16_kernel() : logreg_acts_kernel(),
-                           dim3(grid_for(static_cast<uint64_t>(upper) / 4 + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
+        if (d.lr_coef16_t) {       // screen (a wave per act and class range), then decide (a wave per act)
+            hipLaunchKernelGGL(logreg_screen_kernel(), dim3(grid_for((static_cast<uint64_t>(upper) / 4 + 64) * kLrSplit, kBlock / 64)),
+                               dim3(kBlock), 0, st, d, t);
+            hipLaunchKernelGGL(logreg_decide_kernel(), dim3(grid_for(static_cast<uint64_t>(upper) / 4 + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
+        } else
+            hipLaunchKernelGGL(logreg_acts_kernel(), dim3(grid_for(static_cast<uint64_t>(upper) / 4 + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
     }
     if (int rc = prof_mark(sim, st)) return rc;
     // 2. click draws, transitions, drift, next lists, bandit + phantom rows
@@ -6983,7 +7050,7 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     s->walk_occ = 3;
     d.walk_bias = 8;
     d.walk_refill = 8;
-    d.walk_handover = 16;
+    d.walk_handover = 32;
     if (const char* e = getenv("RECOGYM_WALK_HANDOVER")) d.walk_handover = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_REFILL")) d.walk_refill = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_BIAS")) d.walk_bias = static_cast<uint32_t>(atoi(e));
@@ -7040,7 +7107,7 @@ int rg_sim_set_tables(rg_sim* sim, const double* d_gamma, const double* d_mu_org
         const size_t n = static_cast<size_t>(sim->d.P_pad) * sim->d.KS;
         hipLaunchKernelGGL(k_make_fp32_tables, dim3(grid_for(n)), dim3(kBlock), 0,
                            static_cast<hipStream_t>(stream), sim->d);
-        hipLaunchKernelGGL(k_table_stats, dim3(2 * sim->d.KH + 2), dim3(kBlock), 0,
+        hipLaunchKernelGGL(k_table_stats, dim3(2 * sim->d.KH + 2 + kAhatGrid), dim3(kBlock), 0,
                            static_cast<hipStream_t>(stream), sim->d);
         if (sim->d.N1)
             hipLaunchKernelGGL(k_make_split_table, dim3(grid_for(static_cast<size_t>(sim->d.P_pad) * (sim->d.RS / 2))),

@@ -39,3 +39,31 @@ def test_fp16_pieces_reconstruct_fp32():
     h1, h2 = split2(x)
     e = np.abs(x.astype(np.float64) - h1 - h2)
     assert (e <= np.maximum(2.0 ** -22 * np.abs(x), 2.0 ** -25)).all()
+
+
+@pytest.mark.parametrize('P, K, sigma_mu, scale', [(10000, 20, 3.0, 1.0), (2000, 20, 3.0, 2.5), (3000, 64, 3.0, 1.0), (500, 5, 30.0, 0.3)])
+def test_joint_logit_bound_dominates_every_partial_sum(P, K, sigma_mu, scale):
+    """`ahat_of` (recogym_hip.hip): the bound the certificate's accumulation budget (K + 5) 2^-24 Ahat is proportional to.
+    Restated here: max_p (|mu_p| + ||Gamma_p||_2 r) read off a grid of r = (i + 1) / 4 at the grid point at or above
+    ||omega||_2 (and the two older bounds).  It must dominate |mu_p + sum_{k <= j} Gamma_pk omega_k| for every product p and
+    every partial sum j, and it should be visibly tighter than taking the two maxima separately."""
+    rng = np.random.RandomState(P + K)
+    gamma = rng.randn(P, K)
+    mu = rng.randn(P) * sigma_mu
+    norm = np.sqrt((gamma ** 2).sum(axis=1))
+    mumax, g2max = np.abs(mu).max(), norm.max()
+    gmax_k = np.abs(gamma).max(axis=0)
+    grid = np.array([(np.abs(mu) + norm * ((i + 1) * 0.25)).max() for i in range(64)])
+    gains = []
+    for _ in range(200):
+        om = rng.randn(K) * scale
+        r = float(np.sqrt((om ** 2).sum())) * 1.000001
+        joint = mumax + g2max * r
+        gi = max(int(np.ceil(r * 4.0)), 1)
+        if gi <= 64:
+            joint = min(joint, grid[gi - 1])
+        ahat = min(mumax + float((np.abs(om) * gmax_k).sum()), joint)
+        partial = np.abs(mu[:, None] + np.cumsum(gamma * om[None, :], axis=1))
+        assert partial.max() <= ahat * (1 + 1e-12), (partial.max(), ahat)
+        gains.append(ahat / (mumax + min(float((np.abs(om) * gmax_k).sum()), g2max * r)))
+    assert np.mean(gains) <= 1.0 and min(gains) < 0.97         # never looser than before, usually tighter

@@ -1,51 +1,76 @@
 #!/usr/bin/env python
-"""profiles/r2/pmc_traffic.json from the counter summaries tools/r2_profiles.sh leaves under gpurun_out/r2_prof/
-(and copies of those summaries + kernel stats into profiles/r2/)."""
+"""profiles/<round>/pmc_traffic.json from the counter summaries tools/r3_profiles.sh leaves under gpurun_out/<round>_prof/
+(and copies of those summaries + kernel stats + bench lines into profiles/<round>/).
+
+Every PMC pass runs `bench.py --single-run`: exactly ONE simulation per arm inside the profiled process, so the counter
+value summed over a kernel's dispatches belongs to one run and is divided by THAT run's units (round 2 divided the sum
+over two runs by one run's events: 2x too much)."""
 import csv
 import json
 import os
 import shutil
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-O = os.path.join(ROOT, 'gpurun_out', 'r2_prof')
-P = os.path.join(ROOT, 'profiles', 'r2')
+RND = sys.argv[1] if len(sys.argv) > 1 else 'r3'
+O = os.path.join(ROOT, 'gpurun_out', f'{RND}_prof')
+P = os.path.join(ROOT, 'profiles', RND)
 
 
 def val(name, kern, counter):
+    tot, disp = 0.0, 0
     for r in csv.DictReader(open(f'{O}/{name}_counters.csv')):
         if kern in r['kernel'] and r['counter'] == counter:
-            return float(r['value'])
-    raise KeyError((name, kern, counter))
+            tot += float(r['value'])
+            disp += int(r['dispatches'])
+    if not disp:
+        raise KeyError((name, kern, counter))
+    return tot, disp
 
 
 def bench_line(name):
-    return json.loads(open(f'{O}/{name}.out').read().strip().splitlines()[-1])
+    return json.loads(open(f'{O}/{name}_bench_line.json').read().strip().splitlines()[-1])
 
 
-def entry(fetch_run, write_run, kern, units, unit_name, what):
-    f, w = val(fetch_run, kern, 'FETCH_SIZE'), val(write_run, kern, 'WRITE_SIZE')
-    return dict(unit_name=unit_name, units_in_profiled_run=units, fetch_size_kb=f, write_size_kb=w,
+def entry(workload, fetch_run, write_run, kern, units, unit_name, what):
+    (f, nf), (w, nw) = val(fetch_run, kern, 'FETCH_SIZE'), val(write_run, kern, 'WRITE_SIZE')
+    return dict(workload=workload, unit_name=unit_name, units_in_profiled_run=units, dispatches_in_profiled_run=nf,
+                fetch_size_kb=f, write_size_kb=w,
                 hbm_bytes_per_unit=(2 * f + w) * 1024 / units, fetch_bytes_per_unit_uncorrected=f * 1024 / units,
                 write_bytes_per_unit=w * 1024 / units,
-                source=f'profiles/r2/{fetch_run}_counters.csv + {write_run}_counters.csv ({what}; offline rocprofv3 --pmc, scaled to the run)')
+                source=f'profiles/{RND}/{fetch_run}_counters.csv + {write_run}_counters.csv ({what}; rocprofv3 --pmc on bench.py '
+                       f'--single-run: one run per pass)')
 
 
 def main():
     os.makedirs(P, exist_ok=True)
-    out = {'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KB), one counter per pass, --kernel-trace only (tools/r2_profiles.sh). '
-                   'hbm_bytes_per_unit = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / units: FETCH_SIZE doubled as MI355X_MICROARCH.md '
-                   'prescribes for gfx950 (128-byte requests tallied at 64 B; an upper bound for narrower accesses); the counters sit '
-                   'at the L2 <-> fabric boundary, Infinity-Cache hits included.  Measured on reduced runs (C3 / c3drift: 2 M users, '
-                   'C4: 300 k users) as per-unit figures; bench.py scales them to the benched run.',
+    out = {'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KB), one counter per pass, --kernel-trace only, on bench.py --single-run '
+                   '(ONE simulation per pass).  hbm_bytes_per_unit = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / units of that run: FETCH_SIZE '
+                   'doubled as MI355X_MICROARCH.md prescribes for gfx950 (128-byte requests tallied at 64 B; an upper bound for narrower '
+                   'accesses); the counters sit at the L2 <-> fabric boundary, Infinity-Cache hits included.  Measured on reduced runs '
+                   '(users stated per entry) as per-unit figures; bench.py scales them to the benched run.',
            'kernels': {}}
+    def try_add(key, fn):
+        try:
+            out['kernels'][key] = fn()
+        except Exception as e:      # a pass that was not taken this round
+            print('skipped', key, repr(e))
     d = bench_line('pmc_c3_fetch')
-    out['kernels']['k_walk'] = entry('pmc_c3_fetch', 'pmc_c3_write', 'k_walk', d['config']['events_per_step'], 'events', 'C3, 2 M users')
-    d = bench_line('pmc_c3drift_fetch')
-    out['kernels']['k_draw_bf16p'] = entry('pmc_c3drift_fetch', 'pmc_c3drift_write', 'k_draw_bf16p', d['kernels']['draw_sweep']['units'],
-                                           'swept draws', 'c3drift, 2 M users')
-    d = bench_line('pmc_c4_fetch')
-    out['kernels']['k_draw_*'] = entry('pmc_c4_fetch', 'pmc_c4_write', 'k_draw_f16w', d['kernels']['draw_sweep']['units'],
-                                       'swept draws', 'c4shard, 300 k users')
+    try_add('k_walk', lambda: entry('c3', 'pmc_c3_fetch', 'pmc_c3_write', 'k_walk', d['config']['events_per_step'], 'events',
+                                    f"C3, {d['config']['users_per_gpu']} users; k_walk2 rounds + k_walk_solo"))
+    try:
+        dd = bench_line('pmc_c3drift_fetch')
+        try_add('k_draw_bf16p', lambda: entry('c3drift', 'pmc_c3drift_fetch', 'pmc_c3drift_write', 'k_draw_bf16p',
+                                              dd['kernels']['draw_sweep']['units'], 'swept draws', f"c3drift, {dd['config']['users_per_gpu']} users"))
+    except Exception as e:
+        print('skipped c3drift', repr(e))
+    try:
+        d5 = bench_line('pmc_c5_fetch')
+        k5 = d5['kernels']['logreg_ips_frozen.logreg_acts']
+        try_add('k_logreg_select', lambda: entry('c5', 'pmc_c5_fetch', 'pmc_c5_write', 'k_logreg_acts', k5['units'], 'acts',
+                                                 f"c5, {d5['config']['users_per_gpu']} users per arm"))
+    except Exception as e:
+        print('skipped c5', repr(e))
     json.dump(out, open(os.path.join(P, 'pmc_traffic.json'), 'w'), indent=1)
     for k, v in out['kernels'].items():
         print(k, {a: (round(b, 1) if isinstance(b, float) else b) for a, b in v.items() if a != 'source'})
