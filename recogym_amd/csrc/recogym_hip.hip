@@ -165,7 +165,9 @@ struct DevSim {
     // every super-chunk (cache_chunk holds the chunk-level prefixes once k_cache_prefix ran)
     float* walk_hot; float* walk_scp;
     // user-major walk of the sigma_omega == 0 mode (k_walk): users parked at their first uncertified draw
-    uint32_t sweep_only;      // the step-0 sweep only fills the cache (no search, no rows): k_walk draws t = 0 too
+    uint32_t sweep_only;      // the step-0 sweep only fills the cache (no search, no rows): k_walk draws t = 0 too;
+                              // 2: ... and k_draw_bf16p stores the chunk sums as running PREFIXES on the reference in force (and the
+                              // prefix at every super-chunk end in walk_scp): k_walk2's form, no conversion pass
     uint32_t* park_list;      // [n_cap + 64] user indices, reserved in chunks of 64 (0xFFFFFFFF = unused entry)
     uint32_t* park_t;         // [n_cap] time of the parked draw
     uint8_t* f64_valid;       // [n_cap] exact_sums / exact_ref rows (indexed by user index in this mode) are valid
@@ -291,7 +293,7 @@ walk_kernel_t walk_kernel_for(const DevSim& d, int occ);   // part 7
 walk_kernel_t walk2_kernel_for(const DevSim& d, int occ);  // (nullptr: this configuration keeps k_walk)
 typedef void (*solo_kernel_t)(DevSim, uint32_t, uint32_t, uint32_t);
 solo_kernel_t solo_kernel_for(const DevSim& d);            // (nullptr: the last round is k_walk2's too)
-void (*cache_prefix_kernel())(DevSim);
+void (*cache_prefix_kernel())(DevSim, int);
 
 // ------------------------------------------------------------------------------------------
 // workspace carving (host)
@@ -2872,6 +2874,10 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         int n_resc = 0;
         float q_done = 0.0f;       // reference the pending sums were taken with
         float q_next = 0.0f;       // reference to switch to at the next super-chunk start
+        const bool prefix_mode = d.sweep_only == 2u && S == 1 && d.use_cache;
+        double run_pref = 0.0;     // prefix_mode: running prefix of the chunk sums ...
+        float q_run = 0.0f;        // ... on this reference (0 = not started: the first tile sets it)
+        float* scp_row = prefix_mode ? d.walk_scp + (active ? static_cast<size_t>(d.uid[slot]) : static_cast<size_t>(d.n_cap)) * kMaxSC : nullptr;
         uint32_t sc_cur = chunk_lo / d.sc_chunks;
         uint32_t sc_left = d.sc_chunks / 4;                    // tiles left in it
         float2 wlo = make_float2(0.f, 0.f);
@@ -2893,10 +2899,22 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             const float4 w4 = make_float4(wlo.x, wlo.y, s0, s1);
             // scratch layout [tile][user][4 chunks]; both lanes of the user hold the same sums: one of them stores
             // (unpredicated, the duplicate store doubled the kernel's write traffic: 3.1 KB per draw, profiles/r2)
+            if (prefix_mode) {
+                // k_walk2's form: the running prefix (float64) on the reference these sums were taken with, rounded to fp32;
+                // a reference switch rescales the running sum exactly (power of two) — the entries stored before it stay
+                // on theirs and are rescaled by k_cache_prefix for the (rare) users it happened to (cache_resc != 0)
+                if (q_done != q_run) { run_pref *= static_cast<double>(__builtin_amdgcn_exp2f(q_run - q_done)); q_run = q_done; }
+                const double r0 = run_pref + static_cast<double>(w4.x), r1 = r0 + static_cast<double>(w4.y);
+                const double r2 = r1 + static_cast<double>(w4.z), r3 = r2 + static_cast<double>(w4.w);
+                run_pref = r3;
+                if (h == 0) *reinterpret_cast<float4*>(view.chunk + static_cast<size_t>(ti) * view.tile_stride) =
+                    make_float4(static_cast<float>(r0), static_cast<float>(r1), static_cast<float>(r2), static_cast<float>(r3));
+            } else
             if (h == 0 && !RG_SWEEP_ABL(16u)) *reinterpret_cast<float4*>(view.chunk + static_cast<size_t>(ti) * view.tile_stride) = w4;
             wcmax = fmaxf(fmaxf(wcmax, fmaxf(w4.x, w4.y)), fmaxf(w4.z, w4.w));
             s_sc += static_cast<double>((w4.x + w4.y) + (w4.z + w4.w));
             if (--sc_left == 0) {
+                if (prefix_mode && h == 0) scp_row[sc_cur] = static_cast<float>(run_pref);
                 if (h == 0) view.rec[sc_cur * view.rec_stride] = make_float2(static_cast<float>(s_sc), q_done);
                 s_sc = 0.0;
                 // some logit is >= ~43 above the reference: re-reference from the next super-chunk
@@ -2988,6 +3006,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         }
         if (sc_left != d.sc_chunks / 4 && h == 0) {            // partial last super-chunk
             view.rec[sc_cur * view.rec_stride] = make_float2(static_cast<float>(s_sc), q_done);
+            if (prefix_mode) scp_row[sc_cur] = static_cast<float>(run_pref);
         }
         if (d.use_cache && S == 1 && active && h == 0) d.cache_resc[d.uid[slot]] = static_cast<uint8_t>(min(n_resc, 255));
         if (S == 1 && !RG_SWEEP_ABL(128u) && !d.sweep_only) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, delta_fixed, &view);
@@ -5130,7 +5149,10 @@ __host__ __device__ inline size_t walk2_wave_lds(int hist) { return (hist ? 16 *
 // The prefix form.  Eight lanes per user, 32 chunks per pass (one 128-byte line of the user's chunk sums): scaled to the
 // user's common reference Q (exact powers of two), summed in float64 in chunk order, stored back in place as fp32
 // prefixes; the prefix at the end of every super-chunk also goes to the user's scp row, the total into its hot row.
-__global__ void __launch_bounds__(kBlock) k_cache_prefix(DevSim d) {
+// fused = 1: k_draw_bf16p already stored prefixes (sweep_only = 2), each on the reference of its super-chunk: what is left is
+// the hot row's header and, for the users whose reference moved during the sweep (cache_resc != 0: rare), the exact rescaling
+// (powers of two) of their entries to the common reference.
+__global__ void __launch_bounds__(kBlock) k_cache_prefix(DevSim d, int fused) {
     const int lane = lane_id(), grp = lane >> 3, gl = lane & 7;
     const uint32_t n_groups = (d.n_users + 7) / 8;
     const uint32_t waves = gridDim.x * (kBlock / 64);
@@ -5143,6 +5165,28 @@ __global__ void __launch_bounds__(kBlock) k_cache_prefix(DevSim d) {
         float* cp = d.cache_chunk + row * d.n_chunks;
         float* scp = d.walk_scp + row * kMaxSC;
         double run = 0.0;
+        const bool moved = fused && act && d.cache_resc[row] != 0;
+        if (fused) {
+            if (moved) {
+                for (uint32_t c0 = 0; c0 < d.n_chunks; c0 += 32) {
+                    const uint32_t c = c0 + 4 * gl;
+                    if (c >= d.n_chunks) continue;
+                    const uint32_t sc = min(c / d.sc_chunks, kMaxSC - 1u);
+                    const uint32_t q = sc >> 2;
+                    const float4 o4 = q < 4 ? of0 : of1;
+                    const float ow = (q & 3) == 0 ? o4.x : (q & 3) == 1 ? o4.y : (q & 3) == 2 ? o4.z : o4.w;
+                    const uint32_t off = (__builtin_bit_cast(uint32_t, ow) >> (8 * (sc & 3))) & 0xFFu;
+                    const float f = off >= 127u ? 0.0f : __builtin_amdgcn_exp2f(-static_cast<float>(off));
+                    float4 w = *reinterpret_cast<const float4*>(cp + c);
+                    w.x *= f; w.y *= f; w.z *= f; w.w *= f;
+                    *reinterpret_cast<float4*>(cp + c) = w;
+                    if ((c + 4) % d.sc_chunks == 0 || c + 4 == d.n_chunks) scp[sc] = w.w;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            run = act ? static_cast<double>(scp[d.n_sc - 1]) : 0.0;
+        } else
         for (uint32_t c0 = 0; c0 < d.n_chunks; c0 += 32) {
             const uint32_t c = c0 + 4 * gl;
             const bool in = c < d.n_chunks;
@@ -6254,7 +6298,7 @@ walk_kernel_t walk2_kernel_for(const DevSim& d, int occ) {
     }
 #endif
 }
-void (*cache_prefix_kernel())(DevSim) { return k_cache_prefix; }
+void (*cache_prefix_kernel())(DevSim, int) { return k_cache_prefix; }
 #endif
 
 // closes the books of a walked run: no lock-step step holds events; step 1 exists, is empty and starts after the raw rows
@@ -6802,22 +6846,27 @@ int run_walk(rg_sim* sim, hipStream_t st) {
         return RG_OK;
     };
     if (int rc = mark(0)) return rc;
+    bool fused_prefix = false;
     // 1. every user's first product sweep: only the per-user sums are kept (no search, no rows)
     {
         DevSim ds = d;
-        ds.sweep_only = 1;
         const uint32_t tiles_up = (d.n_users + sim->draw_users - 1) / sim->draw_users;
         uint32_t S = tiles_up >= 131072u / sim->draw_users ? 1u : (262144u / sim->draw_users) / (tiles_up ? tiles_up : 1u);
         if (const char* e = getenv("RECOGYM_SLICES")) S = static_cast<uint32_t>(atoi(e));
         if (S > d.n_sc) S = d.n_sc;
         if (S < 1) S = 1;
+        // k_walk2 behind the fused (unsliced) form of the pipelined fp16 sweep of K <= 21: the sweep stores the sums in the
+        // walk's prefix form itself (no conversion pass over the 1.3 KB of chunk sums per user)
+        fused_prefix = sim->walk2 && S == 1 && sim->bf16_kernel == bf16p_kernel_for(d) && d.f16 && !d.wide && !getenv("RECOGYM_SWEEP_PREFIX_OFF");
+        ds.sweep_only = fused_prefix ? 2u : 1u;
         const int grid = sweep_grid(sim, static_cast<uint64_t>(tiles_up) * S, S);
         hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid), dim3(sim->draw_threads), sim->bf16_smem, st, ds, 0u, S);
     }
     if (int rc = mark(1)) return rc;
     hipLaunchKernelGGL(finalize_kernel_for(d), dim3(grid_for(d.n_users)), dim3(kBlock), 0, st, d);
     if (sim->walk2)      // the sums in prefix form, the memo rows emptied
-        hipLaunchKernelGGL(cache_prefix_kernel(), dim3(grid_for((static_cast<uint64_t>(d.n_users) + 7) / 8, kBlock / 64)), dim3(kBlock), 0, st, d);
+        hipLaunchKernelGGL(cache_prefix_kernel(), dim3(grid_for((static_cast<uint64_t>(d.n_users) + 7) / 8, kBlock / 64)), dim3(kBlock), 0, st, d,
+                           fused_prefix ? 1 : 0);
     if (int rc = mark(2)) return rc;
     // 2. round 1: every user from t = 0 to its end or to its first uncertified draw
     const size_t smem = sim->walk2 ? (kBlock / 64) * walk2_wave_lds(d.policy == RG_POLICY_ORGANIC_USER_COUNT)
@@ -6865,10 +6914,16 @@ int run_walk(rg_sim* sim, hipStream_t st) {
             HIP_TRY(hipMemsetAsync(d.counters + kCntWalkTicket, 0, sizeof(unsigned long long), st));
             const solo_kernel_t sk = (sim->walk2 && sim->walk_solo) ? solo_kernel_for(d) : nullptr;
             if (sk) {      // a wave per user, a lane per consecutive event
-                uint32_t blocks = (n_left + 3u) / 4u;
+                // >= 4 listed users per wave; rows reserved per wave in chunks of ~1/8 of what it will emit (a commit is <= 64
+                // rows; what a wave leaves of its last chunk are holes in the raw log: a few percent of this round's rows)
+                uint32_t blocks = (n_left + 15u) / 16u;
                 const uint32_t cap = static_cast<uint32_t>(sim->n_cus) * 8u;
                 if (blocks > cap) blocks = cap;
-                hipLaunchKernelGGL(sk, dim3(blocks), dim3(kBlock), 0, st, d, n_left, 256u, base3);
+                uint64_t chunk = static_cast<uint64_t>(n_left) * 150 / (static_cast<uint64_t>(blocks) * 4 * 8);
+                chunk = chunk / 64 * 64;
+                if (chunk < 64) chunk = 64;
+                if (chunk > 1024) chunk = 1024;
+                hipLaunchKernelGGL(sk, dim3(blocks), dim3(kBlock), 0, st, d, n_left, static_cast<uint32_t>(chunk), base3);
             } else launch_walk(n_left, 3, base3, base3);
         }
         return RG_OK;
