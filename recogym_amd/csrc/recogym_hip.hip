@@ -294,6 +294,7 @@ walk_kernel_t walk2_kernel_for(const DevSim& d, int occ);  // (nullptr: this con
 typedef void (*solo_kernel_t)(DevSim, uint32_t, uint32_t, uint32_t);
 solo_kernel_t solo_kernel_for(const DevSim& d);            // (nullptr: the last round is k_walk2's too)
 void (*cache_prefix_kernel())(DevSim, int);
+void (*exact_prefix_kernel())(DevSim, uint32_t);
 
 // ------------------------------------------------------------------------------------------
 // workspace carving (host)
@@ -2904,11 +2905,14 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
                 // a reference switch rescales the running sum exactly (power of two) — the entries stored before it stay
                 // on theirs and are rescaled by k_cache_prefix for the (rare) users it happened to (cache_resc != 0)
                 if (q_done != q_run) { run_pref *= static_cast<double>(__builtin_amdgcn_exp2f(q_run - q_done)); q_run = q_done; }
-                const double r0 = run_pref + static_cast<double>(w4.x), r1 = r0 + static_cast<double>(w4.y);
-                const double r2 = r1 + static_cast<double>(w4.z), r3 = r2 + static_cast<double>(w4.w);
-                run_pref = r3;
+                // (fp32 inside the tile, on the fp32 rounding of the float64 running prefix: <= 5 roundings of 2^-24 relative to the
+                // prefix — part of the 2^-21 the header's delta grants the stored prefixes — and ONE float64 add per tile: this
+                // kernel is bound by its VALU work)
+                const float base = static_cast<float>(run_pref);
+                const float p1 = w4.x, p2 = p1 + w4.y, p3 = p2 + w4.z, p4 = p3 + w4.w;
+                run_pref += static_cast<double>(p4);
                 if (h == 0) *reinterpret_cast<float4*>(view.chunk + static_cast<size_t>(ti) * view.tile_stride) =
-                    make_float4(static_cast<float>(r0), static_cast<float>(r1), static_cast<float>(r2), static_cast<float>(r3));
+                    make_float4(base + p1, base + p2, base + p3, base + p4);
             } else
             if (h == 0 && !RG_SWEEP_ABL(16u)) *reinterpret_cast<float4*>(view.chunk + static_cast<size_t>(ti) * view.tile_stride) = w4;
             wcmax = fmaxf(fmaxf(wcmax, fmaxf(w4.x, w4.y)), fmaxf(w4.z, w4.w));
@@ -5217,10 +5221,10 @@ __global__ void __launch_bounds__(kBlock) k_cache_prefix(DevSim d, int fused) {
         if (act) {
             for (uint32_t sc = d.n_sc + gl; sc < kMaxSC; sc += 8) scp[sc] = INFINITY;     // never counted
             if (gl == 0) {
-                // S~ as the search sees it (the last prefix), the certificate's delta + the roundings of the stored prefixes
-                // (2^-24 each, relative to the prefix: the same kind of error the budget is made of), Q, an empty memo
+                // S~ as the search sees it (the last prefix), the certificate's delta + 2^-21 for the roundings of the stored
+                // prefixes (<= 5 of 2^-24 each, relative to the prefix: the same kind of error the budget is made of), Q, an empty memo
                 float4* hot = reinterpret_cast<float4*>(d.walk_hot + row * 32);
-                hot[0] = make_float4(static_cast<float>(run), hdr.y * 1.000001f + 2.4e-7f, hdr.x, __builtin_bit_cast(float, 0u));
+                hot[0] = make_float4(static_cast<float>(run), hdr.y * 1.000001f + 4.8e-7f, hdr.x, __builtin_bit_cast(float, 0u));
             }
         }
     }
@@ -5234,6 +5238,57 @@ __device__ __forceinline__ float f32_up(float x) {
 __device__ __forceinline__ float f32_down(float x) {
     const uint32_t b = __builtin_bit_cast(uint32_t, x);
     return x == 0.0f ? __builtin_bit_cast(float, 0x80000001u) : __builtin_bit_cast(float, x > 0.0f ? b - 1u : b + 1u);
+}
+
+// The float64 pick on sums stored as PREFIXES (k_exact_prefix): the 64-product chunk by counting the prefixes <= u total
+// (three ballots instead of three wave scans), then its products walked in product order as exact_pick_wave does.
+__device__ __forceinline__ uint32_t exact_pick_pfx(const DevSim& d, const double* pfx, const double* om, double M, double u, int lane) {
+    const uint32_t n_cc = d.PT / 64;
+    const double total = pfx[n_cc - 1];
+    const double target = u * total;
+    uint32_t cnt = 0;
+    for (uint32_t c0 = 0; c0 < n_cc; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        cnt += static_cast<uint32_t>(__popcll(__ballot(c < n_cc && pfx[c] <= target)));
+    }
+    const uint32_t ccstar = min(cnt, n_cc - 1u);            // (u * total rounded up to total: the last chunk)
+    double acc = ccstar ? pfx[ccstar - 1] : 0.0;
+    uint32_t v = min(ccstar * 64 + 63, d.P - 1);           // if rounding leaves no hit: the chunk's last product
+    const uint32_t p = ccstar * 64 + lane;
+    const double* g = d.gammaT + p;                        // PT columns: always in range
+    double lg = 0.0;
+    for (uint32_t k0 = 0; k0 < d.K; k0 += 8) {             // same association as the oracle (k ascending)
+        double gv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[j] = g[static_cast<size_t>(min(k0 + j, d.K - 1)) * d.PT];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (k0 + j < d.K) lg += gv[j] * om[k0 + j];
+    }
+    lg = p < d.P ? lg + d.mu_o[p] : -INFINITY;
+    const double inc = wave_scan(exp64(lg - M), lane);
+    const unsigned long long hit = __ballot(p < d.P && acc + inc > target);
+    if (hit) v = ccstar * 64 + static_cast<uint32_t>(__builtin_ctzll(hit));
+    return v;
+}
+
+// exact_sums rows of the listed users (the float64 batch between rounds 1 and 2 just took them) -> inclusive prefixes, in
+// place, in exact_pick_wave's association (a wave scan per block of 64 sums, the blocks in order).  A wave per user.
+__global__ void __launch_bounds__(kBlock) k_exact_prefix(DevSim d, uint32_t n_list) {
+    const int lane = lane_id();
+    const uint32_t n_cc = d.PT / 64;
+    const uint32_t waves = gridDim.x * (kBlock / 64);
+    for (uint32_t w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < n_list; w += waves) {
+        const uint32_t slot = d.park_list[w];
+        if (slot == 0xFFFFFFFFu) continue;
+        double* row = d.exact_sums + static_cast<size_t>(slot) * n_cc;
+        double run = 0.0;
+        for (uint32_t c0 = 0; c0 < n_cc; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            const double incl = wave_scan(c < n_cc ? row[c] : 0.0, lane);
+            if (c < n_cc) row[c] = run + incl;
+            run += __shfl(incl, 63);
+        }
+    }
 }
 
 // (the float64 pick as a noinline CALL freed ~40 registers of the walk's loop, but at four blocks per CU — 128 VGPRs, the loop
@@ -5272,7 +5327,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
     uint32_t park_next = 0, park_end = 0;
     bool exhausted = false;
     // wave-uniform tallies (scalar registers): events are counted by ballots
-    uint32_t c_org = 0, c_ban = 0, c_clicks = 0, c_ph = 0, c_pick = 0, c_sweeps = 0, c_maxt = 0, c_limit = 0, c_hit = 0;
+    uint32_t c_org = 0, c_ban = 0, c_clicks = 0, c_ph = 0, c_pick = 0, c_sweeps = 0, c_maxt = 0, c_limit = 0, c_hit = 0, c_anch = 0;
 
     for (;;) {
         asm volatile("" : "+s"(kargs));
@@ -5403,7 +5458,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
         } else if (kind == 1) {
             // =========================== organic draw by the search over the user's prefix sums ===========================
             const bool is_s = st == kWSlow;
-            const bool search = is_s && !pend;
+            const bool search = is_s;            // (a parked draw too: its chunk is where the anchored certificate starts)
             const size_t row = search ? slot : d.n_cap;
             const float4* hp = reinterpret_cast<const float4*>(d.walk_hot + row * 32);
             const float4 h0 = hp[0];
@@ -5453,12 +5508,12 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             }
             const double pb = static_cast<double>(pbf);
             const float rem = static_cast<float>(tau - pb);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            // ---- the 32 products of the chunk: eight searching users per pass, eight lanes per user, four products per lane ----
-            {
+            // ---- the 32 products of a chunk: eight users per pass, eight lanes per user, four products per lane.  For every
+            // lane that wants it: mboxf[lane] = {index in the chunk of the first product whose fp32 prefix exceeds rem_f, the
+            // prefix before it, the prefix with it}, or {-1, chunk total, chunk total} ----
+            auto chunk_pass = [&](bool want, uint32_t chunk, float rem_f) {
                 const int grp = lane >> 3, gl = lane & 7;
-                unsigned long long todo = __ballot(search);
+                unsigned long long todo = __ballot(want);
                 while (todo) {
                     int src = -1;
 #pragma unroll
@@ -5469,9 +5524,9 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     }
                     const bool has = src >= 0;
                     const int s2 = has ? src : 0;
-                    const uint32_t cs = static_cast<uint32_t>(__shfl(static_cast<int>(c_star), s2));
+                    const uint32_t cs = static_cast<uint32_t>(__shfl(static_cast<int>(chunk), s2));
                     const float Qs = __shfl(Q, s2);
-                    const float rems = __shfl(rem, s2);                  // what is left of u S~ at the chunk's start
+                    const float rems = __shfl(rem_f, s2);                // what is left of u S~ at the chunk's start
                     const float4* gp = reinterpret_cast<const float4*>(d.gamma32t + (static_cast<size_t>(cs) * K2) * 32) + gl;
                     float4 l = *(reinterpret_cast<const float4*>(d.mu32 + cs * 32) + gl);
 #pragma unroll
@@ -5498,8 +5553,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     }
                     float ex = __shfl_up(inc, 1, 8);
                     if (gl == 0) ex = 0.0f;
-                    // the product in fp32 (which product is only a proposal: the certificate below is taken in float64 from
-                    // the two prefixes around it and rejects a wrong one)
+                    // the product in fp32 (which product is only a proposal: the certificate is taken in float64 from the two
+                    // prefixes around it and rejects a wrong one)
                     const float x0 = ex + q0, x1 = ex + q1, x2 = ex + q2, x3 = ex + q3;
                     const int j0 = x0 > rems ? 0 : x1 > rems ? 1 : x2 > rems ? 2 : x3 > rems ? 3 : -1;
                     const unsigned long long hits = __ballot(has && j0 >= 0);
@@ -5511,12 +5566,15 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                                 mboxf[src * 3 + 1] = j0 == 0 ? ex : j0 == 1 ? x0 : j0 == 2 ? x1 : x2;
                                 mboxf[src * 3 + 2] = j0 == 0 ? x0 : j0 == 1 ? x1 : j0 == 2 ? x2 : x3;
                             }
-                        } else if (gl == 0) { mboxf[src * 3] = -1.0f; mboxf[src * 3 + 1] = 0.0f; mboxf[src * 3 + 2] = 0.0f; }
+                        } else if (gl == 7) { mboxf[src * 3] = -1.0f; mboxf[src * 3 + 1] = inc; mboxf[src * 3 + 2] = inc; }
                     }
                 }
-            }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            };
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
+            chunk_pass(search, c_star, rem);
             bool ok = false;
             if (search) {
                 const int idx = static_cast<int>(mboxf[lane * 3]);
@@ -5546,11 +5604,54 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     reinterpret_cast<uint32_t*>(hf)[3] = n_hot + 1u;
                 }
             }
-            // ---- uncertified: float64 pick from the user's stored sums, or park the user until they exist ----
+            // ---- uncertified: with the user's float64 sums, or park the user until they exist ----
             const bool need64 = is_s && !ok;
             const bool have64 = need64 && d.f64_valid[slot] != 0;
             parked = need64 && !have64;
-            unsigned long long picks = __ballot(have64);
+            // ANCHORED certificate.  The float64 sums of a user (k_exact_prefix left them as prefixes at the end of every 64
+            // products, on the same reference Q as the fp32 exps) pin the prefix at the start of the draw's 64-product chunk to
+            // ~1e-13 S; only the part INSIDE the chunk is fp32, so the same test with delta applied to that part alone — and
+            // 1e-12 S of slack for the anchors' own roundings — certifies all but ~2.5 % of the draws the plain certificate
+            // rejected (those need a heavy product earlier in the same chunk).  Lane-parallel, like the search: what is left
+            // for the wave-serial float64 pick below is ~0.1 % of the organic draws instead of 3 %.
+            bool got64 = false;
+            if (__ballot(have64)) {
+                const double* pfx = d.exact_sums + static_cast<size_t>(have64 ? slot : 0u) * n_cc;
+                const double S64 = pfx[n_cc - 1];
+                const double target = u_org * S64;
+                uint32_t cc = min(c_star >> 1, n_cc - 1u);               // the fp32 search's chunk is (nearly always) the float64 one
+                double hi64 = pfx[cc], lo64 = cc ? pfx[cc - 1] : 0.0;
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    if (!(lo64 <= target) && cc > 0u) { --cc; hi64 = lo64; lo64 = cc ? pfx[cc - 1] : 0.0; }
+                    else if (!(target < hi64) && cc + 1u < n_cc) { ++cc; lo64 = hi64; hi64 = pfx[cc]; }
+                }
+                const bool anchored = have64 && lo64 <= target && target < hi64;
+                const float rem1 = static_cast<float>(target - lo64);
+                chunk_pass(anchored, 2u * cc, rem1);
+                const int idx1 = anchored ? static_cast<int>(mboxf[lane * 3]) : 0;
+                const float a1 = mboxf[lane * 3 + 1], b1 = mboxf[lane * 3 + 2];
+                const bool in2 = anchored && idx1 < 0;
+                __builtin_amdgcn_wave_barrier();
+                chunk_pass(in2, 2u * cc + 1u, rem1 - a1);
+                if (anchored) {
+                    int ix = idx1;
+                    float fa = a1, fb = b1;
+                    uint32_t va = 64u * cc + static_cast<uint32_t>(max(idx1, 0));
+                    if (in2) {
+                        ix = static_cast<int>(mboxf[lane * 3]);
+                        fa = a1 + mboxf[lane * 3 + 1]; fb = a1 + mboxf[lane * 3 + 2];
+                        va = 64u * cc + 32u + static_cast<uint32_t>(max(ix, 0));
+                    }
+                    const double slack = 1.0e-12 * S64;
+                    const bool lo_ok = va == 0u || lo64 + static_cast<double>(fa) * (1.0 + delta) + slack < target;
+                    const bool hi_ok = va == d.P - 1 || target + slack < lo64 + static_cast<double>(fb) * (1.0 - delta);
+                    got64 = ix >= 0 && va < d.P && lo_ok && hi_ok;
+                    if (got64) v = va;
+                }
+            }
+            c_anch += static_cast<uint32_t>(__popcll(__ballot(got64)));
+            unsigned long long picks = __ballot(have64 && !got64);
             c_pick += static_cast<uint32_t>(__popcll(picks));
             while (picks) {
                 const int L = __builtin_ctzll(picks);
@@ -5558,8 +5659,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                 const uint32_t s_slot = static_cast<uint32_t>(__shfl(static_cast<int>(slot), L));
                 const double s_u = __shfl(u_org, L);
                 const double M = static_cast<double>(d.exact_ref[s_slot]) * 0.69314718055994530942;
-                const uint32_t pv = exact_pick_call(d, d.exact_sums + static_cast<size_t>(s_slot) * n_cc,
-                                                    d.omega + static_cast<size_t>(s_slot) * d.OMS, M, s_u, lane);
+                const uint32_t pv = exact_pick_pfx(d, d.exact_sums + static_cast<size_t>(s_slot) * n_cc,
+                                                   d.omega + static_cast<size_t>(s_slot) * d.OMS, M, s_u, lane);
                 if (lane == L) v = pv;
                 __builtin_amdgcn_wave_barrier();
             }
@@ -5826,6 +5927,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             if (c_pick) atomicAdd(&d.counters[RG_CNT_EXACT_DRAWS], static_cast<unsigned long long>(c_pick));
             if (c_sweeps) atomicAdd(&d.counters[RG_CNT_EXACT_SWEEPS], static_cast<unsigned long long>(c_sweeps));
             if (c_hit) atomicAdd(&d.counters[kCntWalkHits], static_cast<unsigned long long>(c_hit));
+            if (c_anch) atomicAdd(&d.counters[RG_CNT_ANCHORED], static_cast<unsigned long long>(c_anch));
             if (c_maxt) atomicMax(&d.counters[kCntTailMaxT], static_cast<unsigned long long>(c_maxt));
             if (c_limit) atomicAdd(&d.counters[kCntTailLimit], static_cast<unsigned long long>(c_limit));
         }
@@ -6205,8 +6307,8 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
                     picks &= picks - 1;
                     const double s_u = __shfl(u_org, L);
                     const double M = static_cast<double>(d.exact_ref[slot]) * 0.69314718055994530942;
-                    const uint32_t pv = exact_pick_call(d, d.exact_sums + static_cast<size_t>(slot) * n_cc,
-                                                        d.omega + static_cast<size_t>(slot) * d.OMS, M, s_u, lane);
+                    const uint32_t pv = exact_pick_pfx(d, d.exact_sums + static_cast<size_t>(slot) * n_cc,
+                                                       d.omega + static_cast<size_t>(slot) * d.OMS, M, s_u, lane);
                     if (lane == L) v = pv;
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -6299,6 +6401,7 @@ walk_kernel_t walk2_kernel_for(const DevSim& d, int occ) {
 #endif
 }
 void (*cache_prefix_kernel())(DevSim, int) { return k_cache_prefix; }
+void (*exact_prefix_kernel())(DevSim, uint32_t) { return k_exact_prefix; }
 #endif
 
 // closes the books of a walked run: no lock-step step holds events; step 1 exists, is empty and starts after the raw rows
@@ -6903,6 +7006,8 @@ int run_walk(rg_sim* sim, hipStream_t st) {
     // round 2 over the parked (and handed-over) users; what IT hands over is appended behind them for round 3
     auto later_rounds = [&](uint32_t n_list) -> int {
         const uint32_t base3 = (n_list + 63u) & ~63u;
+        if (sim->walk2)      // the listed users' float64 sums as prefixes (anchored certificate, prefix pick)
+            hipLaunchKernelGGL(exact_prefix_kernel(), dim3(grid_for(n_list, kBlock / 64)), dim3(kBlock), 0, st, d, n_list);
         HIP_TRY(hipMemsetAsync(d.counters + kCntWalkTicket, 0, sizeof(unsigned long long), st));
         HIP_TRY(hipMemsetAsync(d.counters + kCntParkCnt, 0, sizeof(unsigned long long), st));
         launch_walk(n_list, 2, 0u, base3);

@@ -230,7 +230,9 @@ class Simulator:
         names = ['organic', 'bandit', 'clicks', 'phantom', 'live', 'step', 'log_rows',
                  'log_dropped', 'exact_draws', 'hist_overflow', 'exact_sweeps', 'exact_overflow', 'lr_acts', 'lr_rows',
                  'lr_exact', 'memo_hits']
-        return {k: int(out[i]) for i, k in enumerate(names)}
+        res = {k: int(out[i]) for i, k in enumerate(names)}
+        res['anchored'] = int(out[_abi.RG_CNT_ANCHORED])
+        return res
 
     def set_profiling(self, on=True):
         _abi.check(self.lib.rg_sim_set_profiling(self._h, int(on)), 'rg_sim_set_profiling')

@@ -38,7 +38,7 @@ for wl in workloads:
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         c = sim.counters()
         out[name] = dict(workload=wl, path=name, env=env, p_click_export=p_click, users=n, seconds=round(dt, 3),
-                         counters={k: c[k] for k in ('organic', 'bandit', 'clicks', 'phantom', 'exact_draws', 'exact_sweeps',
+                         counters={k: c[k] for k in ('organic', 'bandit', 'clicks', 'phantom', 'exact_draws', 'exact_sweeps', 'anchored', 'memo_hits',
                                                      'exact_overflow', 'hist_overflow', 'log_dropped', 'live')},
                          digest=sim.log_digest())
         print(json.dumps(out[name]), flush=True)
