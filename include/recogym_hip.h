@@ -131,8 +131,9 @@ typedef struct rg_event {
 #define RG_CNT_LR_ROWS 13       /* ... and the coef^T rows (viewed products) those acts read */
 #define RG_CNT_LR_EXACT 14      /* ... acts the fp32 scores could not certify (decided by float64 scores) */
 #define RG_CNT_MEMO_HITS 15     /* sigma_omega = 0, user-major walk: organic draws answered by the user's memo of certified draws */
-#define RG_CNT_ANCHORED 24      /* sigma_omega = 0 walk: draws the plain certificate rejected and the float64-ANCHORED one accepted
-                                   (the user's float64 prefix at the start of the draw's 64-product chunk + fp32 inside it) */
+#define RG_CNT_ANCHORED 24      /* sigma_omega = 0 walk: the part of RG_CNT_EXACT_DRAWS that the float64-ANCHORED certificate resolved
+                                   (the user's float64 prefix at the start of the draw's 64-product chunk + fp32 inside it) instead
+                                   of a float64 walk of the chunk's products */
 #define RG_CNT_N 32             /* out[] of rg_sim_read_counters; slots 16..23 are internal */
 
 typedef struct rg_sim rg_sim;

@@ -206,6 +206,12 @@ struct DevSim {
     uint32_t* lr_list;        // [n_cap] slots whose act is to be computed this step
     uint32_t* lr_cnt;         // [kMaxSteps + 2]
     uint32_t* lr_part;        // [n_cap][kLrSplit][kLrPartWords]: the screen's result per listed act and class range
+    // omega drift of a lock-step step (sigma_omega > 0): k_advance lists the users whose transition drifts omega, k_drift applies
+    // the K normals a lane per (user, Box-Muller pair) — ~2 600 float64 instructions per drifting user that only ~22 % of
+    // k_advance's lanes would execute (the others idle through them)
+    uint32_t* drift_list;     // [n_cap] slots
+    double* drift_sig;        // [n_cap] sigma_omega x time delta of the entry (NormalTimeGenerator only; else sigma_omega)
+    uint32_t* drift_cnt;      // [kMaxSteps + 2]
     unsigned long long* counters;   // [RG_CNT_N]
     // log
     rg_event* log; uint64_t log_cap;
@@ -283,7 +289,8 @@ finalize_kernel_t finalize_kernel_for(const DevSim& d);    // part 4
 cached_kernel_t cached_kernel_for(const DevSim& d);
 draw_kernel_t bf16p_kernel_for(const DevSim& d);
 draw_kernel_t f16w_kernel_for(const DevSim& d);            // part 5
-search_kernel_t logreg_select_kernel();                    // part 6
+search_kernel_t drift_kernel();                            // part 6
+search_kernel_t logreg_select_kernel();
 search_kernel_t logreg_acts_kernel();
 search_kernel_t logreg_screen_kernel();
 search_kernel_t logreg_decide_kernel();
@@ -462,6 +469,10 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     unsigned long long* hist = w.take<unsigned long long>(hc * n_pad);
     uint32_t* lpv = w.take<uint32_t>(c.policy == RG_POLICY_LAST_VIEW_TABLE ? n : 1);
     unsigned long long* counters = w.take<unsigned long long>(RG_CNT_N);
+    const bool drifts = c.sigma_omega != 0.0;
+    uint32_t* drift_list = w.take<uint32_t>(drifts ? n : 1);
+    double* drift_sig = w.take<double>(drifts && c.time_mode ? n : 1);
+    uint32_t* drift_cnt = w.take<uint32_t>(drifts ? kMaxSteps + 2 : 1);
     uint32_t* uid = w.take<uint32_t>(n);
     double* phantom_ps = w.take<double>(n);
     double* utime = w.take<double>(c.time_mode ? n : 1);
@@ -495,6 +506,7 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint32_t* uid_alt = w.take<uint32_t>(rp ? n : 1);
     if (d) {
         d->phantom_ps = phantom_ps; d->utime = utime; d->phantom_time = phantom_time;
+        d->drift_list = drift_list; d->drift_sig = drift_sig; d->drift_cnt = drift_cnt;
         d->use_cache = cache ? 1u : 0u; d->cache_rec = cache_rec; d->cache_chunk = cache_chunk; d->cache_resc = cache_resc;
         d->cache_sub = sub ? cache_sub : nullptr;
         d->beta32 = cache ? beta32 : nullptr; d->KB4 = static_cast<uint32_t>(KB4);
@@ -4103,7 +4115,7 @@ constexpr int kAdvBlock = 256;
 #if RG_HAS(6)
 __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, const int32_t* actions) {
     constexpr int kSub = 1;                     // block iterations that share one reservation
-    __shared__ uint32_t s_cnt_o[kSub][kAdvBlock / 64], s_cnt_b[kSub][kAdvBlock / 64], s_base_o, s_base_b;
+    __shared__ uint32_t s_cnt_o[kSub][kAdvBlock / 64], s_cnt_b[kSub][kAdvBlock / 64], s_cnt_d[kSub][kAdvBlock / 64], s_base_o, s_base_b, s_base_d;
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
     const uint32_t n_b = d.step_cnt[2 * t + RG_STATE_BANDIT];
     const uint32_t n = n_o + n_b;
@@ -4120,12 +4132,16 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
     for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
       int ns_j[kSub];
       uint32_t slot_j[kSub];
-      unsigned long long mo_j[kSub], mb_j[kSub];
+      unsigned long long mo_j[kSub], mb_j[kSub], md_j[kSub];
+      bool dr_j[kSub];
+      double ds_j[kSub];
 #pragma unroll
       for (int sub = 0; sub < kSub; ++sub) {
         const uint32_t i = (it * kSub + sub) * kAdvBlock + threadIdx.x;
         int ns = RG_STATE_STOP;       // inactive lanes look dead
         uint32_t slot = 0;
+        bool drift_me = false;
+        double drift_sig = 0.0;
         uint32_t lr_a = 0;            // RG_POLICY_LOGREG_FROZEN: this user's action for its current view history
         if (d.policy == RG_POLICY_LOGREG_FROZEN && i < n)
             // the policy reads only the view history: its act was computed by k_logreg_acts when the history last changed
@@ -4218,16 +4234,10 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                 d.utime[uidx] = d.utime[uidx] + dt;
                 omega_k = dt == 0.0 ? 1.0 : dt;
             }
-            const double sig = d.sigma_omega * omega_k;
-            if (d.sigma_omega != 0.0 && (d.change_omega_for_bandits || ns == RG_STATE_ORGANIC)) {
-                for (uint32_t j = 0; 2 * j < d.K; ++j) {
-                    double z0, z1;
-                    normal_pair(d.seed, user, t, j, RG_DRAW_DRIFT, &z0, &z1);
-                    double* o0 = d.omega + static_cast<size_t>(slot) * d.OMS + 2 * j;
-                    *o0 = *o0 + sig * z0;
-                    if (2 * j + 1 < d.K) { double* o1 = o0 + 1; *o1 = *o1 + sig * z1; }
-                }
-            }
+            // omega drifts when the DRAWN next state is organic (reco_env_v1.py:95-98; the click override below does not
+            // redraw it): listed for k_drift, which runs right behind this kernel
+            drift_me = d.sigma_omega != 0.0 && (d.change_omega_for_bandits || ns == RG_STATE_ORGANIC);
+            drift_sig = d.sigma_omega * omega_k;
             if (click) ns = RG_STATE_ORGANIC;          // abstract.py:180-181
             const bool organic_only = (d.first_user + uidx) < d.organic_only_below;
             if (organic_only && ns != RG_STATE_ORGANIC) {
@@ -4253,17 +4263,20 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
         ns_j[sub] = ns; slot_j[sub] = slot;
         mo_j[sub] = __ballot(ns == RG_STATE_ORGANIC);
         mb_j[sub] = __ballot(ns == RG_STATE_BANDIT);
-        if (lane == 0) { s_cnt_o[sub][wave] = __popcll(mo_j[sub]); s_cnt_b[sub][wave] = __popcll(mb_j[sub]); }
+        md_j[sub] = __ballot(drift_me);
+        dr_j[sub] = drift_me; ds_j[sub] = drift_sig;
+        if (lane == 0) { s_cnt_o[sub][wave] = __popcll(mo_j[sub]); s_cnt_b[sub][wave] = __popcll(mb_j[sub]); s_cnt_d[sub][wave] = __popcll(md_j[sub]); }
       }
         // Ordered compaction of the survivors into next step's lists: ballot + mbcnt inside the
         // wave, one returning 64-bit atomic per block iteration reserves room in both lists.
         __syncthreads();
         if (threadIdx.x == 0) {
-            uint32_t to = 0, tb = 0;
+            uint32_t to = 0, tb = 0, td = 0;
 #pragma unroll
             for (int sub = 0; sub < kSub; ++sub)
 #pragma unroll
-                for (int w2 = 0; w2 < kAdvBlock / 64; ++w2) { to += s_cnt_o[sub][w2]; tb += s_cnt_b[sub][w2]; }
+                for (int w2 = 0; w2 < kAdvBlock / 64; ++w2) { to += s_cnt_o[sub][w2]; tb += s_cnt_b[sub][w2]; td += s_cnt_d[sub][w2]; }
+            s_base_d = td ? atomicAdd(&d.drift_cnt[t], td) : 0u;
             // step_cnt[t+1] = {organic, bandit} is an aligned u32 pair: reserve both lists at once
             unsigned long long base = 0;
             if (to | tb)
@@ -4273,15 +4286,20 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
             s_base_b = static_cast<uint32_t>(base >> 32);
         }
         __syncthreads();
-        uint32_t off_o = s_base_o, off_b = s_base_b;
+        uint32_t off_o = s_base_o, off_b = s_base_b, off_d = s_base_d;
 #pragma unroll
         for (int sub = 0; sub < kSub; ++sub) {
-            uint32_t wo = off_o, wb = off_b;
-            for (int w2 = 0; w2 < wave; ++w2) { wo += s_cnt_o[sub][w2]; wb += s_cnt_b[sub][w2]; }
+            uint32_t wo = off_o, wb = off_b, wd = off_d;
+            for (int w2 = 0; w2 < wave; ++w2) { wo += s_cnt_o[sub][w2]; wb += s_cnt_b[sub][w2]; wd += s_cnt_d[sub][w2]; }
             if (ns_j[sub] == RG_STATE_ORGANIC) next_o[wo + prefix_in_mask(mo_j[sub])] = slot_j[sub];
             if (ns_j[sub] == RG_STATE_BANDIT) next_b[wb + prefix_in_mask(mb_j[sub])] = slot_j[sub];
+            if (dr_j[sub]) {
+                const uint32_t e = wd + prefix_in_mask(md_j[sub]);
+                d.drift_list[e] = slot_j[sub];
+                if (d.time_mode) d.drift_sig[e] = ds_j[sub];
+            }
 #pragma unroll
-            for (int w2 = 0; w2 < kAdvBlock / 64; ++w2) { off_o += s_cnt_o[sub][w2]; off_b += s_cnt_b[sub][w2]; }
+            for (int w2 = 0; w2 < kAdvBlock / 64; ++w2) { off_o += s_cnt_o[sub][w2]; off_b += s_cnt_b[sub][w2]; off_d += s_cnt_d[sub][w2]; }
         }
         __syncthreads();
     }
@@ -4292,6 +4310,28 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
         if (phantoms) atomicAdd(&d.counters[RG_CNT_PHANTOM], static_cast<unsigned long long>(phantoms));
     }
 }
+#endif
+
+// k_drift — omega <- omega + sigma_omega (time delta) Z(K) (reco_env_v1.py:95-98) of the users k_advance listed at step t: a lane per
+// (user, Box-Muller pair), the K normals addressed by (user, t, pair) as everywhere else.
+#if RG_HAS(6)
+__global__ void __launch_bounds__(kBlock) k_drift(DevSim d, uint32_t t) {
+    const uint32_t n = d.drift_cnt[t];
+    const uint32_t KP = (d.K + 1) / 2;
+    const uint64_t items = static_cast<uint64_t>(n) * KP;
+    for (uint64_t it = blockIdx.x * static_cast<uint64_t>(kBlock) + threadIdx.x; it < items; it += static_cast<uint64_t>(gridDim.x) * kBlock) {
+        const uint32_t e = static_cast<uint32_t>(it / KP), j = static_cast<uint32_t>(it % KP);
+        const uint32_t slot = d.drift_list[e];
+        const uint32_t user = static_cast<uint32_t>(d.first_user + d.uid[slot]);
+        const double sig = d.time_mode ? d.drift_sig[e] : d.sigma_omega;
+        double z0, z1;
+        normal_pair(d.seed, user, t, j, RG_DRAW_DRIFT, &z0, &z1);
+        double* o0 = d.omega + static_cast<size_t>(slot) * d.OMS + 2 * j;
+        *o0 = *o0 + sig * z0;
+        if (2 * j + 1 < d.K) { double* o1 = o0 + 1; *o1 = *o1 + sig * z1; }
+    }
+}
+search_kernel_t drift_kernel() { return k_drift; }
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -5651,8 +5691,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                 }
             }
             c_anch += static_cast<uint32_t>(__popcll(__ballot(got64)));
+            c_pick += static_cast<uint32_t>(__popcll(__ballot(have64)));     // resolved with float64 sums: anchored or picked
             unsigned long long picks = __ballot(have64 && !got64);
-            c_pick += static_cast<uint32_t>(__popcll(picks));
             while (picks) {
                 const int L = __builtin_ctzll(picks);
                 picks &= picks - 1;
@@ -6914,6 +6954,8 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     if (int rc = prof_mark(sim, st)) return rc;
     // 2. click draws, transitions, drift, next lists, bandit + phantom rows
     hipLaunchKernelGGL(advance_kernel(), dim3(grid_for(upper, kAdvBlock)), dim3(kAdvBlock), 0, st, d, t, d_actions);
+    if (d.sigma_omega != 0.0)
+        hipLaunchKernelGGL(drift_kernel(), dim3(grid_for(static_cast<uint64_t>(upper) * ((d.K + 1) / 2))), dim3(kBlock), 0, st, d, t);
     HIP_TRY(hipGetLastError());
     if (int rc = prof_mark(sim, st)) return rc;
     sim->t = t + 1;
@@ -7359,6 +7401,7 @@ int rg_sim_reset_users(rg_sim* sim, uint64_t first_user_id, uint64_t n, uint64_t
     HIP_TRY(hipMemsetAsync(d.exact_cnt, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
     HIP_TRY(hipMemsetAsync(d.exact_cnt_b, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
     if (d.lr_dirty) HIP_TRY(hipMemsetAsync(d.lr_cnt, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
+    if (d.sigma_omega != 0.0) HIP_TRY(hipMemsetAsync(d.drift_cnt, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
     HIP_TRY(hipMemsetAsync(d.counters, 0, sizeof(unsigned long long) * RG_CNT_N, st));
     hipLaunchKernelGGL(k_reset_users, dim3(grid_for(n)), dim3(kBlock), 0, st, d);
     HIP_TRY(hipGetLastError());
