@@ -496,7 +496,7 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint8_t* lr_dirty = w.take<uint8_t>(lr ? n : 1);
     uint32_t* lr_list = w.take<uint32_t>(lr ? n : 1);
     uint32_t* lr_cnt = w.take<uint32_t>(lr ? kMaxSteps + 2 : 1);
-    uint32_t* lr_part = w.take<uint32_t>(lr ? n * static_cast<size_t>(8 * (4 + 2 * 8)) : 1);
+    uint32_t* lr_part = w.take<uint32_t>(lr ? n * static_cast<size_t>(20 * (4 + 2 * 3)) : 1);      // kLrSplit x kLrPartWords
     uint32_t* park_list = w.take<uint32_t>(cache ? n + 64 + 64 * 16384 : 1);   // round 1's list, then round 2's hand-overs, 64-entry blocks per wave
     uint32_t* park_t = w.take<uint32_t>(cache ? n : 1);
     const bool rp = n >= repack_min_users();      // small runs never repack: no second copy
@@ -3947,7 +3947,10 @@ __global__ void __launch_bounds__(kBlock) k_logreg_acts(DevSim d, uint32_t t) {
 // sklearn's predict() bit for bit, as before; a range with more than kLrCand candidates (degenerate models): the float64
 // walk over all classes.  Needs n_classes % 8 == 0 (16-byte loads of 8 halves); the host keeps the fp32 kernel otherwise.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kLrSplit = 8, kLrCand = 8;
+// 20 ranges x 3 candidates = 60 lanes of the deciding wave.  At 10^4 classes a range is 504 classes = ONE block of 512: the
+// chain of a screening wave is two memory round trips (the history; then its wmax entries and row segments together).
+// Measured on config 5: 8 ranges (three blocks each) 199 ms of screening per arm run, see profiles/r3.
+constexpr uint32_t kLrSplit = 20, kLrCand = 3;
 // per act and range: {range maximum, candidates (0xFFFFFFFF: too many), 2B, -} then kLrCand x {class, score}
 constexpr uint32_t kLrPartWords = 4 + 2 * kLrCand;
 #if RG_HAS(6)
@@ -4057,11 +4060,13 @@ __global__ void __launch_bounds__(kBlock) k_logreg_decide(DevSim d, uint32_t t) 
         const uint32_t uidx = d.uid[slot];
         const hent_t* hr = hist_row(d, slot) + 1;
         const uint32_t* part = d.lr_part + static_cast<size_t>(w) * kLrSplit * kLrPartWords;
-        // lane = (range, candidate index)
-        const uint32_t r = static_cast<uint32_t>(lane) / kLrCand, k = static_cast<uint32_t>(lane) % kLrCand;
+        // lane = (range, candidate index); the last 64 - kLrSplit kLrCand lanes have no range
+        const uint32_t r_raw = static_cast<uint32_t>(lane) / kLrCand, k = static_cast<uint32_t>(lane) % kLrCand;
+        const bool has_r = r_raw < kLrSplit;
+        const uint32_t r = has_r ? r_raw : 0u;
         const uint32_t* pr = part + r * kLrPartWords;
-        const float rmax = __builtin_bit_cast(float, pr[0]);
-        const uint32_t nk = pr[1];
+        const float rmax = has_r ? __builtin_bit_cast(float, pr[0]) : -INFINITY;
+        const uint32_t nk = has_r ? pr[1] : 0u;
         const float thr = __builtin_bit_cast(float, part[2]);
         const uint32_t nd = part[3];
         c_acts += 1; c_rows += nd;
