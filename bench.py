@@ -185,18 +185,14 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
                                  exp_bound_ms=round(exp_ms, 2), frac_of_exp_bound=round(exp_ms / prof['draw_mfma_ms'], 4))
     walked = prof.get('walk1_ms', 0.0) > 0
     b_survey = survey_bytes_per_event(cfg, pol)
-    # the user-major walk (sigma_omega = 0, run to the end).  `bytes_per_unit` is SURVEY.md 8d's figure; what this
-    # implementation's cached organic draw moves on top of it (128 B of super-chunk prefixes, 48 B of chunk sums) is
-    # reported as implementation_bytes_per_unit
+    # the user-major walk (sigma_omega = 0, run to the end).  `bytes_per_unit` is SURVEY.md 8d's figure; what the
+    # implementation really moves is the measured `traffic_bytes_per_unit` of the roofline entry (PMC passes)
     if walked:
-        b_b = 4 * K + 8 + 16 + 3 + (35 if pol == 'ouc' else 0)
-        b_o = 8 + 128 + 48 + 4 * K + 16
-        by_impl = b_b * c['bandit'] + b_o * c['organic']
         ms = prof['walk1_ms'] + prof['walk2_ms']
         gbps = b_survey * events / (ms * 1e-3) / 1e9
-        out['walk'] = dict(kernel='k_walk', bound='hbm', ms=round(ms, 2), round1_ms=round(prof['walk1_ms'], 2),
+        out['walk'] = dict(kernel='k_walk', kernels='k_walk2 (rounds 1-2) + k_walk_solo (last round)', bound='hbm', ms=round(ms, 2), round1_ms=round(prof['walk1_ms'], 2),
                            later_rounds_ms=round(prof['walk2_ms'], 2), units=int(events), unit_name='events',
-                           bytes_per_unit=b_survey, implementation_bytes_per_unit=round(by_impl / max(events, 1), 1),
+                           bytes_per_unit=b_survey,
                            achieved=round(gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(gbps / HBM_PEAK_GBPS, 4),
                            note='latency bound on per-user state that lives in L2 and the Infinity Cache (DESIGN.md 4), not on '
                                 'HBM bandwidth')

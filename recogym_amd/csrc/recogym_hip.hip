@@ -496,7 +496,7 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint8_t* lr_dirty = w.take<uint8_t>(lr ? n : 1);
     uint32_t* lr_list = w.take<uint32_t>(lr ? n : 1);
     uint32_t* lr_cnt = w.take<uint32_t>(lr ? kMaxSteps + 2 : 1);
-    uint32_t* lr_part = w.take<uint32_t>(lr ? n * static_cast<size_t>(20 * (4 + 2 * 3)) : 1);      // kLrSplit x kLrPartWords
+    uint32_t* lr_part = w.take<uint32_t>(lr ? n * static_cast<size_t>(8 * (4 + 2 * 8)) : 1);       // kLrSplit x kLrPartWords
     uint32_t* park_list = w.take<uint32_t>(cache ? n + 64 + 64 * 16384 : 1);   // round 1's list, then round 2's hand-overs, 64-entry blocks per wave
     uint32_t* park_t = w.take<uint32_t>(cache ? n : 1);
     const bool rp = n >= repack_min_users();      // small runs never repack: no second copy
@@ -3947,10 +3947,10 @@ __global__ void __launch_bounds__(kBlock) k_logreg_acts(DevSim d, uint32_t t) {
 // sklearn's predict() bit for bit, as before; a range with more than kLrCand candidates (degenerate models): the float64
 // walk over all classes.  Needs n_classes % 8 == 0 (16-byte loads of 8 halves); the host keeps the fp32 kernel otherwise.
 // ------------------------------------------------------------------------------------------
-// 20 ranges x 3 candidates = 60 lanes of the deciding wave.  At 10^4 classes a range is 504 classes = ONE block of 512: the
-// chain of a screening wave is two memory round trips (the history; then its wmax entries and row segments together).
-// Measured on config 5: 8 ranges (three blocks each) 199 ms of screening per arm run, see profiles/r3.
-constexpr uint32_t kLrSplit = 20, kLrCand = 3;
+// 8 ranges x 8 candidates = the 64 lanes of the deciding wave.  Measured on config 5 (act kernels per LogReg-arm run):
+// 1 range (one wave per act, 20 blocks in sequence) 390 ms, 8 ranges (three blocks each) 323 ms, 20 ranges of one block
+// 388 ms (every wave pays the history read and the bound again): profiles/r3/ab_call5*, ab_call10*.
+constexpr uint32_t kLrSplit = 8, kLrCand = 8;
 // per act and range: {range maximum, candidates (0xFFFFFFFF: too many), 2B, -} then kLrCand x {class, score}
 constexpr uint32_t kLrPartWords = 4 + 2 * kLrCand;
 #if RG_HAS(6)
