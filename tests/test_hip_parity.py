@@ -866,3 +866,63 @@ def test_bench_shards_of_a_strongly_scaled_job_add_up_to_the_whole_run(workload,
         assert n == users
         assert tot == whole['totals'], (W, tot, whole['totals'])
         assert dig == whole['digest'][0], (W, dig, whole['digest'][0])
+
+
+@pytest.mark.parametrize('policy', ['uniform', 'random', 'ouc', 'table'])
+@pytest.mark.parametrize('handover', ['64', '1'])
+def test_last_round_wave_per_user_kernel_matches_the_oracle(policy, handover, monkeypatch):
+    """k_walk_solo (the last round of the sigma_omega = 0 walk: a wave per user, a lane per consecutive event of the user's
+    current run) for every policy the walk serves.  RECOGYM_WALK_HANDOVER=64 makes every wave hand its users over as soon
+    as the queue is empty, so that most of a small run's events are emitted by the solo kernel — organic runs (memo, search,
+    float64 pick of the parked draw, view-history insertions in a row), bandit runs cut by clicks and transitions, phantom
+    rows, warm-up users; =1 leaves it only the very last users.  Rows vs the oracle, bit for bit."""
+    from oracle import oracle as orc
+    monkeypatch.setenv('RECOGYM_WALK_HANDOVER', handover)
+    P, K, n, n_org = 700, 12, 1500, 30
+    cfg = Configuration({**env_1_args, 'random_seed': 900 + len(policy), 'num_products': P, 'K': K, 'sigma_omega': 0.0})
+    rng = np.random.RandomState(4)
+    pol = {'uniform': {},
+           'random': dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=77),
+           'ouc': dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=31, ouc=dict(gu.OUC_DEFAULTS)),
+           'table': dict(policy=_abi.RG_POLICY_LAST_VIEW_TABLE, policy_seed=0, policy_table=rng.randint(0, P, P).astype(np.int32),
+                         policy_ps=rng.rand(P))}[policy]
+    want_env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol)
+    want = want_env.generate_logs(n, n_org)
+    rows, cnt = run_sim(cfg, n, n_org, p_click=False, **pol)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps')},
+                         ps_rtol=1e-5 if policy == 'table' else 1e-12, what=f'solo {policy} handover {handover}')
+    assert (rows['phantom'] == want['phantom']).all()
+    oc = want_env.counters()
+    assert (cnt['organic'], cnt['bandit'], cnt['clicks'], cnt['phantom']) == (oc['organic'], oc['bandit'], oc['clicks'], oc['phantom'])
+    assert cnt['live'] == 0 and cnt['log_dropped'] == 0 and cnt['hist_overflow'] == 0
+
+
+def test_memo_and_anchored_certificate_carry_the_walk_at_scale(monkeypatch):
+    """400 000 users, P = 10 000, sigma_omega = 0, OrganicUserEventCounter: most organic draws are answered by the per-user
+    memo of certified draws, nearly all draws the plain certificate rejects by the float64-anchored one, a sliver by the
+    float64 pick — and the log is the lock-step float64-only path's (order-independent checksum of every row)."""
+    from recogym_amd.sim import Simulator
+    cfg = Configuration({**env_1_args, 'random_seed': 23, 'num_products': 10000, 'K': 20, 'sigma_omega': 0.0})
+    n = 400_000
+    pol = dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=5, ouc=dict(gu.OUC_DEFAULTS))
+
+    def run(env):
+        for k in ('RECOGYM_DRAW', 'RECOGYM_WALK'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sim = Simulator(cfg, n, device='cuda:0', **pol)
+        sim.reset_users(0, n)
+        sim.run()
+        c, dig = sim.counters(), sim.log_digest()
+        sim.close()
+        return c, dig
+
+    c, dig = run({})
+    c64, dig64 = run({'RECOGYM_DRAW': 'f64', 'RECOGYM_WALK': '0'})
+    assert dig == dig64
+    for k in ('organic', 'bandit', 'clicks', 'phantom'):
+        assert c[k] == c64[k], k
+    assert c['memo_hits'] > 0.5 * c['organic']                      # the memo answers most draws
+    assert c['anchored'] > 0.9 * c['exact_draws'] > 0               # the anchors nearly all of the rejected ones
+    assert c['exact_draws'] < 0.05 * c['organic'] and 0 < c['exact_sweeps'] < n

@@ -35,6 +35,7 @@ def bench_line(name):
 def entry(workload, fetch_run, write_run, kern, units, unit_name, what):
     (f, nf), (w, nw) = val(fetch_run, kern, 'FETCH_SIZE'), val(write_run, kern, 'WRITE_SIZE')
     return dict(workload=workload, unit_name=unit_name, units_in_profiled_run=units, dispatches_in_profiled_run=nf,
+                kernels_matched=kern + '*',
                 fetch_size_kb=f, write_size_kb=w,
                 hbm_bytes_per_unit=(2 * f + w) * 1024 / units, fetch_bytes_per_unit_uncorrected=f * 1024 / units,
                 write_bytes_per_unit=w * 1024 / units,
@@ -67,8 +68,8 @@ def main():
     try:
         d5 = bench_line('pmc_c5_fetch')
         k5 = d5['kernels']['logreg_ips_frozen.logreg_acts']
-        try_add('k_logreg_select', lambda: entry('c5', 'pmc_c5_fetch', 'pmc_c5_write', 'k_logreg_acts', k5['units'], 'acts',
-                                                 f"c5, {d5['config']['users_per_gpu']} users per arm"))
+        try_add('k_logreg_select', lambda: entry('c5', 'pmc_c5_fetch', 'pmc_c5_write', 'k_logreg_', k5['units'], 'acts',
+                                                 f"c5, {d5['config']['users_per_gpu']} users per arm; k_logreg_select + screen + decide"))
     except Exception as e:
         print('skipped c5', repr(e))
     json.dump(out, open(os.path.join(P, 'pmc_traffic.json'), 'w'), indent=1)
