@@ -5344,35 +5344,12 @@ __device__ __forceinline__ uint32_t exact_pick_call(const DevSim& d, const doubl
     return exact_pick_wave(d, sums, om, M, u, 1u, lane);
 }
 
-#ifdef RG_W2_PIN
-template <class T> __device__ __forceinline__ void pin_g(T*& p) {      // a pointer into global memory
-    auto g = (__attribute__((address_space(1))) T*)p;
-    asm volatile("" : "+s"(g));
-    p = (T*)g;
-}
-template <class T> __device__ __forceinline__ void pin_s(T& x) { asm volatile("" : "+s"(x)); }
-#define RG_W2_PIN_FIELDS_A(D) \
-    pin_s(D.PT); pin_s(D.P); pin_s(D.seed); pin_s(D.policy_seed); pin_s(D.first_user); pin_s(D.walk_bias); pin_s(D.cache_row_f); pin_s(D.KB4); pin_s(D.log_cap); pin_s(D.n_cap); \
-    pin_g(D.walk_hot); pin_g(D.walk_scp); pin_g(D.cache_chunk); pin_g(D.cache_row); pin_g(D.mu32); pin_g(D.gamma32t); pin_g(D.beta32); pin_g(D.mu_b); pin_g(D.log); pin_g(D.hist); pin_g(D.counters); pin_g(D.n_events); pin_g(D.u_override); pin_g(D.aux_pclick); pin_g(D.aux_ps);
-#define RG_W2_HOT_FIELDS_A(D, H) \
-    D.PT = H.PT; D.P = H.P; D.seed = H.seed; D.policy_seed = H.policy_seed; D.first_user = H.first_user; D.walk_bias = H.walk_bias; D.cache_row_f = H.cache_row_f; D.KB4 = H.KB4; D.log_cap = H.log_cap; D.n_cap = H.n_cap; D.walk_hot = H.walk_hot; D.walk_scp = H.walk_scp; D.cache_chunk = H.cache_chunk; D.cache_row = H.cache_row; D.mu32 = H.mu32; D.gamma32t = H.gamma32t; D.beta32 = H.beta32; D.mu_b = H.mu_b; D.log = H.log; D.hist = H.hist; D.counters = H.counters; D.n_events = H.n_events; D.u_override = H.u_override; D.aux_pclick = H.aux_pclick; D.aux_ps = H.aux_ps;
-#define RG_W2_PIN_FIELDS_B(D) \
-    pin_s(D.hist_cap); pin_s(D.cdf_o0); pin_s(D.cdf_o1); pin_s(D.cdf_b0); pin_s(D.cdf_b1); pin_s(D.organic_only_below); pin_s(D.walk_refill); pin_s(D.walk_handover); pin_s(D.K); pin_s(D.OMS); \
-    pin_g(D.lpv); pin_g(D.uid); pin_g(D.lr_dirty);
-#define RG_W2_HOT_FIELDS_B(D, H) \
-    D.hist_cap = H.hist_cap; D.cdf_o0 = H.cdf_o0; D.cdf_o1 = H.cdf_o1; D.cdf_b0 = H.cdf_b0; D.cdf_b1 = H.cdf_b1; D.organic_only_below = H.organic_only_below; D.walk_refill = H.walk_refill; D.walk_handover = H.walk_handover; D.K = H.K; D.OMS = H.OMS; D.lpv = H.lpv; D.uid = H.uid; D.lr_dirty = H.lr_dirty;
-#if RG_W2_PIN >= 2
-#define RG_W2_PIN_FIELDS(D) RG_W2_PIN_FIELDS_A(D) RG_W2_PIN_FIELDS_B(D)
-#define RG_W2_HOT_FIELDS(D, H) RG_W2_HOT_FIELDS_A(D, H) RG_W2_HOT_FIELDS_B(D, H)
-#else
-#define RG_W2_PIN_FIELDS(D) RG_W2_PIN_FIELDS_A(D)
-#define RG_W2_HOT_FIELDS(D, H) RG_W2_HOT_FIELDS_A(D, H)
-#endif
-#endif
-
 // Three blocks per CU (168 VGPRs, no spills).  Four (128 VGPRs) were measured in two forms — omega32 re-read from the cache
 // row instead of held in registers, and the Gamma rows of the chunk pass in two batches — and did not pay: the extra loads and
 // spills cost what the fourth wave brought (C3 walk 130.9 vs 133.8 ms, C2 13.2 vs 12.1 ms: profiles/r3/ab_walk_call3.jsonl).
+// The DevSim fields are read from the kernel-argument segment where they are used (as in k_walk); pinning the 25 or 38 of
+// the main path in registers instead (104 -> 70 / 60 scalar loads in the code, 200 / 259 scalar registers in VGPR lanes)
+// measured the same to 0.3 % (profiles/r3/ab_call11_pinned_fields_shard_sizes.jsonl): the waits are not the scalar loads'.
 template <int KH, int HIST>
 __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_arg, uint32_t n_work, int round, uint32_t chunk_rows,
                                                         uint32_t in_base, uint32_t out_base) {
@@ -5400,22 +5377,9 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
     // wave-uniform tallies (scalar registers): events are counted by ballots
     uint32_t c_org = 0, c_ban = 0, c_clicks = 0, c_ph = 0, c_pick = 0, c_sweeps = 0, c_maxt = 0, c_limit = 0, c_hit = 0, c_anch = 0;
 
-#ifdef RG_W2_PIN
-    // the fields of the loop's main path are read ONCE and pinned (opaque to rematerialisation: the register allocator keeps
-    // them in scalar registers or VGPR lanes instead of re-reading the kernel-argument segment, a load + s_waitcnt each)
-    DevSim dh = *(const DevSim*)kargs;
-    RG_W2_PIN_FIELDS(dh)
-#endif
     for (;;) {
-#ifdef RG_W2_PIN
-        asm volatile("" : "+s"(kargs));
-        DevSim dl = *(const DevSim*)kargs;         // the other fields: from the kernel-argument segment, where they are used
-        RG_W2_HOT_FIELDS(dl, dh)
-        const DevSim& d = dl;
-#else
         asm volatile("" : "+s"(kargs));
         const DevSim& d = *(const DevSim*)kargs;
-#endif
         const uint32_t n_cc = d.PT / 64;
         // ---- refill the lanes whose user has stopped (or was parked) ----
         {

