@@ -2034,6 +2034,31 @@ __device__ __forceinline__ float ahat_of(const DevSim& d, float mumax, float g2m
     return fminf(mumax + absdot, joint) * 1.00001f;
 }
 
+// The certificate of every fp32 search, on CORRELATED errors.  The search's quantities are A (the prefix at the start of the
+// draw's chunk), S (the total) — both running sums of the SAME sweep terms s_p = e_p (1 + eps_p), |eps_p| <= delta — and
+// a, b (the recomputed fp32 prefixes inside the chunk, before / with product v; their terms carry their own errors <= delta).
+// Product v is float64's answer iff  C[v-1] <= u S < C[v],  and with T = S - A (the sum of the sweep terms from the chunk's
+// start on: every error of A is ALSO in S and cancels in the difference)
+//     u S - C[v-1] = u T - (1 - u) A - a,      C[v] - u S = (1 - u) A + b - u T,
+// whose computed values are off by at most  delta' (u T + (1 - u) A + a|b) + rho S:  delta' = delta / (1 - delta) on the true
+// sums behind T, A, a|b, and rho = 2^-20 for the fp32 roundings of the two stored prefixes (<= 2^-21 each, relative to S and
+// A).  At u S ~ A that is 2 delta A T / S where the independent form  C~(1 + delta) < u S~ (1 - delta)  pays 2 delta A — the
+// band around a boundary shrinks by the mass BEHIND it, a third of the uncertified draws are left.
+// Both tests are linear in u:  u den_lo > num_lo  and  u den_hi < num_hi  — the memo keeps num / den, rounded inwards.
+struct CertLin { double num_lo, den_lo, num_hi, den_hi; bool valid; };
+__device__ __forceinline__ CertLin cert_correlated(double S, double A, double a, double b, double delta) {
+    const double dp = delta * (1.0 + 2.0 * delta);         // >= delta / (1 - delta) for delta <= 1/2
+    const double rho = 0x1.0p-20 * 1.001 * S;              // (.001: second-order terms and the float64 roundings of these lines)
+    const double T = S - A;                                // exact: both are fp32 values
+    CertLin c;
+    c.valid = T >= 0.0 && delta < 0.25;
+    c.num_lo = (A + a) * (1.0 + dp) + rho;
+    c.den_lo = T * (1.0 - dp) + A * (1.0 + dp);
+    c.num_hi = (A + b) * (1.0 - dp) - rho;
+    c.den_hi = T * (1.0 + dp) + A * (1.0 - dp);
+    return c;
+}
+
 __device__ __forceinline__ float wave_scan_f32(float x, int lane) {
     for (int o = 1; o < 64; o <<= 1) {
         const float y = __shfl_up(x, o);
@@ -2121,7 +2146,8 @@ __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, con
             if (sc < d.n_sc) S += static_cast<double>(rec[sc].x);
         }
         const uint32_t user = static_cast<uint32_t>(d.first_user + d.uid[slot]);
-        const double tau = organic_uniform(d, d.uid[slot], user, t) * S;
+        const double u_draw = organic_uniform(d, d.uid[slot], user, t);
+        const double tau = u_draw * S;
         double pb = 0.0;
         uint32_t sc_star = d.n_sc - 1;
         float f_star = 1.0f;
@@ -2224,9 +2250,11 @@ __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, con
             else        { if (idx_o >= 0) { vi = idx_o; Av = A_o; Bv = B_o; } else { vi = idx >= 0 ? 16 + idx : -1; Av = A; Bv = B; } }
             const uint32_t v = c_star * 32 + static_cast<uint32_t>(max(vi, 0));
             my_v = v;
-            my_ok = found_c && vi >= 0 && v < d.P &&
-                    (v == 0 || Av * (1.0 + delta) < tau * (1.0 - delta)) &&
-                    (v == d.P - 1 || tau * (1.0 + delta) < Bv * (1.0 - delta));
+            // (S, pb: float64 sums of the sweep's fp32 super-chunk / chunk sums, <= 2^-22 S off the exact sums of its terms)
+            const CertLin ct = cert_correlated(S, pb, Av - pb, Bv - pb, delta);
+            my_ok = found_c && vi >= 0 && v < d.P && ct.valid &&
+                    (v == 0 || u_draw * ct.den_lo > ct.num_lo) &&
+                    (v == d.P - 1 || u_draw * ct.den_hi < ct.num_hi);
         } else { my_v = static_cast<uint32_t>(S) % d.P; my_ok = true; }
         // ---- emit (lane per user) ----
         if (active && h == 0) {
@@ -3203,7 +3231,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 3 : 2)) k_draw_cached(DevS
 #pragma unroll
         for (uint32_t sc = 0; sc < kMaxSC; ++sc) S += static_cast<double>(W[sc]);     // unused records hold 0
         const uint32_t user = static_cast<uint32_t>(d.first_user + uidx);
-        const double tau = organic_uniform(d, uidx, user, t) * S;
+        const double u_draw = organic_uniform(d, uidx, user, t);
+        const double tau = u_draw * S;
         double pb = 0.0;
         uint32_t sc_star = d.n_sc - 1;
         bool found_sc = false;
@@ -3312,9 +3341,10 @@ __global__ void __launch_bounds__(kBlock, (KH <= 16 ? 3 : 2)) k_draw_cached(DevS
             if (lane == src) {
                 const uint32_t v = cs * 32 + static_cast<uint32_t>(max(idx, 0));
                 my_v = v;
-                my_ok = found_c && idx >= 0 && v < d.P &&
-                        (v == 0 || Av * (1.0 + delta) < tau * (1.0 - delta)) &&
-                        (v == d.P - 1 || tau * (1.0 + delta) < Bv * (1.0 - delta));
+                const CertLin ct = cert_correlated(S, pb, Av - pb, Bv - pb, delta);
+                my_ok = found_c && idx >= 0 && v < d.P && ct.valid &&
+                        (v == 0 || u_draw * ct.den_lo > ct.num_lo) &&
+                        (v == d.P - 1 || u_draw * ct.den_hi < ct.num_hi);
             }
         }
         // ---- emit (a lane per user) ----
@@ -4980,9 +5010,10 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
                 const int idx = static_cast<int>(mbox[lane * 3]);
                 const double Av = mbox[lane * 3 + 1], Bv = mbox[lane * 3 + 2];
                 v = c_star * 32 + (d.cache_sub ? g_star * 8 : 0u) + static_cast<uint32_t>(max(idx, 0));
-                ok = found_c && idx >= 0 && v < d.P &&
-                     (v == 0 || Av * (1.0 + delta) < tau * (1.0 - delta)) &&
-                     (v == d.P - 1 || tau * (1.0 + delta) < Bv * (1.0 - delta));
+                const CertLin ct = cert_correlated(S, pb, Av - pb, Bv - pb, delta);
+                ok = found_c && idx >= 0 && v < d.P && ct.valid &&
+                     (v == 0 || u_org * ct.den_lo > ct.num_lo) &&
+                     (v == d.P - 1 || u_org * ct.den_hi < ct.num_hi);
             }
             // ---- uncertified: float64 pick from the user's stored sums, or park the user until they exist ----
             const bool need64 = is_org && !ok;
@@ -5626,22 +5657,22 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             bool ok = false;
             if (search) {
                 const int idx = static_cast<int>(mboxf[lane * 3]);
-                const double Av = pb + static_cast<double>(mboxf[lane * 3 + 1]), Bv = pb + static_cast<double>(mboxf[lane * 3 + 2]);
+                const CertLin ct = cert_correlated(S, pb, static_cast<double>(mboxf[lane * 3 + 1]), static_cast<double>(mboxf[lane * 3 + 2]), delta);
                 v = c_star * 32 + static_cast<uint32_t>(max(idx, 0));
-                const bool lo_ok = v == 0 || Av * (1.0 + delta) < tau * (1.0 - delta);
-                const bool hi_ok = v == d.P - 1 || tau * (1.0 + delta) < Bv * (1.0 - delta);
-                ok = found && idx >= 0 && v < d.P && lo_ok && hi_ok;
-                if (ok && n_hot < static_cast<uint32_t>(kHotEntries) && !d.u_override) {
+                const bool lo_ok = v == 0 || u_org * ct.den_lo > ct.num_lo;
+                const bool hi_ok = v == d.P - 1 || u_org * ct.den_hi < ct.num_hi;
+                ok = found && idx >= 0 && v < d.P && ct.valid && lo_ok && hi_ok;
+                if (ok && n_hot < static_cast<uint32_t>(kHotEntries)) {
                     // memoise the certified u-interval of v, rounded inwards (and a hair more for the float64 roundings of
                     // the inequality above): u in (lo, hi) implies both conditions, whatever u
                     float lo = -1.0f, hi = 2.0f;
                     if (v != 0) {
-                        const double x = Av * (1.0 + delta) / ((1.0 - delta) * S) * (1.0 + 1e-14);
+                        const double x = ct.num_lo / ct.den_lo * (1.0 + 1e-14);
                         lo = static_cast<float>(x);
                         if (static_cast<double>(lo) < x) lo = f32_up(lo);
                     }
                     if (v != d.P - 1) {
-                        const double x = Bv * (1.0 - delta) / ((1.0 + delta) * S) * (1.0 - 1e-14);
+                        const double x = ct.num_hi / ct.den_hi * (1.0 - 1e-14);
                         hi = static_cast<float>(x);
                         if (static_cast<double>(hi) > x) hi = f32_down(hi);
                     }
@@ -6213,7 +6244,7 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
                 const double S = static_cast<double>(h0.x), delta = static_cast<double>(h0.y);
                 const float Q = h0.z;
                 const uint32_t n_hot = __builtin_bit_cast(uint32_t, h0.w);
-                const double u_org = rg_uniform(w.w[0], w.w[1]);
+                const double u_org = d.u_override ? d.u_override[slot] : rg_uniform(w.w[0], w.w[1]);   // (test hook)
                 float uf = static_cast<float>(u_org), u_dn = uf, u_up = uf;
                 if (static_cast<double>(uf) > u_org) u_dn = f32_down(uf);
                 if (static_cast<double>(uf) < u_org) u_up = f32_up(uf);
@@ -6340,11 +6371,11 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
                     __builtin_amdgcn_wave_barrier();
                     if (search) {
                         const int ix = static_cast<int>(mboxf[lane * 3]);
-                        const double Av = pb + static_cast<double>(mboxf[lane * 3 + 1]), Bv = pb + static_cast<double>(mboxf[lane * 3 + 2]);
+                        const CertLin ct = cert_correlated(S, pb, static_cast<double>(mboxf[lane * 3 + 1]), static_cast<double>(mboxf[lane * 3 + 2]), delta);
                         v = c_star * 32 + static_cast<uint32_t>(max(ix, 0));
-                        const bool lo_ok = v == 0 || Av * (1.0 + delta) < tau * (1.0 - delta);
-                        const bool hi_ok = v == d.P - 1 || tau * (1.0 + delta) < Bv * (1.0 - delta);
-                        ok = found && ix >= 0 && v < d.P && lo_ok && hi_ok;
+                        const bool lo_ok = v == 0 || u_org * ct.den_lo > ct.num_lo;
+                        const bool hi_ok = v == d.P - 1 || u_org * ct.den_hi < ct.num_hi;
+                        ok = found && ix >= 0 && v < d.P && ct.valid && lo_ok && hi_ok;
                     }
                 }
                 // uncertified draws (and the parked one): float64 picks from the user's stored sums, one after the other
