@@ -2059,33 +2059,6 @@ __device__ __forceinline__ CertLin cert_correlated(double S, double A, double a,
     return c;
 }
 
-// The same test taken from BOTH ends of the draw's chunk (the walk's searches, which also hold A2 = the stored prefix at the
-// chunk's END and R = the recomputed sum of the whole chunk).  Forward: C[v-1] = A + a, C[v] = A + b as above.  Backward:
-// C[v-1] = A2 - (R - a), C[v] = A2 - (R - b) with T2 = S - A2: the errors are delta' (u T2 + (1 - u) A2 + (R - a|b)) + rho2 S.
-// A heavy product v costs the forward form delta e_v at its UPPER boundary (b holds e_v, recomputed, next to the sweep's copy
-// inside T) and the backward form delta e_v at its LOWER one; each boundary takes the form that certifies it.  rho2 = 2^-19:
-// the stored prefixes' roundings as before plus the fp32 scan's (<= 10 adds of 2^-24 R) that R - a|b inherits.
-struct CertLin2 { CertLin f, b; };
-__device__ __forceinline__ CertLin2 cert_two_sided(double S, double A, double A2, double a, double b, double R, double delta) {
-    CertLin2 c;
-    c.f = cert_correlated(S, A, a, b, delta);
-    const double dp = delta * (1.0 + 2.0 * delta);
-    const double rho2 = 0x1.0p-19 * 1.001 * S;
-    const double T2 = S - A2, ta = fmax(R - a, 0.0), tb = fmax(R - b, 0.0);
-    c.b.valid = T2 >= 0.0 && A2 >= A && delta < 0.25;
-    c.b.num_lo = A2 * (1.0 + dp) - ta * (1.0 - dp) + rho2;
-    c.b.den_lo = T2 * (1.0 - dp) + A2 * (1.0 + dp);
-    c.b.num_hi = A2 * (1.0 - dp) - tb * (1.0 + dp) - rho2;
-    c.b.den_hi = T2 * (1.0 + dp) + A2 * (1.0 - dp);
-    return c;
-}
-__device__ __forceinline__ bool cert_lo_ok(const CertLin2& c, double u) {
-    return (c.f.valid && u * c.f.den_lo > c.f.num_lo) || (c.b.valid && u * c.b.den_lo > c.b.num_lo);
-}
-__device__ __forceinline__ bool cert_hi_ok(const CertLin2& c, double u) {
-    return (c.f.valid && u * c.f.den_hi < c.f.num_hi) || (c.b.valid && u * c.b.den_hi < c.b.num_hi);
-}
-
 __device__ __forceinline__ float wave_scan_f32(float x, int lane) {
     for (int o = 1; o < 64; o <<= 1) {
         const float y = __shfl_up(x, o);
@@ -5250,7 +5223,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
 // ------------------------------------------------------------------------------------------
 constexpr int kHotEntries = 9;          // memo entries of a user: floats [4 + 3 j, 7 + 3 j) of its hot row = {product, u_lo, u_hi}
 constexpr int kWSlow = 6;               // lane state: organic draw that missed the memo (RG_STATE_* = 0..2, empty 3, phantom 4)
-__host__ __device__ inline size_t walk2_wave_lds(int hist) { return (hist ? 16 * 64 * 8 : 0) + 64 * 16; }
+__host__ __device__ inline size_t walk2_wave_lds(int hist) { return (hist ? 16 * 64 * 8 : 0) + 64 * 12; }
 #if RG_HAS(7)
 
 // The prefix form.  Eight lanes per user, 32 chunks per pass (one 128-byte line of the user's chunk sums): scaled to the
@@ -5421,7 +5394,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
     const int wave = threadIdx.x >> 6, lane = lane_id();
     char* wbase = smem_raw + static_cast<size_t>(wave) * walk2_wave_lds(HIST);
     hent_t* hl = reinterpret_cast<hent_t*>(wbase) + lane;               // HIST: [16][64] entry-major: hl[i * 64]
-    float* mboxf = reinterpret_cast<float*>(wbase + (HIST ? 16 * 64 * 8 : 0));   // [64][4]: the search's result per lane
+    float* mboxf = reinterpret_cast<float*>(wbase + (HIST ? 16 * 64 * 8 : 0));   // [64][3]: the search's result per lane
     uint32_t slot = 0, t = 0;
     int st = kEmpty;
     bool pend = false;                                                 // rounds >= 2: the parked draw, to be picked in float64
@@ -5576,7 +5549,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             const float tauf = static_cast<float>(tau);
             // ---- super-chunk: the prefixes <= tau (an unused entry is +inf) ----
             uint32_t sc_star = 0;
-            float pbf = 0.0f, pnf = INFINITY;        // the stored prefixes around tau: at the start / the end of the draw's chunk
+            float pbf = 0.0f;
             {
                 const float4* sp = reinterpret_cast<const float4*>(d.walk_scp + row * kMaxSC);
 #pragma unroll
@@ -5584,12 +5557,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     const float4 x = sp[i];
                     const float xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bool le = xs[q] <= tauf;
-                        sc_star += le ? 1u : 0u;
-                        pbf = le ? fmaxf(pbf, xs[q]) : pbf;
-                        pnf = le ? pnf : fminf(pnf, xs[q]);
-                    }
+                    for (int q = 0; q < 4; ++q)
+                        if (xs[q] <= tauf) { sc_star += 1; pbf = fmaxf(pbf, xs[q]); }
                 }
             }
             bool found = sc_star < d.n_sc;
@@ -5609,12 +5578,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     for (int i = 0; i < 4; ++i) {
                         const float xs[4] = {w4[i].x, w4[i].y, w4[i].z, w4[i].w};
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const bool le = xs[q] <= tauf;
-                            cnt += le ? 1u : 0u;
-                            pbf = le ? fmaxf(pbf, xs[q]) : pbf;
-                            pnf = le ? pnf : fminf(pnf, xs[q]);
-                        }
+                        for (int q = 0; q < 4; ++q)
+                            if (xs[q] <= tauf) { cnt += 1; pbf = fmaxf(pbf, xs[q]); }
                     }
                 }
                 found = found && cnt < c1 - c0;
@@ -5673,16 +5638,14 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     const int j0 = x0 > rems ? 0 : x1 > rems ? 1 : x2 > rems ? 2 : x3 > rems ? 3 : -1;
                     const unsigned long long hits = __ballot(has && j0 >= 0);
                     const uint32_t gmask = static_cast<uint32_t>(hits >> (8 * grp)) & 0xFFu;
-                    const float tot = __shfl(inc, 7, 8);                 // the chunk's recomputed sum
                     if (has) {
                         if (gmask) {
                             if (gl == __builtin_ctz(gmask)) {
-                                mboxf[src * 4] = static_cast<float>(4 * gl + j0);
-                                mboxf[src * 4 + 1] = j0 == 0 ? ex : j0 == 1 ? x0 : j0 == 2 ? x1 : x2;
-                                mboxf[src * 4 + 2] = j0 == 0 ? x0 : j0 == 1 ? x1 : j0 == 2 ? x2 : x3;
-                                mboxf[src * 4 + 3] = tot;
+                                mboxf[src * 3] = static_cast<float>(4 * gl + j0);
+                                mboxf[src * 3 + 1] = j0 == 0 ? ex : j0 == 1 ? x0 : j0 == 2 ? x1 : x2;
+                                mboxf[src * 3 + 2] = j0 == 0 ? x0 : j0 == 1 ? x1 : j0 == 2 ? x2 : x3;
                             }
-                        } else if (gl == 7) { mboxf[src * 4] = -1.0f; mboxf[src * 4 + 1] = inc; mboxf[src * 4 + 2] = inc; mboxf[src * 4 + 3] = inc; }
+                        } else if (gl == 7) { mboxf[src * 3] = -1.0f; mboxf[src * 3 + 1] = inc; mboxf[src * 3 + 2] = inc; }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -5693,26 +5656,23 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             chunk_pass(search, c_star, rem);
             bool ok = false;
             if (search) {
-                const int idx = static_cast<int>(mboxf[lane * 4]);
-                const CertLin2 ct = cert_two_sided(S, pb, static_cast<double>(pnf), static_cast<double>(mboxf[lane * 4 + 1]),
-                                                   static_cast<double>(mboxf[lane * 4 + 2]), static_cast<double>(mboxf[lane * 4 + 3]), delta);
+                const int idx = static_cast<int>(mboxf[lane * 3]);
+                const CertLin ct = cert_correlated(S, pb, static_cast<double>(mboxf[lane * 3 + 1]), static_cast<double>(mboxf[lane * 3 + 2]), delta);
                 v = c_star * 32 + static_cast<uint32_t>(max(idx, 0));
-                const bool lo_ok = v == 0 || cert_lo_ok(ct, u_org);
-                const bool hi_ok = v == d.P - 1 || cert_hi_ok(ct, u_org);
-                ok = found && idx >= 0 && v < d.P && lo_ok && hi_ok;
+                const bool lo_ok = v == 0 || u_org * ct.den_lo > ct.num_lo;
+                const bool hi_ok = v == d.P - 1 || u_org * ct.den_hi < ct.num_hi;
+                ok = found && idx >= 0 && v < d.P && ct.valid && lo_ok && hi_ok;
                 if (ok && n_hot < static_cast<uint32_t>(kHotEntries)) {
                     // memoise the certified u-interval of v, rounded inwards (and a hair more for the float64 roundings of
                     // the inequality above): u in (lo, hi) implies both conditions, whatever u
                     float lo = -1.0f, hi = 2.0f;
                     if (v != 0) {
-                        const double xf = ct.f.valid ? ct.f.num_lo / ct.f.den_lo : 2.0, xb = ct.b.valid ? ct.b.num_lo / ct.b.den_lo : 2.0;
-                        const double x = fmin(xf, xb) * (1.0 + 1e-14);
+                        const double x = ct.num_lo / ct.den_lo * (1.0 + 1e-14);
                         lo = static_cast<float>(x);
                         if (static_cast<double>(lo) < x) lo = f32_up(lo);
                     }
                     if (v != d.P - 1) {
-                        const double xf = ct.f.valid ? ct.f.num_hi / ct.f.den_hi : -1.0, xb = ct.b.valid ? ct.b.num_hi / ct.b.den_hi : -1.0;
-                        const double x = fmax(xf, xb) * (1.0 - 1e-14);
+                        const double x = ct.num_hi / ct.den_hi * (1.0 - 1e-14);
                         hi = static_cast<float>(x);
                         if (static_cast<double>(hi) > x) hi = f32_down(hi);
                     }
@@ -5748,8 +5708,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                 const bool anchored = have64 && lo64 <= target && target < hi64;
                 const float rem1 = static_cast<float>(target - lo64);
                 chunk_pass(anchored, 2u * cc, rem1);
-                const int idx1 = anchored ? static_cast<int>(mboxf[lane * 4]) : 0;
-                const float a1 = mboxf[lane * 4 + 1], b1 = mboxf[lane * 4 + 2];
+                const int idx1 = anchored ? static_cast<int>(mboxf[lane * 3]) : 0;
+                const float a1 = mboxf[lane * 3 + 1], b1 = mboxf[lane * 3 + 2];
                 const bool in2 = anchored && idx1 < 0;
                 __builtin_amdgcn_wave_barrier();
                 chunk_pass(in2, 2u * cc + 1u, rem1 - a1);
@@ -5758,8 +5718,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     float fa = a1, fb = b1;
                     uint32_t va = 64u * cc + static_cast<uint32_t>(max(idx1, 0));
                     if (in2) {
-                        ix = static_cast<int>(mboxf[lane * 4]);
-                        fa = a1 + mboxf[lane * 4 + 1]; fb = a1 + mboxf[lane * 4 + 2];
+                        ix = static_cast<int>(mboxf[lane * 3]);
+                        fa = a1 + mboxf[lane * 3 + 1]; fb = a1 + mboxf[lane * 3 + 2];
                         va = 64u * cc + 32u + static_cast<uint32_t>(max(ix, 0));
                     }
                     const double slack = 1.0e-12 * S64;
@@ -6159,7 +6119,7 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
     constexpr int KC = ((K2 + 3) / 4) * 4;
     constexpr int kEmpty = 3, kPhantom = 4;
     __shared__ hent_t s_hist[kBlock / 64][HIST ? kSoloHist : 1];      // the user's history row: [0] header, then the entries
-    __shared__ float s_mbox[kBlock / 64][64 * 4];
+    __shared__ float s_mbox[kBlock / 64][64 * 3];
     const int wave = threadIdx.x >> 6, lane = lane_id();
     hent_t* hs = s_hist[wave];
     float* mboxf = s_mbox[wave];
@@ -6312,7 +6272,7 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
                     const double tau = u_org * S;
                     const float tauf = static_cast<float>(tau);
                     uint32_t sc_star = 0;
-                    float pbf = 0.0f, pnf = INFINITY;
+                    float pbf = 0.0f;
                     {
                         const float4* sp = reinterpret_cast<const float4*>(d.walk_scp + static_cast<size_t>(slot) * kMaxSC);
 #pragma unroll
@@ -6320,12 +6280,8 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
                             const float4 x = sp[i];
                             const float xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const bool le = xs[q] <= tauf;
-                                sc_star += le ? 1u : 0u;
-                                pbf = le ? fmaxf(pbf, xs[q]) : pbf;
-                                pnf = le ? pnf : fminf(pnf, xs[q]);
-                            }
+                            for (int q = 0; q < 4; ++q)
+                                if (xs[q] <= tauf) { sc_star += 1; pbf = fmaxf(pbf, xs[q]); }
                         }
                     }
                     bool found = sc_star < d.n_sc;
@@ -6344,12 +6300,8 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
                             for (int i = 0; i < 4; ++i) {
                                 const float xs[4] = {w4[i].x, w4[i].y, w4[i].z, w4[i].w};
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    const bool le = xs[q] <= tauf;
-                                    cnt += le ? 1u : 0u;
-                                    pbf = le ? fmaxf(pbf, xs[q]) : pbf;
-                                    pnf = le ? pnf : fminf(pnf, xs[q]);
-                                }
+                                for (int q = 0; q < 4; ++q)
+                                    if (xs[q] <= tauf) { cnt += 1; pbf = fmaxf(pbf, xs[q]); }
                             }
                         }
                         found = found && cnt < cc1 - cc0;
@@ -6404,29 +6356,26 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
                             const int j0 = x0 > rems ? 0 : x1 > rems ? 1 : x2 > rems ? 2 : x3 > rems ? 3 : -1;
                             const unsigned long long hits = __ballot(has && j0 >= 0);
                             const uint32_t gmask = static_cast<uint32_t>(hits >> (8 * grp)) & 0xFFu;
-                            const float tot = __shfl(inc, 7, 8);
                             if (has) {
                                 if (gmask) {
                                     if (gl == __builtin_ctz(gmask)) {
-                                        mboxf[src * 4] = static_cast<float>(4 * gl + j0);
-                                        mboxf[src * 4 + 1] = j0 == 0 ? ex : j0 == 1 ? x0 : j0 == 2 ? x1 : x2;
-                                        mboxf[src * 4 + 2] = j0 == 0 ? x0 : j0 == 1 ? x1 : j0 == 2 ? x2 : x3;
-                                        mboxf[src * 4 + 3] = tot;
+                                        mboxf[src * 3] = static_cast<float>(4 * gl + j0);
+                                        mboxf[src * 3 + 1] = j0 == 0 ? ex : j0 == 1 ? x0 : j0 == 2 ? x1 : x2;
+                                        mboxf[src * 3 + 2] = j0 == 0 ? x0 : j0 == 1 ? x1 : j0 == 2 ? x2 : x3;
                                     }
-                                } else if (gl == 0) { mboxf[src * 4] = -1.0f; mboxf[src * 4 + 1] = 0.0f; mboxf[src * 4 + 2] = 0.0f; mboxf[src * 4 + 3] = 0.0f; }
+                                } else if (gl == 0) { mboxf[src * 3] = -1.0f; mboxf[src * 3 + 1] = 0.0f; mboxf[src * 3 + 2] = 0.0f; }
                             }
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                     __builtin_amdgcn_wave_barrier();
                     if (search) {
-                        const int ix = static_cast<int>(mboxf[lane * 4]);
-                        const CertLin2 ct = cert_two_sided(S, pb, static_cast<double>(pnf), static_cast<double>(mboxf[lane * 4 + 1]),
-                                                           static_cast<double>(mboxf[lane * 4 + 2]), static_cast<double>(mboxf[lane * 4 + 3]), delta);
+                        const int ix = static_cast<int>(mboxf[lane * 3]);
+                        const CertLin ct = cert_correlated(S, pb, static_cast<double>(mboxf[lane * 3 + 1]), static_cast<double>(mboxf[lane * 3 + 2]), delta);
                         v = c_star * 32 + static_cast<uint32_t>(max(ix, 0));
-                        const bool lo_ok = v == 0 || cert_lo_ok(ct, u_org);
-                        const bool hi_ok = v == d.P - 1 || cert_hi_ok(ct, u_org);
-                        ok = found && ix >= 0 && v < d.P && lo_ok && hi_ok;
+                        const bool lo_ok = v == 0 || u_org * ct.den_lo > ct.num_lo;
+                        const bool hi_ok = v == d.P - 1 || u_org * ct.den_hi < ct.num_hi;
+                        ok = found && ix >= 0 && v < d.P && ct.valid && lo_ok && hi_ok;
                     }
                 }
                 // uncertified draws (and the parked one): float64 picks from the user's stored sums, one after the other

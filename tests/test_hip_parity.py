@@ -545,9 +545,8 @@ def test_certificate_is_sound_for_uniforms_next_to_cdf_boundaries(mode, shape, m
     placed next to a boundary of ITS float64 cdf: u = cdf[b] * (1 +- eps), eps from 1e-9 (closer than any
     fp32 sum can resolve) to 3e-3, through the test hook rg_sim_debug_set_uniforms.  Then
       * every draw the matrix-core kernel certified must equal the float64 decision (soundness);
-      * nothing within 5e-7 of a boundary may be certified (the certificate's floor is 2^-20 of the total — the fp32
-        roundings of the stored prefixes — next to delta times the masses before AND behind the boundary; the COMPUTED
-        boundary a certified draw keeps that distance from is itself off the true one by the actual roundings);
+      * nothing within 9e-7 of a boundary may be certified (the certificate's floor: 2^-20 of the total for the fp32
+        roundings of the stored prefixes, next to delta times the masses before AND behind the boundary);
       * draws >= 1e-3 away from both neighbouring boundaries mostly are certified (the test is not
         vacuous), and the logged index of EVERY user equals the float64 one (uncertified draws are
         resolved by the float64 kernels)."""
@@ -602,8 +601,8 @@ def test_certificate_is_sound_for_uniforms_next_to_cdf_boundaries(mode, shape, m
     bad = np.flatnonzero(cert & (got_v != want_v))
     assert bad.size == 0, (f'{bad.size} CERTIFIED draws differ from float64; first: user {bad[0]} got {got_v[bad[0]]} '
                            f'want {want_v[bad[0]]} margin {margin[bad[0]]:.3e}')
-    assert not cert[margin < 5e-7].any(), 'a draw within 5e-7 of a cdf boundary was certified'
-    assert (margin < 5e-7).sum() > 200 and cert.sum() > 200
+    assert not cert[margin < 9e-7].any(), 'a draw within 9e-7 of a cdf boundary was certified'
+    assert (margin < 9e-7).sum() > 200 and cert.sum() > 200
     far = margin > 1e-3
     assert far.sum() > 20 and cert[far].mean() > 0.9
     # float64 resolve of the rest.  Where the neighbouring products' masses are below float64 resolution of the
