@@ -570,6 +570,13 @@ __device__ __forceinline__ double ff64(double x) {
     return sigmoid64(5.0 * sigmoid64(2.0 * sigmoid64(0.3 * x) - 2.0) - 6.0);
 }
 
+// No click below this uniform, whatever the action and omega: ff() is three nested sigmoids, sigmoid(0.3 x) in [0, 1] ->
+// 2 s - 2 in [-2, 0] -> sigmoid in [0.119, 0.5] -> 5 s - 6 in [-5.40, -3.5] -> ctr in [0.004478, 0.0293123] (SURVEY.md
+// appendix A.8), and numpy's choice([0, 1], p = [1 - ctr, ctr]) clicks iff u >= (1 - ctr) / ((1 - ctr) + ctr) >= 0.97068.
+// 97 % of the bandit events need neither beta[a] nor omega: their click is 0 (the float64 path is taken when ctr itself
+// is exported, `aux_pclick`).
+constexpr double kNoClickBelow = 0.97;
+
 // The click of a bandit event, click = [u >= 1 - ff(beta[a].omega + mu_b[a])] (reco_env_v1.py:104-116), decided in fp32
 // wherever that is provably the float64 decision.  `b_row` = beta32[a] (KB4 floats, zero padded), om_at(k) =
 // float(omega_k), mb = float(mu_b[a]).  Returns 1 / 0 = click / no click, -1 = undecided (the caller evaluates float64).
@@ -4191,16 +4198,20 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
             const double u_trans = rg_uniform(w.w[2], w.w[3]);
             bool click = false;
             if (!is_org) {
+                // 97 % of the bandit events cannot click whatever beta[a] . omega is (kNoClickBelow): they read neither row
+                const double u_click = rg_uniform(w.w[0], w.w[1]);
+                const bool need_ctr = d.aux_pclick != nullptr || !(u_click < kNoClickBelow);
                 // Touch the two cache lines of the user's omega row (and the head of its view
                 // history) NOW: they arrive while the policy draws and walks the history, instead
                 // of costing another HBM round trip after it — this kernel is latency-bound.
                 const double* om_row = d.omega + static_cast<size_t>(slot) * d.OMS;
-                const double touch0 = om_row[0], touch1 = om_row[d.K - 1];
+                double touch0 = 0.0, touch1 = 0.0;
+                if (need_ctr) { touch0 = om_row[0]; touch1 = om_row[d.K - 1]; }
                 // K even and <= 24 (rows are 16-byte aligned): the whole omega row is fetched here as 16-byte
                 // loads and held across the policy, so that only beta's row is left on the critical path
                 const bool pre = d.K <= 24 && !(d.K & 1);
                 double2 wpre[12];
-                if (pre) {
+                if (pre && need_ctr) {
 #pragma unroll
                     for (int k2 = 0; k2 < 12; ++k2)
                         wpre[k2] = *reinterpret_cast<const double2*>(om_row + 2 * min(static_cast<uint32_t>(k2), d.K / 2 - 1));
@@ -4218,7 +4229,8 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                 const double* b = d.beta + static_cast<size_t>(a) * d.K;
                 const double* om = d.omega + static_cast<size_t>(slot) * d.OMS;
                 double x = 0.0;
-                if (pre) {
+                if (!need_ctr) {}
+                else if (pre) {
                     double2 bpre[12];
 #pragma unroll
                     for (int k2 = 0; k2 < 12; ++k2)
@@ -4240,9 +4252,12 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                         if (k0 + i < d.K) x += bv[i] * wv[i];
                 }
                 asm volatile("" ::"v"(touch0), "v"(touch1), "v"(touch2));   // keeps the early loads alive
-                const double ctr = ff64(x + d.mu_b[a]);
-                const double p0 = 1.0 - ctr;
-                click = (p0 / (p0 + ctr)) <= rg_uniform(w.w[0], w.w[1]);
+                double ctr = 0.0;
+                if (need_ctr) {
+                    ctr = ff64(x + d.mu_b[a]);
+                    const double p0 = 1.0 - ctr;
+                    click = (p0 / (p0 + ctr)) <= u_click;
+                }
                 clicks += click;
                 const uint64_t row = d.log_base[t] + i;
                 if (d.log && row < d.log_cap) {
@@ -4500,12 +4515,16 @@ __global__ void __launch_bounds__(kBlock) k_tail(DevSim d, uint32_t t0) {
                 } else {
                     double ps;
                     const uint32_t a = policy_act(d, slot, user, t, &ps);
-                    const double* b = d.beta + static_cast<size_t>(a) * d.K;
-                    double x = 0.0;
-                    for (uint32_t k = 0; k < d.K; ++k) x += b[k] * om[k];
-                    const double ctr = ff64(x + d.mu_b[a]);
-                    const double p0 = 1.0 - ctr;
-                    click = (p0 / (p0 + ctr)) <= rg_uniform(w.w[0], w.w[1]);
+                    double ctr = 0.0;
+                    click = false;
+                    if (d.aux_pclick || !(rg_uniform(w.w[0], w.w[1]) < kNoClickBelow)) {
+                        const double* b = d.beta + static_cast<size_t>(a) * d.K;
+                        double x = 0.0;
+                        for (uint32_t k = 0; k < d.K; ++k) x += b[k] * om[k];
+                        ctr = ff64(x + d.mu_b[a]);
+                        const double p0 = 1.0 - ctr;
+                        click = (p0 / (p0 + ctr)) <= rg_uniform(w.w[0], w.w[1]);
+                    }
                     c_clicks += click;
                     const uint64_t row = d.log_base[t0] + atomicAdd(&d.counters[kCntTailRows], 1ull);
                     if (d.log && row < d.log_cap) {
@@ -5089,6 +5108,8 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
             // slope <= 0.05; three v_exp / v_rcp at ~1e-6); the float64 evaluation below is for the lanes inside that
             // band (~4e-5 of the acts) and for runs that export the click probability.
             bool click_known = false;
+            if (is_ban && !d.aux_pclick && rg_uniform(w.w[0], w.w[1]) < kNoClickBelow) click_known = true;     // (click = false)
+            else
             if (is_ban && !d.aux_pclick && !RG_WALK_ABL(21)) {
                 const float* om_l = om_sel + lane;
                 const int dec = click_decide32<((K2 + 3) / 4) * 4>(d.beta32 + static_cast<size_t>(a) * d.KB4, [&](int k) { return om_l[k * 64]; },
@@ -5223,6 +5244,8 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
 // ------------------------------------------------------------------------------------------
 constexpr int kHotEntries = 9;          // memo entries of a user: floats [4 + 3 j, 7 + 3 j) of its hot row = {product, u_lo, u_hi}
 constexpr int kWSlow = 6;               // lane state: organic draw that missed the memo (RG_STATE_* = 0..2, empty 3, phantom 4)
+constexpr int kWClick = 7;              // lane state: bandit event whose click needs ctr (uniform >= kNoClickBelow): taken in batches
+constexpr uint32_t kClickBatch = 4;
 __host__ __device__ inline size_t walk2_wave_lds(int hist) { return (hist ? 16 * 64 * 8 : 0) + 64 * 12; }
 #if RG_HAS(7)
 
@@ -5397,6 +5420,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
     float* mboxf = reinterpret_cast<float*>(wbase + (HIST ? 16 * 64 * 8 : 0));   // [64][3]: the search's result per lane
     uint32_t slot = 0, t = 0;
     int st = kEmpty;
+    bool hdirty = false;                                               // the history line in LDS is newer than the user's row
     bool pend = false;                                                 // rounds >= 2: the parked draw, to be picked in float64
     float om[KC];                                                      // omega32 of the lane's user
 #pragma unroll
@@ -5412,6 +5436,14 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
         asm volatile("" : "+s"(kargs));
         const DevSim& d = *(const DevSim*)kargs;
         const uint32_t n_cc = d.PT / 64;
+        // the view history is written back when the lane lets go of the user (stop, park, hand-over) or needs the row
+        auto flush_hist = [&](bool c) {
+            if (HIST && c) {
+                ulonglong2* hw = reinterpret_cast<ulonglong2*>(hist_row(d, slot));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) hw[i] = make_ulonglong2(hl[(2 * i) * 64], hl[(2 * i + 1) * 64]);
+            }
+        };
         // ---- refill the lanes whose user has stopped (or was parked) ----
         {
             unsigned long long dead = __ballot(st == kEmpty);
@@ -5433,7 +5465,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                         uint32_t s2 = idx;
                         if (round >= 2) s2 = d.park_list[in_base + idx];
                         if (s2 != 0xFFFFFFFFu) {
-                            slot = s2; st = RG_STATE_ORGANIC; t = 0u; pend = false;
+                            slot = s2; st = RG_STATE_ORGANIC; t = 0u; pend = false; hdirty = false;
                             if (round >= 2) {
                                 const uint32_t pt = d.park_t[s2];
                                 t = pt & 0xFFFFFFu; st = static_cast<int>((pt >> 24) & 7u); pend = (pt >> 27) & 1u;
@@ -5481,9 +5513,10 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                 base = __builtin_amdgcn_readfirstlane(base);
                 park_next = base; park_end = base + 64;
             }
+            flush_hist(give && hdirty);
             if (give) {
                 d.park_list[out_base + park_next + prefix_in_mask(gm)] = slot;
-                const int st_out = st == kWSlow ? RG_STATE_ORGANIC : st;     // (a searching draw restarts at the memo check)
+                const int st_out = st == kWSlow ? RG_STATE_ORGANIC : st == kWClick ? RG_STATE_BANDIT : st;     // (they restart at the memo check / the act)
                 d.park_t[slot] = t | (static_cast<uint32_t>(st_out) << 24) | (pend ? 1u << 27 : 0u);
                 if (round == 1) d.exact_ref[slot] = d.cache_row[static_cast<size_t>(slot) * d.cache_row_f + 32];
                 st = kEmpty;
@@ -5495,16 +5528,21 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
         const uint32_t n_o = static_cast<uint32_t>(__popcll(__ballot(st == RG_STATE_ORGANIC)));
         const uint32_t n_s = static_cast<uint32_t>(__popcll(__ballot(st == kWSlow)));
         const uint32_t n_b = static_cast<uint32_t>(__popcll(__ballot(st == RG_STATE_BANDIT || st == kPhantom)));
-        int kind;                                  // 0 = memo check, 1 = search, 2 = bandit
-        if (n_s >= 16u || (n_s && !n_o && !n_b)) kind = 1;
-        else if (n_o && (n_o * d.walk_bias >= n_b * 4u)) kind = 0;
-        else if (n_b) kind = 2;
-        else kind = n_o ? 0 : 1;
+        const uint32_t n_c = static_cast<uint32_t>(__popcll(__ballot(st == kWClick)));
+        // (walk_bias == 0: the memo-answered draws AND the bandit events of the wave in the same iteration)
+        bool do_org = false, do_srch = false, do_ban = false, do_clk = false;
+        if (n_s >= 16u || (n_s && !n_o && !n_b)) do_srch = true;
+        else if (n_c >= kClickBatch || (n_c && !n_o && !n_b)) do_ban = do_clk = true;        // the bandit events that need ctr
+        else if (d.walk_bias == 0u) { do_org = n_o != 0u; do_ban = n_b != 0u; }
+        else if (n_o && (n_o * d.walk_bias >= n_b * 4u)) do_org = true;
+        else if (n_b) do_ban = true;
+        else if (n_o) do_org = true;
+        else do_srch = true;
         const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
         const rg_u32x4 w = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
         bool have_v = false, parked = false;
         uint32_t v = 0;
-        if (kind == 0) {
+        if (do_org) {
             // =========================== organic draw, answered by the user's memo ===========================
             const bool is_o = st == RG_STATE_ORGANIC;
             const size_t row = is_o ? slot : d.n_cap;
@@ -5516,7 +5554,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             if (static_cast<double>(uf) > u_org) u_dn = f32_down(uf);
             if (static_cast<double>(uf) < u_org) u_up = f32_up(uf);
             bool hit = false;
-            {
+            if RG_WALK_ABL(23) { hit = true; v = (user + (t & 7u)) % d.P; }     // timing experiment: every draw a memo hit, no row read
+            else {
                 // the whole line in one round trip (the entries behind n_hot are not looked at), selects only
                 float e[28];
 #pragma unroll
@@ -5534,7 +5573,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             have_v = is_o && hit;
             if (is_o && !hit) st = kWSlow;
             c_hit += static_cast<uint32_t>(__popcll(__ballot(have_v)));
-        } else if (kind == 1) {
+        }
+        if (do_srch) {
             // =========================== organic draw by the search over the user's prefix sums ===========================
             const bool is_s = st == kWSlow;
             const bool search = is_s;            // (a parked draw too: its chunk is where the anchored certificate starts)
@@ -5761,16 +5801,18 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                 base = __builtin_amdgcn_readfirstlane(base);
                 park_next = base; park_end = base + 64;
             }
+            flush_hist(parked && hdirty);
             if (parked) { d.park_list[out_base + park_next + prefix_in_mask(pmask)] = slot; st = kEmpty; }
             park_next += np;
         }
         // =========================== bandit event: the policy's act and the click ===========================
-        const bool is_ban = kind == 2 && st == RG_STATE_BANDIT, is_ph = kind == 2 && st == kPhantom;
+        bool is_ban = do_ban && (do_clk ? st == kWClick : st == RG_STATE_BANDIT);
+        const bool is_ph = do_ban && !do_clk && st == kPhantom;
         double ps = 1.0;
         uint32_t a = 0;
         bool click = false, click_known = false;
         double ctr = 0.0;
-        if (kind == 2) {
+        if (do_ban) {
             if (is_ban || is_ph) {
                 if (HIST) {
                     // OrganicUserEventCounterModel.act (organic_user_count.py:45-96; exploit_explore, epsilon = 0,
@@ -5852,7 +5894,16 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                 d.has_phantom[slot] = 1;
                 st = kEmpty;
             }
+            flush_hist(is_ph && hdirty);
             c_ph += static_cast<uint32_t>(__popcll(__ballot(is_ph)));
+            if (is_ban && RG_WALK_ABL(24)) { click = false; click_known = true; }        // timing experiment: no beta row
+            else
+            if (is_ban && !d.aux_pclick && !do_clk) {
+                // no click below kNoClickBelow; the 3 % above it wait (kWClick) until kClickBatch lanes of the wave do: the
+                // beta row is a memory round trip the whole wave would otherwise sit out in every bandit iteration
+                if (rg_uniform(w.w[0], w.w[1]) < kNoClickBelow) { click = false; click_known = true; }
+                else { st = kWClick; is_ban = false; }
+            } else
             if (is_ban && !d.aux_pclick) {
                 const int dec = click_decide32<KC>(d.beta32 + static_cast<size_t>(a) * d.KB4, [&](int k) { return om[k]; }, d.K, d.KB4,
                                                    static_cast<float>(d.mu_b[a]), rg_uniform(w.w[0], w.w[1]));
@@ -5895,7 +5946,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             }
             const uint64_t my_row = row_next + prefix_in_mask(rowm);
             row_next += nrow;
-            if (ev && d.log && my_row < d.log_cap) {
+            if (ev && d.log && my_row < d.log_cap && !RG_WALK_ABL(25)) {
                 rg_event e;
                 e.u = user; e.t = t;
                 e.code = have_v ? v : (RG_EV_BANDIT | (click ? RG_EV_CLICK : 0u) | a);
@@ -5909,7 +5960,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             c_clicks += static_cast<uint32_t>(__popcll(__ballot(is_ban && click)));
             if (have_v) {
                 if (d.lpv) d.lpv[slot] = v;
-                if (HIST) {
+                if (HIST && !RG_WALK_ABL(27)) {
                     // ViewsFeaturesProvider.observe (agents/abstract.py:347-358) on the line in LDS, written through to the row
                     hent_t* hr = hist_row(d, slot);
                     const hent_t h0 = hl[0];
@@ -5943,11 +5994,11 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                         }
 #pragma unroll
                         for (int i = 0; i < 16; ++i) hl[i * 64] = f[i];
-                        ulonglong2* hw = reinterpret_cast<ulonglong2*>(hr);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) hw[i] = make_ulonglong2(f[2 * i], f[2 * i + 1]);
+                        hdirty = true;                                         // (written back when the lane lets go of the user)
                     } else {
                         // the line is full (or the history longer): the general insertion on the row, then the line again
+                        flush_hist(hdirty);
+                        hdirty = false;
                         history_add(d, slot, v);
                         const ulonglong2* hr2 = reinterpret_cast<const ulonglong2*>(hr);
 #pragma unroll
@@ -5983,6 +6034,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     c_maxt = max(c_maxt, t + 1);
                 }
                 if (limit) c_limit += 1;
+                flush_hist(ns == RG_STATE_STOP && hdirty);
                 if (ns == RG_STATE_STOP) st = kEmpty;
                 else { st = ns; t += 1; }
             }
@@ -6211,9 +6263,11 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
                     a = rg_bounded(pw.w[0], pw.w[1], d.P);
                 }
                 int dec = -1;
-                if (!d.aux_pclick)
-                    dec = click_decide32<KC>(d.beta32 + static_cast<size_t>(a) * d.KB4, [&](int k) { return om[k]; }, d.K, d.KB4,
-                                             static_cast<float>(d.mu_b[a]), rg_uniform(w.w[0], w.w[1]));
+                if (!d.aux_pclick) {
+                    if (rg_uniform(w.w[0], w.w[1]) < kNoClickBelow) dec = 0;
+                    else dec = click_decide32<KC>(d.beta32 + static_cast<size_t>(a) * d.KB4, [&](int k) { return om[k]; }, d.K, d.KB4,
+                                                  static_cast<float>(d.mu_b[a]), rg_uniform(w.w[0], w.w[1]));
+                }
                 if (dec >= 0) click = dec != 0;
                 else {
                     const double* b = d.beta + static_cast<size_t>(a) * d.K;
