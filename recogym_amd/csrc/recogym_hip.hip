@@ -122,6 +122,7 @@ struct DevSim {
     uint32_t walk_handover;   // k_walk: live lanes at which a wave whose queue is empty passes its users to the next round (0: never)
     uint32_t walk_refill;     // k_walk: free lanes of a wave at which it takes new users from the queue
     uint32_t walk_bias;       // k_walk: 0 = both event kinds every iteration; else one kind, organic when n_org * walk_bias >= n_bandit * 4
+    uint32_t walk_click_batch;   // k_walk2: lanes waiting for ctr (kWClick) at which the wave takes them (0: in the bandit iteration itself)
     uint32_t exact_base;      // first exact_list entry of the batch being resolved
     uint32_t exact_last;      // this is the last batch launched for the step
     float2* sc_scratch;       // [kMaxGrid*4 waves][kMaxSC][32] {sum, reference} of the MFMA draw kernel
@@ -1137,6 +1138,40 @@ __device__ void history_add(const DevSim& d, uint32_t slot, uint32_t v) {
     }
     hr[pos] = key | 1ull;
     hr[0] = e[0] + (1ull << 32) + 1ull;
+}
+
+// The same for a product BEHIND the first line of a longer history (k_walk2: the header and the 15 smallest products live in
+// LDS, entries 16 .. nd of the row in memory are current and all larger than the line's last product).  Touches only entries
+// >= 16 of the row; the header stays with the caller.  Returns 1 if the product is new (the caller's distinct count), 0 if
+// its count was raised; `nd` = distinct products before the view (>= 15, nd + 1 < hist_cap checked by the caller).
+__device__ __forceinline__ uint32_t history_tail_add(hent_t* hr, uint32_t nd, uint32_t v) {
+    const hent_t key = static_cast<hent_t>(v) << 32;
+    uint32_t pos = 16;                          // first entry >= 16 with product >= v (nd + 1 if none)
+    hent_t at = 0ull;
+    bool past = false;
+    for (uint32_t base = 16; base <= nd && !past; base += kHistRegs) {
+        hent_t f[kHistRegs];
+        hist_load_line(hr + base, f);
+#pragma unroll
+        for (int i = 0; i < kHistRegs; ++i) {
+            const uint32_t idx = base + i;
+            if (idx <= nd && !past) {
+                if (f[i] < key) pos = idx + 1;
+                else { past = true; at = f[i]; }
+            }
+        }
+    }
+    if (past && h_prod(at) == v) { hr[pos] = at + 1ull; return 0u; }
+    uint32_t j = nd + 1;                        // entries [pos, j) move up by one, highest first
+    while (j > pos) {
+        if (j >= pos + 4) {
+            const hent_t a0 = hr[j - 4], a1 = hr[j - 3], a2 = hr[j - 2], a3 = hr[j - 1];
+            hr[j - 3] = a0; hr[j - 2] = a1; hr[j - 1] = a2; hr[j] = a3;
+            j -= 4;
+        } else { hr[j] = hr[j - 1]; --j; }
+    }
+    hr[pos] = key | 1ull;
+    return 1u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -5245,7 +5280,6 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
 constexpr int kHotEntries = 9;          // memo entries of a user: floats [4 + 3 j, 7 + 3 j) of its hot row = {product, u_lo, u_hi}
 constexpr int kWSlow = 6;               // lane state: organic draw that missed the memo (RG_STATE_* = 0..2, empty 3, phantom 4)
 constexpr int kWClick = 7;              // lane state: bandit event whose click needs ctr (uniform >= kNoClickBelow): taken in batches
-constexpr uint32_t kClickBatch = 4;
 __host__ __device__ inline size_t walk2_wave_lds(int hist) { return (hist ? 16 * 64 * 8 : 0) + 64 * 12; }
 #if RG_HAS(7)
 
@@ -5532,7 +5566,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
         // (walk_bias == 0: the memo-answered draws AND the bandit events of the wave in the same iteration)
         bool do_org = false, do_srch = false, do_ban = false, do_clk = false;
         if (n_s >= 16u || (n_s && !n_o && !n_b)) do_srch = true;
-        else if (n_c >= kClickBatch || (n_c && !n_o && !n_b)) do_ban = do_clk = true;        // the bandit events that need ctr
+        else if (n_c && (n_c >= d.walk_click_batch || (!n_o && !n_b))) do_ban = do_clk = true;   // the bandit events that need ctr
         else if (d.walk_bias == 0u) { do_org = n_o != 0u; do_ban = n_b != 0u; }
         else if (n_o && (n_o * d.walk_bias >= n_b * 4u)) do_org = true;
         else if (n_b) do_ban = true;
@@ -5813,6 +5847,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
         bool click = false, click_known = false;
         double ctr = 0.0;
         if (do_ban) {
+            if ((is_ban || is_ph) && RG_WALK_ABL(28)) { a = user % d.P; ps = 1.0; }      // timing experiment: no policy act
+            else
             if (is_ban || is_ph) {
                 if (HIST) {
                     // OrganicUserEventCounterModel.act (organic_user_count.py:45-96; exploit_explore, epsilon = 0,
@@ -5899,12 +5935,12 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             if (is_ban && RG_WALK_ABL(24)) { click = false; click_known = true; }        // timing experiment: no beta row
             else
             if (is_ban && !d.aux_pclick && !do_clk) {
-                // no click below kNoClickBelow; the 3 % above it wait (kWClick) until kClickBatch lanes of the wave do: the
+                // no click below kNoClickBelow; the 3 % above it wait (kWClick) until walk_click_batch lanes of the wave do: the
                 // beta row is a memory round trip the whole wave would otherwise sit out in every bandit iteration
                 if (rg_uniform(w.w[0], w.w[1]) < kNoClickBelow) { click = false; click_known = true; }
-                else { st = kWClick; is_ban = false; }
-            } else
-            if (is_ban && !d.aux_pclick) {
+                else if (d.walk_click_batch) { st = kWClick; is_ban = false; }
+            }
+            if (is_ban && !d.aux_pclick && !click_known) {
                 const int dec = click_decide32<KC>(d.beta32 + static_cast<size_t>(a) * d.KB4, [&](int k) { return om[k]; }, d.K, d.KB4,
                                                    static_cast<float>(d.mu_b[a]), rg_uniform(w.w[0], w.w[1]));
                 if (dec >= 0) { click = dec != 0; click_known = true; }
@@ -5966,21 +6002,25 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     const hent_t h0 = hl[0];
                     const uint32_t nd = h_cnt(h0);
                     const hent_t key = static_cast<hent_t>(v) << 32;
-                    if (nd < 15u) {
-                        // the whole line in registers (one LDS round trip), the new line by selects, written back whole —
-                        // to LDS and, as eight 16-byte stores, to the row: no data-dependent branch, no dependent loads
-                        hent_t e[17];
-                        e[0] = h0; e[16] = 0ull;
+                    // the line in registers (one LDS round trip): position of v, whether it is there
+                    hent_t e[17];
+                    e[0] = h0; e[16] = 0ull;
 #pragma unroll
-                        for (int i = 1; i < 16; ++i) e[i] = hl[i * 64];
-                        uint32_t pos = 1;                       // first entry with product >= v (nd + 1 if none)
-                        bool hit = false;
+                    for (int i = 1; i < 16; ++i) e[i] = hl[i * 64];
+                    uint32_t pos = 1;                       // first entry with product >= v (min(nd, 15) + 1 if none)
+                    bool hit = false;
 #pragma unroll
-                        for (int i = 1; i < 16; ++i) {
-                            const bool in = static_cast<uint32_t>(i) <= nd;
-                            pos += (in && e[i] < key) ? 1u : 0u;
-                            hit = hit || (in && h_prod(e[i]) == v);
-                        }
+                    for (int i = 1; i < 16; ++i) {
+                        const bool in = static_cast<uint32_t>(i) <= nd;
+                        pos += (in && e[i] < key) ? 1u : 0u;
+                        hit = hit || (in && h_prod(e[i]) == v);
+                    }
+                    if (nd < 15u && RG_WALK_ABL(29)) {}                        // timing experiment: no insertion into the line
+                    else if (nd >= 15u && RG_WALK_ABL(26)) {}                  // timing experiment: no insertion into a longer history
+                    else
+                    if (nd < 15u || hit) {
+                        // the new line by selects, written back whole to LDS (the row gets it when the lane lets go of the
+                        // user): no data-dependent branch, no dependent loads.  A longer history whose line holds v: the same
                         const bool full = !hit && nd + 1 >= d.hist_cap;
                         if (full) atomicAdd(&d.counters[RG_CNT_HIST_OVERFLOW], 1ull);
                         hent_t f[16];
@@ -5995,8 +6035,23 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
 #pragma unroll
                         for (int i = 0; i < 16; ++i) hl[i * 64] = f[i];
                         hdirty = true;                                         // (written back when the lane lets go of the user)
+                    } else if (v > h_prod(e[15])) {
+                        // a longer history, v behind the line's 15 products: entries >= 16 of the row (always current), the
+                        // header in LDS — one round trip, nothing to read back
+                        if (nd + 1 >= d.hist_cap) {
+                            // (a new product would not fit: the general insertion decides and counts the overflow)
+                            flush_hist(hdirty);
+                            hdirty = false;
+                            history_add(d, slot, v);
+                            hl[0] = hr[0];
+                        } else {
+                            const uint32_t fresh = history_tail_add(hr, nd, v);
+                            hl[0] = h0 + (1ull << 32) + fresh;
+                            hdirty = true;
+                        }
                     } else {
-                        // the line is full (or the history longer): the general insertion on the row, then the line again
+                        // a new product inside the line of a longer history (its last product moves to the row): the general
+                        // insertion on the row, then the line again
                         flush_hist(hdirty);
                         hdirty = false;
                         history_add(d, slot, v);
@@ -7347,6 +7402,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     d.walk_refill = 8;
     d.walk_handover = 32;
     if (const char* e = getenv("RECOGYM_WALK_HANDOVER")) d.walk_handover = static_cast<uint32_t>(atoi(e));
+    d.walk_click_batch = 8;
+    if (const char* e = getenv("RECOGYM_WALK_CLICK_BATCH")) d.walk_click_batch = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_REFILL")) d.walk_refill = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_BIAS")) d.walk_bias = static_cast<uint32_t>(atoi(e));
     // k_walk2 where it is instantiated for the configuration (RECOGYM_WALK=1: k_walk), four blocks per CU at K <= 20
