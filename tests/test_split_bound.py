@@ -67,3 +67,25 @@ def test_joint_logit_bound_dominates_every_partial_sum(P, K, sigma_mu, scale):
         assert partial.max() <= ahat * (1 + 1e-12), (partial.max(), ahat)
         gains.append(ahat / (mumax + min(float((np.abs(om) * gmax_k).sum()), g2max * r)))
     assert np.mean(gains) <= 1.0 and min(gains) < 0.97         # never looser than before, usually tighter
+
+
+def test_no_click_threshold_is_below_every_click_boundary():
+    """kNoClickBelow (recogym_hip.hip): a bandit event whose uniform is below it cannot click, whatever beta[a].omega is.
+    The reference's draw (reco_env_v1.py:38-41, 104-116): ctr = ff(x) = sig(5 sig(2 sig(0.3 x) - 2) - 6) and
+    choice([0, 1], p=[1 - ctr, ctr]) = [u >= cdf[0]], cdf = cumsum(p) / cumsum(p)[-1].  Checked here: the constant in the
+    source, the range of ff over the whole float64 line, and numpy's own boundary for the largest ctr."""
+    import os, re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'recogym_amd', 'csrc', 'recogym_hip.hip')).read()
+    thr = float(re.search(r'constexpr double kNoClickBelow = ([0-9.]+);', src).group(1))
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x))
+    ff = lambda x: sig(5.0 * sig(2.0 * sig(0.3 * x) - 2.0) - 6.0)
+    with np.errstate(over='ignore'):
+        x = np.concatenate([np.linspace(-200, 200, 400001), [-1e308, -1e30, 1e30, 1e308, -np.inf, np.inf]])
+        ctr = ff(x)
+    assert ctr.max() <= sig(-3.5) * (1 + 1e-15) and ctr.min() >= 0.0044
+    p = np.stack([1.0 - ctr, ctr], axis=1)
+    cdf = np.cumsum(p, axis=1)
+    cdf /= cdf[:, -1:]
+    assert thr < cdf[:, 0].min() - 5e-4          # 0.97 against 0.970688: three orders above any rounding of the chain
+    # and the threshold is worth having: it spares 97 % of the events
+    assert thr >= 0.97
