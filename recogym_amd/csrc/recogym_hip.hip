@@ -108,6 +108,7 @@ struct DevSim {
     // tables (caller-owned float64) and fp32 copies (workspace)
     const double* gamma; const double* mu_o; const double* beta; const double* mu_b;
     float* gamma32; float* mu32;   // [P_pad][KS] (k >= K zero, rows >= P zero) / [P_pad] (-inf pad)
+    uint32_t has_g32t;        // gamma32t is there (gamma32t_wanted)
     float* gamma32t;          // [n_chunks][2 KH][32]: the same values chunk by chunk, k-major inside a chunk — a lane per
                               // product reads one k of its chunk as one coalesced 128-byte run (k_draw_cached)
     double* gammaT;           // [K][PT] float64 transpose of Gamma, PT = P rounded up to 64 (coalesced f64 draw)
@@ -394,6 +395,11 @@ inline bool cache_wanted(const rg_config& c, const Geom& g) {
     return c.sigma_omega == 0.0 && g.N1 != 0 && !(e && e[0] == '0');
 }
 
+// The chunk-major fp32 copy of Gamma (gamma32t): the recompute of a draw's chunk reads it as one 128-byte run per k and user
+// (eight lanes per user); the row-major gather it replaces was address-rate-bound.  The walk's and the cached draw's searches
+// need it, and the lock-step search of K <= 32 uses it too.
+inline bool gamma32t_wanted(const rg_config& c, const Geom& g) { return g.KH != 0 && (cache_wanted(c, g) || g.KH <= 16); }
+
 // Sums of 8-product groups next to the chunk sums: where the run will be walked user by user (k_walk), the recompute
 // that turns a chunk into a product streams the chunk's Gamma rows through the CU's L1 — the walk's bound — and a
 // group is a quarter of that.  16 bytes per chunk and user, written by the SUB instantiation of the fp16 sweep.
@@ -462,7 +468,7 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     (void)P; (void)K;
     float* gamma32 = w.take<float>(static_cast<size_t>(g.P_pad) * (g.KS ? g.KS : 1));
     float* mu32 = w.take<float>(g.P_pad ? g.P_pad : 1);
-    float* gamma32t = w.take<float>(cache_wanted(c, g) ? static_cast<size_t>(g.n_chunks) * 2 * g.KH * 32 : 1);
+    float* gamma32t = w.take<float>(gamma32t_wanted(c, g) ? static_cast<size_t>(g.n_chunks) * 2 * g.KH * 32 : 1);
     float* stats = w.take<float>(2 * g.KH + 2 + kAhatGrid);
     const size_t PT = align_up(P, 64);
     double* gammaT = w.take<double>(K * PT);
@@ -537,7 +543,7 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->lr_action = lr_action; d->lr_dirty = lr ? lr_dirty : nullptr; d->lr_list = lr_list; d->lr_cnt = lr_cnt; d->lr_part = lr_part;
         d->uid = uid; d->omega_alt = omega_alt; d->hist_alt = hist_alt;
         d->lpv_alt = lpv_alt; d->uid_alt = uid_alt;
-        d->gamma32 = gamma32; d->mu32 = mu32; d->gamma32t = gamma32t; d->stats = stats; d->omega = omega; d->list = list;
+        d->gamma32 = gamma32; d->mu32 = mu32; d->gamma32t = gamma32t; d->has_g32t = gamma32t_wanted(c, g) ? 1u : 0u; d->stats = stats; d->omega = omega; d->list = list;
         d->gamma_rm = gamma_rm; d->XKB = xkb;
         d->exact_rows = static_cast<uint32_t>(exact_rows); d->exact_base = 0;
         d->gammaT = gammaT; d->PT = static_cast<uint32_t>(PT); d->exact_ref = exact_ref; d->exact_sums = exact_sums; d->sc_scratch = sc_scratch; d->chunk_scratch = chunk_scratch; d->tile_resc = tile_resc;
@@ -703,7 +709,7 @@ __global__ void __launch_bounds__(kBlock) k_make_fp32_tables(DevSim d) {
         d.gamma32[i] = (p < d.P && k < d.K) ? static_cast<float>(d.gamma[p * d.K + k]) : 0.0f;
         if (i < d.P_pad) d.mu32[i] = i < d.P ? static_cast<float>(d.mu_o[i]) : -INFINITY;
     }
-    if (d.use_cache) {
+    if (d.has_g32t) {
         const size_t K2 = 2 * d.KH, nt = static_cast<size_t>(d.n_chunks) * K2 * 32;
         for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < nt;
              i += static_cast<size_t>(gridDim.x) * kBlock) {
@@ -2265,6 +2271,68 @@ __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, con
         uint32_t my_v = 0;
         bool my_ok = false;
         if (!(d.ablate & 1u)) {
+            int vi; double Av, Bv;
+            if constexpr (KH <= 16) {               // (gamma32t is always there at K <= 32: gamma32t_wanted)
+                // the chunk from the chunk-major copy of Gamma: eight users per pass, eight lanes per user, four products per
+                // lane — every load is a 128-byte run per k and user (the row-major gather below: 16 rows of 88 bytes per lane,
+                // address-rate-bound: 29 % of the lock-step sweep's time at K = 20)
+                constexpr int K2 = 2 * KH;
+                const int lane_w = 32 * h + j, grp = lane_w >> 3, gl = lane_w & 7;
+                const float remf = static_cast<float>(tau - pb);
+                int r_idx = -1;
+                float r_a = 0.0f, r_b = 0.0f;
+#pragma unroll 1
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int u = 8 * ps + grp;                        // the user this group works for (its h = 0 lane)
+                    const uint32_t cs = static_cast<uint32_t>(__shfl(static_cast<int>(c_star), u));
+                    const float Qs = __shfl(Q, u);
+                    const float rems = __shfl(remf, u);
+                    const float* ou = om_lds + (u - j) * K2;           // that user's omega32 in the wave's stage
+                    const float4* gp = reinterpret_cast<const float4*>(d.gamma32t + (static_cast<size_t>(cs) * K2) * 32) + gl;
+                    float4 l = *(reinterpret_cast<const float4*>(d.mu32 + cs * 32) + gl);
+#pragma unroll
+                    for (int kh = 0; kh < K2; kh += KH) {
+                        float4 gk[KH];
+#pragma unroll
+                        for (int k = 0; k < KH; ++k) gk[k] = gp[(kh + k) * 8];
+#pragma unroll
+                        for (int k = 0; k < KH; ++k) {
+                            const float wk = ou[kh + k];
+                            l.x = fmaf(gk[k].x, wk, l.x); l.y = fmaf(gk[k].y, wk, l.y);
+                            l.z = fmaf(gk[k].z, wk, l.z); l.w = fmaf(gk[k].w, wk, l.w);
+                        }
+                        asm volatile("" : "+v"(l.x), "+v"(l.y), "+v"(l.z), "+v"(l.w));
+                    }
+                    const float e0 = __builtin_amdgcn_exp2f(fmaf(l.x, kLog2e, -Qs)), e1 = __builtin_amdgcn_exp2f(fmaf(l.y, kLog2e, -Qs));
+                    const float e2 = __builtin_amdgcn_exp2f(fmaf(l.z, kLog2e, -Qs)), e3 = __builtin_amdgcn_exp2f(fmaf(l.w, kLog2e, -Qs));
+                    const float q0 = e0, q1 = q0 + e1, q2 = q1 + e2, q3 = q2 + e3;
+                    float inc = q3;
+#pragma unroll
+                    for (int o2 = 1; o2 < 8; o2 <<= 1) {
+                        const float y = __shfl_up(inc, o2, 8);
+                        if (gl >= o2) inc += y;
+                    }
+                    float ex = __shfl_up(inc, 1, 8);
+                    if (gl == 0) ex = 0.0f;
+                    // the product in fp32 is only a proposal: the certificate below is taken from the two prefixes around it
+                    const float x0 = ex + q0, x1 = ex + q1, x2 = ex + q2, x3 = ex + q3;
+                    const int j0 = x0 > rems ? 0 : x1 > rems ? 1 : x2 > rems ? 2 : x3 > rems ? 3 : -1;
+                    const unsigned long long hits = __ballot(j0 >= 0);
+                    const uint32_t gmask = static_cast<uint32_t>(hits >> (8 * grp)) & 0xFFu;
+                    const int win = 8 * grp + (gmask ? __builtin_ctz(gmask) : 7);          // the group's first hit (else its last lane)
+                    const float f_idx = j0 >= 0 ? static_cast<float>(4 * gl + j0) : -1.0f;
+                    const float f_a = j0 <= 0 ? (j0 == 0 ? ex : x3) : j0 == 1 ? x0 : j0 == 2 ? x1 : x2;   // (no hit: the chunk's sum)
+                    const float f_b = j0 < 0 ? x3 : j0 == 0 ? x0 : j0 == 1 ? x1 : j0 == 2 ? x2 : x3;
+                    const float g_idx = __shfl(f_idx, win), g_a = __shfl(f_a, win), g_b = __shfl(f_b, win);
+                    // back to the user's own lanes (both halves): user u' is served in pass u' >> 3 by group u' & 7
+                    const int from = 8 * (j & 7);
+                    const float o_idx = __shfl(g_idx, from), o_a = __shfl(g_a, from), o_b = __shfl(g_b, from);
+                    if ((j >> 3) == ps) { r_idx = static_cast<int>(o_idx); r_a = o_a; r_b = o_b; }
+                }
+                vi = r_idx;
+                Av = pb + static_cast<double>(r_a);
+                Bv = pb + static_cast<double>(r_b);
+            } else {
             float om[2 * KH];
 #pragma unroll
             for (int k = 0; k < 2 * KH; ++k) om[k] = om_lds[k];
@@ -2307,9 +2375,9 @@ __device__ __forceinline__ void search_and_emit(const DevSim& d, uint32_t t, con
             // the user's answer is lane h=0's hit if it has one, else lane h=1's
             const int idx_o = __shfl_xor(idx, 32);
             const double A_o = __shfl_xor(A, 32), B_o = __shfl_xor(B, 32);
-            int vi; double Av, Bv;
             if (h == 0) { if (idx >= 0) { vi = idx; Av = A; Bv = B; } else { vi = idx_o >= 0 ? 16 + idx_o : -1; Av = A_o; Bv = B_o; } }
             else        { if (idx_o >= 0) { vi = idx_o; Av = A_o; Bv = B_o; } else { vi = idx >= 0 ? 16 + idx : -1; Av = A; Bv = B; } }
+            }
             const uint32_t v = c_star * 32 + static_cast<uint32_t>(max(vi, 0));
             my_v = v;
             // (S, pb: float64 sums of the sweep's fp32 super-chunk / chunk sums, <= 2^-22 S off the exact sums of its terms)
@@ -3124,11 +3192,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
 // second kernel of the sliced mode: the search over the sums all slices of a user tile left
 #if RG_HAS(3)
 template <int KH>
-#ifdef RG_SEARCH_OCC2
 __global__ void __launch_bounds__(kBlock) k_draw_search(DevSim d, uint32_t t) {
-#else
-__global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : KH <= 16 ? 2 : 1)) k_draw_search(DevSim d, uint32_t t) {
-#endif
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* om_stage = reinterpret_cast<float*>(smem_raw);             // [4 waves][32 users][2KH]
     const int wave = threadIdx.x >> 6, lane = lane_id();
