@@ -124,8 +124,6 @@ struct DevSim {
     uint32_t walk_refill;     // k_walk: free lanes of a wave at which it takes new users from the queue
     uint32_t walk_bias;       // k_walk: 0 = both event kinds every iteration; else one kind, organic when n_org * walk_bias >= n_bandit * 4
     uint32_t walk_click_batch;   // k_walk2: lanes waiting for ctr (kWClick) at which the wave takes them (0: in the bandit iteration itself)
-    uint32_t split_search;    // this launch of the sweep leaves the search to k_draw_search (scratch slot = user tile, as in the sliced form)
-    uint8_t* tile_resc;       // [scratch tiles][128] re-references of the split sweep, per user of the tile (the search's certificate budget)
     uint32_t exact_base;      // first exact_list entry of the batch being resolved
     uint32_t exact_last;      // this is the last batch launched for the step
     float2* sc_scratch;       // [kMaxGrid*4 waves][kMaxSC][32] {sum, reference} of the MFMA draw kernel
@@ -248,8 +246,6 @@ struct rg_sim {
     bool cached_search_old;   // RECOGYM_CACHED=search: the first form of the cached draw (k_draw_search over the cache)
     bool walk;                // rg_sim_run "to the end" walks the run user-major (k_walk) instead of step-major
     int walk_occ;             // blocks per CU of the walk kernel (RECOGYM_WALK_OCC: 2, 3 or 4)
-    uint32_t scratch_tiles;   // user tiles the sweep's sum scratch holds (scratch_tiles_of)
-    bool split_search;        // the lock-step sweep leaves the search to k_draw_search where the scratch allows (RECOGYM_SPLIT_SEARCH_OFF: fused)
     bool walk2;               // the walk is k_walk2 (prefix sums + memo; RECOGYM_WALK=1 keeps k_walk)
     bool walk_solo;           // its last round is k_walk_solo (RECOGYM_WALK_SOLO=0: k_walk2's)
     int n_cus;                // compute units of the device (grid of the persistent walk kernel)
@@ -439,20 +435,6 @@ inline uint32_t exact_kb_of(uint32_t K) {
     return 0;
 }
 
-// Wave slots of the sweep's sum scratch ({sum, reference} of every super-chunk, exp-sum of every chunk, per user).  The
-// fused sweep (search at the end of every user tile) needs one per resident wave: kMaxGrid blocks.  With sigma_omega > 0 the
-// search runs as its own kernel over the whole step (k_draw_search: the sweep's blocks do not sit out its dependent loads),
-// which needs a slot per USER TILE of the step — all users at step 0 — where that fits 24 GB; else the step stays fused.
-inline size_t scratch_tiles_of(const rg_config& c, const Geom& g, size_t n) {
-    size_t tiles = kMaxGrid;
-    if (c.sigma_omega != 0.0 && g.KH && g.KH <= 16) {
-        const size_t want = (n + 127) / 128;
-        const size_t per_tile = 4 * (static_cast<size_t>(g.n_chunks) * 32 * 4 + static_cast<size_t>(kMaxSC) * 32 * 8);
-        if (want > tiles && want * per_tile <= (24ull << 30)) tiles = want;
-    }
-    return tiles;
-}
-
 inline uint32_t hist_cap_of(const rg_config& c) {
     if (c.policy != RG_POLICY_ORGANIC_USER_COUNT && c.policy != RG_POLICY_LOGREG_FROZEN) return 0;
     // entries per row: the header + the distinct products kept, rounded up to whole 128-byte lines of 16 entries (what
@@ -479,10 +461,8 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     double* exact_sums = w.take<double>(exact_rows * (PT / 64));
     unsigned short* gsplit = w.take<unsigned short>(g.N1 ? static_cast<size_t>(g.P_pad) * (g.RS / 2) : 1);
     float* mu32s = w.take<float>(g.N1 ? g.P_pad : 1);
-    const size_t scr_tiles = scratch_tiles_of(c, g, n);
-    float2* sc_scratch = w.take<float2>(g.KH ? scr_tiles * 4 * kMaxSC * 32 : 1);
-    float* chunk_scratch = w.take<float>(g.KH ? scr_tiles * 4 * g.n_chunks * 32 : 1);
-    uint8_t* tile_resc = w.take<uint8_t>(g.KH ? scr_tiles * 128 : 1);
+    float2* sc_scratch = w.take<float2>(g.KH ? static_cast<size_t>(kMaxGrid) * 4 * kMaxSC * 32 : 1);
+    float* chunk_scratch = w.take<float>(g.KH ? static_cast<size_t>(kMaxGrid) * 4 * g.n_chunks * 32 : 1);
     double* omega = w.take<double>(((K + 1) & ~static_cast<size_t>(1)) * n_pad);
     uint32_t* list = w.take<uint32_t>(4 * n);
     uint32_t* step_cnt = w.take<uint32_t>(2 * (kMaxSteps + 2));
@@ -546,7 +526,7 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->gamma32 = gamma32; d->mu32 = mu32; d->gamma32t = gamma32t; d->has_g32t = gamma32t_wanted(c, g) ? 1u : 0u; d->stats = stats; d->omega = omega; d->list = list;
         d->gamma_rm = gamma_rm; d->XKB = xkb;
         d->exact_rows = static_cast<uint32_t>(exact_rows); d->exact_base = 0;
-        d->gammaT = gammaT; d->PT = static_cast<uint32_t>(PT); d->exact_ref = exact_ref; d->exact_sums = exact_sums; d->sc_scratch = sc_scratch; d->chunk_scratch = chunk_scratch; d->tile_resc = tile_resc;
+        d->gammaT = gammaT; d->PT = static_cast<uint32_t>(PT); d->exact_ref = exact_ref; d->exact_sums = exact_sums; d->sc_scratch = sc_scratch; d->chunk_scratch = chunk_scratch;
         d->gsplit = gsplit; d->mu32s = mu32s; d->N1 = g.N1; d->N2 = g.N2; d->N3 = g.N3; d->RS = g.RS; d->TPB = g.TPB;
         d->f16 = g.F16 ? 1u : 0u; d->wide = g.F16 == 2 ? 1u : 0u;
         d->KH = g.KH; d->KS = g.KS; d->TP = g.TP; d->P_pad = g.P_pad; d->n_chunks = g.n_chunks;
@@ -2857,7 +2837,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         if (chunk_lo >= chunk_hi) continue;
         const uint32_t pt_lo = chunk_lo / 4, pt_hi = (chunk_hi + 3) / 4;   // product tiles (TPB = 128: 4 chunks each)
         const uint32_t np = 2 * (pt_hi - pt_lo);                          // pairs of chunks
-        const size_t wslot = (S == 1 && !d.split_search ? static_cast<size_t>(blockIdx.x) : static_cast<size_t>(tb)) * 4 + wave;
+        const size_t wslot = (S == 1 ? static_cast<size_t>(blockIdx.x) : static_cast<size_t>(tb)) * 4 + wave;
         float* scr_chunk = d.chunk_scratch + wslot * d.n_chunks * 32;
         float2* scr = d.sc_scratch + wslot * kMaxSC * 32;
         const uint32_t pos = tb * 128 + wave * 32 + j;
@@ -3183,8 +3163,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             if (prefix_mode) scp_row[sc_cur] = static_cast<float>(run_pref);
         }
         if (d.use_cache && S == 1 && active && h == 0) d.cache_resc[d.uid[slot]] = static_cast<uint8_t>(min(n_resc, 255));
-        if (d.split_search && h == 0) d.tile_resc[static_cast<size_t>(tb) * 128 + wave * 32 + j] = static_cast<uint8_t>(min(n_resc, 255));
-        if (S == 1 && !RG_SWEEP_ABL(128u) && !d.sweep_only && !d.split_search) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, delta_fixed, &view);
+        if (S == 1 && !RG_SWEEP_ABL(128u) && !d.sweep_only) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, delta_fixed, &view);
     }
 }
 #endif
@@ -3225,8 +3204,7 @@ __global__ void __launch_bounds__(kBlock) k_draw_search(DevSim d, uint32_t t) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         const SumsView view = sums_view(d, d.sc_scratch + wslot * kMaxSC * 32, d.chunk_scratch + wslot * d.n_chunks * 32, j, active, slot);
-        const int n_resc = (d.use_cache && active) ? d.cache_resc[d.uid[slot]]
-                           : d.split_search ? d.tile_resc[static_cast<size_t>(tb) * 128 + wave * 32 + j] : 0;
+        const int n_resc = (d.use_cache && active) ? d.cache_resc[d.uid[slot]] : 0;
         search_and_emit<KH>(d, t, d.sc_scratch + wslot * kMaxSC * 32, d.chunk_scratch + wslot * d.n_chunks * 32, omu,
                             Ahat, n_resc, active, pos, slot, j, h, true, kDeltaFixedBf16 + (d.f16 ? f16_extra_delta(d, Ahat, absw) : 0.0), &view);
         __builtin_amdgcn_wave_barrier();
@@ -7156,17 +7134,13 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         if (S > d.n_sc) S = d.n_sc;
         if (S < 1) S = 1;
         const int grid = sweep_grid(sim, static_cast<uint64_t>(tiles_up) * S, S);
-        // sigma_omega > 0, the pipelined sweep of K <= 21: the search as its own kernel over the step's users where the
-        // scratch holds a slot per user tile (scratch_tiles_of) — 29 % of the fused kernel's time was its blocks sitting out
-        // the search's dependent loads at two waves per SIMD (profiles/r3/ab_call25_*)
-        DevSim ds = d;
-        ds.split_search = (S == 1 && sim->split_search && !d.use_cache && !d.wide && sim->bf16_kernel == bf16p_kernel_for(d) &&
-                           tiles_up <= sim->scratch_tiles) ? 1u : 0u;
-        hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid), dim3(sim->draw_threads), sim->bf16_smem, st, ds, t, S);
+        // (the search stays at the end of every user tile of the sweep: as its own kernel over the whole step — scratch slot
+        // per user tile — the sweep got 15 % shorter and the step 6 % longer: profiles/r3/ab_call26_*, ab_call27_*)
+        hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid), dim3(sim->draw_threads), sim->bf16_smem, st, d, t, S);
         if (int rc = prof_mark(sim, st)) return rc;
-        if (S > 1 || ds.split_search)
+        if (S > 1)
             hipLaunchKernelGGL(search_kernel_for(d), dim3(grid_for(upper, 128)), dim3(kBlock),
-                               sizeof(float) * 4 * 32 * 2 * d.KH, st, ds, t);
+                               sizeof(float) * 4 * 32 * 2 * d.KH, st, d, t);
         if (d.use_cache)       // step 0 of a sigma_omega == 0 run: the rows every later draw starts from
             hipLaunchKernelGGL(finalize_kernel_for(d), dim3(grid_for(d.n_users)), dim3(kBlock), 0, st, d);
         if (int rc = prof_mark(sim, st)) return rc;
@@ -7499,9 +7473,6 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     d.walk_handover = 32;
     if (const char* e = getenv("RECOGYM_WALK_HANDOVER")) d.walk_handover = static_cast<uint32_t>(atoi(e));
     d.walk_click_batch = 8;
-    d.split_search = 0;
-    s->scratch_tiles = static_cast<uint32_t>(scratch_tiles_of(*cfg, geom_of(*cfg), n_users));
-    s->split_search = !getenv("RECOGYM_SPLIT_SEARCH_OFF");
     if (const char* e = getenv("RECOGYM_WALK_CLICK_BATCH")) d.walk_click_batch = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_REFILL")) d.walk_refill = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_BIAS")) d.walk_bias = static_cast<uint32_t>(atoi(e));
