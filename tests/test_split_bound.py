@@ -89,3 +89,55 @@ def test_no_click_threshold_is_below_every_click_boundary():
     assert thr < cdf[:, 0].min() - 5e-4          # 0.97 against 0.970688: three orders above any rounding of the chain
     # and the threshold is worth having: it spares 97 % of the events
     assert thr >= 0.97
+
+
+def _cert_correlated(S, A, a, b, delta):
+    """Host restatement of cert_correlated (recogym_hip.hip): -> (num_lo, den_lo, num_hi, den_hi, valid)."""
+    dp = delta * (1.0 + 2.0 * delta)
+    rho = 2.0 ** -20 * 1.001 * S
+    T = S - A
+    return ((A + a) * (1.0 + dp) + rho, T * (1.0 - dp) + A * (1.0 + dp),
+            (A + b) * (1.0 - dp) - rho, T * (1.0 + dp) + A * (1.0 - dp), T >= 0.0 and delta < 0.25)
+
+
+@pytest.mark.parametrize('delta', [1e-6, 8.6e-5, 1e-3])
+def test_correlated_certificate_is_sound_for_worst_case_term_errors(delta):
+    """The certificate on correlated errors: the prefix A at the start of the draw's chunk and the total S are
+    sums of the SAME sweep terms e_p (1 + eps_p), the prefixes a, b inside the chunk are recomputed terms with errors of their
+    own, all |eps| <= delta, and the stored A, S carry up to 2^-21 of fp32 rounding each.  For random softmax-like term
+    vectors and the sign patterns that move a boundary furthest (prefix up / suffix down and the reverse, chunk terms against
+    them, storage roundings against the decision), a certified product must be the true one — and the certified band must be
+    narrower than the independent-error form's, which is the point of it."""
+    rng = np.random.RandomState(5)
+    P, n_cases = 2048, 300
+    wins = 0
+    for case in range(n_cases):
+        e = np.exp(rng.standard_normal(P) * rng.choice([1.0, 3.0, 4.5]))          # true terms
+        c_true = np.cumsum(e)
+        S_true = c_true[-1]
+        v = int(np.searchsorted(c_true, rng.random_sample() * S_true, 'right'))   # the product a draw would land in
+        v = min(v, P - 1)
+        c0 = (v // 32) * 32                                                       # its chunk starts here
+        for sgn in (+1.0, -1.0):                                                  # which way the sweep's errors lean
+            for sgn_in in (+1.0, -1.0):                                           # ... and the recomputed chunk's
+                for sgn_r in (+1.0, -1.0):                                        # ... and the storage roundings
+                    sweep = e.copy()
+                    sweep[:c0] *= 1.0 + sgn * delta                               # terms before the chunk
+                    sweep[c0:] *= 1.0 - sgn * delta                               # the chunk and everything behind it
+                    A = sweep[:c0].sum() * (1.0 + sgn_r * 2.0 ** -21)
+                    S = sweep.sum() * (1.0 - sgn_r * 2.0 ** -21)
+                    rec = e[c0:v + 1] * (1.0 + sgn_in * delta)
+                    a, b = rec[:-1].sum(), rec.sum()
+                    num_lo, den_lo, num_hi, den_hi, valid = _cert_correlated(S, A, a, b, delta)
+                    if not valid or den_lo <= 0 or den_hi <= 0:
+                        continue
+                    u_lo, u_hi = num_lo / den_lo, num_hi / den_hi                 # certified iff u_lo < u < u_hi
+                    t_lo = (c_true[v - 1] if v else 0.0) / S_true                 # the true interval of product v
+                    t_hi = c_true[v] / S_true
+                    if u_lo < u_hi:
+                        assert (v == 0 or u_lo >= t_lo) and (v == P - 1 or u_hi <= t_hi), (case, v, sgn, sgn_in, sgn_r)
+                        # the independent form's interval: C~[v-1](1+d) / (S~(1-d)) < u < C~[v](1-d) / (S~(1+d))
+                        o_lo = (A + a) * (1 + delta) / (S * (1 - delta))
+                        o_hi = (A + b) * (1 - delta) / (S * (1 + delta))
+                        wins += (u_hi - u_lo) > max(o_hi - o_lo, 0.0)
+    assert wins > n_cases            # (8 sign patterns per case: the correlated interval is the wider one in most of them)
