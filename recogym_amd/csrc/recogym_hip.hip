@@ -124,6 +124,7 @@ struct DevSim {
     uint32_t walk_refill;     // k_walk: free lanes of a wave at which it takes new users from the queue
     uint32_t walk_bias;       // k_walk: 0 = both event kinds every iteration; else one kind, organic when n_org * walk_bias >= n_bandit * 4
     uint32_t walk_click_batch;   // k_walk2: lanes waiting for ctr (kWClick) at which the wave takes them (0: in the bandit iteration itself)
+    uint32_t walk_search_batch;  // k_walk2: lanes that missed the memo at which the wave runs the search (its chunk passes take 8 users each)
     uint32_t exact_base;      // first exact_list entry of the batch being resolved
     uint32_t exact_last;      // this is the last batch launched for the step
     float2* sc_scratch;       // [kMaxGrid*4 waves][kMaxSC][32] {sum, reference} of the MFMA draw kernel
@@ -5633,7 +5634,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
         const uint32_t n_c = static_cast<uint32_t>(__popcll(__ballot(st == kWClick)));
         // (walk_bias == 0: the memo-answered draws AND the bandit events of the wave in the same iteration)
         bool do_org = false, do_srch = false, do_ban = false, do_clk = false;
-        if (n_s >= 16u || (n_s && !n_o && !n_b)) do_srch = true;
+        if (n_s >= d.walk_search_batch || (n_s && !n_o && !n_b)) do_srch = true;
         else if (n_c && (n_c >= d.walk_click_batch || (!n_o && !n_b))) do_ban = do_clk = true;   // the bandit events that need ctr
         else if (d.walk_bias == 0u) { do_org = n_o != 0u; do_ban = n_b != 0u; }
         else if (n_o && (n_o * d.walk_bias >= n_b * 4u)) do_org = true;
@@ -7474,6 +7475,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     if (const char* e = getenv("RECOGYM_WALK_HANDOVER")) d.walk_handover = static_cast<uint32_t>(atoi(e));
     d.walk_click_batch = 8;
     if (const char* e = getenv("RECOGYM_WALK_CLICK_BATCH")) d.walk_click_batch = static_cast<uint32_t>(atoi(e));
+    d.walk_search_batch = 16;
+    if (const char* e = getenv("RECOGYM_WALK_SEARCH_BATCH")) d.walk_search_batch = static_cast<uint32_t>(atoi(e)) ? static_cast<uint32_t>(atoi(e)) : 1u;
     if (const char* e = getenv("RECOGYM_WALK_REFILL")) d.walk_refill = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_BIAS")) d.walk_bias = static_cast<uint32_t>(atoi(e));
     // k_walk2 where it is instantiated for the configuration (RECOGYM_WALK=1: k_walk), four blocks per CU at K <= 20
