@@ -38,6 +38,9 @@ WORKLOADS = {
     'c4shard': (dict(num_products=100000, K=64, sigma_omega=0.1), 1_250_000, 10_000_000, 'none'),
     # verify_agents(env, users, {BanditMFSquare, LogregMulticlassIps}) with the env's defaults (sigma_omega = 0.1)
     'c5': (dict(num_products=10000, K=20), 1_250_000, 10_000_000, 'c5'),
+    # the same A/B loop at a size the REFERENCE can train: both policies fitted by the reference's own code (tests/make_golden.py
+    # c5_trained -> tests/golden/c5_trained_p100.npz: LogregMulticlassIps build() and BanditMFSquare train() on 1 000 users)
+    'c5trained': (dict(num_products=100, K=20), 1_250_000, 10_000_000, 'c5trained'),
     'tiny': (dict(num_products=100, K=20, sigma_omega=0.0), 20_000, 20_000, 'ouc'),
     'tiny5': (dict(num_products=300, K=20), 20_000, 20_000, 'c5'),
 }
@@ -66,6 +69,15 @@ def arms_of(workload, cfg):
     LogregMulticlassIps model with one class per product.  The models are random (training is the reference's host
     code, SURVEY.md §2: a random table and N(0, 0.1) coefficients), seeded, the same on every rank."""
     pol = WORKLOADS[workload][3]
+    if pol == 'c5trained':
+        import numpy as np
+        from recogym_amd.agents import LastViewTableAgent, LogregFrozenAgent
+        z = np.load(os.path.join(ROOT, 'tests', 'golden', 'c5_trained_p100.npz'))
+        assert int(z['bmf_product_embedding'].shape[0]) == cfg.num_products
+        mf = LastViewTableAgent.from_bandit_mf(cfg, z['bmf_product_embedding'], z['bmf_user_embedding'])
+        lr = LogregFrozenAgent(cfg, z['logreg_coef'], z['logreg_intercept'], z['logreg_classes'])
+        strip = lambda d: {k: v for k, v in d.items() if k != 'ouc'}
+        return [('bandit_mf_fitted', strip(mf.device_policy())), ('logreg_ips_fitted', strip(lr.device_policy()))]
     if pol != 'c5':
         return [(pol, policy_kwargs(pol))]
     import numpy as np
@@ -134,7 +146,7 @@ def cpu_baseline(workload, seconds_target=12.0):
     out = {}
     try:      # the NumPy reference itself, measured where /root/reference exists (tools/time_reference.py)
         ref = json.load(open(os.path.join(ROOT, 'profiles', 'r2', 'numpy_reference_cpu.json')))
-        case = {'c3': 'c3', 'c3drift': 'c3', 'c2': 'c2', 'c4shard': 'c4_capped', 'tiny': 'c1', 'c5': 'c3', 'tiny5': 'c1'}[workload]
+        case = {'c3': 'c3', 'c3drift': 'c3', 'c2': 'c2', 'c4shard': 'c4_capped', 'tiny': 'c1', 'c5': 'c3', 'tiny5': 'c1', 'c5trained': 'c2'}[workload]
         rc = ref['cases'][case]
         out['reference_numpy'] = dict(
             one_core_events_per_s=rc['one_core_events_per_s'], all_core_events_per_s=rc['all_core_events_per_s'],
@@ -289,8 +301,13 @@ def main():
         sys.exit(rc)
 
     import torch
-    rank, local_rank, world, dist = parallel.init_from_env('nccl')
+    # (RECOGYM_BENCH_BACKEND=gloo RECOGYM_BENCH_ONE_DEVICE=1: the N > 1 code path on a ONE-GPU box, every rank on cuda:0 — a test
+    # of this script's multi-rank logic, tests/test_hip_parity.py; never a measurement)
+    one_device = os.environ.get('RECOGYM_BENCH_ONE_DEVICE') == '1'
+    rank, local_rank, world, dist = parallel.init_from_env(os.environ.get('RECOGYM_BENCH_BACKEND', 'nccl'))
     assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if one_device:
+        local_rank = 0
     device = torch.device(f'cuda:{local_rank}')
     torch.cuda.set_device(device)
 
@@ -341,6 +358,8 @@ def main():
             vec += v
         return per_arm, vec
 
+    per_rank_ms = []          # ms per step of every rank in the last timed() (N > 1)
+
     def sync():
         if dist:
             dist.barrier()
@@ -364,11 +383,15 @@ def main():
         elapsed = time.perf_counter() - t0
         el = torch.tensor([elapsed], dtype=torch.float64, device=device)
         if dist:
+            every = [torch.zeros_like(el) for _ in range(world)]
+            dist.all_gather(every, el)
+            per_rank_ms[:] = [round(1e3 * float(x.item()) / max(steps, 1), 3) for x in every]
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el.item()), totals.cpu().numpy(), last
 
     elapsed, totals, last = timed(arms, args.steps, args.warmup, profiled=args.single_run)
     events = int(totals[0] + totals[1])
+    ranks_ms = list(per_rank_ms)
     for c in last:
         assert c['hist_overflow'] == 0 and c['log_dropped'] == 0 and c['live'] == 0 and c['exact_overflow'] == 0, c
 
@@ -491,6 +514,47 @@ def main():
         del darms
         torch.cuda.empty_cache()
 
+    # --- N > 1: the OTHER scaling form in the same run (north_star states the target as 10 M users in total over 1/2/4/8
+    # GPUs: strong; the contract's `value` keeps per-GPU work fixed: weak), and the latency of the one collective the path has ---
+    other = allreduce = None
+    if dist and not args.shard and not args.single_run:
+        o_form = 'strong' if args.scaling == 'weak' else 'weak'
+        if o_form == 'strong':
+            o_total = args.users * world if args.users else total
+            o_first, o_users = parallel.shard_range(o_total, rank, world)
+        else:
+            o_users = (args.users // world if args.users else per_gpu)
+            o_first, o_total = rank * o_users, o_users * world
+        saved = (first_user, users)
+        first_user, users = o_first, o_users          # (one_step reads these)
+        _, o_arms = build(args.workload, o_users)
+        o_el, o_tot, _ = timed(o_arms, args.steps, args.warmup)
+        other = dict(scaling=o_form, value=float(o_tot[0] + o_tot[1]) / o_el, unit='events/s', ms_per_step=1e3 * o_el / args.steps,
+                     users_total=int(o_total), users_per_gpu=int(o_users), events_per_step=int(o_tot[0] + o_tot[1]) // args.steps,
+                     per_rank_ms_per_step=list(per_rank_ms))
+        for _, sim_o in o_arms:
+            sim_o.close()
+        del o_arms
+        torch.cuda.empty_cache()
+        first_user, users = saved
+        # the CTR reduction itself: 100 all-reduces of the 24-byte {clicks, impressions, phantom} vector, each timed to completion
+        v = torch.zeros(3, dtype=torch.int64, device=device)
+        for _ in range(10):
+            dist.all_reduce(v)
+        torch.cuda.synchronize(device)
+        lat = []
+        for _ in range(100):
+            dist.barrier()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            dist.all_reduce(v)
+            torch.cuda.synchronize(device)
+            lat.append(1e6 * (time.perf_counter() - t0))
+        lat.sort()
+        allreduce = dict(bytes=24, median_us=round(lat[50], 1), p10_us=round(lat[10], 1), p90_us=round(lat[90], 1), samples=100,
+                         note='one all_reduce(SUM) per agent per evaluation closes test_agent / verify_agents (bench_agents.py:203-206): '
+                              'host-timed from launch to completion, after a barrier')
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:     # the CPU leg runs at N = 1 only
         cpu = cpu_baseline(args.workload)
@@ -514,7 +578,9 @@ def main():
             'config': {'workload': f'{args.workload}: reco-gym-v1 P={cfg.num_products} K={cfg.K} '
                                    f'sigma_omega={cfg.sigma_omega} policy={pol}'
                                    + (' (verify_agents: frozen BanditMFSquare table arm + frozen LogregMulticlassIps arm, same users)'
-                                      if pol == 'c5' else ''),
+                                      if pol == 'c5' else '')
+                                   + (' (verify_agents: both arms FITTED BY THE REFERENCE\'s code on 1 000 users, same users)'
+                                      if pol == 'c5trained' else ''),
                        'users_per_gpu': users, 'users_total': users_total, 'first_user': first_user,
                        'events_per_step': events // args.steps,
                        'log': 'off' if args.no_log else '16 B/row device log + float64 ps side array',
@@ -525,6 +591,11 @@ def main():
             'sigma_omega_gt0': drift,
             'cpu_baseline': cpu,
         }
+        if world > 1:
+            out['per_rank_ms_per_step'] = ranks_ms
+            out['other_scaling'] = other
+            out['allreduce_us'] = None if allreduce is None else allreduce['median_us']
+            out['allreduce'] = allreduce
         if shard_note:
             out['config']['shard'] = shard_note
         if digest is not None:

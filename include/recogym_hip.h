@@ -223,6 +223,20 @@ int rg_sim_reseed(rg_sim* sim, uint64_t seed, uint64_t policy_seed);
  * bandit state; a user that stops then gets no phantom row — the caller's agent owns it). */
 int rg_sim_step(rg_sim* sim, const int32_t* d_actions, void* stream);
 
+/* AbstractEnv.step for ONE user (the gym.Env episode API: reset / step, abstract.py:123-197) with a single read-back: needs
+ * RG_POLICY_EXTERNAL and a one-user reset range.  `action` is the agent's action for a user in the bandit state (ignored in
+ * the organic state).  One Markov transition; then *out (host memory) receives, through one pinned-memory copy and ONE stream
+ * synchronisation, the row the step emitted, the user's state and clock after it, and the float64 side values of the row. */
+typedef struct rg_step_result {
+    rg_event row;        /* the emitted row (has_row = 0: none, e.g. no log attached) */
+    int32_t state;       /* RG_STATE_* after the transition */
+    int32_t has_row;
+    double time;         /* the user's clock after the step (event index + 1 with the default time generator) */
+    double ps;           /* float64 propensity of the row where the side array is attached, else the row's float32 value */
+    double p_click;      /* click probability of a bandit row where that side array is attached, else 0 */
+} rg_step_result;
+int rg_sim_step_user(rg_sim* sim, int32_t action, rg_step_result* out, void* stream);
+
 /* generate_logs' user loop (abstract.py:299-316) for all users at once: steps until every user
  * reached `stop` or max_steps transitions were made.  Synchronises `stream`.  With max_steps >=
  * 65536 ("to the end") the last users of the run (<= 4096 alive at a 16-step poll, fewer for tables larger than 10^4 x 20; RECOGYM_TAIL overrides) are walked
@@ -294,6 +308,11 @@ int rg_sim_debug_uncertified(rg_sim* sim, uint8_t* d_flags, void* stream);
  * rg_sim_debug_ouc_acts: OrganicUserEventCounterModel.act (organic_user_count.py:45-96) of every user index on its
  * current history with d_u1[i] as the uniform of the action draw: d_action / d_ps (float64) as logged, d_flags[i] = 1
  * iff the action was decided by the integer prefix walk (outside its 2^-36 band), 0 = float64 cdf walk. */
+/* rg_sim_debug_walk_fate: after a sigma_omega == 0 run "to the end" (the user-major walk), d_flags[i] (n bytes) = bit 0: user
+ * index i met a draw the fast certificate rejected (or was handed over by a draining wave) and went through the float64
+ * batch and round 2; bit 1: its last events were walked by the last round (a wave per user).  The sampled-oracle parity
+ * check picks users of every kind with it. */
+int rg_sim_debug_walk_fate(rg_sim* sim, uint8_t* d_flags, void* stream);
 int rg_sim_debug_click_decisions(rg_sim* sim, const int32_t* d_actions, const double* d_u, uint8_t* d_out, void* stream);
 int rg_sim_debug_set_history(rg_sim* sim, const uint32_t* d_nd, const uint32_t* d_products, const uint32_t* d_counts,
                              uint32_t stride, void* stream);

@@ -61,6 +61,12 @@ class RgEvent(C.Structure):
     _fields_ = [('u', C.c_uint32), ('t', C.c_uint32), ('code', C.c_uint32), ('ps', C.c_float)]
 
 
+class RgStepResult(C.Structure):
+    """struct rg_step_result: what rg_sim_step_user reads back."""
+    _fields_ = [('row', RgEvent), ('state', C.c_int32), ('has_row', C.c_int32), ('time', C.c_double), ('ps', C.c_double),
+                ('p_click', C.c_double)]
+
+
 # every symbol include/recogym_hip.h declares, with its ctypes signature
 _SIM = C.c_void_p
 SYMBOLS = {
@@ -81,6 +87,7 @@ SYMBOLS = {
     'rg_sim_reset_users': (C.c_int, [_SIM, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     'rg_sim_reseed': (C.c_int, [_SIM, C.c_uint64, C.c_uint64]),
     'rg_sim_step': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
+    'rg_sim_step_user': (C.c_int, [_SIM, C.c_int32, C.POINTER(RgStepResult), C.c_void_p]),
     'rg_sim_run': (C.c_int, [_SIM, C.c_uint32, C.c_void_p]),
     'rg_sim_read_counters': (C.c_int, [_SIM, C.POINTER(C.c_int64), C.c_void_p]),
     'rg_sim_set_profiling': (C.c_int, [_SIM, C.c_int]),
@@ -98,6 +105,7 @@ SYMBOLS = {
     'rg_sim_debug_set_omega': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_debug_set_uniforms': (C.c_int, [_SIM, C.c_void_p]),
     'rg_sim_debug_uncertified': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
+    'rg_sim_debug_walk_fate': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_debug_click_decisions': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'rg_sim_debug_set_history': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     'rg_sim_debug_ouc_acts': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -174,6 +174,17 @@ struct DevSim {
     uint32_t* park_list;      // [n_cap + 64] user indices, reserved in chunks of 64 (0xFFFFFFFF = unused entry)
     uint32_t* park_t;         // [n_cap] time of the parked draw
     uint8_t* f64_valid;       // [n_cap] exact_sums / exact_ref rows (indexed by user index in this mode) are valid
+    // The walked run as a pipeline over user groups (run_walk_pipe): every launch works on the user-index range
+    // [grp_lo, grp_lo + grp_n) and on work queues of its own, so that the launches of different groups can be in flight at once
+    // on different streams.  Outside the pipeline: the whole reset range and the two counters[] slots.
+    uint32_t grp_lo, grp_n;
+    uint32_t list_in;         // first park_list entry of the list k_exact_sums_h / k_exact_prefix read
+    unsigned long long* q_ticket;        // ticket counter of the launch's work queue
+    unsigned long long* q_park;          // entries reserved so far in the list the launch appends to (blocks of 64)
+    const unsigned long long* q_count;   // non-null: the length of the list the launch reads is *q_count, known on the device
+                                         // only (the argument is then an upper bound used for nothing but launch shapes)
+    unsigned long long* walk_ctl;        // [kWalkCtlWords] the queues' counters (workspace)
+    unsigned long long* step1_buf;       // [16] rg_sim_step_user: word 0 = the action, words 8.. = the packed result
     uint32_t* exact_cnt_b;    // [kMaxSteps+2] draws to resolve whose float64 sums are already there: they sit at the
                               // BACK of exact_list (entry n_cap - 1 - i); those that need the sums at the front
     // state (workspace)
@@ -251,10 +262,23 @@ struct rg_sim {
     bool walk_solo;           // its last round is k_walk_solo (RECOGYM_WALK_SOLO=0: k_walk2's)
     int n_cus;                // compute units of the device (grid of the persistent walk kernel)
     double prof_walk_ms[2];   // round 1 / round 2 of k_walk
+    // the walked run as a pipeline over user groups on two or three streams (run_walk_pipe)
+    int pipe_groups;          // user groups (1 = one group: the serial chain without host read-backs); 0 = run_walk (host-side counts)
+    int pipe_mode;            // 0: every launch on the caller's stream; 1: float64 batch + round 2 of a group on a second stream;
+                              // 2: ... and the sweeps on a third
+    int pipe_occ1, pipe_occ2; // blocks per CU of the round-1 / round-2 grids (<= what the kernel is compiled for)
+    int pipe_xblocks;         // blocks of the float64 batch's grid
+    uint32_t pipe_min_users;  // users of a group (and of a pipelined run) at least: an unsliced sweep's 1024 user tiles (RECOGYM_PIPE_MIN: tests)
+    hipStream_t pipe_streams[2];
+    std::vector<hipEvent_t> pipe_events;   // ordering events (no timing), created once
+    double prof_pipe_ms;      // profiling: wall time of the pipelined runs (its kernels' own times overlap)
+    // rg_sim_debug_walk_fate: where the last walked run left the list of its last round (null: there was none)
+    uint32_t fate_base; const unsigned long long* fate_count;
     uint32_t repack_every;    // steps between repacks (RECOGYM_REPACK, 0 = never)
     uint32_t tail_below;      // rg_sim_run hands the run to k_tail once at most this many users live (RECOGYM_TAIL, 0 = never)
     double prof_tail_ms;
     uint32_t* h_pinned;       // 4 x u32 staging for the live-count readback
+    char* h_step;             // 128 pinned bytes of rg_sim_step_user: the action going down, the packed result coming back
     size_t mfma_smem, bf16_smem;
     void (*bf16_kernel)(DevSim, uint32_t, uint32_t);
     uint32_t draw_threads, draw_users;   // block size of that kernel and the users one block sweeps for (256 / 128; wide K: 512 / 256)
@@ -334,6 +358,15 @@ constexpr uint32_t kHoleCode = 0xFFFFFFFFu;   // rg_event.code of an unused raw-
 constexpr int kCntTailRows = 16, kCntTailOrganic = 17, kCntTailBandit = 18, kCntTailMaxT = 19, kCntTailTicket = 20,
               kCntTailLimit = 21, kCntWalkTicket = 22, kCntParkCnt = 23;   // internal slots of counters[] (RG_CNT_N = 24)
 constexpr int kCntWalkHits = RG_CNT_MEMO_HITS;
+// the walked run as a pipeline over user groups (run_walk_pipe): at most kMaxWalkGroups groups; a park_list region per group
+// holds its users plus the 64-entry blocks its waves leave part-used (<= 2 per wave: parked users, hand-over); walk_ctl =
+// 8 counters per group {round-1 ticket, round-1 list length, float64 batch ticket, round-2 ticket, -...} and, in block
+// kMaxWalkGroups, {last round's list length, last round's ticket}.  The last round's list: kParkSlack entries per group
+// (a wave of a round 2 hands over once: <= 2 blocks).  Walk grids are capped at kMaxWalkWaves waves.
+constexpr uint32_t kMaxWalkGroups = 16;
+constexpr uint32_t kMaxWalkWaves = 4096;
+constexpr uint32_t kParkSlack = 2u * 64u * kMaxWalkWaves;
+constexpr uint32_t kWalkCtlWords = 8u * (kMaxWalkGroups + 1u);
 
 struct Geom { uint32_t KH, KS, TP, P_pad, n_chunks, sc_chunks, n_sc, N1, N2, N3, RS, TPB, F16; };
 
@@ -505,7 +538,11 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint32_t* lr_list = w.take<uint32_t>(lr ? n : 1);
     uint32_t* lr_cnt = w.take<uint32_t>(lr ? kMaxSteps + 2 : 1);
     uint32_t* lr_part = w.take<uint32_t>(lr ? n * static_cast<size_t>(8 * (4 + 2 * 8)) : 1);       // kLrSplit x kLrPartWords
-    uint32_t* park_list = w.take<uint32_t>(cache ? n + 64 + 64 * 16384 : 1);   // round 1's list, then round 2's hand-overs, 64-entry blocks per wave
+    // round 1's list, then round 2's hand-overs, 64-entry blocks per wave; the pipeline: a region per user group (its users +
+    // kParkSlack for the blocks its waves leave part-used) and one for the last round's list
+    uint32_t* park_list = w.take<uint32_t>(cache ? n + 128 + static_cast<size_t>(2 * kMaxWalkGroups) * kParkSlack : 1);
+    unsigned long long* walk_ctl = w.take<unsigned long long>(kWalkCtlWords);
+    unsigned long long* step1_buf = w.take<unsigned long long>(16);      // rg_sim_step_user: {action | result}
     uint32_t* park_t = w.take<uint32_t>(cache ? n : 1);
     const bool rp = n >= repack_min_users();      // small runs never repack: no second copy
     double* omega_alt = w.take<double>(rp ? ((K + 1) & ~static_cast<size_t>(1)) * n_pad : 1);
@@ -520,6 +557,7 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->beta32 = cache ? beta32 : nullptr; d->KB4 = static_cast<uint32_t>(KB4);
         d->f64_valid = f64_valid; d->exact_cnt_b = exact_cnt_b; d->cache_row = cache_row; d->cache_row_f = cache_row_f;
         d->park_list = park_list; d->park_t = park_t; d->sweep_only = 0;
+        d->walk_ctl = walk_ctl; d->step1_buf = step1_buf;
         d->walk_hot = cache ? walk_hot : nullptr; d->walk_scp = walk_scp;
         d->lr_action = lr_action; d->lr_dirty = lr ? lr_dirty : nullptr; d->lr_list = lr_list; d->lr_cnt = lr_cnt; d->lr_part = lr_part;
         d->uid = uid; d->omega_alt = omega_alt; d->hist_alt = hist_alt;
@@ -1151,12 +1189,12 @@ __device__ void history_add(const DevSim& d, uint32_t slot, uint32_t v) {
 // LDS, entries 16 .. nd of the row in memory are current and all larger than the line's last product).  Touches only entries
 // >= 16 of the row; the header stays with the caller.  Returns 1 if the product is new (the caller's distinct count), 0 if
 // its count was raised; `nd` = distinct products before the view (>= 15, nd + 1 < hist_cap checked by the caller).
-__device__ __forceinline__ uint32_t history_tail_add(hent_t* hr, uint32_t nd, uint32_t v) {
+__device__ __forceinline__ uint32_t history_tail_add(hent_t* hr, uint32_t nd, uint32_t v, uint32_t first = 16u) {
     const hent_t key = static_cast<hent_t>(v) << 32;
-    uint32_t pos = 16;                          // first entry >= 16 with product >= v (nd + 1 if none)
+    uint32_t pos = first;                       // first entry >= `first` (the caller's line: 16, compact 32) with product >= v (nd + 1 if none)
     hent_t at = 0ull;
     bool past = false;
-    for (uint32_t base = 16; base <= nd && !past; base += kHistRegs) {
+    for (uint32_t base = first; base <= nd && !past; base += kHistRegs) {
         hent_t f[kHistRegs];
         hist_load_line(hr + base, f);
 #pragma unroll
@@ -1703,10 +1741,12 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_h(DevSim d, uint32_t n, u
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int q = lane >> 4, jl = lane & 15;
     const uint32_t n_cc = d.PT / 64;
+    if (d.q_count) n = static_cast<uint32_t>(*d.q_count);      // the list's length as the kernel before this one left it
+    const uint32_t* plist = d.park_list + d.list_in;
     const uint32_t n_groups = (n + UPB - 1) / UPB;
     for (;;) {
         __syncthreads();                       // s_grp and the LDS tiles of the previous group are free
-        if (threadIdx.x == 0) s_grp = static_cast<uint32_t>(atomicAdd(&d.counters[kCntWalkTicket], 1ull));
+        if (threadIdx.x == 0) s_grp = static_cast<uint32_t>(atomicAdd(d.q_ticket, 1ull));
         __syncthreads();
         const uint32_t grp = s_grp;
         if (grp >= n_groups) break;
@@ -1718,7 +1758,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_h(DevSim d, uint32_t n, u
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const uint32_t w_idx = grp * UPB + wave * UPW + g * 16 + jl;
-                uint32_t slot = w_idx < n ? d.park_list[w_idx] : 0xFFFFFFFFu;
+                uint32_t slot = w_idx < n ? plist[w_idx] : 0xFFFFFFFFu;
                 act[g] = slot != 0xFFFFFFFFu;
                 if (!act[g]) slot = 0u;
                 row[g] = slot;
@@ -1794,7 +1834,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_h(DevSim d, uint32_t n, u
 #pragma unroll
             for (int j = 0; j < UPL; ++j) {
                 const uint32_t w_idx = grp * UPB + wave * 64 * UPL + j * 64 + lane;
-                uint32_t slot = w_idx < n ? d.park_list[w_idx] : 0xFFFFFFFFu;
+                uint32_t slot = w_idx < n ? plist[w_idx] : 0xFFFFFFFFu;
                 act[j] = slot != 0xFFFFFFFFu;
                 if (!act[j]) slot = 0u;
                 w_row[j] = slot;
@@ -2821,8 +2861,11 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
     float* om_stage = mu_buf + 3 * d.TPB + 64;                        // [4 waves][32 users][2KH] omega32
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();   // scalar: per-wave pointers stay in SGPRs
     const int j = lane & 31, h = lane >> 5;
-    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
-    const uint32_t n_tiles = (n_o + 127) / 128;
+    // (the walked run's sweep, sweep_only: every user of the launch's group [grp_lo, grp_lo + grp_n) is organic at t = 0 and the
+    // list is still the identity — the pipeline sweeps one group per launch)
+    const uint32_t pos0 = d.sweep_only ? d.grp_lo : 0u;
+    const uint32_t n_o = d.sweep_only ? pos0 + d.grp_n : d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const uint32_t n_tiles = (n_o - pos0 + 127) / 128;
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
     const float mumax = d.stats[2 * KH + 1], g2max = d.stats[2 * KH];
     const uint32_t scps = (d.n_sc + S - 1) / S;                       // super-chunks per slice
@@ -2841,7 +2884,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         const size_t wslot = (S == 1 ? static_cast<size_t>(blockIdx.x) : static_cast<size_t>(tb)) * 4 + wave;
         float* scr_chunk = d.chunk_scratch + wslot * d.n_chunks * 32;
         float2* scr = d.sc_scratch + wslot * kMaxSC * 32;
-        const uint32_t pos = tb * 128 + wave * 32 + j;
+        const uint32_t pos = pos0 + tb * 128 + wave * 32 + j;
         const bool active = pos < n_o;
         const uint32_t slot = active ? cur[pos] : 0u;
         const SumsView view = sums_view(d, scr, scr_chunk, j, active, slot);
@@ -3236,7 +3279,7 @@ __global__ void __launch_bounds__(kBlock) k_cache_finalize(DevSim d) {
     const float mumax = d.stats[2 * KH + 1], g2max = d.stats[2 * KH];
     float gsum = 0.0f;
     if (d.f16) for (uint32_t k = 0; k < d.K; ++k) gsum += d.stats[k];
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) {
+    for (uint32_t i = d.grp_lo + blockIdx.x * kBlock + threadIdx.x; i < d.grp_lo + d.grp_n; i += gridDim.x * kBlock) {
         // everything is staged in registers and leaves as 16-byte stores (a row is 256-byte aligned)
         float4* row4 = reinterpret_cast<float4*>(d.cache_row + static_cast<size_t>(i) * d.cache_row_f);
         // omega32 and the logit error bound, exactly as the sweep kernel computes them
@@ -4795,7 +4838,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
                 if (res_next == res_end) {
                     if (exhausted) break;
                     uint32_t base = 0;
-                    if (lane == 0) base = static_cast<uint32_t>(atomicAdd(&d.counters[kCntWalkTicket], 64ull));
+                    if (lane == 0) base = static_cast<uint32_t>(atomicAdd(d.q_ticket, 64ull));
                     base = __builtin_amdgcn_readfirstlane(base);
                     if (base >= n_work) { exhausted = true; break; }
                     res_next = base; res_end = min(base + 64u, n_work);
@@ -4860,7 +4903,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
                 if (park_next + np > park_end) {
                     for (uint32_t r = park_next + lane; r < park_end; r += 64) d.park_list[out_base + r] = 0xFFFFFFFFu;
                     uint32_t base = 0;
-                    if (lane == 0) base = static_cast<uint32_t>(atomicAdd(&d.counters[kCntParkCnt], 64ull));
+                    if (lane == 0) base = static_cast<uint32_t>(atomicAdd(d.q_park, 64ull));
                     base = __builtin_amdgcn_readfirstlane(base);
                     park_next = base; park_end = base + 64;
                 }
@@ -5177,7 +5220,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
             if (park_next + np > park_end) {
                 for (uint32_t r = park_next + lane; r < park_end; r += 64) d.park_list[out_base + r] = 0xFFFFFFFFu;
                 uint32_t base = 0;
-                if (lane == 0) base = static_cast<uint32_t>(atomicAdd(&d.counters[kCntParkCnt], 64ull));
+                if (lane == 0) base = static_cast<uint32_t>(atomicAdd(d.q_park, 64ull));
                 base = __builtin_amdgcn_readfirstlane(base);
                 park_next = base; park_end = base + 64;
             }
@@ -5360,11 +5403,11 @@ __host__ __device__ inline size_t walk2_wave_lds(int hist) { return (hist ? 16 *
 // (powers of two) of their entries to the common reference.
 __global__ void __launch_bounds__(kBlock) k_cache_prefix(DevSim d, int fused) {
     const int lane = lane_id(), grp = lane >> 3, gl = lane & 7;
-    const uint32_t n_groups = (d.n_users + 7) / 8;
+    const uint32_t n_groups = (d.grp_n + 7) / 8;
     const uint32_t waves = gridDim.x * (kBlock / 64);
     for (uint32_t ug = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); ug < n_groups; ug += waves) {
-        const uint32_t i = ug * 8 + grp;
-        const bool act = i < d.n_users;
+        const uint32_t i = d.grp_lo + ug * 8 + grp;
+        const bool act = i < d.grp_lo + d.grp_n;
         const size_t row = act ? i : d.n_cap;
         const float4* r4 = reinterpret_cast<const float4*>(d.cache_row + row * d.cache_row_f);
         const float4 hdr = r4[8], of0 = r4[9], of1 = r4[10];
@@ -5479,8 +5522,9 @@ __global__ void __launch_bounds__(kBlock) k_exact_prefix(DevSim d, uint32_t n_li
     const int lane = lane_id();
     const uint32_t n_cc = d.PT / 64;
     const uint32_t waves = gridDim.x * (kBlock / 64);
+    if (d.q_count) n_list = static_cast<uint32_t>(*d.q_count);
     for (uint32_t w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < n_list; w += waves) {
-        const uint32_t slot = d.park_list[w];
+        const uint32_t slot = d.park_list[d.list_in + w];
         if (slot == 0xFFFFFFFFu) continue;
         double* row = d.exact_sums + static_cast<size_t>(slot) * n_cc;
         double run = 0.0;
@@ -5500,6 +5544,16 @@ __device__ __forceinline__ uint32_t exact_pick_call(const DevSim& d, const doubl
                                                    double u, int lane) {
     return exact_pick_wave(d, sums, om, M, u, 1u, lane);
 }
+
+// k_walk2's COMPACT history line (HIST == 2: products < 65 535, hist_cap <= 32 768): the same 128 bytes of LDS per lane hold
+// 32 words instead of 16 64-bit entries — word 0 the header (views << 15 | distinct), words 1 .. 31 the 31 smallest products as
+// (PREFIX << 16 | product): the running view count up to and including the product in the high half (a user has < 65 536
+// events), so the words ascend with the index, an unused word is 0xFFFFFFFF, and the policy's act — first product whose
+// cumulative count exceeds u x views — is a COUNT of words below a key: two LDS round trips (the last word of every 8-word
+// segment, then the segment) and ~40 vector instructions instead of a 10-instruction step per entry, and all but ~1 % of C3's
+// events find their whole history in the line (15 products in 64-bit entries: 11.6 % beyond).  Word w of the line is half
+// (w & 1) of the 64-bit LDS entry hl[(w >> 1) * 64]; the user's ROW keeps the (product, count) form every other kernel reads.
+constexpr uint32_t kHcLine = 32;     // words of the compact line (header + 31 products)
 
 // Three blocks per CU (168 VGPRs, no spills).  Four (128 VGPRs) were measured in two forms — omega32 re-read from the cache
 // row instead of held in registers, and the Gamma rows of the chunk pass in two batches — and did not pay: the extra loads and
@@ -5534,6 +5588,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
     bool exhausted = false;
     // wave-uniform tallies (scalar registers): events are counted by ballots
     uint32_t c_org = 0, c_ban = 0, c_clicks = 0, c_ph = 0, c_pick = 0, c_sweeps = 0, c_maxt = 0, c_limit = 0, c_hit = 0, c_anch = 0;
+    if (const unsigned long long* qc = ((const DevSim*)kargs)->q_count) n_work = static_cast<uint32_t>(*qc);   // (pipeline: the list's length is on the device)
 
     for (;;) {
         asm volatile("" : "+s"(kargs));
@@ -5541,10 +5596,51 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
         const uint32_t n_cc = d.PT / 64;
         // the view history is written back when the lane lets go of the user (stop, park, hand-over) or needs the row
         auto flush_hist = [&](bool c) {
+            if (HIST == 2 && c) {
+                // (product, count) entries from the prefixes; the pairs that hold entries <= nd (what lies behind them in the row
+                // is don't-care)
+                ulonglong2* hw = reinterpret_cast<ulonglong2*>(hist_row(d, slot));
+                const uint32_t h0 = static_cast<uint32_t>(hl[0]);
+                const uint32_t nd = h0 & 0x7FFFu;
+                uint32_t prev = 0u;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const hent_t x = hl[i * 64];
+                    const uint32_t w0 = static_cast<uint32_t>(x), w1 = static_cast<uint32_t>(x >> 32);
+                    hent_t e0, e1;
+                    if (i == 0) e0 = (static_cast<hent_t>(h0 >> 15) << 32) | nd;
+                    else { e0 = (static_cast<hent_t>(w0 & 0xFFFFu) << 32) | ((w0 >> 16) - prev); prev = w0 >> 16; }
+                    e1 = (static_cast<hent_t>(w1 & 0xFFFFu) << 32) | ((w1 >> 16) - prev); prev = w1 >> 16;
+                    if (static_cast<uint32_t>(2 * i) <= nd) hw[i] = make_ulonglong2(e0, e1);
+                }
+            } else
             if (HIST && c) {
                 ulonglong2* hw = reinterpret_cast<ulonglong2*>(hist_row(d, slot));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) hw[i] = make_ulonglong2(hl[(2 * i) * 64], hl[(2 * i + 1) * 64]);
+            }
+        };
+        // the compact line from the user's row (its first 32 entries): running prefixes of the counts, unused words all ones
+        auto load_compact = [&](uint32_t s_row) {
+            const ulonglong2* hr2 = reinterpret_cast<const ulonglong2*>(hist_row(d, s_row));
+            uint32_t run = 0u, nd = 0u;
+#pragma unroll
+            for (int b = 0; b < 16; b += 8) {           // (two batches of eight 16-byte loads: 32 registers in flight, not 64)
+                ulonglong2 x[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = hr2[b + i];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    uint32_t w0, w1;
+                    const bool in0 = static_cast<uint32_t>(2 * (b + i)) <= nd || b + i == 0;
+                    if (b + i == 0) { nd = h_cnt(x[0].x); w0 = (h_prod(x[0].x) << 15) | nd; }
+                    else { run += in0 ? h_cnt(x[i].x) : 0u; w0 = in0 ? ((run << 16) | h_prod(x[i].x)) : 0xFFFFFFFFu; }
+                    const bool in1 = static_cast<uint32_t>(2 * (b + i) + 1) <= nd;
+                    run += in1 ? h_cnt(x[i].y) : 0u;
+                    w1 = in1 ? ((run << 16) | h_prod(x[i].y)) : 0xFFFFFFFFu;
+                    hl[(b + i) * 64] = static_cast<hent_t>(w0) | (static_cast<hent_t>(w1) << 32);
+                }
+                asm volatile("" ::: "memory");
             }
         };
         // ---- refill the lanes whose user has stopped (or was parked) ----
@@ -5555,7 +5651,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     if (res_next == res_end) {
                         if (exhausted) break;
                         uint32_t base = 0;
-                        if (lane == 0) base = static_cast<uint32_t>(atomicAdd(&d.counters[kCntWalkTicket], 64ull));
+                        if (lane == 0) base = static_cast<uint32_t>(atomicAdd(d.q_ticket, 64ull));
                         base = __builtin_amdgcn_readfirstlane(base);
                         if (base >= n_work) { exhausted = true; break; }
                         res_next = base; res_end = min(base + 64u, n_work);
@@ -5565,7 +5661,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     const bool mine = ((dead >> lane) & 1ull) != 0 && r < take;
                     if (mine) {
                         const uint32_t idx = res_next + r;
-                        uint32_t s2 = idx;
+                        uint32_t s2 = d.grp_lo + idx;
                         if (round >= 2) s2 = d.park_list[in_base + idx];
                         if (s2 != 0xFFFFFFFFu) {
                             slot = s2; st = RG_STATE_ORGANIC; t = 0u; pend = false; hdirty = false;
@@ -5585,6 +5681,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
 #pragma unroll
                                 for (int k = (K2 / 4) * 4; k < K2; ++k) om[k] = reinterpret_cast<const float*>(rp)[44 + k];
                             }
+                            if (HIST == 2) load_compact(s2);
+                            else
                             if (HIST) {
                                 const ulonglong2* hr2 = reinterpret_cast<const ulonglong2*>(hist_row(d, s2));
 #pragma unroll
@@ -5612,7 +5710,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             if (park_next + np > park_end) {
                 for (uint32_t r = park_next + lane; r < park_end; r += 64) d.park_list[out_base + r] = 0xFFFFFFFFu;
                 uint32_t base = 0;
-                if (lane == 0) base = static_cast<uint32_t>(atomicAdd(&d.counters[kCntParkCnt], 64ull));
+                if (lane == 0) base = static_cast<uint32_t>(atomicAdd(d.q_park, 64ull));
                 base = __builtin_amdgcn_readfirstlane(base);
                 park_next = base; park_end = base + 64;
             }
@@ -5900,7 +5998,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             if (park_next + np > park_end) {
                 for (uint32_t r = park_next + lane; r < park_end; r += 64) d.park_list[out_base + r] = 0xFFFFFFFFu;
                 uint32_t base = 0;
-                if (lane == 0) base = static_cast<uint32_t>(atomicAdd(&d.counters[kCntParkCnt], 64ull));
+                if (lane == 0) base = static_cast<uint32_t>(atomicAdd(d.q_park, 64ull));
                 base = __builtin_amdgcn_readfirstlane(base);
                 park_next = base; park_end = base + 64;
             }
@@ -5919,6 +6017,84 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             if ((is_ban || is_ph) && RG_WALK_ABL(28)) { a = user % d.P; ps = 1.0; }      // timing experiment: no policy act
             else
             if (is_ban || is_ph) {
+                if (HIST == 2) {
+                    // the same act on the COMPACT line (prefix form): the first product whose cumulative count exceeds u x views
+                    // = the number of words below the key (Thi + 1) << 16 — the last word of each 8-word segment, then the segment
+                    const rg_u32x4 pw = rg_draw(d.policy_seed, user, t, 0, RG_DRAW_POLICY);
+                    const double u1 = rg_uniform(pw.w[2], pw.w[3]);
+                    const hent_t* hr = hist_row(d, slot);
+                    const uint32_t* hw32 = reinterpret_cast<const uint32_t*>(hl);      // word w: hw32[(w >> 1) * 128 + (w & 1)]
+                    const uint32_t h0 = hw32[0];
+                    const uint32_t p7 = hw32[3 * 128 + 1], p15 = hw32[7 * 128 + 1], p23 = hw32[11 * 128 + 1], p31 = hw32[15 * 128 + 1];
+                    const uint32_t nd = h0 & 0x7FFFu;
+                    const double sum = static_cast<double>(h0 >> 15);
+                    const double T = u1 * sum;
+                    const uint32_t Thi = static_cast<uint32_t>(fmin(floor(T * (1.0 + 0x1p-36)), 4294967295.0));
+                    const uint32_t Tlo = static_cast<uint32_t>(fmin(ceil(T * (1.0 - 0x1p-36)), 4294967295.0));
+                    const bool over = Thi >= 65535u;                                     // (u x views at the top of the range: no entry exceeds it)
+                    const uint32_t khi = over ? 0u : (Thi + 1u) << 16;                   // prefix <= Thi  <=>  word < khi
+                    const uint32_t seg = (p7 < khi ? 1u : 0u) + (p15 < khi ? 1u : 0u) + (p23 < khi ? 1u : 0u);
+                    uint32_t x[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const hent_t y = hl[(seg * 4 + j) * 64];
+                        x[2 * j] = static_cast<uint32_t>(y); x[2 * j + 1] = static_cast<uint32_t>(y >> 32);
+                    }
+                    if (seg == 0u) x[0] = 0u;                                             // (the header: counted, prefix 0)
+                    uint32_t in_seg = 0u;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) in_seg += x[j] < khi ? 1u : 0u;
+                    const uint32_t idx = seg * 8u + in_seg;                              // first entry with prefix > Thi (32: none in the line)
+                    // its word and the one before it (the entry before a segment's first: the segment end read above)
+                    uint32_t w_at = 0xFFFFFFFFu, w_prev = seg == 0u ? 0u : (seg == 1u ? p7 : (seg == 2u ? p15 : p23));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        w_at = in_seg == static_cast<uint32_t>(j) ? x[j] : w_at;
+                        w_prev = in_seg == static_cast<uint32_t>(j + 1) ? x[j] : w_prev;
+                    }
+                    bool found = !over && idx <= nd && idx < kHcLine;
+                    // an entry inside the 2^-36 band of u x views: only the last one at or below Thi can be (prefixes ascend)
+                    bool amb = idx >= 2u && (w_prev >> 16) >= Tlo;
+                    uint32_t c_f = (w_at >> 16) - (idx >= 2u ? (w_prev >> 16) : 0u);
+                    a = w_at & 0xFFFFu;
+                    uint32_t C = p31 >> 16;                                              // (nd >= 31: the line's last prefix)
+                    for (uint32_t base = kHcLine; base <= nd && !found; base += kHistRegs) {      // longer histories: from the row
+                        hent_t f[kHistRegs];
+                        hist_load_line(hr + base, f);
+#pragma unroll
+                        for (int i = 0; i < kHistRegs; ++i)
+                            if (base + i <= nd && !found) {
+                                C += h_cnt(f[i]);
+                                if (C > Thi) { found = true; a = h_prod(f[i]); c_f = h_cnt(f[i]); }
+                                else if (C >= Tlo) amb = true;
+                            }
+                    }
+                    if (found && !amb) ps = static_cast<double>(c_f) / sum;
+                    else {
+                        // inside the band (~1e-10 of the acts): numpy's arithmetic over the viewed products, as below
+                        auto ent = [&](uint32_t i, uint32_t* prev) -> hent_t {       // (product, count) of entry i, walked in order
+                            if (i >= kHcLine) return hr[i];
+                            const uint32_t w = hw32[(i >> 1) * 128 + (i & 1u)];
+                            const uint32_t cnt = (w >> 16) - *prev;
+                            *prev = w >> 16;
+                            return (static_cast<hent_t>(w & 0xFFFFu) << 32) | cnt;
+                        };
+                        double last = 0.0;
+                        uint32_t pv = 0u;
+                        for (uint32_t i = 1; i <= nd; ++i) last += static_cast<double>(h_cnt(ent(i, &pv))) / sum;
+                        double acc = 0.0, pa = 0.0;
+                        a = d.P - 1;
+                        bool fnd = false;
+                        pv = 0u;
+                        for (uint32_t i = 1; i <= nd && !fnd; ++i) {
+                            const hent_t y = ent(i, &pv);
+                            const double p = static_cast<double>(h_cnt(y)) / sum;
+                            acc += p;
+                            if (!(acc / last <= u1)) { a = h_prod(y); pa = p; fnd = true; }
+                        }
+                        ps = pa;
+                    }
+                } else
                 if (HIST) {
                     // OrganicUserEventCounterModel.act (organic_user_count.py:45-96; exploit_explore, epsilon = 0,
                     // select_randomly: the host instantiates HIST = 1 for this form only) on the history line in LDS: decided
@@ -6065,6 +6241,70 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             c_clicks += static_cast<uint32_t>(__popcll(__ballot(is_ban && click)));
             if (have_v) {
                 if (d.lpv) d.lpv[slot] = v;
+                if (HIST == 2 && !RG_WALK_ABL(27)) {
+                    // ViewsFeaturesProvider.observe (agents/abstract.py:347-358) on the COMPACT line in LDS: position and hit of v,
+                    // then the line with the prefixes from there on raised by the view (and shifted by the new product)
+                    hent_t* hr = hist_row(d, slot);
+                    uint32_t e[kHcLine];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const hent_t y = hl[i * 64];
+                        e[2 * i] = static_cast<uint32_t>(y); e[2 * i + 1] = static_cast<uint32_t>(y >> 32);
+                    }
+                    const uint32_t h0 = e[0];
+                    const uint32_t nd = h0 & 0x7FFFu;
+                    uint32_t pos = 1;                       // first entry with product >= v (min(nd, 31) + 1 if none)
+                    bool hit = false;
+#pragma unroll
+                    for (int i = 1; i < static_cast<int>(kHcLine); ++i) {
+                        const uint32_t pl = e[i] & 0xFFFFu;                   // (an unused word: 0xFFFF, above every product)
+                        pos += pl < v ? 1u : 0u;
+                        hit = hit || pl == v;
+                    }
+                    uint32_t* hw32 = reinterpret_cast<uint32_t*>(hl);           // word w of this lane's line: hw32[(w >> 1) * 128 + (w & 1)]
+                    const bool room = nd < kHcLine - 1u;
+                    if (hit || room) {
+                        const bool full = !hit && nd + 1 >= d.hist_cap;
+                        if (full) atomicAdd(&d.counters[RG_CNT_HIST_OVERFLOW], 1ull);
+                        // new word i: below pos unchanged; at pos the product's own (raised, or new: the prefix before it + 1);
+                        // above it the old word (hit) or the old word below (new product), raised by the view
+                        uint32_t f[kHcLine];
+                        f[0] = full ? h0 : h0 + (1u << 15) + (hit ? 0u : 1u);
+                        const uint32_t last = hit ? nd : nd + 1u;              // entries in use after the view
+#pragma unroll
+                        for (int i = 1; i < static_cast<int>(kHcLine); ++i) {
+                            const uint32_t ui = static_cast<uint32_t>(i);
+                            const uint32_t below = i == 1 ? 0u : e[i - 1];
+                            const uint32_t src = hit ? e[i] : (ui == pos ? ((below & 0xFFFF0000u) | v) : below);
+                            const uint32_t raised = src + 0x10000u;
+                            f[i] = (full || ui < pos) ? e[i] : (ui <= last ? raised : 0xFFFFFFFFu);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) hl[i * 64] = static_cast<hent_t>(f[2 * i]) | (static_cast<hent_t>(f[2 * i + 1]) << 32);
+                        hdirty = true;
+                    } else if (v > (e[kHcLine - 1] & 0xFFFFu)) {
+                        // a longer history, v behind the line's 31 products: entries >= 32 of the row (always current), the
+                        // header in LDS — one round trip, nothing to read back
+                        if (nd + 1 >= d.hist_cap) {
+                            flush_hist(hdirty);
+                            hdirty = false;
+                            history_add(d, slot, v);
+                            const hent_t hh = hr[0];
+                            hw32[0] = (h_prod(hh) << 15) | h_cnt(hh);
+                        } else {
+                            const uint32_t fresh = history_tail_add(hr, nd, v, kHcLine);
+                            hw32[0] = h0 + (1u << 15) + fresh;
+                            hdirty = true;
+                        }
+                    } else {
+                        // a new product inside the line of a longer history (its last product moves to the row): the general
+                        // insertion on the row, then the line again
+                        flush_hist(hdirty);
+                        hdirty = false;
+                        history_add(d, slot, v);
+                        load_compact(slot);
+                    }
+                } else
                 if (HIST && !RG_WALK_ABL(27)) {
                     // ViewsFeaturesProvider.observe (agents/abstract.py:347-358) on the line in LDS, written through to the row
                     hent_t* hr = hist_row(d, slot);
@@ -6302,9 +6542,10 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
     const uint32_t n_cc = d.PT / 64;
     uint64_t row_next = 0, row_end = 0;
     uint32_t c_org = 0, c_ban = 0, c_clicks = 0, c_ph = 0, c_pick = 0, c_maxt = 0, c_limit = 0, c_hit = 0;
+    if (d.q_count) n_work = static_cast<uint32_t>(*d.q_count);
     for (;;) {
         uint32_t idx = 0;
-        if (lane == 0) idx = static_cast<uint32_t>(atomicAdd(&d.counters[kCntWalkTicket], 1ull));
+        if (lane == 0) idx = static_cast<uint32_t>(atomicAdd(d.q_ticket, 1ull));
         idx = __builtin_amdgcn_readfirstlane(idx);
         if (idx >= n_work) break;
         const uint32_t slot = __builtin_amdgcn_readfirstlane(d.park_list[in_base + idx]);
@@ -6647,13 +6888,17 @@ walk_kernel_t walk2_kernel_for(const DevSim& d, int occ) {
     if (ouc && !(d.ouc_exploit_explore && d.ouc_epsilon == 0.0 && d.ouc_select_randomly)) return nullptr;
     if (d.policy != RG_POLICY_UNIFORM_ENV && d.policy != RG_POLICY_RANDOM_AGENT && d.policy != RG_POLICY_LAST_VIEW_TABLE && !ouc) return nullptr;
 #ifdef RG_W2_ONLY     // kernel work: one instantiation, seconds to compile (never a shipped build)
-    return k_walk2<10, 1>;
+    return k_walk2<10, 2>;
 #else
     (void)occ;
+    // the view-history line in LDS: compact (31 products per line) where a product fits 16 bits (RECOGYM_WALK_HIST=1: the
+    // 64-bit line of 15 products, A/B)
+    const char* e_h = getenv("RECOGYM_WALK_HIST");
+    const bool compact = ouc && d.P <= 65535u && d.hist_cap >= 32u && d.hist_cap <= 32768u && !(e_h && e_h[0] == '1');
     switch (d.KH) {
-        case 4: return ouc ? k_walk2<4, 1> : k_walk2<4, 0>;
-        case 10: return ouc ? k_walk2<10, 1> : k_walk2<10, 0>;
-        default: return ouc ? k_walk2<16, 1> : k_walk2<16, 0>;
+        case 4: return ouc ? (compact ? k_walk2<4, 2> : k_walk2<4, 1>) : k_walk2<4, 0>;
+        case 10: return ouc ? (compact ? k_walk2<10, 2> : k_walk2<10, 1>) : k_walk2<10, 0>;
+        default: return ouc ? (compact ? k_walk2<16, 2> : k_walk2<16, 1>) : k_walk2<16, 0>;
     }
 #endif
 }
@@ -6715,6 +6960,22 @@ __global__ void k_totals(DevSim d, uint32_t t_now) {
 #endif
 
 #if RG_HAS(1)
+// rg_sim_step_user: what step t of a ONE-user simulator produced, packed for one read-back — the row it emitted (first row of
+// the step; a stopping user's phantom row is not part of the step), the user's state and clock after it
+__global__ void k_step_user_pack(DevSim d, uint32_t t) {
+    rg_step_result* out = reinterpret_cast<rg_step_result*>(d.step1_buf + 8);
+    const uint64_t row = d.log_base[t];
+    rg_event e; e.u = 0; e.t = 0; e.code = kHoleCode; e.ps = 0.0f;
+    const bool has = d.log && row < d.log_cap && d.log_base[t + 1] > row;
+    if (has) e = d.log[row];
+    out->row = e;
+    out->state = d.step_cnt[2 * (t + 1)] ? RG_STATE_ORGANIC : (d.step_cnt[2 * (t + 1) + 1] ? RG_STATE_BANDIT : RG_STATE_STOP);
+    out->has_row = has ? 1 : 0;
+    out->time = d.time_mode ? d.utime[0] : static_cast<double>(t + 1);
+    out->ps = (has && d.aux_ps) ? d.aux_ps[row] : static_cast<double>(e.ps);
+    out->p_click = (has && d.aux_pclick) ? d.aux_pclick[row] : 0.0;
+}
+
 __global__ void __launch_bounds__(kBlock) k_export_state(DevSim d, uint32_t t, int8_t* state) {
     const uint32_t n_o = d.step_cnt[2 * t], n_b = d.step_cnt[2 * t + 1];
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_o + n_b; i += gridDim.x * kBlock) {
@@ -6784,6 +7045,16 @@ __global__ void __launch_bounds__(kBlock) k_debug_ouc_acts(DevSim d, const doubl
         int fl = 0;
         const uint32_t a = policy_act<true, true>(d, i, static_cast<uint32_t>(d.first_user + i), 0u, &p, u1[i], &fl);
         action[i] = static_cast<int32_t>(a); ps[i] = p; flags[i] = static_cast<uint8_t>(fl);
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_debug_fate_round2(DevSim d, uint8_t* flags) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) flags[i] = d.f64_valid[i] ? 1 : 0;
+}
+__global__ void __launch_bounds__(kBlock) k_debug_fate_last(DevSim d, uint8_t* flags, uint32_t base, const unsigned long long* count) {
+    const uint32_t n = static_cast<uint32_t>(*count);
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const uint32_t slot = d.park_list[base + i];
+        if (slot != 0xFFFFFFFFu) flags[slot] |= 2;
     }
 }
 __global__ void __launch_bounds__(kBlock) k_debug_uncertified(DevSim d, uint32_t t_prev, uint8_t* flags) {
@@ -7210,6 +7481,7 @@ int run_walk(rg_sim* sim, hipStream_t st) {
         return RG_OK;
     };
     if (int rc = mark(0)) return rc;
+    sim->fate_count = nullptr;
     bool fused_prefix = false;
     // 1. every user's first product sweep: only the per-user sums are kept (no search, no rows)
     {
@@ -7273,6 +7545,7 @@ int run_walk(rg_sim* sim, hipStream_t st) {
         HIP_TRY(hipMemsetAsync(d.counters + kCntParkCnt, 0, sizeof(unsigned long long), st));
         launch_walk(n_list, 2, 0u, base3);
         if (!d.walk_handover) return RG_OK;
+        sim->fate_base = base3; sim->fate_count = d.counters + kCntParkCnt;
         HIP_TRY(hipMemcpyAsync(h64, d.counters + kCntParkCnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const uint32_t n_left = static_cast<uint32_t>(*h64);
@@ -7348,6 +7621,190 @@ walked:
     return RG_OK;
 }
 
+// The same run as a PIPELINE over user groups: the reset range is cut into G groups of equal size; per group
+//   sweep -> finalize -> round 1          (k_draw_bf16p sweep_only = 2, k_cache_finalize + k_cache_prefix, k_walk2)
+//   float64 batch -> prefixes -> round 2  (k_exact_sums_h, k_exact_prefix, k_walk2) on the users round 1 parked
+// and one last round (k_walk_solo) over what the rounds 2 handed over.  The second chain of group g runs on a second stream
+// while the first chain of group g + 1 runs on the caller's: the float64 batch is bound by the float64 pipes, the walk by its
+// chains of dependent loads (half of its wave cycles are waits), so they share the compute units instead of taking turns.
+// Every list length stays on the device (q_count): no host read-back between the launches, one at the end (the step limit).
+// Results are those of run_walk bit for bit: every draw is addressed by (seed, user, t), a user's events are walked by one
+// lane at a time, and the sorted log does not depend on the raw order.
+int run_walk_pipe(rg_sim* sim, hipStream_t st) {
+    const DevSim& d = sim->d;
+    const int n_cus = device_cus(sim);
+    const uint32_t n = d.n_users;
+    // groups: equal sizes, multiples of 256 users, each large enough for the unsliced sweep (>= 1024 user tiles)
+    uint32_t G = static_cast<uint32_t>(sim->pipe_groups);
+    if (G > kMaxWalkGroups) G = kMaxWalkGroups;
+    while (G > 1 && n / G < sim->pipe_min_users) --G;
+    const uint32_t gsz = (((n + G - 1) / G) + 255u) & ~255u;
+    G = (n + gsz - 1) / gsz;
+    const int mode = G > 1 ? sim->pipe_mode : 0;
+    if (mode >= 1 && !sim->pipe_streams[0]) {
+        HIP_TRY(hipStreamCreateWithFlags(&sim->pipe_streams[0], hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&sim->pipe_streams[1], hipStreamNonBlocking));
+    }
+    const size_t n_ev = 3 * static_cast<size_t>(kMaxWalkGroups) + 2;
+    while (sim->pipe_events.size() < n_ev) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        sim->pipe_events.push_back(e);
+    }
+    hipStream_t sA = st, sB = mode >= 1 ? sim->pipe_streams[0] : st, sS = mode >= 2 ? sim->pipe_streams[1] : st;
+    // profiling: a pair of timing events around every launch group, on the stream it is launched on
+    struct Span { int cls; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    auto span_begin = [&](int cls, hipStream_t s) -> int {
+        if (!sim->profiling) return RG_OK;
+        Span sp{cls, nullptr, nullptr};
+        HIP_TRY(hipEventCreate(&sp.a)); HIP_TRY(hipEventCreate(&sp.b));
+        HIP_TRY(hipEventRecord(sp.a, s));
+        spans.push_back(sp);
+        return RG_OK;
+    };
+    auto span_end = [&](hipStream_t s) -> int {
+        if (!sim->profiling) return RG_OK;
+        HIP_TRY(hipEventRecord(spans.back().b, s));
+        return RG_OK;
+    };
+    hipEvent_t wall[2] = {nullptr, nullptr};
+    if (sim->profiling) {
+        HIP_TRY(hipEventCreate(&wall[0])); HIP_TRY(hipEventCreate(&wall[1]));
+        HIP_TRY(hipEventRecord(wall[0], st));
+    }
+    HIP_TRY(hipMemsetAsync(d.walk_ctl, 0, sizeof(unsigned long long) * kWalkCtlWords, st));
+    hipEvent_t ev_start = sim->pipe_events[3 * kMaxWalkGroups];
+    if (sB != st || sS != st) {
+        HIP_TRY(hipEventRecord(ev_start, st));
+        if (sB != st) HIP_TRY(hipStreamWaitEvent(sB, ev_start, 0));
+        if (sS != st) HIP_TRY(hipStreamWaitEvent(sS, ev_start, 0));
+    }
+    const bool hist = d.policy == RG_POLICY_ORGANIC_USER_COUNT;
+    const size_t smem = (kBlock / 64) * walk2_wave_lds(hist);
+    const walk_kernel_t wk = walk2_kernel_for(d, sim->walk_occ);
+    const solo_kernel_t sk = solo_kernel_for(d);
+    const exact_h_kernel_t kh = exact_h_kernel_for(d.XKB);
+    if (!wk || !sk || !kh) return fail(RG_ESTATE, "run_walk_pipe: no kernel for this configuration");
+    uint32_t mfma_of_8 = 5;
+    if (const char* e = getenv("RECOGYM_EXACT_MIX")) mfma_of_8 = static_cast<uint32_t>(atoi(e));
+    auto walk_chunk = [&](uint64_t n_work, int blocks) {
+        uint64_t chunk = n_work * 100 / (static_cast<uint64_t>(blocks) * 4 * 32);
+        chunk = chunk / 64 * 64;
+        if (chunk < 256) chunk = 256;
+        if (chunk > 4096) chunk = 4096;
+        return static_cast<uint32_t>(chunk);
+    };
+    unsigned long long* ctl_last = d.walk_ctl + 8 * kMaxWalkGroups;
+    const uint32_t base_solo = ((n + 63u) & ~63u) + kMaxWalkGroups * kParkSlack;    // behind every group's region
+    for (uint32_t g = 0; g < G; ++g) {
+        DevSim dg = d;
+        dg.grp_lo = g * gsz;
+        dg.grp_n = n - dg.grp_lo < gsz ? n - dg.grp_lo : gsz;
+        unsigned long long* ctl = d.walk_ctl + 8 * g;
+        const uint32_t region = dg.grp_lo + g * kParkSlack;
+        // ---- sweep, finalize ----
+        {
+            DevSim ds = dg;
+            ds.sweep_only = 2u;
+            const uint32_t tiles_up = (dg.grp_n + sim->draw_users - 1) / sim->draw_users;
+            if (int rc = span_begin(0, sS)) return rc;
+            hipLaunchKernelGGL(sim->bf16_kernel, dim3(sweep_grid(sim, tiles_up, 1)), dim3(sim->draw_threads), sim->bf16_smem, sS, ds, 0u, 1u);
+            if (int rc = span_end(sS)) return rc;
+            if (int rc = span_begin(1, sS)) return rc;
+            hipLaunchKernelGGL(finalize_kernel_for(d), dim3(grid_for(dg.grp_n)), dim3(kBlock), 0, sS, dg);
+            hipLaunchKernelGGL(cache_prefix_kernel(), dim3(grid_for((static_cast<uint64_t>(dg.grp_n) + 7) / 8, kBlock / 64)), dim3(kBlock), 0, sS, dg, 1);
+            if (int rc = span_end(sS)) return rc;
+            if (sS != sA) {
+                HIP_TRY(hipEventRecord(sim->pipe_events[3 * g], sS));
+                HIP_TRY(hipStreamWaitEvent(sA, sim->pipe_events[3 * g], 0));
+            }
+        }
+        // ---- round 1 ----
+        {
+            DevSim dw = dg;
+            dw.q_ticket = ctl + 0; dw.q_park = ctl + 1; dw.q_count = nullptr;
+            int blocks = static_cast<int>((static_cast<uint64_t>(dg.grp_n) + kBlock - 1) / kBlock);
+            if (blocks > n_cus * sim->pipe_occ1) blocks = n_cus * sim->pipe_occ1;
+            if (blocks > static_cast<int>(kMaxWalkWaves / 4)) blocks = kMaxWalkWaves / 4;
+            if (int rc = span_begin(2, sA)) return rc;
+            hipLaunchKernelGGL(wk, dim3(blocks), dim3(kBlock), smem, sA, dw, dg.grp_n, 1, walk_chunk(dg.grp_n, blocks), 0u, region);
+            if (int rc = span_end(sA)) return rc;
+            if (sB != sA) {
+                HIP_TRY(hipEventRecord(sim->pipe_events[3 * g + 1], sA));
+                HIP_TRY(hipStreamWaitEvent(sB, sim->pipe_events[3 * g + 1], 0));
+            }
+        }
+        // ---- the users it parked: float64 sums, prefixes, round 2 (what it hands over: the last round's list) ----
+        {
+            DevSim dx = dg;
+            dx.q_ticket = ctl + 2; dx.q_count = ctl + 1; dx.list_in = region;
+            const uint32_t est = dg.grp_n / 3 + 4096u;                  // launch shapes only: the lengths are read on the device
+            uint32_t xgrid = (dg.grp_n + 255u) / 256u;
+            if (xgrid > static_cast<uint32_t>(sim->pipe_xblocks)) xgrid = static_cast<uint32_t>(sim->pipe_xblocks);
+            if (int rc = span_begin(3, sB)) return rc;
+            hipLaunchKernelGGL(kh, dim3(xgrid), dim3(kBlock), exact_m_lds(d.XKB), sB, dx, dg.grp_n, mfma_of_8);
+            hipLaunchKernelGGL(exact_prefix_kernel(), dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, sB, dx, dg.grp_n);
+            if (int rc = span_end(sB)) return rc;
+            DevSim dr = dg;
+            dr.q_ticket = ctl + 3; dr.q_park = ctl_last + 0; dr.q_count = ctl + 1;
+            int blocks = static_cast<int>((static_cast<uint64_t>(est) + kBlock - 1) / kBlock);
+            if (blocks > n_cus * sim->pipe_occ2) blocks = n_cus * sim->pipe_occ2;
+            if (blocks > static_cast<int>(kMaxWalkWaves / 4)) blocks = kMaxWalkWaves / 4;
+            if (int rc = span_begin(4, sB)) return rc;
+            hipLaunchKernelGGL(wk, dim3(blocks), dim3(kBlock), smem, sB, dr, dg.grp_n, 2, walk_chunk(est, blocks), region, base_solo);
+            if (int rc = span_end(sB)) return rc;
+            if (sB != sA && g + 1 == G) {
+                HIP_TRY(hipEventRecord(sim->pipe_events[3 * g + 2], sB));
+                HIP_TRY(hipStreamWaitEvent(sA, sim->pipe_events[3 * g + 2], 0));
+            }
+        }
+    }
+    // ---- last round: a wave per user (k_walk_solo) over what the rounds 2 handed over ----
+    sim->fate_base = base_solo; sim->fate_count = ctl_last + 0;
+    if (d.walk_handover) {
+        DevSim dl = d;
+        dl.q_ticket = ctl_last + 1; dl.q_count = ctl_last + 0;
+        const uint32_t est = n / 256u + 1024u;
+        uint32_t blocks = (est + 15u) / 16u;
+        const uint32_t cap = static_cast<uint32_t>(n_cus) * 8u;
+        if (blocks > cap) blocks = cap;
+        uint64_t chunk = static_cast<uint64_t>(est) * 150 / (static_cast<uint64_t>(blocks) * 4 * 8);
+        chunk = chunk / 64 * 64;
+        if (chunk < 64) chunk = 64;
+        if (chunk > 1024) chunk = 1024;
+        if (int rc = span_begin(4, sA)) return rc;
+        hipLaunchKernelGGL(sk, dim3(blocks), dim3(kBlock), 0, sA, dl, n, static_cast<uint32_t>(chunk), base_solo);
+        if (int rc = span_end(sA)) return rc;
+    }
+    hipLaunchKernelGGL(k_walk_finish, dim3(1), dim3(1), 0, st, d);
+    HIP_TRY(hipGetLastError());
+    if (sim->profiling) HIP_TRY(hipEventRecord(wall[1], st));
+    unsigned long long* h64 = reinterpret_cast<unsigned long long*>(sim->h_pinned);
+    HIP_TRY(hipMemcpyAsync(h64, d.counters + kCntTailLimit, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (sim->profiling) {
+        for (const Span& sp : spans) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, sp.a, sp.b));
+            if (sp.cls == 0) sim->prof_ms[0] += ms;
+            else if (sp.cls == 1) sim->prof_ms[1] += ms;
+            else if (sp.cls == 3) sim->prof_ms[2] += ms;
+            else { sim->prof_walk_ms[sp.cls == 2 ? 0 : 1] += ms; sim->prof_tail_ms += ms; }
+            (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b);
+        }
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, wall[0], wall[1]));
+        sim->prof_pipe_ms += ms;
+        (void)hipEventDestroy(wall[0]); (void)hipEventDestroy(wall[1]);
+        sim->prof_launches += 1;
+    }
+    sim->t = 1;
+    sim->live_upper = 0;
+    if (*h64) return fail(RG_ELIMIT, "more than %u steps", kMaxSteps);
+    return RG_OK;
+}
+
 #endif  // RG_HAS(1): host code
 }  // namespace rgk
 
@@ -7403,7 +7860,7 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     d.ouc_epsilon = cfg->ouc_epsilon;
     d.time_mode = cfg->time_mode; d.time_mu = cfg->time_mu; d.time_sigma = cfg->time_sigma;
     d.n_users = d.n_cap = static_cast<uint32_t>(n_users);
-    s->h_pinned = nullptr;
+    s->h_pinned = nullptr; s->h_step = nullptr;
     s->profiling = false; s->prof_used = 0; s->prof_launches = 0;
     s->prof_ms[0] = s->prof_ms[1] = s->prof_ms[2] = s->prof_ms[3] = s->prof_ms[4] = 0.0;
     s->mfma_smem = d.use_mfma ? mfma_smem_bytes(geom_of(*cfg)) : 0;
@@ -7487,6 +7944,27 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     s->walk_solo = true;
     if (const char* e = getenv("RECOGYM_WALK_SOLO")) s->walk_solo = e[0] != '0';
     s->prof_walk_ms[0] = s->prof_walk_ms[1] = 0.0;
+    // the walked run as a pipeline over user groups (run_walk_pipe).  RECOGYM_PIPE=G (0: run_walk, host-side list lengths),
+    // RECOGYM_PIPE_MODE=0|1|2, RECOGYM_PIPE_OCC1 / _OCC2 (blocks per CU of the rounds' grids), RECOGYM_PIPE_XBLOCKS: A/B tests
+    // Default: ONE group (the serial chain, every list length read on the device: no host read-back between the launches).
+    // More groups on two or three streams were measured on C3 and do not pay (profiles/r4/ab_call1_pipe_forms.jsonl, DESIGN.md
+    // 3a): the walk's three waves per SIMD fill the register file, so nothing co-resides with it, and every group adds a
+    // drain tail to both walk rounds and a partial last wave of blocks to the float64 batch.
+    s->pipe_groups = 1; s->pipe_mode = 1;
+    s->pipe_occ1 = s->pipe_occ2 = s->walk_occ;
+    s->pipe_xblocks = 1024;
+    s->pipe_streams[0] = s->pipe_streams[1] = nullptr;
+    s->fate_base = 0; s->fate_count = nullptr;
+    s->prof_pipe_ms = 0.0;
+    if (const char* e = getenv("RECOGYM_PIPE")) s->pipe_groups = atoi(e);
+    if (const char* e = getenv("RECOGYM_PIPE_MODE")) s->pipe_mode = atoi(e);
+    if (const char* e = getenv("RECOGYM_PIPE_OCC1")) { const int o = atoi(e); if (o >= 1 && o <= s->walk_occ) s->pipe_occ1 = o; }
+    if (const char* e = getenv("RECOGYM_PIPE_OCC2")) { const int o = atoi(e); if (o >= 1 && o <= s->walk_occ) s->pipe_occ2 = o; }
+    if (const char* e = getenv("RECOGYM_PIPE_XBLOCKS")) { const int o = atoi(e); if (o >= 1) s->pipe_xblocks = o; }
+    s->pipe_min_users = 1u << 17;
+    if (const char* e = getenv("RECOGYM_PIPE_MIN")) { const int o = atoi(e); if (o >= 256) s->pipe_min_users = static_cast<uint32_t>(o); }
+    d.grp_lo = 0; d.grp_n = d.n_users; d.list_in = 0;
+    d.q_ticket = d.counters + kCntWalkTicket; d.q_park = d.counters + kCntParkCnt; d.q_count = nullptr;
     if (const char* e = getenv("RECOGYM_TAIL")) s->tail_below = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_REPACK")) s->repack_every = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_ABLATE")) d.ablate = static_cast<uint32_t>(atoi(e));
@@ -7509,7 +7987,10 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
 int rg_sim_destroy(rg_sim* sim) {
     if (!sim) return RG_OK;
     if (sim->h_pinned) (void)hipHostFree(sim->h_pinned);
+    if (sim->h_step) (void)hipHostFree(sim->h_step);
     for (hipEvent_t e : sim->prof_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : sim->pipe_events) (void)hipEventDestroy(e);
+    for (hipStream_t ps : sim->pipe_streams) if (ps) (void)hipStreamDestroy(ps);
     delete sim;
     return RG_OK;
 }
@@ -7620,6 +8101,7 @@ int rg_sim_reset_users(rg_sim* sim, uint64_t first_user_id, uint64_t n, uint64_t
     d.first_user = first_user_id;
     d.organic_only_below = organic_only_below;
     d.n_users = static_cast<uint32_t>(n);      // lists stay strided by the carve-time n_cap
+    d.grp_lo = 0; d.grp_n = d.n_users;
     HIP_TRY(hipMemsetAsync(d.step_cnt, 0, sizeof(uint32_t) * 2 * (kMaxSteps + 2), st));
     HIP_TRY(hipMemsetAsync(d.exact_cnt, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
     HIP_TRY(hipMemsetAsync(d.exact_cnt_b, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
@@ -7649,13 +8131,43 @@ int rg_sim_step(rg_sim* sim, const int32_t* d_actions, void* stream) {
     return launch_step(sim, d_actions, static_cast<hipStream_t>(stream));
 }
 
+int rg_sim_step_user(rg_sim* sim, int32_t action, rg_step_result* out, void* stream) {
+    if (!sim || !out) return fail(RG_EINVAL, "NULL argument");
+    if (!sim->users_reset) return fail(RG_ESTATE, "rg_sim_reset_users must be called first");
+    if (sim->d.policy != RG_POLICY_EXTERNAL || sim->d.n_users != 1) return fail(RG_ESTATE, "rg_sim_step_user needs RG_POLICY_EXTERNAL and a one-user reset range");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!sim->h_step) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sim->h_step), 128));
+    int32_t* h_act = reinterpret_cast<int32_t*>(sim->h_step);
+    *h_act = action;
+    HIP_TRY(hipMemcpyAsync(sim->d.step1_buf, h_act, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    const uint32_t t = sim->t;
+    if (int rc = launch_step(sim, reinterpret_cast<const int32_t*>(sim->d.step1_buf), st)) return rc;
+    hipLaunchKernelGGL(k_step_user_pack, dim3(1), dim3(1), 0, st, sim->d, t);
+    HIP_TRY(hipGetLastError());
+    rg_step_result* h_res = reinterpret_cast<rg_step_result*>(sim->h_step + 64);
+    HIP_TRY(hipMemcpyAsync(h_res, sim->d.step1_buf + 8, sizeof(rg_step_result), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *out = *h_res;
+    return RG_OK;
+}
+
 int rg_sim_run(rg_sim* sim, uint32_t max_steps, void* stream) {
     if (!sim) return fail(RG_EINVAL, "sim is NULL");
     if (!sim->users_reset) return fail(RG_ESTATE, "rg_sim_reset_users must be called first");
     if (sim->d.policy == RG_POLICY_EXTERNAL) return fail(RG_ESTATE, "rg_sim_run needs a device policy");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!sim->h_pinned) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sim->h_pinned), 4 * sizeof(uint32_t)));
-    if (sim->walk && sim->t == 0 && max_steps >= kMaxSteps) return run_walk(sim, st);
+    if (sim->walk && sim->t == 0 && max_steps >= kMaxSteps) {
+        // the pipelined form where its kernels exist (k_walk2 behind the fused-prefix fp16 sweep, k_walk_solo, the mixed float64
+        // batch) and the reset range fills an unsliced sweep; else the serial chain with its list lengths read back by the host
+        uint32_t mix = 5;
+        if (const char* e = getenv("RECOGYM_EXACT_MIX")) mix = static_cast<uint32_t>(atoi(e));
+        const bool pipe = sim->pipe_groups >= 1 && sim->walk2 && sim->walk_solo && solo_kernel_for(sim->d) && sim->d.walk_handover &&
+                          sim->bf16_kernel == bf16p_kernel_for(sim->d) && sim->d.f16 && !sim->d.wide && sim->d.n_users >= sim->pipe_min_users &&
+                          exact_h_kernel_for(sim->d.XKB) && mix < 8 && !getenv("RECOGYM_EXACT") && !getenv("RECOGYM_SLICES") &&
+                          !getenv("RECOGYM_SWEEP_PREFIX_OFF");
+        return pipe ? run_walk_pipe(sim, st) : run_walk(sim, st);
+    }
     uint32_t done_steps = 0;
     const uint32_t chunk = 16;
     while (done_steps < max_steps) {
@@ -7728,6 +8240,7 @@ int rg_sim_set_profiling(rg_sim* sim, int on) {
     sim->prof_ms[0] = sim->prof_ms[1] = sim->prof_ms[2] = sim->prof_ms[3] = sim->prof_ms[4] = 0.0;
     sim->prof_tail_ms = 0.0;
     sim->prof_walk_ms[0] = sim->prof_walk_ms[1] = 0.0;
+    sim->prof_pipe_ms = 0.0;
     return RG_OK;
 }
 
@@ -7738,7 +8251,7 @@ int rg_sim_get_profile(rg_sim* sim, double* out) {
     out[4] = static_cast<double>(sim->prof_launches);
     out[5] = sim->prof_tail_ms;
     out[6] = sim->prof_walk_ms[0]; out[7] = sim->prof_walk_ms[1];
-    out[8] = sim->prof_ms[3]; out[9] = 0.0;
+    out[8] = sim->prof_ms[3]; out[9] = sim->prof_pipe_ms;
     return RG_OK;
 }
 
@@ -7839,6 +8352,17 @@ int rg_sim_debug_ouc_acts(rg_sim* sim, const double* d_u1, int32_t* d_action, do
     if (!sim->users_reset) return fail(RG_ESTATE, "no reset range");
     hipLaunchKernelGGL(k_debug_ouc_acts, dim3(grid_for(sim->d.n_users)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), sim->d,
                        d_u1, d_action, d_ps, d_flags);
+    HIP_TRY(hipGetLastError());
+    return RG_OK;
+}
+
+int rg_sim_debug_walk_fate(rg_sim* sim, uint8_t* d_flags, void* stream) {
+    if (!sim || !d_flags) return fail(RG_EINVAL, "NULL argument");
+    if (!sim->d.use_cache || !sim->walk) return fail(RG_ESTATE, "no walked run (sigma_omega == 0, rg_sim_run to the end)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_debug_fate_round2, dim3(grid_for(sim->d.n_users)), dim3(kBlock), 0, st, sim->d, d_flags);
+    if (sim->fate_count)
+        hipLaunchKernelGGL(k_debug_fate_last, dim3(grid_for(sim->d.n_users / 16 + 1)), dim3(kBlock), 0, st, sim->d, d_flags, sim->fate_base, sim->fate_count);
     HIP_TRY(hipGetLastError());
     return RG_OK;
 }

@@ -67,11 +67,28 @@ env_1_args = {
 }
 
 
-class Discrete:
-    """gym.spaces.Discrete stand-in (only `.n` is read)."""
+class _DiscreteStandIn:
+    """gym.spaces.Discrete stand-in (only `.n` is read) where no gym is importable."""
 
     def __init__(self, n):
         self.n = n
+
+
+def _gym_surface():
+    """(base class, Discrete) — `gym.Env` / `gym.spaces.Discrete` (or gymnasium's) where such a package is importable, the way
+    the reference's AbstractEnv derives from gym.Env (recogym/envs/abstract.py:46-57); else plain object and a stand-in."""
+    for name in ('gym', 'gymnasium'):
+        try:
+            mod = __import__(name)
+            spaces = __import__(name + '.spaces', fromlist=['Discrete'])
+            if isinstance(getattr(mod, 'Env', None), type) and hasattr(spaces, 'Discrete'):
+                return mod.Env, spaces.Discrete
+        except Exception:       # noqa: BLE001 — not installed, or a stub without the Env / spaces surface
+            continue
+    return object, _DiscreteStandIn
+
+
+_EnvBase, Discrete = _gym_surface()
 
 
 def device_policy_of(agent):
@@ -213,12 +230,17 @@ def columns_to_dataframe(cols, num_products, with_ps_all=False):
     return pd.DataFrame(out, columns=['t', 'u', 'z', 'v', 'a', 'c', 'ps', 'ps-a'], copy=False)
 
 
-class RecoEnv1:
-    """Drop-in for the object `gym.make('reco-gym-v1')` returns."""
+class RecoEnv1(_EnvBase):
+    """Drop-in for the object `gym.make('reco-gym-v1')` returns: a `gym.Env` subclass wherever gym is importable (like the
+    reference's AbstractEnv, abstract.py:46-57), with `action_space = Discrete(num_products)` after init_gym (abstract.py:69)
+    and — what gym's checkers ask of an Env — an `observation_space`: Discrete(num_products), the product ids an observation's
+    organic sessions carry."""
 
     metadata = {}
 
     def __init__(self):
+        if _EnvBase is not object:
+            _EnvBase.__init__(self)
         self.first_step = True
         self.config = None
         self.state = None
@@ -237,6 +259,7 @@ class RecoEnv1:
     def init_gym(self, args):
         self.config = Configuration(args)
         self.action_space = Discrete(self.config.num_products)
+        self.observation_space = Discrete(self.config.num_products)
         # abstract.py:72-76: the default generator unless one is passed in.  A NormalTimeGenerator (this package's or the
         # reference's own object) only contributes mu / sigma: the device keeps the per-user clocks
         self._time_mode = time_generator_params(self.config)[0]
@@ -280,6 +303,7 @@ class RecoEnv1:
         other = RecoEnv1()
         other.config = self.config
         other.action_space = getattr(self, 'action_space', None)
+        other.observation_space = getattr(self, 'observation_space', None)
         other.time_generator = (DefaultTimeGenerator(self.config) if not getattr(self, '_time_mode', 0)
                                 else self.time_generator) if self.config else None
         other._time_mode = getattr(self, '_time_mode', 0)
@@ -365,17 +389,12 @@ class RecoEnv1:
         self._rows_read = 0
 
     def _advance(self, action=None):
-        """One Markov transition of the current user on the device -> the emitted row."""
-        sim = self._seq
-        if action is not None:
-            self._act.fill_(int(action))
-        sim.step(self._act)
-        raw = sim.log[self._rows_read:self._rows_read + 1].cpu().numpy()
+        """One Markov transition of the current user on the device -> the emitted row.  One launch sequence and ONE
+        pinned-memory read-back of (row, state, clock) per event (rg_sim_step_user)."""
+        row, self.state, clock = self._seq.step_user(action)
         self._rows_read += 1
-        row = decode_rows(raw)[0]
-        self.state = int(sim.states()[0].item())
         self._event_index += 1
-        self.current_time = float(sim.user_times()[0].item()) if self._time_mode else self.time_generator.new_time()
+        self.current_time = clock if self._time_mode else self.time_generator.new_time()
         return row
 
     def _context(self, t, u, n):

@@ -60,6 +60,68 @@ def flip_index(Gamma, number_of_flips):
     return index
 
 
+def flip_index_blocked(Gamma, number_of_flips, block_rows=None, keep=None):
+    """The same pairing without the P x P matrix (80 GB at P = 10^5): Gamma Gamma^T is symmetric, so the walk only ever needs
+    the pairs i < j in descending order of their value, and it stops after `number_of_flips` swaps — long before it leaves the
+    top few thousand pairs.  Rounds: (1) over row blocks of Gamma Gamma^T (upper triangle), the `keep`-th largest value below
+    the previous round's threshold; (2) every pair at or above it, sorted descending, walked exactly like flip_index walks the
+    full argsort.  A pair (i, j) and its mirror (j, i) are the same swap, whichever the reference's unstable argsort meets
+    first; exact float64 ties between DIFFERENT pairs have no defined order in the reference either (numpy's introsort) and
+    probability ~1e-10 among the few thousand pairs walked.  Memory: block_rows x P doubles."""
+    P, K = Gamma.shape
+    if block_rows is None:
+        block_rows = max(1, min(P, (256 << 20) // (8 * P)))
+    if keep is None:
+        keep = max(4096, 64 * int(number_of_flips))
+    index = np.arange(P)
+    taken = np.zeros(P, dtype=bool)
+    done = 0
+    upper = np.inf                      # pairs with a value >= upper were walked in an earlier round
+    cols = np.arange(P)
+    while done < number_of_flips:
+        # round, pass 1: the keep-th largest remaining value
+        vals, thr = np.empty(0), -np.inf          # the `keep` largest so far and the smallest of them (a running filter)
+        for lo in range(0, P, block_rows):
+            blk = Gamma[lo:lo + block_rows] @ Gamma.T
+            m = (cols[None, :] > np.arange(lo, lo + blk.shape[0])[:, None]) & (blk < upper) & (blk > thr)
+            vals = np.concatenate([vals, blk[m]])
+            if vals.size > keep:
+                vals = np.partition(vals, vals.size - keep)[vals.size - keep:]
+                thr = vals.min()
+        if vals.size == 0:
+            break
+        tau = vals.min()
+        # pass 2: every remaining pair at or above it
+        ii, jj, vv = [], [], []
+        for lo in range(0, P, block_rows):
+            blk = Gamma[lo:lo + block_rows] @ Gamma.T
+            m = (cols[None, :] > np.arange(lo, lo + blk.shape[0])[:, None]) & (blk < upper) & (blk >= tau)
+            r, c = np.nonzero(m)
+            ii.append(r + lo); jj.append(c); vv.append(blk[r, c])
+        ii, jj, vv = np.concatenate(ii), np.concatenate(jj), np.concatenate(vv)
+        for k in np.argsort(-vv, kind='stable'):
+            i, j = int(ii[k]), int(jj[k])
+            if taken[i] or taken[j]:
+                continue
+            index[i], index[j] = j, i
+            taken[i] = taken[j] = True
+            done += 1
+            if done == number_of_flips:
+                break
+        if tau <= 0.0:
+            # the walk would now enter the zeroed diagonal and the negative half: hand the (tiny) rest to the full algorithm's
+            # order — only reachable when number_of_flips approaches P / 2 on a small table
+            if done < number_of_flips:
+                raise ValueError('flip_index_blocked: number_of_flips too large for the blocked walk; use flip_index')
+        upper = tau
+    return index
+
+
+# tables above this many products build the pairing in row blocks (the P x P float64 matrix of the reference's algorithm: 0.8 GB
+# at 10^4 products, 80 GB at 10^5)
+FLIP_BLOCKED_ABOVE = 8192
+
+
 def draw_tables(config):
     """Gamma (P,K), mu_organic (P,), beta (P,K), mu_bandit (P,) as float64 C-contiguous arrays,
     drawn in the reference's order from RandomState(random_seed)."""
@@ -71,7 +133,7 @@ def draw_tables(config):
     if flips == 0:
         beta, mu_bandit = Gamma, mu_organic
     else:
-        idx = flip_index(Gamma, flips)
+        idx = flip_index_blocked(Gamma, flips) if P > FLIP_BLOCKED_ABOVE else flip_index(Gamma, flips)
         beta, mu_bandit = Gamma[idx, :], mu_organic[idx, :]
     if getattr(config, 'normalize_beta', False):
         beta = beta / np.sqrt((beta ** 2).sum(1)[:, np.newaxis])

@@ -116,6 +116,15 @@ class Simulator:
                     None if self.policy_ps is None else self.policy_ps.data_ptr()), 'rg_sim_set_policy_table')
             if policy == _abi.RG_POLICY_LOGREG_FROZEN:
                 # dict(coef_t (P, C) float64 = sklearn coef_.T, intercept (C,), classes (C,))
+                n_fit = int(np.asarray(logreg['classes']).size)
+                if n_fit % 8 and logreg.get('fp16', True) and logreg.get('fp32', True):
+                    # the fp16 screening pass reads 8 classes per 16-byte load: pad with copies of the LAST class (same
+                    # column, intercept and action: an exact tie with it, whichever of them wins the action is the same)
+                    pad = 8 - n_fit % 8
+                    logreg = dict(logreg,
+                                  coef_t=np.concatenate([logreg['coef_t'], np.repeat(np.asarray(logreg['coef_t'])[:, -1:], pad, axis=1)], axis=1),
+                                  intercept=np.concatenate([logreg['intercept'], np.repeat(np.asarray(logreg['intercept'])[-1:], pad)]),
+                                  classes=np.concatenate([logreg['classes'], np.repeat(np.asarray(logreg['classes'])[-1:], pad)]))
                 self.logreg = (
                     torch.as_tensor(np.ascontiguousarray(logreg['coef_t'], dtype=np.float64)).to(self.device),
                     torch.as_tensor(np.ascontiguousarray(logreg['intercept'], dtype=np.float64)).to(self.device),
@@ -217,6 +226,21 @@ class Simulator:
         with torch.cuda.device(self.device):
             _abi.check(self.lib.rg_sim_step(self._h, ptr, self._stream()), 'rg_sim_step')
 
+    def step_user(self, action=None):
+        """One Markov transition of a ONE-user external-policy simulator with a single read-back (rg_sim_step_user) ->
+        (decoded row or None, state, clock)."""
+        res = _abi.RgStepResult()
+        with torch.cuda.device(self.device):
+            _abi.check(self.lib.rg_sim_step_user(self._h, -1 if action is None else int(action), C.byref(res), self._stream()),
+                       'rg_sim_step_user')
+        row = None
+        if res.has_row:
+            raw = np.array([[res.row.u, res.row.t, res.row.code, 0]], dtype=np.uint32)
+            raw[0, 3] = np.float32(res.row.ps).view(np.uint32)
+            row = decode_rows(raw.view(np.int32), ps64=np.array([res.ps]) if self.aux_ps is not None else None,
+                              p_click=np.array([res.p_click]) if self.aux_p_click is not None else None)[0]
+        return row, int(res.state), float(res.time)
+
     def run(self, max_steps=1 << 16):
         """rg_sim_run; raises when the run is incomplete (uncertified draws beyond the float64 resolve scratch)."""
         with torch.cuda.device(self.device):
@@ -251,6 +275,14 @@ class Simulator:
             _abi.check(self.lib.rg_sim_export_state(self._h, st.data_ptr(), self._stream()),
                        'rg_sim_export_state')
         return st[:self.n_active]
+
+    def walk_fate(self):
+        """uint8 per user of the reset range after a walked run: bit 0 = went through the float64 batch and round 2, bit 1 =
+        finished by the last round (rg_sim_debug_walk_fate; the sampled-oracle check picks its users with it)."""
+        with torch.cuda.device(self.device):
+            fl = torch.zeros(self.n_users, dtype=torch.uint8, device=self.device)
+            _abi.check(self.lib.rg_sim_debug_walk_fate(self._h, fl.data_ptr(), self._stream()), 'rg_sim_debug_walk_fate')
+        return fl[:self.n_active]
 
     def omega(self):
         with torch.cuda.device(self.device):
@@ -363,19 +395,43 @@ class Simulator:
         step = 1 << 24
         return torch.cat([raw[i:i + step][raw[i:i + step, 2] != -1] for i in range(0, n, step)])
 
-    def log_digest(self):
-        """Order-independent checksum of every real row of the raw device log (unused entries of a walked run skipped):
-        one sum per column of the 16-byte row (u, t, code, ps bits), each row weighted by (t + 7) (u + 13), modulo
-        2^64.  Equal digests of two runs = the same multiset of rows, whatever order the execution form emitted them
-        in; digests of disjoint user shards add up (mod 2^64) to the digest of the whole run."""
-        n = min(self.counters()['log_rows'], self.log_capacity)
-        chk = [0, 0, 0, 0]
+    @staticmethod
+    def _mix64(x):
+        """splitmix64 finaliser on int64 tensors (arithmetic wraps modulo 2^64; shifts made logical by masking)."""
+        def shr(v, k):
+            return (v >> k) & ((1 << (64 - k)) - 1)
+        x = x + (-7046029254386353131)                     # 0x9E3779B97F4A7C15
+        x = (x ^ shr(x, 30)) * (-4658895280553007687)      # 0xBF58476D1CE4E5B9
+        x = (x ^ shr(x, 27)) * (-7723592293110705685)      # 0x94D049BB133111EB
+        return x ^ shr(x, 31)
+
+    def log_digest(self, phantom=True):
+        """Order-independent checksum of the run's log: one sum (modulo 2^64) per column of the 16-byte row (u, t, code,
+        ps bits) and one over the float64 `ps` side array's bit patterns, every row weighted by a 64-bit hash of its key
+        (u, t) — a key occurs once per run, so values swapped between rows do not cancel.  Unused entries of a walked run
+        are skipped.  `phantom`: the trailing phantom row of every user (kept beside the raw log) is folded in too, which
+        costs one rg_sim_sort_log (the digest is then taken over the sorted log).  Equal digests of two runs = a checksum
+        match of the same multiset of rows, whatever order the execution form emitted them in; digests of disjoint user
+        shards add up (mod 2^64) to the digest of the whole run."""
+        if phantom:
+            rows_all, offsets = self.sorted_log()
+            ps64, _ = self.sorted_aux(offsets, rows_all.shape[0])
+            n = int(rows_all.shape[0])
+        else:
+            n = min(self.counters()['log_rows'], self.log_capacity)
+            rows_all, ps64 = self.log, self.aux_ps
+        chk = [0, 0, 0, 0, 0]
         step = 1 << 25
         for lo in range(0, n, step):
-            rows = self.log[lo:min(lo + step, n)].to(torch.int64)
-            w = (rows[:, 1] + 7) * (rows[:, 0] + 13) * (rows[:, 2] != -1).to(torch.int64)
+            rows = rows_all[lo:min(lo + step, n)].to(torch.int64)
+            live = (rows[:, 2] != -1)
+            w = self._mix64((rows[:, 0] << 32) | (rows[:, 1] & 0xFFFFFFFF)) * live.to(torch.int64)
             for i in range(4):
                 chk[i] = (chk[i] + int((rows[:, i] * w).sum().item())) % (1 << 64)
+            if ps64 is not None:
+                is_b = live & ((rows[:, 2] & _abi.RG_EV_BANDIT) != 0)
+                bits = ps64[lo:min(lo + step, n)].view(torch.int64)
+                chk[4] = (chk[4] + int((torch.where(is_b, bits, torch.zeros_like(bits)) * w).sum().item())) % (1 << 64)
         return chk
 
     def rows(self):

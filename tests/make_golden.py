@@ -266,6 +266,77 @@ def bandit_mf_training_golden(fixture):
     print(f'bandit_mf_training_{fixture}: {agent.curr_step} train calls -> {os.path.getsize(path) / 1024:.0f} KiB')
 
 
+def c5_trained_models(name='c5_trained_p100', P=100, K=20, n_train=1000, seed=42):
+    """The two policies of BASELINE config 5 FITTED BY THE REFERENCE'S OWN CODE, at a size it can train: a uniform-policy
+    log of `n_train` users generated by the unmodified reference (env defaults, sigma_omega = 0.1), then
+    LogregMulticlassIpsAgent's build() (train_data + sklearn multinomial fit, agents/logreg_ips.py:89-99) and BanditMFSquare's
+    train() (one call per bandit row with the observation that preceded it, agents/bandit_mf.py:89-126).  Only the fitted
+    arrays travel (bench.py's `c5trained` workload and the sampled-oracle check run them; margins between class scores — hence
+    the refine rate of the fp16 screen — are those of fitted models, not of random weights)."""
+    rh.import_reference()
+    import torch
+    from recogym import Configuration, Observation, DefaultContext
+    from recogym.envs.session import OrganicSessions
+    from recogym.agents import (BanditMFSquare, bandit_mf_square_args, LogregMulticlassIpsAgent,
+                                logreg_multiclass_ips_args)
+    args = {**BASE, 'random_seed': seed, 'num_products': P, 'K': K}
+    train_env = rh.make_reference_env({**args, 'random_seed': seed + 1000})
+    log = train_env.generate_logs(n_train)
+    lr_agent = LogregMulticlassIpsAgent(Configuration({**logreg_multiclass_ips_args, 'num_products': P, 'random_seed': 7,
+                                                       'select_randomly': False}))
+    torch.manual_seed(5)
+    mf_agent = BanditMFSquare(Configuration({**bandit_mf_square_args, 'num_products': P}))
+    d = lr_agent.model_builder.data
+    sessions, cur = OrganicSessions(), None
+    t_arr, u_arr, z_arr = log['t'].to_numpy(), log['u'].to_numpy(), log['z'].to_numpy()
+    v_arr, a_arr, c_arr, ps_arr = log['v'].to_numpy(), log['a'].to_numpy(), log['c'].to_numpy(), log['ps'].to_numpy()
+    for i in range(len(log)):
+        t, u, bandit = int(t_arr[i]), int(u_arr[i]), z_arr[i] == 'bandit'
+        d['t'].append(t); d['u'].append(u); d['z'].append(z_arr[i])
+        d['v'].append(None if bandit else int(v_arr[i]))
+        d['a'].append(int(a_arr[i]) if bandit else None)
+        d['c'].append(int(c_arr[i]) if bandit else None)
+        d['ps'].append(float(ps_arr[i]) if bandit else None)
+        if u != cur:
+            cur, sessions = u, OrganicSessions()
+        if not bandit:
+            sessions.next(DefaultContext(t, u), int(v_arr[i]))
+        else:
+            action = {'t': t, 'u': u, 'a': int(a_arr[i]), 'ps': float(ps_arr[i]), 'ps-a': ()}
+            mf_agent.train(Observation(DefaultContext(t, u), sessions), action, int(c_arr[i]), False)
+            sessions = OrganicSessions()
+    _, model = lr_agent.model_builder.build()               # the reference's train_data + sklearn fit
+    lr = model.logreg
+    path = os.path.join(GOLDEN, name + '.npz')
+    meta = dict(env_args=args, n_train=n_train, train_rows=int(len(log)), clicks_in_training=int(np.nansum(c_arr.astype(float))),
+                bandit_mf_train_calls=int(mf_agent.curr_step), logreg_classes=int(len(lr.classes_)),
+                what='policies of BASELINE config 5 fitted by the unmodified reference (logreg_ips.py build, bandit_mf.py train)')
+    np.savez_compressed(path, meta=np.array(json.dumps(meta)),
+                        logreg_coef=np.asarray(lr.coef_, dtype=np.float64), logreg_intercept=np.asarray(lr.intercept_, dtype=np.float64),
+                        logreg_classes=np.asarray(lr.classes_, dtype=np.int64),
+                        bmf_product_embedding=mf_agent.product_embedding.weight.detach().numpy(),
+                        bmf_user_embedding=mf_agent.user_embedding.weight.detach().numpy())
+    print(f'{name}: {len(log)} training rows, {meta["clicks_in_training"]} clicks, {len(lr.classes_)} classes, '
+          f'{mf_agent.curr_step} BanditMF train calls -> {os.path.getsize(path) / 1024:.0f} KiB')
+
+
+def flips_index_golden(name='flips_p2000', P=2000, K=20, flips=150, seed=42):
+    """generate_beta's pairing of the UNMODIFIED reference (reco_env_v1.py:147-168) at a size where its P x P argsort is still
+    cheap: the permutation `index` with beta = Gamma[index] recovered from the reference env's own tables (SURVEY.md 8f-4:
+    recogym_amd.envs.static_params.flip_index_blocked must reproduce it without the P x P matrix)."""
+    rh.import_reference()
+    args = {**BASE, 'random_seed': seed, 'num_products': P, 'K': K, 'number_of_flips': flips}
+    env = rh.make_reference_env(args)
+    G, B = np.asarray(env.Gamma), np.asarray(env.beta)
+    # row i of beta is row index[i] of Gamma: match rows through a hash of their bytes (rows are distinct normal draws)
+    where = {G[j].tobytes(): j for j in range(P)}
+    index = np.array([where[B[i].tobytes()] for i in range(P)], dtype=np.int32)
+    assert (index != np.arange(P)).sum() == 2 * flips
+    path = os.path.join(GOLDEN, name + '.npz')
+    np.savez_compressed(path, meta=np.array(json.dumps(dict(env_args=args, flips=flips))), index=index)
+    print(f'{name}: {flips} flips at P = {P} -> {os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def train_feed_golden(fixture):
     """The training set the UNMODIFIED reference builds from a log: the rows of an
     existing fixture are pushed through ModelBuilder.train's bookkeeping (agents/abstract.py:55-83:
@@ -325,6 +396,12 @@ def main():
         run_case('philox_ouc_p10000', {**S, 'num_products': 10000, 'K': 20, 'sigma_omega': 0.0}, 40,
                  agent_kind='ouc', agent_args=dict(random_seed=11), injected=True)
         normal_time_goldens()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'flips':           # generate_beta's pairing at P = 2 000
+        flips_index_golden()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'c5_trained':      # the fitted policies of bench.py's c5trained workload
+        c5_trained_models()
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'logreg_random':
         run_logreg_case('hostpath_logreg_random', {'random_seed': 42, 'num_products': 10, 'K': 5}, 800, 100, select_randomly=True)

@@ -993,3 +993,74 @@ def test_memo_and_anchored_certificate_carry_the_walk_at_scale(monkeypatch):
     # share of a small run — goes to the float64 pick directly
     assert c['anchored'] > 0.5 * c['exact_draws'] > 0
     assert c['exact_draws'] < 0.05 * c['organic'] and 0 < c['exact_sweeps'] < n
+
+
+@pytest.mark.parametrize('form', ['g1', 'g3_one_stream', 'g4_two_streams', 'g4_three_streams', 'g5_handover64', 'g4_small_grids'])
+@pytest.mark.parametrize('policy', ['uniform', 'ouc'])
+def test_pipelined_walk_matches_the_oracle(policy, form, monkeypatch):
+    """run_walk_pipe — the sigma_omega = 0 run as a pipeline over user groups (sweep -> finalize -> round 1 on one stream, float64
+    batch -> prefixes -> round 2 of the group before on a second, every list length read on the device, one last round) — at a
+    size the oracle replays: RECOGYM_PIPE_MIN lowers the group size from 131 072 users to 256.  Group counts that do and do not
+    divide the users, one / two / three streams, every wave handing over at once, grids smaller than the device.  Rows vs the
+    oracle, bit for bit."""
+    from oracle import oracle as orc
+    env = {'g1': dict(RECOGYM_PIPE='1'),
+           'g3_one_stream': dict(RECOGYM_PIPE='3', RECOGYM_PIPE_MODE='0'),
+           'g4_two_streams': dict(RECOGYM_PIPE='4', RECOGYM_PIPE_MODE='1'),
+           'g4_three_streams': dict(RECOGYM_PIPE='4', RECOGYM_PIPE_MODE='2'),
+           'g5_handover64': dict(RECOGYM_PIPE='5', RECOGYM_PIPE_MODE='1', RECOGYM_WALK_HANDOVER='64'),
+           'g4_small_grids': dict(RECOGYM_PIPE='4', RECOGYM_PIPE_MODE='2', RECOGYM_PIPE_OCC1='1', RECOGYM_PIPE_OCC2='1', RECOGYM_PIPE_XBLOCKS='3')}[form]
+    monkeypatch.setenv('RECOGYM_PIPE_MIN', '256')
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    P, K, n, n_org = 2500, 20, 3100, 40
+    cfg = Configuration({**env_1_args, 'random_seed': 4100 + len(form), 'num_products': P, 'K': K, 'sigma_omega': 0.0})
+    pol = {'uniform': {},
+           'ouc': dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=31, ouc=dict(gu.OUC_DEFAULTS))}[policy]
+    want_env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol)
+    want = want_env.generate_logs(n, n_org)
+    rows, cnt = run_sim(cfg, n, n_org, p_click=False, **pol)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps')}, ps_rtol=1e-12, what=f'pipe {policy} {form}')
+    assert (rows['phantom'] == want['phantom']).all()
+    oc = want_env.counters()
+    assert (cnt['organic'], cnt['bandit'], cnt['clicks'], cnt['phantom']) == (oc['organic'], oc['bandit'], oc['clicks'], oc['phantom'])
+    assert cnt['live'] == 0 and cnt['log_dropped'] == 0 and cnt['hist_overflow'] == 0
+    assert cnt['exact_sweeps'] > 0            # some users went through the float64 batch and round 2
+
+
+def test_bench_multi_rank_line_reports_both_scaling_forms_and_the_allreduce(tmp_path):
+    """`bench.py --gpus 2` end to end on THIS one-GPU box (both ranks on cuda:0, gloo instead of RCCL: the script's multi-rank
+    logic, not a measurement): one JSON line with the weak form as `value`, the strong form beside it, the per-rank step times
+    and the latency of the counter all-reduce; both forms count the events of the id ranges they simulate."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RECOGYM_BENCH_BACKEND='gloo', RECOGYM_BENCH_ONE_DEVICE='1')
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--workload', 'tiny', '--steps', '2', '--warmup', '1',
+                          '--no-cpu-baseline', '--no-materialise'], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['config']['users_total'] == 40_000
+    o = line['other_scaling']
+    assert o['scaling'] == 'strong' and o['users_total'] == 20_000 and o['users_per_gpu'] == 10_000
+    assert len(line['per_rank_ms_per_step']) == 2 and len(o['per_rank_ms_per_step']) == 2
+    assert line['allreduce_us'] > 0 and line['allreduce']['samples'] == 100
+    # ~100 events per user in both forms
+    assert 0.8 < (line['config']['events_per_step'] / 40_000) / (o['events_per_step'] / 20_000) < 1.25
+
+
+@pytest.mark.parametrize('workload,users', [('c3', 2_000_000), ('c2', 1_000_000), ('c3drift', 1_000_000), ('c4shard', 250_000),
+                                            ('c5', 250_000), ('c5trained', 1_000_000)])
+def test_sampled_oracle_parity_at_bench_size(workload, users):
+    """The oracle replays >= 2 000 user ids of a bench-size run of the default path — the longest-lived users, users of every
+    fate of the user-major walk (round 1 only / float64 batch + round 2 / finished by the wave-per-user last round), a uniform
+    spread — and their rows from the sorted device log are the oracle's bit for bit (ps, and p_click in a second run, to
+    1e-12): tests/oracle_spot_check.py.  c5: both frozen arms at 10^4 classes; c5trained: both arms fitted by the reference."""
+    import oracle_spot_check as osc
+    for line in osc.spot_check(workload, users, n_sample=2000):
+        assert line['sampled_users'] >= 2000 and line['rows_compared'] > 100 * 2000
+        if workload in ('c3', 'c2'):
+            k = line['kinds']
+            assert k['float64_batch_and_round_2'] > 0 and k['finished_by_the_last_round'] > 0 and k['round_1_only'] > 0, k

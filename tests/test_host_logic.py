@@ -334,3 +334,66 @@ def test_bandit_mf_table_is_built_in_row_blocks():
     assert np.array_equal(ag.ps, full.max(axis=1).astype(np.float64))
     big = LastViewTableAgent.from_bandit_mf(Configuration({'num_products': 6000}), rng.randn(6000, 5), rng.randn(6000, 5))
     assert big.table.shape == (6000,) and big.table.max() < 6000
+
+
+def test_reco_env_is_a_gym_env_where_gym_is_importable(tmp_path, monkeypatch):
+    """RecoEnv1 derives from gym.Env when a gym with that surface is importable (the reference's AbstractEnv does,
+    recogym/envs/abstract.py:46-57) — here a stand-in package with `Env` and `spaces.Discrete` — and from object otherwise;
+    init_gym sets action_space / observation_space = Discrete(num_products)."""
+    import importlib
+    pkg = tmp_path / 'gym'
+    (pkg / 'envs').mkdir(parents=True)
+    (pkg / '__init__.py').write_text('from . import spaces\nfrom .envs import registration\n'
+                                     'class Env:\n    metadata = {}\n    def __init__(self):\n        self.gym_env_init_ran = True\n')
+    (pkg / 'spaces.py').write_text('class Discrete:\n    def __init__(self, n):\n        self.n = n\n        self.from_gym = True\n')
+    (pkg / 'envs' / '__init__.py').write_text('from . import registration\n')
+    (pkg / 'envs' / 'registration.py').write_text('registry = {}\ndef register(id, entry_point, **kw):\n    registry[id] = entry_point\n')
+    for m in [k for k in sys.modules if k == 'gym' or k.startswith('gym.')]:
+        monkeypatch.delitem(sys.modules, m)
+    monkeypatch.syspath_prepend(str(tmp_path))
+    import recogym_amd.envs.reco_env_v1 as mod
+    try:
+        mod = importlib.reload(mod)
+        import gym
+        assert issubclass(mod.RecoEnv1, gym.Env)
+        env = mod.RecoEnv1()
+        assert env.gym_env_init_ran
+        # (init_gym draws the tables on the host; no device needed)
+        env.init_gym({**mod.env_1_args, 'random_seed': 3, 'num_products': 12})
+        assert env.action_space.n == 12 and env.action_space.from_gym and env.observation_space.n == 12
+    finally:
+        for m in [k for k in sys.modules if k == 'gym' or k.startswith('gym.')]:
+            sys.modules.pop(m, None)
+        sys.path.remove(str(tmp_path))
+        mod = importlib.reload(mod)
+    assert mod._EnvBase is object or mod._EnvBase.__module__.split('.')[0] in ('gym', 'gymnasium')
+
+
+def test_blocked_generate_beta_pairing_equals_the_reference():
+    """SURVEY.md 8f-4, table construction at large P: flip_index_blocked (row blocks of Gamma Gamma^T, a bounded candidate
+    set per round, no P x P matrix) gives (a) the pairing of the reference's full-argsort algorithm as restated by flip_index,
+    for block sizes and candidate budgets that force several rounds, and (b) the pairing the UNMODIFIED reference computed
+    at P = 2 000 (tests/golden/flips_p2000.npz, made by tests/make_golden.py flips)."""
+    import json
+    from numpy.random.mtrand import RandomState
+    from recogym_amd.envs import static_params as sp
+    rng = np.random.RandomState(11)
+    for P, K, F, rows, keep in [(300, 8, 20, 64, 50), (1500, 20, 60, 170, 500), (1000, 5, 300, 333, 256), (64, 5, 10, 7, 16)]:
+        G = rng.normal(size=(P, K))
+        assert np.array_equal(sp.flip_index(G, F), sp.flip_index_blocked(G, F, block_rows=rows, keep=keep)), (P, K, F)
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'flips_p2000.npz'))
+    meta = json.loads(str(z['meta']))
+    a = meta['env_args']
+    r = RandomState(a['random_seed'])
+    Gamma = r.normal(size=(a['num_products'], a['K']))
+    assert np.array_equal(sp.flip_index_blocked(Gamma, meta['flips'], block_rows=300), z['index'])
+    assert np.array_equal(sp.flip_index(Gamma, meta['flips']), z['index'])
+    # draw_tables switches to the blocked form above FLIP_BLOCKED_ABOVE products: same tables either way
+    cfg = Configuration({**{k: v for k, v in a.items()}, 'num_products': 600, 'number_of_flips': 25})
+    full = sp.draw_tables(cfg)
+    old, sp.FLIP_BLOCKED_ABOVE = sp.FLIP_BLOCKED_ABOVE, 100
+    try:
+        blocked = sp.draw_tables(cfg)
+    finally:
+        sp.FLIP_BLOCKED_ABOVE = old
+    assert all(np.array_equal(x, y) for x, y in zip(full, blocked))

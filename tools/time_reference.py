@@ -2,10 +2,14 @@
 """Times the UNMODIFIED NumPy reference (/root/reference, via tests/ref_harness.py's gym/numba shims) on bounded
 samples of BASELINE.json's configurations, on the cores of the box this script runs on (SURVEY.md §8d "CPU
 baseline timing").  /root/reference exists only in the build container, not on the GPU box, so the result is
-committed as profiles/r2/numpy_reference_cpu.json and bench.py quotes it (with this provenance) beside the
-C-port baseline it times live.
+committed as profiles/r4/numpy_reference_cpu.json and bench.py quotes it (with this provenance) beside the
+C-port baseline it times live.  Sample sizes are SURVEY.md §8(d)'s: C1 all 1 000 users, C2 2 000, C3 200, C4's shape with P
+capped at the reference's np.int16 ceiling on 50 users; one process, and 8 processes on disjoint seeds.  The C port
+(oracle/recogym_oracle.c, float64) is timed IN THE SAME CONTAINER on the same samples (1 and 8 threads), so that the
+port / NumPy ratio is a same-box figure: bench.py's live port timing on the GPU box's host cores divided by that ratio is
+what the NumPy reference would do there.
 
-    python tools/time_reference.py            # ~2-3 minutes
+    python tools/time_reference.py            # ~5 minutes
 """
 import json
 import multiprocessing as mp
@@ -21,9 +25,9 @@ sys.path.insert(0, ROOT)
 CASES = {
     # name: (env overrides, agent kind, users in the sample)
     'c1': (dict(num_products=10, K=5, sigma_omega=0.0), None, 1000),
-    'c2': (dict(num_products=1000, K=20, sigma_omega=0.0), 'random', 300),
-    'c3': (dict(num_products=10000, K=20, sigma_omega=0.0), 'ouc', 40),
-    'c4_capped': (dict(num_products=32767, K=64, sigma_omega=0.1), None, 6),   # reference ceiling: np.int16 ids
+    'c2': (dict(num_products=1000, K=20, sigma_omega=0.0), 'random', 2000),
+    'c3': (dict(num_products=10000, K=20, sigma_omega=0.0), 'ouc', 200),
+    'c4_capped': (dict(num_products=32767, K=64, sigma_omega=0.1), None, 50),   # reference ceiling: np.int16 ids
 }
 
 
@@ -47,6 +51,42 @@ def _worker(a):
     return run_case(*a)
 
 
+def port_case(name, threads):
+    """The C port on the same sample: `threads` oracle instances on disjoint id ranges (ctypes releases the GIL)."""
+    import threading
+    from oracle import oracle as orc
+    from recogym_amd import _abi
+    from recogym_amd.envs.configuration import Configuration
+    from recogym_amd.envs.reco_env_v1 import env_1_args
+    over, kind, users = CASES[name]
+    cfg = Configuration({**env_1_args, 'random_seed': 42, **over})
+    kw = {}
+    if kind == 'random':
+        kw = dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=42)
+    elif kind == 'ouc':
+        kw = dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=42,
+                  ouc=dict(select_randomly=True, epsilon=0.0, exploit_explore=True, reverse_pop=False))
+    orc.lib()
+    res = [0] * threads
+
+    def work(k):
+        env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **kw)
+        ev = 0
+        for lo in range(0, users, 25):
+            n = min(25, users - lo)
+            rows = env.generate_logs(n, first_user_id=1_000_000 * k + lo, capacity=n * 2000 + 10000)
+            ev += int((rows['phantom'] == 0).sum())
+        res[k] = ev
+    th = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    return sum(res), wall
+
+
 def main():
     out = dict(host=platform.node(), cpu_count=os.cpu_count(), python=platform.python_version(),
                numba='absent (sig/ff run as NumPy; affects reco_env_v1.py:32-41 only)',
@@ -65,8 +105,16 @@ def main():
                                   one_core_events_per_s=ev / dt, one_core_events=ev, one_core_seconds=dt,
                                   processes=n, all_core_events_per_s=sum(r[0] for r in res) / wall,
                                   all_core_wall_seconds=wall)
+        pe1, pw1 = port_case(name, 1)
+        pe8, pw8 = port_case(name, n)
+        c = out['cases'][name]
+        c['port_same_box'] = dict(what='oracle/recogym_oracle.c (float64 C port, Philox draws) on the same sample in this container',
+                                  one_thread_events_per_s=pe1 / pw1, one_thread_events=pe1, one_thread_seconds=pw1,
+                                  threads=n, all_thread_events_per_s=pe8 / pw8, all_thread_wall_seconds=pw8,
+                                  port_over_numpy_one_core=(pe1 / pw1) / c['one_core_events_per_s'],
+                                  port_over_numpy_all_core=(pe8 / pw8) / c['all_core_events_per_s'])
         print(name, json.dumps(out['cases'][name]))
-    path = os.path.join(ROOT, 'profiles', 'r2', 'numpy_reference_cpu.json')
+    path = os.path.join(ROOT, 'profiles', 'r4', 'numpy_reference_cpu.json')
     os.makedirs(os.path.dirname(path), exist_ok=True)
     json.dump(out, open(path, 'w'), indent=1)
     print('wrote', path)
