@@ -50,7 +50,7 @@ F16_MFMA_PEAK_TFLOPS = 2516.6      # v_mfma_f32_32x32x16_f16 / bf16, dense (256 
 F64_VALU_PEAK_TFLOPS = 78.6
 HBM_PEAK_GBPS = 8000.0
 EXP_PEAK_PER_S = 1024 * 4 * 2.4e9  # v_exp_f32: quarter rate, 4 lanes per cycle and SIMD (MI355X_MICROARCH.md: transcendentals)
-PROFILE_ROUNDS = ('r3', 'r2')      # profiles/<round>/pmc_traffic.json, newest first
+PROFILE_ROUNDS = ('r4', 'r3', 'r2')      # profiles/<round>/pmc_traffic.json, newest first
 
 
 def policy_kwargs(pol):
@@ -145,7 +145,8 @@ def cpu_baseline(workload, seconds_target=12.0):
 
     out = {}
     try:      # the NumPy reference itself, measured where /root/reference exists (tools/time_reference.py)
-        ref = json.load(open(os.path.join(ROOT, 'profiles', 'r2', 'numpy_reference_cpu.json')))
+        ref_path = next(p for p in (os.path.join(ROOT, 'profiles', r, 'numpy_reference_cpu.json') for r in ('r4', 'r2')) if os.path.exists(p))
+        ref = json.load(open(ref_path))
         case = {'c3': 'c3', 'c3drift': 'c3', 'c2': 'c2', 'c4shard': 'c4_capped', 'tiny': 'c1', 'c5': 'c3', 'tiny5': 'c1', 'c5trained': 'c2'}[workload]
         rc = ref['cases'][case]
         out['reference_numpy'] = dict(
@@ -153,11 +154,23 @@ def cpu_baseline(workload, seconds_target=12.0):
             processes=rc['processes'], case=case, env=rc['env'], agent=rc['agent'], users=rc['users'],
             provenance=f"unmodified criteo-research/reco-gym (NumPy {ref['numpy']}, numba absent) timed by "
                        f"tools/time_reference.py in the build container ({ref['cpu_count']} vCPU), NOT on this box; "
-                       f"profiles/r2/numpy_reference_cpu.json")
+                       f"{os.path.relpath(ref_path, ROOT)}")
+        if rc.get('port_same_box'):      # the C port on the same samples in the same container: a same-box port / NumPy ratio
+            ps = rc['port_same_box']
+            out['reference_numpy'].update(
+                port_same_box_one_thread_events_per_s=ps['one_thread_events_per_s'],
+                port_same_box_all_thread_events_per_s=ps['all_thread_events_per_s'],
+                port_over_numpy_one_core=ps['port_over_numpy_one_core'], port_over_numpy_all_core=ps['port_over_numpy_all_core'])
     except Exception:
         out['reference_numpy'] = None
     u1, e1, w1 = measure(1, 3.0)
     users, events, wall = measure(cores, seconds_target)
+    rn = out.get('reference_numpy') or {}
+    if rn.get('port_over_numpy_one_core'):
+        # what the NumPy reference would do on THIS box's cores: the live port figures divided by the same-box ratio
+        rn['estimated_on_this_box'] = dict(one_core_events_per_s=e1 / w1 / rn['port_over_numpy_one_core'],
+                                           all_core_events_per_s=events / wall / rn['port_over_numpy_all_core'], cores=cores,
+                                           how='this box\'s live C-port timing / the port-over-NumPy ratio measured in the build container')
     out.update(value=events / wall, unit='events/s', cores=cores, kind='port',
                per_core=events / wall / cores, one_thread=e1 / w1,
                sample=f'{users} users / {events} events of the same workload in {wall:.1f} s on {cores} threads '

@@ -242,7 +242,8 @@ int rg_sim_step_user(rg_sim* sim, int32_t action, rg_step_result* out, void* str
  * 65536 ("to the end") the last users of the run (<= 4096 alive at a 16-step poll, fewer for tables larger than 10^4 x 20; RECOGYM_TAIL overrides) are walked
  * to their end one user per workgroup instead of step by step; rows, counters and the sorted
  * log are the same, RG_CNT_STEP then reports the longest trajectory.  Fails with RG_ELIMIT when the run is incomplete
- * (RG_CNT_EXACT_OVERFLOW != 0, or a user reached the step limit). */
+ * (RG_CNT_EXACT_OVERFLOW != 0, or a user reached the step limit).  The sigma_omega = 0 user-major walk cannot overflow the
+ * float64 scratch (it holds a row per user there), so only the step limit applies to it. */
 int rg_sim_run(rg_sim* sim, uint32_t max_steps, void* stream);
 
 /* Synchronises `stream` and copies RG_CNT_N counters to the host. */

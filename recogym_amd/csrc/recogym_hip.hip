@@ -5963,8 +5963,11 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                         fa = a1 + mboxf[lane * 3 + 1]; fb = a1 + mboxf[lane * 3 + 2];
                         va = 64u * cc + 32u + static_cast<uint32_t>(max(ix, 0));
                     }
+                    // (a computed in-chunk prefix s = e (1 + eps), |eps| <= delta: the true e is at most s / (1 - delta) <=
+                    // s (1 + dp), dp = delta (1 + 2 delta) as in cert_correlated, and at least s / (1 + delta) >= s (1 - delta))
                     const double slack = 1.0e-12 * S64;
-                    const bool lo_ok = va == 0u || lo64 + static_cast<double>(fa) * (1.0 + delta) + slack < target;
+                    const double dp = delta * (1.0 + 2.0 * delta);
+                    const bool lo_ok = va == 0u || lo64 + static_cast<double>(fa) * (1.0 + dp) + slack < target;
                     const bool hi_ok = va == d.P - 1 || target + slack < lo64 + static_cast<double>(fb) * (1.0 - delta);
                     got64 = ix >= 0 && va < d.P && lo_ok && hi_ok;
                     if (got64) v = va;
@@ -8040,6 +8043,9 @@ int rg_sim_set_logreg(rg_sim* sim, const double* d_coef_t, const double* d_inter
     if (!d_coef_t || !d_intercept || !d_classes || n_classes == 0) return fail(RG_EINVAL, "NULL model array or no classes");
     sim->d.lr_coef_t = d_coef_t; sim->d.lr_intercept = d_intercept; sim->d.lr_classes = d_classes;
     sim->d.lr_n = n_classes;
+    // a new model invalidates the optional copies of the old one (their shapes and bounds belong to it): set them again
+    sim->d.lr_coef32_t = nullptr; sim->d.lr_intercept32 = nullptr; sim->d.lr_wmax = nullptr; sim->d.lr_bmax = 0.0f;
+    sim->d.lr_coef16_t = nullptr;
     return RG_OK;
 }
 
@@ -8050,6 +8056,7 @@ int rg_sim_set_logreg_fp32(rg_sim* sim, const float* d_coef32_t, const float* d_
     if ((d_coef32_t || d_intercept32 || d_wmax) && !(d_coef32_t && d_intercept32 && d_wmax)) return fail(RG_EINVAL, "all three arrays or none");
     if (!(bmax >= 0.0f)) return fail(RG_EINVAL, "bmax must be >= 0");
     sim->d.lr_coef32_t = d_coef32_t; sim->d.lr_intercept32 = d_intercept32; sim->d.lr_wmax = d_wmax; sim->d.lr_bmax = bmax;
+    sim->d.lr_coef16_t = nullptr;      // the screening pass reads intercept32 / wmax / bmax: attach it again after this call
     return RG_OK;
 }
 

@@ -918,13 +918,13 @@ def test_bench_shards_of_a_strongly_scaled_job_add_up_to_the_whole_run(workload,
     whole = _bench_line(base, capsys, monkeypatch)
     assert whole['config']['users_per_gpu'] == users
     for W in (2, 4):
-        dig = [0, 0, 0, 0]
+        dig = [0] * len(whole['digest'][0])         # (u, t, code, ps bits, float64 ps bits), phantom rows included
         tot = dict(organic=0, bandit=0, clicks=0, phantom=0)
         n = 0
         for r in range(W):
             line = _bench_line(base + ['--shard', f'{r}/{W}'], capsys, monkeypatch)
             n += line['config']['users_per_gpu']
-            for i in range(4):
+            for i in range(len(dig)):
                 dig[i] = (dig[i] + line['digest'][0][i]) % (1 << 64)
             for k in tot:
                 tot[k] += line['totals'][k]

@@ -52,39 +52,10 @@ def _worker(a):
 
 
 def port_case(name, threads):
-    """The C port on the same sample: `threads` oracle instances on disjoint id ranges (ctypes releases the GIL)."""
-    import threading
-    from oracle import oracle as orc
-    from recogym_amd import _abi
-    from recogym_amd.envs.configuration import Configuration
-    from recogym_amd.envs.reco_env_v1 import env_1_args
+    """The C port on the same sample (tests/port_timing.py: the oracle is test infrastructure and is imported from tests/ only)."""
+    import port_timing
     over, kind, users = CASES[name]
-    cfg = Configuration({**env_1_args, 'random_seed': 42, **over})
-    kw = {}
-    if kind == 'random':
-        kw = dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=42)
-    elif kind == 'ouc':
-        kw = dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=42,
-                  ouc=dict(select_randomly=True, epsilon=0.0, exploit_explore=True, reverse_pop=False))
-    orc.lib()
-    res = [0] * threads
-
-    def work(k):
-        env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **kw)
-        ev = 0
-        for lo in range(0, users, 25):
-            n = min(25, users - lo)
-            rows = env.generate_logs(n, first_user_id=1_000_000 * k + lo, capacity=n * 2000 + 10000)
-            ev += int((rows['phantom'] == 0).sum())
-        res[k] = ev
-    th = [threading.Thread(target=work, args=(k,)) for k in range(threads)]
-    t0 = time.perf_counter()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    wall = time.perf_counter() - t0
-    return sum(res), wall
+    return port_timing.port_case(over, kind, users, threads)
 
 
 def main():
