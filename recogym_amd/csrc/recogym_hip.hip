@@ -7942,6 +7942,9 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     // k_walk2 where it is instantiated for the configuration (RECOGYM_WALK=1: k_walk), four blocks per CU at K <= 20
     s->walk2 = s->walk && walk2_kernel_for(d, 4) != nullptr;
     if (const char* e = getenv("RECOGYM_WALK")) if (e[0] == '1') s->walk2 = false;
+    // (k_walk2: 4 since the act is a count on the compact history line — the bandit iteration got shorter, so the organic kind
+    // waits for more lanes: profiles/r4/ab_call6_walk_bias.jsonl; k_walk keeps round 2's 8)
+    if (s->walk2 && !getenv("RECOGYM_WALK_BIAS")) d.walk_bias = 4;
     if (const char* e = getenv("RECOGYM_WALK_OCC")) { const int o = atoi(e); if (o >= 2 && o <= 4) s->walk_occ = o; }
     if (s->walk2) s->walk_occ = d.KH <= 10 ? 3 : 2;     // (what k_walk2 is compiled for: K <= 20 three blocks per CU, K <= 32 two)
     s->walk_solo = true;

@@ -110,7 +110,8 @@ def oracle_rows_of(cfg, kw, ids, first_user, lens, threads):
     return np.concatenate(res)
 
 
-def spot_check(workload, users=None, n_sample=2000, first_user=0, env=None, seed=1, threads=None, arm_kwargs=None, config=None):
+def spot_check(workload, users=None, n_sample=2000, first_user=0, env=None, seed=1, threads=None, arm_kwargs=None, config=None,
+               p_click_modes=(False, True)):
     """Run `workload` (bench.WORKLOADS) over `users` users on the default device path, replay a sample with the oracle, compare.
     Raises AssertionError on the first difference; -> list of summaries (one per arm and per p_click setting)."""
     import torch
@@ -125,7 +126,7 @@ def spot_check(workload, users=None, n_sample=2000, first_user=0, env=None, seed
     try:
         for arm, kw in (arm_kwargs or bench.arms_of(workload, cfg)):
             ids = kinds = None
-            for p_click in (False, True):
+            for p_click in p_click_modes:
                 sim = Simulator(cfg, n, device='cuda:0', log_capacity=default_log_capacity(cfg, n), p_click=p_click, **kw)
                 sim.reset_users(first_user, n)
                 torch.cuda.synchronize(); t0 = time.perf_counter()
