@@ -13,9 +13,10 @@
 //   k_exact_sums_m / k_exact_pick (k_exact_sums_u: its vector-ALU form; k_exact_sums: K > 64)
 //                     the same draw in float64 for the draws the fast path cannot certify (dot products on the
 //                     float64 matrix cores)
-//   k_cache_finalize, k_walk (sigma_omega == 0)
+//   k_cache_finalize, k_walk2 / k_walk / k_walk_solo (sigma_omega == 0)
 //                     the whole run user-major from a per-user cache of exp-sums: draw, policy act, click,
-//                     transition and row of every event of a user on one lane
+//                     transition and row of every event of a user on one lane (run_walk_pipe: every list length stays
+//                     on the device; k_walk2's view-history line in LDS is compact and in prefix form)
 //   k_advance         AbstractEnv.step / step_offline, RecoEnv1.draw_click / update_state, the
 //                     policy's act (policy_act / logreg_act_wave) and the log rows of generate_logs
 //                                                                 abstract.py:123-239,267-316
@@ -1726,6 +1727,8 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_m(DevSim d, uint32_t t, i
 // vector form (a lane per user, Gamma rows through the scalar cache), so that the waves resident on a SIMD are a mix
 // of both and the two pipes work side by side.  Exp-sums only (mode 1), whole table per user (no product slices).
 // ------------------------------------------------------------------------------------------
+// (compiled for four waves per SIMD — 127 registers instead of 102 + 32 — the batch takes the same time, as it does with 4 or 6
+// of 8 groups in the matrix form: profiles/r4/ab_call7_exact_occupancy.jsonl)
 #if RG_HAS(2)
 template <int KB>
 __global__ void __launch_bounds__(kBlock) k_exact_sums_h(DevSim d, uint32_t n, uint32_t mfma_of_8) {
