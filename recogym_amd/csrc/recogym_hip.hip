@@ -169,6 +169,9 @@ struct DevSim {
     // every super-chunk (cache_chunk holds the chunk-level prefixes once k_cache_prefix ran)
     float* walk_hot; float* walk_scp;
     // user-major walk of the sigma_omega == 0 mode (k_walk): users parked at their first uncertified draw
+    uint32_t fin_in_sweep;    // run_walk_pipe: the prefix-form sweep also leaves what k_cache_finalize + k_cache_prefix would (the
+                              // user's Q, delta, omega32, empty memo) for every user whose reference never moved; those two
+                              // kernels then only visit the (rare) users it did move for (cache_resc != 0)
     uint32_t sweep_only;      // the step-0 sweep only fills the cache (no search, no rows): k_walk draws t = 0 too;
                               // 2: ... and k_draw_bf16p stores the chunk sums as running PREFIXES on the reference in force (and the
                               // prefix at every super-chunk end in walk_scp): k_walk2's form, no conversion pass
@@ -269,6 +272,7 @@ struct rg_sim {
                               // 2: ... and the sweeps on a third
     int pipe_occ1, pipe_occ2; // blocks per CU of the round-1 / round-2 grids (<= what the kernel is compiled for)
     int pipe_xblocks;         // blocks of the float64 batch's grid
+    bool fin_in_sweep;        // the sweep of run_walk_pipe leaves the finalize / prefix kernels' output itself (RECOGYM_FIN_IN_SWEEP=0: A/B)
     uint32_t pipe_min_users;  // users of a group (and of a pipelined run) at least: an unsliced sweep's 1024 user tiles (RECOGYM_PIPE_MIN: tests)
     hipStream_t pipe_streams[2];
     std::vector<hipEvent_t> pipe_events;   // ordering events (no timing), created once
@@ -3210,6 +3214,24 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             if (prefix_mode) scp_row[sc_cur] = static_cast<float>(run_pref);
         }
         if (d.use_cache && S == 1 && active && h == 0) d.cache_resc[d.uid[slot]] = static_cast<uint8_t>(min(n_resc, 255));
+        if (prefix_mode && scp_row && d.fin_in_sweep && active && h == 0 && n_resc == 0) {
+            // what k_cache_finalize and k_cache_prefix would leave for this user (one reference for the whole sweep: nothing to
+            // rescale): Q and the certificate's delta in its cache row, omega32 behind them, the unused super-chunk prefixes,
+            // the hot row {S~, delta + 2^-21 for the stored prefixes' roundings, Q, an empty memo}
+            const size_t urow = d.uid[slot];
+            float4* row4 = reinterpret_cast<float4*>(d.cache_row + urow * d.cache_row_f);
+            const double delta = static_cast<double>(d.K + 5) * 5.9604644775390625e-08 * static_cast<double>(Ahat) + delta_fixed;
+            const float dlt = static_cast<float>(delta * 1.000001);          // rounded up: the budget must not shrink
+            row4[8] = make_float4(q, dlt, 0.0f, 0.0f);
+            const float* ou = om_stage + (wave * 32 + j) * 2 * KH;
+#pragma unroll
+            for (int k4 = 0; k4 < (2 * KH) / 4; ++k4) row4[11 + k4] = make_float4(ou[4 * k4], ou[4 * k4 + 1], ou[4 * k4 + 2], ou[4 * k4 + 3]);
+#pragma unroll
+            for (int k = ((2 * KH) / 4) * 4; k < 2 * KH; ++k) reinterpret_cast<float*>(row4)[44 + k] = ou[k];
+            for (uint32_t sc = d.n_sc; sc < kMaxSC; ++sc) scp_row[sc] = INFINITY;
+            *reinterpret_cast<float4*>(d.walk_hot + urow * 32) =
+                make_float4(static_cast<float>(run_pref), dlt * 1.000001f + 4.8e-7f, q, __builtin_bit_cast(float, 0u));
+        }
         if (S == 1 && !RG_SWEEP_ABL(128u) && !d.sweep_only) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, delta_fixed, &view);
     }
 }
@@ -3283,6 +3305,7 @@ __global__ void __launch_bounds__(kBlock) k_cache_finalize(DevSim d) {
     float gsum = 0.0f;
     if (d.f16) for (uint32_t k = 0; k < d.K; ++k) gsum += d.stats[k];
     for (uint32_t i = d.grp_lo + blockIdx.x * kBlock + threadIdx.x; i < d.grp_lo + d.grp_n; i += gridDim.x * kBlock) {
+        if (d.fin_in_sweep && d.cache_resc[i] == 0) continue;        // (the sweep left this user's row itself)
         // everything is staged in registers and leaves as 16-byte stores (a row is 256-byte aligned)
         float4* row4 = reinterpret_cast<float4*>(d.cache_row + static_cast<size_t>(i) * d.cache_row_f);
         // omega32 and the logit error bound, exactly as the sweep kernel computes them
@@ -5410,7 +5433,9 @@ __global__ void __launch_bounds__(kBlock) k_cache_prefix(DevSim d, int fused) {
     const uint32_t waves = gridDim.x * (kBlock / 64);
     for (uint32_t ug = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); ug < n_groups; ug += waves) {
         const uint32_t i = d.grp_lo + ug * 8 + grp;
-        const bool act = i < d.grp_lo + d.grp_n;
+        // (fin_in_sweep: only the users whose reference moved during the sweep — the others' prefixes need no rescaling and the
+        // sweep left their hot rows)
+        const bool act = i < d.grp_lo + d.grp_n && !(d.fin_in_sweep && d.cache_resc[i < d.grp_lo + d.grp_n ? i : d.n_cap] == 0);
         const size_t row = act ? i : d.n_cap;
         const float4* r4 = reinterpret_cast<const float4*>(d.cache_row + row * d.cache_row_f);
         const float4 hdr = r4[8], of0 = r4[9], of1 = r4[10];
@@ -7713,6 +7738,7 @@ int run_walk_pipe(rg_sim* sim, hipStream_t st) {
         {
             DevSim ds = dg;
             ds.sweep_only = 2u;
+            ds.fin_in_sweep = dg.fin_in_sweep = sim->fin_in_sweep ? 1u : 0u;
             const uint32_t tiles_up = (dg.grp_n + sim->draw_users - 1) / sim->draw_users;
             if (int rc = span_begin(0, sS)) return rc;
             hipLaunchKernelGGL(sim->bf16_kernel, dim3(sweep_grid(sim, tiles_up, 1)), dim3(sim->draw_threads), sim->bf16_smem, sS, ds, 0u, 1u);
@@ -7970,6 +7996,9 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     if (const char* e = getenv("RECOGYM_PIPE_OCC1")) { const int o = atoi(e); if (o >= 1 && o <= s->walk_occ) s->pipe_occ1 = o; }
     if (const char* e = getenv("RECOGYM_PIPE_OCC2")) { const int o = atoi(e); if (o >= 1 && o <= s->walk_occ) s->pipe_occ2 = o; }
     if (const char* e = getenv("RECOGYM_PIPE_XBLOCKS")) { const int o = atoi(e); if (o >= 1) s->pipe_xblocks = o; }
+    s->fin_in_sweep = true;
+    if (const char* e = getenv("RECOGYM_FIN_IN_SWEEP")) s->fin_in_sweep = e[0] != '0';
+    d.fin_in_sweep = 0;
     s->pipe_min_users = 1u << 17;
     if (const char* e = getenv("RECOGYM_PIPE_MIN")) { const int o = atoi(e); if (o >= 256) s->pipe_min_users = static_cast<uint32_t>(o); }
     d.grp_lo = 0; d.grp_n = d.n_users; d.list_in = 0;
