@@ -1751,12 +1751,20 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_h(DevSim d, uint32_t n, u
     if (d.q_count) n = static_cast<uint32_t>(*d.q_count);      // the list's length as the kernel before this one left it
     const uint32_t* plist = d.park_list + d.list_in;
     const uint32_t n_groups = (n + UPB - 1) / UPB;
+    // Few groups per resident block (a rank's share of a strongly scaled run; the last round of blocks of any run): cut every
+    // group's pass over the table into S product slices, so that the work items are >= 16 per launched block and the last
+    // round of blocks is a slice, not a table, long (C3, 1.25 M users: 1 290 groups over 768 resident blocks = 2 rounds for 1.7)
+    uint32_t S = 1;
+    if (n_groups && n_groups < 16u * gridDim.x) S = min(8u, (16u * gridDim.x + n_groups - 1) / n_groups);
+    S = min(S, n_cc);
+    const uint32_t n_items = n_groups * S;
     for (;;) {
         __syncthreads();                       // s_grp and the LDS tiles of the previous group are free
         if (threadIdx.x == 0) s_grp = static_cast<uint32_t>(atomicAdd(d.q_ticket, 1ull));
         __syncthreads();
-        const uint32_t grp = s_grp;
-        if (grp >= n_groups) break;
+        if (s_grp >= n_items) break;
+        const uint32_t grp = s_grp / S, slice = s_grp % S;
+        const uint32_t cc_lo = slice * n_cc / S, cc_hi = (slice + 1u) * n_cc / S;      // this item's 64-product chunks
         if ((grp & 7u) < mfma_of_8) {
             // ================= matrix form (k_exact_sums_m's body, from_list == 2, one slice) =================
             uint32_t row[G];
@@ -1793,11 +1801,11 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_h(DevSim d, uint32_t n, u
                     if (idx < TILE / 2) dst[idx] = pf[i];
                 }
             };
-            fetch(0);
-            stash(0);
-            for (uint32_t cc = 0; cc < n_cc; ++cc) {
+            fetch(cc_lo);
+            stash(cc_lo & 1u);
+            for (uint32_t cc = cc_lo; cc < cc_hi; ++cc) {
                 __syncthreads();
-                const bool more = cc + 1 < n_cc;
+                const bool more = cc + 1 < cc_hi;
                 if (more) fetch(cc + 1);
                 const double* A = tiles + (cc & 1u) * TILE;
                 double sum[G];
@@ -1850,7 +1858,7 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_h(DevSim d, uint32_t n, u
                     om[j][k] = (act[j] && static_cast<uint32_t>(k) < d.K) ? d.omega[static_cast<size_t>(slot) * d.OMS + k] : 0.0;
                 M[j] = act[j] ? static_cast<double>(d.exact_ref[slot]) * 0.69314718055994530942 : 0.0;
             }
-            for (uint32_t cc = 0; cc < n_cc; ++cc) {
+            for (uint32_t cc = cc_lo; cc < cc_hi; ++cc) {
                 double acc[UPL];
 #pragma unroll
                 for (int j = 0; j < UPL; ++j) acc[j] = 0.0;
