@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION 3
+#define RG_ABI_VERSION 4
 
 /* error codes */
 #define RG_OK 0
@@ -153,6 +153,15 @@ size_t rg_sim_workspace_bytes(const rg_config* cfg, uint64_t n_users);
 int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_workspace,
                   size_t workspace_bytes);
 int rg_sim_destroy(rg_sim* sim);
+
+/* Run-path tuning knobs by name (none changes a result or the workspace layout; the defaults are the measured optima, DESIGN.md
+ * §4 / §9).  rg_sim_create takes their initial values from the RECOGYM_* environment variables of the same meaning (the A/B
+ * tests' way in); after that the library never reads the environment on the run path.  Names: walk_bias, walk_refill,
+ * walk_handover, walk_click_batch, walk_search_batch, walk_line64, pipe_groups, pipe_mode, pipe_occ1, pipe_occ2, pipe_xblocks,
+ * pipe_min_users, exact_mix, exact_valu, exact_tile, resident_grid, slices (-1 = by population), sweep_prefix_off, tail_below,
+ * repack_every, debug.  RG_EINVAL for an unknown name or a value out of range. */
+int rg_sim_set_option(rg_sim* sim, const char* name, int64_t value);
+int rg_sim_get_option(rg_sim* sim, const char* name, int64_t* value);
 
 /* RecoEnv1.set_static_params / generate_beta results (reco_env_v1.py:51-75,133-174): row-major
  * float64 device arrays Gamma (P,K), mu_organic (P), beta (P,K), mu_bandit (P), drawn on the

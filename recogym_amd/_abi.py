@@ -7,7 +7,7 @@ infrastructure and is never imported from this package.)
 import ctypes as C
 import os
 
-RG_ABI_VERSION = 3
+RG_ABI_VERSION = 4
 
 RG_STATE_ORGANIC, RG_STATE_BANDIT, RG_STATE_STOP = 0, 1, 2
 
@@ -77,6 +77,8 @@ SYMBOLS = {
     'rg_sim_create': (C.c_int, [C.POINTER(_SIM), C.POINTER(RgConfig), C.c_uint64, C.c_void_p,
                                 C.c_size_t]),
     'rg_sim_destroy': (C.c_int, [_SIM]),
+    'rg_sim_set_option': (C.c_int, [_SIM, C.c_char_p, C.c_int64]),
+    'rg_sim_get_option': (C.c_int, [_SIM, C.c_char_p, C.POINTER(C.c_int64)]),
     'rg_sim_set_tables': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     'rg_sim_set_policy_table': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),

@@ -126,6 +126,7 @@ struct DevSim {
     uint32_t walk_bias;       // k_walk: 0 = both event kinds every iteration; else one kind, organic when n_org * walk_bias >= n_bandit * 4
     uint32_t walk_click_batch;   // k_walk2: lanes waiting for ctr (kWClick) at which the wave takes them (0: in the bandit iteration itself)
     uint32_t walk_search_batch;  // k_walk2: lanes that missed the memo at which the wave runs the search (its chunk passes take 8 users each)
+    uint32_t walk_line64;        // k_walk2 (host side: which instantiation): round 3's 64-bit history line of 15 products (RECOGYM_WALK_HIST=1)
     uint32_t exact_base;      // first exact_list entry of the batch being resolved
     uint32_t exact_last;      // this is the last batch launched for the step
     float2* sc_scratch;       // [kMaxGrid*4 waves][kMaxSC][32] {sum, reference} of the MFMA draw kernel
@@ -250,9 +251,23 @@ struct DevSim {
 }  // namespace rgk
 using namespace rgk;
 
+// Run-path options: every switch the launch code consults, read ONCE (rg_sim_create, from the RECOGYM_* environment: the A/B
+// tests' way in) and settable through rg_sim_set_option — no getenv on the run path.
+struct RunOpts {
+    int exact_tile;          // RECOGYM_EXACT_TILE: the K > 64 tile kernel for every float64 resolve
+    int exact_valu;          // RECOGYM_EXACT (any value): no matrix-form float64 kernels (the vector-ALU kernel)
+    int exact_mix;           // RECOGYM_EXACT_MIX: groups of every 8 of the walk's float64 batch in the matrix form (8 = all)
+    int resident_grid;       // RECOGYM_RESIDENT_GRID: sweep grid = the resident blocks
+    int slices;              // RECOGYM_SLICES: product slices of the lock-step sweep (-1 = by population)
+    int sweep_prefix_off;    // RECOGYM_SWEEP_PREFIX_OFF: the sweep stores sums, k_cache_prefix converts them
+    int debug;               // RECOGYM_DEBUG
+    unsigned long long repack_min;   // RECOGYM_REPACK_MIN: users below which slot == user index throughout
+};
+
 struct rg_sim {
     rg_config cfg;
     DevSim d;
+    RunOpts opt;
     void* workspace;
     size_t workspace_bytes;
     uint32_t t;               // next step to run
@@ -1898,7 +1913,6 @@ exact_h_kernel_t exact_h_kernel_for(uint32_t kb) {
 }
 
 exact_m_kernel_t exact_m_kernel_for(uint32_t kb) {
-    if (const char* e = getenv("RECOGYM_EXACT")) if (!strcmp(e, "valu")) return nullptr;     // A/B: the vector-ALU kernel
     switch (kb) {
         case 1: return k_exact_sums_m<1>;   case 2: return k_exact_sums_m<2>;   case 3: return k_exact_sums_m<3>;
         case 4: return k_exact_sums_m<4>;   case 5: return k_exact_sums_m<5>;   case 6: return k_exact_sums_m<6>;
@@ -6932,8 +6946,7 @@ walk_kernel_t walk2_kernel_for(const DevSim& d, int occ) {
     (void)occ;
     // the view-history line in LDS: compact (31 products per line) where a product fits 16 bits (RECOGYM_WALK_HIST=1: the
     // 64-bit line of 15 products, A/B)
-    const char* e_h = getenv("RECOGYM_WALK_HIST");
-    const bool compact = ouc && d.P <= 65535u && d.hist_cap >= 32u && d.hist_cap <= 32768u && !(e_h && e_h[0] == '1');
+    const bool compact = ouc && d.P <= 65535u && d.hist_cap >= 32u && d.hist_cap <= 32768u && !d.walk_line64;
     switch (d.KH) {
         case 4: return ouc ? (compact ? k_walk2<4, 2> : k_walk2<4, 1>) : k_walk2<4, 0>;
         case 10: return ouc ? (compact ? k_walk2<10, 2> : k_walk2<10, 1>) : k_walk2<10, 0>;
@@ -7341,7 +7354,7 @@ void launch_exact(rg_sim* sim, uint32_t t, int from_list, uint64_t est, hipStrea
         d.exact_base = batched ? static_cast<uint32_t>(b) * d.exact_rows : 0u;
         d.exact_last = b + 1 == n_batches ? 1u : 0u;
         if (batched && est > d.exact_rows) est = d.exact_rows;
-        if (exact_m_kernel_t km = (getenv("RECOGYM_EXACT_TILE") ? nullptr : exact_m_kernel_for(d.XKB))) {
+        if (exact_m_kernel_t km = ((sim->opt.exact_tile || sim->opt.exact_valu) ? nullptr : exact_m_kernel_for(d.XKB))) {
             if (!from_list) {
                 launch_exact_m(km, d, t, 0, 0, est, st);
                 hipLaunchKernelGGL(exact_ref_kernel(), dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t, 1u);
@@ -7351,7 +7364,7 @@ void launch_exact(rg_sim* sim, uint32_t t, int from_list, uint64_t est, hipStrea
                                sizeof(double) * d.K * (kBlock / 64), st, d, t, from_list, 1u);
             continue;
         }
-        if (exact_u_kernel_t ku = (getenv("RECOGYM_EXACT_TILE") ? nullptr : exact_u_kernel_for(d.XKB))) {
+        if (exact_u_kernel_t ku = (sim->opt.exact_tile ? nullptr : exact_u_kernel_for(d.XKB))) {
             const uint64_t upl = 64ull * exact_upl_of(d.XKB);
             const uint64_t groups = (est + upl - 1) / upl;
             // The kernel's stall is the scalar-load latency of a Gamma row (the table streams through
@@ -7405,7 +7418,7 @@ int device_cus(rg_sim* sim) {
 int sweep_grid(rg_sim* sim, uint64_t work_items, uint32_t S) {
     int grid = grid_for(work_items, 1);
     const int resident = device_cus(sim) * (sim->draw_users == 256 ? 1 : 2);
-    if (S == 1 && grid > resident && getenv("RECOGYM_RESIDENT_GRID")) grid = resident;
+    if (S == 1 && grid > resident && sim->opt.resident_grid) grid = resident;
     if (sim->draw_users == 256 && grid > kMaxGrid / 2) grid = kMaxGrid / 2;     // 8 groups per block share the per-wave scratch
     return grid;
 }
@@ -7415,14 +7428,14 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     const DevSim& d = sim->d;
     const uint32_t t = sim->t;
     const uint32_t upper = sim->live_upper;
-    if (sim->repack_every && t && t % sim->repack_every == 0 && sim->d.n_cap >= repack_min_users() && upper >= repack_min_users() / 4) {
+    if (sim->repack_every && t && t % sim->repack_every == 0 && sim->d.n_cap >= sim->opt.repack_min && upper >= sim->opt.repack_min / 4) {
         DevSim& m = sim->d;
         hipLaunchKernelGGL(k_repack_copy, dim3(grid_for(upper, kBlock / 32)), dim3(kBlock), 0, st, m, t);
         hipLaunchKernelGGL(k_repack_lists, dim3(grid_for(upper)), dim3(kBlock), 0, st, m, t);
         std::swap(m.omega, m.omega_alt); std::swap(m.hist, m.hist_alt); std::swap(m.uid, m.uid_alt);
         if (m.lpv) std::swap(m.lpv, m.lpv_alt);
         sim->repacked = true;
-        if (getenv("RECOGYM_DEBUG")) fprintf(stderr, "[recogym] repack at t=%u (upper %u)\n", t, upper);
+        if (sim->opt.debug) fprintf(stderr, "[recogym] repack at t=%u (upper %u)\n", t, upper);
     }
     if (int rc = prof_mark(sim, st)) return rc;
     // 1. organic product draws of this step (read omega before the transition drifts it)
@@ -7441,7 +7454,7 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         // few user tiles: slice the products so that the step's latency is a slice, not a sweep
         const uint32_t tiles_up = (upper + sim->draw_users - 1) / sim->draw_users;
         uint32_t S = tiles_up >= 131072u / sim->draw_users ? 1u : (262144u / sim->draw_users) / (tiles_up ? tiles_up : 1u);
-        if (const char* e = getenv("RECOGYM_SLICES")) S = static_cast<uint32_t>(atoi(e));   // tests: force either form
+        if (sim->opt.slices >= 0) S = static_cast<uint32_t>(sim->opt.slices);   // tests: force either form
         if (S > d.n_sc) S = d.n_sc;
         if (S < 1) S = 1;
         const int grid = sweep_grid(sim, static_cast<uint64_t>(tiles_up) * S, S);
@@ -7527,12 +7540,12 @@ int run_walk(rg_sim* sim, hipStream_t st) {
         DevSim ds = d;
         const uint32_t tiles_up = (d.n_users + sim->draw_users - 1) / sim->draw_users;
         uint32_t S = tiles_up >= 131072u / sim->draw_users ? 1u : (262144u / sim->draw_users) / (tiles_up ? tiles_up : 1u);
-        if (const char* e = getenv("RECOGYM_SLICES")) S = static_cast<uint32_t>(atoi(e));
+        if (sim->opt.slices >= 0) S = static_cast<uint32_t>(sim->opt.slices);
         if (S > d.n_sc) S = d.n_sc;
         if (S < 1) S = 1;
         // k_walk2 behind the fused (unsliced) form of the pipelined fp16 sweep of K <= 21: the sweep stores the sums in the
         // walk's prefix form itself (no conversion pass over the 1.3 KB of chunk sums per user)
-        fused_prefix = sim->walk2 && S == 1 && sim->bf16_kernel == bf16p_kernel_for(d) && d.f16 && !d.wide && !getenv("RECOGYM_SWEEP_PREFIX_OFF");
+        fused_prefix = sim->walk2 && S == 1 && sim->bf16_kernel == bf16p_kernel_for(d) && d.f16 && !d.wide && !sim->opt.sweep_prefix_off;
         ds.sweep_only = fused_prefix ? 2u : 1u;
         const int grid = sweep_grid(sim, static_cast<uint64_t>(tiles_up) * S, S);
         hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid), dim3(sim->draw_threads), sim->bf16_smem, st, ds, 0u, S);
@@ -7570,7 +7583,7 @@ int run_walk(rg_sim* sim, hipStream_t st) {
     HIP_TRY(hipMemcpyAsync(h64, d.counters + kCntParkCnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const uint32_t n_park = static_cast<uint32_t>(*h64);
-    if (getenv("RECOGYM_DEBUG")) {
+    if (sim->opt.debug) {
         unsigned long long ev2[2] = {0, 0};
         HIP_TRY(hipMemcpy(ev2, d.counters + kCntTailOrganic, sizeof(ev2), hipMemcpyDeviceToHost));
         fprintf(stderr, "[recogym] walk round 1: %llu organic + %llu bandit events, %u users parked of %u\n", ev2[0], ev2[1], n_park, d.n_users);
@@ -7607,9 +7620,8 @@ int run_walk(rg_sim* sim, hipStream_t st) {
         return RG_OK;
     };
     if (n_park) {
-        uint32_t mfma_of_8 = 5;                 // groups of every 8 that take the matrix form (RECOGYM_EXACT_MIX; 8 = all)
-        if (const char* e = getenv("RECOGYM_EXACT_MIX")) mfma_of_8 = static_cast<uint32_t>(atoi(e));
-        exact_h_kernel_t kh = (mfma_of_8 < 8 && !getenv("RECOGYM_EXACT")) ? exact_h_kernel_for(d.XKB) : nullptr;
+        const uint32_t mfma_of_8 = static_cast<uint32_t>(sim->opt.exact_mix);     // groups of every 8 that take the matrix form (8 = all)
+        exact_h_kernel_t kh = (mfma_of_8 < 8 && !sim->opt.exact_valu) ? exact_h_kernel_for(d.XKB) : nullptr;
         if (kh) {
             HIP_TRY(hipMemsetAsync(d.counters + kCntWalkTicket, 0, sizeof(unsigned long long), st));
             const uint32_t groups = (n_park + 255u) / 256u;
@@ -7619,7 +7631,7 @@ int run_walk(rg_sim* sim, hipStream_t st) {
             if (int rc = later_rounds(n_park)) return rc;
             goto walked;
         }
-        if (exact_m_kernel_t km = exact_m_kernel_for(d.XKB)) {
+        if (exact_m_kernel_t km = (sim->opt.exact_valu ? nullptr : exact_m_kernel_for(d.XKB))) {
             launch_exact_m(km, d, n_park, 2, 1, n_park, st);
             if (int rc = mark(4)) return rc;
             if (int rc = later_rounds(n_park)) return rc;
@@ -7725,8 +7737,7 @@ int run_walk_pipe(rg_sim* sim, hipStream_t st) {
     const solo_kernel_t sk = solo_kernel_for(d);
     const exact_h_kernel_t kh = exact_h_kernel_for(d.XKB);
     if (!wk || !sk || !kh) return fail(RG_ESTATE, "run_walk_pipe: no kernel for this configuration");
-    uint32_t mfma_of_8 = 5;
-    if (const char* e = getenv("RECOGYM_EXACT_MIX")) mfma_of_8 = static_cast<uint32_t>(atoi(e));
+    const uint32_t mfma_of_8 = static_cast<uint32_t>(sim->opt.exact_mix);
     auto walk_chunk = [&](uint64_t n_work, int blocks) {
         uint64_t chunk = n_work * 100 / (static_cast<uint64_t>(blocks) * 4 * 32);
         chunk = chunk / 64 * 64;
@@ -7901,6 +7912,21 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     d.time_mode = cfg->time_mode; d.time_mu = cfg->time_mu; d.time_sigma = cfg->time_sigma;
     d.n_users = d.n_cap = static_cast<uint32_t>(n_users);
     s->h_pinned = nullptr; s->h_step = nullptr;
+    {   // run-path options from the environment, once
+        RunOpts& o = s->opt;
+        o.exact_tile = getenv("RECOGYM_EXACT_TILE") ? 1 : 0;
+        o.exact_valu = getenv("RECOGYM_EXACT") ? 1 : 0;
+        o.exact_mix = 5;
+        if (const char* e = getenv("RECOGYM_EXACT_MIX")) o.exact_mix = atoi(e);
+        o.resident_grid = getenv("RECOGYM_RESIDENT_GRID") ? 1 : 0;
+        o.slices = -1;
+        if (const char* e = getenv("RECOGYM_SLICES")) o.slices = atoi(e);
+        o.sweep_prefix_off = getenv("RECOGYM_SWEEP_PREFIX_OFF") ? 1 : 0;
+        o.debug = getenv("RECOGYM_DEBUG") ? 1 : 0;
+        o.repack_min = repack_min_users();
+        const char* e_h = getenv("RECOGYM_WALK_HIST");
+        d.walk_line64 = (e_h && e_h[0] == '1') ? 1u : 0u;
+    }
     s->profiling = false; s->prof_used = 0; s->prof_launches = 0;
     s->prof_ms[0] = s->prof_ms[1] = s->prof_ms[2] = s->prof_ms[3] = s->prof_ms[4] = 0.0;
     s->mfma_smem = d.use_mfma ? mfma_smem_bytes(geom_of(*cfg)) : 0;
@@ -8015,7 +8041,7 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     if (const char* e = getenv("RECOGYM_REPACK")) s->repack_every = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_ABLATE")) d.ablate = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_LDS_PAD")) s->mfma_smem += static_cast<size_t>(atoi(e));
-    if (getenv("RECOGYM_DEBUG") && d.use_mfma && rg_device_count() > 0) {
+    if (s->opt.debug && d.use_mfma && rg_device_count() > 0) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(mfma_kernel_for(10)), kBlock, s->mfma_smem);
         fprintf(stderr, "[recogym] k_draw_mfma<10>: dynamic LDS %zu B, occupancy API %d blocks/CU\n", s->mfma_smem, nb);
@@ -8039,6 +8065,64 @@ int rg_sim_destroy(rg_sim* sim) {
     for (hipStream_t ps : sim->pipe_streams) if (ps) (void)hipStreamDestroy(ps);
     delete sim;
     return RG_OK;
+}
+
+// name -> the field it sets; every entry is a run-path tuning knob (none changes the workspace layout or a result)
+namespace {
+int* opt_int(rg_sim* s, const char* n) {
+    if (!strcmp(n, "pipe_groups")) return &s->pipe_groups;
+    if (!strcmp(n, "pipe_mode")) return &s->pipe_mode;
+    if (!strcmp(n, "pipe_occ1")) return &s->pipe_occ1;
+    if (!strcmp(n, "pipe_occ2")) return &s->pipe_occ2;
+    if (!strcmp(n, "pipe_xblocks")) return &s->pipe_xblocks;
+    if (!strcmp(n, "exact_mix")) return &s->opt.exact_mix;
+    if (!strcmp(n, "exact_valu")) return &s->opt.exact_valu;
+    if (!strcmp(n, "exact_tile")) return &s->opt.exact_tile;
+    if (!strcmp(n, "resident_grid")) return &s->opt.resident_grid;
+    if (!strcmp(n, "slices")) return &s->opt.slices;
+    if (!strcmp(n, "sweep_prefix_off")) return &s->opt.sweep_prefix_off;
+    if (!strcmp(n, "debug")) return &s->opt.debug;
+    return nullptr;
+}
+uint32_t* opt_u32(rg_sim* s, const char* n) {
+    if (!strcmp(n, "walk_bias")) return &s->d.walk_bias;
+    if (!strcmp(n, "walk_refill")) return &s->d.walk_refill;
+    if (!strcmp(n, "walk_handover")) return &s->d.walk_handover;
+    if (!strcmp(n, "walk_click_batch")) return &s->d.walk_click_batch;
+    if (!strcmp(n, "walk_search_batch")) return &s->d.walk_search_batch;
+    if (!strcmp(n, "walk_line64")) return &s->d.walk_line64;
+    if (!strcmp(n, "pipe_min_users")) return &s->pipe_min_users;
+    if (!strcmp(n, "tail_below")) return &s->tail_below;
+    if (!strcmp(n, "repack_every")) return &s->repack_every;
+    return nullptr;
+}
+}  // namespace
+
+int rg_sim_set_option(rg_sim* sim, const char* name, int64_t value) {
+    if (!sim || !name) return fail(RG_EINVAL, "NULL argument");
+    if (int* p = opt_int(sim, name)) {
+        if ((!strcmp(name, "pipe_occ1") || !strcmp(name, "pipe_occ2")) && (value < 1 || value > sim->walk_occ))
+            return fail(RG_EINVAL, "%s must be in [1, %d]", name, sim->walk_occ);
+        if (!strcmp(name, "pipe_xblocks") && value < 1) return fail(RG_EINVAL, "pipe_xblocks must be >= 1");
+        if (!strcmp(name, "exact_mix") && (value < 0 || value > 8)) return fail(RG_EINVAL, "exact_mix must be in [0, 8]");
+        *p = static_cast<int>(value);
+        return RG_OK;
+    }
+    if (uint32_t* p = opt_u32(sim, name)) {
+        if (value < 0) return fail(RG_EINVAL, "%s must be >= 0", name);
+        if (!strcmp(name, "walk_search_batch") && value < 1) value = 1;
+        if (!strcmp(name, "pipe_min_users") && value < 256) return fail(RG_EINVAL, "pipe_min_users must be >= 256");
+        *p = static_cast<uint32_t>(value);
+        return RG_OK;
+    }
+    return fail(RG_EINVAL, "unknown option '%s'", name);
+}
+
+int rg_sim_get_option(rg_sim* sim, const char* name, int64_t* value) {
+    if (!sim || !name || !value) return fail(RG_EINVAL, "NULL argument");
+    if (int* p = opt_int(sim, name)) { *value = *p; return RG_OK; }
+    if (uint32_t* p = opt_u32(sim, name)) { *value = *p; return RG_OK; }
+    return fail(RG_EINVAL, "unknown option '%s'", name);
 }
 
 int rg_sim_set_tables(rg_sim* sim, const double* d_gamma, const double* d_mu_organic,
@@ -8210,12 +8294,11 @@ int rg_sim_run(rg_sim* sim, uint32_t max_steps, void* stream) {
     if (sim->walk && sim->t == 0 && max_steps >= kMaxSteps) {
         // the pipelined form where its kernels exist (k_walk2 behind the fused-prefix fp16 sweep, k_walk_solo, the mixed float64
         // batch) and the reset range fills an unsliced sweep; else the serial chain with its list lengths read back by the host
-        uint32_t mix = 5;
-        if (const char* e = getenv("RECOGYM_EXACT_MIX")) mix = static_cast<uint32_t>(atoi(e));
+        const int mix = sim->opt.exact_mix;
         const bool pipe = sim->pipe_groups >= 1 && sim->walk2 && sim->walk_solo && solo_kernel_for(sim->d) && sim->d.walk_handover &&
                           sim->bf16_kernel == bf16p_kernel_for(sim->d) && sim->d.f16 && !sim->d.wide && sim->d.n_users >= sim->pipe_min_users &&
-                          exact_h_kernel_for(sim->d.XKB) && mix < 8 && !getenv("RECOGYM_EXACT") && !getenv("RECOGYM_SLICES") &&
-                          !getenv("RECOGYM_SWEEP_PREFIX_OFF");
+                          exact_h_kernel_for(sim->d.XKB) && mix < 8 && !sim->opt.exact_valu && sim->opt.slices < 0 &&
+                          !sim->opt.sweep_prefix_off;
         return pipe ? run_walk_pipe(sim, st) : run_walk(sim, st);
     }
     uint32_t done_steps = 0;

@@ -207,6 +207,15 @@ class Simulator:
         self.rg_config.policy_seed = ps
         _abi.check(self.lib.rg_sim_reseed(self._h, seed, ps), 'rg_sim_reseed')
 
+    def set_option(self, name, value):
+        """A run-path tuning knob by name (rg_sim_set_option; include/recogym_hip.h lists them)."""
+        _abi.check(self.lib.rg_sim_set_option(self._h, name.encode(), int(value)), f'rg_sim_set_option({name})')
+
+    def get_option(self, name):
+        v = C.c_int64(0)
+        _abi.check(self.lib.rg_sim_get_option(self._h, name.encode(), C.byref(v)), f'rg_sim_get_option({name})')
+        return int(v.value)
+
     def reset_users(self, first_user_id=0, n=None, organic_only_below=0):
         n = self.n_users if n is None else int(n)
         self.first_user_id = int(first_user_id)

@@ -88,3 +88,29 @@ def test_no_cpu_fallback(lib):
     assert lib.rg_sim_set_tables(h, C.c_void_p(base), C.c_void_p(base), C.c_void_p(base),
                                  C.c_void_p(base), None) == -2           # RG_ENODEV
     lib.rg_sim_destroy(h)
+
+
+def test_run_options_are_set_by_name_not_by_the_environment_at_run_time(lib, monkeypatch):
+    """rg_sim_create takes the run-path knobs' initial values from the RECOGYM_* environment once; afterwards
+    rg_sim_set_option / rg_sim_get_option are the way to them (host-only calls: no device needed)."""
+    monkeypatch.setenv('RECOGYM_EXACT_MIX', '6')
+    monkeypatch.setenv('RECOGYM_WALK_HANDOVER', '48')
+    cfg = make_rg_config(Configuration({**env_1_args, 'random_seed': 1, 'sigma_omega': 0.0}), 1)
+    need = lib.rg_sim_workspace_bytes(C.byref(cfg), 16)
+    buf = (C.c_char * (need + 256))()
+    base = (C.addressof(buf) + 255) // 256 * 256
+    h = C.c_void_p()
+    assert lib.rg_sim_create(C.byref(h), C.byref(cfg), 16, C.c_void_p(base), need) == 0
+    v = C.c_int64(0)
+    assert lib.rg_sim_get_option(h, b'exact_mix', C.byref(v)) == 0 and v.value == 6
+    assert lib.rg_sim_get_option(h, b'walk_handover', C.byref(v)) == 0 and v.value == 48
+    monkeypatch.setenv('RECOGYM_EXACT_MIX', '3')                       # too late: the handle has its options
+    assert lib.rg_sim_get_option(h, b'exact_mix', C.byref(v)) == 0 and v.value == 6
+    assert lib.rg_sim_set_option(h, b'exact_mix', 4) == 0
+    assert lib.rg_sim_get_option(h, b'exact_mix', C.byref(v)) == 0 and v.value == 4
+    assert lib.rg_sim_set_option(h, b'pipe_groups', 4) == 0 and lib.rg_sim_set_option(h, b'walk_bias', 6) == 0
+    assert lib.rg_sim_get_option(h, b'walk_bias', C.byref(v)) == 0 and v.value == 6
+    assert lib.rg_sim_set_option(h, b'exact_mix', 9) == -1 and b'exact_mix' in lib.rg_last_error()
+    assert lib.rg_sim_set_option(h, b'pipe_occ1', 0) == -1
+    assert lib.rg_sim_set_option(h, b'no_such_option', 1) == -1 and b'no_such_option' in lib.rg_last_error()
+    lib.rg_sim_destroy(h)
