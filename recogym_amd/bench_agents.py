@@ -7,7 +7,12 @@ counters leave the GPU; ranks (if torch.distributed is initialised) simulate dis
 ranges and all-reduce {clicks, impressions}.  Training keeps the reference's per-user protocol
 (agent.train on every observation) and is skipped for agents that have nothing to learn.
 """
+import hashlib
+import json
+import os
+import pickle
 from copy import deepcopy
+from pathlib import Path
 
 from scipy.stats.distributions import beta
 
@@ -67,6 +72,63 @@ def _train(env, agent, num_offline_users, num_organic_offline_users, first_user_
         agent.train(old_obs, action, reward, True)
 
 
+# the reference's offline-log cache (bench_agents.py:17-63): one pickle of generate_logs' DataFrame per (env config, users)
+CACHE_DIR = os.path.join(os.path.join(str(Path.home()), '.reco-gym'), 'cache')
+
+
+def _cache_file_name(env, num_organic_offline_users, num_offline_users):
+    """The reference's key: a hash over the env configuration's fields and the two user counts (the epoch is not part of it
+    there either: with the cache on, every epoch trains on the same log)."""
+    c = env.config
+    fields = ('K', 'change_omega_for_bandits', 'normalize_beta', 'num_clusters', 'num_products', 'num_users', 'number_of_flips',
+              'phi_var', 'prob_bandit_to_organic', 'prob_leave_bandit', 'prob_leave_organic', 'prob_organic_to_bandit',
+              'random_seed', 'sigma_mu_organic', 'sigma_omega', 'sigma_omega_initial', 'with_ps_all')
+    key = (tuple([str(type(getattr(c, 'agent', None)))] + [getattr(c, f, None) for f in fields]),
+           num_organic_offline_users, num_offline_users)
+    return f'{hashlib.sha1(json.dumps(key, default=str).encode()).hexdigest()}.pkl'
+
+
+def _cached_data(env, num_organic_offline_users, num_offline_users):
+    cache_dir = os.environ.get('RECOGYM_CACHE_DIR', CACHE_DIR)
+    os.makedirs(cache_dir, exist_ok=True)
+    path = os.path.join(cache_dir, _cache_file_name(env, num_organic_offline_users, num_offline_users))
+    if os.path.exists(path):
+        with open(path, 'rb') as fh:
+            return pickle.load(fh, fix_imports=False)
+    data = env.generate_logs(num_offline_users=num_offline_users, num_organic_offline_users=num_organic_offline_users)
+    with open(path, 'wb') as fh:
+        pickle.dump(data, fh, protocol=pickle.HIGHEST_PROTOCOL, fix_imports=False)
+    return data
+
+
+def _train_from_dataframe(agent, data):
+    """agent.train over a cached log, the way the offline protocol would have called it live: per user, every bandit row with
+    the organic session that preceded it; the user's last row closes the episode (done = True), an organic-only user is one
+    call without an action (bench_agents.py:90-190)."""
+    import numpy as np
+    from .envs.context import DefaultContext
+    from .envs.observation import Observation
+    from .envs.session import OrganicSessions
+    t, u, z = data['t'].to_numpy(), data['u'].to_numpy(dtype=np.int64), (data['z'] == 'bandit').to_numpy()
+    v, a, c = data['v'].to_numpy(dtype=float, na_value=np.nan), data['a'].to_numpy(dtype=float, na_value=np.nan), data['c'].to_numpy(dtype=float)
+    ps = data['ps'].to_numpy(dtype=float)
+    ps_a = data['ps-a'].to_list() if 'ps-a' in data else [()] * len(data)
+    n = len(data)
+    last_of_user = np.r_[u[1:] != u[:-1], True] if n else np.zeros(0, dtype=bool)
+    sessions = OrganicSessions()
+    for i in range(n):
+        ctx = DefaultContext(t[i], int(u[i]))
+        if not z[i]:
+            sessions.next(ctx, int(v[i]))
+            if last_of_user[i]:                       # an organic-only (warm-up) user
+                agent.train(Observation(ctx, sessions), None, None, True)
+                sessions = OrganicSessions()
+            continue
+        action = {'t': t[i], 'u': int(u[i]), 'a': int(a[i]), 'ps': float(ps[i]), 'ps-a': ps_a[i] if ps_a[i] is not None else ()}
+        agent.train(Observation(ctx, sessions), action, int(c[i]), bool(last_of_user[i]))
+        sessions = OrganicSessions()
+
+
 def test_agent(env, agent, num_offline_users=1000, num_online_users=100,
                num_organic_offline_users=0, num_epochs=1, epoch_with_random_reset=False,
                with_cache=False):
@@ -76,12 +138,8 @@ def test_agent(env, agent, num_offline_users=1000, num_online_users=100,
     # [base, base + organic + offline) for training and the next `num_online_users` ids for evaluation; without
     # epoch_with_random_reset the next epoch starts where this one ended (with it, the epoch re-keys the draws
     # and ids restart at 0, as the reference's reset_random_seed(epoch) restarts its stream).
-    if with_cache:
-        # the reference's with_cache pickles the offline log under the working directory and re-reads it on the next call
-        # (bench_agents.py:50-63): out of scope here — the log is regenerated on the device every time
-        import warnings
-        warnings.warn('test_agent(with_cache=True): the offline-log pickle cache is not implemented; the training log is '
-                      'regenerated on the device (same rows for the same seed)', RuntimeWarning, stacklevel=2)
+    # with_cache (bench_agents.py:50-63,90-166): the offline log is generate_logs' DataFrame, pickled under ~/.reco-gym/cache
+    # (RECOGYM_CACHE_DIR overrides) by a hash of the env configuration and the user counts, and the agent is trained from it
     successes = failures = 0
     per_epoch = num_organic_offline_users + num_offline_users + num_online_users
     for epoch in range(num_epochs):
@@ -95,7 +153,13 @@ def test_agent(env, agent, num_offline_users=1000, num_online_users=100,
             eval_env.reset_random_seed(epoch)
         else:
             train_env = eval_env = env
-        if hasattr(new_agent, 'train_from_log') and getattr(train_env, 'agent', None) is None:
+        if with_cache and (_learns(new_agent) or hasattr(new_agent, 'train_from_log')):
+            data = _cached_data(train_env, num_organic_offline_users, num_offline_users)
+            if hasattr(new_agent, 'train_from_log'):
+                new_agent.train_from_log(data, num_organic_offline_users)
+            else:
+                _train_from_dataframe(new_agent, data)
+        elif hasattr(new_agent, 'train_from_log') and getattr(train_env, 'agent', None) is None:
             # the offline protocol shows the agent exactly the rows of generate_logs(offline users) under the
             # env's own uniform policy (bench_agents.py:168-190): produce that log on the device in one go
             cnt, sim = train_env.simulate(num_offline_users, None, num_organic_offline_users, first_user_id=base)

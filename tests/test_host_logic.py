@@ -397,3 +397,51 @@ def test_blocked_generate_beta_pairing_equals_the_reference():
     finally:
         sp.FLIP_BLOCKED_ABOVE = old
     assert all(np.array_equal(x, y) for x, y in zip(full, blocked))
+
+
+def test_test_agent_with_cache_trains_from_the_pickled_offline_log(tmp_path, monkeypatch):
+    """test_agent(with_cache=True) (reference: bench_agents.py:17-63,90-166): the offline log is generate_logs' DataFrame pickled
+    by a hash of the env configuration and the user counts; the agent is trained from it — the first call generates and writes
+    it, the second reads it back; agent.train sees every bandit row with the organic session before it, the user's last row
+    closing the episode, an organic-only user as one call without an action."""
+    from recogym_amd import bench_agents
+    from recogym_amd.envs.reco_env_v1 import rows_to_dataframe
+    monkeypatch.setenv('RECOGYM_CACHE_DIR', str(tmp_path))
+    cfg = Configuration({**env_1_args, 'random_seed': 13, 'num_products': 12, 'K': 4})
+    calls = dict(generate=0)
+
+    class Env:                      # test double for RecoEnv1 on a CPU-only box: same contract, oracle arithmetic
+        config = cfg
+        agent = None
+        def __deepcopy__(self, memo): return self
+        def generate_logs(self, num_offline_users, agent=None, num_organic_offline_users=0, first_user_id=0):
+            calls['generate'] += 1
+            rows = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX).generate_logs(num_offline_users, num_organic_offline_users, first_user_id)
+            return rows_to_dataframe(rows, cfg.num_products)
+        def simulate(self, num_users, agent=None, num_organic_users=0, first_user_id=0, log=True, device=None):
+            env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **agent.device_policy())
+            env.generate_logs(num_users, first_user_id=first_user_id)
+            c = env.counters()
+            class S:
+                device = None
+                def close(self): pass
+            return dict(clicks=c['clicks'], bandit=c['bandit'], phantom=c['phantom'], organic=c['organic']), S()
+
+    seen = []
+
+    class Learner(RandomAgent):
+        def train(self, observation, action, reward, done=False):
+            seen.append((len(observation.sessions()), None if action is None else action['a'], reward, done))
+
+    agent = Learner(Configuration({'num_products': 12, 'random_seed': 4, 'with_ps_all': False}))
+    q1 = bench_agents.test_agent(Env(), agent, 30, 50, num_organic_offline_users=5, with_cache=True)
+    assert calls['generate'] == 1 and len(os.listdir(tmp_path)) == 1
+    first = list(seen)
+    seen.clear()
+    q2 = bench_agents.test_agent(Env(), agent, 30, 50, num_organic_offline_users=5, with_cache=True)
+    assert calls['generate'] == 1 and q1 == q2 and seen == first           # read back, same training calls
+    want = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX).generate_logs(30, 5)
+    assert len(first) == int((want['z'] == 1).sum()) + 5                   # every bandit row (phantom included) + 5 warm-up users
+    assert sum(1 for s in first if s[3]) == 35                             # one closing call per user
+    assert [s for s in first if s[1] is None] == [s for s in first[:5]] and all(s[0] > 0 for s in first[:5])
+    assert bench_agents._cache_file_name(Env(), 5, 30) != bench_agents._cache_file_name(Env(), 5, 31)
