@@ -1,5 +1,9 @@
-"""Times the C port (oracle/recogym_oracle.c) on a bounded sample of a configuration — TEST INFRASTRUCTURE (imports the oracle);
-tools/time_reference.py calls it so that the NumPy reference and the port are timed on the same box and the same samples."""
+"""Times the C port (oracle/recogym_oracle.c) on the samples tools/time_reference.py timed the NumPy reference on — TEST
+INFRASTRUCTURE (imports the oracle) — and adds `port_same_box` + the port / NumPy ratios to profiles/r4/numpy_reference_cpu.json, so
+that both were timed on the same box.
+
+    python tools/time_reference.py && python tests/port_timing.py"""
+import json
 import os
 import sys
 import threading
@@ -41,3 +45,19 @@ def port_case(env_over, kind, users, threads):
     for t in th:
         t.join()
     return sum(res), time.perf_counter() - t0
+
+
+if __name__ == '__main__':
+    path = os.path.join(ROOT, 'profiles', 'r4', 'numpy_reference_cpu.json')
+    out = json.load(open(path))
+    for name, c in out['cases'].items():
+        n = c['processes']
+        pe1, pw1 = port_case(c['env'], c['agent'], c['users'], 1)
+        pe8, pw8 = port_case(c['env'], c['agent'], c['users'], n)
+        c['port_same_box'] = dict(what='oracle/recogym_oracle.c (float64 C port, Philox draws) on the same sample in this container',
+                                  one_thread_events_per_s=pe1 / pw1, one_thread_events=pe1, one_thread_seconds=pw1,
+                                  threads=n, all_thread_events_per_s=pe8 / pw8, all_thread_wall_seconds=pw8,
+                                  port_over_numpy_one_core=(pe1 / pw1) / c['one_core_events_per_s'],
+                                  port_over_numpy_all_core=(pe8 / pw8) / c['all_core_events_per_s'])
+        print(name, json.dumps(c['port_same_box']))
+    json.dump(out, open(path, 'w'), indent=1)

@@ -5,11 +5,12 @@ baseline timing").  /root/reference exists only in the build container, not on t
 committed as profiles/r4/numpy_reference_cpu.json and bench.py quotes it (with this provenance) beside the
 C-port baseline it times live.  Sample sizes are SURVEY.md §8(d)'s: C1 all 1 000 users, C2 2 000, C3 200, C4's shape with P
 capped at the reference's np.int16 ceiling on 50 users; one process, and 8 processes on disjoint seeds.  The C port
-(oracle/recogym_oracle.c, float64) is timed IN THE SAME CONTAINER on the same samples (1 and 8 threads), so that the
-port / NumPy ratio is a same-box figure: bench.py's live port timing on the GPU box's host cores divided by that ratio is
-what the NumPy reference would do there.
+(oracle/recogym_oracle.c, float64) is timed IN THE SAME CONTAINER on the same samples (1 and 8 threads) by
+`python tests/port_timing.py` right after this script (the oracle is test infrastructure: only code under tests/ runs it), which
+adds `port_same_box` and the port / NumPy ratios to the same JSON: bench.py's live port timing on the GPU box's host cores divided
+by that ratio is what the NumPy reference would do there.
 
-    python tools/time_reference.py            # ~5 minutes
+    python tools/time_reference.py && python tests/port_timing.py            # ~5 minutes
 """
 import json
 import multiprocessing as mp
@@ -51,13 +52,6 @@ def _worker(a):
     return run_case(*a)
 
 
-def port_case(name, threads):
-    """The C port on the same sample (tests/port_timing.py: the oracle is test infrastructure and is imported from tests/ only)."""
-    import port_timing
-    over, kind, users = CASES[name]
-    return port_timing.port_case(over, kind, users, threads)
-
-
 def main():
     out = dict(host=platform.node(), cpu_count=os.cpu_count(), python=platform.python_version(),
                numba='absent (sig/ff run as NumPy; affects reco_env_v1.py:32-41 only)',
@@ -76,19 +70,11 @@ def main():
                                   one_core_events_per_s=ev / dt, one_core_events=ev, one_core_seconds=dt,
                                   processes=n, all_core_events_per_s=sum(r[0] for r in res) / wall,
                                   all_core_wall_seconds=wall)
-        pe1, pw1 = port_case(name, 1)
-        pe8, pw8 = port_case(name, n)
-        c = out['cases'][name]
-        c['port_same_box'] = dict(what='oracle/recogym_oracle.c (float64 C port, Philox draws) on the same sample in this container',
-                                  one_thread_events_per_s=pe1 / pw1, one_thread_events=pe1, one_thread_seconds=pw1,
-                                  threads=n, all_thread_events_per_s=pe8 / pw8, all_thread_wall_seconds=pw8,
-                                  port_over_numpy_one_core=(pe1 / pw1) / c['one_core_events_per_s'],
-                                  port_over_numpy_all_core=(pe8 / pw8) / c['all_core_events_per_s'])
         print(name, json.dumps(out['cases'][name]))
     path = os.path.join(ROOT, 'profiles', 'r4', 'numpy_reference_cpu.json')
     os.makedirs(os.path.dirname(path), exist_ok=True)
     json.dump(out, open(path, 'w'), indent=1)
-    print('wrote', path)
+    print('wrote', path, '- now run: python tests/port_timing.py')
 
 
 if __name__ == '__main__':
