@@ -219,8 +219,9 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
                            later_rounds_ms=round(prof['walk2_ms'], 2), units=int(events), unit_name='events',
                            bytes_per_unit=b_survey,
                            achieved=round(gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(gbps / HBM_PEAK_GBPS, 4),
-                           note='latency bound on per-user state that lives in L2 and the Infinity Cache (DESIGN.md 4), not on '
-                                'HBM bandwidth')
+                           note='not bound by HBM bandwidth: the per-user state lives in L2 and the Infinity Cache, and the kernel is '
+                                'bound by its instruction stream (24 vector + 12 scalar wave-instructions per event: ~40 of its '
+                                '67 ms are vector-ALU issue, profiles/r4/pmc_c3_sq_counters.csv) and its dependent loads (DESIGN.md 4)')
         if prof['draw_search_ms'] > 0:
             by = 512 + 8 * K
             out['cache_finalize'] = dict(kernel='k_cache_finalize', bound='hbm', ms=round(prof['draw_search_ms'], 2), units=int(users),
