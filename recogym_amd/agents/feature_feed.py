@@ -12,8 +12,8 @@ pass of array operations: organic rows are grouped by (user, product); a group c
 CSR entry to every bandit row of its user that comes after its first view, and the entry's value
 is the number of the group's views before that row (one searchsorted on composite keys).
 
-Only the reference's default feature set is covered (no `weight_history_function`, which this
-package rejects anyway — see envs/reco_env_v1.py).
+With a `weight_history_function` the features are time-weighted float sums, not counts: that (rare) form takes the exact
+per-row construction of agents/views_history.train_data_weighted instead of the vectorised count path.
 """
 import numpy as np
 from scipy import sparse
@@ -36,13 +36,21 @@ def _columns_of(log):
             log['ps'].to_numpy(dtype=np.float64, na_value=np.nan))
 
 
-def train_data_from_log(log, num_products, is_sparse=True):
+def _times_of(log):
+    return np.asarray(log['t']) if isinstance(log, dict) else log['t'].to_numpy()
+
+
+def train_data_from_log(log, num_products, is_sparse=True, weight_history_function=None):
     """-> (features, actions, deltas, pss) as AbstractFeatureProvider.train_data returns them:
     features  CSR (n_bandit_rows, P) of int16 view counts, sorted indices (dense float64 array
               when is_sparse is False), rows in log order (users ascending, t ascending);
     actions   int16; deltas int16 (the click column); pss float64.
     `log` must be in the reference's row order (every user's rows contiguous, t ascending)."""
     u, is_b, v, a, c, ps = _columns_of(log)
+    if weight_history_function is not None:             # time-weighted views (agents/abstract.py:216-263): the exact per-row form
+        from .views_history import train_data_weighted
+        return train_data_weighted((_times_of(log), u, is_b, v, a, np.nan_to_num(c), ps), int(num_products),
+                                   weight_history_function, is_sparse)
     n = len(u)
     P = int(num_products)
     pos = np.arange(n, dtype=np.int64)

@@ -34,6 +34,12 @@ class LogregFrozenAgent(Agent):
         self.coef_t = np.ascontiguousarray(coef.T)          # (P, n_classes): what the ABI takes
         self.intercept = np.ascontiguousarray(intercept)
         self.classes = np.ascontiguousarray(classes)
+        # weight_history_function (ViewsFeaturesProvider with history, agents/abstract.py:343-382): time-weighted float features
+        # instead of view counts — host path only
+        self.history = None
+        if getattr(config, 'weight_history_function', None) is not None:
+            from .views_history import ViewsHistory
+            self.history = ViewsHistory(config.num_products, config.weight_history_function, is_sparse=True)
         self.reset()
 
     @classmethod
@@ -41,20 +47,31 @@ class LogregFrozenAgent(Agent):
         return cls(config, logreg.coef_, logreg.intercept_, logreg.classes_)
 
     def device_policy(self):
-        if getattr(self.config, 'with_ps_all', False) or self.select_randomly:
+        if getattr(self.config, 'with_ps_all', False) or self.select_randomly or self.history is not None:
             return None
         return dict(policy=_abi.RG_POLICY_LOGREG_FROZEN, policy_seed=0, ouc=None,
                     logreg=dict(coef_t=self.coef_t, intercept=self.intercept, classes=self.classes))
 
     def reset(self):
         self.views = np.zeros(self.config.num_products, dtype=np.int64)
+        if getattr(self, 'history', None) is not None:
+            self.history.reset()
 
     def act(self, observation, reward, done):
         for session in observation.sessions():
             self.views[int(session['v'])] += 1
         score = np.zeros(len(self.classes))
-        for p in np.flatnonzero(self.views):                 # ascending, multiply then add
-            score = score + np.float64(self.views[p]) * self.coef_t[p]
+        if self.history is not None:
+            # the weighted features as the reference's provider builds them (float32 sums per viewed product), through the same
+            # CSR x dense product order: stored entries ascending, each widened to float64, multiply then add
+            self.history.observe(observation)
+            f = self.history.features(observation.context().time()).tocsr()
+            f.sort_indices()
+            for p, w in zip(f.indices, f.data):
+                score = score + np.float64(w) * self.coef_t[p]
+        else:
+            for p in np.flatnonzero(self.views):             # ascending, multiply then add
+                score = score + np.float64(self.views[p]) * self.coef_t[p]
         score = score + self.intercept
         if self.select_randomly:
             # sklearn's multinomial predict_proba: softmax(decision_function) (sklearn.utils.extmath.softmax)

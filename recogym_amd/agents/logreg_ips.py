@@ -39,7 +39,7 @@ class LogregMulticlassIpsAgent(Agent):
 
     def __init__(self, config=Configuration(logreg_multiclass_ips_args)):
         super().__init__(config)
-        self._rows = {k: [] for k in ('u', 'is_bandit', 'v', 'a', 'c', 'ps')}
+        self._rows = {k: [] for k in ('t', 'u', 'is_bandit', 'v', 'a', 'c', 'ps')}
         self._log = None
         self.logreg = None
         self.frozen = None
@@ -49,10 +49,10 @@ class LogregMulticlassIpsAgent(Agent):
         """ModelBuilder.train (agents/abstract.py:55-83): the organic rows of the observation, then the action."""
         r = self._rows
         for s in observation.sessions():
-            r['u'].append(s['u']); r['is_bandit'].append(False); r['v'].append(s['v'])
+            r['t'].append(s['t']); r['u'].append(s['u']); r['is_bandit'].append(False); r['v'].append(s['v'])
             r['a'].append(0); r['c'].append(np.nan); r['ps'].append(np.nan)
         if action:
-            r['u'].append(action['u']); r['is_bandit'].append(True); r['v'].append(0)
+            r['t'].append(action['t']); r['u'].append(action['u']); r['is_bandit'].append(True); r['v'].append(0)
             r['a'].append(action['a']); r['c'].append(reward); r['ps'].append(action['ps'])
 
     def train_from_log(self, log, num_organic_users=0):
@@ -60,14 +60,16 @@ class LogregMulticlassIpsAgent(Agent):
         self._log = log
 
     def _training_set(self):
+        wf = getattr(self.config, 'weight_history_function', None)     # time-weighted views (agents/abstract.py:216-263)
         if self._log is not None:
-            return train_data_from_log(self._log, self.config.num_products)
+            return train_data_from_log(self._log, self.config.num_products, weight_history_function=wf)
         r = self._rows
-        cols = dict(u=np.asarray(r['u'], dtype=np.int64).astype(np.uint32).view(np.int32),
+        cols = dict(t=np.asarray(r['t'], dtype=np.float64),
+                    u=np.asarray(r['u'], dtype=np.int64).astype(np.uint32).view(np.int32),
                     is_bandit=np.asarray(r['is_bandit'], dtype=bool),
                     v=np.asarray(r['v'], dtype=np.int32), a=np.asarray(r['a'], dtype=np.int32),
                     c=np.asarray(r['c'], dtype=np.float32), ps=np.asarray(r['ps'], dtype=np.float64))
-        return train_data_from_log(cols, self.config.num_products)
+        return train_data_from_log(cols, self.config.num_products, weight_history_function=wf)
 
     def build(self):
         """logreg_ips.py:89-99."""

@@ -23,8 +23,8 @@ organic_user_count_args = {
 
 
 def _icdf(p, u):
-    """RandomState.choice(P, p=p) given its uniform."""
-    cdf = p.cumsum()
+    """RandomState.choice(P, p=p) given its uniform (choice works on a float64 copy of p)."""
+    cdf = np.asarray(p, dtype=np.float64).cumsum()
     cdf /= cdf[-1]
     return int(cdf.searchsorted(u, side='right'))
 
@@ -32,12 +32,18 @@ def _icdf(p, u):
 class OrganicUserEventCounterAgent(Agent):
     def __init__(self, config=Configuration(organic_user_count_args)):
         super().__init__(config)
+        # weight_history_function (organic_user_count.py:19, agents/abstract.py:343-382): time-weighted views instead of
+        # counts — float features per event: the per-user host path (no device policy)
+        self.history = None
         if getattr(config, 'weight_history_function', None) is not None:
-            raise NotImplementedError('weight_history_function is not supported (SURVEY.md §8f)')
+            from .views_history import ViewsHistory
+            self.history = ViewsHistory(config.num_products, config.weight_history_function)
         self.views = np.zeros(config.num_products, dtype=np.int64)
 
     def device_policy(self):
         c = self.config
+        if self.history is not None:
+            return None
         pol = dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=c.random_seed,
                    ouc=dict(select_randomly=c.select_randomly, epsilon=c.epsilon,
                             exploit_explore=c.exploit_explore,
@@ -99,6 +105,8 @@ class OrganicUserEventCounterAgent(Agent):
 
     def reset(self):
         self.views[:] = 0
+        if self.history is not None:
+            self.history.reset()
 
     def act(self, observation, reward, done):
         c = self.config
@@ -107,12 +115,18 @@ class OrganicUserEventCounterAgent(Agent):
         ctx = observation.context()
         _, u0, u1 = rng.policy_uniforms(c.random_seed, *(ctx.draw_key() if hasattr(ctx, 'draw_key') else (ctx.user(), ctx.time())))
         eps = c.epsilon
-        f = self.views.astype(np.float64)
+        if self.history is not None:
+            # float32 weighted views, exactly as the reference's feature provider builds them; the arithmetic below then runs
+            # in float32 where the reference's does (features / sum, eps * p[a])
+            self.history.observe(observation)
+            f = self.history.features(ctx.time()).flatten()
+        else:
+            f = self.views.astype(np.float64)
         explore = False
         if c.exploit_explore:
             explore = not (eps / (eps + (1 - eps)) <= u0)
             if explore:
-                f = (self.views == 0).astype(np.float64)
+                f = (f == 0).astype(f.dtype)
             p = f / np.sum(f)
         else:
             f = eps + f

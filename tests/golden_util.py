@@ -15,6 +15,9 @@ POLICY_OF = {None: _abi.RG_POLICY_UNIFORM_ENV, 'random': _abi.RG_POLICY_RANDOM_A
 
 OUC_DEFAULTS = dict(select_randomly=True, epsilon=0.0, exploit_explore=True, reverse_pop=False)
 
+# weight_history_function by name (a fixture's meta is JSON: the function itself cannot travel)
+WEIGHT_FUNCS = {'exp_0.2': lambda dt: np.exp(-0.2 * dt), 'inverse': lambda dt: 1.0 / (1.0 + dt)}
+
 
 def fixtures(prefix):
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith(prefix) and f.endswith('.npz'))

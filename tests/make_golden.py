@@ -39,8 +39,12 @@ def make_agent(kind, agent_args):
         return RandomAgent(Configuration({**random_args, **agent_args}))
     if kind == 'ouc':
         from recogym.agents import OrganicUserEventCounterAgent, organic_user_count_args
+        args = dict(agent_args)
+        if args.get('weight_history'):       # by name: tests/golden_util.WEIGHT_FUNCS
+            import golden_util as gu
+            args['weight_history_function'] = gu.WEIGHT_FUNCS[args.pop('weight_history')]
         return OrganicUserEventCounterAgent(
-            Configuration({**organic_user_count_args, **agent_args}))
+            Configuration({**organic_user_count_args, **args}))
     if kind == 'bmf':
         import torch
         from recogym.agents import BanditMFSquare, bandit_mf_square_args
@@ -181,7 +185,7 @@ def notebook_goldens():
     assert same7 and same9
 
 
-def run_logreg_case(name, env_over, n_train, n_users, injected=True, select_randomly=False):
+def run_logreg_case(name, env_over, n_train, n_users, injected=True, select_randomly=False, weight_history=None):
     """LogregMulticlassIpsAgent of the UNMODIFIED reference (agents/logreg_ips.py): trained by the
     reference's own build() (train_data + sklearn fit) on a uniform-policy log of n_train users that the
     reference generated, then run through generate_logs with the counter RNG injected into the env (the
@@ -192,9 +196,13 @@ def run_logreg_case(name, env_over, n_train, n_users, injected=True, select_rand
     args = {**BASE, **env_over}
     train_env = rh.make_reference_env({**args, 'random_seed': args['random_seed'] + 1000})
     train_log = train_env.generate_logs(n_train)
+    extra = {}
+    if weight_history:       # ViewsFeaturesProvider / train_data with a weight function (agents/abstract.py:199-263,343-382)
+        import golden_util as gu
+        extra['weight_history_function'] = gu.WEIGHT_FUNCS[weight_history]
     agent = LogregMulticlassIpsAgent(Configuration({**logreg_multiclass_ips_args,
                                                     'num_products': args['num_products'],
-                                                    'random_seed': 7, 'select_randomly': select_randomly}))
+                                                    'random_seed': 7, 'select_randomly': select_randomly, **extra}))
     d = agent.model_builder.data
     for _, r in train_log.iterrows():                       # ModelBuilder.train's bookkeeping, row by row
         bandit = r['z'] == 'bandit'
@@ -210,12 +218,23 @@ def run_logreg_case(name, env_over, n_train, n_users, injected=True, select_rand
     df = env.generate_logs(n_users, agent)                  # first act() builds the model
     lr = agent.model.logreg
     arrays = rh.log_to_arrays(df)
+    train_extra = {}
+    if weight_history:       # the training log and the training set the reference built from it (weighted features)
+        tl = rh.log_to_arrays(train_log)
+        feats, t_actions, t_deltas, t_pss = agent.model_builder.train_data()
+        from scipy import sparse as _sp
+        dense_dtype = None if _sp.issparse(feats) else str(feats.dtype)          # (the logreg builder asks for the dense form)
+        feats = _sp.csr_matrix(feats); feats.sort_indices()
+        train_extra = dict(trainlog_t=tl['t'].astype(np.int32), trainlog_u=tl['u'].astype(np.int32), trainlog_z=tl['z'].astype(np.int8),
+                           trainlog_v=tl['v'].astype(np.int32), trainlog_a=tl['a'].astype(np.int32), trainlog_c=tl['c'].astype(np.int8),
+                           trainlog_ps=tl['ps'], train_data=feats.data, train_indices=feats.indices.astype(np.int32),
+                           train_indptr=feats.indptr.astype(np.int64), train_actions=t_actions, train_deltas=t_deltas, train_pss=t_pss)
     arrays['logreg_coef'] = np.asarray(lr.coef_, dtype=np.float64)
     arrays['logreg_intercept'] = np.asarray(lr.intercept_, dtype=np.float64)
     arrays['logreg_classes'] = np.asarray(lr.classes_, dtype=np.int64)
     meta = dict(env_args=args, n_users=n_users, n_organic=0, agent='logreg',
                 agent_args=dict(n_train=n_train, clicks_in_training=int(np.nansum(train_log['c'].to_numpy(dtype=float))),
-                                select_randomly=bool(select_randomly), random_seed=7),
+                                select_randomly=bool(select_randomly), random_seed=7, weight_history=weight_history),
                 rng='philox' if injected else 'mt')
     small = {}
     for k, v in arrays.items():
@@ -226,7 +245,7 @@ def run_logreg_case(name, env_over, n_train, n_users, injected=True, select_rand
         else:
             small[k] = v.astype(np.int32)
     path = os.path.join(GOLDEN, name + '.npz')
-    np.savez_compressed(path, meta=np.array(json.dumps(meta)), **small)
+    np.savez_compressed(path, meta=np.array(json.dumps(meta)), **small, **train_extra)
     print(f'{name}: {len(arrays["t"])} rows, {len(lr.classes_)} classes, actions used '
           f'{len(np.unique(arrays["a"][arrays["z"] == 1]))} -> {os.path.getsize(path) / 1024:.0f} KiB')
 
@@ -396,6 +415,13 @@ def main():
         run_case('philox_ouc_p10000', {**S, 'num_products': 10000, 'K': 20, 'sigma_omega': 0.0}, 40,
                  agent_kind='ouc', agent_args=dict(random_seed=11), injected=True)
         normal_time_goldens()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'weight_history':  # ViewsFeaturesProvider's time-weighted history (agents/abstract.py:343-382)
+        run_case('hostpath_ouc_weight_history', {'random_seed': 42, 'num_products': 30, 'K': 8}, 120, agent_kind='ouc',
+                 agent_args=dict(random_seed=77, weight_history='exp_0.2'), injected=True)
+        run_logreg_case('hostpath_logreg_weight_history', {'random_seed': 42, 'num_products': 20, 'K': 6}, 150, 60, weight_history='exp_0.2')
+        run_case('hostpath_ouc_weight_history_eps', {'random_seed': 43, 'num_products': 30, 'K': 8}, 80, agent_kind='ouc',
+                 agent_args=dict(random_seed=78, weight_history='inverse', epsilon=0.2), injected=True)
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'flips':           # generate_beta's pairing at P = 2 000
         flips_index_golden()
