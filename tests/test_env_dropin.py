@@ -457,3 +457,24 @@ def test_logreg_select_randomly_samples_like_the_reference():
     for k in ('t', 'u', 'z', 'v', 'a', 'c'):
         assert np.array_equal(cols[k], want[k][keep].astype(np.int64)), k
     np.testing.assert_allclose(cols['ps'], want['ps'][keep], rtol=1e-12, equal_nan=True)
+
+
+@pytest.mark.parametrize('name', ['hostpath_ouc_weight_history', 'hostpath_ouc_weight_history_eps'])
+def test_weight_history_agent_through_the_per_user_gym_path(name):
+    """An OrganicUserEventCounterAgent with a `weight_history_function` (time-weighted views, agents/abstract.py:343-382) has no
+    device policy: env.generate_logs walks it one user at a time (rg_sim_step_user underneath, the agent's act on the host).
+    The log equals the unmodified reference's (fixture; counter RNG injected) on every column, `ps` bit for bit."""
+    from recogym_amd.agents import organic_user_count_args
+    meta, want = gu.load(name)
+    aa = meta['agent_args']
+    cfg = Configuration({**organic_user_count_args, 'num_products': meta['env_args']['num_products'], 'random_seed': aa['random_seed'],
+                         'epsilon': aa.get('epsilon', 0.0), 'weight_history_function': gu.WEIGHT_FUNCS[aa['weight_history']]})
+    agent = OrganicUserEventCounterAgent(cfg)
+    assert agent.device_policy() is None
+    n = 20
+    df = make_env(meta['env_args']).generate_logs(n, agent)
+    keep = want['u'] < n
+    cols = frame_to_cols(df)
+    for k in ('t', 'u', 'z', 'v', 'a', 'c'):
+        assert np.array_equal(cols[k], want[k][keep].astype(np.int64)), k
+    np.testing.assert_array_equal(cols['ps'], want['ps'][keep])
