@@ -10,7 +10,7 @@
 //                     certified against float64 (search_and_emit); k_draw_bf16 = its
 //                     one-accumulator form, k_draw_mfma = fp32 MFMA (K classes without a 16-bit
 //                     instantiation), k_draw_search = the search of the product-sliced form
-//   k_exact_sums_m / k_exact_pick (k_exact_sums_u: its vector-ALU form; k_exact_sums: K > 64)
+//   k_exact_sums_m / k_exact_pick (k_exact_sums_h: matrix and vector-ALU forms side by side; k_exact_sums: K > 64)
 //                     the same draw in float64 for the draws the fast path cannot certify (dot products on the
 //                     float64 matrix cores)
 //   k_cache_finalize, k_walk2 / k_walk / k_walk_solo (sigma_omega == 0)
@@ -159,7 +159,6 @@ struct DevSim {
     float* cache_chunk;       // [n_cap + 1][n_chunks] exp-sum of every 32-product chunk
     float* beta32;            // [P][KB4] fp32 copy of beta (rows padded with zeros to KB4 = K rounded up to 4): k_walk's click fast path
     uint32_t KB4;
-    float* cache_sub;         // [n_cap + 1][n_chunks][4] exp-sums of the four 8-product groups of every chunk (k_walk's recompute unit), or null
     uint8_t* cache_resc;      // [n_cap + 1] re-references of the sweep (certificate budget)
     // what every later draw of a user starts from, one contiguous row per user (k_cache_finalize builds it from the
     // records above right after step 0): [0,32) super-chunk sums scaled to the common reference | 32: that reference,
@@ -255,7 +254,6 @@ using namespace rgk;
 // tests' way in) and settable through rg_sim_set_option — no getenv on the run path.
 struct RunOpts {
     int exact_tile;          // RECOGYM_EXACT_TILE: the K > 64 tile kernel for every float64 resolve
-    int exact_valu;          // RECOGYM_EXACT (any value): no matrix-form float64 kernels (the vector-ALU kernel)
     int exact_mix;           // RECOGYM_EXACT_MIX: groups of every 8 of the walk's float64 batch in the matrix form (8 = all)
     int resident_grid;       // RECOGYM_RESIDENT_GRID: sweep grid = the resident blocks
     int slices;              // RECOGYM_SLICES: product slices of the lock-step sweep (-1 = by population)
@@ -274,9 +272,8 @@ struct rg_sim {
     uint32_t live_upper;      // upper bound of live users (for grid sizing)
     bool tables_set, users_reset;
     bool repacked;            // slots no longer equal user indices (since the last reset)
-    bool cached_search_old;   // RECOGYM_CACHED=search: the first form of the cached draw (k_draw_search over the cache)
     bool walk;                // rg_sim_run "to the end" walks the run user-major (k_walk) instead of step-major
-    int walk_occ;             // blocks per CU of the walk kernel (RECOGYM_WALK_OCC: 2, 3 or 4)
+    int walk_occ;             // blocks per CU the walk kernel is compiled for (k_walk: 3; k_walk2: 3 at K <= 20, 2 at K <= 32)
     bool walk2;               // the walk is k_walk2 (prefix sums + memo; RECOGYM_WALK=1 keeps k_walk)
     bool walk_solo;           // its last round is k_walk_solo (RECOGYM_WALK_SOLO=0: k_walk2's)
     int n_cus;                // compute units of the device (grid of the persistent walk kernel)
@@ -314,7 +311,6 @@ namespace rgk {
 // kernels of the other parts, as the host code (part 1) gets them
 typedef void (*exact_h_kernel_t)(DevSim, uint32_t, uint32_t);
 typedef void (*exact_m_kernel_t)(DevSim, uint32_t, int, int, uint32_t);
-typedef void (*exact_u_kernel_t)(DevSim, uint32_t, int, int, uint32_t);
 typedef void (*exact_pick_kernel_t)(DevSim, uint32_t, int, uint32_t);
 typedef void (*finalize_kernel_t)(DevSim);
 typedef void (*cached_kernel_t)(DevSim, uint32_t);
@@ -325,7 +321,6 @@ typedef void (*advance_kernel_t)(DevSim, uint32_t, const int32_t*);
 typedef void (*walk_kernel_t)(DevSim, uint32_t, int, uint32_t, uint32_t, uint32_t);
 exact_h_kernel_t exact_h_kernel_for(uint32_t kb);          // part 2
 exact_m_kernel_t exact_m_kernel_for(uint32_t kb);
-exact_u_kernel_t exact_u_kernel_for(uint32_t kb);
 exact_m_kernel_t exact_tile_kernel();                      // k_exact_sums
 exact_h_kernel_t exact_ref_kernel();                       // k_exact_ref
 exact_pick_kernel_t exact_pick_kernel();                   // k_exact_pick
@@ -450,19 +445,6 @@ inline bool cache_wanted(const rg_config& c, const Geom& g) {
 // need it, and the lock-step search of K <= 32 uses it too.
 inline bool gamma32t_wanted(const rg_config& c, const Geom& g) { return g.KH != 0 && (cache_wanted(c, g) || g.KH <= 16); }
 
-// Sums of 8-product groups next to the chunk sums: where the run will be walked user by user (k_walk), the recompute
-// that turns a chunk into a product streams the chunk's Gamma rows through the CU's L1 — the walk's bound — and a
-// group is a quarter of that.  16 bytes per chunk and user, written by the SUB instantiation of the fp16 sweep.
-// OPT-IN (RECOGYM_SUB=1).  Measured (profiles/r2): the walk's L1 requests per event drop 2.3x and its time does not
-// move (C3: 266 -> 267 ms; C2: 17.9 -> 16.1 ms) while the sweep that writes 4x the sums goes 29 -> 45 ms on C3 —
-// the walk is bound by its chains of dependent loads, not by L1 bytes.
-inline bool sub_wanted(const rg_config& c, const Geom& g) {
-    const char* e = getenv("RECOGYM_SUB");
-    const bool walks = c.policy == RG_POLICY_UNIFORM_ENV || c.policy == RG_POLICY_RANDOM_AGENT ||
-                       c.policy == RG_POLICY_ORGANIC_USER_COUNT || c.policy == RG_POLICY_LAST_VIEW_TABLE;
-    return cache_wanted(c, g) && g.F16 == 1 && g.KH <= 16 && walks && !c.time_mode && e && e[0] == '1';
-}
-
 // rows of the float64 chunk-sum scratch (see DevSim::exact_rows)
 inline size_t exact_rows_of(const rg_config& c, const Geom& g, uint64_t n) {
     const char* e = getenv("RECOGYM_DRAW");
@@ -542,10 +524,8 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     float2* cache_rec = w.take<float2>(cache ? (n + 1) * kMaxSC : 1);
     float* cache_chunk = w.take<float>(cache ? (n + 1) * static_cast<size_t>(g.n_chunks) : 1);
     uint8_t* cache_resc = w.take<uint8_t>(cache ? n + 1 : 1);
-    const bool sub = sub_wanted(c, g);
     const size_t KB4 = (K + 3) & ~static_cast<size_t>(3);
     float* beta32 = w.take<float>(cache ? P * KB4 : 4);
-    float* cache_sub = w.take<float>(sub ? (n + 1) * static_cast<size_t>(g.n_chunks) * 4 : 4);
     const uint32_t cache_row_f = (44u + 2u * g.KH + 31u) & ~31u;
     float* cache_row = w.take<float>(cache ? (n + 1) * static_cast<size_t>(cache_row_f) : 1);
     float* walk_hot = w.take<float>(cache ? (n + 1) * 32 : 1);
@@ -573,7 +553,6 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->phantom_ps = phantom_ps; d->utime = utime; d->phantom_time = phantom_time;
         d->drift_list = drift_list; d->drift_sig = drift_sig; d->drift_cnt = drift_cnt;
         d->use_cache = cache ? 1u : 0u; d->cache_rec = cache_rec; d->cache_chunk = cache_chunk; d->cache_resc = cache_resc;
-        d->cache_sub = sub ? cache_sub : nullptr;
         d->beta32 = cache ? beta32 : nullptr; d->KB4 = static_cast<uint32_t>(KB4);
         d->f64_valid = f64_valid; d->exact_cnt_b = exact_cnt_b; d->cache_row = cache_row; d->cache_row_f = cache_row_f;
         d->park_list = park_list; d->park_t = park_t; d->sweep_only = 0;
@@ -1488,114 +1467,6 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums(DevSim d, uint32_t t, int
 }
 #endif
 
-// User-per-lane variant of k_exact_sums for K <= 64 (the one that runs; the tile kernel above
-// remains for larger K).  With a product per lane every FMA needs an omega value broadcast from
-// LDS, and the LDS return path (64 lanes x 16 B per ds_read_b128, shared by the CU's 4 SIMDs)
-// capped that kernel at ~1/5 of the float64 FMA rate.  Here a lane owns a USER: its omega sits
-// in registers, the Gamma row of the product being visited is wave-uniform and arrives through
-// the scalar cache (s_load) as the SGPR operand of v_fma_f64, and the running exp-sum of a
-// lane is sequential in product order — no LDS, no cross-lane traffic, no barriers.
-// Work item = (64 users of the list, one slice of the 64-product chunks); one sum per chunk.
-typedef const __attribute__((address_space(4))) double kdouble;   // constant address space: uniform loads become s_load
-
-// users per lane of k_exact_sums_u: two for K <= 20 (every Gamma row fetched through the scalar cache then feeds two
-// independent chains of K dependent FMAs — the row's load latency was exposed once per product and chain), one beyond
-// (omega alone is 2 x 4 KB registers per user)
-__host__ __device__ constexpr int exact_upl_of(uint32_t kb) { return kb <= 5 ? 2 : 1; }
-
-#if RG_HAS(2)
-template <int KB>
-__global__ void __launch_bounds__(kBlock) k_exact_sums_u(DevSim d, uint32_t t, int from_list, int mode, uint32_t S) {
-    constexpr int UPL = exact_upl_of(KB);
-    __shared__ double exp_tab[32];
-    if (threadIdx.x < 32) exp_tab[threadIdx.x] = kExp2Tab32[threadIdx.x];
-    __syncthreads();
-    const int lane = lane_id();
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t n_cc = d.PT / 64;                           // one stored sum per 64-product chunk
-    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
-    // from_list == 2: the users k_walk parked (park_list, `t` = its length; entries 0xFFFFFFFF are unused)
-    // from_list == 1 without the per-user cache: the batch [exact_base, exact_base + exact_rows) of the step's list
-    const bool batched = from_list == 1 && !d.use_cache;
-    const uint32_t base = batched ? d.exact_base : 0u;
-    uint32_t n = from_list == 2 ? t : (from_list ? d.exact_cnt[t] : n_o);
-    if (batched) n = min(n, base + d.exact_rows);
-    const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
-    const uint32_t n_groups = n > base ? (n - base + 64 * UPL - 1) / (64 * UPL) : 0u;
-    const uint32_t ccps = (n_cc + S - 1) / S;                  // chunks per slice
-    const uint32_t n_work = n_groups * S;
-    constexpr uint32_t RSd = 4 * KB + 4;
-    for (uint32_t wk = blockIdx.x * (kBlock / 64) + wave; wk < n_work; wk += gridDim.x * (kBlock / 64)) {
-        const uint32_t grp = wk / S, slice = wk % S;
-        const uint32_t cc0 = slice * ccps, cc1 = min(cc0 + ccps, n_cc);
-        if (cc0 >= cc1) continue;
-        uint32_t w_idx[UPL];
-        bool act[UPL];
-        double om[UPL][4 * KB], M[UPL];
-#pragma unroll
-        for (int j = 0; j < UPL; ++j) {
-            w_idx[j] = base + grp * (64 * UPL) + j * 64 + lane;
-            act[j] = w_idx[j] < n;
-            uint32_t slot;
-            if (from_list == 2) {
-                slot = act[j] ? d.park_list[w_idx[j]] : 0xFFFFFFFFu;
-                act[j] = slot != 0xFFFFFFFFu;
-                if (!act[j]) slot = 0u;
-                w_idx[j] = slot;                                               // slot == user index: nothing was repacked
-            } else {
-                const uint32_t pos = act[j] ? (from_list ? d.exact_list[w_idx[j]] : w_idx[j]) : 0u;
-                slot = act[j] ? cur[pos] : 0u;
-                if (from_list && d.use_cache && act[j]) w_idx[j] = d.uid[slot];   // sums / reference rows are per user in this mode
-            }
-#pragma unroll
-            for (int k = 0; k < 4 * KB; ++k)
-                om[j][k] = (act[j] && static_cast<uint32_t>(k) < d.K) ? d.omega[static_cast<size_t>(slot) * d.OMS + k] : 0.0;
-            M[j] = (mode == 1 && act[j]) ? static_cast<double>(d.exact_ref[w_idx[j]]) * 0.69314718055994530942 : 0.0;
-        }
-        for (uint32_t cc = cc0; cc < cc1; ++cc) {
-            double acc[UPL];
-            const uint32_t p1 = cc * 64 + 64;                  // PT is a multiple of 64
-            // same association as the oracle / numpy: (sum_k Gamma[p][k] omega[k]) + mu[p], k ascending (the zero-padded
-            // k leave the sum unchanged); mu = -inf for products >= P: exp gives exactly 0
-            if (mode == 0) {
-#pragma unroll
-                for (int j = 0; j < UPL; ++j) acc[j] = -INFINITY;
-                for (uint32_t p = cc * 64; p < p1; ++p) {
-                    kdouble* row = (kdouble*)(d.gamma_rm) + static_cast<size_t>(p) * RSd;   // C-style: address-space cast
-#pragma unroll
-                    for (int j = 0; j < UPL; ++j) {
-                        double l = 0.0;
-#pragma unroll
-                        for (int k = 0; k < 4 * KB; ++k) l += row[k] * om[j][k];
-                        acc[j] = fmax(acc[j], l + row[4 * KB]);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < UPL; ++j) acc[j] = 0.0;
-#pragma unroll 2
-                for (uint32_t p = cc * 64; p < p1; ++p) {
-                    kdouble* row = (kdouble*)(d.gamma_rm) + static_cast<size_t>(p) * RSd;
-                    double l[UPL];
-#pragma unroll
-                    for (int j = 0; j < UPL; ++j) l[j] = 0.0;
-#pragma unroll
-                    for (int k = 0; k < 4 * KB; ++k) {
-                        const double g = row[k];
-#pragma unroll
-                        for (int j = 0; j < UPL; ++j) l[j] += g * om[j][k];
-                    }
-#pragma unroll
-                    for (int j = 0; j < UPL; ++j) acc[j] += exp64t(l[j] + row[4 * KB] - M[j], exp_tab);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < UPL; ++j)
-                if (act[j]) d.exact_sums[static_cast<size_t>(w_idx[j] - (batched ? base : 0u)) * n_cc + cc] = acc[j];
-        }
-    }
-}
-#endif
 
 // ------------------------------------------------------------------------------------------
 // k_exact_sums_m — the float64 chunk sums on the float64 MATRIX cores (v_mfma_f64_16x16x4_f64).
@@ -1736,6 +1607,8 @@ __global__ void __launch_bounds__(kBlock) k_exact_sums_m(DevSim d, uint32_t t, i
     }
 }
 #endif
+
+typedef const __attribute__((address_space(4))) double kdouble;   // constant address space: uniform loads become s_load
 
 // ------------------------------------------------------------------------------------------
 // k_exact_sums_h — the parked users' batch of k_walk on BOTH float64 pipes at once.
@@ -1938,16 +1811,6 @@ inline void launch_exact_m(exact_m_kernel_t km, const DevSim& d, uint32_t t, int
     hipLaunchKernelGGL(km, dim3(static_cast<uint32_t>(grid)), dim3(kBlock), smem, st, d, t, from_list, mode, S);
 }
 
-#if RG_HAS(2)
-exact_u_kernel_t exact_u_kernel_for(uint32_t kb) {
-    switch (kb) {
-        case 1: return k_exact_sums_u<1>;   case 2: return k_exact_sums_u<2>;   case 3: return k_exact_sums_u<3>;
-        case 4: return k_exact_sums_u<4>;   case 5: return k_exact_sums_u<5>;   case 6: return k_exact_sums_u<6>;
-        case 8: return k_exact_sums_u<8>;   case 12: return k_exact_sums_u<12>; case 16: return k_exact_sums_u<16>;
-        default: return nullptr;
-    }
-}
-#endif
 
 // pure float64 mode: the reference of every user = its max logit (reco_env_v1.py:121)
 #if RG_HAS(2)
@@ -2219,7 +2082,7 @@ __device__ __forceinline__ float swap32(float x) {
 // Where a lane finds / leaves its user's sums: record of super-chunk sc at rec[sc * rec_stride], the four chunk
 // sums of product tile ti (16 bytes) at chunk[ti * tile_stride].  Per-wave scratch (users interleaved, one sweep's
 // lifetime) or the per-user cache of the sigma_omega == 0 mode.
-struct SumsView { float2* rec; uint32_t rec_stride; float* chunk; uint32_t tile_stride; float* sub; };
+struct SumsView { float2* rec; uint32_t rec_stride; float* chunk; uint32_t tile_stride; };
 
 __device__ __forceinline__ SumsView sums_view(const DevSim& d, float2* scr, float* scr_chunk, int j, bool active, uint32_t slot) {
     SumsView v;
@@ -2227,9 +2090,7 @@ __device__ __forceinline__ SumsView sums_view(const DevSim& d, float2* scr, floa
         const size_t row = active ? d.uid[slot] : d.n_cap;          // inactive lanes: the dummy row
         v.rec = d.cache_rec + row * kMaxSC; v.rec_stride = 1;
         v.chunk = d.cache_chunk + row * d.n_chunks; v.tile_stride = 4;
-        v.sub = d.cache_sub ? d.cache_sub + row * d.n_chunks * 4 : nullptr;
     } else {
-        v.sub = nullptr;
         v.rec = scr + j; v.rec_stride = 32;
         v.chunk = scr_chunk + 4 * j; v.tile_stride = 128;
     }
@@ -2877,7 +2738,7 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* generic_ptr) {
 #endif
 
 #if RG_HAS(4)
-template <int KH, int N1, int N2, int N3, bool F16, bool SUB = false>
+template <int KH, int N1, int N2, int N3, bool F16>
 __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, uint32_t S) {
     constexpr int NM = F16 ? N1 : N1 + N2 + N3;   // MFMAs per chunk (fp16 two-way split: one group)
     // MFMA slots that carry the exps (and the A loads); the rest carry the mu loads.  The fp16 form is VALU-bound:
@@ -3015,8 +2876,6 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         // The exps feed four running packed sums per chunk as they are produced (slots < EXS), so
         // the logit registers are free for the mu quads fetched in the last slots.
         using f32x4 = __attribute__((ext_vector_type(4))) float;
-        constexpr bool sub = SUB;                            // also the sums of the chunk's four 8-product groups (view.sub)
-        f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
         auto stream = [&](const PairOps& co, PairOps& no, uint32_t pi_next, f32x16& a0, f32x16& a1,
                           f32x16& p0, f32x16& p1, float& s0, float& s1) {
             f32x2 x0[4], x1[4];
@@ -3034,10 +2893,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
                     for (int e = (m * 8 / EXS) * 2; e < ((m + 1) * 8 / EXS) * 2; e += 2) {       // exps in pairs
                         f32x2 y = {__builtin_amdgcn_exp2f(p0[e]), __builtin_amdgcn_exp2f(p0[e + 1])};
                         asm volatile("" : "+v"(y));                     // with the pin on p0 above: keeps these pure ops in this slot
-                        // (SUB: x0[q] = accumulator rows 4q..4q+3 = products 8q..8q+7 with the other half-wave; else four
-                        // independent running sums)
-                        if (sub) { if ((e & 3) == 0) x0[e / 4] = y; else x0[e / 4] += y; }
-                        else { if (e < 8) x0[e / 2] = y; else x0[(e / 2) & 3] += y; }
+                        // (four independent running sums)
+                        if (e < 8) x0[e / 2] = y; else x0[(e / 2) & 3] += y;
                     }
                 } else {
 #pragma unroll
@@ -3053,8 +2910,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
                     for (int e = (m * 8 / EXS) * 2; e < ((m + 1) * 8 / EXS) * 2; e += 2) {
                         f32x2 y = {__builtin_amdgcn_exp2f(p1[e]), __builtin_amdgcn_exp2f(p1[e + 1])};
                         asm volatile("" : "+v"(y));                     // with the pin on p1 above: keeps these pure ops in this slot
-                        if (sub) { if ((e & 3) == 0) x1[e / 4] = y; else x1[e / 4] += y; }
-                        else { if (e < 8) x1[e / 2] = y; else x1[(e / 2) & 3] += y; }
+                        if (e < 8) x1[e / 2] = y; else x1[(e / 2) & 3] += y;
                     }
                 } else {
 #pragma unroll
@@ -3066,24 +2922,11 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) { load_mu(p0, mb, 0, qq); load_mu(p1, mb, 1, qq); }
             }
-            if (sub) {
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) { g0[q4] = x0[q4][0] + x0[q4][1]; g1[q4] = x1[q4][0] + x1[q4][1]; }
-                s0 = (g0[0] + g0[1]) + (g0[2] + g0[3]);
-                s1 = (g1[0] + g1[1]) + (g1[2] + g1[3]);
-            } else {
-                x0[0] += x0[2]; x0[1] += x0[3]; x0[0] += x0[1];
-                x1[0] += x1[2]; x1[1] += x1[3]; x1[0] += x1[1];
-                s0 = x0[0][0] + x0[0][1];
-                s1 = x1[0][0] + x1[0][1];
-            }
+            x0[0] += x0[2]; x0[1] += x0[3]; x0[0] += x0[1];
+            x1[0] += x1[2]; x1[1] += x1[3]; x1[0] += x1[1];
+            s0 = x0[0][0] + x0[0][1];
+            s1 = x1[0][0] + x1[0][1];
             RG_PIN();
-        };
-        auto tree4 = [](const f32x16& y) -> f32x4 {
-            f32x4 r;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) r[q4] = (y[4 * q4] + y[4 * q4 + 1]) + (y[4 * q4 + 2] + y[4 * q4 + 3]);
-            return r;
         };
         auto tree = [](const f32x16& y) -> float {
             f32x2 x0 = {y[0], y[1]}, x1 = {y[2], y[3]}, x2 = {y[4], y[5]}, x3 = {y[6], y[7]};
@@ -3109,15 +2952,6 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             if RG_SWEEP_ABL(256u) { wcmax += s0 + s1; return; }
             s0 += swap32(s0);
             s1 += swap32(s1);
-            if (sub) {
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) { g0[q4] += swap32(g0[q4]); g1[q4] += swap32(g1[q4]); }
-                if (h == 0) {
-                    float4* sp = reinterpret_cast<float4*>(view.sub + (static_cast<size_t>(pt_lo) * 4 + 2 * pe) * 4);
-                    sp[0] = make_float4(g0[0], g0[1], g0[2], g0[3]);
-                    sp[1] = make_float4(g1[0], g1[1], g1[2], g1[3]);
-                }
-            }
             if (!(pe & 1)) { wlo = make_float2(s0, s1); return; }
             const uint32_t ti = pt_lo + (pe >> 1);
             const float4 w4 = make_float4(wlo.x, wlo.y, s0, s1);
@@ -3204,7 +3038,6 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             // the scratch stores of the tiles finished since (0, 1, then always 2) -> those may stay in flight ----
             if (T + 2 >= pt_hi) RG_TILE_BARRIER(0);            // nothing was issued behind tile T + 1 but stores
             else if (pi == 1) RG_TILE_BARRIER(4);               // DMA(T + 2)
-            else if (sub) { if (pi == 3) RG_TILE_BARRIER(9); else RG_TILE_BARRIER(14); }   // (five stores per tile with the group sums)
             else if (pi == 3) RG_TILE_BARRIER(5);               // + one store
             else RG_TILE_BARRIER(6);                            // + two stores
             if (T + 3 < pt_hi && !RG_SWEEP_ABL(32u)) fetch_tile(T + 3);
@@ -3228,8 +3061,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) { p0[r] = __builtin_amdgcn_exp2f(p0[r]); p1[r] = __builtin_amdgcn_exp2f(p1[r]); }
             q_done = q;
-            if (sub) { g0 = tree4(p0); g1 = tree4(p1); book(pi, (g0[0] + g0[1]) + (g0[2] + g0[3]), (g1[0] + g1[1]) + (g1[2] + g1[3])); }
-            else book(pi, tree(p0), tree(p1));
+            book(pi, tree(p0), tree(p1));
         }
         if (sc_left != d.sc_chunks / 4 && h == 0) {            // partial last super-chunk
             view.rec[sc_cur * view.rec_stride] = make_float2(static_cast<float>(s_sc), q_done);
@@ -3599,7 +3431,7 @@ search_kernel_t search_kernel_for(const DevSim& d) {
 #if RG_HAS(4)
 draw_kernel_t bf16p_kernel_for(const DevSim& d) {
     if (d.f16) {
-#define RG_CASE(kh, a) if (d.KH == kh && d.N1 == a) return d.cache_sub ? k_draw_bf16p<kh, a, 0, 0, true, true> : k_draw_bf16p<kh, a, 0, 0, true>;
+#define RG_CASE(kh, a) if (d.KH == kh && d.N1 == a) return k_draw_bf16p<kh, a, 0, 0, true>;
         RG_CASE(4, 1) RG_CASE(4, 2) RG_CASE(10, 2) RG_CASE(10, 3) RG_CASE(10, 4) RG_CASE(16, 4)
 #undef RG_CASE
         return nullptr;
@@ -5083,75 +4915,8 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
                 }
             }
             found_c = found_c && found_sc;
-            // ---- the 8-product group inside the chunk, where the sweep kept the group sums ----
-            uint32_t g_star = 3;
-            if (d.cache_sub) {
-                const float4 g4 = *reinterpret_cast<const float4*>(d.cache_sub + (row * d.n_chunks + c_star) * 4);
-                const double G0 = static_cast<double>(g4.x * f_star), G1 = static_cast<double>(g4.y * f_star),
-                             G2 = static_cast<double>(g4.z * f_star);
-                if (pb + G0 > tau) g_star = 0;
-                else if (pb + G0 + G1 > tau) { g_star = 1; pb = pb + G0; }
-                else if (pb + G0 + G1 + G2 > tau) { g_star = 2; pb = pb + G0 + G1; }
-                else pb = pb + G0 + G1 + G2;
-            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            if (d.cache_sub) {
-                // ---- the 8 products of the group (phase 3): 32 searching users per pass, two lanes per user, four
-                // products per lane — a quarter of the Gamma bytes of a whole chunk through the L1, and one latency
-                // chain for all the searching users of the step ----
-                const unsigned long long todo = __ballot(search);
-                const uint32_t n_todo = static_cast<uint32_t>(__popcll(todo));
-                if (search) slots[prefix_in_mask(todo)] = static_cast<uint32_t>(lane);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                const int grp = lane >> 1, gl = lane & 1;
-                for (uint32_t base = RG_WALK_ABL(16) ? n_todo : 0u; base < n_todo; base += 32) {
-                    const bool has = base + grp < n_todo;
-                    const int src = has ? static_cast<int>(slots[base + grp]) : 0;
-                    const uint32_t cs = static_cast<uint32_t>(__shfl(static_cast<int>(c_star), src));
-                    const uint32_t gs = static_cast<uint32_t>(__shfl(static_cast<int>(g_star), src));
-                    const float Qs = __shfl(Q, src);
-                    const double pbs = __shfl(pb, src), taus = __shfl(tau, src);
-                    const float4* gp = reinterpret_cast<const float4*>(d.gamma32t + (static_cast<size_t>(cs) * K2) * 32) + gs * 2 + gl;
-                    float4 l = *(reinterpret_cast<const float4*>(d.mu32 + cs * 32) + gs * 2 + gl);
-                    const float* o = om32 + __shfl(max(sel, 0), src) * (K2 * 64) + src;
-#pragma unroll
-                    for (int kh = 0; kh < K2; kh += KH) {
-                        float4 gk[KH];
-#pragma unroll
-                        for (int k = 0; k < KH; ++k) gk[k] = gp[(kh + k) * 8];
-#pragma unroll
-                        for (int k = 0; k < KH; ++k) {
-                            const float wk = o[(kh + k) * 64];
-                            l.x = fmaf(gk[k].x, wk, l.x); l.y = fmaf(gk[k].y, wk, l.y);
-                            l.z = fmaf(gk[k].z, wk, l.z); l.w = fmaf(gk[k].w, wk, l.w);
-                        }
-                        asm volatile("" : "+v"(l.x), "+v"(l.y), "+v"(l.z), "+v"(l.w));
-                    }
-                    const float e0 = __builtin_amdgcn_exp2f(fmaf(l.x, kLog2e, -Qs)), e1 = __builtin_amdgcn_exp2f(fmaf(l.y, kLog2e, -Qs));
-                    const float e2 = __builtin_amdgcn_exp2f(fmaf(l.z, kLog2e, -Qs)), e3 = __builtin_amdgcn_exp2f(fmaf(l.w, kLog2e, -Qs));
-                    const float q0 = e0, q1 = q0 + e1, q2 = q1 + e2, q3 = q2 + e3;      // prefix inside the lane
-                    float ex = __shfl_up(q3, 1, 2);                                     // ... and after the user's first lane
-                    if (gl == 0) ex = 0.0f;
-                    const double pxb = pbs + static_cast<double>(ex);
-                    const double px0 = pbs + static_cast<double>(ex + q0), px1 = pbs + static_cast<double>(ex + q1);
-                    const double px2 = pbs + static_cast<double>(ex + q2), px3 = pbs + static_cast<double>(ex + q3);
-                    const int j0 = px0 > taus ? 0 : px1 > taus ? 1 : px2 > taus ? 2 : px3 > taus ? 3 : -1;
-                    const unsigned long long hits = __ballot(has && j0 >= 0);
-                    const uint32_t gmask = static_cast<uint32_t>(hits >> (2 * grp)) & 3u;
-                    if (has) {
-                        if (gmask) {
-                            if (gl == __builtin_ctz(gmask)) {
-                                mbox[src * 3] = static_cast<double>(4 * gl + j0);
-                                mbox[src * 3 + 1] = j0 == 0 ? pxb : j0 == 1 ? px0 : j0 == 2 ? px1 : px2;
-                                mbox[src * 3 + 2] = j0 == 0 ? px0 : j0 == 1 ? px1 : j0 == 2 ? px2 : px3;
-                            }
-                        } else if (gl == 0) { mbox[src * 3] = -1.0; mbox[src * 3 + 1] = pbs; mbox[src * 3 + 2] = pbs; }
-                    }
-                }
-                if (RG_WALK_ABL(16) && search) { mbox[lane * 3] = 0.0; mbox[lane * 3 + 1] = 0.0; mbox[lane * 3 + 2] = 1e300; }
-            } else {
             // ---- the 32 products of the chosen chunk (phase 3): eight searching users per pass, eight lanes per
             // user, four products per lane.  A pass is ONE latency chain (user parameters -> 21 coalesced
             // 16-byte loads -> 80 fma -> 4 exp -> 3-step prefix across the user's lanes -> compare); two users
@@ -5215,7 +4980,6 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
                     } else if (gl == 0) { mbox[src * 3] = -1.0; mbox[src * 3 + 1] = pbs; mbox[src * 3 + 2] = pbs; }
                 }
             }
-            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             uint32_t v = 0;
@@ -5223,7 +4987,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
             if (search) {
                 const int idx = static_cast<int>(mbox[lane * 3]);
                 const double Av = mbox[lane * 3 + 1], Bv = mbox[lane * 3 + 2];
-                v = c_star * 32 + (d.cache_sub ? g_star * 8 : 0u) + static_cast<uint32_t>(max(idx, 0));
+                v = c_star * 32 + static_cast<uint32_t>(max(idx, 0));
                 const CertLin ct = cert_correlated(S, pb, Av - pb, Bv - pb, delta);
                 ok = found_c && idx >= 0 && v < d.P && ct.valid &&
                      (v == 0 || u_org * ct.den_lo > ct.num_lo) &&
@@ -6937,7 +6701,7 @@ walk_kernel_t walk2_kernel_for(const DevSim& d, int occ) {
     // the forms k_walk2 is instantiated for: K <= 32, no group sums, the policies without a view history or the
     // OrganicUserEventCounter default (exploit_explore, epsilon = 0, select_randomly)
     const bool ouc = d.policy == RG_POLICY_ORGANIC_USER_COUNT;
-    if (d.KH > 16 || d.cache_sub || !d.walk_hot) return nullptr;
+    if (d.KH > 16 || !d.walk_hot) return nullptr;
     if (ouc && !(d.ouc_exploit_explore && d.ouc_epsilon == 0.0 && d.ouc_select_randomly)) return nullptr;
     if (d.policy != RG_POLICY_UNIFORM_ENV && d.policy != RG_POLICY_RANDOM_AGENT && d.policy != RG_POLICY_LAST_VIEW_TABLE && !ouc) return nullptr;
 #ifdef RG_W2_ONLY     // kernel work: one instantiation, seconds to compile (never a shipped build)
@@ -6977,9 +6741,10 @@ walk_kernel_t walk_kernel_for(const DevSim& d, int occ) {
     const bool dense = d.policy == RG_POLICY_ORGANIC_USER_COUNT && !(d.ouc_exploit_explore && d.ouc_epsilon == 0.0);
 #define RG_W(kh, o) (dense ? k_walk<kh, o, true> : k_walk<kh, o, false>)
     switch (d.KH) {
-        case 4: return occ >= 4 ? RG_W(4, 4) : occ == 3 ? RG_W(4, 3) : RG_W(4, 2);
-        case 10: return occ >= 4 ? RG_W(10, 4) : occ == 3 ? RG_W(10, 3) : RG_W(10, 2);
-        case 16: return occ >= 4 ? RG_W(16, 4) : occ == 3 ? RG_W(16, 3) : RG_W(16, 2);
+        // (three blocks per CU at K <= 32 — two and four were measured in round 2: 358 / 328 against 301 ms — one at K <= 64)
+        case 4: return RG_W(4, 3);
+        case 10: return RG_W(10, 3);
+        case 16: return RG_W(16, 3);
         default: return RG_W(32, 1);
     }
 #undef RG_W
@@ -7354,32 +7119,12 @@ void launch_exact(rg_sim* sim, uint32_t t, int from_list, uint64_t est, hipStrea
         d.exact_base = batched ? static_cast<uint32_t>(b) * d.exact_rows : 0u;
         d.exact_last = b + 1 == n_batches ? 1u : 0u;
         if (batched && est > d.exact_rows) est = d.exact_rows;
-        if (exact_m_kernel_t km = ((sim->opt.exact_tile || sim->opt.exact_valu) ? nullptr : exact_m_kernel_for(d.XKB))) {
+        if (exact_m_kernel_t km = (sim->opt.exact_tile ? nullptr : exact_m_kernel_for(d.XKB))) {
             if (!from_list) {
                 launch_exact_m(km, d, t, 0, 0, est, st);
                 hipLaunchKernelGGL(exact_ref_kernel(), dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t, 1u);
             }
             launch_exact_m(km, d, t, from_list, 1, est, st);
-            hipLaunchKernelGGL(exact_pick_kernel(), dim3(grid_for(est, kBlock / 64)), dim3(kBlock),
-                               sizeof(double) * d.K * (kBlock / 64), st, d, t, from_list, 1u);
-            continue;
-        }
-        if (exact_u_kernel_t ku = (sim->opt.exact_tile ? nullptr : exact_u_kernel_for(d.XKB))) {
-            const uint64_t upl = 64ull * exact_upl_of(d.XKB);
-            const uint64_t groups = (est + upl - 1) / upl;
-            // The kernel's stall is the scalar-load latency of a Gamma row (the table streams through
-            // L2), hidden only by other waves: fill every SIMD to the kernel's occupancy (6 waves) and
-            // cut the work ~4x finer than that so the grid-stride loop balances.
-            uint32_t S = static_cast<uint32_t>(24576 / (groups ? groups : 1));
-            if (S > n_chunks) S = n_chunks;
-            if (S < 1) S = 1;
-            int grid = grid_for(groups * S, kBlock / 64);
-            if (grid > 1536) grid = 1536;
-            if (!from_list) {
-                hipLaunchKernelGGL(ku, dim3(grid), dim3(kBlock), 0, st, d, t, 0, 0, S);
-                hipLaunchKernelGGL(exact_ref_kernel(), dim3(grid_for(est, kBlock / 64)), dim3(kBlock), 0, st, d, t, 1u);
-            }
-            hipLaunchKernelGGL(ku, dim3(grid), dim3(kBlock), 0, st, d, t, from_list, 1, S);
             hipLaunchKernelGGL(exact_pick_kernel(), dim3(grid_for(est, kBlock / 64)), dim3(kBlock),
                                sizeof(double) * d.K * (kBlock / 64), st, d, t, from_list, 1u);
             continue;
@@ -7442,12 +7187,8 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     if (d.use_mfma == 2 && d.use_cache && t > 0) {
         // sigma_omega == 0, after step 0: every live user's exp-sums are in the per-user cache — search only
         if (int rc = prof_mark(sim, st)) return rc;
-        if (sim->cached_search_old)
-            hipLaunchKernelGGL(search_kernel_for(d), dim3(grid_for(upper, 128)), dim3(kBlock),
-                               sizeof(float) * 4 * 32 * 2 * d.KH, st, d, t);
-        else
-            hipLaunchKernelGGL(cached_kernel_for(d), dim3(grid_for(upper, kBlock)), dim3(kBlock),
-                               sizeof(float) * (kBlock / 64) * 64 * 2 * d.KH, st, d, t);
+        hipLaunchKernelGGL(cached_kernel_for(d), dim3(grid_for(upper, kBlock)), dim3(kBlock),
+                           sizeof(float) * (kBlock / 64) * 64 * 2 * d.KH, st, d, t);
         if (int rc = prof_mark(sim, st)) return rc;
         launch_exact(sim, t, 1, upper / 100 + 16, st);
     } else if (d.use_mfma == 2) {
@@ -7621,7 +7362,7 @@ int run_walk(rg_sim* sim, hipStream_t st) {
     };
     if (n_park) {
         const uint32_t mfma_of_8 = static_cast<uint32_t>(sim->opt.exact_mix);     // groups of every 8 that take the matrix form (8 = all)
-        exact_h_kernel_t kh = (mfma_of_8 < 8 && !sim->opt.exact_valu) ? exact_h_kernel_for(d.XKB) : nullptr;
+        exact_h_kernel_t kh = mfma_of_8 < 8 ? exact_h_kernel_for(d.XKB) : nullptr;
         if (kh) {
             HIP_TRY(hipMemsetAsync(d.counters + kCntWalkTicket, 0, sizeof(unsigned long long), st));
             const uint32_t groups = (n_park + 255u) / 256u;
@@ -7631,25 +7372,13 @@ int run_walk(rg_sim* sim, hipStream_t st) {
             if (int rc = later_rounds(n_park)) return rc;
             goto walked;
         }
-        if (exact_m_kernel_t km = (sim->opt.exact_valu ? nullptr : exact_m_kernel_for(d.XKB))) {
+        if (exact_m_kernel_t km = exact_m_kernel_for(d.XKB)) {
             launch_exact_m(km, d, n_park, 2, 1, n_park, st);
             if (int rc = mark(4)) return rc;
             if (int rc = later_rounds(n_park)) return rc;
             goto walked;
         }
-        exact_u_kernel_t ku = exact_u_kernel_for(d.XKB);
-        if (!ku) return fail(RG_ESTATE, "no user-per-lane float64 kernel for K = %u", d.K);
-        const uint32_t n_chunks = d.PT / 64;
-        const uint64_t upl = 64ull * exact_upl_of(d.XKB);
-        const uint64_t groups = (static_cast<uint64_t>(n_park) + upl - 1) / upl;
-        uint32_t S = static_cast<uint32_t>(24576 / groups);
-        if (S > n_chunks) S = n_chunks;
-        if (S < 1) S = 1;
-        int grid = grid_for(groups * S, kBlock / 64);
-        if (grid > 1536) grid = 1536;
-        hipLaunchKernelGGL(ku, dim3(grid), dim3(kBlock), 0, st, d, n_park, 2, 1, S);
-        if (int rc = mark(4)) return rc;
-        if (int rc = later_rounds(n_park)) return rc;
+        return fail(RG_ESTATE, "no float64 batch kernel for K = %u", d.K);
     } else if (int rc = mark(4)) return rc;
 walked:
     if (int rc = mark(5)) return rc;
@@ -7915,7 +7644,6 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     {   // run-path options from the environment, once
         RunOpts& o = s->opt;
         o.exact_tile = getenv("RECOGYM_EXACT_TILE") ? 1 : 0;
-        o.exact_valu = getenv("RECOGYM_EXACT") ? 1 : 0;
         o.exact_mix = 5;
         if (const char* e = getenv("RECOGYM_EXACT_MIX")) o.exact_mix = atoi(e);
         o.resident_grid = getenv("RECOGYM_RESIDENT_GRID") ? 1 : 0;
@@ -7959,11 +7687,6 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     // the per-user sum cache is written by the pipelined 16-bit kernel only
     if (!(d.use_mfma == 2 && s->bf16_kernel &&
           (s->bf16_kernel == bf16p_kernel_for(d) || (d.wide && s->bf16_kernel == f16w_kernel_for(d))))) d.use_cache = 0;
-    if (!d.use_cache && d.cache_sub) {          // no cache, no group sums: back to the plain instantiation of the sweep
-        const bool was_p = s->bf16_kernel == bf16p_kernel_for(d);
-        d.cache_sub = nullptr;
-        if (was_p) s->bf16_kernel = bf16p_kernel_for(d);
-    }
     if (s->bf16_kernel && s->bf16_smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s->bf16_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->bf16_smem));
@@ -7982,8 +7705,6 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
         if (d.policy == RG_POLICY_LOGREG_FROZEN) s->tail_below = 0;
     }
     s->prof_tail_ms = 0.0;
-    s->cached_search_old = false;
-    if (const char* e = getenv("RECOGYM_CACHED")) s->cached_search_old = !strcmp(e, "search");
     // user-major walk: wherever the per-user cache exists and the policy acts lane by lane (the frozen LogReg
     // policy acts wave-cooperatively: lock-step); RECOGYM_WALK=0 keeps the lock-step loop (A/B tests)
     s->walk = d.use_cache && (d.policy == RG_POLICY_UNIFORM_ENV || d.policy == RG_POLICY_RANDOM_AGENT ||
@@ -8008,7 +7729,6 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     // (k_walk2: 4 since the act is a count on the compact history line — the bandit iteration got shorter, so the organic kind
     // waits for more lanes: profiles/r4/ab_call6_walk_bias.jsonl; k_walk keeps round 2's 8)
     if (s->walk2 && !getenv("RECOGYM_WALK_BIAS")) d.walk_bias = 4;
-    if (const char* e = getenv("RECOGYM_WALK_OCC")) { const int o = atoi(e); if (o >= 2 && o <= 4) s->walk_occ = o; }
     if (s->walk2) s->walk_occ = d.KH <= 10 ? 3 : 2;     // (what k_walk2 is compiled for: K <= 20 three blocks per CU, K <= 32 two)
     s->walk_solo = true;
     if (const char* e = getenv("RECOGYM_WALK_SOLO")) s->walk_solo = e[0] != '0';
@@ -8076,7 +7796,6 @@ int* opt_int(rg_sim* s, const char* n) {
     if (!strcmp(n, "pipe_occ2")) return &s->pipe_occ2;
     if (!strcmp(n, "pipe_xblocks")) return &s->pipe_xblocks;
     if (!strcmp(n, "exact_mix")) return &s->opt.exact_mix;
-    if (!strcmp(n, "exact_valu")) return &s->opt.exact_valu;
     if (!strcmp(n, "exact_tile")) return &s->opt.exact_tile;
     if (!strcmp(n, "resident_grid")) return &s->opt.resident_grid;
     if (!strcmp(n, "slices")) return &s->opt.slices;
@@ -8297,7 +8016,7 @@ int rg_sim_run(rg_sim* sim, uint32_t max_steps, void* stream) {
         const int mix = sim->opt.exact_mix;
         const bool pipe = sim->pipe_groups >= 1 && sim->walk2 && sim->walk_solo && solo_kernel_for(sim->d) && sim->d.walk_handover &&
                           sim->bf16_kernel == bf16p_kernel_for(sim->d) && sim->d.f16 && !sim->d.wide && sim->d.n_users >= sim->pipe_min_users &&
-                          exact_h_kernel_for(sim->d.XKB) && mix < 8 && !sim->opt.exact_valu && sim->opt.slices < 0 &&
+                          exact_h_kernel_for(sim->d.XKB) && mix < 8 && sim->opt.slices < 0 &&
                           !sim->opt.sweep_prefix_off;
         return pipe ? run_walk_pipe(sim, st) : run_walk(sim, st);
     }

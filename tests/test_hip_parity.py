@@ -678,7 +678,7 @@ def test_walk_certificate_is_sound_for_uniforms_next_to_cdf_boundaries(shape, wa
     assert 0 < c['exact_draws'] and c['exact_sweeps'] < (margin < 3e-4).sum() + 64
 
 
-@pytest.mark.parametrize('variant', ['default', 'fastclick', 'sub', 'sliced', 'nowalk', 'repack', 'lockstep', 'nowalk_sliced'])
+@pytest.mark.parametrize('variant', ['default', 'fastclick', 'k_walk', 'sliced', 'nowalk', 'repack', 'lockstep', 'nowalk_sliced'])
 @pytest.mark.parametrize('shape', [(129, 9, 1500, 40), (2049, 20, 500, 0), (10000, 20, 150, 0), (33, 3, 2500, 0)])
 def test_sigma_omega_zero_sum_cache_matches_the_oracle(shape, variant, monkeypatch):
     """sigma_omega = 0 (BASELINE configs 2 and 3): a user's omega never changes, so the exp-sums of its first
@@ -699,8 +699,8 @@ def test_sigma_omega_zero_sum_cache_matches_the_oracle(shape, variant, monkeypat
         monkeypatch.setenv('RECOGYM_TAIL', '0')
     if variant in ('sliced', 'nowalk_sliced'):
         monkeypatch.setenv('RECOGYM_SLICES', '4')
-    if variant == 'sub':             # opt-in: the sweep also keeps 8-product group sums, the walk recomputes a group
-        monkeypatch.setenv('RECOGYM_SUB', '1')
+    if variant == 'k_walk':          # round 2's walk kernel (it still serves K > 32 and the dense forms of the policy)
+        monkeypatch.setenv('RECOGYM_WALK', '1')
     pol = dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=31, ouc=dict(gu.OUC_DEFAULTS))
     cfg = Configuration({**env_1_args, 'random_seed': 700 + P, 'num_products': P, 'K': K, 'sigma_omega': 0.0})
     want_env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol)
