@@ -1,0 +1,703 @@
+// rg_advance.hip — librecogym_hip.so, unit 6 of 7: the lock-step transition (k_advance, k_drift), the tail kernel and the frozen LogReg act kernels.
+// (see rg_common.hpp for the shared types and helpers, DESIGN.md for the data layout and the rooflines)
+
+#include "rg_common.hpp"
+
+namespace rgk {
+
+// ------------------------------------------------------------------------------------------
+// Frozen LogregMulticlassIps at scale (BASELINE config 5: 10^4 classes).  a = classes[argmax_c (b_c + sum_p views_p W[p][c])]
+// depends on the view history only, so it is computed when the history has changed (5-6 times per user, not once per
+// event) and kept per user:
+//   k_logreg_select  (lane per live user) the users that need an act at this step — bandit users whose history changed
+//                    since their last act, organic users that stop at this step (their phantom row) — into lr_list;
+//   k_logreg_acts    (wave per listed user, lane = class) scores in fp32 from the fp32 copy of coef^T (half the bytes,
+//                    twice the fma rate of the float64 walk): |s~_c - s_c| <= (nd + 3) 2^-24 (max|b| + sum_p views_p
+//                    max_c |W[p][c]|) for every class, so when the best fp32 score leads the second best by more than
+//                    twice that bound it IS sklearn's argmax; otherwise (near-ties, exact ties) the float64 walk in
+//                    scipy's summation order (logreg_act_wave) decides — predict() bit for bit either way.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_logreg_select(DevSim d, uint32_t t) {
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC], n_b = d.step_cnt[2 * t + RG_STATE_BANDIT], n = n_o + n_b;
+    const uint32_t* cur_o = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const uint32_t* cur_b = list_ptr(d, t & 1, RG_STATE_BANDIT);
+    const uint32_t n_iter = (n + kBlock - 1) / kBlock;
+    for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+        const uint32_t i = it * kBlock + threadIdx.x;
+        bool need = false;
+        uint32_t slot = 0;
+        if (i < n) {
+            const bool is_org = i < n_o;
+            slot = is_org ? cur_o[i] : cur_b[i - n_o];
+            const uint32_t uidx = d.uid[slot];
+            need = d.lr_dirty[uidx] != 0;
+            if (need && is_org) {
+                // an organic user needs an act only for its phantom row: when this step's transition stops it
+                const uint32_t user = static_cast<uint32_t>(d.first_user + uidx);
+                const rg_u32x4 w = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
+                const double u_trans = rg_uniform(w.w[2], w.w[3]);
+                const int ns = (d.cdf_o0 <= u_trans) + (d.cdf_o1 <= u_trans);
+                need = ns == RG_STATE_STOP && !((d.first_user + uidx) < d.organic_only_below);
+            }
+        }
+        const unsigned long long m = __ballot(need);
+        uint32_t base = 0;
+        if (m && lane_id() == 0) base = atomicAdd(&d.lr_cnt[t], static_cast<uint32_t>(__popcll(m)));
+        base = __shfl(static_cast<int>(base), 0);
+        if (need) d.lr_list[base + prefix_in_mask(m)] = slot;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_logreg_acts(DevSim d, uint32_t t) {
+    const int lane = lane_id();
+    const uint32_t n = d.lr_cnt[t];
+    const uint32_t waves_total = gridDim.x * (kBlock / 64);
+    unsigned long long c_acts = 0, c_rows = 0, c_exact = 0;
+    for (uint32_t w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < n; w += waves_total) {
+        const uint32_t slot = d.lr_list[w];
+        const uint32_t uidx = d.uid[slot];
+        uint32_t action = 0;
+        bool done = false;
+        const hent_t* hr = hist_row(d, slot) + 1;
+        const uint32_t nd = h_cnt(hr[-1]);
+        c_acts += 1; c_rows += nd;
+        if (d.lr_coef32_t && nd <= 32 && nd > 0) {
+            // history entries in registers of the first nd lanes, broadcast by readlane
+            const hent_t mine = static_cast<uint32_t>(lane) < nd ? hr[lane] : 0ull;
+            float Ahat = d.lr_bmax;
+            for (uint32_t i = 0; i < nd; ++i) {
+                const hent_t x = __shfl(mine, static_cast<int>(i));
+                Ahat = fmaf(static_cast<float>(h_cnt(x)), d.lr_wmax[h_prod(x)], Ahat);
+            }
+            float best = -INFINITY, second = -INFINITY;
+            uint32_t best_c = 0;
+            for (uint32_t c0 = 0; c0 < d.lr_n; c0 += 256) {
+                float sc[4];
+                uint32_t cc[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    cc[q] = min(c0 + 64u * q + lane, d.lr_n - 1);                  // clamped: masked below
+                    sc[q] = d.lr_intercept32[cc[q]];
+                }
+                for (uint32_t i = 0; i < nd; ++i) {
+                    const hent_t x = __shfl(mine, static_cast<int>(i));
+                    const float cnt = static_cast<float>(h_cnt(x));
+                    const float* row = d.lr_coef32_t + static_cast<size_t>(h_prod(x)) * d.lr_n;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sc[q] = fmaf(cnt, row[cc[q]], sc[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t c = c0 + 64u * q + lane;
+                    if (c < d.lr_n) {
+                        if (sc[q] > best) { second = best; best = sc[q]; best_c = c; }
+                        else if (sc[q] > second) second = sc[q];
+                    }
+                }
+            }
+            // wave top-2 over disjoint class sets: the best score with its class, and the best of everything else
+            // (equal best scores leave a margin of 0: not certified, the float64 walk breaks the tie like numpy)
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(best, o), os = __shfl_xor(second, o);
+                const uint32_t oc = __shfl_xor(best_c, o);
+                const float ns = fmaxf(fminf(best, ob), fmaxf(second, os));
+                if (ob > best) best_c = oc;
+                best = fmaxf(best, ob);
+                second = ns;
+            }
+            const float bound = static_cast<float>(nd + 3) * 5.9604644775390625e-08f * Ahat * 1.01f;
+            if (d.lr_n == 1 || best - second > 2.0f * bound) { action = static_cast<uint32_t>(d.lr_classes[best_c]); done = true; }
+        }
+        if (!done) { action = logreg_act_wave(d, slot, lane); c_exact += 1; }   // float64, scipy's summation order
+        if (lane == 0) { d.lr_action[uidx] = action; d.lr_dirty[uidx] = 0; }
+    }
+    if (lane == 0 && c_acts) {
+        atomicAdd(&d.counters[RG_CNT_LR_ACTS], c_acts);
+        atomicAdd(&d.counters[RG_CNT_LR_ROWS], c_rows);
+        if (c_exact) atomicAdd(&d.counters[RG_CNT_LR_EXACT], c_exact);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_logreg_screen(DevSim d, uint32_t t) {
+    __shared__ uint32_t s_cand[kBlock / 64][32];
+    __shared__ float s_cval[kBlock / 64][32];
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t n = d.lr_cnt[t];
+    const uint32_t C = d.lr_n;
+    const uint32_t RC = ((C + kLrSplit - 1) / kLrSplit + 7u) & ~7u;       // classes per range (a multiple of 8)
+    const uint32_t waves_total = gridDim.x * (kBlock / 64);
+    for (uint32_t item = blockIdx.x * (kBlock / 64) + wave; item < n * kLrSplit; item += waves_total) {
+        const uint32_t w = item / kLrSplit, r = item % kLrSplit;
+        const uint32_t slot = d.lr_list[w];
+        const hent_t* hr = hist_row(d, slot) + 1;
+        const uint32_t nd = h_cnt(hr[-1]);
+        // ---- the error bound of this history ----
+        float A = 0.0f, V = 0.0f;
+        for (uint32_t i = lane; i < nd; i += 64) {
+            const hent_t x = hr[i];
+            const float cnt = static_cast<float>(h_cnt(x));
+            A = fmaf(cnt, d.lr_wmax[h_prod(x)], A);
+            V += cnt;
+        }
+        for (int o = 32; o > 0; o >>= 1) { A += __shfl_xor(A, o); V += __shfl_xor(V, o); }
+        const float B = (A * 4.8828125e-4f + V * 2.98023224e-8f + static_cast<float>(nd + 3) * 5.9604644775390625e-08f * (d.lr_bmax + A)) * 1.02f;
+        const float thr = 2.0f * B * 1.01f + 1e-30f;
+        const uint32_t c_lo = r * RC, c_hi = min(c_lo + RC, C);
+        float rb = -INFINITY;
+        uint32_t n_cand = 0;
+        bool overflow = false;
+        for (uint32_t c0 = c_lo; c0 < c_hi && !overflow; c0 += 512) {
+            const uint32_t c = c0 + 8u * static_cast<uint32_t>(lane);
+            const bool in = c < c_hi;                                // (a lane's 8 classes are all in or all out)
+            const uint32_t cl = in ? c : c_lo;
+            float acc[8];
+            {
+                const float4 b0 = *reinterpret_cast<const float4*>(d.lr_intercept32 + cl);
+                const float4 b1 = *reinterpret_cast<const float4*>(d.lr_intercept32 + cl + 4);
+                acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+            }
+            for (uint32_t i0 = 0; i0 < nd; i0 += 8) {                // eight rows in flight
+                half8 hv[8];
+                float cn[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const hent_t x = hr[min(i0 + e, nd - 1)];
+                    cn[e] = i0 + e < nd ? static_cast<float>(h_cnt(x)) : 0.0f;
+                    hv[e] = *reinterpret_cast<const half8*>(d.lr_coef16_t + static_cast<size_t>(h_prod(x)) * C + cl);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (i0 + e < nd) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] = fmaf(cn[e], static_cast<float>(hv[e][j]), acc[j]);
+                    }
+            }
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = fmaxf(m, acc[j]);
+            if (!in) m = -INFINITY;
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            rb = fmaxf(rb, m);
+            const float cut = rb - thr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool pass = in && acc[j] >= cut;
+                const unsigned long long pm = __ballot(pass);
+                if (pm && !overflow) {
+                    const uint32_t np = static_cast<uint32_t>(__popcll(pm));
+                    if (n_cand + np > 32u) overflow = true;
+                    else {
+                        if (pass) { const uint32_t k = n_cand + prefix_in_mask(pm); s_cand[wave][k] = c + j; s_cval[wave][k] = acc[j]; }
+                        n_cand += np;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // ---- what survives the range's final maximum ----
+        uint32_t* part = d.lr_part + (static_cast<size_t>(w) * kLrSplit + r) * kLrPartWords;
+        const bool mine = !overflow && static_cast<uint32_t>(lane) < n_cand;
+        const bool keep = mine && s_cval[wave][mine ? lane : 0] >= rb - thr;
+        const unsigned long long km = __ballot(keep);
+        uint32_t n_keep = static_cast<uint32_t>(__popcll(km));
+        if (overflow || n_keep > kLrCand) n_keep = 0xFFFFFFFFu;
+        else if (keep) {
+            const uint32_t k = prefix_in_mask(km);
+            part[4 + 2 * k] = s_cand[wave][lane];
+            part[5 + 2 * k] = __builtin_bit_cast(uint32_t, s_cval[wave][lane]);
+        }
+        if (lane == 0) { part[0] = __builtin_bit_cast(uint32_t, rb); part[1] = n_keep; part[2] = __builtin_bit_cast(uint32_t, thr); part[3] = nd; }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_logreg_decide(DevSim d, uint32_t t) {
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t n = d.lr_cnt[t];
+    const uint32_t C = d.lr_n;
+    const uint32_t waves_total = gridDim.x * (kBlock / 64);
+    unsigned long long c_acts = 0, c_rows = 0, c_exact = 0;
+    for (uint32_t w = blockIdx.x * (kBlock / 64) + wave; w < n; w += waves_total) {
+        const uint32_t slot = d.lr_list[w];
+        const uint32_t uidx = d.uid[slot];
+        const hent_t* hr = hist_row(d, slot) + 1;
+        const uint32_t* part = d.lr_part + static_cast<size_t>(w) * kLrSplit * kLrPartWords;
+        // lane = (range, candidate index); the last 64 - kLrSplit kLrCand lanes have no range
+        const uint32_t r_raw = static_cast<uint32_t>(lane) / kLrCand, k = static_cast<uint32_t>(lane) % kLrCand;
+        const bool has_r = r_raw < kLrSplit;
+        const uint32_t r = has_r ? r_raw : 0u;
+        const uint32_t* pr = part + r * kLrPartWords;
+        const float rmax = has_r ? __builtin_bit_cast(float, pr[0]) : -INFINITY;
+        const uint32_t nk = has_r ? pr[1] : 0u;
+        const float thr = __builtin_bit_cast(float, part[2]);
+        const uint32_t nd = part[3];
+        c_acts += 1; c_rows += nd;
+        float gmax = rmax;
+        for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
+        const bool overflow = __ballot(nk == 0xFFFFFFFFu) != 0ull;
+        uint32_t action;
+        if (overflow) { action = logreg_act_wave(d, slot, lane); c_exact += 1; }
+        else {
+            const bool have = k < nk;
+            const uint32_t cc = have ? pr[4 + 2 * k] : 0u;
+            const float cv = have ? __builtin_bit_cast(float, pr[5 + 2 * k]) : -INFINITY;
+            const bool keep = have && cv >= gmax - thr;
+            const unsigned long long km = __ballot(keep);
+            uint32_t best_c = 0xFFFFFFFFu;
+            if (__popcll(km) == 1) best_c = static_cast<uint32_t>(__shfl(static_cast<int>(cc), __builtin_ctzll(km)));
+            else {
+                double sc = -INFINITY;
+                if (keep) {
+                    sc = 0.0;
+                    for (uint32_t i = 0; i < nd; ++i) {
+                        const hent_t x = hr[i];
+                        sc = __dadd_rn(sc, __dmul_rn(static_cast<double>(h_cnt(x)), d.lr_coef_t[static_cast<size_t>(h_prod(x)) * C + cc]));
+                    }
+                    sc = __dadd_rn(sc, d.lr_intercept[cc]);
+                    best_c = cc;
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double os = __shfl_xor(sc, o);
+                    const uint32_t oc = __shfl_xor(best_c, o);
+                    if (oc != 0xFFFFFFFFu && (best_c == 0xFFFFFFFFu || os > sc || (os == sc && oc < best_c))) { sc = os; best_c = oc; }
+                }
+                c_exact += 1;
+            }
+            action = static_cast<uint32_t>(d.lr_classes[best_c]);
+        }
+        if (lane == 0) { d.lr_action[uidx] = action; d.lr_dirty[uidx] = 0; }
+    }
+    if (lane == 0 && c_acts) {
+        atomicAdd(&d.counters[RG_CNT_LR_ACTS], c_acts);
+        atomicAdd(&d.counters[RG_CNT_LR_ROWS], c_rows);
+        if (c_exact) atomicAdd(&d.counters[RG_CNT_LR_EXACT], c_exact);
+    }
+}
+
+__global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, const int32_t* actions) {
+    constexpr int kSub = 1;                     // block iterations that share one reservation
+    __shared__ uint32_t s_cnt_o[kSub][kAdvBlock / 64], s_cnt_b[kSub][kAdvBlock / 64], s_cnt_d[kSub][kAdvBlock / 64], s_base_o, s_base_b, s_base_d;
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const uint32_t n_b = d.step_cnt[2 * t + RG_STATE_BANDIT];
+    const uint32_t n = n_o + n_b;
+    const uint32_t* cur_o = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const uint32_t* cur_b = list_ptr(d, t & 1, RG_STATE_BANDIT);
+    uint32_t* next_o = list_ptr(d, (t + 1) & 1, RG_STATE_ORGANIC);
+    uint32_t* next_b = list_ptr(d, (t + 1) & 1, RG_STATE_BANDIT);
+    uint32_t* next_cnt = d.step_cnt + 2 * (t + 1);
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.log_base[t + 1] = d.log_base[t] + n;
+
+    uint32_t clicks = 0, phantoms = 0;
+    const uint32_t n_iter = (n + kSub * kAdvBlock - 1) / (kSub * kAdvBlock);
+    for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+      int ns_j[kSub];
+      uint32_t slot_j[kSub];
+      unsigned long long mo_j[kSub], mb_j[kSub], md_j[kSub];
+      bool dr_j[kSub];
+      double ds_j[kSub];
+#pragma unroll
+      for (int sub = 0; sub < kSub; ++sub) {
+        const uint32_t i = (it * kSub + sub) * kAdvBlock + threadIdx.x;
+        int ns = RG_STATE_STOP;       // inactive lanes look dead
+        uint32_t slot = 0;
+        bool drift_me = false;
+        double drift_sig = 0.0;
+        uint32_t lr_a = 0;            // RG_POLICY_LOGREG_FROZEN: this user's action for its current view history
+        if (d.policy == RG_POLICY_LOGREG_FROZEN && i < n)
+            // the policy reads only the view history: its act was computed by k_logreg_acts when the history last changed
+            // and serves the bandit event and the phantom row alike
+            lr_a = d.lr_action[d.uid[i < n_o ? cur_o[i] : cur_b[i - n_o]]];
+        if (i < n) {
+            const bool is_org = i < n_o;
+            slot = is_org ? cur_o[i] : cur_b[i - n_o];
+            const uint32_t uidx = d.uid[slot];
+            const uint32_t user = static_cast<uint32_t>(d.first_user + uidx);
+            const rg_u32x4 w = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
+            const double u_trans = rg_uniform(w.w[2], w.w[3]);
+            bool click = false;
+            if (!is_org) {
+                // 97 % of the bandit events cannot click whatever beta[a] . omega is (kNoClickBelow): they read neither row
+                const double u_click = rg_uniform(w.w[0], w.w[1]);
+                const bool need_ctr = d.aux_pclick != nullptr || !(u_click < kNoClickBelow);
+                // Touch the two cache lines of the user's omega row (and the head of its view
+                // history) NOW: they arrive while the policy draws and walks the history, instead
+                // of costing another HBM round trip after it — this kernel is latency-bound.
+                const double* om_row = d.omega + static_cast<size_t>(slot) * d.OMS;
+                double touch0 = 0.0, touch1 = 0.0;
+                if (need_ctr) { touch0 = om_row[0]; touch1 = om_row[d.K - 1]; }
+                // K even and <= 24 (rows are 16-byte aligned): the whole omega row is fetched here as 16-byte
+                // loads and held across the policy, so that only beta's row is left on the critical path
+                const bool pre = d.K <= 24 && !(d.K & 1);
+                double2 wpre[12];
+                if (pre && need_ctr) {
+#pragma unroll
+                    for (int k2 = 0; k2 < 12; ++k2)
+                        wpre[k2] = *reinterpret_cast<const double2*>(om_row + 2 * min(static_cast<uint32_t>(k2), d.K / 2 - 1));
+                }
+                uint32_t touch2 = 0;
+                if (d.hist_cap) touch2 = static_cast<uint32_t>(d.hist[static_cast<size_t>(slot) * d.hist_cap]);
+                // step_offline: the policy acts (abstract.py:202-221), then draw_click
+                double ps;
+                uint32_t a;
+                if (d.policy == RG_POLICY_EXTERNAL) { a = static_cast<uint32_t>(actions[uidx]); ps = __builtin_nan(""); }
+                else if (d.policy == RG_POLICY_LOGREG_FROZEN) { a = lr_a; ps = 1.0; }
+                else a = policy_act(d, slot, user, t, &ps);
+                // beta[a] . omega, k ascending (the oracle's association); loads are issued eight
+                // k at a time — a plain loop leaves one HBM round trip per k on the critical path
+                const double* b = d.beta + static_cast<size_t>(a) * d.K;
+                const double* om = d.omega + static_cast<size_t>(slot) * d.OMS;
+                double x = 0.0;
+                if (!need_ctr) {}
+                else if (pre) {
+                    double2 bpre[12];
+#pragma unroll
+                    for (int k2 = 0; k2 < 12; ++k2)
+                        bpre[k2] = *reinterpret_cast<const double2*>(b + 2 * min(static_cast<uint32_t>(k2), d.K / 2 - 1));
+#pragma unroll
+                    for (int k2 = 0; k2 < 12; ++k2)
+                        if (static_cast<uint32_t>(2 * k2) < d.K) { x += bpre[k2].x * wpre[k2].x; x += bpre[k2].y * wpre[k2].y; }
+                } else
+                for (uint32_t k0 = 0; k0 < d.K; k0 += 8) {
+                    double wv[8], bv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const uint32_t k = min(k0 + i, d.K - 1);
+                        wv[i] = om[k];
+                        bv[i] = b[k];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (k0 + i < d.K) x += bv[i] * wv[i];
+                }
+                asm volatile("" ::"v"(touch0), "v"(touch1), "v"(touch2));   // keeps the early loads alive
+                double ctr = 0.0;
+                if (need_ctr) {
+                    ctr = ff64(x + d.mu_b[a]);
+                    const double p0 = 1.0 - ctr;
+                    click = (p0 / (p0 + ctr)) <= u_click;
+                }
+                clicks += click;
+                const uint64_t row = d.log_base[t] + i;
+                if (d.log && row < d.log_cap) {
+                    rg_event e;
+                    e.u = user; e.t = t;
+                    e.code = RG_EV_BANDIT | (click ? RG_EV_CLICK : 0u) | a;
+                    e.ps = static_cast<float>(ps);
+                    d.log[row] = e;
+                    if (d.aux_ps) d.aux_ps[row] = ps;
+                    if (d.aux_pclick) d.aux_pclick[row] = ctr;
+                    if (d.aux_time) d.aux_time[row] = d.utime[uidx];
+                }
+            }
+            // update_state (reco_env_v1.py:85-100)
+            const double c0 = is_org ? d.cdf_o0 : d.cdf_b0, c1 = is_org ? d.cdf_o1 : d.cdf_b1;
+            ns = (c0 <= u_trans) + (c1 <= u_trans);
+            // NormalTimeGenerator: the clock advances by |mu + sigma z| (normal_time_generator.py:25) and the drift's
+            // standard deviation is scaled by that time delta (1 when it is exactly 0; reco_env_v1.py:91-92)
+            double omega_k = 1.0;
+            if (d.time_mode) {
+                double z0, z1;
+                normal_pair(d.seed, user, t, 0, RG_DRAW_TIME, &z0, &z1);
+                const double dt = fabs(d.time_mu + d.time_sigma * z0);
+                d.utime[uidx] = d.utime[uidx] + dt;
+                omega_k = dt == 0.0 ? 1.0 : dt;
+            }
+            // omega drifts when the DRAWN next state is organic (reco_env_v1.py:95-98; the click override below does not
+            // redraw it): listed for k_drift, which runs right behind this kernel
+            drift_me = d.sigma_omega != 0.0 && (d.change_omega_for_bandits || ns == RG_STATE_ORGANIC);
+            drift_sig = d.sigma_omega * omega_k;
+            if (click) ns = RG_STATE_ORGANIC;          // abstract.py:180-181
+            const bool organic_only = (d.first_user + uidx) < d.organic_only_below;
+            if (organic_only && ns != RG_STATE_ORGANIC) {
+                ns = RG_STATE_STOP;                    // warm-up users end with their first session
+                d.n_events[uidx] = t + 1;
+            } else if (ns == RG_STATE_STOP) {
+                d.n_events[uidx] = t + 1;
+                if (d.policy != RG_POLICY_EXTERNAL) {
+                    // final step_offline(done=True): one more act, reward 0 (abstract.py:223-233,311-316)
+                    double ps = 1.0;
+                    const uint32_t a = d.policy == RG_POLICY_LOGREG_FROZEN ? lr_a : policy_act(d, slot, user, t + 1, &ps);
+                    rg_event e;
+                    e.u = user; e.t = t + 1; e.code = RG_EV_BANDIT | RG_EV_PHANTOM | a;
+                    e.ps = static_cast<float>(ps);
+                    d.phantom[uidx] = e;
+                    d.phantom_ps[uidx] = ps;
+                    if (d.time_mode) d.phantom_time[uidx] = d.utime[uidx];       // (already advanced past the last event)
+                    d.has_phantom[uidx] = 1;
+                    phantoms += 1;
+                }
+            }
+        }
+        ns_j[sub] = ns; slot_j[sub] = slot;
+        mo_j[sub] = __ballot(ns == RG_STATE_ORGANIC);
+        mb_j[sub] = __ballot(ns == RG_STATE_BANDIT);
+        md_j[sub] = __ballot(drift_me);
+        dr_j[sub] = drift_me; ds_j[sub] = drift_sig;
+        if (lane == 0) { s_cnt_o[sub][wave] = __popcll(mo_j[sub]); s_cnt_b[sub][wave] = __popcll(mb_j[sub]); s_cnt_d[sub][wave] = __popcll(md_j[sub]); }
+      }
+        // Ordered compaction of the survivors into next step's lists: ballot + mbcnt inside the
+        // wave, one returning 64-bit atomic per block iteration reserves room in both lists.
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t to = 0, tb = 0, td = 0;
+#pragma unroll
+            for (int sub = 0; sub < kSub; ++sub)
+#pragma unroll
+                for (int w2 = 0; w2 < kAdvBlock / 64; ++w2) { to += s_cnt_o[sub][w2]; tb += s_cnt_b[sub][w2]; td += s_cnt_d[sub][w2]; }
+            s_base_d = td ? atomicAdd(&d.drift_cnt[t], td) : 0u;
+            // step_cnt[t+1] = {organic, bandit} is an aligned u32 pair: reserve both lists at once
+            unsigned long long base = 0;
+            if (to | tb)
+                base = atomicAdd(reinterpret_cast<unsigned long long*>(next_cnt),
+                                 static_cast<unsigned long long>(to) | (static_cast<unsigned long long>(tb) << 32));
+            s_base_o = static_cast<uint32_t>(base);
+            s_base_b = static_cast<uint32_t>(base >> 32);
+        }
+        __syncthreads();
+        uint32_t off_o = s_base_o, off_b = s_base_b, off_d = s_base_d;
+#pragma unroll
+        for (int sub = 0; sub < kSub; ++sub) {
+            uint32_t wo = off_o, wb = off_b, wd = off_d;
+            for (int w2 = 0; w2 < wave; ++w2) { wo += s_cnt_o[sub][w2]; wb += s_cnt_b[sub][w2]; wd += s_cnt_d[sub][w2]; }
+            if (ns_j[sub] == RG_STATE_ORGANIC) next_o[wo + prefix_in_mask(mo_j[sub])] = slot_j[sub];
+            if (ns_j[sub] == RG_STATE_BANDIT) next_b[wb + prefix_in_mask(mb_j[sub])] = slot_j[sub];
+            if (dr_j[sub]) {
+                const uint32_t e = wd + prefix_in_mask(md_j[sub]);
+                d.drift_list[e] = slot_j[sub];
+                if (d.time_mode) d.drift_sig[e] = ds_j[sub];
+            }
+#pragma unroll
+            for (int w2 = 0; w2 < kAdvBlock / 64; ++w2) { off_o += s_cnt_o[sub][w2]; off_b += s_cnt_b[sub][w2]; off_d += s_cnt_d[sub][w2]; }
+        }
+        __syncthreads();
+    }
+    // counters: one atomic per wave per kernel
+    for (int o = 32; o > 0; o >>= 1) { clicks += __shfl_xor(clicks, o); phantoms += __shfl_xor(phantoms, o); }
+    if (lane == 0) {
+        if (clicks) atomicAdd(&d.counters[RG_CNT_CLICKS], static_cast<unsigned long long>(clicks));
+        if (phantoms) atomicAdd(&d.counters[RG_CNT_PHANTOM], static_cast<unsigned long long>(phantoms));
+    }
+}
+
+// k_drift — omega <- omega + sigma_omega (time delta) Z(K) (reco_env_v1.py:95-98) of the users k_advance listed at step t: a lane per
+// (user, Box-Muller pair), the K normals addressed by (user, t, pair) as everywhere else.
+__global__ void __launch_bounds__(kBlock) k_drift(DevSim d, uint32_t t) {
+    const uint32_t n = d.drift_cnt[t];
+    const uint32_t KP = (d.K + 1) / 2;
+    const uint64_t items = static_cast<uint64_t>(n) * KP;
+    for (uint64_t it = blockIdx.x * static_cast<uint64_t>(kBlock) + threadIdx.x; it < items; it += static_cast<uint64_t>(gridDim.x) * kBlock) {
+        const uint32_t e = static_cast<uint32_t>(it / KP), j = static_cast<uint32_t>(it % KP);
+        const uint32_t slot = d.drift_list[e];
+        const uint32_t user = static_cast<uint32_t>(d.first_user + d.uid[slot]);
+        const double sig = d.time_mode ? d.drift_sig[e] : d.sigma_omega;
+        double z0, z1;
+        normal_pair(d.seed, user, t, j, RG_DRAW_DRIFT, &z0, &z1);
+        double* o0 = d.omega + static_cast<size_t>(slot) * d.OMS + 2 * j;
+        *o0 = *o0 + sig * z0;
+        if (2 * j + 1 < d.K) { double* o1 = o0 + 1; *o1 = *o1 + sig * z1; }
+    }
+}
+search_kernel_t drift_kernel() { return k_drift; }
+
+__global__ void __launch_bounds__(kBlock) k_tail(DevSim d, uint32_t t0) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* om = reinterpret_cast<double*>(smem_raw);                       // [K rounded up to 2]
+    double* csum = om + ((d.K + 1) & ~1u);                                   // [n_chunks rounded up to 4]
+    __shared__ uint32_t s_next, s_v;
+    __shared__ int s_state, s_drift;
+    __shared__ double s_max[kBlock / 64];
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t n_o = d.step_cnt[2 * t0 + RG_STATE_ORGANIC], n_b = d.step_cnt[2 * t0 + RG_STATE_BANDIT];
+    const uint32_t n = n_o + n_b;
+    const uint32_t n_chunks = d.PT / 64;
+    const uint32_t* cur_o = list_ptr(d, t0 & 1, RG_STATE_ORGANIC);
+    const uint32_t* cur_b = list_ptr(d, t0 & 1, RG_STATE_BANDIT);
+    unsigned long long c_org = 0, c_ban = 0, c_clicks = 0, c_ph = 0;          // thread 0 only
+    uint32_t c_maxt = 0;
+
+    // block maximum of the logits (pass 0) or chunk sums of exp(l - ref) into csum + that maximum
+    auto sweep = [&](bool sums, double ref) -> double {
+        double wmax = -INFINITY;
+        for (uint32_t g = wave; g * 4 < n_chunks; g += kBlock / 64) {
+            double l[4];
+            logit64x4(d, om, g * 256 + lane, l);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                wmax = fmax(wmax, l[u]);
+                if (sums) {
+                    const double sm = wave_sum(exp64(l[u] - ref));
+                    if (lane == 0) csum[g * 4 + u] = sm;                     // chunks past P: every logit -inf -> 0
+                }
+            }
+        }
+        wmax = wave_max(wmax);
+        __syncthreads();                       // s_max of the previous sweep has been read
+        if (lane == 0) s_max[wave] = wmax;
+        __syncthreads();
+        double m = s_max[0];
+        for (int w2 = 1; w2 < kBlock / 64; ++w2) m = fmax(m, s_max[w2]);
+        return m;
+    };
+
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_next = static_cast<uint32_t>(atomicAdd(&d.counters[kCntTailTicket], 1ull));
+        __syncthreads();
+        const uint32_t i = s_next;
+        if (i >= n) break;
+        const uint32_t slot = i < n_o ? cur_o[i] : cur_b[i - n_o];
+        int state = i < n_o ? RG_STATE_ORGANIC : RG_STATE_BANDIT;
+        const uint32_t uidx = d.uid[slot];
+        const uint32_t user = static_cast<uint32_t>(d.first_user + uidx);
+        for (uint32_t k = threadIdx.x; k < d.K; k += kBlock) om[k] = d.omega[static_cast<size_t>(slot) * d.OMS + k];
+        bool have_ref = false;
+        double Mref = 0.0;
+        __syncthreads();
+        for (uint32_t t = t0;; ++t) {
+            const rg_u32x4 w = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
+            if (state == RG_STATE_ORGANIC) {
+                // ---- organic product draw, float64 across the block ----
+                if (!have_ref) { Mref = sweep(false, 0.0); have_ref = true; }
+                double m = sweep(true, Mref);
+                // any shift near the maximum gives the same decisions (1e-16 level); if omega drifted
+                // the kept reference far from it, take the sums again with the fresh one
+                if (!(fabs(m - Mref) <= 400.0)) { Mref = m; m = sweep(true, Mref); }
+                if (wave == 0) {
+                    double total = 0.0;
+                    for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64) {
+                        const uint32_t c = c0 + lane;
+                        total += __shfl(wave_scan(c < n_chunks ? csum[c] : 0.0, lane), 63);
+                    }
+                    const double target = rg_uniform(w.w[0], w.w[1]) * total;
+                    uint32_t cstar = n_chunks - 1;
+                    double before = 0.0, run = 0.0;
+                    bool found = false;
+                    for (uint32_t c0 = 0; c0 < n_chunks && !found; c0 += 64) {
+                        const uint32_t c = c0 + lane;
+                        const double x = c < n_chunks ? csum[c] : 0.0;
+                        const double incl = wave_scan(x, lane);
+                        const unsigned long long hit = __ballot(c < n_chunks && run + incl > target);
+                        if (hit) {
+                            const int L = __builtin_ctzll(hit);
+                            cstar = c0 + L;
+                            before = run + __shfl(incl - x, L);
+                            found = true;
+                        } else run += __shfl(incl, 63);
+                    }
+                    if (!found) before = run - csum[n_chunks - 1];
+                    const uint32_t p = cstar * 64 + lane;
+                    double lg = 0.0;
+                    const double* g = d.gammaT + p;
+                    for (uint32_t k = 0; k < d.K; ++k) lg += g[static_cast<size_t>(k) * d.PT] * om[k];
+                    lg = p < d.P ? lg + d.mu_o[p] : -INFINITY;
+                    const double incl = wave_scan(exp64(lg - Mref), lane);
+                    const unsigned long long hit = __ballot(p < d.P && before + incl > target);
+                    const uint32_t v = hit ? cstar * 64 + static_cast<uint32_t>(__builtin_ctzll(hit))
+                                           : min(cstar * 64 + 63, d.P - 1);
+                    if (lane == 0) s_v = v;
+                }
+                Mref = m;                                  // reference of this user's next draw
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                if (t > t0) { if (state == RG_STATE_ORGANIC) c_org += 1; else c_ban += 1; }
+                const double u_trans = rg_uniform(w.w[2], w.w[3]);
+                bool click = false;
+                if (state == RG_STATE_ORGANIC) {
+                    const uint32_t v = s_v;
+                    const uint64_t row = d.log_base[t0] + atomicAdd(&d.counters[kCntTailRows], 1ull);
+                    if (d.log && row < d.log_cap) {
+                        rg_event e;
+                        e.u = user; e.t = t; e.code = v; e.ps = __builtin_nanf("");
+                        d.log[row] = e;
+                    }
+                    if (d.lpv) d.lpv[slot] = v;
+                    if (d.hist_cap) history_add(d, slot, v);
+                } else {
+                    double ps;
+                    const uint32_t a = policy_act(d, slot, user, t, &ps);
+                    double ctr = 0.0;
+                    click = false;
+                    if (d.aux_pclick || !(rg_uniform(w.w[0], w.w[1]) < kNoClickBelow)) {
+                        const double* b = d.beta + static_cast<size_t>(a) * d.K;
+                        double x = 0.0;
+                        for (uint32_t k = 0; k < d.K; ++k) x += b[k] * om[k];
+                        ctr = ff64(x + d.mu_b[a]);
+                        const double p0 = 1.0 - ctr;
+                        click = (p0 / (p0 + ctr)) <= rg_uniform(w.w[0], w.w[1]);
+                    }
+                    c_clicks += click;
+                    const uint64_t row = d.log_base[t0] + atomicAdd(&d.counters[kCntTailRows], 1ull);
+                    if (d.log && row < d.log_cap) {
+                        rg_event e;
+                        e.u = user; e.t = t;
+                        e.code = RG_EV_BANDIT | (click ? RG_EV_CLICK : 0u) | a;
+                        e.ps = static_cast<float>(ps);
+                        d.log[row] = e;
+                        if (d.aux_ps) d.aux_ps[row] = ps;
+                        if (d.aux_pclick) d.aux_pclick[row] = ctr;
+                    }
+                }
+                const double c0 = state == RG_STATE_ORGANIC ? d.cdf_o0 : d.cdf_b0;
+                const double c1 = state == RG_STATE_ORGANIC ? d.cdf_o1 : d.cdf_b1;
+                int ns = (c0 <= u_trans) + (c1 <= u_trans);
+                s_drift = d.sigma_omega != 0.0 && (d.change_omega_for_bandits || ns == RG_STATE_ORGANIC);
+                if (click) ns = RG_STATE_ORGANIC;
+                const bool organic_only = (d.first_user + uidx) < d.organic_only_below;
+                if (organic_only && ns != RG_STATE_ORGANIC) {
+                    ns = RG_STATE_STOP;
+                    d.n_events[uidx] = t + 1;
+                } else if (ns == RG_STATE_STOP) {
+                    d.n_events[uidx] = t + 1;
+                    double ps;
+                    const uint32_t a = policy_act(d, slot, user, t + 1, &ps);
+                    rg_event e;
+                    e.u = user; e.t = t + 1; e.code = RG_EV_BANDIT | RG_EV_PHANTOM | a;
+                    e.ps = static_cast<float>(ps);
+                    d.phantom[uidx] = e;
+                    d.phantom_ps[uidx] = ps;
+                    d.has_phantom[uidx] = 1;
+                    c_ph += 1;
+                } else if (t + 2 >= kMaxSteps) {
+                    ns = RG_STATE_STOP;                    // same bound as the lock-step loop; reported by the host
+                    d.n_events[uidx] = t + 1;
+                    atomicAdd(&d.counters[kCntTailLimit], 1ull);
+                }
+                if (ns == RG_STATE_STOP) c_maxt = max(c_maxt, t + 1);
+                s_state = ns;
+            }
+            __syncthreads();
+            state = s_state;
+            if (s_drift && state != RG_STATE_STOP) {
+                // omega drift of this step (k_advance applies it before the click override, which
+                // only changes the state) — pair j by thread j
+                for (uint32_t j = threadIdx.x; 2 * j < d.K; j += kBlock) {
+                    double z0, z1;
+                    normal_pair(d.seed, user, t, j, RG_DRAW_DRIFT, &z0, &z1);
+                    om[2 * j] = om[2 * j] + d.sigma_omega * z0;
+                    if (2 * j + 1 < d.K) om[2 * j + 1] = om[2 * j + 1] + d.sigma_omega * z1;
+                }
+            }
+            __syncthreads();
+            if (state == RG_STATE_STOP) break;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (c_org) atomicAdd(&d.counters[kCntTailOrganic], c_org);
+        if (c_ban) atomicAdd(&d.counters[kCntTailBandit], c_ban);
+        if (c_clicks) atomicAdd(&d.counters[RG_CNT_CLICKS], c_clicks);
+        if (c_ph) atomicAdd(&d.counters[RG_CNT_PHANTOM], c_ph);
+        if (c_maxt) atomicMax(&d.counters[kCntTailMaxT], static_cast<unsigned long long>(c_maxt));
+    }
+}
+search_kernel_t logreg_select_kernel() { return k_logreg_select; }
+search_kernel_t logreg_acts_kernel() { return k_logreg_acts; }
+search_kernel_t logreg_screen_kernel() { return k_logreg_screen; }
+search_kernel_t logreg_decide_kernel() { return k_logreg_decide; }
+advance_kernel_t advance_kernel() { return k_advance; }
+search_kernel_t tail_kernel() { return k_tail; }
+
+}  // namespace rgk

@@ -1,5 +1,5 @@
 """The error budget the certificate grants the two-way fp16 operand split (DESIGN.md §2,
-`f16_extra_delta` in recogym_hip.hip), checked numerically on the host: the device forms
+`f16_extra_delta` in recogym_amd/csrc/rg_common.hpp / rg_draw_pipelined.hip), checked numerically on the host: the device forms
 l = sum_k (h1(g) h1(w) + h2(g) h1(w) + h1(g) h2(w)) with exact products and fp32 accumulation; here
 the same three terms are summed exactly (float64 holds fp16 x fp16 products exactly), so what is
 measured is the REPRESENTATION error the split adds on top of the accumulation budget."""
@@ -43,7 +43,7 @@ def test_fp16_pieces_reconstruct_fp32():
 
 @pytest.mark.parametrize('P, K, sigma_mu, scale', [(10000, 20, 3.0, 1.0), (2000, 20, 3.0, 2.5), (3000, 64, 3.0, 1.0), (500, 5, 30.0, 0.3)])
 def test_joint_logit_bound_dominates_every_partial_sum(P, K, sigma_mu, scale):
-    """`ahat_of` (recogym_hip.hip): the bound the certificate's accumulation budget (K + 5) 2^-24 Ahat is proportional to.
+    """`ahat_of` (rg_common.hpp): the bound the certificate's accumulation budget (K + 5) 2^-24 Ahat is proportional to.
     Restated here: max_p (|mu_p| + ||Gamma_p||_2 r) read off a grid of r = (i + 1) / 4 at the grid point at or above
     ||omega||_2 (and the two older bounds).  It must dominate |mu_p + sum_{k <= j} Gamma_pk omega_k| for every product p and
     every partial sum j, and it should be visibly tighter than taking the two maxima separately."""
@@ -70,12 +70,12 @@ def test_joint_logit_bound_dominates_every_partial_sum(P, K, sigma_mu, scale):
 
 
 def test_no_click_threshold_is_below_every_click_boundary():
-    """kNoClickBelow (recogym_hip.hip): a bandit event whose uniform is below it cannot click, whatever beta[a].omega is.
+    """kNoClickBelow (rg_common.hpp): a bandit event whose uniform is below it cannot click, whatever beta[a].omega is.
     The reference's draw (reco_env_v1.py:38-41, 104-116): ctr = ff(x) = sig(5 sig(2 sig(0.3 x) - 2) - 6) and
     choice([0, 1], p=[1 - ctr, ctr]) = [u >= cdf[0]], cdf = cumsum(p) / cumsum(p)[-1].  Checked here: the constant in the
     source, the range of ff over the whole float64 line, and numpy's own boundary for the largest ctr."""
     import os, re
-    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'recogym_amd', 'csrc', 'recogym_hip.hip')).read()
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'recogym_amd', 'csrc', 'rg_common.hpp')).read()
     thr = float(re.search(r'constexpr double kNoClickBelow = ([0-9.]+);', src).group(1))
     sig = lambda x: 1.0 / (1.0 + np.exp(-x))
     ff = lambda x: sig(5.0 * sig(2.0 * sig(0.3 * x) - 2.0) - 6.0)
@@ -92,7 +92,7 @@ def test_no_click_threshold_is_below_every_click_boundary():
 
 
 def _cert_correlated(S, A, a, b, delta):
-    """Host restatement of cert_correlated (recogym_hip.hip): -> (num_lo, den_lo, num_hi, den_hi, valid)."""
+    """Host restatement of cert_correlated (rg_common.hpp): -> (num_lo, den_lo, num_hi, den_hi, valid)."""
     dp = delta * (1.0 + 2.0 * delta)
     rho = 2.0 ** -20 * 1.001 * S
     T = S - A

@@ -1,16 +1,18 @@
-"""Where a kernel's register spills are: hipcc -gline-tables-only -save-temps on one translation-unit part, scratch_* instructions
+"""Where a kernel's register spills are: hipcc -gline-tables-only -save-temps on one translation unit (1 .. 7: rg_host, rg_exact, rg_draw_fp32, rg_draw_pipelined, rg_draw_wide, rg_advance, rg_walk), scratch_* instructions
 of the chosen kernel mapped to the source lines they were generated for.
     python tools/spill_map.py <part 1..7> <regex of the mangled kernel name> [loop-start-text loop-end-text]
 e.g. python tools/spill_map.py 5 'k_draw_f16wILi32ELi13ELi1E' 'for (uint32_t ti = pt_lo; ti < pt_hi; ++ti) {' "the last pair's own sums"
 """
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, 'recogym_amd', 'csrc', 'recogym_hip.hip')
+UNITS = ['rg_host', 'rg_exact', 'rg_draw_fp32', 'rg_draw_pipelined', 'rg_draw_wide', 'rg_advance', 'rg_walk']
 part, pat = sys.argv[1], sys.argv[2]
+unit = UNITS[int(part) - 1]
+SRC = os.path.join(ROOT, 'recogym_amd', 'csrc', unit + '.hip')
 tmp = tempfile.mkdtemp()
-subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', f'-DRG_PART={part}', '-gline-tables-only',
+subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-gline-tables-only',
                 '-save-temps', '-c', '-o', 'x.o', SRC], cwd=tmp, stderr=subprocess.DEVNULL, check=True)
-txt = open(os.path.join(tmp, 'recogym_hip-hip-amdgcn-amd-amdhsa-gfx950.s')).read()
+txt = open(os.path.join(tmp, unit + '-hip-amdgcn-amd-amdhsa-gfx950.s')).read()
 m = re.search(r'^(_Z\w*' + pat + r'\w*):(.*?)\.Lfunc_end', txt, re.S | re.M)
 print('kernel', m.group(1))
 src = open(SRC).read().split('\n')
