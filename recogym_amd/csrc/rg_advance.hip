@@ -32,12 +32,13 @@ __global__ void __launch_bounds__(kBlock) k_logreg_select(DevSim d, uint32_t t) 
             const uint32_t uidx = d.uid[slot];
             need = d.lr_dirty[uidx] != 0;
             if (need && is_org) {
-                // an organic user needs an act only for its phantom row: when this step's transition stops it
+                // an organic user needs an act only for its phantom row: when this step's transition stops it — and, in run-ahead
+                // rounds, when the transition starts a bandit run (k_advance_run takes the user through it in this round)
                 const uint32_t user = static_cast<uint32_t>(d.first_user + uidx);
-                const rg_u32x4 w = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
+                const rg_u32x4 w = rg_draw(d.seed, user, d.run_ahead ? d.ev[uidx] : t, 0, RG_DRAW_EVENT);
                 const double u_trans = rg_uniform(w.w[2], w.w[3]);
                 const int ns = (d.cdf_o0 <= u_trans) + (d.cdf_o1 <= u_trans);
-                need = ns == RG_STATE_STOP && !((d.first_user + uidx) < d.organic_only_below);
+                need = (ns == RG_STATE_STOP || (d.run_ahead && ns == RG_STATE_BANDIT)) && !((d.first_user + uidx) < d.organic_only_below);
             }
         }
         const unsigned long long m = __ballot(need);
@@ -482,6 +483,223 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_advance_run — k_advance for run-ahead rounds (rg_sim_run to the end; DevSim::run_ahead): a lane takes its user from the event the
+// round found it at — an organic event the sweep has just drawn, or a bandit event — through every following event that needs
+// nothing from another kernel: omega only moves when a transition draws "organic" (reco_env_v1.py:95-98, change_omega_for_bandits
+// off), the view history and the last viewed product only at organic events, so a whole bandit run (~17 events) is this lane's
+// alone.  The round ends for the user at the first event whose drawn next state is not "bandit" (organic: the next round's sweep
+// draws the product; stop), at a bandit event whose uniform can click (kNoClickBelow: 3 % of them — a click sends the user
+// organic), or after `hops` events.
+//   pass 1  the event draws only (one Philox block per event): how many events L the lane takes this round -> its bandit rows;
+//           a block prefix sum and ONE atomic reserve the block's rows: every raw row is used, in user order per lane;
+//   pass 2  the events themselves, as k_advance does them (act, click, row, clock, transition), event index ev[user] + h.
+// The lists, the drift list and the per-round counters are k_advance's; ev[user] moves on by L.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kAdvBlock) k_advance_run(DevSim d, uint32_t t, uint32_t hops) {
+    constexpr int NW = kAdvBlock / 64;
+    __shared__ uint32_t s_cnt_o[NW], s_cnt_b[NW], s_cnt_d[NW], s_rows[NW], s_base_o, s_base_b, s_base_d;
+    __shared__ unsigned long long s_row0;
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const uint32_t n_b = d.step_cnt[2 * t + RG_STATE_BANDIT];
+    const uint32_t n = n_o + n_b;
+    const uint32_t* cur_o = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const uint32_t* cur_b = list_ptr(d, t & 1, RG_STATE_BANDIT);
+    uint32_t* next_o = list_ptr(d, (t + 1) & 1, RG_STATE_ORGANIC);
+    uint32_t* next_b = list_ptr(d, (t + 1) & 1, RG_STATE_BANDIT);
+    uint32_t* next_cnt = d.step_cnt + 2 * (t + 1);
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+
+    uint32_t clicks = 0, phantoms = 0, extra = 0, max_t = 0;
+    const uint32_t n_iter = (n + kAdvBlock - 1) / kAdvBlock;
+    for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+        const uint32_t i = it * kAdvBlock + threadIdx.x;
+        const bool live = i < n;
+        const bool is_org = i < n_o;
+        uint32_t slot = 0, uidx = 0, user = 0, te0 = 0, L = 0;
+        bool organic_only = false;
+        // ---- pass 1: how far this round takes the user
+        if (live) {
+            slot = is_org ? cur_o[i] : cur_b[i - n_o];
+            uidx = d.uid[slot];
+            user = static_cast<uint32_t>(d.first_user + uidx);
+            te0 = d.ev[uidx];
+            organic_only = (d.first_user + uidx) < d.organic_only_below;
+            bool org = is_org;
+            for (;;) {
+                const rg_u32x4 w = rg_draw(d.seed, user, te0 + L, 0, RG_DRAW_EVENT);
+                const double u_trans = rg_uniform(w.w[2], w.w[3]);
+                const double c0 = org ? d.cdf_o0 : d.cdf_b0, c1 = org ? d.cdf_o1 : d.cdf_b1;
+                const int ns = (c0 <= u_trans) + (c1 <= u_trans);
+                L += 1;
+                if (!org && !(rg_uniform(w.w[0], w.w[1]) < kNoClickBelow)) break;      // may click: the round's last event
+                if (ns != RG_STATE_BANDIT || organic_only || L >= hops) break;
+                org = false;
+            }
+        }
+        const uint32_t n_rows = L - ((live && is_org) ? 1u : 0u);       // the organic event's row is the sweep's
+        uint32_t incl = n_rows;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) s_rows[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long tot = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) tot += s_rows[w2];
+            s_row0 = tot ? atomicAdd(&d.run_ctl[0], tot) : 0ull;
+        }
+        __syncthreads();
+        uint64_t row = s_row0 + incl - n_rows;
+        for (int w2 = 0; w2 < wave; ++w2) row += s_rows[w2];
+
+        // ---- pass 2: the events
+        int ns = RG_STATE_STOP;       // inactive lanes look dead
+        bool drift_me = false;
+        double drift_sig = 0.0;
+        if (live) {
+            const uint32_t lr_a = d.policy == RG_POLICY_LOGREG_FROZEN ? d.lr_action[uidx] : 0u;   // one act serves the whole run
+            const double* om = d.omega + static_cast<size_t>(slot) * d.OMS;
+            double clock = d.time_mode ? d.utime[uidx] : 0.0;
+            bool org = is_org, click = false;
+            for (uint32_t h = 0; h < L; ++h) {
+                const uint32_t te = te0 + h;
+                const rg_u32x4 w = rg_draw(d.seed, user, te, 0, RG_DRAW_EVENT);
+                const double u_trans = rg_uniform(w.w[2], w.w[3]);
+                click = false;
+                if (!org) {
+                    const double u_click = rg_uniform(w.w[0], w.w[1]);
+                    const bool need_ctr = d.aux_pclick != nullptr || !(u_click < kNoClickBelow);
+                    double ps;
+                    uint32_t a;
+                    if (d.policy == RG_POLICY_LOGREG_FROZEN) { a = lr_a; ps = 1.0; }
+                    else a = policy_act(d, slot, user, te, &ps);
+                    double ctr = 0.0;
+                    if (need_ctr) {
+                        // beta[a] . omega, k ascending (the oracle's association), loads eight k at a time
+                        const double* b = d.beta + static_cast<size_t>(a) * d.K;
+                        double x = 0.0;
+                        for (uint32_t k0 = 0; k0 < d.K; k0 += 8) {
+                            double wv[8], bv[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const uint32_t k = min(k0 + q, d.K - 1);
+                                wv[q] = om[k];
+                                bv[q] = b[k];
+                            }
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                if (k0 + q < d.K) x += bv[q] * wv[q];
+                        }
+                        ctr = ff64(x + d.mu_b[a]);
+                        const double p0 = 1.0 - ctr;
+                        click = (p0 / (p0 + ctr)) <= u_click;
+                    }
+                    clicks += click;
+                    if (d.log && row < d.log_cap) {
+                        rg_event e;
+                        e.u = user; e.t = te;
+                        e.code = RG_EV_BANDIT | (click ? RG_EV_CLICK : 0u) | a;
+                        e.ps = static_cast<float>(ps);
+                        d.log[row] = e;
+                        if (d.aux_ps) d.aux_ps[row] = ps;
+                        if (d.aux_pclick) d.aux_pclick[row] = ctr;
+                        if (d.aux_time) d.aux_time[row] = clock;
+                    }
+                    row += 1;
+                }
+                // update_state (reco_env_v1.py:85-100)
+                const double c0 = org ? d.cdf_o0 : d.cdf_b0, c1 = org ? d.cdf_o1 : d.cdf_b1;
+                ns = (c0 <= u_trans) + (c1 <= u_trans);
+                double omega_k = 1.0;
+                if (d.time_mode) {
+                    double z0, z1;
+                    normal_pair(d.seed, user, te, 0, RG_DRAW_TIME, &z0, &z1);
+                    const double dt = fabs(d.time_mu + d.time_sigma * z0);
+                    clock = clock + dt;
+                    omega_k = dt == 0.0 ? 1.0 : dt;
+                }
+                drift_me = d.sigma_omega != 0.0 && (d.change_omega_for_bandits || ns == RG_STATE_ORGANIC);
+                drift_sig = d.sigma_omega * omega_k;
+                org = false;          // whatever follows in this round is a bandit event
+            }
+            if (d.time_mode) d.utime[uidx] = clock;
+            const uint32_t t_last = te0 + L - 1u;
+            d.ev[uidx] = te0 + L;
+            extra += L - 1u;
+            if (click) ns = RG_STATE_ORGANIC;          // abstract.py:180-181
+            if (organic_only && ns != RG_STATE_ORGANIC) {
+                ns = RG_STATE_STOP;                    // warm-up users end with their first session
+                d.n_events[uidx] = t_last + 1;
+                max_t = max(max_t, t_last + 1);
+            } else if (ns == RG_STATE_STOP) {
+                d.n_events[uidx] = t_last + 1;
+                max_t = max(max_t, t_last + 1);
+                // final step_offline(done=True): one more act, reward 0 (abstract.py:223-233,311-316)
+                double ps = 1.0;
+                const uint32_t a = d.policy == RG_POLICY_LOGREG_FROZEN ? lr_a : policy_act(d, slot, user, t_last + 1, &ps);
+                rg_event e;
+                e.u = user; e.t = t_last + 1; e.code = RG_EV_BANDIT | RG_EV_PHANTOM | a;
+                e.ps = static_cast<float>(ps);
+                d.phantom[uidx] = e;
+                d.phantom_ps[uidx] = ps;
+                if (d.time_mode) d.phantom_time[uidx] = clock;
+                d.has_phantom[uidx] = 1;
+                phantoms += 1;
+            }
+        }
+        // ordered compaction of the survivors into the next round's lists (as k_advance)
+        const unsigned long long mo = __ballot(ns == RG_STATE_ORGANIC), mb = __ballot(ns == RG_STATE_BANDIT), md = __ballot(drift_me);
+        if (lane == 0) { s_cnt_o[wave] = __popcll(mo); s_cnt_b[wave] = __popcll(mb); s_cnt_d[wave] = __popcll(md); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t to = 0, tb = 0, td = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) { to += s_cnt_o[w2]; tb += s_cnt_b[w2]; td += s_cnt_d[w2]; }
+            s_base_d = td ? atomicAdd(&d.drift_cnt[t], td) : 0u;
+            unsigned long long base = 0;
+            if (to | tb)
+                base = atomicAdd(reinterpret_cast<unsigned long long*>(next_cnt),
+                                 static_cast<unsigned long long>(to) | (static_cast<unsigned long long>(tb) << 32));
+            s_base_o = static_cast<uint32_t>(base);
+            s_base_b = static_cast<uint32_t>(base >> 32);
+        }
+        __syncthreads();
+        uint32_t wo = s_base_o, wb = s_base_b, wd = s_base_d;
+        for (int w2 = 0; w2 < wave; ++w2) { wo += s_cnt_o[w2]; wb += s_cnt_b[w2]; wd += s_cnt_d[w2]; }
+        if (ns == RG_STATE_ORGANIC) next_o[wo + prefix_in_mask(mo)] = slot;
+        if (ns == RG_STATE_BANDIT) next_b[wb + prefix_in_mask(mb)] = slot;
+        if (drift_me) {
+            const uint32_t e = wd + prefix_in_mask(md);
+            d.drift_list[e] = slot;
+            if (d.time_mode) d.drift_sig[e] = drift_sig;
+        }
+        __syncthreads();
+    }
+    // counters: one atomic per wave per kernel (the events beyond a listed user's first are bandit events no list counts)
+    for (int o = 32; o > 0; o >>= 1) {
+        clicks += __shfl_xor(clicks, o); phantoms += __shfl_xor(phantoms, o); extra += __shfl_xor(extra, o);
+        max_t = max(max_t, static_cast<uint32_t>(__shfl_xor(static_cast<int>(max_t), o)));
+    }
+    if (lane == 0) {
+        if (clicks) atomicAdd(&d.counters[RG_CNT_CLICKS], static_cast<unsigned long long>(clicks));
+        if (phantoms) atomicAdd(&d.counters[RG_CNT_PHANTOM], static_cast<unsigned long long>(phantoms));
+        if (extra) atomicAdd(&d.counters[kCntTailBandit], static_cast<unsigned long long>(extra));
+        if (max_t) atomicMax(&d.counters[kCntTailMaxT], static_cast<unsigned long long>(max_t));
+    }
+}
+
+// the raw-log books of run-ahead rounds: round r's rows are [log_base[r], log_base[r + 1]) = the sweep's organic rows (position in
+// the organic list) and then the bandit rows k_advance_run reserved; one thread, before round 0 and after every k_advance_run
+__global__ void k_round_rows(DevSim d, uint32_t t, uint32_t begin) {
+    if (begin) { d.run_ctl[0] = d.log_base[0] + d.step_cnt[RG_STATE_ORGANIC]; return; }
+    const unsigned long long next = d.run_ctl[0];
+    d.log_base[t + 1] = next;
+    d.run_ctl[0] = next + d.step_cnt[2 * (t + 1) + RG_STATE_ORGANIC];
+}
+
 // k_drift — omega <- omega + sigma_omega (time delta) Z(K) (reco_env_v1.py:95-98) of the users k_advance listed at step t: a lane per
 // (user, Box-Muller pair), the K normals addressed by (user, t, pair) as everywhere else.
 __global__ void __launch_bounds__(kBlock) k_drift(DevSim d, uint32_t t) {
@@ -491,10 +709,12 @@ __global__ void __launch_bounds__(kBlock) k_drift(DevSim d, uint32_t t) {
     for (uint64_t it = blockIdx.x * static_cast<uint64_t>(kBlock) + threadIdx.x; it < items; it += static_cast<uint64_t>(gridDim.x) * kBlock) {
         const uint32_t e = static_cast<uint32_t>(it / KP), j = static_cast<uint32_t>(it % KP);
         const uint32_t slot = d.drift_list[e];
-        const uint32_t user = static_cast<uint32_t>(d.first_user + d.uid[slot]);
+        const uint32_t uidx = d.uid[slot];
+        const uint32_t user = static_cast<uint32_t>(d.first_user + uidx);
         const double sig = d.time_mode ? d.drift_sig[e] : d.sigma_omega;
         double z0, z1;
-        normal_pair(d.seed, user, t, j, RG_DRAW_DRIFT, &z0, &z1);
+        // run-ahead rounds: the drifting event is the last one k_advance_run took the user through
+        normal_pair(d.seed, user, d.run_ahead ? d.ev[uidx] - 1u : t, j, RG_DRAW_DRIFT, &z0, &z1);
         double* o0 = d.omega + static_cast<size_t>(slot) * d.OMS + 2 * j;
         *o0 = *o0 + sig * z0;
         if (2 * j + 1 < d.K) { double* o1 = o0 + 1; *o1 = *o1 + sig * z1; }
@@ -556,7 +776,8 @@ __global__ void __launch_bounds__(kBlock) k_tail(DevSim d, uint32_t t0) {
         bool have_ref = false;
         double Mref = 0.0;
         __syncthreads();
-        for (uint32_t t = t0;; ++t) {
+        const uint32_t t_first = d.run_ahead ? d.ev[uidx] : t0;      // run-ahead rounds: the user's own event index
+        for (uint32_t t = t_first;; ++t) {
             const rg_u32x4 w = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
             if (state == RG_STATE_ORGANIC) {
                 // ---- organic product draw, float64 across the block ----
@@ -603,7 +824,7 @@ __global__ void __launch_bounds__(kBlock) k_tail(DevSim d, uint32_t t0) {
                 __syncthreads();
             }
             if (threadIdx.x == 0) {
-                if (t > t0) { if (state == RG_STATE_ORGANIC) c_org += 1; else c_ban += 1; }
+                if (t > t_first) { if (state == RG_STATE_ORGANIC) c_org += 1; else c_ban += 1; }
                 const double u_trans = rg_uniform(w.w[2], w.w[3]);
                 bool click = false;
                 if (state == RG_STATE_ORGANIC) {
@@ -698,6 +919,8 @@ search_kernel_t logreg_acts_kernel() { return k_logreg_acts; }
 search_kernel_t logreg_screen_kernel() { return k_logreg_screen; }
 search_kernel_t logreg_decide_kernel() { return k_logreg_decide; }
 advance_kernel_t advance_kernel() { return k_advance; }
+advance_run_kernel_t advance_run_kernel() { return k_advance_run; }
+round_rows_kernel_t round_rows_kernel() { return k_round_rows; }
 search_kernel_t tail_kernel() { return k_tail; }
 
 }  // namespace rgk

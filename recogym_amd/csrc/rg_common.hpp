@@ -197,6 +197,13 @@ struct DevSim {
     uint64_t* log_base;       // [kMaxSteps+2]: first log row of step t
     uint32_t* exact_list;     // [n_users] organic users whose draw needs the float64 path
     uint32_t* exact_cnt;      // [kMaxSteps+2]
+    // Run-ahead rounds (rg_sim_run to the end without the user-major walk; k_advance_run): a lock-step "step" becomes a ROUND — every
+    // listed user's next organic event, or its whole bandit run up to the next organic event / stop / possible click — so users sit
+    // at different event indices: ev[user index] = index of the user's next event (the `t` of its draws and rows), and the round's
+    // number only indexes the lists and per-step counters.  run_ahead = events a round may take a user through (0 = lock-step).
+    uint32_t run_ahead;
+    uint32_t* ev;             // [n_users] by user index
+    unsigned long long* run_ctl;         // [4] word 0: next free raw-log row (bandit rows of a round are reserved block by block)
     uint32_t* n_events;       // [n_users] rows the user emitted (set when it leaves); these three are indexed by
     rg_event* phantom;        // [n_users] trailing undrawn bandit row                  USER INDEX (uid), not by slot
     uint8_t* has_phantom;     // [n_users]
@@ -266,6 +273,7 @@ struct rg_sim {
     void* workspace;
     size_t workspace_bytes;
     uint32_t t;               // next step to run
+    uint32_t run_ahead;       // option: events per user and round of a run to the end (k_advance_run); 0 = lock-step
     uint32_t live_upper;      // upper bound of live users (for grid sizing)
     bool tables_set, users_reset;
     bool repacked;            // slots no longer equal user indices (since the last reset)
@@ -315,6 +323,8 @@ typedef void (*draw_kernel_t)(DevSim, uint32_t, uint32_t);
 typedef void (*search_kernel_t)(DevSim, uint32_t);
 typedef void (*mfma_kernel_t)(DevSim, uint32_t);
 typedef void (*advance_kernel_t)(DevSim, uint32_t, const int32_t*);
+typedef void (*advance_run_kernel_t)(DevSim, uint32_t, uint32_t);
+typedef void (*round_rows_kernel_t)(DevSim, uint32_t, uint32_t);
 typedef void (*walk_kernel_t)(DevSim, uint32_t, int, uint32_t, uint32_t, uint32_t);
 exact_h_kernel_t exact_h_kernel_for(uint32_t kb);          // part 2
 exact_m_kernel_t exact_m_kernel_for(uint32_t kb);
@@ -334,6 +344,8 @@ search_kernel_t logreg_acts_kernel();
 search_kernel_t logreg_screen_kernel();
 search_kernel_t logreg_decide_kernel();
 advance_kernel_t advance_kernel();
+advance_run_kernel_t advance_run_kernel();
+round_rows_kernel_t round_rows_kernel();
 search_kernel_t tail_kernel();
 walk_kernel_t walk_kernel_for(const DevSim& d, int occ);   // part 7
 walk_kernel_t walk2_kernel_for(const DevSim& d, int occ);  // (nullptr: this configuration keeps k_walk)
@@ -546,7 +558,10 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     unsigned long long* hist_alt = w.take<unsigned long long>(rp ? hc * n_pad : 1);
     uint32_t* lpv_alt = w.take<uint32_t>(rp && c.policy == RG_POLICY_LAST_VIEW_TABLE ? n : 1);
     uint32_t* uid_alt = w.take<uint32_t>(rp ? n : 1);
+    uint32_t* ev = w.take<uint32_t>(n);
+    unsigned long long* run_ctl = w.take<unsigned long long>(4);
     if (d) {
+        d->ev = ev; d->run_ctl = run_ctl; d->run_ahead = 0;
         d->phantom_ps = phantom_ps; d->utime = utime; d->phantom_time = phantom_time;
         d->drift_list = drift_list; d->drift_sig = drift_sig; d->drift_cnt = drift_cnt;
         d->use_cache = cache ? 1u : 0u; d->cache_rec = cache_rec; d->cache_chunk = cache_chunk; d->cache_resc = cache_resc;
@@ -675,6 +690,7 @@ __device__ __forceinline__ void normal_pair(uint64_t seed, uint32_t user, uint32
 // rg_sim_debug_set_uniforms replaces it by a caller-chosen value per user index
 __device__ __forceinline__ double organic_uniform(const DevSim& d, uint32_t uidx, uint32_t user, uint32_t t) {
     if (d.u_override) return d.u_override[uidx];
+    if (d.run_ahead) t = d.ev[uidx];          // run-ahead rounds: the user's own event index
     const rg_u32x4 rw = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
     return rg_uniform(rw.w[0], rw.w[1]);
 }
@@ -1095,7 +1111,7 @@ __device__ __forceinline__ void write_organic_row(const DevSim& d, uint32_t t, u
     const uint64_t row = d.log_base[t] + pos;
     if (d.log && row < d.log_cap) {
         rg_event e;
-        e.u = user; e.t = t; e.code = v; e.ps = __builtin_nanf("");
+        e.u = user; e.t = d.run_ahead ? d.ev[d.uid[slot]] : t; e.code = v; e.ps = __builtin_nanf("");
         d.log[row] = e;
         if (d.aux_time) d.aux_time[row] = d.utime[d.uid[slot]];     // the draw kernels run before k_advance moves the clock
     }

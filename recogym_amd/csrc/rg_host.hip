@@ -25,6 +25,7 @@ __global__ void __launch_bounds__(kBlock) k_reset_users(DevSim d) {
         list_ptr(d, 0, RG_STATE_ORGANIC)[i] = i;
         d.uid[i] = i;
         d.n_events[i] = 0;
+        d.ev[i] = 0;
         d.has_phantom[i] = 0;
         if (d.time_mode) d.utime[i] = 0.0;
         if (d.lr_dirty) d.lr_dirty[i] = 1;
@@ -603,9 +604,13 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     }
     if (int rc = prof_mark(sim, st)) return rc;
     // 2. click draws, transitions, drift, next lists, bandit + phantom rows
-    hipLaunchKernelGGL(advance_kernel(), dim3(grid_for(upper, kAdvBlock)), dim3(kAdvBlock), 0, st, d, t, d_actions);
+    if (d.run_ahead)       // a round: every listed user through its bandit run (k_advance_run), then the round's raw-log books
+        hipLaunchKernelGGL(advance_run_kernel(), dim3(grid_for(upper, kAdvBlock)), dim3(kAdvBlock), 0, st, d, t, d.run_ahead);
+    else
+        hipLaunchKernelGGL(advance_kernel(), dim3(grid_for(upper, kAdvBlock)), dim3(kAdvBlock), 0, st, d, t, d_actions);
     if (d.sigma_omega != 0.0)
         hipLaunchKernelGGL(drift_kernel(), dim3(grid_for(static_cast<uint64_t>(upper) * ((d.K + 1) / 2))), dim3(kBlock), 0, st, d, t);
+    if (d.run_ahead) hipLaunchKernelGGL(round_rows_kernel(), dim3(1), dim3(1), 0, st, d, t, 0u);
     HIP_TRY(hipGetLastError());
     if (int rc = prof_mark(sim, st)) return rc;
     sim->t = t + 1;
@@ -1125,6 +1130,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     d.q_ticket = d.counters + kCntWalkTicket; d.q_park = d.counters + kCntParkCnt; d.q_count = nullptr;
     if (const char* e = getenv("RECOGYM_TAIL")) s->tail_below = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_REPACK")) s->repack_every = static_cast<uint32_t>(atoi(e));
+    s->run_ahead = 32;         // events a round of a run to the end may take a user through (0: lock-step, an event per launch)
+    if (const char* e = getenv("RECOGYM_RUN_AHEAD")) s->run_ahead = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_ABLATE")) d.ablate = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_LDS_PAD")) s->mfma_smem += static_cast<size_t>(atoi(e));
     if (s->opt.debug && d.use_mfma && rg_device_count() > 0) {
@@ -1179,6 +1186,7 @@ uint32_t* opt_u32(rg_sim* s, const char* n) {
     if (!strcmp(n, "pipe_min_users")) return &s->pipe_min_users;
     if (!strcmp(n, "tail_below")) return &s->tail_below;
     if (!strcmp(n, "repack_every")) return &s->repack_every;
+    if (!strcmp(n, "run_ahead")) return &s->run_ahead;
     return nullptr;
 }
 }  // namespace
@@ -1321,6 +1329,7 @@ int rg_sim_reset_users(rg_sim* sim, uint64_t first_user_id, uint64_t n, uint64_t
     d.organic_only_below = organic_only_below;
     d.n_users = static_cast<uint32_t>(n);      // lists stay strided by the carve-time n_cap
     d.grp_lo = 0; d.grp_n = d.n_users;
+    d.run_ahead = 0;                           // rg_sim_run turns the rounds on for a run to the end
     HIP_TRY(hipMemsetAsync(d.step_cnt, 0, sizeof(uint32_t) * 2 * (kMaxSteps + 2), st));
     HIP_TRY(hipMemsetAsync(d.exact_cnt, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
     HIP_TRY(hipMemsetAsync(d.exact_cnt_b, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
@@ -1385,6 +1394,13 @@ int rg_sim_run(rg_sim* sim, uint32_t max_steps, void* stream) {
                           exact_h_kernel_for(sim->d.XKB) && mix < 8 && sim->opt.slices < 0 &&
                           !sim->opt.sweep_prefix_off;
         return pipe ? run_walk_pipe(sim, st) : run_walk(sim, st);
+    }
+    // To the end from a fresh reset, nothing that moves omega inside a bandit run: run-ahead rounds (k_advance_run) — a user's whole
+    // bandit run per round instead of a lock-step launch per event.  Everything else (partial runs, the step API, the sum cache of a
+    // sigma_omega == 0 run without the walk) stays lock-step: event index == step number.
+    if (sim->t == 0 && max_steps >= kMaxSteps && sim->run_ahead && !sim->d.change_omega_for_bandits && !sim->d.use_cache && !sim->d.u_override) {
+        sim->d.run_ahead = sim->run_ahead;
+        hipLaunchKernelGGL(round_rows_kernel(), dim3(1), dim3(1), 0, st, sim->d, 0u, 1u);
     }
     uint32_t done_steps = 0;
     const uint32_t chunk = 16;

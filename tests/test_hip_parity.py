@@ -158,6 +158,53 @@ def test_lock_step_to_the_end_matches_oracle(case, monkeypatch):
         (oc['organic'], oc['bandit'], oc['clicks'], oc['phantom'])
 
 
+@pytest.mark.parametrize('hops', [0, 1, 3, 1000])
+@pytest.mark.parametrize('case', [0, 2, 7, 8, 9, 10, 12])
+def test_run_ahead_rounds_match_the_oracle(case, hops, monkeypatch):
+    """A run to the end goes in ROUNDS (k_advance_run): a launch takes every listed user from its organic event (or the bandit event
+    the last round left it at) through its bandit run — up to `hops` events, to the first transition that is not "bandit" or the
+    first event that can click — so users sit at different event indices; draws and rows are keyed by the user's own index.
+    Whatever the cap (0 = lock-step, an event per launch; 1 = rounds of one event; 3 = runs cut short; 1000 = never cut), the log
+    is the oracle's.  RECOGYM_TAIL=0: the rounds, not the per-user tail kernel, run these small cases to the end."""
+    from oracle import oracle as orc
+    monkeypatch.setenv('RECOGYM_TAIL', '0')
+    monkeypatch.setenv('RECOGYM_RUN_AHEAD', str(hops))
+    over, n_users, n_org, pol = CASES[case]
+    if case == 0:
+        n_org = 100
+    cfg = Configuration({**env_1_args, **over})
+    want_env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol)
+    want = want_env.generate_logs(n_users, n_org)
+    rows, cnt = run_sim(cfg, n_users, n_org, **pol)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps', 'p_click')},
+                         ps_rtol=1e-12, what=f'run-ahead {hops}, case {case}')
+    assert (rows['phantom'] == want['phantom']).all()
+    oc = want_env.counters()
+    assert (cnt['organic'], cnt['bandit'], cnt['clicks'], cnt['phantom']) == \
+        (oc['organic'], oc['bandit'], oc['clicks'], oc['phantom'])
+    assert cnt['live'] == 0 and cnt['log_dropped'] == 0 and cnt['log_rows'] == cnt['organic'] + cnt['bandit']
+
+
+@pytest.mark.parametrize('tail', ['0', None])
+@pytest.mark.parametrize('hops', [0, 2, 32])
+@pytest.mark.parametrize('name', ['philox_normal_time', 'philox_normal_time_ouc', 'philox_logreg', 'philox_bandit_mf',
+                                  'philox_p32767_k64_drift', 'philox_random_agent'])
+def test_run_ahead_rounds_reproduce_reference_fixtures(name, hops, tail, monkeypatch):
+    """The same against logs of the unmodified reference: per-user clocks (NormalTimeGenerator: the clock and the drift's scale move
+    with every event of a run), the frozen LogReg act (one act serves a whole bandit run), the last-viewed-product table, the wide
+    sweep; with the tail kernel taking over from the rounds (default) and without."""
+    if tail is not None:
+        monkeypatch.setenv('RECOGYM_TAIL', tail)
+    monkeypatch.setenv('RECOGYM_RUN_AHEAD', str(hops))
+    meta, cols = gu.load(name)
+    rows, cnt = run_sim(gu.env_config(meta), meta['n_users'], meta['n_organic'], **gu.policy_args(meta, cols))
+    gu.assert_rows_equal(rows, cols, ps_rtol=1e-5 if meta['agent'] == 'bmf' else 1e-12, what=f'{name}, run-ahead {hops}, tail {tail}')
+    assert cnt['organic'] == int((cols['z'] == 0).sum())
+    assert cnt['bandit'] + cnt['phantom'] == int((cols['z'] == 1).sum())
+    assert cnt['clicks'] == int((cols['c'] == 1).sum())
+    assert cnt['live'] == 0 and cnt['log_dropped'] == 0
+
+
 def test_repacked_fixture_last_view_table(monkeypatch):
     """Same, for the policy whose per-user state (last product viewed) also moves."""
     monkeypatch.setenv('RECOGYM_REPACK_MIN', '1')
@@ -399,6 +446,13 @@ def test_repack_and_tail_kernel_do_not_change_the_log_at_scale(monkeypatch):
     for k in ('organic', 'bandit', 'clicks', 'phantom'):
         assert a_c[k] == b_c[k], k
     assert a_chk == b_chk
+    # both of these went in run-ahead rounds (k_advance_run: a user's whole bandit run per launch); an event per launch must log
+    # the same rows
+    monkeypatch.setenv('RECOGYM_RUN_AHEAD', '0')
+    c_c, c_chk = run('16', '4096')
+    for k in ('organic', 'bandit', 'clicks', 'phantom', 'step'):
+        assert a_c[k] == c_c[k], k
+    assert a_chk == c_chk
 
 
 def test_fused_and_sliced_draw_forms_agree_at_scale(monkeypatch):
