@@ -484,22 +484,82 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
 }
 
 // ------------------------------------------------------------------------------------------
-// k_advance_run — k_advance for run-ahead rounds (rg_sim_run to the end; DevSim::run_ahead): a lane takes its user from the event the
-// round found it at — an organic event the sweep has just drawn, or a bandit event — through every following event that needs
-// nothing from another kernel: omega only moves when a transition draws "organic" (reco_env_v1.py:95-98, change_omega_for_bandits
-// off), the view history and the last viewed product only at organic events, so a whole bandit run (~17 events) is this lane's
-// alone.  The round ends for the user at the first event whose drawn next state is not "bandit" (organic: the next round's sweep
-// draws the product; stop), at a bandit event whose uniform can click (kNoClickBelow: 3 % of them — a click sends the user
-// organic), or after `hops` events.
-//   pass 1  the event draws only (one Philox block per event): how many events L the lane takes this round -> its bandit rows;
-//           a block prefix sum and ONE atomic reserve the block's rows: every raw row is used, in user order per lane;
-//   pass 2  the events themselves, as k_advance does them (act, click, row, clock, transition), event index ev[user] + h.
-// The lists, the drift list and the per-round counters are k_advance's; ev[user] moves on by L.
+// k_advance_run — k_advance for run-ahead rounds (rg_sim_run to the end; DevSim::run_ahead): a user goes from the event the round
+// found it at — an organic event the sweep has just drawn, or a bandit event — through every following event that needs nothing
+// from another kernel: omega only moves when a transition draws "organic" (reco_env_v1.py:95-98, change_omega_for_bandits off),
+// the view history and the last viewed product only at organic events, so a whole bandit run (~17 events) is decided by the
+// user's state as it is now.  The round ends for the user at the first event whose drawn next state is not "bandit" (organic:
+// the next round's sweep draws the product; stop), at a bandit event whose uniform can click (kNoClickBelow: 3 % of them — a
+// click sends the user organic), or after `hops` (<= kRunAheadMax) events.
+//   pass 1  a lane per user, the event draws only (one Philox block per event): how many events L the round takes the user
+//           through, and the drawn state after the last -> the user's bandit rows; a block prefix sum and ONE atomic reserve the
+//           block's raw rows: every row is used, a user's rows are consecutive;
+//   pass 2  a lane per EVENT: the events of a run are independent of each other (draws addressed by (user, event index), the
+//           state they read does not move inside the run), so the wave's rows are dealt to its lanes 64 at a time — owner lane and
+//           position from a byte map in LDS, the owner's registers by ds_bpermute — instead of every lane walking its own run
+//           while the wave waits for its longest (measured: rounds of <= 32 events were SLOWER than lock-step that way);
+//           the last event's click goes back to the owner through LDS;
+//   then    the owner closes the books as k_advance does: click override, stop + phantom row, next lists, drift list.
+// Per-user clocks (NormalTimeGenerator) chain the events of a run (every row carries the clock so far): that mode keeps the lane
+// per user walk.  The lists, the drift list and the per-round counters are k_advance's; ev[user] moves on by L.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kAdvBlock) k_advance_run(DevSim d, uint32_t t, uint32_t hops) {
+constexpr uint32_t kRunAheadMax = 64;
+
+// one bandit event of a user whose state does not move: act, click, row (k_advance's arithmetic) -> click
+__device__ __forceinline__ bool run_bandit_event(const DevSim& d, uint32_t slot, uint32_t user, uint32_t te, uint32_t lr_a,
+                                                 uint64_t row, double clock) {
+    const rg_u32x4 w = rg_draw(d.seed, user, te, 0, RG_DRAW_EVENT);
+    const double u_click = rg_uniform(w.w[0], w.w[1]);
+    const bool need_ctr = d.aux_pclick != nullptr || !(u_click < kNoClickBelow);
+    double ps;
+    uint32_t a;
+    if (d.policy == RG_POLICY_LOGREG_FROZEN) { a = lr_a; ps = 1.0; }
+    else a = policy_act(d, slot, user, te, &ps);
+    double ctr = 0.0;
+    bool click = false;
+    if (need_ctr) {
+        // beta[a] . omega, k ascending (the oracle's association), loads eight k at a time
+        const double* b = d.beta + static_cast<size_t>(a) * d.K;
+        const double* om = d.omega + static_cast<size_t>(slot) * d.OMS;
+        double x = 0.0;
+        for (uint32_t k0 = 0; k0 < d.K; k0 += 8) {
+            double wv[8], bv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t k = min(k0 + q, d.K - 1);
+                wv[q] = om[k];
+                bv[q] = b[k];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (k0 + q < d.K) x += bv[q] * wv[q];
+        }
+        ctr = ff64(x + d.mu_b[a]);
+        const double p0 = 1.0 - ctr;
+        click = (p0 / (p0 + ctr)) <= u_click;
+    }
+    if (d.log && row < d.log_cap) {
+        rg_event e;
+        e.u = user; e.t = te;
+        e.code = RG_EV_BANDIT | (click ? RG_EV_CLICK : 0u) | a;
+        e.ps = static_cast<float>(ps);
+        d.log[row] = e;
+        if (d.aux_ps) d.aux_ps[row] = ps;
+        if (d.aux_pclick) d.aux_pclick[row] = ctr;
+        if (d.aux_time) d.aux_time[row] = clock;
+    }
+    return click;
+}
+
+#ifndef RG_ADV_RUN_WAVES
+#define RG_ADV_RUN_WAVES 2
+#endif
+__global__ void __launch_bounds__(kAdvBlock) __attribute__((amdgpu_waves_per_eu(RG_ADV_RUN_WAVES, RG_ADV_RUN_WAVES)))
+k_advance_run(DevSim d, uint32_t t, uint32_t hops) {
     constexpr int NW = kAdvBlock / 64;
     __shared__ uint32_t s_cnt_o[NW], s_cnt_b[NW], s_cnt_d[NW], s_rows[NW], s_base_o, s_base_b, s_base_d;
     __shared__ unsigned long long s_row0;
+    __shared__ uint8_t s_owner[NW][64 * kRunAheadMax], s_click[NW][64];
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
     const uint32_t n_b = d.step_cnt[2 * t + RG_STATE_BANDIT];
     const uint32_t n = n_o + n_b;
@@ -509,6 +569,7 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance_run(DevSim d, uint32_t t,
     uint32_t* next_b = list_ptr(d, (t + 1) & 1, RG_STATE_BANDIT);
     uint32_t* next_cnt = d.step_cnt + 2 * (t + 1);
     const int wave = threadIdx.x >> 6, lane = lane_id();
+    hops = min(hops, kRunAheadMax);
 
     uint32_t clicks = 0, phantoms = 0, extra = 0, max_t = 0;
     const uint32_t n_iter = (n + kAdvBlock - 1) / kAdvBlock;
@@ -516,8 +577,9 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance_run(DevSim d, uint32_t t,
         const uint32_t i = it * kAdvBlock + threadIdx.x;
         const bool live = i < n;
         const bool is_org = i < n_o;
-        uint32_t slot = 0, uidx = 0, user = 0, te0 = 0, L = 0;
+        uint32_t slot = 0, uidx = 0, user = 0, te0 = 0, L = 0, lr_a = 0;
         bool organic_only = false;
+        int ns = RG_STATE_STOP;       // drawn state after the round's last event; inactive lanes look dead
         // ---- pass 1: how far this round takes the user
         if (live) {
             slot = is_org ? cur_o[i] : cur_b[i - n_o];
@@ -525,25 +587,33 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance_run(DevSim d, uint32_t t,
             user = static_cast<uint32_t>(d.first_user + uidx);
             te0 = d.ev[uidx];
             organic_only = (d.first_user + uidx) < d.organic_only_below;
+            if (d.policy == RG_POLICY_LOGREG_FROZEN) lr_a = d.lr_action[uidx];     // one act serves the whole run and the phantom row
             bool org = is_org;
             for (;;) {
                 const rg_u32x4 w = rg_draw(d.seed, user, te0 + L, 0, RG_DRAW_EVENT);
                 const double u_trans = rg_uniform(w.w[2], w.w[3]);
                 const double c0 = org ? d.cdf_o0 : d.cdf_b0, c1 = org ? d.cdf_o1 : d.cdf_b1;
-                const int ns = (c0 <= u_trans) + (c1 <= u_trans);
+                ns = (c0 <= u_trans) + (c1 <= u_trans);
                 L += 1;
                 if (!org && !(rg_uniform(w.w[0], w.w[1]) < kNoClickBelow)) break;      // may click: the round's last event
                 if (ns != RG_STATE_BANDIT || organic_only || L >= hops) break;
                 org = false;
             }
         }
-        const uint32_t n_rows = L - ((live && is_org) ? 1u : 0u);       // the organic event's row is the sweep's
+        const uint32_t skip = (live && is_org) ? 1u : 0u;               // the organic event's row is the sweep's
+        const uint32_t n_rows = L - skip;
         uint32_t incl = n_rows;
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t y = __shfl_up(incl, o);
             if (lane >= o) incl += y;
         }
+        const uint32_t excl = incl - n_rows;
+        const uint32_t rows_w = __shfl(incl, 63);
         if (lane == 63) s_rows[wave] = incl;
+        if (!d.time_mode) {
+            for (uint32_t q = 0; q < n_rows; ++q) s_owner[wave][excl + q] = static_cast<uint8_t>(lane);
+            s_click[wave][lane] = 0;
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned long long tot = 0;
@@ -552,80 +622,54 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance_run(DevSim d, uint32_t t,
             s_row0 = tot ? atomicAdd(&d.run_ctl[0], tot) : 0ull;
         }
         __syncthreads();
-        uint64_t row = s_row0 + incl - n_rows;
-        for (int w2 = 0; w2 < wave; ++w2) row += s_rows[w2];
+        uint64_t row_w = s_row0;                                        // first raw row of this wave's users
+        for (int w2 = 0; w2 < wave; ++w2) row_w += s_rows[w2];
 
         // ---- pass 2: the events
-        int ns = RG_STATE_STOP;       // inactive lanes look dead
-        bool drift_me = false;
-        double drift_sig = 0.0;
-        if (live) {
-            const uint32_t lr_a = d.policy == RG_POLICY_LOGREG_FROZEN ? d.lr_action[uidx] : 0u;   // one act serves the whole run
-            const double* om = d.omega + static_cast<size_t>(slot) * d.OMS;
-            double clock = d.time_mode ? d.utime[uidx] : 0.0;
-            bool org = is_org, click = false;
+        bool click = false;           // of the round's last event
+        double drift_sig = d.sigma_omega;
+        double clock = 0.0;
+        if (!d.time_mode) {
+            for (uint32_t k0 = 0; k0 < rows_w; k0 += 64) {
+                const uint32_t k = k0 + lane;
+                const bool mine = k < rows_w;
+                const int owner = mine ? s_owner[wave][k] : 0;
+                const uint32_t o_slot = __shfl(slot, owner), o_user = __shfl(user, owner), o_lr = __shfl(lr_a, owner);
+                const uint32_t o_te = __shfl(te0 + skip, owner), o_excl = __shfl(excl, owner), o_rows = __shfl(n_rows, owner);
+                if (mine) {
+                    const uint32_t h = k - o_excl;
+                    const bool c = run_bandit_event(d, o_slot, o_user, o_te + h, o_lr, row_w + k, 0.0);
+                    clicks += c;
+                    if (c && h + 1 == o_rows) s_click[wave][owner] = 1;
+                }
+            }
+            __syncthreads();
+            click = live && n_rows && s_click[wave][lane] != 0;
+        } else if (live) {
+            // per-user clocks: the lane walks its own run (the clock of every row is the sum of the time steps before it)
+            clock = d.utime[uidx];
+            uint64_t row = row_w + excl;
             for (uint32_t h = 0; h < L; ++h) {
                 const uint32_t te = te0 + h;
-                const rg_u32x4 w = rg_draw(d.seed, user, te, 0, RG_DRAW_EVENT);
-                const double u_trans = rg_uniform(w.w[2], w.w[3]);
-                click = false;
-                if (!org) {
-                    const double u_click = rg_uniform(w.w[0], w.w[1]);
-                    const bool need_ctr = d.aux_pclick != nullptr || !(u_click < kNoClickBelow);
-                    double ps;
-                    uint32_t a;
-                    if (d.policy == RG_POLICY_LOGREG_FROZEN) { a = lr_a; ps = 1.0; }
-                    else a = policy_act(d, slot, user, te, &ps);
-                    double ctr = 0.0;
-                    if (need_ctr) {
-                        // beta[a] . omega, k ascending (the oracle's association), loads eight k at a time
-                        const double* b = d.beta + static_cast<size_t>(a) * d.K;
-                        double x = 0.0;
-                        for (uint32_t k0 = 0; k0 < d.K; k0 += 8) {
-                            double wv[8], bv[8];
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const uint32_t k = min(k0 + q, d.K - 1);
-                                wv[q] = om[k];
-                                bv[q] = b[k];
-                            }
-#pragma unroll
-                            for (int q = 0; q < 8; ++q)
-                                if (k0 + q < d.K) x += bv[q] * wv[q];
-                        }
-                        ctr = ff64(x + d.mu_b[a]);
-                        const double p0 = 1.0 - ctr;
-                        click = (p0 / (p0 + ctr)) <= u_click;
-                    }
+                if (h >= skip) {
+                    click = run_bandit_event(d, slot, user, te, lr_a, row, clock);
                     clicks += click;
-                    if (d.log && row < d.log_cap) {
-                        rg_event e;
-                        e.u = user; e.t = te;
-                        e.code = RG_EV_BANDIT | (click ? RG_EV_CLICK : 0u) | a;
-                        e.ps = static_cast<float>(ps);
-                        d.log[row] = e;
-                        if (d.aux_ps) d.aux_ps[row] = ps;
-                        if (d.aux_pclick) d.aux_pclick[row] = ctr;
-                        if (d.aux_time) d.aux_time[row] = clock;
-                    }
                     row += 1;
                 }
-                // update_state (reco_env_v1.py:85-100)
-                const double c0 = org ? d.cdf_o0 : d.cdf_b0, c1 = org ? d.cdf_o1 : d.cdf_b1;
-                ns = (c0 <= u_trans) + (c1 <= u_trans);
-                double omega_k = 1.0;
-                if (d.time_mode) {
-                    double z0, z1;
-                    normal_pair(d.seed, user, te, 0, RG_DRAW_TIME, &z0, &z1);
-                    const double dt = fabs(d.time_mu + d.time_sigma * z0);
-                    clock = clock + dt;
-                    omega_k = dt == 0.0 ? 1.0 : dt;
-                }
-                drift_me = d.sigma_omega != 0.0 && (d.change_omega_for_bandits || ns == RG_STATE_ORGANIC);
-                drift_sig = d.sigma_omega * omega_k;
-                org = false;          // whatever follows in this round is a bandit event
+                double z0, z1;
+                normal_pair(d.seed, user, te, 0, RG_DRAW_TIME, &z0, &z1);
+                const double dt = fabs(d.time_mu + d.time_sigma * z0);
+                clock = clock + dt;
+                drift_sig = d.sigma_omega * (dt == 0.0 ? 1.0 : dt);
             }
-            if (d.time_mode) d.utime[uidx] = clock;
+            d.utime[uidx] = clock;
+        }
+
+        // ---- the owner closes the round (update_state, reco_env_v1.py:85-100)
+        bool drift_me = false;
+        if (live) {
+            // omega drifts when the DRAWN next state is organic (the click override below does not redraw it)
+            drift_me = d.sigma_omega != 0.0 && (d.change_omega_for_bandits || ns == RG_STATE_ORGANIC);
             const uint32_t t_last = te0 + L - 1u;
             d.ev[uidx] = te0 + L;
             extra += L - 1u;
