@@ -54,7 +54,9 @@ __global__ void __launch_bounds__(kBlock) k_logreg_acts(DevSim d, uint32_t t) {
     const uint32_t n = d.lr_cnt[t];
     const uint32_t waves_total = gridDim.x * (kBlock / 64);
     unsigned long long c_acts = 0, c_rows = 0, c_exact = 0;
-    for (uint32_t w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < n; w += waves_total) {
+    // beside the fp16 screen / decide pair this kernel takes what the step lists beyond the screen's scratch rows
+    const uint32_t w0 = d.lr_coef16_t ? d.lr_part_cap : 0u;
+    for (uint32_t w = w0 + blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < n; w += waves_total) {
         const uint32_t slot = d.lr_list[w];
         const uint32_t uidx = d.uid[slot];
         uint32_t action = 0;
@@ -124,7 +126,7 @@ __global__ void __launch_bounds__(kBlock) k_logreg_screen(DevSim d, uint32_t t) 
     __shared__ float s_cval[kBlock / 64][32];
     typedef _Float16 half8 __attribute__((ext_vector_type(8)));
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const uint32_t n = d.lr_cnt[t];
+    const uint32_t n = min(d.lr_cnt[t], d.lr_part_cap);         // (the rest: k_logreg_acts)
     const uint32_t C = d.lr_n;
     const uint32_t RC = ((C + kLrSplit - 1) / kLrSplit + 7u) & ~7u;       // classes per range (a multiple of 8)
     const uint32_t waves_total = gridDim.x * (kBlock / 64);
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(kBlock) k_logreg_screen(DevSim d, uint32_t t) 
 
 __global__ void __launch_bounds__(kBlock) k_logreg_decide(DevSim d, uint32_t t) {
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const uint32_t n = d.lr_cnt[t];
+    const uint32_t n = min(d.lr_cnt[t], d.lr_part_cap);
     const uint32_t C = d.lr_n;
     const uint32_t waves_total = gridDim.x * (kBlock / 64);
     unsigned long long c_acts = 0, c_rows = 0, c_exact = 0;

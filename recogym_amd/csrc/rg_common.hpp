@@ -227,7 +227,9 @@ struct DevSim {
     uint8_t* lr_dirty;        // [n_cap] by user index
     uint32_t* lr_list;        // [n_cap] slots whose act is to be computed this step
     uint32_t* lr_cnt;         // [kMaxSteps + 2]
-    uint32_t* lr_part;        // [n_cap][kLrSplit][kLrPartWords]: the screen's result per listed act and class range
+    uint32_t* lr_part;        // [lr_part_cap][kLrSplit][kLrPartWords]: the screen's result per listed act and class range
+    uint32_t lr_part_cap;     // acts of a step the screen / decide pair takes (rows of lr_part: n / 2 + 4096, at most n); the acts a
+                              // step lists beyond that go through k_logreg_acts (no scratch)
     // omega drift of a lock-step step (sigma_omega > 0): k_advance lists the users whose transition drifts omega, k_drift applies
     // the K normals a lane per (user, Box-Muller pair) — ~2 600 float64 instructions per drifting user that only ~22 % of
     // k_advance's lanes would execute (the others idle through them)
@@ -274,6 +276,7 @@ struct rg_sim {
     size_t workspace_bytes;
     uint32_t t;               // next step to run
     uint32_t run_ahead;       // option: events per user and round of a run to the end (k_advance_run); 0 = lock-step
+    uint32_t lr_part_rows;    // rows the workspace holds for the LogReg screen (the option lr_part_cap can only go below it)
     uint32_t live_upper;      // upper bound of live users (for grid sizing)
     bool tables_set, users_reset;
     bool repacked;            // slots no longer equal user indices (since the last reset)
@@ -546,7 +549,10 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint8_t* lr_dirty = w.take<uint8_t>(lr ? n : 1);
     uint32_t* lr_list = w.take<uint32_t>(lr ? n : 1);
     uint32_t* lr_cnt = w.take<uint32_t>(lr ? kMaxSteps + 2 : 1);
-    uint32_t* lr_part = w.take<uint32_t>(lr ? n * static_cast<size_t>(8 * (4 + 2 * 8)) : 1);       // kLrSplit x kLrPartWords
+    // the screen's scratch: a row per act of a STEP, not per user — a step lists the users whose history changed and who act now
+    // (a quarter of the organic users at the default transition matrix); what a step lists beyond the rows goes through k_logreg_acts
+    const size_t lr_part_cap = lr ? (n / 2 + 4096 < n ? n / 2 + 4096 : n) : 0;
+    uint32_t* lr_part = w.take<uint32_t>(lr ? lr_part_cap * static_cast<size_t>(8 * (4 + 2 * 8)) : 1);       // kLrSplit x kLrPartWords
     // round 1's list, then round 2's hand-overs, 64-entry blocks per wave; the pipeline: a region per user group (its users +
     // kParkSlack for the blocks its waves leave part-used) and one for the last round's list
     uint32_t* park_list = w.take<uint32_t>(cache ? n + 128 + static_cast<size_t>(2 * kMaxWalkGroups) * kParkSlack : 1);
@@ -570,7 +576,7 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->park_list = park_list; d->park_t = park_t; d->sweep_only = 0;
         d->walk_ctl = walk_ctl; d->step1_buf = step1_buf;
         d->walk_hot = cache ? walk_hot : nullptr; d->walk_scp = walk_scp;
-        d->lr_action = lr_action; d->lr_dirty = lr ? lr_dirty : nullptr; d->lr_list = lr_list; d->lr_cnt = lr_cnt; d->lr_part = lr_part;
+        d->lr_action = lr_action; d->lr_dirty = lr ? lr_dirty : nullptr; d->lr_list = lr_list; d->lr_cnt = lr_cnt; d->lr_part = lr_part; d->lr_part_cap = static_cast<uint32_t>(lr_part_cap);
         d->uid = uid; d->omega_alt = omega_alt; d->hist_alt = hist_alt;
         d->lpv_alt = lpv_alt; d->uid_alt = uid_alt;
         d->gamma32 = gamma32; d->mu32 = mu32; d->gamma32t = gamma32t; d->has_g32t = gamma32t_wanted(c, g) ? 1u : 0u; d->stats = stats; d->omega = omega; d->list = list;

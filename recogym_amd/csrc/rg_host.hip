@@ -599,6 +599,8 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
             hipLaunchKernelGGL(logreg_screen_kernel(), dim3(grid_for((static_cast<uint64_t>(upper) / 4 + 64) * kLrSplit, kBlock / 64)),
                                dim3(kBlock), 0, st, d, t);
             hipLaunchKernelGGL(logreg_decide_kernel(), dim3(grid_for(static_cast<uint64_t>(upper) / 4 + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
+            if (upper > d.lr_part_cap)     // the step may list more acts than the screen's scratch has rows: the rest in fp32 / float64
+                hipLaunchKernelGGL(logreg_acts_kernel(), dim3(grid_for(static_cast<uint64_t>(upper - d.lr_part_cap) / 4 + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
         } else
             hipLaunchKernelGGL(logreg_acts_kernel(), dim3(grid_for(static_cast<uint64_t>(upper) / 4 + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
     }
@@ -1132,6 +1134,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     if (const char* e = getenv("RECOGYM_REPACK")) s->repack_every = static_cast<uint32_t>(atoi(e));
     s->run_ahead = 32;         // events a round of a run to the end may take a user through (0: lock-step, an event per launch)
     if (const char* e = getenv("RECOGYM_RUN_AHEAD")) s->run_ahead = static_cast<uint32_t>(atoi(e));
+    s->lr_part_rows = d.lr_part_cap;
+    if (const char* e = getenv("RECOGYM_LR_PART_CAP")) { const uint32_t v = static_cast<uint32_t>(atoi(e)); if (v < d.lr_part_cap) d.lr_part_cap = v; }
     if (const char* e = getenv("RECOGYM_ABLATE")) d.ablate = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_LDS_PAD")) s->mfma_smem += static_cast<size_t>(atoi(e));
     if (s->opt.debug && d.use_mfma && rg_device_count() > 0) {
@@ -1187,6 +1191,7 @@ uint32_t* opt_u32(rg_sim* s, const char* n) {
     if (!strcmp(n, "tail_below")) return &s->tail_below;
     if (!strcmp(n, "repack_every")) return &s->repack_every;
     if (!strcmp(n, "run_ahead")) return &s->run_ahead;
+    if (!strcmp(n, "lr_part_cap")) return &s->d.lr_part_cap;
     return nullptr;
 }
 }  // namespace
@@ -1205,6 +1210,8 @@ int rg_sim_set_option(rg_sim* sim, const char* name, int64_t value) {
         if (value < 0) return fail(RG_EINVAL, "%s must be >= 0", name);
         if (!strcmp(name, "walk_search_batch") && value < 1) value = 1;
         if (!strcmp(name, "pipe_min_users") && value < 256) return fail(RG_EINVAL, "pipe_min_users must be >= 256");
+        if (!strcmp(name, "lr_part_cap") && static_cast<uint64_t>(value) > sim->lr_part_rows)
+            return fail(RG_EINVAL, "lr_part_cap can only be lowered (the workspace holds %u rows)", sim->lr_part_rows);
         *p = static_cast<uint32_t>(value);
         return RG_OK;
     }

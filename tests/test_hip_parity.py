@@ -561,7 +561,7 @@ def test_frozen_logreg_with_more_than_256_classes_matches_the_oracle():
     assert (used >= classes[256]).any() and (used >= classes[512]).any()     # later class blocks do win
 
 
-@pytest.mark.parametrize('screen', ['fp16', 'fp32'])
+@pytest.mark.parametrize('screen', ['fp16', 'fp32', 'fp16_cap3'])
 def test_frozen_logreg_at_config_5_scale_matches_the_oracle(screen, monkeypatch):
     """BASELINE config 5's policy shape: one class per product, 4 096 products.  The act screens every class score from
     the half copy of coef^T (RECOGYM_LOGREG=fp32: from the fp32 copy), keeps the classes within twice the rounding
@@ -569,6 +569,11 @@ def test_frozen_logreg_at_config_5_scale_matches_the_oracle(screen, monkeypatch)
     near-ties common; classes duplicated exactly (first maximum wins) and almost exactly (1e-9 apart: far inside the
     fp16 bound, decided by float64) must come out as the oracle's argmax."""
     from oracle import oracle as orc
+    if screen == 'fp16_cap3':
+        # the screen's scratch holds a row per act of a step (n / 2 + 4096 of them); here only 3: every step that lists more acts
+        # sends the rest through k_logreg_acts (fp32 scores, float64 inside the bound)
+        monkeypatch.setenv('RECOGYM_LR_PART_CAP', '3')
+        screen = 'fp16'
     monkeypatch.setenv('RECOGYM_LOGREG', screen)
     P = C = 4096
     rng = np.random.RandomState(5)
