@@ -259,12 +259,13 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
                                   rows_per_act=round(c['lr_rows'] / c['lr_acts'], 2), float64_refined_acts=int(c.get('lr_exact', 0)),
                                   launches=int(prof['steps']), us_per_launch=round(1e3 * prof['logreg_ms'] / max(prof['steps'], 1), 1),
                                   achieved=round(gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(gbps / HBM_PEAK_GBPS, 4),
-                                  note='a lock-step step has few acts (about one per wave slot): the time of a step\'s act kernels is the '
+                                  note='late rounds have few acts (about one per wave slot): the time of such a round\'s act kernels is the '
                                        'latency of one act, not throughput')
     # advance: SURVEY.md 8d bytes per event
     if prof['advance_ms'] > 0:
         gbps = b_survey * events / (prof['advance_ms'] * 1e-3) / 1e9
-        out['advance'] = dict(kernel='k_advance', bound='hbm', ms=round(prof['advance_ms'], 2),
+        out['advance'] = dict(kernel='k_advance_run + k_drift (rounds: a user\'s bandit run per launch)', bound='hbm', ms=round(prof['advance_ms'], 2),
+                              launches=int(prof['steps']),
                               units=int(events), unit_name='events', bytes_per_unit=b_survey,
                               achieved=round(gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(gbps / HBM_PEAK_GBPS, 4))
     return out

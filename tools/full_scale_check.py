@@ -2,7 +2,8 @@
 
 For each workload the DEFAULT path (sigma_omega = 0: sweep -> k_walk with the fp32-decided clicks, the integer-decided
 OrganicUserEventCounter act and the float64 sums of the parked users on both float64 pipes; sigma_omega > 0: certified
-fp16-split MFMA sweeps) is compared with the float64-only lock-step path — RECOGYM_DRAW=f64 RECOGYM_WALK=0 with the
+fp16-split MFMA sweeps, the run in rounds: k_advance_run) is compared with the float64-only lock-step path — RECOGYM_DRAW=f64
+RECOGYM_WALK=0 RECOGYM_RUN_AHEAD=0 with the
 click-probability export on, which forces every click through float64 — on the counters and on an order-independent
 checksum of EVERY log row (Simulator.log_digest).  The float64-only path is the oracle's arithmetic on the device
 (tests/test_hip_parity.py pins it on the oracle and on the reference's logs at small sizes).
@@ -22,7 +23,8 @@ args = [a for a in sys.argv[1:] if not a.startswith('--')]
 users_override = int(sys.argv[sys.argv.index('--users') + 1]) if '--users' in sys.argv else 0
 workloads = args or ['c3', 'c2', 'c4shard']
 FAST = {}                                                           # the default path
-EXACT = {'RECOGYM_DRAW': 'f64', 'RECOGYM_WALK': '0', 'RECOGYM_LOGREG': 'fp32'}   # float64 draws, lock-step, float64 clicks
+# float64 draws, lock-step with an event per launch (no run-ahead rounds), float64 clicks
+EXACT = {'RECOGYM_DRAW': 'f64', 'RECOGYM_WALK': '0', 'RECOGYM_LOGREG': 'fp32', 'RECOGYM_RUN_AHEAD': '0'}
 ok_all = True
 for wl, arm, kw in [(w, a, k) for w in workloads for a, k in bench.arms_of(w, bench.make_config(w))]:
     per_gpu = bench.WORKLOADS[wl][1]
