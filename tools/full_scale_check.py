@@ -19,8 +19,8 @@ import torch
 import bench
 from recogym_amd.sim import Simulator, default_log_capacity
 
-args = [a for a in sys.argv[1:] if not a.startswith('--')]
 users_override = int(sys.argv[sys.argv.index('--users') + 1]) if '--users' in sys.argv else 0
+args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith('--') and sys.argv[i - 1] != '--users']
 workloads = args or ['c3', 'c2', 'c4shard']
 FAST = {}                                                           # the default path
 # float64 draws, lock-step with an event per launch (no run-ahead rounds), float64 clicks
