@@ -506,16 +506,29 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
 // per user walk.  The lists, the drift list and the per-round counters are k_advance's; ev[user] moves on by L.
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kRunAheadMax = 64;
+// timing experiments of k_advance_run (RECOGYM_ABLATE bits 24: no pass 2, 25: no act, 26: no row stores) exist in -DRG_ADV_TIMING
+// builds only (profiles/r4/ab_call22_advance_run_timing.jsonl)
+#ifdef RG_ADV_TIMING
+#define RG_ADV_ABL(bit) (d.ablate & (1u << (bit)))
+#else
+#define RG_ADV_ABL(bit) (false)
+#endif
 
 // one bandit event of a user whose state does not move: act, click, row (k_advance's arithmetic) -> click
+// (may_click = false: pass 1 saw the event's uniform below kNoClickBelow — it cannot click whatever the click probability is, and
+// the event draw, a Philox block, is not taken again)
 __device__ __forceinline__ bool run_bandit_event(const DevSim& d, uint32_t slot, uint32_t user, uint32_t te, uint32_t lr_a,
-                                                 uint64_t row, double clock) {
-    const rg_u32x4 w = rg_draw(d.seed, user, te, 0, RG_DRAW_EVENT);
-    const double u_click = rg_uniform(w.w[0], w.w[1]);
-    const bool need_ctr = d.aux_pclick != nullptr || !(u_click < kNoClickBelow);
-    double ps;
-    uint32_t a;
-    if (d.policy == RG_POLICY_LOGREG_FROZEN) { a = lr_a; ps = 1.0; }
+                                                 uint64_t row, double clock, bool may_click) {
+    double u_click = 0.0;
+    if (may_click) {
+        const rg_u32x4 w = rg_draw(d.seed, user, te, 0, RG_DRAW_EVENT);
+        u_click = rg_uniform(w.w[0], w.w[1]);
+    }
+    const bool need_ctr = d.aux_pclick != nullptr || may_click;
+    double ps = 1.0;
+    uint32_t a = 0;
+    if (RG_ADV_ABL(25)) {}
+    else if (d.policy == RG_POLICY_LOGREG_FROZEN) a = lr_a;
     else a = policy_act(d, slot, user, te, &ps);
     double ctr = 0.0;
     bool click = false;
@@ -540,7 +553,7 @@ __device__ __forceinline__ bool run_bandit_event(const DevSim& d, uint32_t slot,
         const double p0 = 1.0 - ctr;
         click = (p0 / (p0 + ctr)) <= u_click;
     }
-    if (d.log && row < d.log_cap) {
+    if (d.log && row < d.log_cap && !RG_ADV_ABL(26)) {
         rg_event e;
         e.u = user; e.t = te;
         e.code = RG_EV_BANDIT | (click ? RG_EV_CLICK : 0u) | a;
@@ -582,6 +595,7 @@ k_advance_run(DevSim d, uint32_t t, uint32_t hops) {
         uint32_t slot = 0, uidx = 0, user = 0, te0 = 0, L = 0, lr_a = 0;
         bool organic_only = false;
         int ns = RG_STATE_STOP;       // drawn state after the round's last event; inactive lanes look dead
+        bool may_click = false;       // the round's last event is a bandit event whose uniform can click
         // ---- pass 1: how far this round takes the user
         if (live) {
             slot = is_org ? cur_o[i] : cur_b[i - n_o];
@@ -597,7 +611,7 @@ k_advance_run(DevSim d, uint32_t t, uint32_t hops) {
                 const double c0 = org ? d.cdf_o0 : d.cdf_b0, c1 = org ? d.cdf_o1 : d.cdf_b1;
                 ns = (c0 <= u_trans) + (c1 <= u_trans);
                 L += 1;
-                if (!org && !(rg_uniform(w.w[0], w.w[1]) < kNoClickBelow)) break;      // may click: the round's last event
+                if (!org && !(rg_uniform(w.w[0], w.w[1]) < kNoClickBelow)) { may_click = true; break; }   // the round's last event
                 if (ns != RG_STATE_BANDIT || organic_only || L >= hops) break;
                 org = false;
             }
@@ -634,13 +648,14 @@ k_advance_run(DevSim d, uint32_t t, uint32_t hops) {
         if (!d.time_mode) {
             for (uint32_t k0 = 0; k0 < rows_w; k0 += 64) {
                 const uint32_t k = k0 + lane;
-                const bool mine = k < rows_w;
+                const bool mine = k < rows_w && !RG_ADV_ABL(24);
                 const int owner = mine ? s_owner[wave][k] : 0;
                 const uint32_t o_slot = __shfl(slot, owner), o_user = __shfl(user, owner), o_lr = __shfl(lr_a, owner);
                 const uint32_t o_te = __shfl(te0 + skip, owner), o_excl = __shfl(excl, owner), o_rows = __shfl(n_rows, owner);
+                const bool o_mc = __shfl(static_cast<int>(may_click), owner) != 0;
                 if (mine) {
                     const uint32_t h = k - o_excl;
-                    const bool c = run_bandit_event(d, o_slot, o_user, o_te + h, o_lr, row_w + k, 0.0);
+                    const bool c = run_bandit_event(d, o_slot, o_user, o_te + h, o_lr, row_w + k, 0.0, o_mc && h + 1 == o_rows);
                     clicks += c;
                     if (c && h + 1 == o_rows) s_click[wave][owner] = 1;
                 }
@@ -654,7 +669,7 @@ k_advance_run(DevSim d, uint32_t t, uint32_t hops) {
             for (uint32_t h = 0; h < L; ++h) {
                 const uint32_t te = te0 + h;
                 if (h >= skip) {
-                    click = run_bandit_event(d, slot, user, te, lr_a, row, clock);
+                    click = run_bandit_event(d, slot, user, te, lr_a, row, clock, may_click && h + 1 == L);
                     clicks += click;
                     row += 1;
                 }
