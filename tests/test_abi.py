@@ -113,4 +113,9 @@ def test_run_options_are_set_by_name_not_by_the_environment_at_run_time(lib, mon
     assert lib.rg_sim_set_option(h, b'exact_mix', 9) == -1 and b'exact_mix' in lib.rg_last_error()
     assert lib.rg_sim_set_option(h, b'pipe_occ1', 0) == -1
     assert lib.rg_sim_set_option(h, b'no_such_option', 1) == -1 and b'no_such_option' in lib.rg_last_error()
+    # round 4: the rounds of a run to the end (events per user and round; 0 = lock-step) and the LogReg screen's scratch rows
+    assert lib.rg_sim_get_option(h, b'run_ahead', C.byref(v)) == 0 and v.value == 32
+    assert lib.rg_sim_set_option(h, b'run_ahead', 0) == 0 and lib.rg_sim_get_option(h, b'run_ahead', C.byref(v)) == 0 and v.value == 0
+    assert lib.rg_sim_get_option(h, b'lr_part_cap', C.byref(v)) == 0 and v.value == 0          # (not a LogReg policy: no rows)
+    assert lib.rg_sim_set_option(h, b'lr_part_cap', 5) == -1 and b'lowered' in lib.rg_last_error()
     lib.rg_sim_destroy(h)
