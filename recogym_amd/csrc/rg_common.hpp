@@ -467,6 +467,16 @@ inline size_t exact_rows_of(const rg_config& c, const Geom& g, uint64_t n) {
     return r < 4096 ? (n < 4096 ? n : 4096) : r;
 }
 
+// k_draw_bf16p's product-tile ring in LDS and the blocks per CU it is compiled for.  Default since round 4: the tile in use + ONE in
+// flight (48 KB of LDS at K = 20), two blocks per CU (253 registers) — 1 % (C3) to 3 % (C3 with drift) faster than the tile in use
+// + two in flight (-DRG_SWEEP_NB=3, 67 KB).  -DRG_SWEEP_OCC=3 (three blocks per CU fit the 48 KB: 168 registers, the steady-state
+// loop keeps ~8 scratch accesses per iteration) is 30 - 70 % SLOWER: profiles/r4/ab_call26_*, DESIGN.md §10.4.
+#ifndef RG_SWEEP_NB
+#define RG_SWEEP_NB 2
+#endif
+#ifndef RG_SWEEP_OCC
+#define RG_SWEEP_OCC 2
+#endif
 inline size_t bf16_smem_bytes(const Geom& g, uint32_t K, uint32_t buffers) {
     // split tiles + mu tiles (2 buffers: lean kernel, 3: pipelined kernel) + the per-wave omega32 stage [4][32][K]
     return buffers * (static_cast<size_t>(g.TPB) * g.RS + g.TPB * 4) + 4 * 32 * static_cast<size_t>(K) * 4 + 256;

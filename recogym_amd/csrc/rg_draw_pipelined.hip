@@ -6,16 +6,17 @@
 namespace rgk {
 
 template <int KH, int N1, int N2, int N3, bool F16>
-__global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, uint32_t S) {
+__global__ void __launch_bounds__(kBlock, RG_SWEEP_OCC) k_draw_bf16p(DevSim d, uint32_t t, uint32_t S) {
+    constexpr uint32_t NB = RG_SWEEP_NB;       // product tiles in LDS: the one in use and NB - 1 in flight
     constexpr int NM = F16 ? N1 : N1 + N2 + N3;   // MFMAs per chunk (fp16 two-way split: one group)
     // MFMA slots that carry the exps (and the A loads); the rest carry the mu loads.  The fp16 form is VALU-bound:
     // its exps spread over all slots but the last
     constexpr int EXS = F16 ? (NM > 1 ? NM - 1 : 1) : (NM > 3 ? NM - 3 : 1);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const uint32_t tile_b = d.TPB * d.RS;                             // bytes per split tile
-    char* g_buf = smem_raw;                                           // [3][TPB][RS]: the tile in use and two in flight
-    float* mu_buf = reinterpret_cast<float*>(g_buf + 3 * tile_b);     // [3][TPB] (+ pad)
-    float* om_stage = mu_buf + 3 * d.TPB + 64;                        // [4 waves][32 users][2KH] omega32
+    char* g_buf = smem_raw;                                           // [NB][TPB][RS]: the tile in use and two (NB = 3) in flight
+    float* mu_buf = reinterpret_cast<float*>(g_buf + NB * tile_b);    // [NB][TPB] (+ pad)
+    float* om_stage = mu_buf + NB * d.TPB + 64;                       // [4 waves][32 users][2KH] omega32
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();   // scalar: per-wave pointers stay in SGPRs
     const int j = lane & 31, h = lane >> 5;
     // (the walked run's sweep, sweep_only: every user of the launch's group [grp_lo, grp_lo + grp_n) is organic at t = 0 and the
@@ -54,8 +55,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         auto fetch_tile = [&](uint32_t ti) {
             constexpr uint32_t TB = 128u * (32u * N1 + 16u);
             for (uint32_t off = static_cast<uint32_t>(wave) * 1024u; off < TB; off += 4096u)
-                dma_to_lds_b128(rs_g, g_lds + ((ti - pt_lo) % 3u) * TB + off, lane16, ti * TB + off);
-            if (wave == 3 && lane < 32) dma_to_lds_b128(rs_m, mu_lds + ((ti - pt_lo) % 3u) * 512u, lane16, ti * 512u);
+                dma_to_lds_b128(rs_g, g_lds + ((ti - pt_lo) % NB) * TB + off, lane16, ti * TB + off);
+            if (wave == 3 && lane < 32) dma_to_lds_b128(rs_m, mu_lds + ((ti - pt_lo) % NB) * 512u, lane16, ti * 512u);
         };
         fetch_tile(pt_lo);
         // ---- omega32 of the user -> LDS stage (also the logit error bound) ----
@@ -121,8 +122,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         constexpr uint32_t RSc = 32 * N1 + 16, TILE_B = 128 * RSc;
         const char* a_lane = g_buf + j * RSc + 16 * h;
         const char* m_lane = reinterpret_cast<const char*>(mu_buf) + 16 * h;
-        auto a_base = [&](uint32_t pi) { return a_lane + ((pi >> 1) % 3u) * TILE_B + (pi & 1) * (64 * RSc); };
-        auto m_base = [&](uint32_t pi) { return m_lane + ((pi >> 1) % 3u) * (128 * 4) + (pi & 1) * (64 * 4); };
+        auto a_base = [&](uint32_t pi) { return a_lane + ((pi >> 1) % NB) * TILE_B + (pi & 1) * (64 * RSc); };
+        auto m_base = [&](uint32_t pi) { return m_lane + ((pi >> 1) % NB) * (128 * 4) + (pi & 1) * (64 * 4); };
         auto load_a = [&](PairOps& o, const char* ab, int idx) {        // A row block idx of the pair's chunk 0 / 1
             if (idx < N1) o.A0[idx < N1 ? idx : 0] = *reinterpret_cast<const bf16x8*>(ab + 32 * idx);
             else o.A1[idx - N1 < N1 ? idx - N1 : 0] = *reinterpret_cast<const bf16x8*>(ab + 32 * RSc + 32 * (idx - N1));
@@ -259,7 +260,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
         RG_DMA_WAIT();
         __syncthreads();           // tile pt_lo landed
         if (pt_lo + 1 < pt_hi) fetch_tile(pt_lo + 1);
-        if (pt_lo + 2 < pt_hi) fetch_tile(pt_lo + 2);
+        if (NB > 2 && pt_lo + 2 < pt_hi) fetch_tile(pt_lo + 2);
 #pragma unroll
         for (int i = 0; i < 2 * N1; ++i) load_a(oa, a_base(0), i);
 #pragma unroll
@@ -303,11 +304,19 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_bf16p(DevSim d, uint32_t t, 
             // ---- tile barrier: every wave holds tile T's operands (its buffer is refilled with tile T + 3);
             // tile T + 1 has landed.  Issued behind its DMA, per wave: the DMA of tile T + 2 (>= 4 operations) and
             // the scratch stores of the tiles finished since (0, 1, then always 2) -> those may stay in flight ----
-            if (T + 2 >= pt_hi) RG_TILE_BARRIER(0);            // nothing was issued behind tile T + 1 but stores
-            else if (pi == 1) RG_TILE_BARRIER(4);               // DMA(T + 2)
-            else if (pi == 3) RG_TILE_BARRIER(5);               // + one store
-            else RG_TILE_BARRIER(6);                            // + two stores
-            if (T + 3 < pt_hi && !RG_SWEEP_ABL(32u)) fetch_tile(T + 3);
+            if (NB > 2) {
+                if (T + 2 >= pt_hi) RG_TILE_BARRIER(0);            // nothing was issued behind tile T + 1 but stores
+                else if (pi == 1) RG_TILE_BARRIER(4);               // DMA(T + 2)
+                else if (pi == 3) RG_TILE_BARRIER(5);               // + one store
+                else RG_TILE_BARRIER(6);                            // + two stores
+                if (T + 3 < pt_hi && !RG_SWEEP_ABL(32u)) fetch_tile(T + 3);
+            } else {
+                // two buffers: tile T + 1's DMA went out at the last barrier (tile T's buffer is refilled with tile T + 2 now);
+                // behind it this wave issued the scratch store of the tile finished since, nothing else
+                if (T + 1 >= pt_hi || pi == 1) RG_TILE_BARRIER(0);
+                else RG_TILE_BARRIER(1);
+                if (T + 2 < pt_hi && !RG_SWEEP_ABL(32u)) fetch_tile(T + 2);
+            }
             stream(ob, oa, pi + 1, p0, p1, a0, a1, s0, s1);                  // MFMAs of pair pi | sums of pair pi - 1
             book(pi - 1, s0, s1);
             if (--sc_issue_left == 0) sc_issue_left = d.sc_chunks / 4;

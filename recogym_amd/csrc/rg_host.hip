@@ -1042,7 +1042,7 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
         if (!(lean && !strcmp(lean, "lean")))
             if (static_cast<size_t>(d.P_pad) * d.RS < (1ull << 31))     // its DMA uses 31-bit buffer offsets
                 if (draw_kernel_t kp = bf16p_kernel_for(d)) s->bf16_kernel = kp;
-        s->bf16_smem = bf16_smem_bytes(geom_of(*cfg), 2 * d.KH, s->bf16_kernel == bf16p_kernel_for(d) ? 3u : 2u);
+        s->bf16_smem = bf16_smem_bytes(geom_of(*cfg), 2 * d.KH, s->bf16_kernel == bf16p_kernel_for(d) ? static_cast<uint32_t>(RG_SWEEP_NB) : 2u);
         if (d.wide) {
             s->bf16_kernel = static_cast<size_t>(d.P_pad) * d.RS < (1ull << 31) ? f16w_kernel_for(d) : nullptr;
             s->bf16_smem = 3 * (64 * static_cast<size_t>(d.RS) + 256) + 8 * 32 * 2 * static_cast<size_t>(d.KH) * 4;
