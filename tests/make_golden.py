@@ -435,6 +435,14 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'normal_time':
         normal_time_goldens()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'transition':       # round 4: a transition matrix and initial scales that are not the defaults
+        # (prob_leave_bandit is set but the reference never reads it: prob_leave_organic fills the stop column of both rows,
+        # reco_env_v1.py:54-61 — these logs pin that on the unmodified reference)
+        T = dict(random_seed=77, num_products=40, K=6, prob_leave_bandit=0.2, prob_leave_organic=0.03, prob_bandit_to_organic=0.15,
+                 prob_organic_to_bandit=0.4, sigma_omega_initial=0.5, sigma_mu_organic=1.5, sigma_omega=0.2)
+        run_case('mt_transition_probs', T, 150, n_organic=10)
+        run_case('philox_transition_probs', T, 150, n_organic=10, agent_kind='ouc', agent_args=dict(random_seed=21), injected=True)
+        return
     notebook_goldens()
     S = dict(random_seed=42)
     # --- reference as shipped (sequential MT19937) ---
