@@ -435,6 +435,12 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'normal_time':
         normal_time_goldens()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'mt_edges':         # round 4: edge shapes on the reference as shipped (oracle pin only)
+        run_case('mt_p2_k1', dict(random_seed=3, num_products=2, K=1), 300, n_organic=5)
+        run_case('mt_large_drift', dict(random_seed=4, num_products=25, K=4, sigma_omega=0.8, sigma_omega_initial=2.0), 120)
+        run_case('mt_ouc_organic_users', dict(random_seed=5, num_products=12, K=3), 120, n_organic=30,
+                 agent_kind='ouc', agent_args=dict(random_seed=31))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'transition':       # round 4: a transition matrix and initial scales that are not the defaults
         # (prob_leave_bandit is set but the reference never reads it: prob_leave_organic fills the stop column of both rows,
         # reco_env_v1.py:54-61 — these logs pin that on the unmodified reference)
