@@ -146,6 +146,11 @@ struct DevSim {
     uint32_t TPB;             // products per LDS tile of the bf16 kernel
     unsigned short* gsplit;   // [P_pad][RS/2] bf16 three-way split of fl32(Gamma log2 e), then 1,1,1 in the last 3 columns of 16*N1
     float* mu32s;             // [P_pad] fl32(mu_o log2 e), -inf beyond P
+    // k_sweep_xh (rg_draw_exacthi.hip): the prefix-form sweep of sigma_omega = 0 whose leading accumulator is error-free
+    uint32_t XNH, XNL, XRS;   // MFMA k-steps of the exact / the residual group, row stride of xsplit in bytes (0: no such kernel)
+    unsigned short* xsplit;   // [P_pad][XRS/2] fixed-point fp16 pieces of Gamma log2 e and mu log2 e (layout: rg_draw_exacthi.hip)
+    float* xmulo;             // [P_pad] seed of the residual accumulator: 2^9 (mu' - its two fixed-point pieces), -inf beyond P
+    float* xstats;            // [2 KH + 1] max_p |Gamma'_pk - Ghi - Glo| per column, then max |Glo|
     uint32_t ablate;          // timing experiments only (RECOGYM_ABLATE); results are wrong when non-zero
     // sigma_omega == 0: a user's omega — hence its softmax — never changes after the reset, so the exp-sums of its
     // first product sweep (step 0: every user starts organic) are kept PER USER (index = user index, never moved by
@@ -306,6 +311,8 @@ struct rg_sim {
     char* h_step;             // 128 pinned bytes of rg_sim_step_user: the action going down, the packed result coming back
     size_t mfma_smem, bf16_smem;
     void (*bf16_kernel)(DevSim, uint32_t, uint32_t);
+    void (*xh_kernel)(DevSim, uint32_t, uint32_t);   // k_sweep_xh: the walked run's sweep where it exists (else bf16_kernel)
+    size_t xh_smem;
     uint32_t draw_threads, draw_users;   // block size of that kernel and the users one block sweeps for (256 / 128; wide K: 512 / 256)
     bool profiling;
     std::vector<hipEvent_t> prof_events;   // 6 per profiled step: before draw, after mfma, after search, after exact, after the frozen LogReg acts, after advance
@@ -341,6 +348,9 @@ finalize_kernel_t finalize_kernel_for(const DevSim& d);    // part 4
 cached_kernel_t cached_kernel_for(const DevSim& d);
 draw_kernel_t bf16p_kernel_for(const DevSim& d);
 draw_kernel_t f16w_kernel_for(const DevSim& d);            // part 5
+draw_kernel_t xh_kernel_for(const DevSim& d);              // part 8 (nullptr: no error-free sweep for this K class)
+void (*xh_table_kernel())(DevSim);
+void (*xh_stats_kernel())(DevSim);
 search_kernel_t drift_kernel();                            // part 6
 search_kernel_t logreg_select_kernel();
 search_kernel_t logreg_acts_kernel();
@@ -395,7 +405,7 @@ constexpr uint32_t kMaxWalkWaves = 4096;
 constexpr uint32_t kParkSlack = 2u * 64u * kMaxWalkWaves;
 constexpr uint32_t kWalkCtlWords = 8u * (kMaxWalkGroups + 1u);
 
-struct Geom { uint32_t KH, KS, TP, P_pad, n_chunks, sc_chunks, n_sc, N1, N2, N3, RS, TPB, F16; };
+struct Geom { uint32_t KH, KS, TP, P_pad, n_chunks, sc_chunks, n_sc, N1, N2, N3, RS, TPB, F16, XNH, XNL, XRS; };
 
 inline Geom geom_of(const rg_config& c) {
     Geom g{};
@@ -437,6 +447,15 @@ inline Geom geom_of(const rg_config& c) {
         if (g.N1) {
             g.RS = 32 * g.N1 + 16;
             g.TPB = g.F16 == 2 ? 64 : 128;          // 4 chunks per tile: the kernel walks pairs of pairs (wide: one pair)
+        }
+    }
+    // k_sweep_xh classes (exact group: K + 3 slots of 16 NH; residual group: 4 K slots of 16 NL); RECOGYM_XH=0: A/B tests
+    if (g.F16 == 1 && (g.KH == 4 || g.KH == 10)) {
+        const char* e_x = getenv("RECOGYM_XH");
+        if (!(e_x && e_x[0] == '0')) {
+            g.XNH = g.KH == 4 ? 1 : 2; g.XNL = g.KH == 4 ? 2 : 5;
+            if (c.K + 3 > 16 * g.XNH || 4 * c.K > 16 * g.XNL) g.XNH = g.XNL = 0;
+            g.XRS = g.XNH ? 32 * (g.XNH + g.XNL) + 16 : 0;
         }
     }
     g.sc_chunks = (g.n_chunks + kMaxSC - 1) / kMaxSC;
@@ -519,6 +538,10 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     double* exact_sums = w.take<double>(exact_rows * (PT / 64));
     unsigned short* gsplit = w.take<unsigned short>(g.N1 ? static_cast<size_t>(g.P_pad) * (g.RS / 2) : 1);
     float* mu32s = w.take<float>(g.N1 ? g.P_pad : 1);
+    const bool xh = g.XNH != 0 && cache_wanted(c, g);
+    unsigned short* xsplit = w.take<unsigned short>(xh ? static_cast<size_t>(g.P_pad) * (g.XRS / 2) : 1);
+    float* xmulo = w.take<float>(xh ? g.P_pad : 1);
+    float* xstats = w.take<float>(2 * g.KH + 2);
     float2* sc_scratch = w.take<float2>(g.KH ? static_cast<size_t>(kMaxGrid) * 4 * kMaxSC * 32 : 1);
     float* chunk_scratch = w.take<float>(g.KH ? static_cast<size_t>(kMaxGrid) * 4 * g.n_chunks * 32 : 1);
     double* omega = w.take<double>(((K + 1) & ~static_cast<size_t>(1)) * n_pad);
@@ -593,6 +616,8 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->gamma_rm = gamma_rm; d->XKB = xkb;
         d->exact_rows = static_cast<uint32_t>(exact_rows); d->exact_base = 0;
         d->gammaT = gammaT; d->PT = static_cast<uint32_t>(PT); d->exact_ref = exact_ref; d->exact_sums = exact_sums; d->sc_scratch = sc_scratch; d->chunk_scratch = chunk_scratch;
+        d->xsplit = xsplit; d->xmulo = xmulo; d->xstats = xstats;
+        d->XNH = xh ? g.XNH : 0; d->XNL = xh ? g.XNL : 0; d->XRS = xh ? g.XRS : 0;
         d->gsplit = gsplit; d->mu32s = mu32s; d->N1 = g.N1; d->N2 = g.N2; d->N3 = g.N3; d->RS = g.RS; d->TPB = g.TPB;
         d->f16 = g.F16 ? 1u : 0u; d->wide = g.F16 == 2 ? 1u : 0u;
         d->KH = g.KH; d->KS = g.KS; d->TP = g.TP; d->P_pad = g.P_pad; d->n_chunks = g.n_chunks;
@@ -1435,9 +1460,13 @@ __device__ __forceinline__ float ahat_of(const DevSim& d, float mumax, float g2m
 // band around a boundary shrinks by the mass BEHIND it, a third of the uncertified draws are left.
 // Both tests are linear in u:  u den_lo > num_lo  and  u den_hi < num_hi  — the memo keeps num / den, rounded inwards.
 struct CertLin { double num_lo, den_lo, num_hi, den_hi; bool valid; };
-__device__ __forceinline__ CertLin cert_correlated(double S, double A, double a, double b, double delta) {
+// rho_rel: the stored prefixes' own roundings, relative to S — 2^-20 (kRhoLoose) where they went through up to five fp32 adds
+// each, 2^-23 (kRhoTight) where each is ONE rounding of a float64 sum (k_sweep_xh); the hot row carries it per user.
+constexpr float kRhoLoose = 9.5463e-7f;    // 2^-20 x 1.001 (.001: second-order terms and the float64 roundings of the test)
+constexpr float kRhoTight = 1.1933e-7f;    // 2^-23 x 1.001
+__device__ __forceinline__ CertLin cert_correlated(double S, double A, double a, double b, double delta, double rho_rel = static_cast<double>(kRhoLoose)) {
     const double dp = delta * (1.0 + 2.0 * delta);         // >= delta / (1 - delta) for delta <= 1/2
-    const double rho = 0x1.0p-20 * 1.001 * S;              // (.001: second-order terms and the float64 roundings of these lines)
+    const double rho = rho_rel * S;
     const double T = S - A;                                // exact: both are fp32 values
     CertLin c;
     c.valid = T >= 0.0 && delta < 0.25;
@@ -1776,6 +1805,32 @@ __device__ __forceinline__ double f16_extra_delta(const DevSim& d, float Ahat, f
     for (uint32_t k = 0; k < d.K; ++k) gsum += d.stats[k];
     return 12.0 * 5.9604644775390625e-08 * static_cast<double>(Ahat) +
            2.98023223876953125e-08 * (static_cast<double>(gsum) + 0.6931471805599453 * static_cast<double>(absw));
+}
+
+// ---- certificate budget of k_sweep_xh (rg_draw_exacthi.hip; derivation: DESIGN.md §2 "round 5") ----
+// v_exp_f32 (<= 2 ulp = 2.4e-7), the chunk's summation tree / the recomputed in-chunk prefix (<= 12 fp32 adds of positive
+// terms: 7.2e-7), margin
+constexpr double kDeltaFixedXh = 2.0e-6;
+// The exact accumulator holds multiples of 2^-16 below 2^24 x 2^-16 = 256: sum of |terms| = sum_k |Ghi whi| + |m1 + m2| + |q|
+// <= Ahat log2 e (the joint bound dominates every sum of absolute values) + |q| + what the two fixed-point roundings add (< 1).
+__device__ __forceinline__ bool xh_eligible(double Ahat, double qabs) {
+    return Ahat * 1.4426950408889634 * 1.001 + qabs + 2.0 < 255.0;
+}
+// delta of a user swept by k_sweep_xh<.., NL>: Ahat (natural units), absw = sum |omega_k|, egam = sum_k |omega_k| x
+// (column k's representation error of Gamma'), lob = bound on the sum of the residual accumulator's |terms| (log2 units,
+// unscaled), qabs = the largest |reference| used.  The larger of what the SWEEP's terms and the walk's RECOMPUTED terms
+// (float64 dot of the fp32 tables, exp2 of the fp32-rounded argument: rg_walk.hip chunk_pass) can be off by.
+template <int NL>
+__device__ __forceinline__ double xh_delta(const DevSim& d, double Ahat, double absw, double egam, double lob, double qabs) {
+    constexpr double e24 = 5.9604644775390625e-08, ln2 = 0.6931471805599453, log2e = 1.4426950408889634;
+    if (!xh_eligible(Ahat, qabs))      // the leading sum may round: the two-way split kernel's budget (same accumulation model)
+        return static_cast<double>(d.K + 5) * e24 * Ahat + kDeltaFixedBf16 + f16_extra_delta(d, static_cast<float>(Ahat), static_cast<float>(absw));
+    const double e_lo = (16.0 * NL + 4.0) * e24 * (lob + 1.6e-5);        // every add of the residual chain rounds at its own size
+    const double e_x = e24 * (Ahat * log2e + qabs) * 1.01;               // the join H + 2^-9 L: one rounding of the exp2 argument
+    const double e_drop = static_cast<double>(d.K) * 1.5e-8 * (1.0 + absw);   // Glo wlo, the omega tail, the scaled variants
+    const double sweep = ln2 * (egam + e_drop + e_lo + e_x) + kDeltaFixedXh;
+    const double rec = e24 * (3.0 * Ahat + ln2 * qabs) * 1.01 + kDeltaFixedXh;
+    return sweep > rec ? sweep : rec;
 }
 
 // Tile DMA the compiler does not see.  hipcc puts s_waitcnt vmcnt(0) in front of the first ds_read

@@ -361,6 +361,7 @@ __global__ void __launch_bounds__(kBlock, RG_SWEEP_OCC) k_draw_bf16p(DevSim d, u
             for (uint32_t sc = d.n_sc; sc < kMaxSC; ++sc) scp_row[sc] = INFINITY;
             *reinterpret_cast<float4*>(d.walk_hot + urow * 32) =
                 make_float4(static_cast<float>(run_pref), dlt * 1.000001f + 4.8e-7f, q, __builtin_bit_cast(float, 0u));
+            d.walk_hot[urow * 32 + 31] = kRhoLoose;
         }
         if (S == 1 && !RG_SWEEP_ABL(128u) && !d.sweep_only) search_and_emit<KH>(d, t, scr, scr_chunk, omu, Ahat, n_resc, active, pos, slot, j, h, true, delta_fixed, &view);
     }

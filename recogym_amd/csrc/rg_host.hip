@@ -863,6 +863,8 @@ int run_walk_pipe(rg_sim* sim, hipStream_t st) {
             ds.fin_in_sweep = dg.fin_in_sweep = sim->fin_in_sweep ? 1u : 0u;
             const uint32_t tiles_up = (dg.grp_n + sim->draw_users - 1) / sim->draw_users;
             if (int rc = span_begin(0, sS)) return rc;
+            if (sim->xh_kernel) hipLaunchKernelGGL(sim->xh_kernel, dim3(sweep_grid(sim, tiles_up, 1)), dim3(kBlock), sim->xh_smem, sS, ds, 0u, 1u);
+            else
             hipLaunchKernelGGL(sim->bf16_kernel, dim3(sweep_grid(sim, tiles_up, 1)), dim3(sim->draw_threads), sim->bf16_smem, sS, ds, 0u, 1u);
             if (int rc = span_end(sS)) return rc;
             if (int rc = span_begin(1, sS)) return rc;
@@ -1063,6 +1065,16 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     if (s->bf16_kernel && s->bf16_smem > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s->bf16_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->bf16_smem));
+    // the walked run's sweep with an error-free leading accumulator (k_sweep_xh) where the pipelined fp16 sweep would run it
+    s->xh_kernel = nullptr; s->xh_smem = 0;
+    if (d.XNH && d.use_cache && d.use_mfma == 2 && s->bf16_kernel && s->bf16_kernel == bf16p_kernel_for(d) && d.f16 && !d.wide &&
+        static_cast<size_t>(d.P_pad) * d.XRS < (1ull << 31))
+        s->xh_kernel = xh_kernel_for(d);
+    if (s->xh_kernel) {
+        s->xh_smem = 2 * (128 * static_cast<size_t>(d.XRS) + 512) + 256;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s->xh_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->xh_smem));
+    } else { d.XNH = d.XNL = d.XRS = 0; }
     d.ablate = 0;
     s->repack_every = 16;
     s->repacked = false;
@@ -1248,6 +1260,11 @@ int rg_sim_set_tables(rg_sim* sim, const double* d_gamma, const double* d_mu_org
         if (sim->d.N1)
             hipLaunchKernelGGL(k_make_split_table, dim3(grid_for(static_cast<size_t>(sim->d.P_pad) * (sim->d.RS / 2))),
                                dim3(kBlock), 0, static_cast<hipStream_t>(stream), sim->d);
+        if (sim->d.XNH) {
+            hipLaunchKernelGGL(xh_table_kernel(), dim3(grid_for(static_cast<size_t>(sim->d.P_pad) * (sim->d.XRS / 2))),
+                               dim3(kBlock), 0, static_cast<hipStream_t>(stream), sim->d);
+            hipLaunchKernelGGL(xh_stats_kernel(), dim3(2 * sim->d.KH + 2), dim3(kBlock), 0, static_cast<hipStream_t>(stream), sim->d);
+        }
     }
     HIP_TRY(hipGetLastError());
     sim->tables_set = true;

@@ -17,6 +17,8 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
         (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
     const DevSim& d = *(const DevSim*)kargs;
     constexpr int K2 = 2 * KH;
+    constexpr bool kPreciseChunk = KH <= 10;   // the K classes k_sweep_xh serves: a chunk is recomputed to that sweep's accuracy
+    constexpr double kLog2e64 = 1.4426950408889634074;
     constexpr int kEmpty = 3;
     // a user that stops still owes its phantom row (one more policy act, abstract.py:311-316): it takes it on its lane's
     // NEXT step, through the one policy_act call site of the loop (a second inlined copy of the policy cost ~15 % of
@@ -598,6 +600,7 @@ __global__ void __launch_bounds__(kBlock) k_cache_prefix(DevSim d, int fused) {
                 // prefixes (<= 5 of 2^-24 each, relative to the prefix: the same kind of error the budget is made of), Q, an empty memo
                 float4* hot = reinterpret_cast<float4*>(d.walk_hot + row * 32);
                 hot[0] = make_float4(static_cast<float>(run), hdr.y * 1.000001f + 4.8e-7f, hdr.x, __builtin_bit_cast(float, 0u));
+                reinterpret_cast<float*>(hot)[31] = kRhoLoose;      // (these prefixes went through several fp32 / rescaling roundings)
             }
         }
     }
@@ -696,6 +699,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
     const __attribute__((address_space(4))) char* kargs =
         (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int K2 = 2 * KH;
+    constexpr bool kPreciseChunk = KH <= 10;   // the K classes k_sweep_xh serves: a chunk is recomputed to that sweep's accuracy
+    constexpr double kLog2e64 = 1.4426950408889634074;
     constexpr int KC = ((K2 + 3) / 4) * 4;
     constexpr int kEmpty = 3, kPhantom = 4;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -913,6 +918,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             const double S = static_cast<double>(h0.x), delta = static_cast<double>(h0.y);
             const float Q = h0.z;
             const uint32_t n_hot = __builtin_bit_cast(uint32_t, h0.w);
+            const double rho_rel = static_cast<double>(hp[7].w);            // the stored prefixes' roundings (cert_correlated)
             const double u_org = d.u_override ? d.u_override[slot] : rg_uniform(w.w[0], w.w[1]);
             const double tau = u_org * S;
             const float tauf = static_cast<float>(tau);
@@ -976,22 +982,46 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     const float Qs = __shfl(Q, s2);
                     const float rems = __shfl(rem_f, s2);                // what is left of u S~ at the chunk's start
                     const float4* gp = reinterpret_cast<const float4*>(d.gamma32t + (static_cast<size_t>(cs) * K2) * 32) + gl;
-                    float4 l = *(reinterpret_cast<const float4*>(d.mu32 + cs * 32) + gl);
+                    const float4 l = *(reinterpret_cast<const float4*>(d.mu32 + cs * 32) + gl);
+                    float e0, e1, e2, e3;
+                    if constexpr (kPreciseChunk) {
+                        // float64 dot of the fp32 tables (products exact, sums to 1e-16), ONE fp32 rounding of the exp2 argument:
+                        // the recomputed terms then carry the error xh_delta's `rec` grants them (rg_common.hpp)
+                        double lx = static_cast<double>(l.x), ly = static_cast<double>(l.y), lz = static_cast<double>(l.z), lw = static_cast<double>(l.w);
 #pragma unroll
-                    for (int kh = 0; kh < K2; kh += KH) {
-                        float4 gk[KH];
+                        for (int kh = 0; kh < K2; kh += KH) {
+                            float4 gk[KH];
 #pragma unroll
-                        for (int k = 0; k < KH; ++k) gk[k] = gp[(kh + k) * 8];
+                            for (int k = 0; k < KH; ++k) gk[k] = gp[(kh + k) * 8];
 #pragma unroll
-                        for (int k = 0; k < KH; ++k) {
-                            const float wk = __shfl(om[kh + k], s2);
-                            l.x = fmaf(gk[k].x, wk, l.x); l.y = fmaf(gk[k].y, wk, l.y);
-                            l.z = fmaf(gk[k].z, wk, l.z); l.w = fmaf(gk[k].w, wk, l.w);
+                            for (int k = 0; k < KH; ++k) {
+                                const double wk = static_cast<double>(__shfl(om[kh + k], s2));
+                                lx = fma(static_cast<double>(gk[k].x), wk, lx); ly = fma(static_cast<double>(gk[k].y), wk, ly);
+                                lz = fma(static_cast<double>(gk[k].z), wk, lz); lw = fma(static_cast<double>(gk[k].w), wk, lw);
+                            }
+                            asm volatile("" : "+v"(lx), "+v"(ly), "+v"(lz), "+v"(lw));
                         }
-                        asm volatile("" : "+v"(l.x), "+v"(l.y), "+v"(l.z), "+v"(l.w));
+                        const double Qd = static_cast<double>(Qs);
+                        e0 = __builtin_amdgcn_exp2f(static_cast<float>(fma(lx, kLog2e64, -Qd))); e1 = __builtin_amdgcn_exp2f(static_cast<float>(fma(ly, kLog2e64, -Qd)));
+                        e2 = __builtin_amdgcn_exp2f(static_cast<float>(fma(lz, kLog2e64, -Qd))); e3 = __builtin_amdgcn_exp2f(static_cast<float>(fma(lw, kLog2e64, -Qd)));
+                    } else {
+                        float4 lf = l;
+#pragma unroll
+                        for (int kh = 0; kh < K2; kh += KH) {
+                            float4 gk[KH];
+#pragma unroll
+                            for (int k = 0; k < KH; ++k) gk[k] = gp[(kh + k) * 8];
+#pragma unroll
+                            for (int k = 0; k < KH; ++k) {
+                                const float wk = __shfl(om[kh + k], s2);
+                                lf.x = fmaf(gk[k].x, wk, lf.x); lf.y = fmaf(gk[k].y, wk, lf.y);
+                                lf.z = fmaf(gk[k].z, wk, lf.z); lf.w = fmaf(gk[k].w, wk, lf.w);
+                            }
+                            asm volatile("" : "+v"(lf.x), "+v"(lf.y), "+v"(lf.z), "+v"(lf.w));
+                        }
+                        e0 = __builtin_amdgcn_exp2f(fmaf(lf.x, kLog2e, -Qs)); e1 = __builtin_amdgcn_exp2f(fmaf(lf.y, kLog2e, -Qs));
+                        e2 = __builtin_amdgcn_exp2f(fmaf(lf.z, kLog2e, -Qs)); e3 = __builtin_amdgcn_exp2f(fmaf(lf.w, kLog2e, -Qs));
                     }
-                    const float e0 = __builtin_amdgcn_exp2f(fmaf(l.x, kLog2e, -Qs)), e1 = __builtin_amdgcn_exp2f(fmaf(l.y, kLog2e, -Qs));
-                    const float e2 = __builtin_amdgcn_exp2f(fmaf(l.z, kLog2e, -Qs)), e3 = __builtin_amdgcn_exp2f(fmaf(l.w, kLog2e, -Qs));
                     const float q0 = e0, q1 = q0 + e1, q2 = q1 + e2, q3 = q2 + e3;
                     float inc = q3;
 #pragma unroll
@@ -1026,7 +1056,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             bool ok = false;
             if (search) {
                 const int idx = static_cast<int>(mboxf[lane * 3]);
-                const CertLin ct = cert_correlated(S, pb, static_cast<double>(mboxf[lane * 3 + 1]), static_cast<double>(mboxf[lane * 3 + 2]), delta);
+                const CertLin ct = cert_correlated(S, pb, static_cast<double>(mboxf[lane * 3 + 1]), static_cast<double>(mboxf[lane * 3 + 2]), delta, rho_rel);
                 v = c_star * 32 + static_cast<uint32_t>(max(idx, 0));
                 const bool lo_ok = v == 0 || u_org * ct.den_lo > ct.num_lo;
                 const bool hi_ok = v == d.P - 1 || u_org * ct.den_hi < ct.num_hi;
@@ -1566,6 +1596,8 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
     (void)d_arg;       // read where it lies, in the kernel-argument segment (the float64 pick is a call that takes its address)
     const DevSim& d = *(const DevSim*)(const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int K2 = 2 * KH;
+    constexpr bool kPreciseChunk = KH <= 10;   // the K classes k_sweep_xh serves: a chunk is recomputed to that sweep's accuracy
+    constexpr double kLog2e64 = 1.4426950408889634074;
     constexpr int KC = ((K2 + 3) / 4) * 4;
     constexpr int kEmpty = 3, kPhantom = 4;
     __shared__ hent_t s_hist[kBlock / 64][HIST ? kSoloHist : 1];      // the user's history row: [0] header, then the entries
@@ -1697,6 +1729,7 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
                 const double S = static_cast<double>(h0.x), delta = static_cast<double>(h0.y);
                 const float Q = h0.z;
                 const uint32_t n_hot = __builtin_bit_cast(uint32_t, h0.w);
+                const double rho_rel = static_cast<double>(hp[7].w);
                 const double u_org = d.u_override ? d.u_override[slot] : rg_uniform(w.w[0], w.w[1]);   // (test hook)
                 float uf = static_cast<float>(u_org), u_dn = uf, u_up = uf;
                 if (static_cast<double>(uf) > u_org) u_dn = f32_down(uf);
@@ -1780,22 +1813,44 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
                             const uint32_t cs = static_cast<uint32_t>(__shfl(static_cast<int>(c_star), s2));
                             const float rems = __shfl(rem, s2);
                             const float4* gp = reinterpret_cast<const float4*>(d.gamma32t + (static_cast<size_t>(cs) * K2) * 32) + gl;
-                            float4 l = *(reinterpret_cast<const float4*>(d.mu32 + cs * 32) + gl);
+                            const float4 l = *(reinterpret_cast<const float4*>(d.mu32 + cs * 32) + gl);
+                            float e0, e1, e2, e3;
+                            if constexpr (kPreciseChunk) {        // (as k_walk2's chunk_pass: float64 dot, one rounding of the exp2 argument)
+                                double lx = static_cast<double>(l.x), ly = static_cast<double>(l.y), lz = static_cast<double>(l.z), lw = static_cast<double>(l.w);
 #pragma unroll
-                            for (int kh = 0; kh < K2; kh += KH) {
-                                float4 gk[KH];
+                                for (int kh = 0; kh < K2; kh += KH) {
+                                    float4 gk[KH];
 #pragma unroll
-                                for (int k = 0; k < KH; ++k) gk[k] = gp[(kh + k) * 8];
+                                    for (int k = 0; k < KH; ++k) gk[k] = gp[(kh + k) * 8];
 #pragma unroll
-                                for (int k = 0; k < KH; ++k) {
-                                    const float wk = om[kh + k];                 // (every lane holds THE user's omega32)
-                                    l.x = fmaf(gk[k].x, wk, l.x); l.y = fmaf(gk[k].y, wk, l.y);
-                                    l.z = fmaf(gk[k].z, wk, l.z); l.w = fmaf(gk[k].w, wk, l.w);
+                                    for (int k = 0; k < KH; ++k) {
+                                        const double wk = static_cast<double>(om[kh + k]);   // (every lane holds THE user's omega32)
+                                        lx = fma(static_cast<double>(gk[k].x), wk, lx); ly = fma(static_cast<double>(gk[k].y), wk, ly);
+                                        lz = fma(static_cast<double>(gk[k].z), wk, lz); lw = fma(static_cast<double>(gk[k].w), wk, lw);
+                                    }
+                                    asm volatile("" : "+v"(lx), "+v"(ly), "+v"(lz), "+v"(lw));
                                 }
-                                asm volatile("" : "+v"(l.x), "+v"(l.y), "+v"(l.z), "+v"(l.w));
+                                const double Qd = static_cast<double>(Q);
+                                e0 = __builtin_amdgcn_exp2f(static_cast<float>(fma(lx, kLog2e64, -Qd))); e1 = __builtin_amdgcn_exp2f(static_cast<float>(fma(ly, kLog2e64, -Qd)));
+                                e2 = __builtin_amdgcn_exp2f(static_cast<float>(fma(lz, kLog2e64, -Qd))); e3 = __builtin_amdgcn_exp2f(static_cast<float>(fma(lw, kLog2e64, -Qd)));
+                            } else {
+                                float4 lf = l;
+#pragma unroll
+                                for (int kh = 0; kh < K2; kh += KH) {
+                                    float4 gk[KH];
+#pragma unroll
+                                    for (int k = 0; k < KH; ++k) gk[k] = gp[(kh + k) * 8];
+#pragma unroll
+                                    for (int k = 0; k < KH; ++k) {
+                                        const float wk = om[kh + k];
+                                        lf.x = fmaf(gk[k].x, wk, lf.x); lf.y = fmaf(gk[k].y, wk, lf.y);
+                                        lf.z = fmaf(gk[k].z, wk, lf.z); lf.w = fmaf(gk[k].w, wk, lf.w);
+                                    }
+                                    asm volatile("" : "+v"(lf.x), "+v"(lf.y), "+v"(lf.z), "+v"(lf.w));
+                                }
+                                e0 = __builtin_amdgcn_exp2f(fmaf(lf.x, kLog2e, -Q)); e1 = __builtin_amdgcn_exp2f(fmaf(lf.y, kLog2e, -Q));
+                                e2 = __builtin_amdgcn_exp2f(fmaf(lf.z, kLog2e, -Q)); e3 = __builtin_amdgcn_exp2f(fmaf(lf.w, kLog2e, -Q));
                             }
-                            const float e0 = __builtin_amdgcn_exp2f(fmaf(l.x, kLog2e, -Q)), e1 = __builtin_amdgcn_exp2f(fmaf(l.y, kLog2e, -Q));
-                            const float e2 = __builtin_amdgcn_exp2f(fmaf(l.z, kLog2e, -Q)), e3 = __builtin_amdgcn_exp2f(fmaf(l.w, kLog2e, -Q));
                             const float q0 = e0, q1 = q0 + e1, q2 = q1 + e2, q3 = q2 + e3;
                             float inc = q3;
 #pragma unroll
@@ -1824,7 +1879,7 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
                     __builtin_amdgcn_wave_barrier();
                     if (search) {
                         const int ix = static_cast<int>(mboxf[lane * 3]);
-                        const CertLin ct = cert_correlated(S, pb, static_cast<double>(mboxf[lane * 3 + 1]), static_cast<double>(mboxf[lane * 3 + 2]), delta);
+                        const CertLin ct = cert_correlated(S, pb, static_cast<double>(mboxf[lane * 3 + 1]), static_cast<double>(mboxf[lane * 3 + 2]), delta, rho_rel);
                         v = c_star * 32 + static_cast<uint32_t>(max(ix, 0));
                         const bool lo_ok = v == 0 || u_org * ct.den_lo > ct.num_lo;
                         const bool hi_ok = v == d.P - 1 || u_org * ct.den_hi < ct.num_hi;

@@ -674,7 +674,7 @@ def test_certificate_is_sound_for_uniforms_next_to_cdf_boundaries(mode, shape, m
     assert clear.mean() > 0.95
 
 
-@pytest.mark.parametrize('walk', ['default', 'solo_only', 'k_walk'])
+@pytest.mark.parametrize('walk', ['default', 'solo_only', 'k_walk', 'pipe', 'pipe_solo'])
 @pytest.mark.parametrize('shape', [(10000, 20), (3000, 20), (640, 7)])
 def test_walk_certificate_is_sound_for_uniforms_next_to_cdf_boundaries(shape, walk, monkeypatch):
     """The same adversarial placement for the user-major walk (sigma_omega = 0): EVERY organic draw of a user gets the
@@ -682,14 +682,18 @@ def test_walk_certificate_is_sound_for_uniforms_next_to_cdf_boundaries(shape, wa
     the independent-error form of the certificate rejected and the correlated form (cert_correlated) may accept.  Whatever
     decided a draw (the search's certificate, the memo built from it, the float64-anchored certificate, the float64
     pick), every logged product must be float64's.  `solo_only`: hand-over at 64 live lanes, so the wave-per-user kernel
-    takes nearly all users; `k_walk`: round 2's kernel."""
+    takes nearly all users; `k_walk`: round 2's kernel; `pipe` / `pipe_solo`: run_walk_pipe (RECOGYM_PIPE_MIN lowered), whose
+    sweep is k_sweep_xh — the error-free leading accumulator, a delta ~8x smaller and rho = 2^-23: the band these uniforms are
+    placed in is the one that certificate newly ACCEPTS."""
     import ctypes as C
     from recogym_amd.envs.static_params import draw_tables
     from recogym_amd.sim import Simulator
-    for k in ('RECOGYM_DRAW', 'RECOGYM_WALK', 'RECOGYM_WALK_HANDOVER'):
+    for k in ('RECOGYM_DRAW', 'RECOGYM_WALK', 'RECOGYM_WALK_HANDOVER', 'RECOGYM_PIPE_MIN', 'RECOGYM_XH'):
         monkeypatch.delenv(k, raising=False)
-    if walk == 'solo_only':
+    if walk in ('solo_only', 'pipe_solo'):
         monkeypatch.setenv('RECOGYM_WALK_HANDOVER', '64')
+    if walk in ('pipe', 'pipe_solo'):
+        monkeypatch.setenv('RECOGYM_PIPE_MIN', '256')
     if walk == 'k_walk':
         monkeypatch.setenv('RECOGYM_WALK', '1')
     P, K = shape
