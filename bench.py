@@ -50,7 +50,8 @@ F16_MFMA_PEAK_TFLOPS = 2516.6      # v_mfma_f32_32x32x16_f16 / bf16, dense (256 
 F64_VALU_PEAK_TFLOPS = 78.6
 HBM_PEAK_GBPS = 8000.0
 EXP_PEAK_PER_S = 1024 * 4 * 2.4e9  # v_exp_f32: quarter rate, 4 lanes per cycle and SIMD (MI355X_MICROARCH.md: transcendentals)
-PROFILE_ROUNDS = ('r4', 'r3', 'r2')      # profiles/<round>/pmc_traffic.json, newest first
+VALU_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4   # a SIMD issues one full-rate vector wave-instruction per 4 cycles: 256 CUs x 4 SIMDs
+PROFILE_ROUNDS = ('r5', 'r4', 'r3', 'r2')      # profiles/<round>/pmc_traffic.json, newest first
 
 
 def policy_kwargs(pol):
@@ -202,10 +203,11 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
         tf = 2.0 * P * K * swept / (prof['draw_mfma_ms'] * 1e-3) / 1e12
         peak = F16_MFMA_PEAK_TFLOPS if K <= 64 else FP32_MFMA_PEAK_TFLOPS
         exp_ms = 1e3 * float(P) * swept / EXP_PEAK_PER_S
-        out['draw_sweep'] = dict(kernel='k_draw_bf16p' if K <= 21 else 'k_draw_* (K class)', bound='mfma',
+        out['draw_sweep'] = dict(kernel=('k_sweep_xh' if (cached and K <= 20 and os.environ.get('RECOGYM_XH', '1') != '0') else 'k_draw_bf16p') if K <= 21 else 'k_draw_* (K class)', bound='mfma',
                                  ms=round(prof['draw_mfma_ms'], 2), units=int(swept), unit_name='swept draws',
                                  achieved=round(tf, 2), peak=peak, unit='TFLOP/s', frac=round(tf / peak, 4),
-                                 executed_mfma_tflops=round(tf * (64.0 if f16_split else 144.0) / K, 1) if K <= 21 else None,
+                                 executed_mfma_tflops=round(tf * ((112.0 if K > 8 else 48.0) if (cached and K <= 20 and os.environ.get('RECOGYM_XH', '1') != '0')
+                                                                  else (64.0 if f16_split else 144.0)) / K, 1) if K <= 21 else None,
                                  # one v_exp_f32 per logit at a quarter of the fp32 lane rate: the kernel's real ceiling
                                  exp_bound_ms=round(exp_ms, 2), frac_of_exp_bound=round(exp_ms / prof['draw_mfma_ms'], 4))
     walked = prof.get('walk1_ms', 0.0) > 0
@@ -220,15 +222,22 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
                            bytes_per_unit=b_survey,
                            achieved=round(gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(gbps / HBM_PEAK_GBPS, 4),
                            note='not bound by HBM bandwidth: the per-user state lives in L2 and the Infinity Cache, and the kernel is '
-                                'bound by its instruction stream (24 vector + 12 scalar wave-instructions per event: ~40 of its '
-                                '67 ms are vector-ALU issue, profiles/r4/pmc_c3_sq_counters.csv) and its dependent loads (DESIGN.md 4)')
+                                'bound by its instruction stream and its dependent loads (DESIGN.md 4): `issue_roofline` prices the '
+                                'vector wave-instructions it executes against the vector ALUs\' issue rate')
+        iss = measured_issue(pol)
+        if iss is not None:
+            issue_ms = 1e3 * iss['valu_wave_instr_per_unit'] * events / VALU_WAVE_INSTR_PER_S
+            out['walk']['issue_roofline'] = dict(valu_wave_instr_per_event=round(iss['valu_wave_instr_per_unit'], 2),
+                                                 salu_wave_instr_per_event=round(iss.get('salu_wave_instr_per_unit', 0.0), 2),
+                                                 peak_valu_wave_instr_per_s=VALU_WAVE_INSTR_PER_S, issue_bound_ms=round(issue_ms, 2),
+                                                 frac=round(issue_ms / ms, 4), source=iss['source'],
+                                                 note='SQ_INSTS_VALU of the profiled run per event x this run\'s events x 4 cycles / (1024 SIMDs x '
+                                                      '2.4 GHz) over the walk kernels\' time: the fraction of the time the vector ALUs must issue')
         if prof['draw_search_ms'] > 0:
-            by = 512 + 8 * K
-            out['cache_finalize'] = dict(kernel='k_cache_finalize', bound='hbm', ms=round(prof['draw_search_ms'], 2), units=int(users),
-                                         unit_name='users', bytes_per_unit=by,
-                                         achieved=round(by * users / (prof['draw_search_ms'] * 1e-3) / 1e9, 1),
-                                         peak=HBM_PEAK_GBPS, unit='GB/s',
-                                         frac=round(by * users / (prof['draw_search_ms'] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4))
+            # since round 4 the sweep leaves this output itself; the two kernels only visit the users whose reference moved during
+            # the sweep (a count the library does not export): time only, no roofline
+            out['cache_finalize'] = dict(kernel='k_cache_finalize + k_cache_prefix', bound='none', ms=round(prof['draw_search_ms'], 2),
+                                         units=None, unit_name='users whose reference moved during the sweep (not counted)')
     # cached draw (sigma_omega = 0, t >= 1, lock-step form): per draw the user's 32 super-chunk sums (128 B), the chosen
     # super-chunk's chunk sums (48 B), omega32 (4K) and the 16-byte row: HBM gather
     if cached and not walked and prof['draw_search_ms'] > 0:
@@ -241,7 +250,7 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
     # float64 resolve: per sweep P * (2K + ~16) float64 flop-equivalents
     if prof['draw_exact_ms'] > 0 and c['exact_sweeps'] > 0:
         tf = c['exact_sweeps'] * float(P) * (2 * K + 16) / (prof['draw_exact_ms'] * 1e-3) / 1e12
-        out['draw_exact_f64'] = dict(kernel='k_exact_sums_* + k_exact_pick', bound='f64 mfma + valu', ms=round(prof['draw_exact_ms'], 2),
+        out['draw_exact_f64'] = dict(kernel='k_exact_sums_* + k_exact_pick', bound='mfma', pipe='float64 matrix + vector pipes (they share issue: DESIGN.md 4)', ms=round(prof['draw_exact_ms'], 2),
                                      units=int(c['exact_sweeps']), unit_name='float64 sweeps', achieved=round(tf, 2),
                                      peak=F64_VALU_PEAK_TFLOPS, unit='TFLOP/s', frac=round(tf / F64_VALU_PEAK_TFLOPS, 4),
                                      resolved_draws=int(c['exact_draws']))
@@ -269,6 +278,20 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
                               units=int(events), unit_name='events', bytes_per_unit=b_survey,
                               achieved=round(gbps, 1), peak=HBM_PEAK_GBPS, unit='GB/s', frac=round(gbps / HBM_PEAK_GBPS, 4))
     return out
+
+
+def measured_issue(pol):
+    """Vector / scalar wave-instructions per event of the walk kernels from the committed SQ counter pass
+    (profiles/<round>/pmc_traffic.json, entry `k_walk_issue`) — None when there is none for this policy."""
+    for rnd in PROFILE_ROUNDS:
+        try:
+            pt = json.load(open(os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic.json')))
+        except Exception:
+            continue
+        e = pt.get('kernels', {}).get('k_walk_issue')
+        if e is not None and e.get('policy', 'ouc') == pol:
+            return e
+    return None
 
 
 def measured_traffic(workload, name):
@@ -300,6 +323,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-drift-line', action='store_true', help='skip the sigma_omega > 0 companion measurement')
     ap.add_argument('--no-materialise', action='store_true', help='skip the sort_log / log_columns timings')
+    ap.add_argument('--no-other-workloads', action='store_true', help='skip the one-step lines of BASELINE configs 2, 4 (one rank\'s share) and 5')
     ap.add_argument('--single-run', action='store_true',
                     help='exactly ONE simulation per arm in the process (the HIP-event profile is taken on the timed run): what '
                          'the rocprofv3 --pmc passes run, so that a counter summed over the trace belongs to one run')
@@ -308,7 +332,7 @@ def main():
     args = ap.parse_args()
     if args.single_run:
         args.steps, args.warmup = 1, 0
-        args.no_cpu_baseline = args.no_drift_line = args.no_materialise = True
+        args.no_cpu_baseline = args.no_drift_line = args.no_materialise = args.no_other_workloads = True
 
     from recogym_amd import parallel
     rc = parallel.self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:])
@@ -445,7 +469,7 @@ def main():
         roofline['dominant'] = dom
         if roofline['kernel'] == 'k_walk':
             # rounds of one run: 1, the parked users' round 2, and round 3 for what draining waves handed over
-            launches = (3 if os.environ.get('RECOGYM_WALK_HANDOVER', '16') != '0' else 2) if prof['walk2_ms'] > 0 else 1
+            launches = (3 if arms[0][1].get_option('walk_handover') != 0 else 2) if prof['walk2_ms'] > 0 else 1
             roofline['achieved_is'] = ('SURVEY.md 8d bytes per event x events of the run / total time of the run\'s walk launches '
                                        '(rounds of unequal size: avg_launch_ms is the run\'s time divided by their number)')
         elif roofline['unit'] == 'GB/s':
@@ -529,6 +553,33 @@ def main():
         del darms
         torch.cuda.empty_cache()
 
+    # --- the other BASELINE configurations, one timed step each (after one warm-up), so that the driver's clock sees them too:
+    # config 2, one rank's share of config 4, config 5 (both arms) — compact entries: value, ms per step, the kernel with the most time ---
+    others = None
+    if args.workload == 'c3' and world == 1 and not args.no_other_workloads and not args.shard:
+        others = {}
+        saved_fu = (first_user, users)
+        for wl in ('c2', 'c4shard', 'c5'):
+            first_user, users = 0, WORKLOADS[wl][1]
+            ocfg, oarms = build(wl, users)
+            o_el, o_tot, o_last = timed(oarms, 1, 1)
+            for c in o_last:
+                assert c['hist_overflow'] == 0 and c['log_dropped'] == 0 and c['live'] == 0 and c['exact_overflow'] == 0, c
+            _, o_k = profile(oarms, ocfg)
+            o_dom = max(o_k, key=lambda k: o_k[k]['ms'])
+            others[wl] = dict(workload=f'{wl}: reco-gym-v1 P={ocfg.num_products} K={ocfg.K} sigma_omega={ocfg.sigma_omega} policy={WORKLOADS[wl][3]}',
+                              users=users, value=float(o_tot[0] + o_tot[1]) / o_el, unit='events/s', ms_per_step=round(1e3 * o_el, 2),
+                              events_per_step=int(o_tot[0] + o_tot[1]), steps=1, warmup=1,
+                              dominant=o_dom, dominant_kernel=o_k[o_dom]['kernel'], dominant_ms=o_k[o_dom]['ms'],
+                              dominant_bound=o_k[o_dom]['bound'], dominant_frac=o_k[o_dom].get('frac'),
+                              frac_of_exp_bound=o_k[o_dom].get('frac_of_exp_bound'),
+                              kernels_ms={k: v['ms'] for k, v in o_k.items()})
+            for _, s_o in oarms:
+                s_o.close()
+            del oarms
+            torch.cuda.empty_cache()
+        first_user, users = saved_fu
+
     # --- N > 1: the OTHER scaling form in the same run (north_star states the target as 10 M users in total over 1/2/4/8
     # GPUs: strong; the contract's `value` keeps per-GPU work fixed: weak), and the latency of the one collective the path has ---
     other = allreduce = None
@@ -604,6 +655,7 @@ def main():
             'kernels': kernels,
             'materialise': materialise,
             'sigma_omega_gt0': drift,
+            'other_workloads': others,
             'cpu_baseline': cpu,
         }
         if world > 1:

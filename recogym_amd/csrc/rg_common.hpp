@@ -1809,8 +1809,8 @@ __device__ __forceinline__ double f16_extra_delta(const DevSim& d, float Ahat, f
 
 // ---- certificate budget of k_sweep_xh (rg_draw_exacthi.hip; derivation: DESIGN.md §2 "round 5") ----
 // v_exp_f32 (<= 2 ulp = 2.4e-7), the chunk's summation tree / the recomputed in-chunk prefix (<= 12 fp32 adds of positive
-// terms: 7.2e-7), margin
-constexpr double kDeltaFixedXh = 2.0e-6;
+// terms: 7.2e-7): 9.6e-7, + 25 % margin
+constexpr double kDeltaFixedXh = 1.2e-6;
 // The exact accumulator holds multiples of 2^-16 below 2^24 x 2^-16 = 256: sum of |terms| = sum_k |Ghi whi| + |m1 + m2| + |q|
 // <= Ahat log2 e (the joint bound dominates every sum of absolute values) + |q| + what the two fixed-point roundings add (< 1).
 __device__ __forceinline__ bool xh_eligible(double Ahat, double qabs) {
@@ -1827,7 +1827,10 @@ __device__ __forceinline__ double xh_delta(const DevSim& d, double Ahat, double 
         return static_cast<double>(d.K + 5) * e24 * Ahat + kDeltaFixedBf16 + f16_extra_delta(d, static_cast<float>(Ahat), static_cast<float>(absw));
     const double e_lo = (16.0 * NL + 4.0) * e24 * (lob + 1.6e-5);        // every add of the residual chain rounds at its own size
     const double e_x = e24 * (Ahat * log2e + qabs) * 1.01;               // the join H + 2^-9 L: one rounding of the exp2 argument
-    const double e_drop = static_cast<double>(d.K) * 1.5e-8 * (1.0 + absw);   // Glo wlo, the omega tail, the scaled variants
+    // what the pieces leave out, per coordinate: Glo wlo <= 2^-9 2^-21, the omega tail <= |Ghi| 2^-33 <= 2^-30, the second scaled
+    // copies of Glo / wmid (a bit below fp16's normal range at most): 4e-9 covers 2^-29
+    const double e_drop = static_cast<double>(d.K) * 4.0e-9;
+    (void)absw;
     const double sweep = ln2 * (egam + e_drop + e_lo + e_x) + kDeltaFixedXh;
     const double rec = e24 * (3.0 * Ahat + ln2 * qabs) * 1.01 + kDeltaFixedXh;
     return sweep > rec ? sweep : rec;

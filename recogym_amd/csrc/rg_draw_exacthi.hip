@@ -30,6 +30,18 @@
 
 #include "rg_common.hpp"
 
+// -DRG_XH_ABL=bits: timing experiments (results wrong by design; A/B builds only, loaded with RECOGYM_HIP_LIB).  1: no residual
+// MFMAs beyond the first, 2: exps replaced by a move, 4: the next chunk's operand rows are not re-read, 8: no seed reads,
+// 16: no tile DMA / barrier, 32: no scheduling pins, 64: no bookkeeping
+#ifndef RG_XH_ABL
+#define RG_XH_ABL 0
+#endif
+#if (RG_XH_ABL & 32)
+#define RG_XPIN() do {} while (0)
+#else
+#define RG_XPIN() RG_PIN()
+#endif
+
 namespace rgk {
 
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
@@ -236,7 +248,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
                 const int i = m >> 1;
                 if (m & 1) H = mm(o.a[i], Bm[i], i == 0 ? zero16 : H);
                 else L = mm(o.a[NH + i], Bm[NH + i], L);
-            } else L = mm(o.a[m], Bm[m], L);   // residual step m - NH sits at operand index NH + (m - NH)
+            } else if (!(RG_XH_ABL & 1)) L = mm(o.a[m], Bm[m], L);   // residual step m - NH sits at operand index NH + (m - NH)
         };
         // One step: MFMAs of chunk (cur operands) into (Ha, La: La holds its seed) | join + exp-sum of the chunk before in
         // (Hb, Lb) -> sum | operand rows of the next chunk -> no, its seed -> Lb
@@ -244,13 +256,13 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
             f32x2v x[4];
             const char* ab = a_base(ci_next);
             const char* mb = m_base(ci_next);
-            RG_PIN();
+            RG_XPIN();
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 issue(co, m, Ha, La);
                 // the next chunk's operand rows: spread over the first slots
 #pragma unroll
-                for (int i = m * NM / (NM > 2 ? NM - 2 : 1); i < (m + 1) * NM / (NM > 2 ? NM - 2 : 1) && i < NM; ++i) load_a(no, ab, i);
+                for (int i = m * NM / (NM > 2 ? NM - 2 : 1); i < (m + 1) * NM / (NM > 2 ? NM - 2 : 1) && i < NM; ++i) if (!(RG_XH_ABL & 4)) load_a(no, ab, i);
                 if (m == 1 || NM == 1) {
                     // join: logit = H + 2^-9 L (one rounding), in place
 #pragma unroll
@@ -266,13 +278,13 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
                     const int m1 = NM > 1 ? m - 1 : 0;
 #pragma unroll
                     for (int e = (m1 * 8 / ES) * 2; e < ((m1 + 1) * 8 / ES) * 2; e += 2) {
-                        f32x2v y = {__builtin_amdgcn_exp2f(Hb[e]), __builtin_amdgcn_exp2f(Hb[e + 1])};
+                        f32x2v y = {(RG_XH_ABL & 2) ? Hb[e] * 0.5f : __builtin_amdgcn_exp2f(Hb[e]), (RG_XH_ABL & 2) ? Hb[e + 1] * 0.5f : __builtin_amdgcn_exp2f(Hb[e + 1])};
                         asm volatile("" : "+v"(y));
                         if (e < 8) x[e / 2] = y; else x[(e / 2) & 3] += y;
                     }
                 }
-                if (m >= 2 && m - 2 < 4) load_seed(Lb, mb, m - 2);
-                RG_PIN();
+                if (m >= 2 && m - 2 < 4 && !(RG_XH_ABL & 8)) load_seed(Lb, mb, m - 2);
+                RG_XPIN();
             }
             if (NM < 6) {
 #pragma unroll
@@ -280,7 +292,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
             }
             x[0] += x[2]; x[1] += x[3]; x[0] += x[1];
             sum = x[0][0] + x[0][1];
-            RG_PIN();
+            RG_XPIN();
         };
 
         // ---- per-chunk bookkeeping (prefix form: what k_walk2 searches), one chunk behind the MFMAs ----
@@ -294,6 +306,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
         uint32_t sc_left = d.sc_chunks / 4;
         float w0 = 0.f, w1 = 0.f, w2 = 0.f;
         auto book = [&](uint32_t ci, float s) {    // sum of chunk ci
+            if (RG_XH_ABL & 64) { wcmax += s; return; }
             s += swap32(s);
             const uint32_t c = ci & 3;
             if (c == 0) { w0 = s; return; }
@@ -332,7 +345,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
         for (int i = 0; i < NM; ++i) load_a(oa, a_base(0), i);
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) { load_seed(L0, m_base(0), qq); load_seed(L1, m_base(0), qq); }
-        RG_PIN();
+        RG_XPIN();
         {   // chunk 0 with reference 0: its largest logit, rounded up to an integer, becomes the reference
 #pragma unroll
             for (int m = 0; m < NM; ++m) issue(oa, m, H1, L1);
@@ -342,17 +355,17 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
             set_reference(fmaxf(ceilf(fmaxf(cm, swap32(cm))), -1.0e30f));
             q_done = q_next = q;
         }
-        RG_PIN();
+        RG_XPIN();
         // head: chunk 0's MFMAs with nothing to exp yet; chunk 1's rows and seed arrive meanwhile
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             issue(oa, m, H0, L0);
             load_a(ob, a_base(1), m);
-            RG_PIN();
+            RG_XPIN();
         }
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) load_seed(L1, m_base(1), qq);
-        RG_PIN();
+        RG_XPIN();
         const uint32_t n_ch = d.n_chunks;
         uint32_t sc_issue_left = d.sc_chunks / 4;       // tiles left in the super-chunk being ISSUED
         // Steady state: steps (ci, ci + 1) per iteration so that the accumulator sets alternate by name (no branch touches a
@@ -364,9 +377,9 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
             if ((ci & 3) == 3) {
                 // the next step reads tile T + 1: it has landed, and every wave is done reading tile T's buffer... which is
                 // refilled with tile T + 2
-                RG_TILE_BARRIER(0);
+                if (!(RG_XH_ABL & 16)) RG_TILE_BARRIER(0);
                 const uint32_t T = ci >> 2;
-                if (T + 2 < n_pt) fetch_tile(T + 2);
+                if (T + 2 < n_pt && !(RG_XH_ABL & 16)) fetch_tile(T + 2);
             }
             stream(ob, oa, min(ci + 1, n_ch - 1), H1, L1, H0, L0, s);
             book(ci - 1, s);

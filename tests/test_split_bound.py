@@ -141,3 +141,89 @@ def test_correlated_certificate_is_sound_for_worst_case_term_errors(delta):
                         o_hi = (A + b) * (1 - delta) / (S * (1 + delta))
                         wins += (u_hi - u_lo) > max(o_hi - o_lo, 0.0)
     assert wins > n_cases            # (8 sign patterns per case: the correlated interval is the wider one in most of them)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# k_sweep_xh (recogym_amd/csrc/rg_draw_exacthi.hip): the fixed-point pieces, restated in numpy.  Checked here: every product of
+# the leading group is a multiple of 2^-16 and the group's sum is EXACT in fp32 in any order; the residual group carries what
+# is left of Gamma', omega and mu to ~2^-26; the error of a term against float64 stays inside xh_delta's budget.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _f16(x):
+    return np.asarray(x, dtype=np.float64).astype(np.float32).astype(np.float16).astype(np.float64)
+
+
+def _xh_split_omega(w):
+    hi = _f16(np.rint(w * 256.0) / 256.0)
+    r1 = w - hi
+    mid9 = _f16(r1 * 512.0)
+    mid6 = _f16(mid9 * 0.125)
+    lo15 = _f16((r1 - mid9 / 512.0) * 32768.0)
+    return hi, mid9, lo15, mid6, r1
+
+
+def _xh_table(gamma, mu):
+    log2e = 1.4426950408889634074
+    g = gamma * log2e
+    ghi = _f16(np.rint(g * 256.0) / 256.0)
+    rg = g - ghi
+    glo9 = _f16(rg * 512.0)
+    glo3 = _f16(rg * 8.0)
+    ghi6 = _f16(ghi * 0.015625)
+    m = mu * log2e
+    m1 = _f16(np.rint(m * 32.0) / 32.0)
+    r = m - m1
+    m2s = _f16(np.rint(r * 65536.0) / 64.0)
+    seed = ((r - m2s / 1024.0) * 512.0).astype(np.float32).astype(np.float64)
+    return dict(g=g, ghi=ghi, ghi6=ghi6, glo9=glo9, glo3=glo3, m=m, m1=m1, m2s=m2s, seed=seed,
+                err_col=np.abs(rg - glo9 / 512.0).max(axis=0), glomax=np.abs(glo9 / 512.0).max(),
+                seedmax=np.abs(r - m2s / 1024.0).max())
+
+
+@pytest.mark.parametrize('P, K, sigma_mu, scale', [(4000, 20, 3.0, 1.0), (1500, 20, 3.0, 2.0), (800, 7, 3.0, 1.0), (600, 13, 10.0, 0.3)])
+def test_xh_pieces_are_exact_in_fp32_and_inside_the_budget(P, K, sigma_mu, scale):
+    rng = np.random.RandomState(100 + P + K)
+    gamma = rng.randn(P, K)
+    mu = rng.randn(P) * sigma_mu
+    T = _xh_table(gamma, mu)
+    e24, ln2, log2e = 2.0 ** -24, np.log(2.0), 1.4426950408889634074
+    NL = 5 if K > 8 else 2
+    for trial in range(12):
+        om = rng.randn(K) * scale
+        hi, mid9, lo15, mid6, r1 = _xh_split_omega(om)
+        ltrue = (T['g'] * om).sum(axis=1) + T['m']                     # float64, log2 units
+        q = np.ceil(ltrue[:32].max())
+        # ---- the leading group: fixed point, exact in fp32 in any order ----
+        terms = np.concatenate([T['ghi'] * hi, T['m1'][:, None], (T['m2s'] * 2.0 ** -10)[:, None], np.full((P, 1), -q)], axis=1)
+        assert (np.rint(terms * 65536.0) == terms * 65536.0).all()     # multiples of 2^-16
+        assert np.abs(terms).sum(axis=1).max() < 255.0                  # every subset sum below 2^24 quanta
+        for order in range(3):
+            perm = rng.permutation(terms.shape[1])
+            acc = np.zeros(P, dtype=np.float32)
+            for c in perm:
+                acc = (acc + terms[:, c].astype(np.float32)).astype(np.float32)
+            assert (acc.astype(np.float64) == terms.sum(axis=1)).all()
+        H = terms.sum(axis=1)
+        # ---- the residual group, accumulated in fp32 one term at a time from its seed (scaled by 2^9) ----
+        lo_terms = np.concatenate([T['ghi'] * mid9, T['ghi6'] * lo15, T['glo9'] * hi, T['glo3'] * mid6], axis=1)
+        acc = T['seed'].astype(np.float32)
+        for c in rng.permutation(lo_terms.shape[1]):
+            acc = (acc + lo_terms[:, c].astype(np.float32)).astype(np.float32)
+        x32 = (np.float32(2.0 ** -9) * acc + H.astype(np.float32)).astype(np.float32)     # the join: one rounding
+        # what xh_delta (rg_common.hpp) grants this user
+        absw = np.abs(om).sum()
+        egam = (np.abs(om) * T['err_col']).sum()
+        gmax = np.abs(gamma).max(axis=0)
+        lob = (np.abs(r1) * (gmax * log2e + 2.0 ** -8)).sum() + ((np.abs(om) + np.abs(r1)) * T['glomax']).sum() + T['seedmax']
+        norm = np.sqrt((gamma ** 2).sum(axis=1))
+        ahat = (np.abs(mu) + norm * np.sqrt((om ** 2).sum())).max()
+        assert ahat * log2e * 1.001 + abs(q) + 2.0 < 255.0             # xh_eligible
+        e_lo = (16.0 * NL + 4.0) * e24 * (lob + 1.6e-5)
+        e_x = e24 * (ahat * log2e + abs(q)) * 1.01
+        e_drop = K * 4.0e-9
+        err_log2 = np.abs(x32.astype(np.float64) - (ltrue - q))
+        assert (err_log2 <= egam + e_drop + e_lo + e_x).all(), float((err_log2 / (egam + e_drop + e_lo + e_x)).max())
+        # ... and the budget is not vacuous
+        assert (err_log2 / (egam + e_drop + e_lo + e_x)).max() > 0.02
+        delta = ln2 * (egam + e_drop + e_lo + e_x) + 1.2e-6
+        if K == 20 and scale == 1.0 and sigma_mu == 3.0:
+            assert delta < 1.6e-5                                       # (the two-way split's budget at this shape: ~1e-4)
