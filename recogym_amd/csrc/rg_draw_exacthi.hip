@@ -29,6 +29,7 @@
 // tile; tiles of 128 products by buffer_load ... lds DMA, one tile ahead (two buffers), one barrier per tile.
 
 #include "rg_common.hpp"
+#include <type_traits>
 
 // -DRG_XH_ABL=bits: timing experiments (results wrong by design; A/B builds only, loaded with RECOGYM_HIP_LIB).  1: no residual
 // MFMAs beyond the first, 2: exps replaced by a move, 4: the next chunk's operand rows are not re-read, 8: no seed reads,
@@ -250,9 +251,58 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
                 else L = mm(o.a[NH + i], Bm[NH + i], L);
             } else if (!(RG_XH_ABL & 1)) L = mm(o.a[m], Bm[m], L);   // residual step m - NH sits at operand index NH + (m - NH)
         };
-        // One step: MFMAs of chunk (cur operands) into (Ha, La: La holds its seed) | join + exp-sum of the chunk before in
-        // (Hb, Lb) -> sum | operand rows of the next chunk -> no, its seed -> Lb
-        auto stream = [&](const AOps& co, AOps& no, uint32_t ci_next, f32x16& Ha, f32x16& La, f32x16& Hb, f32x16& Lb, float& sum) {
+        // ---- per-chunk bookkeeping (prefix form: what k_walk2 searches).  The sum of chunk i is produced at the end of step i + 1
+        // and BOOKED inside step i + 2, between that step's MFMAs: nothing waits for it (a wave's pace is its own chain of
+        // dependent instructions — timing builds, profiles/r5/ab_call2_xh_ablation.jsonl: with the books closed at the end of
+        // every step, behind branches on the chunk's position, they were a third of the kernel).  The chunk's position in its
+        // tile is a compile-time constant of the step. ----
+        double s_sc = 0.0;
+        float wcmax = 0.0f;
+        int n_resc = 0;
+        float q_done = 0.0f, q_next = 0.0f;
+        double run_pref = 0.0;
+        float q_run = 0.0f;
+        uint32_t sc_cur = 0;
+        uint32_t sc_left = d.sc_chunks / 4;
+        float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+        auto book = [&](auto cpos, uint32_t ti, float s) {    // sum of chunk `cpos` of product tile ti
+            constexpr int c = decltype(cpos)::value;
+            if (RG_XH_ABL & 64) { wcmax += s; return; }
+            s += swap32(s);
+            if constexpr (c == 0) { w0 = s; return; }
+            if constexpr (c == 1) { w1 = s; return; }
+            if constexpr (c == 2) { w2 = s; return; }
+            if constexpr (c == 3) {
+                if (q_done != q_run) { run_pref *= static_cast<double>(__builtin_amdgcn_exp2f(q_run - q_done)); q_run = q_done; }
+                // the tile's four prefixes in float64, each stored as ONE rounding of the float64 value (rho = 2^-24 per stored
+                // prefix: the hot row's rho_rel)
+                const double b1 = run_pref + static_cast<double>(w0), b2 = b1 + static_cast<double>(w1);
+                const double b3 = b2 + static_cast<double>(w2), b4 = b3 + static_cast<double>(s);
+                run_pref = b4;
+                if (h == 0) *reinterpret_cast<float4*>(chunkp + static_cast<size_t>(ti) * 4) =
+                    make_float4(static_cast<float>(b1), static_cast<float>(b2), static_cast<float>(b3), static_cast<float>(b4));
+                wcmax = fmaxf(fmaxf(wcmax, fmaxf(w0, w1)), fmaxf(w2, s));
+                s_sc += static_cast<double>((w0 + w1) + (w2 + s));
+                if (--sc_left == 0) {
+                    if (h == 0) {
+                        scp_row[sc_cur] = static_cast<float>(run_pref);
+                        rec[sc_cur] = make_float2(static_cast<float>(s_sc), q_done);
+                    }
+                    s_sc = 0.0;
+                    // some logit is >= ~43 above the reference: re-reference from the next super-chunk that has not started
+                    if (wcmax > 2.8e14f) q_next = fmaxf(q_next, q_done + floorf(__builtin_amdgcn_logf(wcmax)));
+                    wcmax = 0.0f;
+                    ++sc_cur;
+                    sc_left = d.sc_chunks / 4;
+                }
+            }
+        };
+        using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+        using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
+
+        // One step: MFMAs of a chunk (`co` operands) into (Ha, La: La holds its seed) | join + exp-sum of the chunk before, in
+        // (Hb, Lb) -> sum | operand rows of the next chunk -> `no`, its seed -> Lb | `filler` (the books of the chunk two back)
+        auto stream = [&](const AOps& co, AOps& no, uint32_t ci_next, f32x16& Ha, f32x16& La, f32x16& Hb, f32x16& Lb, float& sum, auto&& filler) {
             f32x2v x[4];
             const char* ab = a_base(ci_next);
             const char* mb = m_base(ci_next);
@@ -272,6 +322,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
                         Hb[r] = hv[0]; Hb[r + 1] = hv[1];
                     }
                 }
+                if (m == 0) filler();          // (independent of this step's MFMAs and of the chunk being joined)
                 if (m >= 1) {
                     asm volatile("" : "+v"(Hb));
                     constexpr int ES = NM > 1 ? NM - 1 : 1;            // slots that carry exps
@@ -295,51 +346,10 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
             RG_XPIN();
         };
 
-        // ---- per-chunk bookkeeping (prefix form: what k_walk2 searches), one chunk behind the MFMAs ----
-        double s_sc = 0.0;
-        float wcmax = 0.0f;
-        int n_resc = 0;
-        float q_done = 0.0f, q_next = 0.0f;
-        double run_pref = 0.0;
-        float q_run = 0.0f;
-        uint32_t sc_cur = 0;
-        uint32_t sc_left = d.sc_chunks / 4;
-        float w0 = 0.f, w1 = 0.f, w2 = 0.f;
-        auto book = [&](uint32_t ci, float s) {    // sum of chunk ci
-            if (RG_XH_ABL & 64) { wcmax += s; return; }
-            s += swap32(s);
-            const uint32_t c = ci & 3;
-            if (c == 0) { w0 = s; return; }
-            if (c == 1) { w1 = s; return; }
-            if (c == 2) { w2 = s; return; }
-            const uint32_t ti = ci >> 2;
-            if (q_done != q_run) { run_pref *= static_cast<double>(__builtin_amdgcn_exp2f(q_run - q_done)); q_run = q_done; }
-            // the tile's four prefixes in float64, each stored as ONE rounding of the float64 value (rho = 2^-24 per stored
-            // prefix: the hot row's rho_rel)
-            const double b1 = run_pref + static_cast<double>(w0), b2 = b1 + static_cast<double>(w1);
-            const double b3 = b2 + static_cast<double>(w2), b4 = b3 + static_cast<double>(s);
-            run_pref = b4;
-            if (h == 0) *reinterpret_cast<float4*>(chunkp + static_cast<size_t>(ti) * 4) =
-                make_float4(static_cast<float>(b1), static_cast<float>(b2), static_cast<float>(b3), static_cast<float>(b4));
-            wcmax = fmaxf(fmaxf(wcmax, fmaxf(w0, w1)), fmaxf(w2, s));
-            s_sc += static_cast<double>((w0 + w1) + (w2 + s));
-            if (--sc_left == 0) {
-                if (h == 0) {
-                    scp_row[sc_cur] = static_cast<float>(run_pref);
-                    rec[sc_cur] = make_float2(static_cast<float>(s_sc), q_done);
-                }
-                s_sc = 0.0;
-                if (wcmax > 2.8e14f) q_next = fmaxf(q_next, q_done + floorf(__builtin_amdgcn_logf(wcmax)));
-                wcmax = 0.0f;
-                ++sc_cur;
-                sc_left = d.sc_chunks / 4;
-            }
-        };
-
         AOps oa, ob;
         f32x16 H0, L0, H1, L1;
         RG_DMA_WAIT();
-        __syncthreads();           // tile 0 landed
+        __syncthreads();           // tile 0 landed (and every wave has built its B rows from the stage in tile buffer 1)
         if (n_pt > 1) fetch_tile(1);
 #pragma unroll
         for (int i = 0; i < NM; ++i) load_a(oa, a_base(0), i);
@@ -368,40 +378,43 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
         RG_XPIN();
         const uint32_t n_ch = d.n_chunks;
         uint32_t sc_issue_left = d.sc_chunks / 4;       // tiles left in the super-chunk being ISSUED
-        // Steady state: steps (ci, ci + 1) per iteration so that the accumulator sets alternate by name (no branch touches a
-        // 16-register tuple).  Step ci = MFMAs of chunk ci | exp-sum of chunk ci - 1 | rows + seed of chunk ci + 1.
-        uint32_t ci = 1;
-        for (; ci + 1 < n_ch; ci += 2) {
-            float s;
-            // ---- step ci (odd: chunk 1 or 3 of its tile) ----
-            if ((ci & 3) == 3) {
-                // the next step reads tile T + 1: it has landed, and every wave is done reading tile T's buffer... which is
-                // refilled with tile T + 2
-                if (!(RG_XH_ABL & 16)) RG_TILE_BARRIER(0);
-                const uint32_t T = ci >> 2;
-                if (T + 2 < n_pt && !(RG_XH_ABL & 16)) fetch_tile(T + 2);
-            }
-            stream(ob, oa, min(ci + 1, n_ch - 1), H1, L1, H0, L0, s);
-            book(ci - 1, s);
-            // ---- step ci + 1 (even: chunk 0 or 2 of its tile) ----
-            bool sc_start = false;
-            if (((ci + 1) & 3) == 0) {
-                if (--sc_issue_left == 0) sc_issue_left = d.sc_chunks / 4;
-                sc_start = sc_issue_left == d.sc_chunks / 4;
-                if (sc_start && q_next != q) { set_reference(q_next); n_resc += 1; }
-            }
-            stream(oa, ob, min(ci + 2, n_ch - 1), H0, L0, H1, L1, s);
-            book(ci, s);           // (ci = chunk 3 of a tile: may flush the finished super-chunk with q_done)
-            if (sc_start) q_done = q;
+        // Step i = MFMAs of chunk i | exp-sum of chunk i - 1 | books of chunk i - 2 | rows + seed of chunk i + 1.  Even chunks use
+        // operand set `oa` and accumulators (H0, L0), odd ones `ob` and (H1, L1).
+        float s_pend, s_new;
+        stream(ob, oa, 2, H1, L1, H0, L0, s_pend, [] {});                   // step 1
+        uint32_t T = 0;
+        for (; T + 1 < n_pt; ++T) {        // steps 4T + 2 .. 4T + 5: the books of tile T
+            const uint32_t c0 = 4 * T;
+            stream(oa, ob, c0 + 3, H0, L0, H1, L1, s_new, [&] { book(C0{}, T, s_pend); });
+            s_pend = s_new;
+            // step 4T + 3 reads chunk 0 of tile T + 1: it has landed, and every wave is done reading tile T's buffer, which is
+            // refilled with tile T + 2
+            // (vector-memory operations complete in issue order: behind tile T + 1's DMA this wave has issued the stores of tile
+            // T - 1's books — one, three where a super-chunk ended — and the newest of them may stay in flight: waiting for it
+            // too cost the wave the write latency once per tile, a quarter of the kernel)
+            if (!(RG_XH_ABL & 16)) { if (T == 0 || (RG_XH_ABL & 64)) RG_TILE_BARRIER(0); else RG_TILE_BARRIER(1); }
+            if (T + 2 < n_pt && !(RG_XH_ABL & 16)) fetch_tile(T + 2);
+            stream(ob, oa, c0 + 4, H1, L1, H0, L0, s_new, [&] { book(C1{}, T, s_pend); });
+            s_pend = s_new;
+            // step 4T + 4 issues the first chunk of tile T + 1: a super-chunk may start there
+            if (--sc_issue_left == 0) sc_issue_left = d.sc_chunks / 4;
+            const bool sc_start = sc_issue_left == d.sc_chunks / 4;
+            if (sc_start && q_next != q) { set_reference(q_next); n_resc += 1; }
+            stream(oa, ob, c0 + 5, H0, L0, H1, L1, s_new, [&] { book(C2{}, T, s_pend); });
+            s_pend = s_new;
+            stream(ob, oa, min(c0 + 6, n_ch - 1), H1, L1, H0, L0, s_new, [&] { book(C3{}, T, s_pend); });   // (may flush the finished super-chunk with q_done)
+            s_pend = s_new;
+            if (sc_start) q_done = q;      // the sums pending from here on were taken with the new reference
         }
-        {   // the last chunk (n_ch - 1, odd), then its own sums
-            float s;
-            stream(ob, oa, n_ch - 1, H1, L1, H0, L0, s);
-            book(ci - 1, s);
+        {   // the last tile: steps n_ch - 2, n_ch - 1, the last chunk's own sums
+            stream(oa, ob, n_ch - 1, H0, L0, H1, L1, s_new, [&] { book(C0{}, T, s_pend); });
+            s_pend = s_new;
+            stream(ob, oa, n_ch - 1, H1, L1, H0, L0, s_new, [&] { book(C1{}, T, s_pend); });
+            book(C2{}, T, s_new);
             float sl = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sl += __builtin_amdgcn_exp2f(fmaf(L1[r], 0.001953125f, H1[r]));
-            book(ci, sl);
+            book(C3{}, T, sl);
         }
         if (sc_left != d.sc_chunks / 4 && h == 0) {            // partial last super-chunk
             rec[sc_cur] = make_float2(static_cast<float>(s_sc), q_done);
