@@ -33,7 +33,7 @@
 
 // -DRG_XH_ABL=bits: timing experiments (results wrong by design; A/B builds only, loaded with RECOGYM_HIP_LIB).  1: no residual
 // MFMAs beyond the first, 2: exps replaced by a move, 4: the next chunk's operand rows are not re-read, 8: no seed reads,
-// 16: no tile DMA / barrier, 32: no scheduling pins, 64: no bookkeeping
+// 16: no tile DMA / barrier, 32: no scheduling pins, 64: no bookkeeping, 128: books without their stores, 1024: no super-chunk records
 #ifndef RG_XH_ABL
 #define RG_XH_ABL 0
 #endif
@@ -279,12 +279,12 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
                 const double b1 = run_pref + static_cast<double>(w0), b2 = b1 + static_cast<double>(w1);
                 const double b3 = b2 + static_cast<double>(w2), b4 = b3 + static_cast<double>(s);
                 run_pref = b4;
-                if (h == 0) *reinterpret_cast<float4*>(chunkp + static_cast<size_t>(ti) * 4) =
+                if (h == 0 && !(RG_XH_ABL & 128)) *reinterpret_cast<float4*>(chunkp + static_cast<size_t>(ti) * 4) =
                     make_float4(static_cast<float>(b1), static_cast<float>(b2), static_cast<float>(b3), static_cast<float>(b4));
                 wcmax = fmaxf(fmaxf(wcmax, fmaxf(w0, w1)), fmaxf(w2, s));
                 s_sc += static_cast<double>((w0 + w1) + (w2 + s));
-                if (--sc_left == 0) {
-                    if (h == 0) {
+                if (--sc_left == 0 && !(RG_XH_ABL & 1024)) {
+                    if (h == 0 && !(RG_XH_ABL & 128)) {
                         scp_row[sc_cur] = static_cast<float>(run_pref);
                         rec[sc_cur] = make_float2(static_cast<float>(s_sc), q_done);
                     }
@@ -389,10 +389,10 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
             s_pend = s_new;
             // step 4T + 3 reads chunk 0 of tile T + 1: it has landed, and every wave is done reading tile T's buffer, which is
             // refilled with tile T + 2
-            // (vector-memory operations complete in issue order: behind tile T + 1's DMA this wave has issued the stores of tile
-            // T - 1's books — one, three where a super-chunk ended — and the newest of them may stay in flight: waiting for it
-            // too cost the wave the write latency once per tile, a quarter of the kernel)
-            if (!(RG_XH_ABL & 16)) { if (T == 0 || (RG_XH_ABL & 64)) RG_TILE_BARRIER(0); else RG_TILE_BARRIER(1); }
+            // (measured and not kept, profiles/r5/ab_call4_*, ab_call6_*: a counted vmcnt that leaves the newest store in flight;
+            // the books' stores issued right behind this barrier instead of a step before it — neither moves the kernel: what
+            // the stores cost, 17 % of it, is not this wait)
+            if (!(RG_XH_ABL & 16)) RG_TILE_BARRIER(0);
             if (T + 2 < n_pt && !(RG_XH_ABL & 16)) fetch_tile(T + 2);
             stream(ob, oa, c0 + 4, H1, L1, H0, L0, s_new, [&] { book(C1{}, T, s_pend); });
             s_pend = s_new;

@@ -1,15 +1,2 @@
-# Round 5, GPU call 4: counted vmcnt at the tile barrier of k_sweep_xh (the newest store stays in flight).
-R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r5
-mkdir -p $O
-cd $R
-timeout 600 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "pipelined_walk or walk_certificate or memo_and_anchored or every_K_class or product_counts_around or wide_logit_range" 2>&1 | tail -5 > $O/gpu_tests_call4.txt
-rm -f $O/ab_call4_xh_ablation.jsonl
-for v in 0 64; do
-  lib=$R/recogym_amd/csrc/librecogym_hip_xhabl$v.so
-  [ $v = 0 ] && lib=$R/recogym_amd/csrc/librecogym_hip.so
-  RECOGYM_HIP_LIB=$lib timeout 90 python tools/xh_probe.py 2000000 abl$v 2>>$O/ab3.err | tail -1 >> $O/ab_call4_xh_ablation.jsonl
-done
-timeout 120 python bench.py --workload c3 --steps 3 --warmup 1 --no-cpu-baseline --no-drift-line --no-materialise --no-other-workloads 2>>$O/ab3.err | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(dict(name='c3_xh_books_in_slots', ms_per_step=round(d['ms_per_step'],2), kernels={k:[v['ms'], v.get('units')] for k,v in d['kernels'].items()})))" > $O/ab_call4_c3.jsonl
+# Round 5, GPU call 3: k_sweep_xh with the books closed inside the next step's MFMA slots (compile-time chunk position): parity, timing builds, C3.
+# (the script of call 4 with `for v in 0 1 2 16 64`, outputs named *_call3_*)
