@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION 4
+#define RG_ABI_VERSION 5
 
 /* error codes */
 #define RG_OK 0
@@ -86,7 +86,9 @@ typedef struct rg_config {
      * 1 = NormalTimeGenerator (normal_time_generator.py:23-26): event n of a user happens at T_n = sum_{i<n} |mu + sigma z_i|,
      * and the drift that follows it is scaled by T_{n+1} - T_n (reco_env_v1.py:89-98).  Lock-step execution only. */
     uint32_t time_mode;
-    uint32_t reserved0;
+    uint32_t env_kind;              /* 0 = reco-gym-v1 (the latent-factor model); 1 = reco-gym-v0 (reco_env_v0.py: the cluster toy model,
+                                     * every draw a table look-up — rg_sim_set_env0_tables instead of rg_sim_set_tables; K is ignored,
+                                     * pass 1).  Lock-step execution only. */
     double time_mu;                 /* config.normal_time_mu (default 0) */
     double time_sigma;              /* config.normal_time_sigma (default 1) */
 } rg_config;
@@ -164,6 +166,23 @@ int rg_sim_destroy(rg_sim* sim);
  * RG_EINVAL for an unknown name or a value out of range. */
 int rg_sim_set_option(rg_sim* sim, const char* name, int64_t value);
 int rg_sim_get_option(rg_sim* sim, const char* name, int64_t* value);
+
+/* env_kind = 1 — RecoEnv0.set_static_params (reco_env_v0.py:22-47), as the tables its draws compare against, float64 device
+ * arrays computed on the host exactly as numpy / the C library do (the device only compares):
+ *   cdf_init    [P]               cumsum(ones(P) / P) / last          — reset: choice(P, p = initial_product_probs), :52-54
+ *   cdf_cluster [cluster_size]    cumsum of a row of the block-diagonal product_transition inside its cluster, / last
+ *                                 (every cluster's row has the same values) — update_product_view: choice(P, p = T[view]), :65-67
+ *   click_p     [P][P]            click_probs[action][view] = f(P / 5 (T + T') + phi), :39-44 (exported as p_click)
+ *   click_qn    [P][P]            exp(log(1 - p)): the threshold legacy binomial(1, p) compares its uniform with (numpy
+ *                                 random_binomial_inversion; 1 - p where p > 0.5: the draw is then 1 - inversion(1 - p))
+ *   click_px1   [P][P]            (p qn) / q of that algorithm's second step (a restart of the inversion, ~1e-16 of the draws)
+ * cluster_size = P / num_clusters.  The library keeps the pointers. */
+/* Host helper (no device, no handle): from click_probs p[n] the two thresholds of numpy's legacy binomial(1, p) —
+ * qn[i] = exp(log(1 - p')) and px1[i] = (p' qn) / (1 - p'), p' = p or 1 - p where p > 0.5 — with the C library's exp / log, the ones
+ * numpy's legacy-distributions.c calls: the device compares against exactly these doubles. */
+int rg_env0_click_thresholds(const double* p, uint64_t n, double* qn, double* px1);
+int rg_sim_set_env0_tables(rg_sim* sim, const double* d_cdf_init, const double* d_cdf_cluster, uint32_t cluster_size,
+                           const double* d_click_p, const double* d_click_qn, const double* d_click_px1, void* stream);
 
 /* RecoEnv1.set_static_params / generate_beta results (reco_env_v1.py:51-75,133-174): row-major
  * float64 device arrays Gamma (P,K), mu_organic (P), beta (P,K), mu_bandit (P), drawn on the

@@ -47,6 +47,7 @@ def lib():
         L.rgo_env_create.argtypes = [C.POINTER(_abi.RgConfig), C.c_int] + [C.c_void_p] * 4
         L.rgo_env_destroy.argtypes = [C.c_void_p]
         L.rgo_env_set_policy_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rgo_env_set_env0.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         L.rgo_env_set_logreg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.rgo_env_reseed.argtypes = [C.c_void_p, C.c_uint64]
         L.rgo_env_reseed_policy.argtypes = [C.c_void_p, C.c_uint64]
@@ -86,13 +87,20 @@ class OracleEnv:
 
     def __init__(self, config, rng_mode=RNG_PHILOX, policy=_abi.RG_POLICY_UNIFORM_ENV,
                  policy_seed=None, ouc=None, epoch=0, tables=None, policy_table=None, policy_ps=None,
-                 logreg=None):
+                 logreg=None, env0=None):
         self.config = config
         self.rg_config = make_rg_config(config, config.random_seed + epoch, policy, policy_seed,
-                                        ouc)
-        self.tables = tables if tables is not None else draw_tables(config)
-        self._ptrs = [t.ctypes.data_as(C.c_void_p) for t in self.tables]
-        self._h = lib().rgo_env_create(C.byref(self.rg_config), rng_mode, *self._ptrs)
+                                        ouc, env_kind=1 if env0 is not None else 0)
+        if env0 is not None:       # reco-gym-v0: dict of recogym_amd.envs.static_params.draw_env0_tables
+            self.tables = []
+            self._ptrs = [None] * 4
+            self._h = lib().rgo_env_create(C.byref(self.rg_config), rng_mode, *self._ptrs)
+            self._click_p = np.ascontiguousarray(env0['click_probs'], dtype=np.float64)
+            lib().rgo_env_set_env0(self._h, self._click_p.ctypes.data_as(C.c_void_p), int(env0['cluster_size']))
+        else:
+            self.tables = tables if tables is not None else draw_tables(config)
+            self._ptrs = [t.ctypes.data_as(C.c_void_p) for t in self.tables]
+            self._h = lib().rgo_env_create(C.byref(self.rg_config), rng_mode, *self._ptrs)
         self._rows = np.zeros(4096, dtype=ROW_DTYPE)
         if policy_table is not None:
             self._pt = np.ascontiguousarray(policy_table, dtype=np.int32)

@@ -167,6 +167,10 @@ typedef struct rgo_env {
     const double* pol_ps;     /* and the ps logged with it (NULL = 1.0) */
     const double* lr_coef_t;  /* RG_POLICY_LOGREG_FROZEN: coef_ transposed [P][n_classes], */
     const double* lr_intercept; const int32_t* lr_classes; uint32_t lr_n;   /* intercept_, classes_ */
+    /* reco-gym-v0 (cfg.env_kind = 1, recogym/envs/reco_env_v0.py): the cluster toy model */
+    const double* e0_click_p; /* (P,P) click_probs[action][view] = f(P / 5 (T + T') + phi), reco_env_v0.py:39-44 */
+    uint32_t e0_cluster;      /* products per cluster: int(P / num_clusters), reco_env_v0.py:33 */
+    int32_t product_view;     /* self.product_view */
     /* scratch */
     double* buf;              /* (P) */
     double* zbuf;             /* (K) */
@@ -211,6 +215,12 @@ void rgo_env_set_policy_table(rgo_env* e, const int32_t* table, const double* ps
     e->pol_ps = ps;
 }
 
+/* RecoEnv0.set_static_params results (reco_env_v0.py:22-47): the click matrix as numpy / scipy computed it, the cluster size */
+void rgo_env_set_env0(rgo_env* e, const double* click_p, uint32_t cluster_size) {
+    e->e0_click_p = click_p;
+    e->e0_cluster = cluster_size;
+}
+
 /* AbstractEnv.reset_random_seed (abstract.py:59-62): seed is already random_seed + epoch. */
 void rgo_env_reseed(rgo_env* e, uint64_t seed) {
     e->cfg.seed = seed;
@@ -247,6 +257,8 @@ static double draw_event_uniform(rgo_env* e, uint32_t t, int which) {
     return which == 0 ? rg_uniform(w.w[0], w.w[1]) : rg_uniform(w.w[2], w.w[3]);
 }
 
+static uint32_t icdf_right(const double* p, uint32_t n, double u, double* cdf);
+
 /* RecoEnv1.reset + AbstractEnv.reset (reco_env_v1.py:78-82, abstract.py:90-103) */
 void rgo_env_reset(rgo_env* e, uint32_t user_id) {
     e->first_step = 1;
@@ -255,6 +267,16 @@ void rgo_env_reset(rgo_env* e, uint32_t user_id) {
     e->clock = 0.0;
     e->user = user_id;
     memset(e->views, 0, sizeof(int32_t) * e->cfg.num_products);   /* agent.reset() */
+    if (e->cfg.env_kind == 1) {
+        /* RecoEnv0.reset (reco_env_v0.py:49-55): product_view = rng.choice(P, p = ones(P) / P) */
+        const uint32_t P = e->cfg.num_products;
+        for (uint32_t p = 0; p < P; ++p) e->buf[p] = 1.0 / (double)P;
+        double u;
+        if (e->rng_mode == RGO_RNG_MT) u = mt_double(&e->env_mt);
+        else { const rg_u32x4 w = rg_draw(e->cfg.seed, e->user, 0, 0, RG_DRAW_RESET); u = rg_uniform(w.w[0], w.w[1]); }
+        e->product_view = (int32_t)icdf_right(e->buf, P, u, e->cdfbuf);
+        return;
+    }
     double* z = e->zbuf;
     draw_normals(e, RG_DRAW_RESET, 0, z);
     for (uint32_t k = 0; k < e->cfg.K; ++k)
@@ -278,6 +300,15 @@ static uint32_t icdf_right(const double* p, uint32_t n, double u, double* cdf) {
 static int32_t update_product_view(rgo_env* e) {
     const uint32_t P = e->cfg.num_products, K = e->cfg.K;
     double* l = e->buf;
+    if (e->cfg.env_kind == 1) {
+        /* RecoEnv0.update_product_view (reco_env_v0.py:65-67): choice(P, p = product_transition[view, :]); the row of the
+         * block-diagonal matrix (:33-37): 1 / cluster_size inside the view's cluster (T / its row sums), 0 elsewhere */
+        const uint32_t cr = e->e0_cluster, c0 = ((uint32_t)e->product_view / cr) * cr;
+        for (uint32_t p = 0; p < P; ++p) l[p] = (p >= c0 && p < c0 + cr) ? 1.0 / (double)cr : 0.0;
+        const double u0 = draw_event_uniform(e, e->time, 0);
+        e->product_view = (int32_t)icdf_right(l, P, u0, e->cdfbuf);
+        return e->product_view;
+    }
     double mx = -INFINITY;
     for (uint32_t p = 0; p < P; ++p) {
         double d = 0.0;
@@ -303,6 +334,9 @@ static void update_state(rgo_env* e) {
     const uint32_t t_event = e->time;
     e->state = ns;
     e->time += 1;
+    if (e->cfg.env_kind == 1) return;   /* RecoEnv0.update_state (reco_env_v0.py:56-58): the Markov draw only — no clock, no omega
+                                         * (`time` stays the event index the draws are addressed by; the reference's current_time
+                                         * never moves: rows carry clock 0) */
     /* time_delta = new_time() - old_time; omega_k = 1 if time_delta == 0 else time_delta (reco_env_v1.py:89-92).
      * DefaultTimeGenerator: always 1.  NormalTimeGenerator (Philox mode only): the increment that follows event t is
      * |mu + sigma z|, z = the RG_DRAW_TIME draw of (user, t) */
@@ -329,8 +363,44 @@ static double ff(double x) { return sig(5.0 * sig(2.0 * sig(0.3 * x) - 2.0) - 6.
 
 /* RecoEnv1.draw_click (reco_env_v1.py:104-116).  The cached_state_seed is semantically
  * transparent: ctr[a] == ff(beta[a].omega + mu_b[a]) for the current omega. */
+/* numpy legacy binomial(n = 1, p) (numpy/random/src/legacy/legacy-distributions.c: legacy_random_binomial_original ->
+ * random_binomial_inversion; p > 0.5 draws n - inversion(1 - p)) */
+static int32_t binomial1(rgo_env* e, double p) {
+    const double pe = p <= 0.5 ? p : 1.0 - p;
+    const int64_t n = 1;
+    const double q = 1.0 - pe;
+    const double qn = exp((double)n * log(q));
+    const double np = (double)n * pe;
+    const double b = np + 10.0 * sqrt(np * q + 1.0);
+    const int64_t bound = (int64_t)((double)n < b ? (double)n : b);
+    int64_t X = 0;
+    double px = qn;
+    uint32_t slot = 0;
+    double U = draw_event_uniform(e, e->time, 0);
+    while (U > px) {
+        X++;
+        if (X > bound) {
+            X = 0;
+            px = qn;
+            slot += 1;
+            if (e->rng_mode == RGO_RNG_MT) U = mt_double(&e->env_mt);
+            else { const rg_u32x4 w = rg_draw(e->cfg.seed, e->user, e->time, slot, RG_DRAW_EVENT); U = rg_uniform(w.w[0], w.w[1]); }
+        } else {
+            U -= px;
+            px = ((double)(n - X + 1) * pe * px) / ((double)X * q);
+        }
+    }
+    return (int32_t)(p <= 0.5 ? X : n - X);
+}
+
 static int32_t draw_click(rgo_env* e, int32_t a) {
     const uint32_t K = e->cfg.K;
+    if (e->cfg.env_kind == 1) {
+        /* RecoEnv0.draw_click (reco_env_v0.py:61-63): rng.binomial(1, click_probs[recommendation, product_view]) */
+        const double p = e->e0_click_p[(size_t)a * e->cfg.num_products + (uint32_t)e->product_view];
+        e->last_p_click = p;
+        return binomial1(e, p);
+    }
     double d = 0.0;
     const double* b = e->beta + (size_t)a * K;
     for (uint32_t k = 0; k < K; ++k) d += b[k] * e->omega[k];

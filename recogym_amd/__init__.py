@@ -23,6 +23,7 @@ def make(env_id):
     return getattr(importlib.import_module(module), cls)()
 
 
+register(id='reco-gym-v0', entry_point='recogym_amd.envs.reco_env_v0:RecoEnv0')      # reference: recogym/__init__.py:37-40
 register(id='reco-gym-v1', entry_point='recogym_amd.envs.reco_env_v1:RecoEnv1')
 
 
@@ -60,6 +61,7 @@ def _auto_register():
     import importlib.util
     try:
         if importlib.util.find_spec('gym') is not None:
+            register_with_gym('reco-gym-v0')
             register_with_gym()
     except Exception:
         pass
@@ -73,6 +75,9 @@ def __getattr__(name):
     if name in ('env_1_args', 'env_args', 'RecoEnv1'):
         from .envs import reco_env_v1
         return getattr(reco_env_v1, name)
+    if name in ('env_0_args', 'RecoEnv0'):
+        from .envs import reco_env_v0
+        return getattr(reco_env_v0, name)
     if name == 'test_agent':
         from .bench_agents import test_agent
         return test_agent

@@ -7,7 +7,7 @@ infrastructure and is never imported from this package.)
 import ctypes as C
 import os
 
-RG_ABI_VERSION = 4
+RG_ABI_VERSION = 5
 
 RG_STATE_ORGANIC, RG_STATE_BANDIT, RG_STATE_STOP = 0, 1, 2
 
@@ -50,7 +50,7 @@ class RgConfig(C.Structure):
         ('ouc_history_cap', C.c_uint32),
         ('ouc_epsilon', C.c_double),
         ('time_mode', C.c_uint32),
-        ('reserved0', C.c_uint32),
+        ('env_kind', C.c_uint32),
         ('time_mu', C.c_double),
         ('time_sigma', C.c_double),
     ]
@@ -81,6 +81,8 @@ SYMBOLS = {
     'rg_sim_get_option': (C.c_int, [_SIM, C.c_char_p, C.POINTER(C.c_int64)]),
     'rg_sim_set_tables': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
+    'rg_env0_click_thresholds': (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    'rg_sim_set_env0_tables': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'rg_sim_set_policy_table': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_set_logreg': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     'rg_sim_set_logreg_fp32': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]),

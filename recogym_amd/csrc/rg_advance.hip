@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
             if (!is_org) {
                 // 97 % of the bandit events cannot click whatever beta[a] . omega is (kNoClickBelow): they read neither row
                 const double u_click = rg_uniform(w.w[0], w.w[1]);
-                const bool need_ctr = d.aux_pclick != nullptr || !(u_click < kNoClickBelow);
+                const bool need_ctr = !d.env_kind && (d.aux_pclick != nullptr || !(u_click < kNoClickBelow));
                 // Touch the two cache lines of the user's omega row (and the head of its view
                 // history) NOW: they arrive while the policy draws and walks the history, instead
                 // of costing another HBM round trip after it — this kernel is latency-bound.
@@ -345,7 +345,12 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                 // step_offline: the policy acts (abstract.py:202-221), then draw_click
                 double ps;
                 uint32_t a;
-                if (d.policy == RG_POLICY_EXTERNAL) { a = static_cast<uint32_t>(actions[uidx]); ps = __builtin_nan(""); }
+                if (d.policy == RG_POLICY_EXTERNAL) {
+                    // (an action outside [0, P) — e.g. the -1 of a caller that had none — must not index beta / mu_b: product 0)
+                    const int32_t ai = actions[uidx];
+                    a = (ai < 0 || static_cast<uint32_t>(ai) >= d.P) ? 0u : static_cast<uint32_t>(ai);
+                    ps = __builtin_nan("");
+                }
                 else if (d.policy == RG_POLICY_LOGREG_FROZEN) { a = lr_a; ps = 1.0; }
                 else a = policy_act(d, slot, user, t, &ps);
                 // beta[a] . omega, k ascending (the oracle's association); loads are issued eight
@@ -377,6 +382,11 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                 }
                 asm volatile("" ::"v"(touch0), "v"(touch1), "v"(touch2));   // keeps the early loads alive
                 double ctr = 0.0;
+                if (d.env_kind) {      // reco-gym-v0: click_probs[action][view], binomial(1, p) (reco_env_v0.py:61-63)
+                    const size_t cell = static_cast<size_t>(a) * d.P + d.pv0[uidx];
+                    ctr = d.e0_click_p[cell];
+                    click = env0_click(d, cell, user, t, u_click);
+                } else
                 if (need_ctr) {
                     ctr = ff64(x + d.mu_b[a]);
                     const double p0 = 1.0 - ctr;

@@ -250,6 +250,10 @@ struct DevSim {
     double* phantom_ps;       // [n_users] float64 propensity of the phantom row
     // test hooks (rg_sim_debug_*): per-user-index uniforms replacing the organic draw's u at the next step
     const double* u_override;
+    // reco-gym-v0 (env_kind = 1, reco_env_v0.py): the user's state is its current product view, every draw a table look-up
+    uint32_t env_kind, e0_cluster;
+    const double* e0_cdf_init; const double* e0_cdf_cluster; const double* e0_click_p; const double* e0_click_qn; const double* e0_click_px1;
+    uint32_t* pv0;            // [n_cap] by user index: the product currently viewed (reco_env_v0.py:52-54,65-67)
     // NormalTimeGenerator (time_mode = 1, normal_time_generator.py:23-26; lock-step only)
     uint32_t time_mode;
     double time_mu, time_sigma;
@@ -598,9 +602,10 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint32_t* lpv_alt = w.take<uint32_t>(rp && c.policy == RG_POLICY_LAST_VIEW_TABLE ? n : 1);
     uint32_t* uid_alt = w.take<uint32_t>(rp ? n : 1);
     uint32_t* ev = w.take<uint32_t>(n);
+    uint32_t* pv0 = w.take<uint32_t>(c.env_kind ? n : 1);
     unsigned long long* run_ctl = w.take<unsigned long long>(4);
     if (d) {
-        d->ev = ev; d->run_ctl = run_ctl; d->run_ahead = 0;
+        d->ev = ev; d->run_ctl = run_ctl; d->run_ahead = 0; d->pv0 = pv0;
         d->phantom_ps = phantom_ps; d->utime = utime; d->phantom_time = phantom_time;
         d->drift_list = drift_list; d->drift_sig = drift_sig; d->drift_cnt = drift_cnt;
         d->use_cache = cache ? 1u : 0u; d->cache_rec = cache_rec; d->cache_chunk = cache_chunk; d->cache_resc = cache_resc;
@@ -643,6 +648,9 @@ inline int validate(const rg_config* c, uint64_t n) {
     if (n == 0 || n >= (1ull << 31)) return fail(RG_EINVAL, "n_users %llu out of range", (unsigned long long)n);
     if (c->policy > RG_POLICY_LOGREG_FROZEN) return fail(RG_EINVAL, "unknown policy %u", c->policy);
     if (c->time_mode > 1) return fail(RG_EINVAL, "unknown time_mode %u", c->time_mode);
+    if (c->env_kind > 1) return fail(RG_EINVAL, "unknown env_kind %u", c->env_kind);
+    if (c->env_kind == 1 && (c->time_mode || c->policy == RG_POLICY_LOGREG_FROZEN || c->policy == RG_POLICY_LAST_VIEW_TABLE))
+        return fail(RG_EINVAL, "env_kind 1 (reco-gym-v0) runs the default clock and the uniform / random / organic-count / external policies");
     if (c->time_mode == 1 && !(c->time_sigma >= 0.0)) return fail(RG_EINVAL, "normal_time_sigma must be >= 0");
     for (int s = 0; s < 2; ++s)
         if (!(c->trans_cdf[s][0] >= 0.0 && c->trans_cdf[s][0] <= c->trans_cdf[s][1] &&
@@ -734,6 +742,34 @@ __device__ __forceinline__ double organic_uniform(const DevSim& d, uint32_t uidx
     if (d.run_ahead) t = d.ev[uidx];          // run-ahead rounds: the user's own event index
     const rg_u32x4 rw = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
     return rg_uniform(rw.w[0], rw.w[1]);
+}
+
+// searchsorted(cdf, u, side='right') of numpy's legacy choice: the number of entries <= u (clamped to the last index, as an
+// index into [0, n) must be: cdf[n - 1] is exactly 1 > u)
+__device__ __forceinline__ uint32_t upper_bound_f64(const double* cdf, uint32_t n, double u) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    return lo < n ? lo : n - 1;
+}
+
+// reco-gym-v0: draw_click (reco_env_v0.py:61-63) = RandomState.binomial(1, p) — numpy's legacy inversion for n = 1: with
+// qn = exp(log(1 - p)) the draw is [U > qn] unless U - qn > (p qn) / q, which restarts the inversion with a fresh uniform
+// (slot j >= 1 of the event's draw); p > 0.5 draws 1 - inversion(1 - p).  `row` = action * P + view.
+__device__ __forceinline__ bool env0_click(const DevSim& d, size_t row, uint32_t user, uint32_t t, double u_first) {
+    const double p = d.e0_click_p[row], qn = d.e0_click_qn[row], px1 = d.e0_click_px1[row];
+    double U = u_first;
+    uint32_t X = 0;
+    for (uint32_t j = 1;; ++j) {
+        if (!(U > qn)) { X = 0; break; }
+        if (!(U - qn > px1)) { X = 1; break; }
+        if (j >= 64u) { X = 1; break; }                    // (never: each restart has probability ~1e-16)
+        const rg_u32x4 w = rg_draw(d.seed, user, t, j, RG_DRAW_EVENT);
+        U = rg_uniform(w.w[0], w.w[1]);
+    }
+    return p <= 0.5 ? X == 1 : X == 0;
 }
 
 __device__ __forceinline__ uint32_t* list_ptr(const DevSim& d, uint32_t parity, uint32_t state) {

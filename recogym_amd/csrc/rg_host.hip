@@ -16,6 +16,10 @@ __global__ void __launch_bounds__(kBlock) k_reset_users(DevSim d) {
     }
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) {
         const uint32_t user = static_cast<uint32_t>(d.first_user + i);
+        if (d.env_kind) {      // reco-gym-v0: the first product view (reco_env_v0.py:52-54), no omega
+            const rg_u32x4 w = rg_draw(d.seed, user, 0u, 0u, RG_DRAW_RESET);
+            d.pv0[i] = upper_bound_f64(d.e0_cdf_init, d.P, rg_uniform(w.w[0], w.w[1]));
+        } else
         for (uint32_t j = 0; 2 * j < d.K; ++j) {
             double z0, z1;
             normal_pair(d.seed, user, 0u, j, RG_DRAW_RESET, &z0, &z1);
@@ -31,6 +35,24 @@ __global__ void __launch_bounds__(kBlock) k_reset_users(DevSim d) {
         if (d.lr_dirty) d.lr_dirty[i] = 1;
         if (d.hist_cap) d.hist[static_cast<size_t>(i) * d.hist_cap] = 0ull;
         if (d.use_cache) { d.f64_valid[i] = 0; d.cache_resc[i] = 0; }
+    }
+}
+
+// reco-gym-v0: update_product_view (reco_env_v0.py:65-67) of the step's organic users — the next view is drawn inside the cluster of
+// the current one: choice(P, p = product_transition[view]) = cluster start + searchsorted(cdf_cluster, u, 'right').
+__global__ void __launch_bounds__(kBlock) k_draw_env0(DevSim d, uint32_t t) {
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    for (uint32_t pos = blockIdx.x * kBlock + threadIdx.x; pos < n_o; pos += gridDim.x * kBlock) {
+        const uint32_t slot = cur[pos], uidx = d.uid[slot];
+        const uint32_t user = static_cast<uint32_t>(d.first_user + uidx);
+        const double u = organic_uniform(d, uidx, user, t);
+        const uint32_t view = d.pv0[uidx];
+        uint32_t v = (view / d.e0_cluster) * d.e0_cluster + upper_bound_f64(d.e0_cdf_cluster, d.e0_cluster, u);
+        if (v >= d.P) v = d.P - 1;
+        d.pv0[uidx] = v;
+        write_organic_row(d, t, pos, slot, user, v);
+        if (d.hist_cap) history_add(d, slot, v);
     }
 }
 
@@ -552,7 +574,11 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     }
     if (int rc = prof_mark(sim, st)) return rc;
     // 1. organic product draws of this step (read omega before the transition drifts it)
-    if (d.use_mfma == 2 && d.use_cache && t > 0) {
+    if (d.env_kind) {          // reco-gym-v0: a table look-up per organic user
+        hipLaunchKernelGGL(k_draw_env0, dim3(grid_for(upper)), dim3(kBlock), 0, st, d, t);
+        if (int rc = prof_mark(sim, st)) return rc;
+        if (int rc = prof_mark(sim, st)) return rc;
+    } else if (d.use_mfma == 2 && d.use_cache && t > 0) {
         // sigma_omega == 0, after step 0: every live user's exp-sums are in the per-user cache — search only
         if (int rc = prof_mark(sim, st)) return rc;
         hipLaunchKernelGGL(cached_kernel_for(d), dim3(grid_for(upper, kBlock)), dim3(kBlock),
@@ -1149,6 +1175,14 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     s->lr_part_rows = d.lr_part_cap;
     if (const char* e = getenv("RECOGYM_LR_PART_CAP")) { const uint32_t v = static_cast<uint32_t>(atoi(e)); if (v < d.lr_part_cap) d.lr_part_cap = v; }
     if (const char* e = getenv("RECOGYM_ABLATE")) d.ablate = static_cast<uint32_t>(atoi(e));
+    if (d.env_kind) {
+        // reco-gym-v0: no omega, no product sweep — the lock-step loop with its own draw kernel (k_draw_env0), nothing else
+        d.use_mfma = 0; d.use_cache = 0; d.XNH = d.XNL = d.XRS = 0;
+        s->bf16_kernel = nullptr; s->xh_kernel = nullptr;
+        s->walk = s->walk2 = false;
+        s->tail_below = 0;
+        s->run_ahead = 0;
+    }
     if (const char* e = getenv("RECOGYM_LDS_PAD")) s->mfma_smem += static_cast<size_t>(atoi(e));
     if (s->opt.debug && d.use_mfma && rg_device_count() > 0) {
         int nb = -1;
@@ -1215,11 +1249,19 @@ int rg_sim_set_option(rg_sim* sim, const char* name, int64_t value) {
             return fail(RG_EINVAL, "%s must be in [1, %d]", name, sim->walk_occ);
         if (!strcmp(name, "pipe_xblocks") && value < 1) return fail(RG_EINVAL, "pipe_xblocks must be >= 1");
         if (!strcmp(name, "exact_mix") && (value < 0 || value > 8)) return fail(RG_EINVAL, "exact_mix must be in [0, 8]");
+        if (value < -2147483647 || value > 2147483647) return fail(RG_EINVAL, "%s out of the range of an int", name);
+        if (!strcmp(name, "pipe_groups") && value < 0) return fail(RG_EINVAL, "pipe_groups must be >= 0");
+        if (!strcmp(name, "pipe_mode") && (value < 0 || value > 2)) return fail(RG_EINVAL, "pipe_mode must be 0, 1 or 2");
+        if (!strcmp(name, "slices") && value < -1) return fail(RG_EINVAL, "slices must be >= -1 (-1 = by population)");
+        if ((!strcmp(name, "exact_tile") || !strcmp(name, "resident_grid") || !strcmp(name, "sweep_prefix_off") || !strcmp(name, "debug")) &&
+            (value < 0 || value > 1)) return fail(RG_EINVAL, "%s is a flag (0 or 1)", name);
         *p = static_cast<int>(value);
         return RG_OK;
     }
     if (uint32_t* p = opt_u32(sim, name)) {
-        if (value < 0) return fail(RG_EINVAL, "%s must be >= 0", name);
+        if (value < 0 || value > 0xFFFFFFFFll) return fail(RG_EINVAL, "%s must be in [0, 2^32)", name);
+        if (!strcmp(name, "run_ahead") && value > 64) return fail(RG_EINVAL, "run_ahead must be <= 64 events");
+        if (!strcmp(name, "run_ahead") && value && sim->d.env_kind) return fail(RG_EINVAL, "env_kind 1 (reco-gym-v0) runs lock-step (run_ahead = 0)");
         if (!strcmp(name, "walk_search_batch") && value < 1) value = 1;
         if (!strcmp(name, "pipe_min_users") && value < 256) return fail(RG_EINVAL, "pipe_min_users must be >= 256");
         if (!strcmp(name, "lr_part_cap") && static_cast<uint64_t>(value) > sim->lr_part_rows)
@@ -1241,6 +1283,7 @@ int rg_sim_set_tables(rg_sim* sim, const double* d_gamma, const double* d_mu_org
                       const double* d_beta, const double* d_mu_bandit, void* stream) {
     if (!sim) return fail(RG_EINVAL, "sim is NULL");
     if (!d_gamma || !d_mu_organic || !d_beta || !d_mu_bandit) return fail(RG_EINVAL, "table pointer is NULL");
+    if (sim->d.env_kind) return fail(RG_ESTATE, "env_kind 1 (reco-gym-v0) takes rg_sim_set_env0_tables");
     if (rg_device_count() <= 0) return fail(RG_ENODEV, "no HIP device");
     sim->d.gamma = d_gamma; sim->d.mu_o = d_mu_organic; sim->d.beta = d_beta; sim->d.mu_b = d_mu_bandit;
     hipLaunchKernelGGL(k_make_gammaT, dim3(grid_for(static_cast<size_t>(sim->d.K) * sim->d.PT)), dim3(kBlock), 0,
@@ -1267,6 +1310,33 @@ int rg_sim_set_tables(rg_sim* sim, const double* d_gamma, const double* d_mu_org
         }
     }
     HIP_TRY(hipGetLastError());
+    sim->tables_set = true;
+    return RG_OK;
+}
+
+int rg_env0_click_thresholds(const double* p, uint64_t n, double* qn, double* px1) {
+    if (!p || !qn || !px1) return fail(RG_EINVAL, "NULL argument");
+    for (uint64_t i = 0; i < n; ++i) {
+        // random_binomial_inversion(n = 1, p'): q = 1 - p', qn = exp(n log q), second step px = ((n - X + 1) p' px) / (X q) at X = 1
+        const double pe = p[i] <= 0.5 ? p[i] : 1.0 - p[i];
+        const double q = 1.0 - pe;
+        const double r = exp(1.0 * log(q));
+        qn[i] = r;
+        px1[i] = (1.0 * pe * r) / (1.0 * q);
+    }
+    return RG_OK;
+}
+
+int rg_sim_set_env0_tables(rg_sim* sim, const double* d_cdf_init, const double* d_cdf_cluster, uint32_t cluster_size,
+                           const double* d_click_p, const double* d_click_qn, const double* d_click_px1, void* stream) {
+    (void)stream;
+    if (!sim) return fail(RG_EINVAL, "sim is NULL");
+    if (!sim->d.env_kind) return fail(RG_ESTATE, "env_kind is not 1 (reco-gym-v0)");
+    if (!d_cdf_init || !d_cdf_cluster || !d_click_p || !d_click_qn || !d_click_px1) return fail(RG_EINVAL, "table pointer is NULL");
+    if (cluster_size == 0 || cluster_size > sim->d.P) return fail(RG_EINVAL, "cluster_size %u out of range", cluster_size);
+    if (rg_device_count() <= 0) return fail(RG_ENODEV, "no HIP device");
+    sim->d.e0_cdf_init = d_cdf_init; sim->d.e0_cdf_cluster = d_cdf_cluster; sim->d.e0_cluster = cluster_size;
+    sim->d.e0_click_p = d_click_p; sim->d.e0_click_qn = d_click_qn; sim->d.e0_click_px1 = d_click_px1;
     sim->tables_set = true;
     return RG_OK;
 }
@@ -1387,6 +1457,8 @@ int rg_sim_step_user(rg_sim* sim, int32_t action, rg_step_result* out, void* str
     if (!sim || !out) return fail(RG_EINVAL, "NULL argument");
     if (!sim->users_reset) return fail(RG_ESTATE, "rg_sim_reset_users must be called first");
     if (sim->d.policy != RG_POLICY_EXTERNAL || sim->d.n_users != 1) return fail(RG_ESTATE, "rg_sim_step_user needs RG_POLICY_EXTERNAL and a one-user reset range");
+    // (-1 = no action: a user in the organic state ignores it; the kernel never indexes beta / mu_b with an action outside [0, P))
+    if (action < -1 || action >= static_cast<int32_t>(sim->d.P)) return fail(RG_EINVAL, "action %d is outside [0, %u) (-1: none)", action, sim->d.P);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!sim->h_step) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sim->h_step), 128));
     int32_t* h_act = reinterpret_cast<int32_t*>(sim->h_step);

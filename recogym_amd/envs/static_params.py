@@ -142,10 +142,29 @@ def draw_tables(config):
 
 
 def make_rg_config(config, seed, policy=_abi.RG_POLICY_UNIFORM_ENV, policy_seed=None,
-                   ouc=None):
-    """Fill struct rg_config from an env Configuration (+ optional agent parameters)."""
+                   ouc=None, env_kind=0):
+    """Fill struct rg_config from an env Configuration (+ optional agent parameters).  env_kind = 1: reco-gym-v0 (no K, no
+    omega: the fields of the latent-factor model are left at neutral values)."""
     cfg = _abi.RgConfig()
     cfg.num_products = int(config.num_products)
+    cfg.env_kind = int(env_kind)
+    if env_kind:
+        cfg.K = 1
+        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cfg.policy_seed = (int(seed) if policy_seed is None else int(policy_seed)) & 0xFFFFFFFFFFFFFFFF
+        cdf = transition_cdf(transition_matrix(config))
+        for s in (0, 1):
+            for j in range(3):
+                cfg.trans_cdf[s][j] = float(cdf[s, j])
+        cfg.policy = int(policy)
+        ouc = ouc or {}
+        cfg.ouc_select_randomly = int(bool(ouc.get('select_randomly', True)))
+        cfg.ouc_exploit_explore = int(bool(ouc.get('exploit_explore', True)))
+        cfg.ouc_reverse_pop = int(bool(ouc.get('reverse_pop', False)))
+        cfg.ouc_history_cap = int(ouc.get('history_cap', 0))
+        cfg.ouc_epsilon = float(ouc.get('epsilon', 0.0))
+        cfg.time_sigma = 1.0
+        return cfg
     cfg.K = int(config.K)
     cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     cfg.policy_seed = (int(seed) if policy_seed is None else int(policy_seed)) & 0xFFFFFFFFFFFFFFFF
@@ -178,3 +197,28 @@ def time_generator_params(config):
         return (1, float(getattr(tg, 'normal_time_mu', getattr(config, 'normal_time_mu', 0))),
                 float(getattr(tg, 'normal_time_sigma', getattr(config, 'normal_time_sigma', 1))))
     raise NotImplementedError(f'time generator {type(tg).__name__} is not supported by the device step loop')
+
+
+def draw_env0_tables(config):
+    """RecoEnv0.set_static_params (recogym/envs/reco_env_v0.py:22-47), with the same numpy / scipy calls on the same
+    RandomState(random_seed) stream -> dict(phi, product_transition, click_probs, cluster_size, cdf_init, cdf_cluster):
+    the last two are what `RandomState.choice(P, p=...)` compares its uniform against at reset (:52-54) and at every organic
+    event (:65-67; every cluster's row of the block-diagonal matrix has the same values inside its cluster)."""
+    from numpy import eye, kron, ones, sqrt
+    from scipy.special import expit
+    P = int(config.num_products)
+    rng = RandomState(config.random_seed)
+    cluster_ratio = int(P / config.num_clusters)
+    ones_mat = ones((cluster_ratio, cluster_ratio))
+    T = kron(eye(config.num_clusters), ones_mat)
+    T = T / kron(T.sum(1), ones((P, 1))).T
+    phi = rng.normal(scale=sqrt(config.phi_var), size=(P, P))
+    click_probs = expit(P / 5. * (T + T.T) + phi - 5)          # abstract.py:34-37: f(mat, offset=5) = sigmoid(mat - offset)
+    init = ones(P) / P
+    cdf_init = init.cumsum()
+    cdf_init /= cdf_init[-1]
+    row = T[0, :cluster_ratio].copy()
+    cdf_cluster = row.cumsum()
+    cdf_cluster /= cdf_cluster[-1]
+    return dict(phi=phi, product_transition=T, click_probs=np.ascontiguousarray(click_probs), cluster_size=cluster_ratio,
+                cdf_init=cdf_init, cdf_cluster=cdf_cluster)

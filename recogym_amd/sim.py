@@ -79,19 +79,21 @@ class Simulator:
 
     def __init__(self, config, n_users, policy=_abi.RG_POLICY_UNIFORM_ENV, policy_seed=None,
                  ouc=None, epoch=0, log_capacity=None, device=None, tables=None, policy_table=None,
-                 policy_ps=None, logreg=None, ps_float64=None, p_click=False):
+                 policy_ps=None, logreg=None, ps_float64=None, p_click=False, env0=None):
         self.lib = _abi.load()
         self.device = require_device(device)
         self.config = config
         self.n_users = int(n_users)
+        # env0: the dict draw_env0_tables(config) returns — reco-gym-v0 (env_kind = 1), every draw a table look-up
+        self.env0 = env0
         self.rg_config = make_rg_config(config, config.random_seed + epoch, policy, policy_seed,
-                                        ouc)
+                                        ouc, env_kind=1 if env0 is not None else 0)
         self.policy = policy
         self.time_mode = int(self.rg_config.time_mode)
         self.ps_float64 = (policy in (_abi.RG_POLICY_ORGANIC_USER_COUNT, _abi.RG_POLICY_LAST_VIEW_TABLE)
                            if ps_float64 is None else bool(ps_float64))
         self.keep_p_click = bool(p_click)
-        host_tables = tables if tables is not None else draw_tables(config)
+        host_tables = () if env0 is not None else (tables if tables is not None else draw_tables(config))
         self.host_tables = host_tables
         with torch.cuda.device(self.device):
             self.tables = [torch.from_numpy(np.ascontiguousarray(t)).to(self.device)
@@ -105,8 +107,20 @@ class Simulator:
             _abi.check(self.lib.rg_sim_create(C.byref(self._h), C.byref(self.rg_config),
                                               self.n_users, self.workspace.data_ptr(), need),
                        'rg_sim_create')
-            _abi.check(self.lib.rg_sim_set_tables(self._h, *[t.data_ptr() for t in self.tables],
-                                                  self._stream()), 'rg_sim_set_tables')
+            if env0 is not None:
+                p = np.ascontiguousarray(env0['click_probs'], dtype=np.float64)
+                qn, px1 = np.empty_like(p), np.empty_like(p)
+                _abi.check(self.lib.rg_env0_click_thresholds(p.ctypes.data, p.size, qn.ctypes.data, px1.ctypes.data),
+                           'rg_env0_click_thresholds')
+                self.tables = [torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(self.device)
+                               for x in (env0['cdf_init'], env0['cdf_cluster'], p, qn, px1)]
+                _abi.check(self.lib.rg_sim_set_env0_tables(self._h, self.tables[0].data_ptr(), self.tables[1].data_ptr(),
+                                                           int(env0['cluster_size']), self.tables[2].data_ptr(),
+                                                           self.tables[3].data_ptr(), self.tables[4].data_ptr(), self._stream()),
+                           'rg_sim_set_env0_tables')
+            else:
+                _abi.check(self.lib.rg_sim_set_tables(self._h, *[t.data_ptr() for t in self.tables],
+                                                      self._stream()), 'rg_sim_set_tables')
             if policy == _abi.RG_POLICY_LAST_VIEW_TABLE:
                 self.policy_table = torch.as_tensor(np.ascontiguousarray(policy_table, dtype=np.int32)).to(self.device)
                 self.policy_ps = None if policy_ps is None else \

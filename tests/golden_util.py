@@ -51,6 +51,14 @@ def policy_args(meta, cols=None):
     return out
 
 
+def env0_tables(meta):
+    """reco-gym-v0 fixtures: the tables RecoEnv0.set_static_params draws (None for a reco-gym-v1 fixture)."""
+    if meta.get('env_id') != 'reco-gym-v0':
+        return None
+    from recogym_amd.envs.static_params import draw_env0_tables
+    return draw_env0_tables(Configuration(dict(meta['env_args'])))
+
+
 def env_config(meta):
     args = dict(meta['env_args'])
     if meta.get('normal_time'):       # fixtures of the reference's NormalTimeGenerator: rebuild this package's descriptor

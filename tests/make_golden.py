@@ -70,15 +70,18 @@ def save(name, arrays, meta):
 
 
 def run_case(name, env_over, n_users, n_organic=0, agent_kind=None, agent_args=None,
-             injected=False, normal_time=None):
+             injected=False, normal_time=None, env_id='reco-gym-v1'):
     args = {**BASE, **env_over}
+    if env_id == 'reco-gym-v0':       # env_0_args (reco_env_v0.py:7-13): no latent-factor keys
+        args = {k: v for k, v in args.items() if k not in ('K', 'sigma_omega_initial', 'sigma_omega', 'number_of_flips',
+                                                           'sigma_mu_organic', 'change_omega_for_bandits')}
     if normal_time is not None:       # {'mu':, 'sigma':}: the reference's NormalTimeGenerator, passed the way init_gym takes it
         rh.import_reference()
         from recogym import Configuration
         from recogym.envs.features.time import NormalTimeGenerator
         args = {**args, 'time_generator': NormalTimeGenerator(Configuration(
             {'random_seed': args['random_seed'], 'normal_time_mu': normal_time['mu'], 'normal_time_sigma': normal_time['sigma']}))}
-    env = rh.make_reference_env(args)
+    env = rh.make_reference_env(args, env_id)
     agent = None
     agent_args = dict(agent_args or {})
     if agent_kind:
@@ -89,7 +92,7 @@ def run_case(name, env_over, n_users, n_organic=0, agent_kind=None, agent_args=N
         rng = rh.inject_counter_rng(env, None if agent_kind == 'bmf' else agent, agent_args.get('random_seed'))
     df = env.generate_logs(n_users, agent, n_organic)
     times = None
-    if normal_time is not None:       # 't' holds the generator's clock: keep it as `time`, and the event index as t
+    if normal_time is not None or env_id == 'reco-gym-v0':       # 't' holds the generator's clock (reco-gym-v0: the constant reset() set): keep it as `time`, and the event index as t
         times = df['t'].to_numpy(dtype=np.float64)
         df = df.copy()
         df['t'] = df.groupby(df['u'].astype('int64')).cumcount().astype(np.float32)
@@ -108,6 +111,8 @@ def run_case(name, env_over, n_users, n_organic=0, agent_kind=None, agent_args=N
         arrays['p_click'] = pc
     meta = dict(env_args={k: v for k, v in args.items() if k != 'time_generator'}, n_users=n_users, n_organic=n_organic,
                 agent=agent_kind, agent_args=agent_args, rng='philox' if injected else 'mt')
+    if env_id != 'reco-gym-v1':
+        meta['env_id'] = env_id
     if normal_time is not None:
         meta['normal_time'] = normal_time
     if agent_kind == 'bmf':      # the (untrained) embeddings the frozen device policy is built from
@@ -422,6 +427,18 @@ def main():
         run_logreg_case('hostpath_logreg_weight_history', {'random_seed': 42, 'num_products': 20, 'K': 6}, 150, 60, weight_history='exp_0.2')
         run_case('hostpath_ouc_weight_history_eps', {'random_seed': 43, 'num_products': 30, 'K': 8}, 80, agent_kind='ouc',
                  agent_args=dict(random_seed=78, weight_history='inverse', epsilon=0.2), injected=True)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'env0':            # reco-gym-v0, the cluster toy model (reco_env_v0.py)
+        V0 = 'reco-gym-v0'
+        run_case('mt_env0_default', {'random_seed': 42}, 400, env_id=V0)                       # env_0_args as shipped
+        run_case('mt_env0_ouc', {'random_seed': 7, 'num_products': 12, 'num_clusters': 3}, 300, n_organic=20, agent_kind='ouc',
+                 agent_args=dict(random_seed=5), env_id=V0)
+        run_case('philox_env0_random', {'random_seed': 11, 'num_products': 20, 'num_clusters': 4}, 300, agent_kind='random',
+                 agent_args=dict(random_seed=9), injected=True, env_id=V0)
+        run_case('philox_env0_ouc', {'random_seed': 13, 'num_products': 30, 'num_clusters': 2, 'phi_var': 0.5}, 250, n_organic=15,
+                 agent_kind='ouc', agent_args=dict(random_seed=3), injected=True, env_id=V0)
+        run_case('philox_env0_uniform', {'random_seed': 17, 'num_products': 64, 'num_clusters': 8,
+                                         'prob_organic_to_bandit': 0.4, 'prob_bandit_to_organic': 0.1}, 200, injected=True, env_id=V0)
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'flips':           # generate_beta's pairing at P = 2 000
         flips_index_golden()

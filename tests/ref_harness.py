@@ -133,10 +133,42 @@ class InjectedEnvRng:
             z = normals(self.seed, self.user, self.t - 1, DRAW_DRIFT, K)
         return loc + scale * z.reshape(K, 1)
 
+    def binomial(self, n, p):
+        """reco-gym-v0's click (reco_env_v0.py:61-63): RandomState.binomial(1, p), i.e. numpy's legacy inversion
+        (numpy/random/src/legacy/legacy-distributions.c) fed with the EVENT draw's words 0,1 (restarts: slots 1, 2, ...)."""
+        import math
+        assert n == 1
+        self.p_click_log.append(float(p))
+        pe = p if p <= 0.5 else 1.0 - p
+        q = 1.0 - pe
+        qn = math.exp(n * math.log(q))
+        np_ = n * pe
+        bound = int(min(n, np_ + 10.0 * math.sqrt(np_ * q + 1)))
+        slot = 0
+        w = draw(self.seed, self.user, self.t, slot, DRAW_EVENT)
+        U = uniform(w[0], w[1])
+        X, px = 0, qn
+        while U > px:
+            X += 1
+            if X > bound:
+                X, px = 0, qn
+                slot += 1
+                w = draw(self.seed, self.user, self.t, slot, DRAW_EVENT)
+                U = uniform(w[0], w[1])
+            else:
+                U -= px
+                px = ((n - X + 1) * pe * px) / (X * q)
+        return X if p <= 0.5 else n - X
+
     def choice(self, a, p=None):
         if p is None:
             w = draw(self.policy_seed, self.user, self.t, 0, DRAW_POLICY)
             return bounded(w[0], w[1], int(a))
+        if self._reset_pending and type(self.env).__name__ == 'RecoEnv0':
+            # reco-gym-v0's reset draws the first product view: choice(P, p = initial_product_probs), reco_env_v0.py:52-54
+            self._reset_pending = False
+            w = draw(self.seed, self.user, 0, 0, DRAW_RESET)
+            return numpy_choice_with_p(a, p, uniform(w[0], w[1]))
         w = draw(self.seed, self.user, self.t, 0, DRAW_EVENT)
         if isinstance(a, (int, np.integer)) and a == 3 and len(p) == 3:
             # NB: P == 3 would be ambiguous with the transition draw; fixtures avoid P == 3
@@ -186,10 +218,10 @@ class InjectedAgentRng:
         return numpy_choice_with_p(a, p, uniform(w[2], w[3]))
 
 
-def make_reference_env(args):
+def make_reference_env(args, env_id='reco-gym-v1'):
     recogym = import_reference()
     import gym
-    env = gym.make('reco-gym-v1')
+    env = gym.make(env_id)
     env.init_gym(args)
     return env
 
