@@ -1040,6 +1040,7 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     d.ouc_reverse_pop = cfg->ouc_reverse_pop;
     d.ouc_epsilon = cfg->ouc_epsilon;
     d.time_mode = cfg->time_mode; d.time_mu = cfg->time_mu; d.time_sigma = cfg->time_sigma;
+    d.env_kind = cfg->env_kind;
     d.n_users = d.n_cap = static_cast<uint32_t>(n_users);
     s->h_pinned = nullptr; s->h_step = nullptr;
     {   // run-path options from the environment, once
