@@ -93,11 +93,18 @@ def _cached_data(env, num_organic_offline_users, num_offline_users):
     os.makedirs(cache_dir, exist_ok=True)
     path = os.path.join(cache_dir, _cache_file_name(env, num_organic_offline_users, num_offline_users))
     if os.path.exists(path):
-        with open(path, 'rb') as fh:
-            return pickle.load(fh, fix_imports=False)
+        try:
+            with open(path, 'rb') as fh:
+                return pickle.load(fh, fix_imports=False)
+        except Exception:       # noqa: BLE001 — a truncated / foreign file (a run killed mid-write): regenerate it
+            pass
     data = env.generate_logs(num_offline_users=num_offline_users, num_organic_offline_users=num_organic_offline_users)
-    with open(path, 'wb') as fh:
+    # written beside its final name and renamed into place: a reader (another rank, another process) sees the old file, no
+    # file, or the whole new one — never half of it
+    tmp = f'{path}.{os.getpid()}.tmp'
+    with open(tmp, 'wb') as fh:
         pickle.dump(data, fh, protocol=pickle.HIGHEST_PROTOCOL, fix_imports=False)
+    os.replace(tmp, path)
     return data
 
 

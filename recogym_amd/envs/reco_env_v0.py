@@ -101,6 +101,14 @@ class RecoEnv0(RecoEnv1):
     def _context(self, t, u, n):
         return DefaultContext(t, u, n)   # time() = the reference's constant; the draws are addressed by the event index
 
+    def _clock_is_constant(self):
+        return True
+
+    def _external_sim(self, n):
+        from ..sim import default_log_capacity
+        return Simulator(self.config, n, policy=_abi.RG_POLICY_EXTERNAL, epoch=self._epoch, env0=self._tables,
+                         log_capacity=default_log_capacity(self.config, n), device=self._device)
+
     def generate_logs(self, num_offline_users, agent=None, num_organic_offline_users=0, first_user_id=0):
         use = agent if agent else self.agent
         from .reco_env_v1 import device_policy_of

@@ -316,6 +316,7 @@ class RecoEnv1(_EnvBase):
     def __getstate__(self):
         st = dict(self.__dict__)
         st['_seq'] = None                          # device state is re-derived from the seed
+        st['_bat'] = None
         return st
 
     # -- the batched device path ----------------------------------------------------------------
@@ -467,7 +468,154 @@ class RecoEnv1(_EnvBase):
             if pol.get('ps_all') is not None:              # the agent's whole distribution per bandit row
                 df['ps-a'] = pd.Series(pol['ps_all'](df), dtype=object, copy=False)
             return df
-        return self._generate_logs_per_user(num_offline_users, use, num_organic_offline_users, first_user_id)
+        if self._time_mode or getattr(use, 'per_user_path', False) or getattr(self.config, 'per_user_path', False):
+            return self._generate_logs_per_user(num_offline_users, use, num_organic_offline_users, first_user_id)
+        return self._generate_logs_batched(num_offline_users, use, num_organic_offline_users, first_user_id)
+
+    # -- any Python agent, B users per launch ------------------------------------------------------
+    def _batch_sim(self, n):
+        """The B-user simulator with the external policy behind _generate_logs_batched (kept across calls)."""
+        sim = getattr(self, '_bat', None)
+        if sim is None or sim.n_users < n:
+            if sim is not None:
+                sim.close()
+            sim = self._bat = self._external_sim(n)
+        return sim
+
+    def _external_sim(self, n):
+        from ..sim import default_log_capacity
+        return Simulator(self.config, n, policy=_abi.RG_POLICY_EXTERNAL, epoch=self._epoch, tables=self._tables,
+                         log_capacity=default_log_capacity(self.config, n), device=self._device)
+
+    def _generate_logs_batched(self, num_offline_users, agent, num_organic_offline_users, first_user_id=0, batch=4096):
+        """The reference's loop (abstract.py:292-316, step_offline :199-239) for ANY Python agent, B users at a time: one
+        `rg_sim_step` launch sequence and one read-back (the step's rows + the users' new states) per Markov transition of all B
+        users, `agent.act` called on the host for every user that needs an action — a copy of the agent per user slot
+        (`deepcopy`, the way the reference's harness copies agents: bench_agents.py:79,85), reset per user like `env.reset` does.
+        Rows are those of the one-user-at-a-time path (`_generate_logs_per_user`) for every agent whose `act` depends on its
+        own user's observations only; an agent that carries state ACROSS users (a sequential RNG stream of its own, a model it
+        trains while acting) sees its users interleaved here — set `agent.per_user_path = True` (or the env arg
+        `per_user_path`) to keep the sequential path for it."""
+        P = self.config.num_products
+        total = num_offline_users + num_organic_offline_users
+        org_below = first_user_id + num_organic_offline_users
+        B = int(min(batch, max(total, 1)))
+        sim = self._batch_sim(B)
+        sim.reseed(self.seed, self.seed)
+        agents = [deepcopy(agent) for _ in range(B)]
+        acts_host = torch.zeros(sim.n_users, dtype=torch.int32).pin_memory()
+        acts_dev = torch.zeros(sim.n_users, dtype=torch.int32, device=sim.device)
+        acts_np = acts_host.numpy()
+        frames = []
+        EV_B, EV_C, EV_MASK = np.uint32(_abi.RG_EV_BANDIT), np.uint32(_abi.RG_EV_CLICK), np.uint32(_abi.RG_EV_INDEX_MASK)
+        empty = self.empty_sessions
+        ctx_of = self._context
+        const_clock = self._clock_is_constant()
+        for b0 in range(0, total, B):
+            n = min(B, total - b0)
+            first = first_user_id + b0
+            sim.reset_users(first, n, organic_only_below=org_below)
+            for ag in agents[:n]:
+                ag.reset()
+            live = np.ones(n, dtype=bool)
+            sessions = [None] * n                     # organic rows since the user's last act
+            last_reward = [None] * n
+            pend = [None] * n                         # the action dict whose bandit event is in flight
+            o_u, o_t, o_v = [], [], []                # organic rows, a chunk per step
+            b_rows = []                               # (u, event index, t as logged, a, c, ps, ps-a) of bandit rows incl. the trailing one
+            base, t = 0, 0
+            while True:
+                n_live = int(live.sum())
+                if n_live == 0:
+                    break
+                if t:
+                    acts_dev.copy_(acts_host, non_blocking=True)
+                sim.step(acts_dev)
+                rows = sim.log[base:base + n_live].cpu().numpy().view(np.uint32).reshape(-1, 4)
+                st = sim.states().cpu().numpy()[:n]
+                base += n_live
+                uu = (rows[:, 0].astype(np.int64) - first)
+                code = rows[:, 2]
+                is_b = (code & EV_B) != 0
+                idx = (code & EV_MASK).astype(np.int64)
+                tt = 0 if const_clock else t
+                uo = uu[~is_b]
+                if uo.size:                           # organic rows of this step
+                    vo = idx[~is_b]
+                    o_u.append(uo + first); o_t.append(np.full(uo.size, t, dtype=np.int64)); o_v.append(vo)
+                    for u, v in zip(uo.tolist(), vo.tolist()):
+                        ss = sessions[u]
+                        if ss is None:
+                            ss = sessions[u] = OrganicSessions()
+                        ss.append({'t': tt, 'u': u + first, 'z': 'pageview', 'v': v})
+                ub = uu[is_b]
+                if ub.size:                           # bandit rows: the click of the action sent down
+                    cb = ((code[is_b] & EV_C) != 0).astype(np.int64)
+                    for u, c in zip(ub.tolist(), cb.tolist()):
+                        a = pend[u]
+                        b_rows.append((u + first, t, a['t'], a['a'], c, a['ps'], a['ps-a'] if 'ps-a' in a else ()))
+                        last_reward[u] = c
+                # who acts now: every live user that is not organic after this transition
+                t1 = t + 1
+                t1c = 0 if const_clock else t1
+                for u in np.flatnonzero(live & (st != organic)).tolist():
+                    done = bool(st[u] == stop)
+                    uid = u + first
+                    if done and uid < org_below:      # warm-up users: organic rows only (abstract.py:293-297)
+                        live[u] = False
+                        continue
+                    ss = sessions[u]
+                    sessions[u] = None
+                    a = agents[u].act(Observation(ctx_of(t1c, uid, t1), ss if ss is not None else empty), last_reward[u], done)
+                    if done:                          # the trailing row: one more act, reward 0 (abstract.py:311-316)
+                        b_rows.append((uid, t1, a['t'], a['a'], 0, a['ps'], a['ps-a'] if 'ps-a' in a else ()))
+                        live[u] = False
+                    else:
+                        ai = a['a']
+                        if not 0 <= int(ai) < P:
+                            raise IndexError(f'action {ai} is out of bounds for {P} products')
+                        acts_np[u] = ai
+                        pend[u] = a
+                t = t1
+            frames.append(self._batched_frame(o_u, o_t, o_v, b_rows, const_clock))
+        df = pd.concat(frames, ignore_index=True) if len(frames) > 1 else frames[0]
+        wide_u = first_user_id + total > 65536
+        wide_p = P > 65535
+        df['u'] = pd.array(df['u'].tolist(), dtype=pd.UInt32Dtype() if wide_u else pd.UInt16Dtype())
+        df['v'] = pd.array(df['v'].tolist(), dtype=pd.UInt32Dtype() if wide_p else pd.UInt16Dtype())
+        df['a'] = pd.array(df['a'].tolist(), dtype=pd.UInt32Dtype() if wide_p else pd.UInt16Dtype())
+        return df
+
+    def _clock_is_constant(self):
+        return False
+
+    @staticmethod
+    def _batched_frame(o_u, o_t, o_v, b_rows, const_clock):
+        """The rows of one batch in the reference's order: by user, inside a user by event index (every event index of a user
+        carries exactly one row: an organic view, a bandit event, or the trailing undrawn one)."""
+        nu = np.concatenate(o_u) if o_u else np.zeros(0, dtype=np.int64)
+        nt = np.concatenate(o_t) if o_t else np.zeros(0, dtype=np.int64)
+        nv = np.concatenate(o_v) if o_v else np.zeros(0, dtype=np.int64)
+        nb = len(b_rows)
+        bu = np.fromiter((r[0] for r in b_rows), dtype=np.int64, count=nb)
+        be = np.fromiter((r[1] for r in b_rows), dtype=np.int64, count=nb)
+        order = np.lexsort((np.concatenate([nt, be]), np.concatenate([nu, bu])))
+        n = order.size
+        is_b = order >= nu.size
+        src = np.where(is_b, order - nu.size, order)
+        t_col = np.zeros(n, dtype=np.float32)
+        v_col, a_col, ps_col, psa_col = [None] * n, [None] * n, [None] * n, [None] * n
+        c_col = np.full(n, np.nan, dtype=np.float32)
+        ob = np.flatnonzero(~is_b)
+        if not const_clock:
+            t_col[ob] = nt[src[ob]]
+        for i, v in zip(ob.tolist(), nv[src[ob]].tolist()):
+            v_col[i] = v
+        for i, j in zip(np.flatnonzero(is_b).tolist(), src[is_b].tolist()):
+            r = b_rows[j]
+            t_col[i] = r[2]; a_col[i] = r[3]; c_col[i] = r[4]; ps_col[i] = r[5]; psa_col[i] = r[6]
+        return pd.DataFrame({'t': t_col, 'u': np.concatenate([nu, bu])[order], 'z': np.where(is_b, 'bandit', 'organic').astype(object),
+                             'v': v_col, 'a': a_col, 'c': c_col, 'ps': ps_col, 'ps-a': psa_col})
 
     def _generate_logs_per_user(self, num_offline_users, agent, num_organic_offline_users, first_user_id=0):
         """Any Python agent: the reference's loop (abstract.py:292-316), one user at a time."""

@@ -547,3 +547,18 @@ def test_env0_test_agent_runs_on_the_device_path():
     q = recogym.test_agent(deepcopy(env), deepcopy(agent), 200, 400)
     assert 0.0 < q[1] < q[0] < q[2] < 0.2
     assert q == recogym.test_agent(deepcopy(env), deepcopy(agent), 200, 400)
+
+
+@pytest.mark.parametrize('sizes', [(70, 0, 4096), (33, 5, 16), (3, 0, 1)])
+def test_batched_episode_path_equals_the_per_user_path_and_the_oracle(sizes):
+    """`generate_logs(n, arbitrary agent)` drives B users per rg_sim_step launch (a copy of the agent per user slot): the rows of
+    the one-user-at-a-time path, several batches and warm-up users included, and the oracle's step API."""
+    n, n_org, batch = sizes
+    over = dict(random_seed=91, num_products=14, K=4)
+    agent = FixedCycleAgent(Configuration({'num_products': 14}))
+    env = make_env(over)
+    a = env._generate_logs_batched(n, deepcopy(agent), n_org, batch=batch)
+    b = make_env(over)._generate_logs_per_user(n, deepcopy(agent), n_org)
+    assert [str(x) for x in a.dtypes] == [str(x) for x in b.dtypes]
+    pd.testing.assert_frame_equal(a, b)
+    assert len(env.generate_logs(n, deepcopy(agent), n_org)) == len(a)        # (the default route of generate_logs)
