@@ -371,36 +371,104 @@ class Simulator:
             uniform = 1.0 / float(self.config.num_products)
         return out.cpu().numpy(), uniform
 
-    def log_columns(self, on_device=False):
-        """The log in the reference's row order, decoded ON THE DEVICE into the columns of the
-        reference's DataFrame and copied to the host column by column:
-        dict(t f32, u i32, is_bandit bool, v i32, a i32, c f32 (NaN on organic rows), ps f64 (NaN))."""
+    def log_columns(self, on_device=False, chunk_rows=1 << 25):
+        """The log in the reference's row order, decoded ON THE DEVICE into the columns of the reference's DataFrame
+        (SURVEY.md §8f-2): dict(t f32, u i32, is_bandit bool, v i32, a i32, c f32 (NaN on organic rows), ps f64 (NaN)).
+
+        To the host (the default) the columns travel in chunks of `chunk_rows` rows: chunk i is decoded into one of two staging
+        sets on the simulator's stream while chunk i - 1 crosses PCIe on a copy stream, straight into PINNED host buffers the
+        simulator keeps between calls (allocated on the first call, grown when a log is longer); the arrays returned are
+        zero-copy NumPy views of those buffers — valid until the next log_columns() of this simulator (they keep the buffers
+        alive on their own: closing the simulator does not invalidate them)."""
         out, offsets = self.sorted_log()
         ps64, _ = self.sorted_aux(offsets, out.shape[0])
-        with torch.cuda.device(self.device):
-            code = out[:, 2]
+        n = int(out.shape[0])
+        uniform = self.policy in (_abi.RG_POLICY_UNIFORM_ENV, _abi.RG_POLICY_RANDOM_AGENT)
+        t_sorted = self.sorted_time(offsets, n) if self.time_mode else None
+
+        def decode(lo, hi, dst=None):
+            """columns of rows [lo, hi) as device tensors (into the staging set `dst` when given)"""
+            rows = out[lo:hi]
+            code = rows[:, 2]
             is_b = (code & _abi.RG_EV_BANDIT) != 0
             idx = code & _abi.RG_EV_INDEX_MASK
             zero = torch.zeros((), dtype=torch.int32, device=out.device)
             nan32 = torch.full((), float('nan'), dtype=torch.float32, device=out.device)
             nan64 = torch.full((), float('nan'), dtype=torch.float64, device=out.device)
-            if self.policy in (_abi.RG_POLICY_UNIFORM_ENV, _abi.RG_POLICY_RANDOM_AGENT):
-                ps_b = torch.full((), 1.0 / float(self.config.num_products), dtype=torch.float64,
-                                  device=out.device)                 # exact 1/P of the uniform policies
+            if uniform:
+                ps_b = torch.full((), 1.0 / float(self.config.num_products), dtype=torch.float64, device=out.device)   # exact 1/P
             elif ps64 is not None:
-                ps_b = ps64                                          # float64 as the policy computed it
+                ps_b = ps64[lo:hi]                                  # float64 as the policy computed it
             else:
-                ps_b = out[:, 3].contiguous().view(torch.float32).to(torch.float64)
+                ps_b = rows[:, 3].contiguous().view(torch.float32).to(torch.float64)
             cols = dict(
-                t=(self.sorted_time(offsets, out.shape[0]) if self.time_mode else out[:, 1]).to(torch.float32),
-                u=out[:, 0].contiguous(),
+                t=(t_sorted[lo:hi] if t_sorted is not None else rows[:, 1]).to(torch.float32),
+                u=rows[:, 0].contiguous(),
                 is_bandit=is_b,
                 v=torch.where(is_b, zero, idx),
                 a=torch.where(is_b, idx, zero),
                 c=torch.where(is_b, ((code & _abi.RG_EV_CLICK) != 0).to(torch.float32), nan32),
                 ps=torch.where(is_b, ps_b, nan64),
             )
-            return cols if on_device else {k: v.cpu().numpy() for k, v in cols.items()}
+            if dst is not None:
+                for k, v in cols.items():
+                    dst[k][:hi - lo].copy_(v)
+                return dst
+            return cols
+
+        with torch.cuda.device(self.device):
+            if on_device:
+                return decode(0, n)
+            host = self._host_columns(n)
+            if n == 0:
+                return {k: v[:0].numpy() for k, v in host.items()}
+            chunk = int(max(1, min(chunk_rows, n)))
+            if getattr(self, '_copy_stream', None) is None:
+                self._copy_stream = torch.cuda.Stream(device=self.device)
+            cs = self._copy_stream
+            stage = getattr(self, '_stage_cols', None)
+            if stage is None or stage[0]['u'].shape[0] < chunk:
+                stage = self._stage_cols = [{k: torch.empty(chunk, dtype=v.dtype, device=self.device) for k, v in host.items()}
+                                            for _ in range(2)]
+            done = [None, None]
+            main = torch.cuda.current_stream(self.device)
+            for i, lo in enumerate(range(0, n, chunk)):
+                hi = min(lo + chunk, n)
+                if done[i & 1] is not None:
+                    main.wait_event(done[i & 1])        # the copy that last read this staging set has finished
+                decode(lo, hi, stage[i & 1])
+                ready = torch.cuda.Event()
+                ready.record(main)
+                cs.wait_event(ready)
+                with torch.cuda.stream(cs):
+                    for k, v in host.items():
+                        v[lo:hi].copy_(stage[i & 1][k][:hi - lo], non_blocking=True)
+                    done[i & 1] = torch.cuda.Event()
+                    done[i & 1].record(cs)
+            cs.synchronize()
+            return {k: v[:n].numpy() for k, v in host.items()}
+
+    _HOST_COLS = (('t', torch.float32), ('u', torch.int32), ('is_bandit', torch.bool), ('v', torch.int32), ('a', torch.int32),
+                  ('c', torch.float32), ('ps', torch.float64))
+
+    def _host_columns(self, n):
+        """Host buffers of log_columns(): pinned (page-locked: PCIe DMA at full rate, asynchronous copies), kept between calls.
+        Where the host cannot spare the memory page-locked (less than twice the need is available) they are ordinary arrays."""
+        have = getattr(self, '_host_cols', None)
+        if have is not None and have['u'].shape[0] >= n:
+            return have
+        cap = int(n * 1.02) + 4096
+        need = cap * sum(torch.empty((), dtype=d).element_size() for _, d in self._HOST_COLS)
+        pin = True
+        try:
+            avail = next(int(l.split()[1]) * 1024 for l in open('/proc/meminfo') if l.startswith('MemAvailable'))
+            pin = need * 2 < avail
+        except Exception:       # noqa: BLE001 — no /proc/meminfo: pin
+            pass
+        self._host_cols = None
+        self._host_cols = {k: torch.empty(cap, dtype=d, pin_memory=pin) for k, d in self._HOST_COLS}
+        self._host_cols_pinned = pin
+        return self._host_cols
 
     def log_columns_device(self):
         """log_columns() left on the device (torch tensors), e.g. for
