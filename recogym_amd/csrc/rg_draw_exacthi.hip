@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* g_buf = smem_raw;                                           // [NB][128][RSc]
     float* mu_buf = reinterpret_cast<float*>(g_buf + NB * TILE_B);    // [NB][128]
+    float* scp_stage = mu_buf + NB * 128 + 64;                        // [4 waves][32 users][kMaxSC] super-chunk prefixes of the work item
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const int j = lane & 31, h = lane >> 5;
     const uint32_t pos0 = d.grp_lo, n_o = pos0 + d.grp_n;
@@ -163,6 +164,18 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
         float* chunkp = d.cache_chunk + urow * d.n_chunks;
         float* scp_row = d.walk_scp + urow * kMaxSC;
         __syncthreads();           // every wave is done with the LDS buffers (previous work item)
+        // The prefix at the end of every super-chunk is gathered in LDS and leaves as ONE 128-byte row per user at the end of
+        // the work item; the {sum, reference} records only exist for the rare users whose reference moves during the sweep
+        // (k_cache_finalize / k_cache_prefix rescale those) or where the sweep does not leave the finalize output itself.
+        // Written at every super-chunk end, as 4- and 8-byte scattered stores, the two cost 12 % of the kernel
+        // (profiles/r5/ab_call5_xh_books.jsonl).  Only the lane h == 0 of a user touches its row: no synchronisation.
+        float* sstage = scp_stage + static_cast<size_t>(wave * 32 + j) * kMaxSC;
+        if (h == 0) {
+#pragma unroll
+            for (int i = 0; i < static_cast<int>(kMaxSC) / 4; ++i)
+                reinterpret_cast<float4*>(sstage)[i] = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);     // unused entries: never counted
+        }
+        bool rec_on = !d.fin_in_sweep;
         const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
         const rg_v4i rs_g = raw_buffer_rsrc(d.xsplit), rs_m = raw_buffer_rsrc(d.xmulo);
         const uint32_t g_lds = lds_addr_of(g_buf), mu_lds = lds_addr_of(mu_buf);
@@ -285,8 +298,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
                 s_sc += static_cast<double>((w0 + w1) + (w2 + s));
                 if (--sc_left == 0 && !(RG_XH_ABL & 1024)) {
                     if (h == 0 && !(RG_XH_ABL & 128)) {
-                        scp_row[sc_cur] = static_cast<float>(run_pref);
-                        rec[sc_cur] = make_float2(static_cast<float>(s_sc), q_done);
+                        sstage[sc_cur] = static_cast<float>(run_pref);
+                        if (rec_on) rec[sc_cur] = make_float2(static_cast<float>(s_sc), q_done);
                     }
                     s_sc = 0.0;
                     // some logit is >= ~43 above the reference: re-reference from the next super-chunk that has not started
@@ -399,7 +412,15 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
             // step 4T + 4 issues the first chunk of tile T + 1: a super-chunk may start there
             if (--sc_issue_left == 0) sc_issue_left = d.sc_chunks / 4;
             const bool sc_start = sc_issue_left == d.sc_chunks / 4;
-            if (sc_start && q_next != q) { set_reference(q_next); n_resc += 1; }
+            if (sc_start && q_next != q) {
+                if (!rec_on) {     // the first move of this user's reference: the records of the super-chunks booked so far (all
+                    rec_on = true; // on the reference in force until now; their sums from the staged prefixes)
+                    if (h == 0)
+                        for (uint32_t sc = 0; sc < sc_cur; ++sc)
+                            rec[sc] = make_float2(sstage[sc] - (sc ? sstage[sc - 1] : 0.0f), q);
+                }
+                set_reference(q_next); n_resc += 1;
+            }
             stream(oa, ob, c0 + 5, H0, L0, H1, L1, s_new, [&] { book(C2{}, T, s_pend); });
             s_pend = s_new;
             stream(ob, oa, min(c0 + 6, n_ch - 1), H1, L1, H0, L0, s_new, [&] { book(C3{}, T, s_pend); });   // (may flush the finished super-chunk with q_done)
@@ -417,8 +438,13 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
             book(C3{}, T, sl);
         }
         if (sc_left != d.sc_chunks / 4 && h == 0) {            // partial last super-chunk
-            rec[sc_cur] = make_float2(static_cast<float>(s_sc), q_done);
-            scp_row[sc_cur] = static_cast<float>(run_pref);
+            if (rec_on) rec[sc_cur] = make_float2(static_cast<float>(s_sc), q_done);
+            sstage[sc_cur] = static_cast<float>(run_pref);
+        }
+        if (h == 0) {              // the user's super-chunk prefixes: one row
+#pragma unroll
+            for (int i = 0; i < static_cast<int>(kMaxSC) / 4; ++i)
+                reinterpret_cast<float4*>(scp_row)[i] = reinterpret_cast<const float4*>(sstage)[i];
         }
         if (active && h == 0) d.cache_resc[urow] = static_cast<uint8_t>(min(n_resc, 255));
         if (d.fin_in_sweep && active && h == 0 && n_resc == 0) {
@@ -436,7 +462,6 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
             for (int k4 = 0; k4 < (2 * KH) / 4; ++k4) row4[11 + k4] = make_float4(ou[4 * k4], ou[4 * k4 + 1], ou[4 * k4 + 2], ou[4 * k4 + 3]);
 #pragma unroll
             for (int k = ((2 * KH) / 4) * 4; k < 2 * KH; ++k) reinterpret_cast<float*>(row4)[44 + k] = ou[k];
-            for (uint32_t sc = d.n_sc; sc < kMaxSC; ++sc) scp_row[sc] = INFINITY;
             float* hot = d.walk_hot + urow * 32;
             *reinterpret_cast<float4*>(hot) = make_float4(static_cast<float>(run_pref), dlt * 1.000001f, q, __builtin_bit_cast(float, 0u));
             hot[31] = xh_eligible(static_cast<double>(Ahat), static_cast<double>(qabs_max)) ? kRhoTight : kRhoLoose;

@@ -443,6 +443,25 @@ def test_wide_logit_range_re_references_and_still_matches_the_oracle(mode, sigma
                          ps_rtol=1e-6, what=f'{mode} sigma_mu={sigma_mu}')
 
 
+@pytest.mark.parametrize('fin', ['1', '0'])
+@pytest.mark.parametrize('sigma_mu', [30.0, 200.0])
+def test_error_free_sweep_re_references_and_still_matches_the_oracle(sigma_mu, fin, monkeypatch):
+    """The same spread of mu_organic at sigma_omega = 0 through run_walk_pipe, whose sweep is k_sweep_xh: its reference moves
+    inside the sweep (an integer in the exact accumulator; past |q| ~ 200 the user is no longer eligible for the tight delta),
+    the {sum, reference} records of such users are back-filled from the staged super-chunk prefixes at the first move, and
+    k_cache_finalize / k_cache_prefix rescale them.  `fin = 0`: the sweep leaves the finalize output to those kernels for
+    every user (RECOGYM_FIN_IN_SWEEP=0)."""
+    from oracle import oracle as orc
+    monkeypatch.delenv('RECOGYM_DRAW', raising=False)
+    monkeypatch.setenv('RECOGYM_PIPE_MIN', '256')
+    monkeypatch.setenv('RECOGYM_FIN_IN_SWEEP', fin)
+    cfg = Configuration({**env_1_args, 'random_seed': 78, 'num_products': 3000, 'K': 20, 'sigma_mu_organic': sigma_mu, 'sigma_omega': 0.0})
+    pol = dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=31, ouc=dict(gu.OUC_DEFAULTS))
+    want = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol).generate_logs(700)
+    rows, cnt = run_sim(cfg, 700, p_click=False, **pol)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps')}, ps_rtol=1e-12, what=f'xh sigma_mu={sigma_mu} fin={fin}')
+
+
 def test_repack_and_tail_kernel_do_not_change_the_log_at_scale(monkeypatch):
     """300 000 users (above the 2^18 threshold where the state repack is on by default): the run with
     the repack every 16 steps and the per-user tail kernel must log the same rows as plain lock-step
