@@ -1099,6 +1099,7 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
         s->xh_kernel = xh_kernel_for(d);
     if (s->xh_kernel) {
         s->xh_smem = 2 * (128 * static_cast<size_t>(d.XRS) + 512) + 256 + 4 * 32 * kMaxSC * sizeof(float);   // tiles, seeds, the super-chunk prefix stage
+        if (const char* e = getenv("RECOGYM_XH_SMEM_PAD")) s->xh_smem += static_cast<size_t>(atoi(e));   // occupancy experiments: one block per CU
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s->xh_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->xh_smem));
     } else { d.XNH = d.XNL = d.XRS = 0; }

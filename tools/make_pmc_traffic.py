@@ -59,6 +59,20 @@ def main():
     d = bench_line('pmc_c3_fetch')
     try_add('k_walk', lambda: entry('c3', 'pmc_c3_fetch', 'pmc_c3_write', 'k_walk', d['config']['events_per_step'], 'events',
                                     f"C3, {d['config']['users_per_gpu']} users; k_walk2 rounds + k_walk_solo"))
+    # the sweep of the same run (k_sweep_xh since round 5) and what the walk kernels ISSUE (bench.py's issue_roofline)
+    try_add('k_sweep_xh', lambda: entry('c3', 'pmc_c3_fetch', 'pmc_c3_write', 'k_sweep_xh', d['config']['users_per_gpu'], 'swept draws',
+                                        f"C3, {d['config']['users_per_gpu']} users"))
+
+    def issue():
+        ds = bench_line('pmc_c3_sq')
+        ev = ds['config']['events_per_step']
+        (valu, nd), (salu, _) = val('pmc_c3_sq', 'k_walk', 'SQ_INSTS_VALU'), val('pmc_c3_sq', 'k_walk', 'SQ_INSTS_SALU')
+        (wc, _), (wa, _) = val('pmc_c3_sq', 'k_walk', 'SQ_WAVE_CYCLES'), val('pmc_c3_sq', 'k_walk', 'SQ_WAIT_ANY')
+        return dict(workload='c3', policy='ouc', unit_name='events', units_in_profiled_run=ev, dispatches_in_profiled_run=nd,
+                    valu_wave_instr_per_unit=valu / ev, salu_wave_instr_per_unit=salu / ev, wait_any_over_wave_cycles=wa / wc,
+                    source=f'profiles/{RND}/pmc_c3_sq_counters.csv (C3, {ds["config"]["users_per_gpu"]} users; SQ_INSTS_VALU / SQ_INSTS_SALU of '
+                           f'k_walk2 + k_walk_solo over the run\'s events; rocprofv3 --pmc on bench.py --single-run)')
+    try_add('k_walk_issue', issue)
     try:
         dd = bench_line('pmc_c3drift_fetch')
         try_add('k_draw_bf16p', lambda: entry('c3drift', 'pmc_c3drift_fetch', 'pmc_c3drift_write', 'k_draw_bf16p',
