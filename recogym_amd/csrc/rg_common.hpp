@@ -317,6 +317,7 @@ struct rg_sim {
     void (*bf16_kernel)(DevSim, uint32_t, uint32_t);
     void (*xh_kernel)(DevSim, uint32_t, uint32_t);   // k_sweep_xh: the walked run's sweep where it exists (else bf16_kernel)
     size_t xh_smem;
+    int xh_waves;            // waves per block of that kernel (4: two blocks per CU, 8: one; RECOGYM_XH_WAVES)
     uint32_t draw_threads, draw_users;   // block size of that kernel and the users one block sweeps for (256 / 128; wide K: 512 / 256)
     bool profiling;
     std::vector<hipEvent_t> prof_events;   // 6 per profiled step: before draw, after mfma, after search, after exact, after the frozen LogReg acts, after advance
@@ -352,7 +353,7 @@ finalize_kernel_t finalize_kernel_for(const DevSim& d);    // part 4
 cached_kernel_t cached_kernel_for(const DevSim& d);
 draw_kernel_t bf16p_kernel_for(const DevSim& d);
 draw_kernel_t f16w_kernel_for(const DevSim& d);            // part 5
-draw_kernel_t xh_kernel_for(const DevSim& d);              // part 8 (nullptr: no error-free sweep for this K class)
+draw_kernel_t xh_kernel_for(const DevSim& d, int waves);   // part 8 (nullptr: no error-free sweep for this K class); waves per block: 4 or 8
 void (*xh_table_kernel())(DevSim);
 void (*xh_stats_kernel())(DevSim);
 search_kernel_t drift_kernel();                            // part 6

@@ -137,18 +137,20 @@ __global__ void __launch_bounds__(kBlock) k_xh_stats(DevSim d) {
     if (threadIdx.x == 0) d.xstats[which] = static_cast<float>(red[0] * (1.0 + 1e-6) + 1e-30);
 }
 
-template <int KH, int NH, int NL>
-__global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, uint32_t S) {
+// NW waves per block (4: two blocks per CU; 8: one — the two halves of the CU's users share one stream of table tiles)
+template <int KH, int NH, int NL, int NW>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) k_sweep_xh(DevSim d, uint32_t t, uint32_t S) {
     constexpr int NM = NH + NL;
     constexpr uint32_t RSc = 32u * NM + 16u, TILE_B = 128u * RSc, NB = 2;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* g_buf = smem_raw;                                           // [NB][128][RSc]
     float* mu_buf = reinterpret_cast<float*>(g_buf + NB * TILE_B);    // [NB][128]
-    float* scp_stage = mu_buf + NB * 128 + 64;                        // [4 waves][32 users][kMaxSC] super-chunk prefixes of the work item
+    float* scp_stage = mu_buf + NB * 128 + 64;                        // [NW waves][32 users][kMaxSC] super-chunk prefixes of the work item
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const int j = lane & 31, h = lane >> 5;
     const uint32_t pos0 = d.grp_lo, n_o = pos0 + d.grp_n;
-    const uint32_t n_tiles_u = (d.grp_n + 127u) / 128u;
+    constexpr uint32_t UPB = 32u * NW;                               // users per block
+    const uint32_t n_tiles_u = (d.grp_n + UPB - 1u) / UPB;
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
     const float mumax = d.stats[2 * KH + 1], g2max = d.stats[2 * KH];
     const uint32_t n_pt = d.n_chunks / 4;                             // product tiles
@@ -156,7 +158,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
     (void)S;
 
     for (uint32_t wk = blockIdx.x; wk < n_tiles_u; wk += gridDim.x) {
-        const uint32_t pos = pos0 + wk * 128 + wave * 32 + j;
+        const uint32_t pos = pos0 + wk * UPB + wave * 32 + j;
         const bool active = pos < n_o;
         const uint32_t slot = active ? cur[pos] : 0u;
         const size_t urow = active ? static_cast<size_t>(d.uid[slot]) : static_cast<size_t>(d.n_cap);   // inactive lanes: the dummy row
@@ -180,15 +182,15 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
         const rg_v4i rs_g = raw_buffer_rsrc(d.xsplit), rs_m = raw_buffer_rsrc(d.xmulo);
         const uint32_t g_lds = lds_addr_of(g_buf), mu_lds = lds_addr_of(mu_buf);
         auto fetch_tile = [&](uint32_t ti) {
-            for (uint32_t off = static_cast<uint32_t>(wave) * 1024u; off < TILE_B; off += 4096u)
+            for (uint32_t off = static_cast<uint32_t>(wave) * 1024u; off < TILE_B; off += NW * 1024u)
                 dma_to_lds_b128(rs_g, g_lds + (ti % NB) * TILE_B + off, lane16, ti * TILE_B + off);
-            if (wave == 3 && lane < 32) dma_to_lds_b128(rs_m, mu_lds + (ti % NB) * 512u, lane16, ti * 512u);
+            if (wave == NW - 1 && lane < 32) dma_to_lds_b128(rs_m, mu_lds + (ti % NB) * 512u, lane16, ti * 512u);
         };
         fetch_tile(0);
         // ---- the user's bounds and the fp16 pieces of its omega (its own K / 2 coordinates per lane, joined across the two
         // lanes of the user); the pieces travel through LDS (tile buffer 1: its DMA goes out after the B rows are built) ----
         const double* om_row = d.omega + static_cast<size_t>(slot) * d.OMS;
-        unsigned short* stage = reinterpret_cast<unsigned short*>(g_buf + TILE_B) + static_cast<size_t>(wave * 32 + j) * (2 * KH) * 4;
+        unsigned short* stage = reinterpret_cast<unsigned short*>(g_buf + TILE_B) + static_cast<size_t>(wave * 32 + j) * (2 * KH) * 3;   // (8 waves x 32 users x 20 x 6 B = one tile buffer)
         float absdot = 0.0f, sq = 0.0f, absw = 0.0f, egam = 0.0f, lob = 0.0f;
         const float glomax = d.xstats[2 * KH];
 #pragma unroll
@@ -197,10 +199,9 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
             double w = 0.0;
             if (active && k < K) w = om_row[k];
             const XhPieces pc = xh_split(w);
-            ushort4 pk;
-            pk.x = __builtin_bit_cast(unsigned short, pc.mid9); pk.y = __builtin_bit_cast(unsigned short, pc.lo15);
-            pk.z = __builtin_bit_cast(unsigned short, pc.hi); pk.w = __builtin_bit_cast(unsigned short, pc.mid6);
-            *reinterpret_cast<ushort4*>(stage + 4 * k) = pk;               // [k][group 0..3]: the residual group's order
+            stage[3 * k] = __builtin_bit_cast(unsigned short, pc.mid9);     // [k][wmid 2^9, wlo 2^15, whi]; wmid 2^6 = wmid 2^9 / 8
+            stage[3 * k + 1] = __builtin_bit_cast(unsigned short, pc.lo15);
+            stage[3 * k + 2] = __builtin_bit_cast(unsigned short, pc.hi);
             const float wf = fabsf(static_cast<float>(w)) * 1.0000002f;
             const float r1f = fabsf(static_cast<float>(pc.r1)) * 1.002f;
             absdot = fmaf(wf, d.stats[k], absdot);
@@ -225,13 +226,15 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
                 unsigned short v = 0;
                 if (m < NH) {
                     const uint32_t ke = 16 * m + 8 * h + e;
-                    if (ke < K) v = stage[4 * ke + 2];
+                    if (ke < K) v = stage[3 * ke + 2];
                     else if (ke == 16 * NH - 3) v = 0x3C00;             // 1.0: the m1 column
                     else if (ke == 16 * NH - 2) v = 0x1400;             // 2^-10: the m2 2^10 column
                 } else {
                     const uint32_t s = 16 * (m - NH) + 8 * h + e;
                     const uint32_t grp = (s >= K) + (s >= 2 * K) + (s >= 3 * K) + (s >= 4 * K);
-                    if (grp < 4) v = stage[4 * (s - grp * K) + grp];
+                    if (grp < 3) v = stage[3 * (s - grp * K) + grp];
+                    else if (grp == 3)       // wmid 2^6: the same fp16 significand three binades down (exact unless it leaves the normal range)
+                        v = __builtin_bit_cast(unsigned short, static_cast<_Float16>(static_cast<float>(__builtin_bit_cast(_Float16, stage[3 * (s - 3 * K)])) * 0.125f));
                 }
                 Bm[m][e] = __builtin_bit_cast(_Float16, v);
             }
@@ -469,9 +472,9 @@ __global__ void __launch_bounds__(kBlock, 2) k_sweep_xh(DevSim d, uint32_t t, ui
     }
 }
 
-draw_kernel_t xh_kernel_for(const DevSim& d) {
-    if (d.XNH == 1 && d.XNL == 2 && d.KH == 4) return k_sweep_xh<4, 1, 2>;
-    if (d.XNH == 2 && d.XNL == 5 && d.KH == 10) return k_sweep_xh<10, 2, 5>;
+draw_kernel_t xh_kernel_for(const DevSim& d, int waves) {
+    if (d.XNH == 1 && d.XNL == 2 && d.KH == 4) return waves == 8 ? k_sweep_xh<4, 1, 2, 8> : k_sweep_xh<4, 1, 2, 4>;
+    if (d.XNH == 2 && d.XNL == 5 && d.KH == 10) return waves == 8 ? k_sweep_xh<10, 2, 5, 8> : k_sweep_xh<10, 2, 5, 4>;
     return nullptr;
 }
 void (*xh_table_kernel())(DevSim) { return k_make_xh_table; }

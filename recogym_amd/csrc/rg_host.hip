@@ -889,7 +889,7 @@ int run_walk_pipe(rg_sim* sim, hipStream_t st) {
             ds.fin_in_sweep = dg.fin_in_sweep = sim->fin_in_sweep ? 1u : 0u;
             const uint32_t tiles_up = (dg.grp_n + sim->draw_users - 1) / sim->draw_users;
             if (int rc = span_begin(0, sS)) return rc;
-            if (sim->xh_kernel) hipLaunchKernelGGL(sim->xh_kernel, dim3(sweep_grid(sim, tiles_up, 1)), dim3(kBlock), sim->xh_smem, sS, ds, 0u, 1u);
+            if (sim->xh_kernel) hipLaunchKernelGGL(sim->xh_kernel, dim3(grid_for((dg.grp_n + 32u * sim->xh_waves - 1) / (32u * sim->xh_waves), 1)), dim3(64 * sim->xh_waves), sim->xh_smem, sS, ds, 0u, 1u);
             else
             hipLaunchKernelGGL(sim->bf16_kernel, dim3(sweep_grid(sim, tiles_up, 1)), dim3(sim->draw_threads), sim->bf16_smem, sS, ds, 0u, 1u);
             if (int rc = span_end(sS)) return rc;
@@ -1096,9 +1096,13 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     s->xh_kernel = nullptr; s->xh_smem = 0;
     if (d.XNH && d.use_cache && d.use_mfma == 2 && s->bf16_kernel && s->bf16_kernel == bf16p_kernel_for(d) && d.f16 && !d.wide &&
         static_cast<size_t>(d.P_pad) * d.XRS < (1ull << 31))
-        s->xh_kernel = xh_kernel_for(d);
+    {
+        s->xh_waves = 4;
+        if (const char* e = getenv("RECOGYM_XH_WAVES")) s->xh_waves = atoi(e) == 8 ? 8 : 4;
+        s->xh_kernel = xh_kernel_for(d, s->xh_waves);
+    }
     if (s->xh_kernel) {
-        s->xh_smem = 2 * (128 * static_cast<size_t>(d.XRS) + 512) + 256 + 4 * 32 * kMaxSC * sizeof(float);   // tiles, seeds, the super-chunk prefix stage
+        s->xh_smem = 2 * (128 * static_cast<size_t>(d.XRS) + 512) + 256 + static_cast<size_t>(s->xh_waves) * 32 * kMaxSC * sizeof(float);   // tiles, seeds, the super-chunk prefix stage
         if (const char* e = getenv("RECOGYM_XH_SMEM_PAD")) s->xh_smem += static_cast<size_t>(atoi(e));   // occupancy experiments: one block per CU
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s->xh_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->xh_smem));

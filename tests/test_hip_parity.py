@@ -846,7 +846,8 @@ def test_sum_cache_does_not_change_the_log_at_scale(monkeypatch):
     for k in ('organic', 'bandit', 'clicks', 'phantom'):
         assert on_c[k] == off_c[k], k
     assert on_chk == off_chk
-    assert abs(on_c['exact_draws'] - off_c['exact_draws']) < 0.05 * off_c['exact_draws']
+    # (round 5: the cached run's sweep is k_sweep_xh — a certificate ~10x tighter than the lock-step sweep's: fewer draws go to float64)
+    assert 0 < on_c['exact_draws'] <= 1.05 * off_c['exact_draws']
     assert off_c['exact_sweeps'] == off_c['exact_draws'] and 0 < on_c['exact_sweeps'] < on_c['exact_draws']
 
 

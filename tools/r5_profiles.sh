@@ -34,7 +34,7 @@ PY
   grep '"metric"' $O/$name.out > $O/${name}_bench_line.json
   rm -rf $O/$name
 }
-stats c3 --workload c3 --steps 2 --warmup 1 --no-cpu-baseline --no-drift-line --no-materialise
+stats c3 --workload c3 --steps 2 --warmup 1 --no-cpu-baseline --no-drift-line --no-materialise --no-other-workloads
 pmc pmc_c3_fetch FETCH_SIZE --workload c3
 pmc pmc_c3_write WRITE_SIZE --workload c3
 pmc pmc_c3_sq "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD" --workload c3
