@@ -91,6 +91,11 @@ typedef struct rg_config {
                                      * pass 1).  Lock-step execution only. */
     double time_mu;                 /* config.normal_time_mu (default 0) */
     double time_sigma;              /* config.normal_time_sigma (default 1) */
+    /* RG_POLICY_LOGREG_FROZEN with select_randomly = True (logreg_ips.py:61-72): the action is SAMPLED from predict_proba —
+     * softmax of the decision function, rng.choice(num_products, p = proba), ps = proba[action] — with the second policy
+     * uniform of the event (words 2,3).  Needs every product as a class (classes = 0 .. P-1) and P <= 1024; lock-step only. */
+    uint32_t lr_select_randomly;
+    uint32_t reserved1;
 } rg_config;
 
 /*

@@ -90,7 +90,8 @@ class OracleEnv:
                  logreg=None, env0=None):
         self.config = config
         self.rg_config = make_rg_config(config, config.random_seed + epoch, policy, policy_seed,
-                                        ouc, env_kind=1 if env0 is not None else 0)
+                                        ouc, env_kind=1 if env0 is not None else 0,
+                                        lr_select_randomly=bool(logreg and logreg.get('select_randomly')))
         if env0 is not None:       # reco-gym-v0: dict of recogym_amd.envs.static_params.draw_env0_tables
             self.tables = []
             self._ptrs = [None] * 4

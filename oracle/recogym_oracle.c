@@ -510,7 +510,23 @@ int32_t rgo_env_policy_act(rgo_env* e, double* ps_out) {
             for (uint32_t p = 0; p < P; ++p)
                 if (e->views[p]) sc = sc + (double)e->views[p] * e->lr_coef_t[(size_t)p * e->lr_n + c];
             sc = sc + e->lr_intercept[c];
+            if (e->cfg.lr_select_randomly && c < P) e->buf[c] = sc;
             if (c == 0 || sc > best_s) { best = c; best_s = sc; }
+        }
+        if (e->cfg.lr_select_randomly) {
+            /* select_randomly (logreg_ips.py:61-72): action_proba = predict_proba(features) = softmax(decision_function)
+             * (sklearn.utils.extmath.softmax: exp(x - max) / sum), action = rng.choice(num_products, p = action_proba) with the
+             * model's own RandomState (the second policy uniform of the event here), ps = action_proba[action].
+             * Needs every product as a class (lr_n == P), like the reference's choice over num_products. */
+            double sum = 0.0;
+            for (uint32_t c = 0; c < P; ++c) { e->buf[c] = exp(e->buf[c] - best_s); sum += e->buf[c]; }
+            for (uint32_t c = 0; c < P; ++c) e->buf[c] = e->buf[c] / sum;
+            double u;
+            if (e->rng_mode == RGO_RNG_MT) u = mt_double(&e->pol_mt);
+            else { const rg_u32x4 w = rg_draw(e->cfg.policy_seed, e->user, e->time, 0, RG_DRAW_POLICY); u = rg_uniform(w.w[2], w.w[3]); }
+            const uint32_t a = icdf_right(e->buf, P, u, e->cdfbuf);
+            *ps_out = e->buf[a < P ? a : P - 1];
+            return (int32_t)a;
         }
         *ps_out = 1.0;
         return e->lr_classes[best];

@@ -53,6 +53,8 @@ class RgConfig(C.Structure):
         ('env_kind', C.c_uint32),
         ('time_mu', C.c_double),
         ('time_sigma', C.c_double),
+        ('lr_select_randomly', C.c_uint32),
+        ('reserved1', C.c_uint32),
     ]
 
 

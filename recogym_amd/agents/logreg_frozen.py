@@ -20,7 +20,8 @@ class LogregFrozenAgent(Agent):
         """coef (n_classes, P) / intercept (n_classes,) / classes (n_classes,) as sklearn stores them;
         a two-class model (coef of one row) is expanded to two rows (zero first row).
         config.select_randomly = True (logreg_ips.py:61-66): the action is sampled from predict_proba — softmax of the
-        same scores, one addressed policy draw — on the per-user path (no device form; needs every product as a class,
+        same scores, one addressed policy draw — on the device where the model has a class per product and P <= 1024
+        (rg_config.lr_select_randomly, k_logreg_sample), else on the host paths (needs every product as a class either way,
         like the reference's rng.choice(num_products, p=proba))."""
         super().__init__(config)
         self.select_randomly = bool(getattr(config, 'select_randomly', False))
@@ -47,8 +48,16 @@ class LogregFrozenAgent(Agent):
         return cls(config, logreg.coef_, logreg.intercept_, logreg.classes_)
 
     def device_policy(self):
-        if getattr(self.config, 'with_ps_all', False) or self.select_randomly or self.history is not None:
+        if getattr(self.config, 'with_ps_all', False) or self.history is not None:
             return None
+        if self.select_randomly:
+            # sampled from predict_proba on the device (k_logreg_sample: a wave per act) where the model has a class per product
+            # — what the reference's rng.choice(num_products, p = proba) needs — and P <= 1024; else the host paths
+            P = self.config.num_products
+            if P > 1024 or len(self.classes) != P or not np.array_equal(self.classes, np.arange(P)):
+                return None
+            return dict(policy=_abi.RG_POLICY_LOGREG_FROZEN, policy_seed=self.config.random_seed, ouc=None,
+                        logreg=dict(coef_t=self.coef_t, intercept=self.intercept, classes=self.classes, select_randomly=True))
         return dict(policy=_abi.RG_POLICY_LOGREG_FROZEN, policy_seed=0, ouc=None,
                     logreg=dict(coef_t=self.coef_t, intercept=self.intercept, classes=self.classes))
 

@@ -30,7 +30,8 @@ __global__ void __launch_bounds__(kBlock) k_logreg_select(DevSim d, uint32_t t) 
             const bool is_org = i < n_o;
             slot = is_org ? cur_o[i] : cur_b[i - n_o];
             const uint32_t uidx = d.uid[slot];
-            need = d.lr_dirty[uidx] != 0;
+            need = d.lr_dirty[uidx] != 0 || d.lr_sample != 0;        // (sampled acts: a fresh draw for every event)
+            if (d.lr_sample && is_org) slot |= 0x80000000u;          // ... and the kernel must know which event the act is for
             if (need && is_org) {
                 // an organic user needs an act only for its phantom row: when this step's transition stops it — and, in run-ahead
                 // rounds, when the transition starts a bandit run (k_advance_run takes the user through it in this round)
@@ -46,6 +47,93 @@ __global__ void __launch_bounds__(kBlock) k_logreg_select(DevSim d, uint32_t t) 
         if (m && lane_id() == 0) base = atomicAdd(&d.lr_cnt[t], static_cast<uint32_t>(__popcll(m)));
         base = __shfl(static_cast<int>(base), 0);
         if (need) d.lr_list[base + prefix_in_mask(m)] = slot;
+    }
+}
+
+// RG_POLICY_LOGREG_FROZEN with select_randomly (logreg_ips.py:61-72): a wave per listed user — the class scores in float64 (scipy's
+// CSR x dense order: viewed products ascending, multiply then add, intercept last), softmax (exp(s - max) / sum), and
+// rng.choice(P, p = proba) = the first class whose normalised cumulative probability exceeds the event's second policy uniform; ps =
+// proba[action].  The sums here run in wave order (the reference: numpy's pairwise sum and sequential cumsum): 1e-16-level
+// deviations, as everywhere the float64 path follows numpy.  A bandit user whose drawn transition is `stop` gets its trailing
+// row's draw too (same probabilities, the uniform of event t + 1); an organic user listed because it stops: that draw only.
+__global__ void __launch_bounds__(kBlock) k_logreg_sample(DevSim d, uint32_t t) {
+    __shared__ double s_p[kBlock / 64][1024];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    double* pr = s_p[wv];
+    const uint32_t n = d.lr_cnt[t], C = d.lr_n;
+    const uint32_t waves_total = gridDim.x * (kBlock / 64);
+    unsigned long long c_acts = 0, c_rows = 0;
+    for (uint32_t w = blockIdx.x * (kBlock / 64) + wv; w < n; w += waves_total) {
+        const uint32_t entry = d.lr_list[w];
+        const bool org = (entry >> 31) != 0;
+        const uint32_t slot = entry & 0x7FFFFFFFu;
+        const uint32_t uidx = d.uid[slot];
+        const uint32_t user = static_cast<uint32_t>(d.first_user + uidx);
+        const hent_t* hr = hist_row(d, slot) + 1;
+        const uint32_t nd = h_cnt(hr[-1]);
+        c_acts += 1; c_rows += nd;
+        double mx = -INFINITY;
+        for (uint32_t c0 = 0; c0 < C; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            double sc = 0.0;
+            if (c < C) {
+                for (uint32_t i = 0; i < nd; ++i) {
+                    const hent_t x = hr[i];
+                    sc = __dadd_rn(sc, __dmul_rn(static_cast<double>(h_cnt(x)), d.lr_coef_t[static_cast<size_t>(h_prod(x)) * C + c]));
+                }
+                sc = __dadd_rn(sc, d.lr_intercept[c]);
+                pr[c] = sc;
+                mx = fmax(mx, sc);
+            }
+        }
+        mx = wave_max(mx);
+        double sum = 0.0;
+        for (uint32_t c0 = 0; c0 < C; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            if (c < C) { const double e = exp(pr[c] - mx); pr[c] = e; sum += e; }
+        }
+        sum = wave_sum(sum);
+        double tot = 0.0;
+        for (uint32_t c0 = 0; c0 < C; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            if (c < C) { const double p = pr[c] / sum; pr[c] = p; tot += p; }
+        }
+        tot = wave_sum(tot);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        auto pick = [&](double u, uint32_t* a_out, double* ps_out) {
+            double run = 0.0;
+            uint32_t a = C - 1;
+            for (uint32_t c0 = 0; c0 < C; c0 += 64) {
+                const uint32_t c = c0 + lane;
+                const double p = c < C ? pr[c] : 0.0;
+                const double incl = wave_scan(p, lane) + run;
+                const unsigned long long hit = __ballot(c < C && incl / tot > u);
+                if (hit) { a = c0 + static_cast<uint32_t>(__builtin_ctzll(hit)); break; }
+                run = __shfl(incl, 63);
+            }
+            *a_out = a; *ps_out = pr[a];
+        };
+        const uint32_t t_act = org ? t + 1 : t;
+        const rg_u32x4 wp = rg_draw(d.policy_seed, user, t_act, 0, RG_DRAW_POLICY);
+        uint32_t a; double ps;
+        pick(rg_uniform(wp.w[2], wp.w[3]), &a, &ps);
+        if (lane == 0) { d.lr_action[uidx] = a; d.lr_ps[uidx] = ps; d.lr_dirty[uidx] = 0; }
+        if (!org) {
+            const rg_u32x4 we = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
+            const double u_trans = rg_uniform(we.w[2], we.w[3]);
+            if ((d.cdf_b0 <= u_trans) + (d.cdf_b1 <= u_trans) == RG_STATE_STOP) {
+                const rg_u32x4 w2 = rg_draw(d.policy_seed, user, t + 1, 0, RG_DRAW_POLICY);
+                uint32_t a2; double ps2;
+                pick(rg_uniform(w2.w[2], w2.w[3]), &a2, &ps2);
+                if (lane == 0) { d.lr_action2[uidx] = a2; d.lr_ps2[uidx] = ps2; }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0 && c_acts) {
+        atomicAdd(&d.counters[RG_CNT_LR_ACTS], c_acts);
+        atomicAdd(&d.counters[RG_CNT_LR_ROWS], c_rows);
     }
 }
 
@@ -351,7 +439,7 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                     a = (ai < 0 || static_cast<uint32_t>(ai) >= d.P) ? 0u : static_cast<uint32_t>(ai);
                     ps = __builtin_nan("");
                 }
-                else if (d.policy == RG_POLICY_LOGREG_FROZEN) { a = lr_a; ps = 1.0; }
+                else if (d.policy == RG_POLICY_LOGREG_FROZEN) { a = lr_a; ps = d.lr_sample ? d.lr_ps[uidx] : 1.0; }
                 else a = policy_act(d, slot, user, t, &ps);
                 // beta[a] . omega, k ascending (the oracle's association); loads are issued eight
                 // k at a time — a plain loop leaves one HBM round trip per k on the critical path
@@ -432,7 +520,11 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                 if (d.policy != RG_POLICY_EXTERNAL) {
                     // final step_offline(done=True): one more act, reward 0 (abstract.py:223-233,311-316)
                     double ps = 1.0;
-                    const uint32_t a = d.policy == RG_POLICY_LOGREG_FROZEN ? lr_a : policy_act(d, slot, user, t + 1, &ps);
+                    uint32_t a;
+                    if (d.policy != RG_POLICY_LOGREG_FROZEN) a = policy_act(d, slot, user, t + 1, &ps);
+                    else if (!d.lr_sample) a = lr_a;
+                    else if (is_org) { a = lr_a; ps = d.lr_ps[uidx]; }                       // k_logreg_sample drew it for event t + 1
+                    else { a = d.lr_action2[uidx]; ps = d.lr_ps2[uidx]; }
                     rg_event e;
                     e.u = user; e.t = t + 1; e.code = RG_EV_BANDIT | RG_EV_PHANTOM | a;
                     e.ps = static_cast<float>(ps);
@@ -989,6 +1081,7 @@ search_kernel_t logreg_select_kernel() { return k_logreg_select; }
 search_kernel_t logreg_acts_kernel() { return k_logreg_acts; }
 search_kernel_t logreg_screen_kernel() { return k_logreg_screen; }
 search_kernel_t logreg_decide_kernel() { return k_logreg_decide; }
+search_kernel_t logreg_sample_kernel() { return k_logreg_sample; }
 advance_kernel_t advance_kernel() { return k_advance; }
 advance_run_kernel_t advance_run_kernel() { return k_advance_run; }
 round_rows_kernel_t round_rows_kernel() { return k_round_rows; }

@@ -229,6 +229,11 @@ struct DevSim {
     const float* lr_coef32_t; const float* lr_intercept32; const float* lr_wmax; float lr_bmax;   // fp32 copies + max_c |coef[p][c]|, max |b|
     const unsigned short* lr_coef16_t;   // fp16 copy of coef^T (screening pass of k_logreg_acts16), or null
     uint32_t* lr_action;      // [n_cap] by user index: action of the user's current history
+    // select_randomly (rg_config.lr_select_randomly): the act is SAMPLED per event from softmax(scores) — k_logreg_sample leaves the
+    // action and its probability for the step's bandit event (or, for an organic user that stops at this step, for its trailing
+    // row) in lr_action / lr_ps, and for a bandit user whose drawn transition is `stop` the trailing row's own draw in lr_action2 / lr_ps2
+    uint32_t lr_sample;
+    double* lr_ps; uint32_t* lr_action2; double* lr_ps2;
     uint8_t* lr_dirty;        // [n_cap] by user index
     uint32_t* lr_list;        // [n_cap] slots whose act is to be computed this step
     uint32_t* lr_cnt;         // [kMaxSteps + 2]
@@ -361,6 +366,7 @@ search_kernel_t logreg_select_kernel();
 search_kernel_t logreg_acts_kernel();
 search_kernel_t logreg_screen_kernel();
 search_kernel_t logreg_decide_kernel();
+search_kernel_t logreg_sample_kernel();
 advance_kernel_t advance_kernel();
 advance_run_kernel_t advance_run_kernel();
 round_rows_kernel_t round_rows_kernel();
@@ -587,6 +593,10 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint8_t* lr_dirty = w.take<uint8_t>(lr ? n : 1);
     uint32_t* lr_list = w.take<uint32_t>(lr ? n : 1);
     uint32_t* lr_cnt = w.take<uint32_t>(lr ? kMaxSteps + 2 : 1);
+    const bool lrs = lr && c.lr_select_randomly;
+    double* lr_ps = w.take<double>(lrs ? n : 1);
+    uint32_t* lr_action2 = w.take<uint32_t>(lrs ? n : 1);
+    double* lr_ps2 = w.take<double>(lrs ? n : 1);
     // the screen's scratch: a row per act of a STEP, not per user — a step lists the users whose history changed and who act now
     // (a quarter of the organic users at the default transition matrix); what a step lists beyond the rows goes through k_logreg_acts
     const size_t lr_part_cap = lr ? (n / 2 + 4096 < n ? n / 2 + 4096 : n) : 0;
@@ -615,6 +625,7 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
         d->park_list = park_list; d->park_t = park_t; d->sweep_only = 0;
         d->walk_ctl = walk_ctl; d->step1_buf = step1_buf;
         d->walk_hot = cache ? walk_hot : nullptr; d->walk_scp = walk_scp;
+        d->lr_ps = lr_ps; d->lr_action2 = lr_action2; d->lr_ps2 = lr_ps2; d->lr_sample = lrs ? 1u : 0u;
         d->lr_action = lr_action; d->lr_dirty = lr ? lr_dirty : nullptr; d->lr_list = lr_list; d->lr_cnt = lr_cnt; d->lr_part = lr_part; d->lr_part_cap = static_cast<uint32_t>(lr_part_cap);
         d->uid = uid; d->omega_alt = omega_alt; d->hist_alt = hist_alt;
         d->lpv_alt = lpv_alt; d->uid_alt = uid_alt;
@@ -650,6 +661,8 @@ inline int validate(const rg_config* c, uint64_t n) {
     if (c->policy > RG_POLICY_LOGREG_FROZEN) return fail(RG_EINVAL, "unknown policy %u", c->policy);
     if (c->time_mode > 1) return fail(RG_EINVAL, "unknown time_mode %u", c->time_mode);
     if (c->env_kind > 1) return fail(RG_EINVAL, "unknown env_kind %u", c->env_kind);
+    if (c->lr_select_randomly && (c->policy != RG_POLICY_LOGREG_FROZEN || c->num_products > 1024))
+        return fail(RG_EINVAL, "lr_select_randomly needs RG_POLICY_LOGREG_FROZEN and at most 1024 products (a class per product)");
     if (c->env_kind == 1 && (c->time_mode || c->policy == RG_POLICY_LOGREG_FROZEN || c->policy == RG_POLICY_LAST_VIEW_TABLE))
         return fail(RG_EINVAL, "env_kind 1 (reco-gym-v0) runs the default clock and the uniform / random / organic-count / external policies");
     if (c->time_mode == 1 && !(c->time_sigma >= 0.0)) return fail(RG_EINVAL, "normal_time_sigma must be >= 0");

@@ -621,7 +621,9 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
     if (d.policy == RG_POLICY_LOGREG_FROZEN) {
         // acts of the users whose view history changed since their last one (frozen LogReg at scale)
         hipLaunchKernelGGL(logreg_select_kernel(), dim3(grid_for(upper)), dim3(kBlock), 0, st, d, t);
-        if (d.lr_coef16_t) {       // screen (a wave per act and class range), then decide (a wave per act)
+        if (d.lr_sample)           // select_randomly: a softmax and a draw per act (a wave each)
+            hipLaunchKernelGGL(logreg_sample_kernel(), dim3(grid_for(static_cast<uint64_t>(upper) + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
+        else if (d.lr_coef16_t) {       // screen (a wave per act and class range), then decide (a wave per act)
             hipLaunchKernelGGL(logreg_screen_kernel(), dim3(grid_for((static_cast<uint64_t>(upper) / 4 + 64) * kLrSplit, kBlock / 64)),
                                dim3(kBlock), 0, st, d, t);
             hipLaunchKernelGGL(logreg_decide_kernel(), dim3(grid_for(static_cast<uint64_t>(upper) / 4 + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
@@ -1181,6 +1183,7 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     s->lr_part_rows = d.lr_part_cap;
     if (const char* e = getenv("RECOGYM_LR_PART_CAP")) { const uint32_t v = static_cast<uint32_t>(atoi(e)); if (v < d.lr_part_cap) d.lr_part_cap = v; }
     if (const char* e = getenv("RECOGYM_ABLATE")) d.ablate = static_cast<uint32_t>(atoi(e));
+    if (d.lr_sample) s->run_ahead = 0;     // a sampled act per event: lock-step (k_advance_run reuses one act for a whole bandit run)
     if (d.env_kind) {
         // reco-gym-v0: no omega, no product sweep — the lock-step loop with its own draw kernel (k_draw_env0), nothing else
         d.use_mfma = 0; d.use_cache = 0; d.XNH = d.XNL = d.XRS = 0;
@@ -1361,6 +1364,8 @@ int rg_sim_set_logreg(rg_sim* sim, const double* d_coef_t, const double* d_inter
     if (!sim) return fail(RG_EINVAL, "sim is NULL");
     if (sim->d.policy != RG_POLICY_LOGREG_FROZEN) return fail(RG_ESTATE, "policy is not RG_POLICY_LOGREG_FROZEN");
     if (!d_coef_t || !d_intercept || !d_classes || n_classes == 0) return fail(RG_EINVAL, "NULL model array or no classes");
+    if (sim->d.lr_sample && n_classes != sim->d.P)
+        return fail(RG_EINVAL, "lr_select_randomly samples a PRODUCT from predict_proba: the model needs a class per product (%u classes, %u products)", n_classes, sim->d.P);
     sim->d.lr_coef_t = d_coef_t; sim->d.lr_intercept = d_intercept; sim->d.lr_classes = d_classes;
     sim->d.lr_n = n_classes;
     // a new model invalidates the optional copies of the old one (their shapes and bounds belong to it): set them again

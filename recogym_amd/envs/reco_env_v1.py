@@ -110,9 +110,10 @@ def device_policy_of(agent):
                     ouc=dict(select_randomly=cfg.select_randomly, epsilon=cfg.epsilon,
                              exploit_explore=cfg.exploit_explore,
                              reverse_pop=getattr(cfg, 'reverse_pop', False)))
-    if name == 'LogregMulticlassIpsAgent' and not getattr(cfg, 'select_randomly', False) \
+    if name == 'LogregMulticlassIpsAgent' \
             and getattr(agent, 'model', None) is not None and hasattr(agent.model, 'logreg'):
-        # the reference's own agent object with a built model: run its fitted arrays on the device
+        # the reference's own agent object with a built model: run its fitted arrays on the device (select_randomly: sampled
+        # there too where the model has a class per product and P <= 1024 — LogregFrozenAgent.device_policy decides)
         from ..agents.logreg_frozen import LogregFrozenAgent
         return LogregFrozenAgent.from_sklearn(cfg, agent.model.logreg).device_policy()
     return None

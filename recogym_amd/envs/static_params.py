@@ -142,7 +142,7 @@ def draw_tables(config):
 
 
 def make_rg_config(config, seed, policy=_abi.RG_POLICY_UNIFORM_ENV, policy_seed=None,
-                   ouc=None, env_kind=0):
+                   ouc=None, env_kind=0, lr_select_randomly=False):
     """Fill struct rg_config from an env Configuration (+ optional agent parameters).  env_kind = 1: reco-gym-v0 (no K, no
     omega: the fields of the latent-factor model are left at neutral values)."""
     cfg = _abi.RgConfig()
@@ -166,6 +166,7 @@ def make_rg_config(config, seed, policy=_abi.RG_POLICY_UNIFORM_ENV, policy_seed=
         cfg.time_sigma = 1.0
         return cfg
     cfg.K = int(config.K)
+    cfg.lr_select_randomly = int(bool(lr_select_randomly))
     cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     cfg.policy_seed = (int(seed) if policy_seed is None else int(policy_seed)) & 0xFFFFFFFFFFFFFFFF
     cdf = transition_cdf(transition_matrix(config))

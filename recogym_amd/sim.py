@@ -87,10 +87,12 @@ class Simulator:
         # env0: the dict draw_env0_tables(config) returns — reco-gym-v0 (env_kind = 1), every draw a table look-up
         self.env0 = env0
         self.rg_config = make_rg_config(config, config.random_seed + epoch, policy, policy_seed,
-                                        ouc, env_kind=1 if env0 is not None else 0)
+                                        ouc, env_kind=1 if env0 is not None else 0,
+                                        lr_select_randomly=bool(logreg and logreg.get('select_randomly')))
         self.policy = policy
         self.time_mode = int(self.rg_config.time_mode)
-        self.ps_float64 = (policy in (_abi.RG_POLICY_ORGANIC_USER_COUNT, _abi.RG_POLICY_LAST_VIEW_TABLE)
+        self.ps_float64 = ((policy in (_abi.RG_POLICY_ORGANIC_USER_COUNT, _abi.RG_POLICY_LAST_VIEW_TABLE)
+                            or bool(logreg and logreg.get('select_randomly')))
                            if ps_float64 is None else bool(ps_float64))
         self.keep_p_click = bool(p_click)
         host_tables = () if env0 is not None else (tables if tables is not None else draw_tables(config))
@@ -147,7 +149,7 @@ class Simulator:
                 _abi.check(self.lib.rg_sim_set_logreg(self._h, self.logreg[0].data_ptr(), self.logreg[1].data_ptr(),
                                                       self.logreg[2].data_ptr(), self.logreg[2].numel()),
                            'rg_sim_set_logreg')
-                if logreg.get('fp32', True):
+                if logreg.get('fp32', True) and not logreg.get('select_randomly'):
                     # fp32 copies for the certified fast scores (the float64 arrays stay the arbiter); bounds rounded up
                     w32 = self.logreg[0].to(torch.float32)
                     b32 = self.logreg[1].to(torch.float32)

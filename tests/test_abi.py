@@ -34,13 +34,13 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_config_struct_layout_matches_header(lib):
     # sizeof(rg_config): 2*4 + 2*8 + 6*8 + 2*8 + 2*4 + 4*4 + 8 + (2*4 + 2*8: time generator)
-    assert C.sizeof(_abi.RgConfig) == 144
+    assert C.sizeof(_abi.RgConfig) == 152
     assert C.sizeof(_abi.RgEvent) == 16
 
 
 def test_integration_stub_declares_the_current_config_struct():
     """The ctypes stub INTEGRATION.md shows a reference maintainer must declare struct rg_config exactly as the header
-    (and the package's own mirror) does: same fields, same order, same types, 144 bytes — a short struct would have
+    (and the package's own mirror) does: same fields, same order, same types, 152 bytes — a short struct would have
     the library read time_mode past its end."""
     md = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
     block = md[md.index('class RgConfig(C.Structure)'):]
@@ -48,7 +48,7 @@ def test_integration_stub_declares_the_current_config_struct():
     ns = {'C': C}
     exec(block, ns)
     stub = ns['RgConfig']
-    assert C.sizeof(stub) == C.sizeof(_abi.RgConfig) == 144
+    assert C.sizeof(stub) == C.sizeof(_abi.RgConfig) == 152
     assert [(n, C.sizeof(t)) for n, t in stub._fields_] == [(n, C.sizeof(t)) for n, t in _abi.RgConfig._fields_]
     assert [getattr(stub, n).offset for n, _ in stub._fields_] == [getattr(_abi.RgConfig, n).offset for n, _ in _abi.RgConfig._fields_]
     header = open(os.path.join(ROOT, 'include', 'recogym_hip.h')).read()

@@ -441,7 +441,7 @@ def test_with_ps_all_under_the_normal_time_generator_uses_the_event_index():
 
 def test_logreg_select_randomly_samples_like_the_reference():
     """LogregMulticlassIpsAgent with select_randomly=True (logreg_ips.py:61-66): the action is sampled from
-    predict_proba with the model's own rng.  Host form only (per-user path, HIP kernels underneath): reproduces the
+    predict_proba with the model's own rng.  Host form (per-user path, HIP kernels underneath) and device form: both reproduce the
     log of the unmodified reference (its fitted model travels with the fixture, its draw injected as the addressed
     policy draw) — actions exactly, `ps` = the sampled class's probability to 1e-12."""
     from recogym_amd.agents import LogregFrozenAgent
@@ -449,14 +449,20 @@ def test_logreg_select_randomly_samples_like_the_reference():
     cfg = Configuration({'num_products': meta['env_args']['num_products'], 'random_seed': meta['agent_args']['random_seed'],
                          'select_randomly': True, 'with_ps_all': False})
     agent = LogregFrozenAgent(cfg, want['logreg_coef'], want['logreg_intercept'], want['logreg_classes'])
-    assert agent.device_policy() is None
     n = 30
-    df = make_env(meta['env_args']).generate_logs(n, agent)
     keep = want['u'] < n
-    cols = frame_to_cols(df)
+    # the host form (one user at a time) ...
+    cols = frame_to_cols(make_env(meta['env_args'])._generate_logs_per_user(n, agent, 0))
     for k in ('t', 'u', 'z', 'v', 'a', 'c'):
         assert np.array_equal(cols[k], want[k][keep].astype(np.int64)), k
     np.testing.assert_allclose(cols['ps'], want['ps'][keep], rtol=1e-12, equal_nan=True)
+    # ... and the device form (round 5: rg_config.lr_select_randomly, k_logreg_sample): the whole fixture
+    pol = agent.device_policy()
+    assert pol is not None and pol['logreg']['select_randomly']
+    cols = frame_to_cols(make_env(meta['env_args']).generate_logs(meta['n_users'], agent))
+    for k in ('t', 'u', 'z', 'v', 'a', 'c'):
+        assert np.array_equal(cols[k], want[k].astype(np.int64)), k
+    np.testing.assert_allclose(cols['ps'], want['ps'], rtol=1e-12, equal_nan=True)
 
 
 @pytest.mark.parametrize('name', ['hostpath_ouc_weight_history', 'hostpath_ouc_weight_history_eps'])

@@ -604,6 +604,28 @@ def test_frozen_logreg_with_more_than_256_classes_matches_the_oracle():
     assert (used >= classes[256]).any() and (used >= classes[512]).any()     # later class blocks do win
 
 
+@pytest.mark.parametrize('P', [10, 200, 1024])
+def test_sampled_frozen_logreg_matches_the_oracle(P):
+    """LogregMulticlassIps with select_randomly = True on the device (k_logreg_sample: softmax of the float64 class scores, the
+    event's second policy uniform against the cumulative probabilities, ps = the sampled class's probability; the trailing
+    row's own draw) against the oracle, which the reference's own log pins (tests/golden/hostpath_logreg_random.npz):
+    actions bit for bit, ps to 1e-12."""
+    from oracle import oracle as orc
+    rng = np.random.RandomState(P)
+    coef_t = rng.standard_normal((P, P)) * (1.5 if P <= 200 else 0.6)
+    intercept = rng.standard_normal(P) * 0.5
+    pol = dict(policy=_abi.RG_POLICY_LOGREG_FROZEN, policy_seed=77,
+               logreg=dict(coef_t=coef_t, intercept=intercept, classes=np.arange(P, dtype=np.int32), select_randomly=True))
+    cfg = Configuration({**env_1_args, 'random_seed': 600 + P, 'num_products': P, 'K': 8})
+    n = 400 if P < 1024 else 150
+    want_env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol)
+    want = want_env.generate_logs(n, 5)
+    rows, cnt = run_sim(cfg, n, 5, **pol)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps', 'p_click')}, ps_rtol=1e-12, what=f'sampled logreg P={P}')
+    assert (rows['phantom'] == want['phantom']).all()
+    assert len(np.unique(rows['a'][rows['z'] == 1])) > min(P, 20) // 2          # it does sample
+
+
 @pytest.mark.parametrize('screen', ['fp16', 'fp32', 'fp16_cap3'])
 def test_frozen_logreg_at_config_5_scale_matches_the_oracle(screen, monkeypatch):
     """BASELINE config 5's policy shape: one class per product, 4 096 products.  The act screens every class score from
