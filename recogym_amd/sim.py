@@ -133,7 +133,7 @@ class Simulator:
             if policy == _abi.RG_POLICY_LOGREG_FROZEN:
                 # dict(coef_t (P, C) float64 = sklearn coef_.T, intercept (C,), classes (C,))
                 n_fit = int(np.asarray(logreg['classes']).size)
-                if n_fit % 8 and logreg.get('fp16', True) and logreg.get('fp32', True):
+                if n_fit % 8 and logreg.get('fp16', True) and logreg.get('fp32', True) and not logreg.get('select_randomly'):
                     # the fp16 screening pass reads 8 classes per 16-byte load: pad with copies of the LAST class (same
                     # column, intercept and action: an exact tie with it, whichever of them wins the action is the same)
                     pad = 8 - n_fit % 8
