@@ -872,8 +872,48 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
         else if (n_b) do_ban = true;
         else if (n_o) do_org = true;
         else do_srch = true;
-        const uint32_t user = static_cast<uint32_t>(d.first_user + slot);
-        const rg_u32x4 w = rg_draw(d.seed, user, t, 0, RG_DRAW_EVENT);
+        // ---- helpers.  Inside a bandit run nothing an event reads moves (the view history, the last view, omega: sigma_omega = 0)
+        // and its draws are addressed by (user, t): the lanes that sit this bandit iteration out — empty, waiting for an organic
+        // iteration, a search or a click batch — take events t + 1 .. t + walk_helpers of the runs of the lanes that are in it
+        // ("owners"), without side effects.  A helper's event counts (its row is written, the owner moves past it) iff it is
+        // PLAIN — no click possible (uniform below kNoClickBelow), next state organic or bandit — and every event of the run
+        // before it, the owner's own included, was plain and stayed in the run; whatever else it finds is dropped and met again
+        // by the owner itself.  e_slot / e_t / e_lane: whose event this lane evaluates (its own unless it helps) ----
+        bool helper = false, owner = false;
+        uint32_t e_slot = slot, e_t = t, h_p = 0, h_e = 0;        // h_p: this lane's place among the dealt events (rank + h_e n_own)
+        int e_lane = lane;
+        uint32_t n_own = 0, n_help = 0;
+        if (do_ban && !do_clk && d.walk_helpers && d.walk_click_batch && !d.aux_pclick) {
+            owner = st == RG_STATE_BANDIT;
+            const bool idle = !(owner || st == kPhantom || (do_org && st == RG_STATE_ORGANIC));
+            const unsigned long long om_mask = __ballot(owner), id_mask = __ballot(idle);
+            n_own = static_cast<uint32_t>(__popcll(om_mask));
+            if (n_own && id_mask) {
+                n_help = min(static_cast<uint32_t>(__popcll(id_mask)), d.walk_helpers * n_own);
+                uint32_t* tab = reinterpret_cast<uint32_t*>(mboxf);             // [rank]{slot, t | lane << 24} (the search's mailbox: idle now)
+                if (owner) {
+                    h_p = prefix_in_mask(om_mask);
+                    tab[2 * h_p] = slot;
+                    tab[2 * h_p + 1] = t | (static_cast<uint32_t>(lane) << 24);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t i = prefix_in_mask(id_mask);
+                if (idle && i < n_help) {
+                    helper = true;
+                    h_e = 1u + (i >= n_own ? 1u : 0u) + (i >= 2u * n_own ? 1u : 0u);
+                    const uint32_t r = i - (h_e - 1u) * n_own;
+                    h_p = i + n_own;
+                    e_slot = tab[2 * r];
+                    const uint32_t tl = tab[2 * r + 1];
+                    e_t = (tl & 0xFFFFFFu) + h_e;
+                    e_lane = static_cast<int>(tl >> 24);
+                }
+            }
+        }
+        hent_t* const hle = reinterpret_cast<hent_t*>(wbase) + e_lane;      // that user's history line
+        const uint32_t user = static_cast<uint32_t>(d.first_user + e_slot);
+        const rg_u32x4 w = rg_draw(d.seed, user, e_t, 0, RG_DRAW_EVENT);
         bool have_v = false, parked = false;
         uint32_t v = 0;
         if (do_org) {
@@ -1168,8 +1208,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             park_next += np;
         }
         // =========================== bandit event: the policy's act and the click ===========================
-        bool is_ban = do_ban && (do_clk ? st == kWClick : st == RG_STATE_BANDIT);
-        const bool is_ph = do_ban && !do_clk && st == kPhantom;
+        bool is_ban = do_ban && (do_clk ? st == kWClick : (st == RG_STATE_BANDIT || helper));
+        const bool is_ph = do_ban && !do_clk && st == kPhantom && !helper;
         double ps = 1.0;
         uint32_t a = 0;
         bool click = false, click_known = false;
@@ -1181,10 +1221,10 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                 if (HIST == 2) {
                     // the same act on the COMPACT line (prefix form): the first product whose cumulative count exceeds u x views
                     // = the number of words below the key (Thi + 1) << 16 — the last word of each 8-word segment, then the segment
-                    const rg_u32x4 pw = rg_draw(d.policy_seed, user, t, 0, RG_DRAW_POLICY);
+                    const rg_u32x4 pw = rg_draw(d.policy_seed, user, e_t, 0, RG_DRAW_POLICY);
                     const double u1 = rg_uniform(pw.w[2], pw.w[3]);
-                    const hent_t* hr = hist_row(d, slot);
-                    const uint32_t* hw32 = reinterpret_cast<const uint32_t*>(hl);      // word w: hw32[(w >> 1) * 128 + (w & 1)]
+                    const hent_t* hr = hist_row(d, e_slot);
+                    const uint32_t* hw32 = reinterpret_cast<const uint32_t*>(hle);     // word w: hw32[(w >> 1) * 128 + (w & 1)]
                     const uint32_t h0 = hw32[0];
                     const uint32_t p7 = hw32[3 * 128 + 1], p15 = hw32[7 * 128 + 1], p23 = hw32[11 * 128 + 1], p31 = hw32[15 * 128 + 1];
                     const uint32_t nd = h0 & 0x7FFFu;
@@ -1198,7 +1238,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     uint32_t x[8];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const hent_t y = hl[(seg * 4 + j) * 64];
+                        const hent_t y = hle[(seg * 4 + j) * 64];
                         x[2 * j] = static_cast<uint32_t>(y); x[2 * j + 1] = static_cast<uint32_t>(y >> 32);
                     }
                     if (seg == 0u) x[0] = 0u;                                             // (the header: counted, prefix 0)
@@ -1260,12 +1300,12 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     // OrganicUserEventCounterModel.act (organic_user_count.py:45-96; exploit_explore, epsilon = 0,
                     // select_randomly: the host instantiates HIST = 1 for this form only) on the history line in LDS: decided
                     // by integer prefix counts outside a 2^-36 band (see policy_act), by the float64 cdf walk inside it
-                    const rg_u32x4 pw = rg_draw(d.policy_seed, user, t, 0, RG_DRAW_POLICY);
+                    const rg_u32x4 pw = rg_draw(d.policy_seed, user, e_t, 0, RG_DRAW_POLICY);
                     const double u1 = rg_uniform(pw.w[2], pw.w[3]);
-                    const hent_t h0 = hl[0];
+                    const hent_t h0 = hle[0];
                     const uint32_t nd = h_cnt(h0);
                     const double sum = static_cast<double>(h_prod(h0));
-                    const hent_t* hr = hist_row(d, slot);
+                    const hent_t* hr = hist_row(d, e_slot);
                     const double T = u1 * sum;
                     const uint32_t Thi = static_cast<uint32_t>(fmin(floor(T * (1.0 + 0x1p-36)), 4294967295.0));
                     const uint32_t Tlo = static_cast<uint32_t>(fmin(ceil(T * (1.0 - 0x1p-36)), 4294967295.0));
@@ -1276,7 +1316,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                         // with its two exits compiled to 15 dependent round trips and 30 branches
                         hent_t e[16];
 #pragma unroll
-                        for (int i = 1; i < 16; ++i) e[i] = hl[i * 64];
+                        for (int i = 1; i < 16; ++i) e[i] = hle[i * 64];
 #pragma unroll
                         for (int i = 1; i < 16; ++i) {
                             const bool in = static_cast<uint32_t>(i) <= nd;
@@ -1305,12 +1345,12 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                         // inside the band (~1e-10 of the acts): numpy's arithmetic — p_i = count_i / sum, cdf = cumsum(p) / last,
                         // first index with cdf > u1 — over the viewed products (zero entries add exactly 0.0)
                         double last = 0.0;
-                        for (uint32_t i = 1; i <= nd; ++i) last += static_cast<double>(h_cnt(i < 16 ? hl[i * 64] : hr[i])) / sum;
+                        for (uint32_t i = 1; i <= nd; ++i) last += static_cast<double>(h_cnt(i < 16 ? hle[i * 64] : hr[i])) / sum;
                         double acc = 0.0, pa = 0.0;
                         a = d.P - 1;
                         bool fnd = false;
                         for (uint32_t i = 1; i <= nd && !fnd; ++i) {
-                            const hent_t x = i < 16 ? hl[i * 64] : hr[i];
+                            const hent_t x = i < 16 ? hle[i * 64] : hr[i];
                             const double p = static_cast<double>(h_cnt(x)) / sum;
                             acc += p;
                             if (!(acc / last <= u1)) { a = h_prod(x); pa = p; fnd = true; }
@@ -1318,11 +1358,11 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                         ps = pa;
                     }
                 } else if (d.policy == RG_POLICY_LAST_VIEW_TABLE) {
-                    const uint32_t p = d.lpv[slot];
+                    const uint32_t p = d.lpv[e_slot];
                     ps = d.pol_ps ? static_cast<double>(d.pol_ps[p]) : 1.0;
                     a = static_cast<uint32_t>(d.pol_table[p]);
                 } else {        // agent = None / RandomAgent: uniform over P from the env / the agent stream
-                    const rg_u32x4 pw = rg_draw(d.policy_seed, user, t, 0, RG_DRAW_POLICY);
+                    const rg_u32x4 pw = rg_draw(d.policy_seed, user, e_t, 0, RG_DRAW_POLICY);
                     ps = 1.0 / static_cast<double>(d.P);
                     a = rg_bounded(pw.w[0], pw.w[1], d.P);
                 }
@@ -1344,7 +1384,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                 // no click below kNoClickBelow; the 3 % above it wait (kWClick) until walk_click_batch lanes of the wave do: the
                 // beta row is a memory round trip the whole wave would otherwise sit out in every bandit iteration
                 if (rg_uniform(w.w[0], w.w[1]) < kNoClickBelow) { click = false; click_known = true; }
-                else if (d.walk_click_batch) { st = kWClick; is_ban = false; }
+                else if (d.walk_click_batch) { if (!helper) st = kWClick; is_ban = false; }      // (a helper drops the event: not plain)
             }
             if (is_ban && !d.aux_pclick && !click_known) {
                 const int dec = click_decide32<KC>(d.beta32 + static_cast<size_t>(a) * d.KB4, [&](int k) { return om[k]; }, d.K, d.KB4,
@@ -1373,8 +1413,49 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             }
         }
         // =========================== the event's row, the view, the transition ===========================
-        const bool ev = have_v || is_ban;
-        const unsigned long long rowm = __ballot(ev);
+        const bool ev = have_v || is_ban;          // (a helper's: a candidate)
+        // the transition of every event (abstract.py:160-185), side effects below
+        int ns = RG_STATE_STOP;
+        bool limit = false, ended = false;
+        if (ev) {
+            const double u_trans = rg_uniform(w.w[2], w.w[3]);
+            const double c0 = have_v ? d.cdf_o0 : d.cdf_b0, c1 = have_v ? d.cdf_o1 : d.cdf_b1;
+            ns = (c0 <= u_trans) + (c1 <= u_trans);
+            if (click) ns = RG_STATE_ORGANIC;                  // abstract.py:180-181 (sigma_omega == 0: no drift to apply)
+            const bool organic_only = (d.first_user + e_slot) < d.organic_only_below;
+            if (organic_only && ns != RG_STATE_ORGANIC) { ns = RG_STATE_STOP; ended = true; }
+            else if (ns == RG_STATE_STOP) { ns = kPhantom; ended = true; }      // the phantom row's act: this lane's next bandit iteration
+            else if (e_t + 2 >= kMaxSteps) { ns = RG_STATE_STOP; ended = true; limit = true; }
+        }
+        // which of the helpers' events count, and how far each owner moves
+        bool counts = ev && !helper;
+        uint32_t adv = 0u;
+        if (n_help) {
+            unsigned char* fl = reinterpret_cast<unsigned char*>(mboxf) + 512;          // [place] bit 0: stayed in the run, bit 1: plain
+            const bool plain = is_ban && !click && !ended;                               // (next state organic or bandit)
+            const bool stays = plain && ns == RG_STATE_BANDIT;
+            if (owner || helper) fl[h_p] = static_cast<unsigned char>((stays ? 1u : 0u) | (plain ? 2u : 0u));
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (helper) {
+                bool ok = plain;
+#pragma unroll
+                for (uint32_t e2 = 1; e2 <= 3u; ++e2)                                    // the run's events before this one
+                    if (e2 <= h_e) ok = ok && (fl[h_p - e2 * n_own] & 1u) != 0u;
+                counts = ok;
+            } else if (owner && stays) {
+                bool alive = true;
+#pragma unroll
+                for (uint32_t e2 = 1; e2 <= 3u; ++e2) {
+                    const uint32_t pl = h_p + e2 * n_own;                                // (helper of idle rank pl - n_own)
+                    const uint32_t f = pl < n_own + n_help ? fl[pl] : 0u;
+                    const bool ok = alive && (f & 2u) != 0u;
+                    if (ok) { adv = e2; ns = (f & 1u) ? RG_STATE_BANDIT : RG_STATE_ORGANIC; }
+                    alive = ok && (f & 1u) != 0u;
+                }
+            }
+        }
+        const unsigned long long rowm = __ballot(counts);
         if (rowm) {
             const uint32_t nrow = static_cast<uint32_t>(__popcll(rowm));
             if (row_next + nrow > row_end) {
@@ -1388,9 +1469,9 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             }
             const uint64_t my_row = row_next + prefix_in_mask(rowm);
             row_next += nrow;
-            if (ev && d.log && my_row < d.log_cap && !RG_WALK_ABL(25)) {
+            if (counts && d.log && my_row < d.log_cap && !RG_WALK_ABL(25)) {
                 rg_event e;
-                e.u = user; e.t = t;
+                e.u = user; e.t = e_t;
                 e.code = have_v ? v : (RG_EV_BANDIT | (click ? RG_EV_CLICK : 0u) | a);
                 e.ps = have_v ? __builtin_nanf("") : static_cast<float>(ps);
                 d.log[my_row] = e;
@@ -1398,8 +1479,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                 if (is_ban && d.aux_pclick) d.aux_pclick[my_row] = ctr;
             }
             c_org += static_cast<uint32_t>(__popcll(__ballot(have_v)));
-            c_ban += static_cast<uint32_t>(__popcll(__ballot(is_ban)));
-            c_clicks += static_cast<uint32_t>(__popcll(__ballot(is_ban && click)));
+            c_ban += static_cast<uint32_t>(__popcll(__ballot(is_ban && counts)));
+            c_clicks += static_cast<uint32_t>(__popcll(__ballot(is_ban && click && counts)));
             if (have_v) {
                 if (d.lpv) d.lpv[slot] = v;
                 if (HIST == 2 && !RG_WALK_ABL(27)) {
@@ -1534,34 +1615,15 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     }
                 }
             }
-            if (ev) {
-                const double u_trans = rg_uniform(w.w[2], w.w[3]);
-                const double c0 = have_v ? d.cdf_o0 : d.cdf_b0, c1 = have_v ? d.cdf_o1 : d.cdf_b1;
-                int ns = (c0 <= u_trans) + (c1 <= u_trans);
-                if (click) ns = RG_STATE_ORGANIC;                  // abstract.py:180-181 (sigma_omega == 0: no drift to apply)
-                const bool organic_only = (d.first_user + slot) < d.organic_only_below;
-                bool limit = false;
-                if (organic_only && ns != RG_STATE_ORGANIC) {
-                    ns = RG_STATE_STOP;
+            if (ev && !helper) {
+                if (ended) {
                     d.n_events[slot] = t + 1;
-                } else if (ns == RG_STATE_STOP) {
-                    d.n_events[slot] = t + 1;
-                    ns = kPhantom;                                 // the phantom row's act: this lane's next bandit iteration
-                } else if (t + 2 >= kMaxSteps) {
-                    ns = RG_STATE_STOP;
-                    d.n_events[slot] = t + 1;
-                    limit = true;
-                }
-                const unsigned long long endm = __ballot(ns == RG_STATE_STOP || ns == kPhantom);
-                (void)endm;
-                if (ns == RG_STATE_STOP || ns == kPhantom) {
-                    // (maximum over the wave taken once at the end: a per-lane maximum in one register)
-                    c_maxt = max(c_maxt, t + 1);
+                    c_maxt = max(c_maxt, t + 1);       // (maximum over the wave taken once at the end: a per-lane maximum in one register)
                 }
                 if (limit) c_limit += 1;
                 flush_hist(ns == RG_STATE_STOP && hdirty);
                 if (ns == RG_STATE_STOP) st = kEmpty;
-                else { st = ns; t += 1; }
+                else { st = ns; t += 1u + adv; }       // (adv: the helpers' events of this run that count)
             }
         }
     }
