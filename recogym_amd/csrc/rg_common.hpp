@@ -123,7 +123,7 @@ struct DevSim {
     uint32_t walk_bias;       // k_walk: 0 = both event kinds every iteration; else one kind, organic when n_org * walk_bias >= n_bandit * 4
     uint32_t walk_click_batch;   // k_walk2: lanes waiting for ctr (kWClick) at which the wave takes them (0: in the bandit iteration itself)
     uint32_t walk_search_batch;  // k_walk2: lanes that missed the memo at which the wave runs the search (its chunk passes take 8 users each)
-    uint32_t walk_helpers;       // k_walk2: events of a bandit run its owner's lane may hand to the wave's idle lanes in one bandit iteration (0 .. 3)
+    uint32_t walk_helpers;       // k_walk2: events of a bandit run its owner's lane may hand to the wave's idle lanes in one bandit iteration (0 .. kWalkHelpersMax)
     uint32_t walk_line64;        // k_walk2 (host side: which instantiation): round 3's 64-bit history line of 15 products (RECOGYM_WALK_HIST=1)
     uint32_t exact_base;      // first exact_list entry of the batch being resolved
     uint32_t exact_last;      // this is the last batch launched for the step
@@ -2132,6 +2132,7 @@ __host__ __device__ inline size_t walk_wave_lds(uint32_t KH) { return static_cas
 // ------------------------------------------------------------------------------------------
 constexpr int kHotEntries = 9;          // memo entries of a user: floats [4 + 3 j, 7 + 3 j) of its hot row = {product, u_lo, u_hi}
 constexpr int kWSlow = 6;               // lane state: organic draw that missed the memo (RG_STATE_* = 0..2, empty 3, phantom 4)
+constexpr uint32_t kWalkHelpersMax = 7;  // k_walk2: events of a bandit run that idle lanes may take in one iteration (DevSim::walk_helpers)
 constexpr int kWClick = 7;              // lane state: bandit event whose click needs ctr (uniform >= kNoClickBelow): taken in batches
 __host__ __device__ inline size_t walk2_wave_lds(int hist) { return (hist ? 16 * 64 * 8 : 0) + 64 * 12; }
 // ------------------------------------------------------------------------------------------

@@ -1139,8 +1139,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     d.walk_click_batch = 8;
     if (const char* e = getenv("RECOGYM_WALK_CLICK_BATCH")) d.walk_click_batch = static_cast<uint32_t>(atoi(e));
     d.walk_search_batch = 16;
-    d.walk_helpers = 3;
-    if (const char* e = getenv("RECOGYM_WALK_HELPERS")) d.walk_helpers = static_cast<uint32_t>(atoi(e)) > 3u ? 3u : static_cast<uint32_t>(atoi(e));
+    d.walk_helpers = kWalkHelpersMax;
+    if (const char* e = getenv("RECOGYM_WALK_HELPERS")) d.walk_helpers = static_cast<uint32_t>(atoi(e)) > kWalkHelpersMax ? kWalkHelpersMax : static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_SEARCH_BATCH")) d.walk_search_batch = static_cast<uint32_t>(atoi(e)) ? static_cast<uint32_t>(atoi(e)) : 1u;
     if (const char* e = getenv("RECOGYM_WALK_REFILL")) d.walk_refill = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_BIAS")) d.walk_bias = static_cast<uint32_t>(atoi(e));
@@ -1149,7 +1149,10 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     if (const char* e = getenv("RECOGYM_WALK")) if (e[0] == '1') s->walk2 = false;
     // (k_walk2: 4 since the act is a count on the compact history line — the bandit iteration got shorter, so the organic kind
     // waits for more lanes: profiles/r4/ab_call6_walk_bias.jsonl; k_walk keeps round 2's 8)
-    if (s->walk2 && !getenv("RECOGYM_WALK_BIAS")) d.walk_bias = 4;
+    // (round 5, with helpers: a bandit iteration is full whatever the number of bandit lanes, so the organic kinds wait for
+    // more of theirs — bias 2, search batch 24: profiles/r5/ab_call18_walk_tuning.jsonl)
+    if (s->walk2 && !getenv("RECOGYM_WALK_BIAS")) d.walk_bias = d.walk_helpers ? 2 : 4;
+    if (s->walk2 && !getenv("RECOGYM_WALK_SEARCH_BATCH") && d.walk_helpers) d.walk_search_batch = 24;
     if (s->walk2) s->walk_occ = d.KH <= 10 ? 3 : 2;     // (what k_walk2 is compiled for: K <= 20 three blocks per CU, K <= 32 two)
     s->walk_solo = true;
     if (const char* e = getenv("RECOGYM_WALK_SOLO")) s->walk_solo = e[0] != '0';
@@ -1275,7 +1278,7 @@ int rg_sim_set_option(rg_sim* sim, const char* name, int64_t value) {
         if (!strcmp(name, "run_ahead") && value > 64) return fail(RG_EINVAL, "run_ahead must be <= 64 events");
         if (!strcmp(name, "run_ahead") && value && sim->d.env_kind) return fail(RG_EINVAL, "env_kind 1 (reco-gym-v0) runs lock-step (run_ahead = 0)");
         if (!strcmp(name, "walk_search_batch") && value < 1) value = 1;
-        if (!strcmp(name, "walk_helpers") && value > 3) return fail(RG_EINVAL, "walk_helpers must be in [0, 3]");
+        if (!strcmp(name, "walk_helpers") && value > kWalkHelpersMax) return fail(RG_EINVAL, "walk_helpers must be in [0, %u]", kWalkHelpersMax);
         if (!strcmp(name, "pipe_min_users") && value < 256) return fail(RG_EINVAL, "pipe_min_users must be >= 256");
         if (!strcmp(name, "lr_part_cap") && static_cast<uint64_t>(value) > sim->lr_part_rows)
             return fail(RG_EINVAL, "lr_part_cap can only be lowered (the workspace holds %u rows)", sim->lr_part_rows);

@@ -874,7 +874,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
         else do_srch = true;
         // ---- helpers.  Inside a bandit run nothing an event reads moves (the view history, the last view, omega: sigma_omega = 0)
         // and its draws are addressed by (user, t): the lanes that sit this bandit iteration out — empty, waiting for an organic
-        // iteration, a search or a click batch — take events t + 1 .. t + walk_helpers of the runs of the lanes that are in it
+        // iteration, a search or a click batch — take events t + 1 .. t + walk_helpers (<= kWalkHelpersMax) of the runs of the lanes that are in it
         // ("owners"), without side effects.  A helper's event counts (its row is written, the owner moves past it) iff it is
         // PLAIN — no click possible (uniform below kNoClickBelow), next state organic or bandit — and every event of the run
         // before it, the owner's own included, was plain and stayed in the run; whatever else it finds is dropped and met again
@@ -901,7 +901,9 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                 const uint32_t i = prefix_in_mask(id_mask);
                 if (idle && i < n_help) {
                     helper = true;
-                    h_e = 1u + (i >= n_own ? 1u : 0u) + (i >= 2u * n_own ? 1u : 0u);
+                    h_e = 1u;
+#pragma unroll
+                    for (uint32_t e2 = 1; e2 < kWalkHelpersMax; ++e2) h_e += i >= e2 * n_own ? 1u : 0u;
                     const uint32_t r = i - (h_e - 1u) * n_own;
                     h_p = i + n_own;
                     e_slot = tab[2 * r];
@@ -1440,13 +1442,13 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             if (helper) {
                 bool ok = plain;
 #pragma unroll
-                for (uint32_t e2 = 1; e2 <= 3u; ++e2)                                    // the run's events before this one
+                for (uint32_t e2 = 1; e2 <= kWalkHelpersMax; ++e2)                       // the run's events before this one
                     if (e2 <= h_e) ok = ok && (fl[h_p - e2 * n_own] & 1u) != 0u;
                 counts = ok;
             } else if (owner && stays) {
                 bool alive = true;
 #pragma unroll
-                for (uint32_t e2 = 1; e2 <= 3u; ++e2) {
+                for (uint32_t e2 = 1; e2 <= kWalkHelpersMax; ++e2) {
                     const uint32_t pl = h_p + e2 * n_own;                                // (helper of idle rank pl - n_own)
                     const uint32_t f = pl < n_own + n_help ? fl[pl] : 0u;
                     const bool ok = alive && (f & 2u) != 0u;
