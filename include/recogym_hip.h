@@ -164,7 +164,7 @@ int rg_sim_destroy(rg_sim* sim);
 /* Run-path tuning knobs by name (none changes a result or the workspace layout; the defaults are the measured optima, DESIGN.md
  * §4 / §9).  rg_sim_create takes their initial values from the RECOGYM_* environment variables of the same meaning (the A/B
  * tests' way in); after that the library never reads the environment on the run path.  Names: walk_bias, walk_refill,
- * walk_handover, walk_click_batch, walk_search_batch, walk_helpers (0 .. 7), walk_line64, pipe_groups, pipe_mode, pipe_occ1, pipe_occ2, pipe_xblocks,
+ * walk_handover, walk_click_batch, walk_search_batch, walk_helpers (0 .. 7), walk_click_join, walk_line64, pipe_groups, pipe_mode, pipe_occ1, pipe_occ2, pipe_xblocks,
  * pipe_min_users, exact_mix, exact_tile, resident_grid, slices (-1 = by population), sweep_prefix_off, tail_below,
  * repack_every, run_ahead (events a round of a run to the end may take a user through, 0 = an event per launch), lr_part_cap (acts
  * of a step the frozen-LogReg fp16 screen takes; can only be lowered), debug.

@@ -124,6 +124,7 @@ struct DevSim {
     uint32_t walk_click_batch;   // k_walk2: lanes waiting for ctr (kWClick) at which the wave takes them (0: in the bandit iteration itself)
     uint32_t walk_search_batch;  // k_walk2: lanes that missed the memo at which the wave runs the search (its chunk passes take 8 users each)
     uint32_t walk_helpers;       // k_walk2: events of a bandit run its owner's lane may hand to the wave's idle lanes in one bandit iteration (0 .. kWalkHelpersMax)
+    uint32_t walk_click_join;    // k_walk2: the click batch is taken inside a bandit iteration (1) or in an iteration of its own (0)
     uint32_t walk_line64;        // k_walk2 (host side: which instantiation): round 3's 64-bit history line of 15 products (RECOGYM_WALK_HIST=1)
     uint32_t exact_base;      // first exact_list entry of the batch being resolved
     uint32_t exact_last;      // this is the last batch launched for the step
@@ -1961,6 +1962,12 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* generic_ptr) {
 #define RG_F16W_ABL(bit) (d.ablate & (bit))
 #else
 #define RG_F16W_ABL(bit) (false)
+#endif
+#ifdef RG_WALK_TIMING
+// -DRG_WALK_TIMING: k_walk2's iterations by kind — [4 k + 0] iterations, [4 k + 1] lanes with an event of the kind, [4 k + 2] wave
+// cycles (s_memtime) spent in them; k = 0 memo-answered organic, 1 search, 2 bandit, 3 click batch; [16] helpers' events that
+// counted, [17] helpers dealt (tools/walk_kinds.py)
+static __device__ unsigned long long g_walk_stat[20];
 #endif
 #ifdef RG_F16W_TIMING
 // -DRG_F16W_TIMING: s_memtime per section of the tile loop, summed over wave 0 of every block (tools/wide_probe.py)

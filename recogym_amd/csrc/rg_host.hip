@@ -1140,6 +1140,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     if (const char* e = getenv("RECOGYM_WALK_CLICK_BATCH")) d.walk_click_batch = static_cast<uint32_t>(atoi(e));
     d.walk_search_batch = 16;
     d.walk_helpers = kWalkHelpersMax;
+    d.walk_click_join = 1;
+    if (const char* e = getenv("RECOGYM_WALK_CLICK_JOIN")) d.walk_click_join = e[0] != '0';
     if (const char* e = getenv("RECOGYM_WALK_HELPERS")) d.walk_helpers = static_cast<uint32_t>(atoi(e)) > kWalkHelpersMax ? kWalkHelpersMax : static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_WALK_SEARCH_BATCH")) d.walk_search_batch = static_cast<uint32_t>(atoi(e)) ? static_cast<uint32_t>(atoi(e)) : 1u;
     if (const char* e = getenv("RECOGYM_WALK_REFILL")) d.walk_refill = static_cast<uint32_t>(atoi(e));
@@ -1248,6 +1250,7 @@ uint32_t* opt_u32(rg_sim* s, const char* n) {
     if (!strcmp(n, "walk_search_batch")) return &s->d.walk_search_batch;
     if (!strcmp(n, "walk_line64")) return &s->d.walk_line64;
     if (!strcmp(n, "walk_helpers")) return &s->d.walk_helpers;
+    if (!strcmp(n, "walk_click_join")) return &s->d.walk_click_join;
     if (!strcmp(n, "pipe_min_users")) return &s->pipe_min_users;
     if (!strcmp(n, "tail_below")) return &s->tail_below;
     if (!strcmp(n, "repack_every")) return &s->repack_every;
@@ -1278,6 +1281,7 @@ int rg_sim_set_option(rg_sim* sim, const char* name, int64_t value) {
         if (!strcmp(name, "run_ahead") && value > 64) return fail(RG_EINVAL, "run_ahead must be <= 64 events");
         if (!strcmp(name, "run_ahead") && value && sim->d.env_kind) return fail(RG_EINVAL, "env_kind 1 (reco-gym-v0) runs lock-step (run_ahead = 0)");
         if (!strcmp(name, "walk_search_batch") && value < 1) value = 1;
+        if (!strcmp(name, "walk_click_join") && value > 1) return fail(RG_EINVAL, "walk_click_join is a flag (0 or 1)");
         if (!strcmp(name, "walk_helpers") && value > kWalkHelpersMax) return fail(RG_EINVAL, "walk_helpers must be in [0, %u]", kWalkHelpersMax);
         if (!strcmp(name, "pipe_min_users") && value < 256) return fail(RG_EINVAL, "pipe_min_users must be >= 256");
         if (!strcmp(name, "lr_part_cap") && static_cast<uint64_t>(value) > sim->lr_part_rows)

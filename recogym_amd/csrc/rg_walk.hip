@@ -722,11 +722,22 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
     // wave-uniform tallies (scalar registers): events are counted by ballots
     uint32_t c_org = 0, c_ban = 0, c_clicks = 0, c_ph = 0, c_pick = 0, c_sweeps = 0, c_maxt = 0, c_limit = 0, c_hit = 0, c_anch = 0;
     if (const unsigned long long* qc = ((const DevSim*)kargs)->q_count) n_work = static_cast<uint32_t>(*qc);   // (pipeline: the list's length is on the device)
+#ifdef RG_WALK_TIMING
+    unsigned long long wk_it[4] = {0, 0, 0, 0}, wk_ln[4] = {0, 0, 0, 0}, wk_cy[4] = {0, 0, 0, 0}, wk_hv = 0, wk_hd = 0, wk_t0 = __builtin_amdgcn_s_memtime();
+    int wk_kind = -1;
+#endif
 
     for (;;) {
         asm volatile("" : "+s"(kargs));
         const DevSim& d = *(const DevSim*)kargs;
         const uint32_t n_cc = d.PT / 64;
+#ifdef RG_WALK_TIMING
+        {
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();
+            if (wk_kind >= 0) wk_cy[wk_kind] += now_ - wk_t0;
+            wk_t0 = now_; wk_kind = -1;
+        }
+#endif
         // the view history is written back when the lane lets go of the user (stop, park, hand-over) or needs the row
         auto flush_hist = [&](bool c) {
             if (HIST == 2 && c) {
@@ -879,13 +890,20 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
         // PLAIN — no click possible (uniform below kNoClickBelow), next state organic or bandit — and every event of the run
         // before it, the owner's own included, was plain and stayed in the run; whatever else it finds is dropped and met again
         // by the owner itself.  e_slot / e_t / e_lane: whose event this lane evaluates (its own unless it helps) ----
+#ifdef RG_WALK_TIMING
+        wk_kind = do_srch ? 1 : do_clk ? 3 : do_ban ? 2 : 0;
+        wk_it[wk_kind] += 1;
+        wk_ln[wk_kind] += do_srch ? n_s : do_clk ? n_c : do_ban ? n_b : n_o;
+#endif
         bool helper = false, owner = false;
         uint32_t e_slot = slot, e_t = t, h_p = 0, h_e = 0;        // h_p: this lane's place among the dealt events (rank + h_e n_own)
         int e_lane = lane;
         uint32_t n_own = 0, n_help = 0;
-        if (do_ban && !do_clk && d.walk_helpers && d.walk_click_batch && !d.aux_pclick) {
+        // (walk_click_join: the click batch rides along in a bandit iteration instead of taking one of its own)
+        const bool ban_all = do_ban && (!do_clk || d.walk_click_join);      // the bandit lanes take part
+        if (ban_all && d.walk_helpers && d.walk_click_batch && !d.aux_pclick) {
             owner = st == RG_STATE_BANDIT;
-            const bool idle = !(owner || st == kPhantom || (do_org && st == RG_STATE_ORGANIC));
+            const bool idle = !(owner || st == kPhantom || (do_org && st == RG_STATE_ORGANIC) || (do_clk && st == kWClick));
             const unsigned long long om_mask = __ballot(owner), id_mask = __ballot(idle);
             n_own = static_cast<uint32_t>(__popcll(om_mask));
             if (n_own && id_mask) {
@@ -896,7 +914,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     tab[2 * h_p] = slot;
                     tab[2 * h_p + 1] = t | (static_cast<uint32_t>(lane) << 24);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                // (LDS instructions of a wave execute in order: only the compiler has to keep the order)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const uint32_t i = prefix_in_mask(id_mask);
                 if (idle && i < n_help) {
@@ -1210,8 +1229,9 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             park_next += np;
         }
         // =========================== bandit event: the policy's act and the click ===========================
-        bool is_ban = do_ban && (do_clk ? st == kWClick : (st == RG_STATE_BANDIT || helper));
-        const bool is_ph = do_ban && !do_clk && st == kPhantom && !helper;
+        const bool mine_clk = do_clk && st == kWClick && !helper;          // its uniform is known to be >= kNoClickBelow
+        bool is_ban = mine_clk || (ban_all && (st == RG_STATE_BANDIT || helper));
+        const bool is_ph = ban_all && st == kPhantom && !helper;
         double ps = 1.0;
         uint32_t a = 0;
         bool click = false, click_known = false;
@@ -1382,7 +1402,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             c_ph += static_cast<uint32_t>(__popcll(__ballot(is_ph)));
             if (is_ban && RG_WALK_ABL(24)) { click = false; click_known = true; }        // timing experiment: no beta row
             else
-            if (is_ban && !d.aux_pclick && !do_clk) {
+            if (is_ban && !d.aux_pclick && !mine_clk) {
                 // no click below kNoClickBelow; the 3 % above it wait (kWClick) until walk_click_batch lanes of the wave do: the
                 // beta row is a memory round trip the whole wave would otherwise sit out in every bandit iteration
                 if (rg_uniform(w.w[0], w.w[1]) < kNoClickBelow) { click = false; click_known = true; }
@@ -1437,7 +1457,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             const bool plain = is_ban && !click && !ended;                               // (next state organic or bandit)
             const bool stays = plain && ns == RG_STATE_BANDIT;
             if (owner || helper) fl[h_p] = static_cast<unsigned char>((stays ? 1u : 0u) | (plain ? 2u : 0u));
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (helper) {
                 bool ok = plain;
@@ -1457,6 +1477,10 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                 }
             }
         }
+#ifdef RG_WALK_TIMING
+        wk_hv += static_cast<unsigned long long>(__popcll(__ballot(helper && counts)));
+        wk_hd += n_help;
+#endif
         const unsigned long long rowm = __ballot(counts);
         if (rowm) {
             const uint32_t nrow = static_cast<uint32_t>(__popcll(rowm));
@@ -1629,6 +1653,12 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             }
         }
     }
+#ifdef RG_WALK_TIMING
+    if (lane == 0) {
+        for (int k = 0; k < 4; ++k) { atomicAdd(&g_walk_stat[4 * k], wk_it[k]); atomicAdd(&g_walk_stat[4 * k + 1], wk_ln[k]); atomicAdd(&g_walk_stat[4 * k + 2], wk_cy[k]); }
+        atomicAdd(&g_walk_stat[16], wk_hv); atomicAdd(&g_walk_stat[17], wk_hd);
+    }
+#endif
     // ---- leftovers of the reserved chunks, counters ----
     {
         const DevSim& d = *(const DevSim*)kargs;
@@ -2077,3 +2107,12 @@ walk_kernel_t walk_kernel_for(const DevSim& d, int occ) {
 }
 
 }  // namespace rgk
+
+#ifdef RG_WALK_TIMING
+// (in this unit: g_walk_stat is a per-unit static)
+extern "C" void rg_debug_walk_kinds(unsigned long long* out, int clear) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(rgk::g_walk_stat), sizeof(unsigned long long) * 20);
+    if (clear) { unsigned long long z[20] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(rgk::g_walk_stat), z, sizeof(z)); }
+}
+#endif
