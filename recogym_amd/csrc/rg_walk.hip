@@ -791,6 +791,10 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
         {
             unsigned long long dead = __ballot(st == kEmpty);
             if (dead && !exhausted && (static_cast<uint32_t>(__popcll(dead)) >= d.walk_refill || dead == ~0ull)) {
+                // the lines of the users these lanes let go of (stop, phantom row, park), all at once: a write-back per stop
+                // ran in ~40 % of the iterations for one or two lanes
+                flush_hist(st == kEmpty && hdirty);
+                hdirty = hdirty && st != kEmpty;
                 for (int pass = 0; pass < 2 && dead; ++pass) {
                     if (res_next == res_end) {
                         if (exhausted) break;
@@ -845,9 +849,9 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             }
         }
         const unsigned long long live = __ballot(st != kEmpty);
-        if (!live) { if (exhausted) break; else continue; }
-        // ---- hand-over (see k_walk) ----
-        if (exhausted && round < 3 && d.walk_handover && static_cast<uint32_t>(__popcll(live)) <= d.walk_handover) {
+        if (!live && !exhausted) continue;
+        // ---- hand-over (see k_walk); the wave's end: the lines still waiting for their write-back (one copy of that code) ----
+        if (!live || (exhausted && round < 3 && d.walk_handover && static_cast<uint32_t>(__popcll(live)) <= d.walk_handover)) {
             const bool give = st != kEmpty;
             const unsigned long long gm = __ballot(give);
             const uint32_t np = static_cast<uint32_t>(__popcll(gm));
@@ -858,7 +862,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                 base = __builtin_amdgcn_readfirstlane(base);
                 park_next = base; park_end = base + 64;
             }
-            flush_hist(give && hdirty);
+            flush_hist(hdirty);                  // (the users handed over and the lines of lanes that are already empty)
             if (give) {
                 d.park_list[out_base + park_next + prefix_in_mask(gm)] = slot;
                 const int st_out = st == kWSlow ? RG_STATE_ORGANIC : st == kWClick ? RG_STATE_BANDIT : st;     // (they restart at the memo check / the act)
@@ -1224,8 +1228,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                 base = __builtin_amdgcn_readfirstlane(base);
                 park_next = base; park_end = base + 64;
             }
-            flush_hist(parked && hdirty);
-            if (parked) { d.park_list[out_base + park_next + prefix_in_mask(pmask)] = slot; st = kEmpty; }
+            if (parked) { d.park_list[out_base + park_next + prefix_in_mask(pmask)] = slot; st = kEmpty; }      // (its line: written back at the refill)
             park_next += np;
         }
         // =========================== bandit event: the policy's act and the click ===========================
@@ -1398,7 +1401,6 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                 d.has_phantom[slot] = 1;
                 st = kEmpty;
             }
-            flush_hist(is_ph && hdirty);
             c_ph += static_cast<uint32_t>(__popcll(__ballot(is_ph)));
             if (is_ban && RG_WALK_ABL(24)) { click = false; click_known = true; }        // timing experiment: no beta row
             else
@@ -1521,34 +1523,40 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     }
                     const uint32_t h0 = e[0];
                     const uint32_t nd = h0 & 0x7FFFu;
-                    uint32_t pos = 1;                       // first entry with product >= v (min(nd, 31) + 1 if none)
-                    bool hit = false;
+                    // first entry with product >= v (min(nd, 31) + 1 if none: an unused word holds 0xFFFF, above every product);
+                    // the products ascend, so v is in the line iff it is the product of that entry (one more look at the line)
+                    uint32_t pos = 1;
 #pragma unroll
-                    for (int i = 1; i < static_cast<int>(kHcLine); ++i) {
-                        const uint32_t pl = e[i] & 0xFFFFu;                   // (an unused word: 0xFFFF, above every product)
-                        pos += pl < v ? 1u : 0u;
-                        hit = hit || pl == v;
-                    }
+                    for (int i = 1; i < static_cast<int>(kHcLine); ++i) pos += static_cast<uint16_t>(e[i]) < static_cast<uint16_t>(v) ? 1u : 0u;
                     uint32_t* hw32 = reinterpret_cast<uint32_t*>(hl);           // word w of this lane's line: hw32[(w >> 1) * 128 + (w & 1)]
+                    const uint32_t wp = pos < kHcLine ? hw32[(pos >> 1) * 128u + (pos & 1u)] : 0xFFFFFFFFu;
+                    const bool hit = (wp & 0xFFFFu) == v;
                     const bool room = nd < kHcLine - 1u;
                     if (hit || room) {
                         const bool full = !hit && nd + 1 >= d.hist_cap;
                         if (full) atomicAdd(&d.counters[RG_CNT_HIST_OVERFLOW], 1ull);
-                        // new word i: below pos unchanged; at pos the product's own (raised, or new: the prefix before it + 1);
-                        // above it the old word (hit) or the old word below (new product), raised by the view
-                        uint32_t f[kHcLine];
-                        f[0] = full ? h0 : h0 + (1u << 15) + (hit ? 0u : 1u);
-                        const uint32_t last = hit ? nd : nd + 1u;              // entries in use after the view
+                        // new word i: below pos unchanged; from pos on raised by the view (a repeat view), or — a new product —
+                        // the old word below it raised (entries pos + 1 .. nd + 1; its own word is written last).  Which words
+                        // are raised / shifted: two bit masks per lane, two instructions per word each
+                        const uint32_t last = min(hit ? nd : nd + 1u, kHcLine - 1u);          // last entry of the line in use after the view
+                        const uint32_t upto = 0xFFFFFFFFu >> (31u - last), from = 0xFFFFFFFFu << pos;      // (pos <= 31 here)
+                        const uint32_t shifted = (full || hit) ? 0u : (upto & (from << 1));
+                        const uint32_t raised = full ? 0u : (hit ? (upto & from) : shifted);
+                        auto word = [&](int i) -> uint32_t {
+                            if (i == 0) return full ? h0 : h0 + (1u << 15) + (hit ? 0u : 1u);
+                            const uint32_t x = ((shifted >> i) & 1u) ? e[i - 1] : e[i];
+                            return x + (((raised >> i) & 1u) << 16);
+                        };
 #pragma unroll
-                        for (int i = 1; i < static_cast<int>(kHcLine); ++i) {
-                            const uint32_t ui = static_cast<uint32_t>(i);
-                            const uint32_t below = i == 1 ? 0u : e[i - 1];
-                            const uint32_t src = hit ? e[i] : (ui == pos ? ((below & 0xFFFF0000u) | v) : below);
-                            const uint32_t raised = src + 0x10000u;
-                            f[i] = (full || ui < pos) ? e[i] : (ui <= last ? raised : 0xFFFFFFFFu);
+                        for (int i = 15; i >= 0; --i) {       // (from the top: word i reads e[i - 1], nothing above it)
+                            const uint32_t f0 = word(2 * i), f1 = word(2 * i + 1);
+                            hl[i * 64] = static_cast<hent_t>(f0) | (static_cast<hent_t>(f1) << 32);
                         }
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) hl[i * 64] = static_cast<hent_t>(f[2 * i]) | (static_cast<hent_t>(f[2 * i + 1]) << 32);
+                        if (!hit && !full) {
+                            // the new product's own word: the prefix of the entry before it (unchanged above; 0 before the first) + 1
+                            const uint32_t wq = pos > 1u ? hw32[((pos - 1u) >> 1) * 128u + ((pos - 1u) & 1u)] : 0u;
+                            hw32[(pos >> 1) * 128u + (pos & 1u)] = ((wq & 0xFFFF0000u) + 0x10000u) | v;
+                        }
                         hdirty = true;
                     } else if (v > (e[kHcLine - 1] & 0xFFFFu)) {
                         // a longer history, v behind the line's 31 products: entries >= 32 of the row (always current), the
@@ -1647,8 +1655,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     c_maxt = max(c_maxt, t + 1);       // (maximum over the wave taken once at the end: a per-lane maximum in one register)
                 }
                 if (limit) c_limit += 1;
-                flush_hist(ns == RG_STATE_STOP && hdirty);
-                if (ns == RG_STATE_STOP) st = kEmpty;
+                if (ns == RG_STATE_STOP) st = kEmpty;        // (its line is written back when the lane is refilled, or at the end)
                 else { st = ns; t += 1u + adv; }       // (adv: the helpers' events of this run that count)
             }
         }
