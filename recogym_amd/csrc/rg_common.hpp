@@ -2141,7 +2141,7 @@ constexpr int kHotEntries = 9;          // memo entries of a user: floats [4 + 3
 constexpr int kWSlow = 6;               // lane state: organic draw that missed the memo (RG_STATE_* = 0..2, empty 3, phantom 4)
 constexpr uint32_t kWalkHelpersMax = 7;  // k_walk2: events of a bandit run that idle lanes may take in one iteration (DevSim::walk_helpers)
 constexpr int kWClick = 7;              // lane state: bandit event whose click needs ctr (uniform >= kNoClickBelow): taken in batches
-__host__ __device__ inline size_t walk2_wave_lds(int hist) { return (hist ? 16 * 64 * 8 : 0) + 64 * 12; }
+__host__ __device__ inline size_t walk2_wave_lds(int hist) { return (hist ? 16 * 64 * 8 : 0) + 64 * 12 + 64; }   // history lines, the search's mailbox (the helpers' tables), the search's lane list
 // ------------------------------------------------------------------------------------------
 // k_walk_solo — the LAST round of the user-major walk: a WAVE per user, a LANE per consecutive event.
 //

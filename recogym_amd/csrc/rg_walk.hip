@@ -998,7 +998,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     const float xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (xs[q] <= tauf) { sc_star += 1; pbf = fmaxf(pbf, xs[q]); }
+                        { const bool le = xs[q] <= tauf; sc_star += le ? 1u : 0u; pbf = le ? xs[q] : pbf; }      // (prefixes ascend: the last one <= tau is the largest)
                 }
             }
             bool found = sc_star < d.n_sc;
@@ -1019,7 +1019,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                         const float xs[4] = {w4[i].x, w4[i].y, w4[i].z, w4[i].w};
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (xs[q] <= tauf) { cnt += 1; pbf = fmaxf(pbf, xs[q]); }
+                            { const bool le = xs[q] <= tauf; cnt += le ? 1u : 0u; pbf = le ? xs[q] : pbf; }
                     }
                 }
                 found = found && cnt < c1 - c0;
@@ -1032,16 +1032,17 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             // prefix before it, the prefix with it}, or {-1, chunk total, chunk total} ----
             auto chunk_pass = [&](bool want, uint32_t chunk, float rem_f) {
                 const int grp = lane >> 3, gl = lane & 7;
-                unsigned long long todo = __ballot(want);
-                while (todo) {
-                    int src = -1;
-#pragma unroll
-                    for (int g = 0; g < 8; ++g) {
-                        const int bit = todo ? __builtin_ctzll(todo) : -1;
-                        if (g == grp) src = bit;
-                        if (todo) todo &= todo - 1;
-                    }
-                    const bool has = src >= 0;
+                // which lanes want it, in lane order, as a list in LDS: group g of pass p serves entry 8 p + g (picking the next
+                // eight set bits of the ballot one by one was ~75 instructions per pass)
+                const unsigned long long want_m = __ballot(want);
+                const uint32_t n_want = static_cast<uint32_t>(__popcll(want_m));
+                unsigned char* wlist = reinterpret_cast<unsigned char*>(mboxf) + 64 * 12;
+                if (want) wlist[prefix_in_mask(want_m)] = static_cast<unsigned char>(lane);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t wbase_i = 0; wbase_i < n_want; wbase_i += 8) {
+                    const bool has = wbase_i + static_cast<uint32_t>(grp) < n_want;
+                    const int src = has ? static_cast<int>(wlist[wbase_i + grp]) : -1;
                     const int s2 = has ? src : 0;
                     const uint32_t cs = static_cast<uint32_t>(__shfl(static_cast<int>(chunk), s2));
                     const float Qs = __shfl(Q, s2);
