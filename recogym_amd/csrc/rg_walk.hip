@@ -1285,7 +1285,9 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     uint32_t c_f = (w_at >> 16) - (idx >= 2u ? (w_prev >> 16) : 0u);
                     a = w_at & 0xFFFFu;
                     uint32_t C = p31 >> 16;                                              // (nd >= 31: the line's last prefix)
-                    for (uint32_t base = kHcLine; base <= nd && !found; base += kHistRegs) {      // longer histories: from the row
+                    // (a helper leaves a history beyond the line to its owner: with 64 lanes evaluating, half the iterations had
+                    // some lane in this loop)
+                    for (uint32_t base = kHcLine; base <= nd && !found && !helper; base += kHistRegs) {      // longer histories: from the row
                         hent_t f[kHistRegs];
                         hist_load_line(hr + base, f);
 #pragma unroll
@@ -1297,6 +1299,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                             }
                     }
                     if (found && !amb) ps = static_cast<double>(c_f) / sum;
+                    else if (helper) is_ban = false;      // (dropped: not plain)
                     else {
                         // inside the band (~1e-10 of the acts): numpy's arithmetic over the viewed products, as below
                         auto ent = [&](uint32_t i, uint32_t* prev) -> hent_t {       // (product, count) of entry i, walked in order
@@ -1355,7 +1358,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                             found = found || take;
                         }
                     }
-                    for (uint32_t base = 16; base <= nd && !found; base += kHistRegs) {      // longer histories: from the row
+                    for (uint32_t base = 16; base <= nd && !found && !helper; base += kHistRegs) {      // longer histories: from the row
                         hent_t f[kHistRegs];
                         hist_load_line(hr + base, f);
 #pragma unroll
@@ -1367,6 +1370,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                             }
                     }
                     if (found && !amb) ps = static_cast<double>(c_f) / sum;
+                    else if (helper) is_ban = false;      // (dropped: not plain)
                     else {
                         // inside the band (~1e-10 of the acts): numpy's arithmetic — p_i = count_i / sum, cdf = cumsum(p) / last,
                         // first index with cdf > u1 — over the viewed products (zero entries add exactly 0.0)
