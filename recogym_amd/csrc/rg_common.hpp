@@ -57,6 +57,13 @@
 // unit); a unit hands its kernels to the host code through the *_kernel_for functions declared here.
 #pragma once
 
+// RG_WALK_PRECISE_CHUNK = 1 (default): the walk behind k_sweep_xh recomputes a draw's chunk as a float64 dot (one budget delta for
+// sweep and recomputed terms); -DRG_WALK_PRECISE_CHUNK=0: in plain fp32 with its own in-chunk budget delta_c (cert_correlated,
+// hot_budgets) — measured a tie on C3 (walk -1.0 ms, 4 % more parked users: +0.4 ms of float64 batch; profiles/r5/ab_call27.jsonl)
+#ifndef RG_WALK_PRECISE_CHUNK
+#define RG_WALK_PRECISE_CHUNK 1
+#endif
+
 namespace rgk {
 
 constexpr uint32_t kMaxSteps = 1u << 16;       // P(a user survives that long) ~ exp(-650)
@@ -1516,17 +1523,30 @@ struct CertLin { double num_lo, den_lo, num_hi, den_hi; bool valid; };
 // each, 2^-23 (kRhoTight) where each is ONE rounding of a float64 sum (k_sweep_xh); the hot row carries it per user.
 constexpr float kRhoLoose = 9.5463e-7f;    // 2^-20 x 1.001 (.001: second-order terms and the float64 roundings of the test)
 constexpr float kRhoTight = 1.1933e-7f;    // 2^-23 x 1.001
-__device__ __forceinline__ CertLin cert_correlated(double S, double A, double a, double b, double delta, double rho_rel = static_cast<double>(kRhoLoose)) {
+// delta_c (< 0: = delta): the budget of the RECOMPUTED in-chunk prefixes a, b where it differs from the sweep terms' — the walk
+// behind k_sweep_xh recomputes a chunk in plain fp32 (delta_c ~ 7e-5) against sweep terms good to ~1e-5: a and b are a chunk's
+// worth of mass, A and T the whole table's, so the looser in-chunk budget widens the band by ~3 % (tools: DESIGN.md §2 "Round 5").
+__device__ __forceinline__ CertLin cert_correlated(double S, double A, double a, double b, double delta, double rho_rel = static_cast<double>(kRhoLoose),
+                                                   double delta_c = -1.0) {
     const double dp = delta * (1.0 + 2.0 * delta);         // >= delta / (1 - delta) for delta <= 1/2
+    const double dc = delta_c < 0.0 ? dp : delta_c * (1.0 + 2.0 * delta_c);
     const double rho = rho_rel * S;
     const double T = S - A;                                // exact: both are fp32 values
     CertLin c;
-    c.valid = T >= 0.0 && delta < 0.25;
-    c.num_lo = (A + a) * (1.0 + dp) + rho;
+    c.valid = T >= 0.0 && delta < 0.25 && delta_c < 0.25;
+    c.num_lo = A * (1.0 + dp) + a * (1.0 + dc) + rho;
     c.den_lo = T * (1.0 - dp) + A * (1.0 + dp);
-    c.num_hi = (A + b) * (1.0 - dp) - rho;
+    c.num_hi = A * (1.0 - dp) + b * (1.0 - dc) - rho;
     c.den_hi = T * (1.0 + dp) + A * (1.0 - dp);
     return c;
+}
+// Float 31 of a user's hot row: rho_rel (2^-20 / 2^-23: the in-chunk budget is delta itself), or — a value >= kHotDcMin — the
+// in-chunk budget delta_c of a user k_sweep_xh finalised (its stored prefixes are single roundings: rho_rel = 2^-23)
+constexpr float kHotDcMin = 4.0e-6f;
+__device__ __forceinline__ void hot_budgets(float r31, double delta, double* rho_rel, double* delta_c) {
+    const bool has_dc = r31 >= kHotDcMin;
+    *rho_rel = has_dc ? static_cast<double>(kRhoTight) : static_cast<double>(r31);
+    *delta_c = has_dc ? static_cast<double>(r31) : delta;
 }
 
 __device__ __forceinline__ float wave_scan_f32(float x, int lane) {
@@ -1870,8 +1890,8 @@ __device__ __forceinline__ bool xh_eligible(double Ahat, double qabs) {
 }
 // delta of a user swept by k_sweep_xh<.., NL>: Ahat (natural units), absw = sum |omega_k|, egam = sum_k |omega_k| x
 // (column k's representation error of Gamma'), lob = bound on the sum of the residual accumulator's |terms| (log2 units,
-// unscaled), qabs = the largest |reference| used.  The larger of what the SWEEP's terms and the walk's RECOMPUTED terms
-// (float64 dot of the fp32 tables, exp2 of the fp32-rounded argument: rg_walk.hip chunk_pass) can be off by.
+// unscaled), qabs = the largest |reference| used.  What the SWEEP's terms can be off by (the walk's recomputed in-chunk terms
+// have their own budget: xh_delta_chunk).
 template <int NL>
 __device__ __forceinline__ double xh_delta(const DevSim& d, double Ahat, double absw, double egam, double lob, double qabs) {
     constexpr double e24 = 5.9604644775390625e-08, ln2 = 0.6931471805599453, log2e = 1.4426950408889634;
@@ -1884,8 +1904,19 @@ __device__ __forceinline__ double xh_delta(const DevSim& d, double Ahat, double 
     const double e_drop = static_cast<double>(d.K) * 4.0e-9;
     (void)absw;
     const double sweep = ln2 * (egam + e_drop + e_lo + e_x) + kDeltaFixedXh;
+#if RG_WALK_PRECISE_CHUNK
+    // (the walk's recomputed terms share delta: a float64 dot of the fp32 tables, exp2 of the fp32-rounded argument)
     const double rec = e24 * (3.0 * Ahat + ln2 * qabs) * 1.01 + kDeltaFixedXh;
     return sweep > rec ? sweep : rec;
+#else
+    return sweep;
+#endif
+}
+// The in-chunk budget of those users: the walk recomputes the draw's chunk in plain fp32 from the fp32 tables (K fused
+// multiply-adds on partial sums <= Ahat, the referenced exp2 argument, exp2, <= 12 adds) — the accumulation budget of the
+// fp32 / split kernels, which covers it with room to spare ((K + 5) 2^-24 Ahat + 1e-5 + the split's own terms)
+__device__ __forceinline__ double xh_delta_chunk(const DevSim& d, double Ahat, double absw) {
+    return static_cast<double>(d.K + 5) * 5.9604644775390625e-08 * Ahat + kDeltaFixedBf16 + f16_extra_delta(d, static_cast<float>(Ahat), static_cast<float>(absw));
 }
 
 // Tile DMA the compiler does not see.  hipcc puts s_waitcnt vmcnt(0) in front of the first ds_read

@@ -467,7 +467,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) k_sweep_xh(DevSim d,
             for (int k = ((2 * KH) / 4) * 4; k < 2 * KH; ++k) reinterpret_cast<float*>(row4)[44 + k] = ou[k];
             float* hot = d.walk_hot + urow * 32;
             *reinterpret_cast<float4*>(hot) = make_float4(static_cast<float>(run_pref), dlt * 1.000001f, q, __builtin_bit_cast(float, 0u));
-            hot[31] = xh_eligible(static_cast<double>(Ahat), static_cast<double>(qabs_max)) ? kRhoTight : kRhoLoose;
+            // float 31: the in-chunk budget of the walk's fp32 recompute (hot_budgets: rho_rel = 2^-23 with it), or rho_rel = 2^-20
+            // for a user whose delta is the loose one anyway
+            const float dcf = fmaxf(static_cast<float>(xh_delta_chunk(d, static_cast<double>(Ahat), static_cast<double>(absw)) * 1.000001), kHotDcMin);
+            hot[31] = xh_eligible(static_cast<double>(Ahat), static_cast<double>(qabs_max)) ? dcf : kRhoLoose;
         }
     }
 }

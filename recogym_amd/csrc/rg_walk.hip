@@ -17,7 +17,8 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
         (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
     const DevSim& d = *(const DevSim*)kargs;
     constexpr int K2 = 2 * KH;
-    constexpr bool kPreciseChunk = KH <= 10;   // the K classes k_sweep_xh serves: a chunk is recomputed to that sweep's accuracy
+    // (the draw's chunk recomputed as a float64 dot; -DRG_WALK_PRECISE_CHUNK=0: in fp32 with its own budget delta_c — a tie: rg_common.hpp)
+    constexpr bool kPreciseChunk = RG_WALK_PRECISE_CHUNK && KH <= 10;
     constexpr double kLog2e64 = 1.4426950408889634074;
     constexpr int kEmpty = 3;
     // a user that stops still owes its phantom row (one more policy act, abstract.py:311-316): it takes it on its lane's
@@ -699,7 +700,8 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
     const __attribute__((address_space(4))) char* kargs =
         (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int K2 = 2 * KH;
-    constexpr bool kPreciseChunk = KH <= 10;   // the K classes k_sweep_xh serves: a chunk is recomputed to that sweep's accuracy
+    // (the draw's chunk recomputed as a float64 dot; -DRG_WALK_PRECISE_CHUNK=0: in fp32 with its own budget delta_c — a tie: rg_common.hpp)
+    constexpr bool kPreciseChunk = RG_WALK_PRECISE_CHUNK && KH <= 10;
     constexpr double kLog2e64 = 1.4426950408889634074;
     constexpr int KC = ((K2 + 3) / 4) * 4;
     constexpr int kEmpty = 3, kPhantom = 4;
@@ -983,7 +985,9 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             const double S = static_cast<double>(h0.x), delta = static_cast<double>(h0.y);
             const float Q = h0.z;
             const uint32_t n_hot = __builtin_bit_cast(uint32_t, h0.w);
-            const double rho_rel = static_cast<double>(hp[7].w);            // the stored prefixes' roundings (cert_correlated)
+            double rho_rel, delta_c;                                        // the stored prefixes' roundings, the in-chunk budget (cert_correlated)
+            hot_budgets(hp[7].w, delta, &rho_rel, &delta_c);
+            if (kPreciseChunk) delta_c = delta;
             const double u_org = d.u_override ? d.u_override[slot] : rg_uniform(w.w[0], w.w[1]);
             const double tau = u_org * S;
             const float tauf = static_cast<float>(tau);
@@ -1122,7 +1126,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
             bool ok = false;
             if (search) {
                 const int idx = static_cast<int>(mboxf[lane * 3]);
-                const CertLin ct = cert_correlated(S, pb, static_cast<double>(mboxf[lane * 3 + 1]), static_cast<double>(mboxf[lane * 3 + 2]), delta, rho_rel);
+                const CertLin ct = cert_correlated(S, pb, static_cast<double>(mboxf[lane * 3 + 1]), static_cast<double>(mboxf[lane * 3 + 2]), delta, rho_rel, delta_c);
                 v = c_star * 32 + static_cast<uint32_t>(max(idx, 0));
                 const bool lo_ok = v == 0 || u_org * ct.den_lo > ct.num_lo;
                 const bool hi_ok = v == d.P - 1 || u_org * ct.den_hi < ct.num_hi;
@@ -1190,9 +1194,9 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     // (a computed in-chunk prefix s = e (1 + eps), |eps| <= delta: the true e is at most s / (1 - delta) <=
                     // s (1 + dp), dp = delta (1 + 2 delta) as in cert_correlated, and at least s / (1 + delta) >= s (1 - delta))
                     const double slack = 1.0e-12 * S64;
-                    const double dp = delta * (1.0 + 2.0 * delta);
+                    const double dp = delta_c * (1.0 + 2.0 * delta_c);       // (the in-chunk terms are recomputed ones)
                     const bool lo_ok = va == 0u || lo64 + static_cast<double>(fa) * (1.0 + dp) + slack < target;
-                    const bool hi_ok = va == d.P - 1 || target + slack < lo64 + static_cast<double>(fb) * (1.0 - delta);
+                    const bool hi_ok = va == d.P - 1 || target + slack < lo64 + static_cast<double>(fb) * (1.0 - delta_c);
                     got64 = ix >= 0 && va < d.P && lo_ok && hi_ok;
                     if (got64) v = va;
                 }
@@ -1702,7 +1706,8 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
     (void)d_arg;       // read where it lies, in the kernel-argument segment (the float64 pick is a call that takes its address)
     const DevSim& d = *(const DevSim*)(const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int K2 = 2 * KH;
-    constexpr bool kPreciseChunk = KH <= 10;   // the K classes k_sweep_xh serves: a chunk is recomputed to that sweep's accuracy
+    // (the draw's chunk recomputed as a float64 dot; -DRG_WALK_PRECISE_CHUNK=0: in fp32 with its own budget delta_c — a tie: rg_common.hpp)
+    constexpr bool kPreciseChunk = RG_WALK_PRECISE_CHUNK && KH <= 10;
     constexpr double kLog2e64 = 1.4426950408889634074;
     constexpr int KC = ((K2 + 3) / 4) * 4;
     constexpr int kEmpty = 3, kPhantom = 4;
@@ -1835,7 +1840,9 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
                 const double S = static_cast<double>(h0.x), delta = static_cast<double>(h0.y);
                 const float Q = h0.z;
                 const uint32_t n_hot = __builtin_bit_cast(uint32_t, h0.w);
-                const double rho_rel = static_cast<double>(hp[7].w);
+                double rho_rel, delta_c;
+                hot_budgets(hp[7].w, delta, &rho_rel, &delta_c);
+                if (kPreciseChunk) delta_c = delta;
                 const double u_org = d.u_override ? d.u_override[slot] : rg_uniform(w.w[0], w.w[1]);   // (test hook)
                 float uf = static_cast<float>(u_org), u_dn = uf, u_up = uf;
                 if (static_cast<double>(uf) > u_org) u_dn = f32_down(uf);
@@ -1985,7 +1992,7 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
                     __builtin_amdgcn_wave_barrier();
                     if (search) {
                         const int ix = static_cast<int>(mboxf[lane * 3]);
-                        const CertLin ct = cert_correlated(S, pb, static_cast<double>(mboxf[lane * 3 + 1]), static_cast<double>(mboxf[lane * 3 + 2]), delta, rho_rel);
+                        const CertLin ct = cert_correlated(S, pb, static_cast<double>(mboxf[lane * 3 + 1]), static_cast<double>(mboxf[lane * 3 + 2]), delta, rho_rel, delta_c);
                         v = c_star * 32 + static_cast<uint32_t>(max(ix, 0));
                         const bool lo_ok = v == 0 || u_org * ct.den_lo > ct.num_lo;
                         const bool hi_ok = v == d.P - 1 || u_org * ct.den_hi < ct.num_hi;

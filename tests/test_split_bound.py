@@ -91,17 +91,19 @@ def test_no_click_threshold_is_below_every_click_boundary():
     assert thr >= 0.97
 
 
-def _cert_correlated(S, A, a, b, delta):
-    """Host restatement of cert_correlated (rg_common.hpp): -> (num_lo, den_lo, num_hi, den_hi, valid)."""
+def _cert_correlated(S, A, a, b, delta, delta_c=None):
+    """Host restatement of cert_correlated (rg_common.hpp): -> (num_lo, den_lo, num_hi, den_hi, valid).  delta_c: the budget of
+    the recomputed in-chunk prefixes a, b where it differs from the sweep terms' (the walk behind k_sweep_xh: fp32 recompute)."""
     dp = delta * (1.0 + 2.0 * delta)
+    dc = dp if delta_c is None else delta_c * (1.0 + 2.0 * delta_c)
     rho = 2.0 ** -20 * 1.001 * S
     T = S - A
-    return ((A + a) * (1.0 + dp) + rho, T * (1.0 - dp) + A * (1.0 + dp),
-            (A + b) * (1.0 - dp) - rho, T * (1.0 + dp) + A * (1.0 - dp), T >= 0.0 and delta < 0.25)
+    return (A * (1.0 + dp) + a * (1.0 + dc) + rho, T * (1.0 - dp) + A * (1.0 + dp),
+            A * (1.0 - dp) + b * (1.0 - dc) - rho, T * (1.0 + dp) + A * (1.0 - dp), T >= 0.0 and delta < 0.25)
 
 
-@pytest.mark.parametrize('delta', [1e-6, 8.6e-5, 1e-3])
-def test_correlated_certificate_is_sound_for_worst_case_term_errors(delta):
+@pytest.mark.parametrize('delta, delta_c', [(1e-6, None), (8.6e-5, None), (1e-3, None), (1.0e-5, 7.4e-5), (1e-6, 1e-3)])
+def test_correlated_certificate_is_sound_for_worst_case_term_errors(delta, delta_c):
     """The certificate on correlated errors: the prefix A at the start of the draw's chunk and the total S are
     sums of the SAME sweep terms e_p (1 + eps_p), the prefixes a, b inside the chunk are recomputed terms with errors of their
     own, all |eps| <= delta, and the stored A, S carry up to 2^-21 of fp32 rounding each.  For random softmax-like term
@@ -126,9 +128,9 @@ def test_correlated_certificate_is_sound_for_worst_case_term_errors(delta):
                     sweep[c0:] *= 1.0 - sgn * delta                               # the chunk and everything behind it
                     A = sweep[:c0].sum() * (1.0 + sgn_r * 2.0 ** -21)
                     S = sweep.sum() * (1.0 - sgn_r * 2.0 ** -21)
-                    rec = e[c0:v + 1] * (1.0 + sgn_in * delta)
+                    rec = e[c0:v + 1] * (1.0 + sgn_in * (delta if delta_c is None else delta_c))
                     a, b = rec[:-1].sum(), rec.sum()
-                    num_lo, den_lo, num_hi, den_hi, valid = _cert_correlated(S, A, a, b, delta)
+                    num_lo, den_lo, num_hi, den_hi, valid = _cert_correlated(S, A, a, b, delta, delta_c)
                     if not valid or den_lo <= 0 or den_hi <= 0:
                         continue
                     u_lo, u_hi = num_lo / den_lo, num_hi / den_hi                 # certified iff u_lo < u < u_hi
@@ -137,8 +139,9 @@ def test_correlated_certificate_is_sound_for_worst_case_term_errors(delta):
                     if u_lo < u_hi:
                         assert (v == 0 or u_lo >= t_lo) and (v == P - 1 or u_hi <= t_hi), (case, v, sgn, sgn_in, sgn_r)
                         # the independent form's interval: C~[v-1](1+d) / (S~(1-d)) < u < C~[v](1-d) / (S~(1+d))
-                        o_lo = (A + a) * (1 + delta) / (S * (1 - delta))
-                        o_hi = (A + b) * (1 - delta) / (S * (1 + delta))
+                        dmax = delta if delta_c is None else max(delta, delta_c)
+                        o_lo = (A + a) * (1 + dmax) / (S * (1 - dmax))
+                        o_hi = (A + b) * (1 - dmax) / (S * (1 + dmax))
                         wins += (u_hi - u_lo) > max(o_hi - o_lo, 0.0)
     assert wins > n_cases            # (8 sign patterns per case: the correlated interval is the wider one in most of them)
 
