@@ -1157,6 +1157,43 @@ def test_pipelined_walk_matches_the_oracle(policy, form, monkeypatch):
     assert cnt['exact_sweeps'] > 0            # some users went through the float64 batch and round 2
 
 
+@pytest.mark.parametrize('form', ['helpers0', 'helpers1', 'helpers7_own_click_batches', 'helpers7_bias4', 'helpers3_click_batch2'])
+@pytest.mark.parametrize('policy', ['uniform', 'random', 'ouc', 'ouc_wide', 'last_view'])
+def test_walk_helpers_do_not_change_the_log(policy, form, monkeypatch):
+    """k_walk2's helpers (round 5): the idle lanes of a bandit iteration evaluate the NEXT events of the bandit runs in it, and
+    an owner skips what its helpers found.  Every form — none, one, seven per owner; the click batch inside a bandit iteration
+    or in its own; other event-kind biases and batch sizes — must leave the oracle's rows, bit for bit: policies whose act
+    reads the view history line (OrganicUserEventCounter at 60 and 3 000 products), the last view (frozen table), or nothing;
+    organic-only users (their runs end the user), long histories (few products: lines fill up), phantom rows."""
+    from oracle import oracle as orc
+    env = {'helpers0': dict(RECOGYM_WALK_HELPERS='0'),
+           'helpers1': dict(RECOGYM_WALK_HELPERS='1'),
+           'helpers7_own_click_batches': dict(RECOGYM_WALK_HELPERS='7', RECOGYM_WALK_CLICK_JOIN='0'),
+           'helpers7_bias4': dict(RECOGYM_WALK_HELPERS='7', RECOGYM_WALK_BIAS='4', RECOGYM_WALK_SEARCH_BATCH='8'),
+           'helpers3_click_batch2': dict(RECOGYM_WALK_HELPERS='3', RECOGYM_WALK_CLICK_BATCH='2', RECOGYM_WALK_REFILL='1')}[form]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    P, K, n, n_org = {'ouc': 60, 'ouc_wide': 3000}.get(policy, 700), 20, 2600, 37
+    cfg = Configuration({**env_1_args, 'random_seed': 5200 + len(form) + len(policy), 'num_products': P, 'K': K, 'sigma_omega': 0.0})
+    pol = {'uniform': {},
+           'random': dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=77),
+           'ouc': dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=31, ouc=dict(gu.OUC_DEFAULTS)),
+           'ouc_wide': dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=32, ouc=dict(gu.OUC_DEFAULTS)),
+           'last_view': None}[policy]
+    if pol is None:
+        rs = np.random.RandomState(9)
+        pol = dict(policy=_abi.RG_POLICY_LAST_VIEW_TABLE, policy_seed=0, policy_table=rs.randint(0, P, size=P).astype(np.int32),
+                   policy_ps=rs.uniform(0.1, 1.0, size=P))
+    want_env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol)
+    want = want_env.generate_logs(n, n_org)
+    rows, cnt = run_sim(cfg, n, n_org, p_click=False, **pol)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps')}, ps_rtol=1e-12, what=f'helpers {policy} {form}')
+    assert (rows['phantom'] == want['phantom']).all()
+    oc = want_env.counters()
+    assert (cnt['organic'], cnt['bandit'], cnt['clicks'], cnt['phantom']) == (oc['organic'], oc['bandit'], oc['clicks'], oc['phantom'])
+    assert cnt['live'] == 0 and cnt['log_dropped'] == 0
+
+
 def test_bench_multi_rank_line_reports_both_scaling_forms_and_the_allreduce(tmp_path):
     """`bench.py --gpus 2` end to end on THIS one-GPU box (both ranks on cuda:0, gloo instead of RCCL: the script's multi-rank
     logic, not a measurement): one JSON line with the weak form as `value`, the strong form beside it, the per-rank step times
