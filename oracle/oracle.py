@@ -170,7 +170,10 @@ class OracleEnv:
         return lib().rgo_env_last_p_click(self._h)
 
     def generate_logs(self, n_users, n_organic_users=0, first_user_id=0, capacity=None):
-        cap = capacity or int((n_users + n_organic_users) * 140 + 4096)
+        # (each user lives ~Geometric(prob_leave_organic) events plus its phantom row: the stop column of both rows of the
+        # transition matrix, reco_env_v1.py:54-61)
+        mean = 1.0 / max(float(getattr(self.config, 'prob_leave_organic', 0.01)), 1e-6) + 2.0
+        cap = capacity or int((n_users + n_organic_users) * max(140.0, 1.4 * mean) + 12.0 * mean * (n_users + n_organic_users) ** 0.5 + 4096)
         while True:
             rows = np.zeros(cap, dtype=ROW_DTYPE)
             n = lib().rgo_env_generate_logs(self._h, first_user_id, n_users, n_organic_users,

@@ -466,6 +466,12 @@ def main():
         run_case('mt_transition_probs', T, 150, n_organic=10)
         run_case('philox_transition_probs', T, 150, n_organic=10, agent_kind='ouc', agent_args=dict(random_seed=21), injected=True)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == 'long_runs':        # round 5: long bandit runs at sigma_omega = 0 (k_walk2's helpers take up to
+        # seven events of a run per iteration), long view histories (60 products: lines fill up), organic-only users among them
+        T = dict(random_seed=91, K=20, sigma_omega=0.0, prob_leave_organic=0.004, prob_bandit_to_organic=0.03, prob_organic_to_bandit=0.3)
+        run_case('philox_long_runs_ouc', {**T, 'num_products': 60}, 110, n_organic=6, agent_kind='ouc', agent_args=dict(random_seed=17), injected=True)
+        run_case('philox_long_runs_random', {**T, 'num_products': 400, 'random_seed': 92}, 90, agent_kind='random', agent_args=dict(random_seed=18), injected=True)
+        return
     notebook_goldens()
     S = dict(random_seed=42)
     # --- reference as shipped (sequential MT19937) ---
