@@ -693,6 +693,14 @@ __device__ __forceinline__ uint32_t prefix_in_mask(unsigned long long mask) {
                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
+// a 64-bit value of the wave's first active lane, as a scalar (the builtin returns a SIGNED int: OR-ing its low word into a 64-bit
+// value without the cast sign-extends it — a raw-log row base beyond 2^31 rows, a mask with bit 31 set)
+__device__ __forceinline__ unsigned long long readfirstlane_u64(unsigned long long x) {
+    const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(x)));
+    const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(x >> 32)));
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
 __device__ __forceinline__ double sigmoid64(double x) { return 1.0 / (1.0 + exp(-x)); }
 // ff(): reco_env_v1.py:38-41
 __device__ __forceinline__ double ff64(double x) {

@@ -175,8 +175,7 @@ __global__ void __launch_bounds__(kBlock, OCC) k_walk(DevSim d_arg, uint32_t n_w
                 if (d.log && r < d.log_cap) { rg_event e; e.u = 0; e.t = 0; e.code = kHoleCode; e.ps = 0.0f; d.log[r] = e; }
             unsigned long long base = 0;
             if (lane == 0) base = atomicAdd(&d.counters[kCntTailRows], static_cast<unsigned long long>(chunk_rows));
-            base = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32))) << 32) |
-                   __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
+            base = readfirstlane_u64(base);
             row_next = base; row_end = base + chunk_rows;
         }
         const uint64_t my_row = row_next + prefix_in_mask(rowm);
@@ -1500,8 +1499,7 @@ __global__ void __launch_bounds__(kBlock, (KH <= 10 ? 3 : 2)) k_walk2(DevSim d_a
                     if (d.log && r < d.log_cap) { rg_event e; e.u = 0; e.t = 0; e.code = kHoleCode; e.ps = 0.0f; d.log[r] = e; }
                 unsigned long long base = 0;
                 if (lane == 0) base = atomicAdd(&d.counters[kCntTailRows], static_cast<unsigned long long>(chunk_rows));
-                base = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32))) << 32) |
-                       __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
+                base = readfirstlane_u64(base);
                 row_next = base; row_end = base + chunk_rows;
             }
             const uint64_t my_row = row_next + prefix_in_mask(rowm);
@@ -2021,8 +2019,7 @@ __global__ void __launch_bounds__(kBlock) k_walk_solo(DevSim d_arg, uint32_t n_w
                     if (d.log && r < d.log_cap) { rg_event e; e.u = 0; e.t = 0; e.code = kHoleCode; e.ps = 0.0f; d.log[r] = e; }
                 unsigned long long base = 0;
                 if (lane == 0) base = atomicAdd(&d.counters[kCntTailRows], static_cast<unsigned long long>(chunk_rows));
-                base = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32))) << 32) |
-                       __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
+                base = readfirstlane_u64(base);
                 row_next = base; row_end = base + chunk_rows;
             }
             const uint64_t my_row = row_next + static_cast<uint32_t>(lane);
