@@ -167,7 +167,9 @@ int rg_sim_destroy(rg_sim* sim);
  * walk_handover, walk_click_batch, walk_search_batch, walk_helpers (0 .. 7), walk_click_join, walk_line64, pipe_groups, pipe_mode, pipe_occ1, pipe_occ2, pipe_xblocks,
  * pipe_min_users, exact_mix, exact_tile, resident_grid, slices (-1 = by population), sweep_prefix_off, tail_below,
  * repack_every, run_ahead (events a round of a run to the end may take a user through, 0 = an event per launch), lr_part_cap (acts
- * of a step the frozen-LogReg fp16 screen takes; can only be lowered), debug.
+ * of a step the frozen-LogReg fp16 screen takes; can only be lowered), sweep_lds (1: the unsliced sweep of a run whose draws are
+ * not cached keeps its tile prefixes in LDS and searches them there, k_draw_tp; 0: k_draw_bf16p's scratch + search), debug.
+ * Read-only: sweep_lds_kernel (1 where k_draw_tp serves the configuration).
  * RG_EINVAL for an unknown name or a value out of range. */
 int rg_sim_set_option(rg_sim* sim, const char* name, int64_t value);
 int rg_sim_get_option(rg_sim* sim, const char* name, int64_t* value);

@@ -1,4 +1,4 @@
-// recogym_hip.hip — librecogym_hip.so as ONE translation unit: the eight units of the library, in order (the parallel build
+// recogym_hip.hip — librecogym_hip.so as ONE translation unit: the nine units of the library, in order (the parallel build
 // compiles them separately: __graft_entry__.build()).  gfx950 only.
 #include "rg_host.hip"
 #include "rg_exact.hip"
@@ -8,3 +8,4 @@
 #include "rg_advance.hip"
 #include "rg_walk.hip"
 #include "rg_draw_exacthi.hip"
+#include "rg_draw_lds.hip"

@@ -332,6 +332,12 @@ struct rg_sim {
     void (*xh_kernel)(DevSim, uint32_t, uint32_t);   // k_sweep_xh: the walked run's sweep where it exists (else bf16_kernel)
     size_t xh_smem;
     int xh_waves;            // waves per block of that kernel (4: two blocks per CU, 8: one; RECOGYM_XH_WAVES)
+    // k_draw_tp (rg_draw_lds.hip): the unsliced sweep of a step whose draws cannot be cached (sigma_omega > 0) — tile prefixes in
+    // LDS, the search on them; nullptr where no instance serves the configuration or its LDS does not fit (then bf16_kernel)
+    void (*tp_kernel)(DevSim, uint32_t, uint32_t);
+    size_t tp_smem;
+    uint32_t tp_nts;         // its LDS row stride (floats) of a user's tile prefixes
+    uint32_t sweep_lds;      // option: 1 = use it (default), 0 = k_draw_bf16p everywhere (A/B tests)
     uint32_t draw_threads, draw_users;   // block size of that kernel and the users one block sweeps for (256 / 128; wide K: 512 / 256)
     bool profiling;
     std::vector<hipEvent_t> prof_events;   // 6 per profiled step: before draw, after mfma, after search, after exact, after the frozen LogReg acts, after advance
@@ -367,6 +373,7 @@ finalize_kernel_t finalize_kernel_for(const DevSim& d);    // part 4
 cached_kernel_t cached_kernel_for(const DevSim& d);
 draw_kernel_t bf16p_kernel_for(const DevSim& d);
 draw_kernel_t f16w_kernel_for(const DevSim& d);            // part 5
+draw_kernel_t tp_kernel_for(const DevSim& d);              // part 9 (nullptr: k_draw_bf16p serves the configuration)
 draw_kernel_t xh_kernel_for(const DevSim& d, int waves);   // part 8 (nullptr: no error-free sweep for this K class); waves per block: 4 or 8
 void (*xh_table_kernel())(DevSim);
 void (*xh_stats_kernel())(DevSim);

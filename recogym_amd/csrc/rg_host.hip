@@ -595,6 +595,9 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         const int grid = sweep_grid(sim, static_cast<uint64_t>(tiles_up) * S, S);
         // (the search stays at the end of every user tile of the sweep: as its own kernel over the whole step — scratch slot
         // per user tile — the sweep got 15 % shorter and the step 6 % longer: profiles/r3/ab_call26_*, ab_call27_*)
+        if (S == 1 && sim->tp_kernel && sim->sweep_lds && !d.use_cache)
+            hipLaunchKernelGGL(sim->tp_kernel, dim3(grid), dim3(kBlock), sim->tp_smem, st, d, t, sim->tp_nts);
+        else
         hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid), dim3(sim->draw_threads), sim->bf16_smem, st, d, t, S);
         if (int rc = prof_mark(sim, st)) return rc;
         if (S > 1)
@@ -1109,6 +1112,20 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(s->xh_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(s->xh_smem));
     } else { d.XNH = d.XNL = d.XRS = 0; }
+    // the sweep whose search stays in LDS (k_draw_tp): where every draw sweeps (no per-user cache) and the two-way fp16 split of
+    // K <= 20 serves the table; a user's tile prefixes must fit beside the tiles (P <= ~12 000 at two blocks per CU)
+    s->tp_kernel = nullptr; s->tp_smem = 0; s->tp_nts = 0; s->sweep_lds = 1;
+    if (const char* e = getenv("RECOGYM_SWEEP_LDS")) s->sweep_lds = e[0] != '0';
+    if (d.use_mfma == 2 && !d.use_cache && s->bf16_kernel && s->bf16_kernel == bf16p_kernel_for(d) && d.f16 && !d.wide) {
+        if (draw_kernel_t kt = tp_kernel_for(d)) {
+            const uint32_t nts = ((d.n_chunks / 4) + 3u) & ~3u;
+            const size_t smem = 2 * (128 * static_cast<size_t>(d.RS) + 512) + 256 + 4 * 32 * static_cast<size_t>(nts) * sizeof(float);
+            if (smem <= 160 * 1024) {
+                s->tp_kernel = kt; s->tp_smem = smem; s->tp_nts = nts;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
+            }
+        }
+    }
     d.ablate = 0;
     s->repack_every = 16;
     s->repacked = false;
@@ -1255,6 +1272,7 @@ uint32_t* opt_u32(rg_sim* s, const char* n) {
     if (!strcmp(n, "tail_below")) return &s->tail_below;
     if (!strcmp(n, "repack_every")) return &s->repack_every;
     if (!strcmp(n, "run_ahead")) return &s->run_ahead;
+    if (!strcmp(n, "sweep_lds")) return &s->sweep_lds;
     if (!strcmp(n, "lr_part_cap")) return &s->d.lr_part_cap;
     return nullptr;
 }
@@ -1294,6 +1312,7 @@ int rg_sim_set_option(rg_sim* sim, const char* name, int64_t value) {
 
 int rg_sim_get_option(rg_sim* sim, const char* name, int64_t* value) {
     if (!sim || !name || !value) return fail(RG_EINVAL, "NULL argument");
+    if (!strcmp(name, "sweep_lds_kernel")) { *value = sim->tp_kernel ? 1 : 0; return RG_OK; }     // read-only: k_draw_tp serves the configuration
     if (int* p = opt_int(sim, name)) { *value = *p; return RG_OK; }
     if (uint32_t* p = opt_u32(sim, name)) { *value = *p; return RG_OK; }
     return fail(RG_EINVAL, "unknown option '%s'", name);

@@ -662,7 +662,45 @@ def test_frozen_logreg_at_config_5_scale_matches_the_oracle(screen, monkeypatch)
     assert cnt['lr_acts'] > 300 and cnt['lr_exact'] > 0 and cnt['lr_rows'] >= cnt['lr_acts']
 
 
-@pytest.mark.parametrize('mode', ['f16', 'bf16', 'fp32'])
+LDS_EXTRA_CASES = [
+    # the (KH, N1) classes of k_draw_tp the oracle cases above do not reach: (10, 2) K = 10, (10, 3) K = 13, (4, 2) at P around a tile
+    (dict(num_products=300, K=10, random_seed=61, sigma_omega=0.2), 1200, 0, {}),
+    (dict(num_products=129, K=13, random_seed=62), 900, 5, dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=7)),
+    (dict(num_products=128, K=8, random_seed=63, sigma_omega=0.5), 900, 0, {}),
+    (dict(num_products=2000, K=20, random_seed=64, sigma_omega=0.3, sigma_mu_organic=12.0), 500, 0,
+     dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=27, ouc=dict(gu.OUC_DEFAULTS))),
+]
+
+
+@pytest.mark.parametrize('run_ahead', ['32', '0'])
+@pytest.mark.parametrize('case', [0, 2, 6, 7, 8, 9, 10, 'x0', 'x1', 'x2', 'x3'])
+def test_lds_search_sweep_matches_the_oracle(case, run_ahead, monkeypatch):
+    """k_draw_tp (rg_draw_lds.hip: tile prefixes in LDS, the search on them, one tile of Gamma recomputed) is the sweep of every
+    UNSLICED step of a run whose draws cannot be cached; populations the oracle finishes in seconds take the sliced form, so the
+    unsliced one is forced here (RECOGYM_SLICES=1) on every (KH, N1) class it is instantiated for, in rounds and in lock-step."""
+    from oracle import oracle as orc
+    from recogym_amd.sim import Simulator
+    monkeypatch.setenv('RECOGYM_SLICES', '1')
+    monkeypatch.setenv('RECOGYM_RUN_AHEAD', run_ahead)
+    monkeypatch.setenv('RECOGYM_TAIL', '0')            # (the tail kernel would take these small populations from the first poll on)
+    over, n_users, n_org, pol = CASES[case] if isinstance(case, int) else LDS_EXTRA_CASES[int(case[1:])]
+    cfg = Configuration({**env_1_args, **over})
+    probe = Simulator(cfg, 64, device='cuda:0', **pol)
+    assert probe.get_option('sweep_lds_kernel') == 1, 'k_draw_tp does not serve this configuration'
+    probe.close()
+    want_env = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol)
+    want = want_env.generate_logs(n_users, n_org)
+    rows, cnt = run_sim(cfg, n_users, n_org, **pol)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps', 'p_click')},
+                         ps_rtol=1e-12, what=f'lds case {case}')
+    assert (rows['phantom'] == want['phantom']).all()
+    oc = want_env.counters()
+    assert (cnt['organic'], cnt['bandit'], cnt['clicks'], cnt['phantom']) == (oc['organic'], oc['bandit'], oc['clicks'], oc['phantom'])
+    # most draws are certified by the kernel itself (the float64 resolve is the exception, not the path)
+    assert cnt['exact_draws'] < 0.2 * cnt['organic'] + 50, (cnt['exact_draws'], cnt['organic'])
+
+
+@pytest.mark.parametrize('mode', ['f16', 'f16_lds', 'bf16', 'fp32'])
 @pytest.mark.parametrize('shape', [(10000, 20), (3000, 20), (1500, 40)])
 def test_certificate_is_sound_for_uniforms_next_to_cdf_boundaries(mode, shape, monkeypatch):
     """Adversarial check of the margin certificate.  The uniform of every user's draw is
@@ -678,6 +716,11 @@ def test_certificate_is_sound_for_uniforms_next_to_cdf_boundaries(mode, shape, m
     import ctypes as C
     from recogym_amd.envs.static_params import draw_tables
     from recogym_amd.sim import Simulator
+    if mode == 'f16_lds':          # the unsliced sweep whose search runs on tile prefixes in LDS (k_draw_tp; K <= 20)
+        if shape[1] > 20:
+            pytest.skip('k_draw_tp serves K <= 20')
+        monkeypatch.setenv('RECOGYM_SLICES', '1')
+        mode = 'f16'
     monkeypatch.setenv('RECOGYM_DRAW', mode)
     P, K = shape
     n = 4096

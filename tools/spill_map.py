@@ -5,7 +5,7 @@ e.g. python tools/spill_map.py 5 'k_draw_f16wILi32ELi13ELi1E' 'for (uint32_t ti 
 """
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-UNITS = ['rg_host', 'rg_exact', 'rg_draw_fp32', 'rg_draw_pipelined', 'rg_draw_wide', 'rg_advance', 'rg_walk', 'rg_draw_exacthi']
+UNITS = ['rg_host', 'rg_exact', 'rg_draw_fp32', 'rg_draw_pipelined', 'rg_draw_wide', 'rg_advance', 'rg_walk', 'rg_draw_exacthi', 'rg_draw_lds']
 part, pat = sys.argv[1], sys.argv[2]
 unit = UNITS[int(part) - 1]
 SRC = os.path.join(ROOT, 'recogym_amd', 'csrc', unit + '.hip')
