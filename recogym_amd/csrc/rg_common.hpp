@@ -95,6 +95,11 @@ inline int fail(int code, const char* fmt, ...) {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// What k_draw_tp leaves per organic draw of an unsliced step for k_pick (rg_draw_lds.hip), indexed by the draw's position in the
+// step's organic list: the draw's uniform, the total and the prefix at the start of the draw's 128-product tile (fp32 roundings of
+// the float64 running prefix), the reference and the certificate's delta, the tile (>= n_tiles: no tile found — float64).
+struct TpRec { double u; float S, pb, q, dlt; uint32_t ti, pad; };
+
 // Everything a kernel needs, passed by value.
 struct DevSim {
     // configuration
@@ -137,6 +142,7 @@ struct DevSim {
     uint32_t exact_last;      // this is the last batch launched for the step
     float2* sc_scratch;       // [kMaxGrid*4 waves][kMaxSC][32] {sum, reference} of the MFMA draw kernel
     float* chunk_scratch;     // [kMaxGrid*4 waves][n_chunks][32] exp-sum of every 32-product chunk
+    TpRec* tp_rec;            // [n_cap] k_draw_tp -> k_pick (null: the configuration has no k_draw_tp)
     float* stats;             // [2*KH] max_p |Gamma[p][k]|, then max_p ||Gamma[p]||_2, max_p |mu_o[p]|
     // geometry of the MFMA draw kernel
     uint32_t KH;              // MFMA k-steps per chunk (each 32x32x2 step consumes 2 k); 0 = no MFMA path
@@ -335,6 +341,7 @@ struct rg_sim {
     // k_draw_tp (rg_draw_lds.hip): the unsliced sweep of a step whose draws cannot be cached (sigma_omega > 0) — tile prefixes in
     // LDS, the search on them; nullptr where no instance serves the configuration or its LDS does not fit (then bf16_kernel)
     void (*tp_kernel)(DevSim, uint32_t, uint32_t);
+    void (*pick_kernel)(DevSim, uint32_t, uint32_t);
     size_t tp_smem;
     uint32_t tp_nts;         // its LDS row stride (floats) of a user's tile prefixes
     uint32_t sweep_lds;      // option: 1 = use it (default), 0 = k_draw_bf16p everywhere (A/B tests)
@@ -374,6 +381,7 @@ cached_kernel_t cached_kernel_for(const DevSim& d);
 draw_kernel_t bf16p_kernel_for(const DevSim& d);
 draw_kernel_t f16w_kernel_for(const DevSim& d);            // part 5
 draw_kernel_t tp_kernel_for(const DevSim& d);              // part 9 (nullptr: k_draw_bf16p serves the configuration)
+draw_kernel_t pick_kernel_for(const DevSim& d);            // k_pick: its second half (the draws grouped by tile, one tile on the matrix cores)
 draw_kernel_t xh_kernel_for(const DevSim& d, int waves);   // part 8 (nullptr: no error-free sweep for this K class); waves per block: 4 or 8
 void (*xh_table_kernel())(DevSim);
 void (*xh_stats_kernel())(DevSim);
@@ -631,7 +639,10 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint32_t* ev = w.take<uint32_t>(n);
     uint32_t* pv0 = w.take<uint32_t>(c.env_kind ? n : 1);
     unsigned long long* run_ctl = w.take<unsigned long long>(4);
+    const bool tp = g.F16 == 1 && g.KH <= 10 && !cache;          // k_draw_tp's classes (tp_kernel_for), every draw a sweep
+    TpRec* tp_rec = w.take<TpRec>(tp ? n : 1);
     if (d) {
+        d->tp_rec = tp ? tp_rec : nullptr;
         d->ev = ev; d->run_ctl = run_ctl; d->run_ahead = 0; d->pv0 = pv0;
         d->phantom_ps = phantom_ps; d->utime = utime; d->phantom_time = phantom_time;
         d->drift_list = drift_list; d->drift_sig = drift_sig; d->drift_cnt = drift_cnt;

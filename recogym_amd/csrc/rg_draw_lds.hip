@@ -1,4 +1,4 @@
-// rg_draw_lds.hip — librecogym_hip.so, unit 9 of 9: k_draw_tp, the sigma_omega > 0 sweep whose search never leaves the CU.
+// rg_draw_lds.hip — librecogym_hip.so, unit 9 of 9: k_draw_tp + k_pick, the sigma_omega > 0 sweep without a scratch and its search on the matrix cores.
 // (see rg_common.hpp for the shared types and helpers, DESIGN.md §4 "Round 6" for the measurements)
 //
 // What it replaces: k_draw_bf16p<.., F16> + search_and_emit where every organic draw needs its own product sweep (omega
@@ -9,12 +9,11 @@
 //   * the sweep (same tiles, same MFMA / exp stream, same arithmetic and certificate budget) keeps ONE number per 128-product
 //     tile and user: the running prefix of the exp-sums at the tile's end, float64 in a register, stored as ONE fp32 rounding
 //     in LDS ([wave][user][tile]: 316 B per user at P = 10^4).  Nothing goes to global memory during the sweep;
-//   * the search counts the user's tile prefixes <= u S in LDS (two lanes per user), then RECOMPUTES the 128 products of that
-//     tile in fp32 from the chunk-major copy of Gamma (eight users per pass, eight lanes per user, 16 products per lane) — the
-//     arithmetic of search_and_emit's chunk recompute on four chunks — and takes the certificate of cert_correlated with
-//     A = the tile's starting prefix: two round trips (the Gamma tile in two batches) instead of twelve;
+//   * at the end of its sweep a user's tile prefixes <= u S are COUNTED in LDS (two lanes per user): the tile of the draw and the
+//     prefix A at its start; those, the total, the reference and the certificate's budget go to k_pick (32 bytes per draw),
+//     which finds the product inside the tile on the matrix cores, 32 draws of one tile at a time (below);
 //   * no re-referencing: the reference is the first chunk's largest logit; a user whose sums overflow fp32 (a logit > 2^127
-//     above it) fails the certificate and is drawn in float64 like every uncertified draw.
+//     above it) has no tile and is drawn in float64 like every uncertified draw.
 // LDS: tiles 2 x 18 KB + prefixes 40 KB per block of 4 waves x 32 users (P = 10^4, K = 20): two blocks per CU.  Served: the
 // two-way fp16 split classes with K <= 20 (KH <= 10), unsliced sweeps (S = 1), no per-user cache; everything else keeps
 // k_draw_bf16p.
@@ -34,10 +33,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
     char* g_buf = smem_raw;                                           // [NB][128][RSc]: the tile in use and the one in flight
     float* mu_buf = reinterpret_cast<float*>(g_buf + NB * TILE_B);    // [NB][128] (+ pad)
     float* tpref = mu_buf + NB * 128 + 64;                            // [4 waves][32 users][NTs] tile prefixes
-    // omega32 of the block's users [4][32][K2]: in tile buffer 1 while the B rows are built (its first DMA goes out after
-    // them), in tile buffer 0 again for the search (behind a barrier: every wave is done with the tiles)
+    // omega32 of the block's users [4][32][K2]: in tile buffer 1 while the B rows are built (its first DMA goes out after them)
     float* om_pre = reinterpret_cast<float*>(g_buf + TILE_B);
-    float* om_post = reinterpret_cast<float*>(g_buf);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const int j = lane & 31, h = lane >> 5;
     const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
@@ -54,7 +51,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
         const uint32_t pos = tb * 128 + wave * 32 + j;
         const bool active = pos < n_o;
         const uint32_t slot = active ? cur[pos] : 0u;
-        __syncthreads();           // every wave is done with the LDS buffers (previous work item's search)
+        __syncthreads();           // every wave is done with the LDS buffers (previous work item)
         const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
         const rg_v4i rs_g = raw_buffer_rsrc(d.gsplit), rs_m = raw_buffer_rsrc(d.mu32s);
         const uint32_t g_lds = lds_addr_of(g_buf), mu_lds = lds_addr_of(mu_buf);
@@ -252,14 +249,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
             book(pi, tree(p0), tree(p1));
         }
 
-        // =========================== the search: LDS, then one tile of Gamma ===========================
-        // omega32 again (the stage was overwritten by tile 1): requested now, staged behind the barrier below
-        float wre[KH];
-#pragma unroll
-        for (int s = 0; s < KH; ++s) {
-            const uint32_t k = h * KH + s;
-            wre[s] = (active && k < d.K) ? static_cast<float>(d.omega[static_cast<size_t>(slot) * d.OMS + k]) : 0.0f;
-        }
+        // ---- what the search needs from here: the tile of the draw (a count in LDS) and five numbers; k_pick does the rest ----
         const uint32_t uidx = d.uid[slot];
         const uint32_t user = static_cast<uint32_t>(d.first_user + uidx);
         const double u_draw = organic_uniform(d, uidx, user, t);
@@ -282,115 +272,205 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
         }
         cnt += static_cast<uint32_t>(__shfl_xor(static_cast<int>(cnt), 32));
         const bool found_t = cnt < n_pt && S > 0.0 && S < 3.0e38;
-        const uint32_t ti_star = cnt < n_pt ? cnt : n_pt - 1u;
-        const double pb = ti_star ? static_cast<double>(trow[ti_star - 1u]) : 0.0;    // A: the prefix at the tile's start
-        const float remf = static_cast<float>(tau - pb);
-        const double delta = static_cast<double>(d.K + 5) * 5.9604644775390625e-08 * static_cast<double>(Ahat) + delta_fixed;
-        __syncthreads();           // every wave is done with the tile buffers
+        const float pbf = (found_t && cnt) ? trow[cnt - 1u] : 0.0f;                   // A: the prefix at the tile's start
+        if (active && h == 0) {
+            const double delta = static_cast<double>(d.K + 5) * 5.9604644775390625e-08 * static_cast<double>(Ahat) + delta_fixed;
+            TpRec r;
+            r.u = u_draw; r.S = Sf; r.pb = pbf; r.q = q; r.dlt = static_cast<float>(delta * 1.000001);      // (rounded up: the budget must not shrink)
+            r.ti = found_t ? cnt : 0xFFFFFFFFu; r.pad = 0u;
+            d.tp_rec[pos] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pick — the second half of an unsliced step's organic draws: product, certificate, row.
+//
+// k_draw_tp left, per draw, the 128-product tile u S falls into and the prefix A at its start.  What is left is the position
+// inside the tile: the tile's 128 terms once more.  Recomputed per user from the fp32 table that is 10 KB of L2 traffic and
+// 2 560 fused multiply-adds per draw on an eighth of a wave (measured inside the sweep kernel: as slow as the search it replaced,
+// profiles/r6/ab_call1_tp.jsonl).  Here the draws of a segment of the organic list are first GROUPED BY TILE (a counting sort in
+// LDS: 79 bins at P = 10^4), and a wave takes 32 draws of ONE tile: the tile's split rows are the A operands of all of them
+// (18 KB from L2 per 32 draws), the users' omega the B operands — the sweep's own MFMA, bit for bit the sweep's logits — and the
+// exps, the in-tile prefix and the first product beyond the remainder are two lanes per user in the accumulator layout
+// (rows 8 g + 4 h + r of a chunk in register 4 g + r of lane (user, h)).  The certificate is search_and_emit's
+// (cert_correlated) with A = the tile's start.  ~1 400 vector instructions per 32 draws, no scratch.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kPickBins = 128;          // tiles a segment is sorted by (k_draw_tp's LDS holds <= ~100 tile prefixes per user)
+
+template <int KH, int N1>
+__global__ void __launch_bounds__(kBlock) k_pick(DevSim d, uint32_t t, uint32_t seg_shift) {
+    constexpr int K2 = 2 * KH;
+    constexpr uint32_t RSc = 32 * N1 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const uint32_t SEG = 1u << seg_shift;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);            // [kPickBins + 1] draws per tile (last bin: no tile)
+    uint32_t* start = hist + (kPickBins + 1);                          // [kPickBins + 1] first perm entry of the tile
+    uint32_t* cursor = start + (kPickBins + 1);                        // [kPickBins + 1]
+    uint32_t* gstart = cursor + (kPickBins + 1);                       // [kPickBins + 1] first group of the tile
+    float* om_stage = reinterpret_cast<float*>(gstart + (kPickBins + 1) + 4);   // [4 waves][32][K2]
+    unsigned short* perm = reinterpret_cast<unsigned short*>(om_stage + 4 * 32 * K2);   // [SEG] draws of the segment, by tile
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const uint32_t n_pt = d.n_chunks / 4;
+    const uint32_t seg0 = blockIdx.x * SEG;
+    if (seg0 >= n_o) return;
+    const uint32_t n = min(SEG, n_o - seg0);
+    // ---- counting sort of the segment's draws by tile ----
+    for (uint32_t i = threadIdx.x; i <= kPickBins; i += kBlock) { hist[i] = 0u; cursor[i] = 0u; }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+        const uint32_t ti = d.tp_rec[seg0 + i].ti;
+        atomicAdd(&hist[ti < n_pt && ti < kPickBins ? ti : kPickBins], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {           // exclusive scans over the bins: perm entries and groups of 32
+        uint32_t c0 = hist[lane], c1 = hist[64 + lane];
+        uint32_t g0 = (c0 + 31u) >> 5, g1 = (c1 + 31u) >> 5;
+        uint32_t sc = c0, sg = g0;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t yc = __shfl_up(sc, o), yg = __shfl_up(sg, o);
+            if (lane >= o) { sc += yc; sg += yg; }
+        }
+        const uint32_t tc = __shfl(sc, 63), tg = __shfl(sg, 63);
+        start[lane] = sc - c0; gstart[lane] = sg - g0;
+        uint32_t sc1 = c1, sg1 = g1;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t yc = __shfl_up(sc1, o), yg = __shfl_up(sg1, o);
+            if (lane >= o) { sc1 += yc; sg1 += yg; }
+        }
+        start[64 + lane] = tc + sc1 - c1; gstart[64 + lane] = tg + sg1 - g1;
+        if (lane == 63) { start[kPickBins] = tc + sc1; gstart[kPickBins] = tg + sg1; }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
+        const TpRec* rp = d.tp_rec + seg0 + i;
+        const uint32_t ti = rp->ti;
+        const uint32_t bin = ti < n_pt && ti < kPickBins ? ti : kPickBins;
+        if (bin == kPickBins) {            // no tile (sums that overflowed, u S beyond the last prefix): float64
+            const uint32_t xi = atomicAdd(&d.exact_cnt[t], 1u);
+            d.exact_list[xi] = seg0 + i;
+            d.exact_ref[xi] = rp->q;
+        } else perm[start[bin] + atomicAdd(&cursor[bin], 1u)] = static_cast<unsigned short>(i);
+    }
+    __syncthreads();
+    const uint32_t n_groups = gstart[kPickBins];
+    float* omw = om_stage + wave * 32 * K2;
+    for (uint32_t g = wave; g < n_groups; g += kBlock / 64) {
+        // the group's tile: the last bin whose first group is <= g (wave-uniform; bins with no draws have no groups)
+        uint32_t lo = 0, hi = kPickBins;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (gstart[mid] <= g) lo = mid; else hi = mid; }
+        const uint32_t tile = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lo)));
+        const uint32_t gi = g - gstart[tile];
+        const uint32_t first = start[tile] + 32u * gi;
+        const uint32_t cnt = min(32u, hist[tile] - 32u * gi);
+        const bool active = static_cast<uint32_t>(j) < cnt;
+        const uint32_t pos = seg0 + (active ? perm[first + j] : perm[first]);
+        const uint32_t slot = cur[pos];
+        const TpRec rec = d.tp_rec[pos];
+        // ---- omega32 of the 32 users -> the wave's stage -> B fragments [w1 | w1 | w2 | 0 .. | -q] (as the sweep built them) ----
         {
-            float* o = om_post + (wave * 32 + j) * K2 + h * KH;
+            float* o = omw + j * K2 + h * KH;
+            const double* om_row = d.omega + static_cast<size_t>(slot) * d.OMS;
 #pragma unroll
-            for (int s = 0; s < KH; ++s) o[s] = wre[s];
+            for (int s = 0; s < KH; ++s) {
+                const uint32_t k = h * KH + s;
+                o[s] = k < d.K ? static_cast<float>(om_row[k]) : 0.0f;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        // ---- the 128 products of tile ti_star: eight users per pass, eight lanes per user, per lane four consecutive products
-        // of each of the tile's four chunks (every load a 128-byte run per k and user) ----
-        int r_idx = -1;
-        float r_a = 0.0f, r_b = 0.0f;
+        bf16x8 Bm[N1];
         {
-            const int lane_w = 32 * h + j, grp = lane_w >> 3, gl = lane_w & 7;
-#pragma unroll 1
-            for (int ps = 0; ps < 4; ++ps) {
-                const int u = 8 * ps + grp;                        // the user this group works for (its h = 0 lane)
-                const uint32_t ts = static_cast<uint32_t>(__shfl(static_cast<int>(ti_star), u));
-                const float Qs = __shfl(q, u);
-                const float rems = __shfl(remf, u);
-                const float* ou = om_post + (wave * 32 + u) * K2;
-                float wv[K2];
+            const uint32_t K = d.K;
+            const float* omu = omw + j * K2;
 #pragma unroll
-                for (int k4 = 0; k4 < K2 / 4; ++k4) {
-                    const float4 w4 = *reinterpret_cast<const float4*>(ou + 4 * k4);
-                    wv[4 * k4] = w4.x; wv[4 * k4 + 1] = w4.y; wv[4 * k4 + 2] = w4.z; wv[4 * k4 + 3] = w4.w;
+            for (int s = 0; s < N1; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t ke = 16 * s + 8 * h + e;
+                    unsigned short sp[2] = {0, 0};
+                    if (ke < 3 * K) f16_split2(omu[ke % K], sp);
+                    Bm[s][e] = static_cast<short>(ke < 2 * K ? sp[0] : sp[1]);
                 }
-#pragma unroll
-                for (int k = (K2 / 4) * 4; k < K2; ++k) wv[k] = ou[k];
-                float qx[4][4];                                    // in-lane inclusive prefixes of every chunk
-                float exl[4], tot[4];
-#pragma unroll
-                for (int c2 = 0; c2 < 4; c2 += 2) {                // two chunks' rows in flight
-                    float4 gk[2][K2], l[2];
-#pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) {
-                        const uint32_t cs = ts * 4 + c2 + cc;
-                        const float4* gp = reinterpret_cast<const float4*>(d.gamma32t + (static_cast<size_t>(cs) * K2) * 32) + gl;
-                        l[cc] = *(reinterpret_cast<const float4*>(d.mu32 + cs * 32) + gl);
-#pragma unroll
-                        for (int k = 0; k < K2; ++k) gk[cc][k] = gp[k * 8];
-                    }
-#pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) {
-#pragma unroll
-                        for (int k = 0; k < K2; ++k) {
-                            l[cc].x = fmaf(gk[cc][k].x, wv[k], l[cc].x); l[cc].y = fmaf(gk[cc][k].y, wv[k], l[cc].y);
-                            l[cc].z = fmaf(gk[cc][k].z, wv[k], l[cc].z); l[cc].w = fmaf(gk[cc][k].w, wv[k], l[cc].w);
-                        }
-                        const float e0 = __builtin_amdgcn_exp2f(fmaf(l[cc].x, kLog2e, -Qs)), e1 = __builtin_amdgcn_exp2f(fmaf(l[cc].y, kLog2e, -Qs));
-                        const float e2 = __builtin_amdgcn_exp2f(fmaf(l[cc].z, kLog2e, -Qs)), e3 = __builtin_amdgcn_exp2f(fmaf(l[cc].w, kLog2e, -Qs));
-                        const int c = c2 + cc;
-                        qx[c][0] = e0; qx[c][1] = qx[c][0] + e1; qx[c][2] = qx[c][1] + e2; qx[c][3] = qx[c][2] + e3;
-                        float inc = qx[c][3];
-#pragma unroll
-                        for (int o2 = 1; o2 < 8; o2 <<= 1) {
-                            const float y = __shfl_up(inc, o2, 8);
-                            if (gl >= o2) inc += y;
-                        }
-                        float ex = __shfl_up(inc, 1, 8);
-                        if (gl == 0) ex = 0.0f;
-                        exl[c] = ex;
-                        tot[c] = __shfl(inc, 8 * grp + 7);
-                    }
-                }
-                // the proposal: the first product whose in-tile prefix exceeds the remainder (fp32: only a proposal — the
-                // certificate is taken from the two prefixes around it)
-                float f_idx = -1.0f, f_a = 0.0f, f_b = 0.0f;
-                bool g_done = false;
-                float off = 0.0f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float base = off + exl[c];
-                    const float x0 = base + qx[c][0], x1 = base + qx[c][1], x2 = base + qx[c][2], x3 = base + qx[c][3];
-                    const int j0 = x0 > rems ? 0 : x1 > rems ? 1 : x2 > rems ? 2 : x3 > rems ? 3 : -1;
-                    const unsigned long long hits = __ballot(j0 >= 0);
-                    const uint32_t gmask = static_cast<uint32_t>(hits >> (8 * grp)) & 0xFFu;
-                    const int win = 8 * grp + (gmask ? __builtin_ctz(gmask) : 7);
-                    const float c_idx = j0 >= 0 ? static_cast<float>(32 * c + 4 * gl + j0) : -1.0f;
-                    const float c_a = j0 <= 0 ? (j0 == 0 ? base : x3) : j0 == 1 ? x0 : j0 == 2 ? x1 : x2;
-                    const float c_b = j0 < 0 ? x3 : j0 == 0 ? x0 : j0 == 1 ? x1 : j0 == 2 ? x2 : x3;
-                    const float w_idx = __shfl(c_idx, win), w_a = __shfl(c_a, win), w_b = __shfl(c_b, win);
-                    if (!g_done && gmask) { f_idx = w_idx; f_a = w_a; f_b = w_b; g_done = true; }
-                    off += tot[c];
-                }
-                // back to the user's own lanes (both halves): user u' is served in pass u' >> 3 by group u' & 7
-                const int from = 8 * (j & 7);
-                const float o_idx = __shfl(f_idx, from), o_a = __shfl(f_a, from), o_b = __shfl(f_b, from);
-                if ((j >> 3) == ps) { r_idx = static_cast<int>(o_idx); r_a = o_a; r_b = o_b; }
-            }
+            if (h == 1) Bm[N1 - 1][7] = static_cast<short>(__builtin_bit_cast(unsigned short, static_cast<_Float16>(-rec.q)));
         }
-        const uint32_t v = ti_star * 128u + static_cast<uint32_t>(max(r_idx, 0));
-        // (S, pb: fp32 roundings of the float64 running prefix; a, b: fp32 sums of the tile's recomputed terms)
-        const CertLin ct = cert_correlated(S, pb, static_cast<double>(r_a), static_cast<double>(r_b), delta);
-        const bool ok = found_t && r_idx >= 0 && v < d.P && ct.valid &&
-                        (v == 0 || u_draw * ct.den_lo > ct.num_lo) &&
-                        (v == d.P - 1 || u_draw * ct.den_hi < ct.num_hi);
+        __builtin_amdgcn_wave_barrier();                                   // (the stage is rewritten by the next group)
+        const double S = static_cast<double>(rec.S), pb = static_cast<double>(rec.pb);
+        const float rems = static_cast<float>(rec.u * S - pb);
+        // ---- the tile's four chunks: logits on the matrix cores, then two lanes per user in the accumulator layout ----
+        const char* a_lane = reinterpret_cast<const char*>(d.gsplit) + (static_cast<size_t>(tile) * 128 + j) * RSc + 16 * h;
+        const float* mu_lane = d.mu32s + static_cast<size_t>(tile) * 128 + 4 * h;
+        int r_idx = -1;
+        float r_a = 0.0f, r_b = 0.0f, off = 0.0f;
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            f32x16 acc;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 m = *reinterpret_cast<const float4*>(mu_lane + 32 * c + 8 * gq);
+                acc[4 * gq] = m.x; acc[4 * gq + 1] = m.y; acc[4 * gq + 2] = m.z; acc[4 * gq + 3] = m.w;
+            }
+            bf16x8 A[N1];
+#pragma unroll
+            for (int m = 0; m < N1; ++m) A[m] = *reinterpret_cast<const bf16x8*>(a_lane + static_cast<size_t>(c) * 32 * RSc + 32 * m);
+            using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+#pragma unroll
+            for (int m = 0; m < N1; ++m)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[m]), __builtin_bit_cast(f16x8, Bm[m]), acc, 0, 0, 0);
+            // in-group inclusive prefixes (a group = 4 consecutive products: rows 8 gq + 4 h .. + 3), the groups' sums
+            float p[16], sg[4], so[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                p[4 * gq] = __builtin_amdgcn_exp2f(acc[4 * gq]);
+                p[4 * gq + 1] = p[4 * gq] + __builtin_amdgcn_exp2f(acc[4 * gq + 1]);
+                p[4 * gq + 2] = p[4 * gq + 1] + __builtin_amdgcn_exp2f(acc[4 * gq + 2]);
+                p[4 * gq + 3] = p[4 * gq + 2] + __builtin_amdgcn_exp2f(acc[4 * gq + 3]);
+                sg[gq] = p[4 * gq + 3];
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) so[gq] = swap32(sg[gq]);
+            // product order alternates the two lanes: group 2 gq + h; `run` = the sum of the groups before this lane's group gq
+            float run = off;
+            int ci = -1;
+            float ca = 0.0f, cb = 0.0f;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float base = h ? run + so[gq] : run;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = base + p[4 * gq + r];
+                    if (ci < 0 && x > rems) { ci = 32 * c + 8 * gq + 4 * h + r; cb = x; ca = r ? base + p[4 * gq + r - 1] : base; }
+                }
+                run += h ? so[gq] + sg[gq] : sg[gq] + so[gq];                 // (the same value on both lanes: lane 0's group first)
+            }
+            off = run;
+            // the user's first hit: the smaller product index of its two lanes'
+            const int oi = __builtin_bit_cast(int, swap32(__builtin_bit_cast(float, ci)));
+            const float oa = swap32(ca), ob = swap32(cb);
+            if (r_idx < 0) {
+                if (ci >= 0 && (oi < 0 || ci < oi)) { r_idx = ci; r_a = ca; r_b = cb; }
+                else if (oi >= 0) { r_idx = oi; r_a = oa; r_b = ob; }
+            }
+            if (__ballot(active && r_idx < 0) == 0ull) break;                // every user of the group has its product
+        }
+        const uint32_t v = tile * 128u + static_cast<uint32_t>(max(r_idx, 0));
+        // (S, pb: fp32 roundings of the sweep's float64 running prefix; a, b: fp32 sums of the tile's terms before / with v)
+        const CertLin ct = cert_correlated(S, pb, static_cast<double>(r_a), static_cast<double>(r_b), static_cast<double>(rec.dlt));
+        const bool ok = r_idx >= 0 && v < d.P && ct.valid &&
+                        (v == 0 || rec.u * ct.den_lo > ct.num_lo) &&
+                        (v == d.P - 1 || rec.u * ct.den_hi < ct.num_hi);
         if (active && h == 0) {
             if (ok) {
+                const uint32_t user = static_cast<uint32_t>(d.first_user + d.uid[slot]);
                 write_organic_row(d, t, pos, slot, user, v);
                 if (d.hist_cap) history_add(d, slot, v);
             } else {
                 const uint32_t xi = atomicAdd(&d.exact_cnt[t], 1u);
                 d.exact_list[xi] = pos;
-                d.exact_ref[xi] = q;
+                d.exact_ref[xi] = rec.q;
             }
         }
     }
@@ -399,6 +479,13 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
 draw_kernel_t tp_kernel_for(const DevSim& d) {
     if (!d.f16 || d.wide) return nullptr;
 #define RG_CASE(kh, a) if (d.KH == kh && d.N1 == a) return k_draw_tp<kh, a>;
+    RG_CASE(4, 1) RG_CASE(4, 2) RG_CASE(10, 2) RG_CASE(10, 3) RG_CASE(10, 4)
+#undef RG_CASE
+    return nullptr;
+}
+draw_kernel_t pick_kernel_for(const DevSim& d) {
+    if (!d.f16 || d.wide) return nullptr;
+#define RG_CASE(kh, a) if (d.KH == kh && d.N1 == a) return k_pick<kh, a>;
     RG_CASE(4, 1) RG_CASE(4, 2) RG_CASE(10, 2) RG_CASE(10, 3) RG_CASE(10, 4)
 #undef RG_CASE
     return nullptr;

@@ -595,11 +595,19 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         const int grid = sweep_grid(sim, static_cast<uint64_t>(tiles_up) * S, S);
         // (the search stays at the end of every user tile of the sweep: as its own kernel over the whole step — scratch slot
         // per user tile — the sweep got 15 % shorter and the step 6 % longer: profiles/r3/ab_call26_*, ab_call27_*)
-        if (S == 1 && sim->tp_kernel && sim->sweep_lds && !d.use_cache)
-            hipLaunchKernelGGL(sim->tp_kernel, dim3(grid), dim3(kBlock), sim->tp_smem, st, d, t, sim->tp_nts);
+        const bool tp = S == 1 && sim->tp_kernel && sim->sweep_lds && !d.use_cache;
+        if (tp) hipLaunchKernelGGL(sim->tp_kernel, dim3(grid), dim3(kBlock), sim->tp_smem, st, d, t, sim->tp_nts);
         else
         hipLaunchKernelGGL(sim->bf16_kernel, dim3(grid), dim3(sim->draw_threads), sim->bf16_smem, st, d, t, S);
         if (int rc = prof_mark(sim, st)) return rc;
+        if (tp) {
+            // k_pick: the step's draws in segments of 2^shift list positions, each sorted by tile in LDS (>= ~2 blocks per CU
+            // where the population allows; <= 16 384: the sort's index is 16 bits and 32 KB of LDS)
+            uint32_t shift = 11;
+            while (shift < 14 && (upper >> (shift + 1)) >= 640u) ++shift;
+            const size_t psmem = 4 * (128 + 1) * sizeof(uint32_t) + 16 + 4 * 32 * 2 * static_cast<size_t>(d.KH) * sizeof(float) + (static_cast<size_t>(2) << shift);
+            hipLaunchKernelGGL(sim->pick_kernel, dim3((upper + (1u << shift) - 1u) >> shift), dim3(kBlock), psmem, st, d, t, shift);
+        }
         if (S > 1)
             hipLaunchKernelGGL(search_kernel_for(d), dim3(grid_for(upper, 128)), dim3(kBlock),
                                sizeof(float) * 4 * 32 * 2 * d.KH, st, d, t);
@@ -1114,14 +1122,15 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     } else { d.XNH = d.XNL = d.XRS = 0; }
     // the sweep whose search stays in LDS (k_draw_tp): where every draw sweeps (no per-user cache) and the two-way fp16 split of
     // K <= 20 serves the table; a user's tile prefixes must fit beside the tiles (P <= ~12 000 at two blocks per CU)
-    s->tp_kernel = nullptr; s->tp_smem = 0; s->tp_nts = 0; s->sweep_lds = 1;
+    s->tp_kernel = nullptr; s->pick_kernel = nullptr; s->tp_smem = 0; s->tp_nts = 0; s->sweep_lds = 1;
     if (const char* e = getenv("RECOGYM_SWEEP_LDS")) s->sweep_lds = e[0] != '0';
     if (d.use_mfma == 2 && !d.use_cache && s->bf16_kernel && s->bf16_kernel == bf16p_kernel_for(d) && d.f16 && !d.wide) {
-        if (draw_kernel_t kt = tp_kernel_for(d)) {
+        draw_kernel_t kt = tp_kernel_for(d), kp = pick_kernel_for(d);
+        if (kt && kp && d.tp_rec) {
             const uint32_t nts = ((d.n_chunks / 4) + 3u) & ~3u;
             const size_t smem = 2 * (128 * static_cast<size_t>(d.RS) + 512) + 256 + 4 * 32 * static_cast<size_t>(nts) * sizeof(float);
-            if (smem <= 160 * 1024) {
-                s->tp_kernel = kt; s->tp_smem = smem; s->tp_nts = nts;
+            if (smem <= 160 * 1024 && d.n_chunks / 4 <= 128u) {          // (k_pick sorts a segment's draws into <= 128 tile bins)
+                s->tp_kernel = kt; s->pick_kernel = kp; s->tp_smem = smem; s->tp_nts = nts;
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
             }
         }

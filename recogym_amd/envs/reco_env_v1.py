@@ -231,6 +231,84 @@ def columns_to_dataframe(cols, num_products, with_ps_all=False):
     return pd.DataFrame(out, columns=['t', 'u', 'z', 'v', 'a', 'c', 'ps', 'ps-a'], copy=False)
 
 
+_RNG_TYPES = None
+
+
+def _rng_types():
+    global _RNG_TYPES
+    if _RNG_TYPES is None:
+        import random as _random
+        t = [np.random.RandomState, np.random.Generator, np.random.BitGenerator, _random.Random]
+        try:
+            t.append(torch.Generator)
+        except Exception:
+            pass
+        _RNG_TYPES = tuple(t)
+    return _RNG_TYPES
+
+
+def _walk_state(obj, depth=3, seen=None):
+    """The objects reachable from `obj` through instance attributes, lists, tuples and dict values (bounded depth)."""
+    seen = set() if seen is None else seen
+    if id(obj) in seen or depth < 0:
+        return
+    seen.add(id(obj))
+    yield obj
+    if isinstance(obj, (str, bytes, int, float, bool, type(None), np.ndarray, torch.Tensor)):
+        return
+    kids = []
+    if isinstance(obj, dict):
+        kids = list(obj.values())
+    elif isinstance(obj, (list, tuple, set, frozenset)):
+        kids = list(obj)
+    elif hasattr(obj, '__dict__'):
+        kids = list(vars(obj).values())
+    for k in kids:
+        yield from _walk_state(k, depth - 1, seen)
+
+
+def batch_safe(agent):
+    """May `generate_logs` advance this agent B users at a time with a copy of it per user slot (_generate_logs_batched)?
+    The copies of an agent that owns a sequential random stream (EpsilonGreedy, NnIpsAgent, RandomAgent with its RandomState —
+    `random_agent.py:14-20`, `epsilon_greedy.py`) would all draw the SAME sequence: such agents keep the reference's one-user-
+    at-a-time loop, whose single stream is consumed sequentially as in `abstract.py:292-316`.  `agent.batch_safe = True / False`
+    overrides the inspection (an agent whose draws are addressed by user, or that does not care)."""
+    flag = getattr(agent, 'batch_safe', None)
+    if flag is not None:
+        return bool(flag)
+    rng = _rng_types()
+    for o in _walk_state(agent):
+        if isinstance(o, rng):
+            return False
+    return True
+
+
+def _shared_state_memo(agent):
+    """deepcopy memo that maps the agent's large read-only model state onto itself (shared by the per-slot copies)."""
+    memo = {}
+    for o in _walk_state(agent):
+        big_array = isinstance(o, np.ndarray) and o.nbytes >= (64 << 10)
+        big_tensor = isinstance(o, torch.Tensor) and o.numel() * o.element_size() >= (64 << 10)
+        model = isinstance(o, torch.nn.Module) or (hasattr(o, 'predict') and hasattr(o, 'get_params'))     # torch / sklearn estimators
+        if big_array or big_tensor or model:
+            memo[id(o)] = o
+    return memo
+
+
+def _approx_owned_bytes(agent, shared):
+    n = 256
+    for o in _walk_state(agent):
+        if id(o) in shared:
+            continue
+        if isinstance(o, np.ndarray):
+            n += o.nbytes
+        elif isinstance(o, torch.Tensor):
+            n += o.numel() * o.element_size()
+        else:
+            n += 64
+    return n
+
+
 class RecoEnv1(_EnvBase):
     """Drop-in for the object `gym.make('reco-gym-v1')` returns: a `gym.Env` subclass wherever gym is importable (like the
     reference's AbstractEnv, abstract.py:46-57), with `action_space = Discrete(num_products)` after init_gym (abstract.py:69)
@@ -469,9 +547,27 @@ class RecoEnv1(_EnvBase):
             if pol.get('ps_all') is not None:              # the agent's whole distribution per bandit row
                 df['ps-a'] = pd.Series(pol['ps_all'](df), dtype=object, copy=False)
             return df
-        if self._time_mode or getattr(use, 'per_user_path', False) or getattr(self.config, 'per_user_path', False):
+        if self._time_mode or getattr(use, 'per_user_path', False) or getattr(self.config, 'per_user_path', False) or \
+                not batch_safe(use):
             return self._generate_logs_per_user(num_offline_users, use, num_organic_offline_users, first_user_id)
         return self._generate_logs_batched(num_offline_users, use, num_organic_offline_users, first_user_id)
+
+    def close(self):
+        """Release the device simulators this environment keeps between calls (the per-user one and the batched one)."""
+        for name in ('_bat', '_seq'):
+            sim = getattr(self, name, None)
+            if sim is not None:
+                try:
+                    sim.close()
+                except Exception:
+                    pass
+                setattr(self, name, None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # -- any Python agent, B users per launch ------------------------------------------------------
     def _batch_sim(self, n):
@@ -501,9 +597,14 @@ class RecoEnv1(_EnvBase):
         total = num_offline_users + num_organic_offline_users
         org_below = first_user_id + num_organic_offline_users
         B = int(min(batch, max(total, 1)))
+        # a copy of the agent per user slot; large read-only model state (arrays, tensors, torch modules, fitted estimators) is
+        # SHARED between the copies, and what a copy still owns bounds the batch (64 MB of agent state per batch at most)
+        shared = _shared_state_memo(agent)
+        own = _approx_owned_bytes(agent, shared)
+        B = int(max(1, min(B, (64 << 20) // max(own, 1))))
         sim = self._batch_sim(B)
         sim.reseed(self.seed, self.seed)
-        agents = [deepcopy(agent) for _ in range(B)]
+        agents = [deepcopy(agent, dict(shared)) for _ in range(B)]
         acts_host = torch.zeros(sim.n_users, dtype=torch.int32).pin_memory()
         acts_dev = torch.zeros(sim.n_users, dtype=torch.int32, device=sim.device)
         acts_np = acts_host.numpy()
