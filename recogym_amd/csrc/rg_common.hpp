@@ -143,6 +143,9 @@ struct DevSim {
     float2* sc_scratch;       // [kMaxGrid*4 waves][kMaxSC][32] {sum, reference} of the MFMA draw kernel
     float* chunk_scratch;     // [kMaxGrid*4 waves][n_chunks][32] exp-sum of every 32-product chunk
     TpRec* tp_rec;            // [n_cap] k_draw_tp -> k_pick (null: the configuration has no k_draw_tp)
+    uint32_t* tp_hist;        // [128 + 4] draws of the step per 128-product tile (k_draw_tp counts, k_pick's last block clears), then
+                              // the blocks of k_pick that are done
+    uint32_t* tp_order;       // [n_chunks / 4][n_cap] list positions of the step's draws, by tile
     float* stats;             // [2*KH] max_p |Gamma[p][k]|, then max_p ||Gamma[p]||_2, max_p |mu_o[p]|
     // geometry of the MFMA draw kernel
     uint32_t KH;              // MFMA k-steps per chunk (each 32x32x2 step consumes 2 k); 0 = no MFMA path
@@ -641,8 +644,10 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     unsigned long long* run_ctl = w.take<unsigned long long>(4);
     const bool tp = g.F16 == 1 && g.KH <= 10 && !cache;          // k_draw_tp's classes (tp_kernel_for), every draw a sweep
     TpRec* tp_rec = w.take<TpRec>(tp ? n : 1);
+    uint32_t* tp_hist = w.take<uint32_t>(128 + 4);
+    uint32_t* tp_order = w.take<uint32_t>(tp ? static_cast<size_t>(g.n_chunks / 4) * n : 1);
     if (d) {
-        d->tp_rec = tp ? tp_rec : nullptr;
+        d->tp_rec = tp ? tp_rec : nullptr; d->tp_hist = tp_hist; d->tp_order = tp_order;
         d->ev = ev; d->run_ctl = run_ctl; d->run_ahead = 0; d->pv0 = pv0;
         d->phantom_ps = phantom_ps; d->utime = utime; d->phantom_time = phantom_time;
         d->drift_list = drift_list; d->drift_sig = drift_sig; d->drift_cnt = drift_cnt;

@@ -279,6 +279,14 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
             r.u = u_draw; r.S = Sf; r.pb = pbf; r.q = q; r.dlt = static_cast<float>(delta * 1.000001);      // (rounded up: the budget must not shrink)
             r.ti = found_t ? cnt : 0xFFFFFFFFu; r.pad = 0u;
             d.tp_rec[pos] = r;
+            if (found_t) {         // the step's draws BY TILE: k_pick takes 32 of one tile at a time
+                const uint32_t k = atomicAdd(&d.tp_hist[cnt], 1u);
+                d.tp_order[static_cast<size_t>(cnt) * d.n_cap + k] = pos;
+            } else {               // no tile (sums that overflowed, u S beyond the last prefix): float64
+                const uint32_t xi = atomicAdd(&d.exact_cnt[t], 1u);
+                d.exact_list[xi] = pos;
+                d.exact_ref[xi] = q;
+            }
         }
     }
 }
@@ -296,78 +304,46 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
 // (rows 8 g + 4 h + r of a chunk in register 4 g + r of lane (user, h)).  The certificate is search_and_emit's
 // (cert_correlated) with A = the tile's start.  ~1 400 vector instructions per 32 draws, no scratch.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kPickBins = 128;          // tiles a segment is sorted by (k_draw_tp's LDS holds <= ~100 tile prefixes per user)
+constexpr uint32_t kPickBins = 128;          // tiles the draws are grouped by (k_draw_tp's LDS holds <= ~100 tile prefixes per user)
 
 template <int KH, int N1>
-__global__ void __launch_bounds__(kBlock) k_pick(DevSim d, uint32_t t, uint32_t seg_shift) {
+__global__ void __launch_bounds__(kBlock, 4) k_pick(DevSim d, uint32_t t, uint32_t unused) {
     constexpr int K2 = 2 * KH;
     constexpr uint32_t RSc = 32 * N1 + 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const uint32_t SEG = 1u << seg_shift;
-    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);            // [kPickBins + 1] draws per tile (last bin: no tile)
-    uint32_t* start = hist + (kPickBins + 1);                          // [kPickBins + 1] first perm entry of the tile
-    uint32_t* cursor = start + (kPickBins + 1);                        // [kPickBins + 1]
-    uint32_t* gstart = cursor + (kPickBins + 1);                       // [kPickBins + 1] first group of the tile
-    float* om_stage = reinterpret_cast<float*>(gstart + (kPickBins + 1) + 4);   // [4 waves][32][K2]
-    unsigned short* perm = reinterpret_cast<unsigned short*>(om_stage + 4 * 32 * K2);   // [SEG] draws of the segment, by tile
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);            // [kPickBins] draws per tile
+    uint32_t* gstart = hist + kPickBins;                               // [kPickBins + 1] first group of the tile
+    float* om_stage = reinterpret_cast<float*>(gstart + kPickBins + 4);   // [4 waves][32][K2]
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const int j = lane & 31, h = lane >> 5;
-    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
-    const uint32_t n_pt = d.n_chunks / 4;
-    const uint32_t seg0 = blockIdx.x * SEG;
-    if (seg0 >= n_o) return;
-    const uint32_t n = min(SEG, n_o - seg0);
-    // ---- counting sort of the segment's draws by tile ----
-    for (uint32_t i = threadIdx.x; i <= kPickBins; i += kBlock) { hist[i] = 0u; cursor[i] = 0u; }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
-        const uint32_t ti = d.tp_rec[seg0 + i].ti;
-        atomicAdd(&hist[ti < n_pt && ti < kPickBins ? ti : kPickBins], 1u);
-    }
-    __syncthreads();
-    if (wave == 0) {           // exclusive scans over the bins: perm entries and groups of 32
-        uint32_t c0 = hist[lane], c1 = hist[64 + lane];
-        uint32_t g0 = (c0 + 31u) >> 5, g1 = (c1 + 31u) >> 5;
-        uint32_t sc = c0, sg = g0;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t yc = __shfl_up(sc, o), yg = __shfl_up(sg, o);
-            if (lane >= o) { sc += yc; sg += yg; }
-        }
-        const uint32_t tc = __shfl(sc, 63), tg = __shfl(sg, 63);
-        start[lane] = sc - c0; gstart[lane] = sg - g0;
-        uint32_t sc1 = c1, sg1 = g1;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t yc = __shfl_up(sc1, o), yg = __shfl_up(sg1, o);
-            if (lane >= o) { sc1 += yc; sg1 += yg; }
-        }
-        start[64 + lane] = tc + sc1 - c1; gstart[64 + lane] = tg + sg1 - g1;
-        if (lane == 63) { start[kPickBins] = tc + sc1; gstart[kPickBins] = tg + sg1; }
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += kBlock) {
-        const TpRec* rp = d.tp_rec + seg0 + i;
-        const uint32_t ti = rp->ti;
-        const uint32_t bin = ti < n_pt && ti < kPickBins ? ti : kPickBins;
-        if (bin == kPickBins) {            // no tile (sums that overflowed, u S beyond the last prefix): float64
-            const uint32_t xi = atomicAdd(&d.exact_cnt[t], 1u);
-            d.exact_list[xi] = seg0 + i;
-            d.exact_ref[xi] = rp->q;
-        } else perm[start[bin] + atomicAdd(&cursor[bin], 1u)] = static_cast<unsigned short>(i);
+    (void)unused;
+    // ---- the step's draws per tile (k_draw_tp counted them and listed them by tile): groups of 32 of one tile ----
+    if (wave == 0) {
+        const uint32_t c0 = d.tp_hist[lane], c1 = d.tp_hist[64 + lane];
+        hist[lane] = c0; hist[64 + lane] = c1;
+        const uint32_t g0 = (c0 + 31u) >> 5, g1 = (c1 + 31u) >> 5;
+        uint32_t sg = g0;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(sg, o); if (lane >= o) sg += y; }
+        const uint32_t tg = __shfl(sg, 63);
+        gstart[lane] = sg - g0;
+        uint32_t sg1 = g1;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(sg1, o); if (lane >= o) sg1 += y; }
+        gstart[64 + lane] = tg + sg1 - g1;
+        if (lane == 63) gstart[kPickBins] = tg + sg1;
     }
     __syncthreads();
     const uint32_t n_groups = gstart[kPickBins];
     float* omw = om_stage + wave * 32 * K2;
-    for (uint32_t g = wave; g < n_groups; g += kBlock / 64) {
+    for (uint32_t g = blockIdx.x * (kBlock / 64) + wave; g < n_groups; g += gridDim.x * (kBlock / 64)) {
         // the group's tile: the last bin whose first group is <= g (wave-uniform; bins with no draws have no groups)
         uint32_t lo = 0, hi = kPickBins;
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (gstart[mid] <= g) lo = mid; else hi = mid; }
         const uint32_t tile = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lo)));
         const uint32_t gi = g - gstart[tile];
-        const uint32_t first = start[tile] + 32u * gi;
         const uint32_t cnt = min(32u, hist[tile] - 32u * gi);
         const bool active = static_cast<uint32_t>(j) < cnt;
-        const uint32_t pos = seg0 + (active ? perm[first + j] : perm[first]);
+        const uint32_t pos = d.tp_order[static_cast<size_t>(tile) * d.n_cap + 32u * gi + (active ? j : 0)];
         const uint32_t slot = cur[pos];
         const TpRec rec = d.tp_rec[pos];
         // ---- omega32 of the 32 users -> the wave's stage -> B fragments [w1 | w1 | w2 | 0 .. | -q] (as the sweep built them) ----
@@ -405,21 +381,27 @@ __global__ void __launch_bounds__(kBlock) k_pick(DevSim d, uint32_t t, uint32_t 
         const float* mu_lane = d.mu32s + static_cast<size_t>(tile) * 128 + 4 * h;
         int r_idx = -1;
         float r_a = 0.0f, r_b = 0.0f, off = 0.0f;
-#pragma unroll 1
-        for (int c = 0; c < 4; ++c) {
-            f32x16 acc;
+        // (a chunk's operands are requested a chunk ahead: the loop is a chain of L2 round trips otherwise)
+        using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+        f32x16 acc_n;
+        bf16x8 A_n[N1];
+        auto fetch_chunk = [&](int c) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const float4 m = *reinterpret_cast<const float4*>(mu_lane + 32 * c + 8 * gq);
-                acc[4 * gq] = m.x; acc[4 * gq + 1] = m.y; acc[4 * gq + 2] = m.z; acc[4 * gq + 3] = m.w;
+                acc_n[4 * gq] = m.x; acc_n[4 * gq + 1] = m.y; acc_n[4 * gq + 2] = m.z; acc_n[4 * gq + 3] = m.w;
             }
-            bf16x8 A[N1];
 #pragma unroll
-            for (int m = 0; m < N1; ++m) A[m] = *reinterpret_cast<const bf16x8*>(a_lane + static_cast<size_t>(c) * 32 * RSc + 32 * m);
-            using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+            for (int m = 0; m < N1; ++m) A_n[m] = *reinterpret_cast<const bf16x8*>(a_lane + static_cast<size_t>(c) * 32 * RSc + 32 * m);
+        };
+        fetch_chunk(0);
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A_n[0]), __builtin_bit_cast(f16x8, Bm[0]), acc_n, 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < N1; ++m)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[m]), __builtin_bit_cast(f16x8, Bm[m]), acc, 0, 0, 0);
+            for (int m = 1; m < N1; ++m)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A_n[m]), __builtin_bit_cast(f16x8, Bm[m]), acc, 0, 0, 0);
+            if (c < 3) fetch_chunk(c + 1);         // (the MFMAs above have read their operands: the registers take the next chunk's)
             // in-group inclusive prefixes (a group = 4 consecutive products: rows 8 gq + 4 h .. + 3), the groups' sums
             float p[16], sg[4], so[4];
 #pragma unroll
@@ -472,6 +454,15 @@ __global__ void __launch_bounds__(kBlock) k_pick(DevSim d, uint32_t t, uint32_t 
                 d.exact_list[xi] = pos;
                 d.exact_ref[xi] = rec.q;
             }
+        }
+    }
+    // the last block to finish leaves the counters empty for the next step's sweep (every block read them before its loop)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&d.tp_hist[kPickBins], 1u) == gridDim.x - 1u) {
+            for (uint32_t i = 0; i <= kPickBins; ++i) d.tp_hist[i] = 0u;
+            __threadfence();
         }
     }
 }

@@ -247,7 +247,7 @@ def _rng_types():
     return _RNG_TYPES
 
 
-def _walk_state(obj, depth=3, seen=None):
+def _walk_state(obj, depth=6, seen=None):
     """The objects reachable from `obj` through instance attributes, lists, tuples and dict values (bounded depth)."""
     seen = set() if seen is None else seen
     if id(obj) in seen or depth < 0:

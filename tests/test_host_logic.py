@@ -518,3 +518,45 @@ def test_weight_history_function_in_the_logreg_training_feed_and_act():
         sess = OrganicSessions()
         checked += 1
     assert checked > 3000
+
+
+def test_generate_logs_batches_only_agents_without_a_sequential_stream_of_their_own():
+    """`generate_logs` may advance an arbitrary Python agent B users at a time with a COPY of it per user slot
+    only where the copies cannot share a random stream — an agent that owns a RandomState / Generator (the reference's
+    RandomAgent, EpsilonGreedy, NnIpsAgent: `random_agent.py:14-20`) keeps the reference's one-user-at-a-time loop, whose
+    single stream is consumed sequentially (`abstract.py:292-316`); `agent.batch_safe` overrides the inspection.  The copies
+    share large read-only model state instead of multiplying it by the batch size."""
+    from copy import deepcopy
+    from recogym_amd.envs.reco_env_v1 import batch_safe, _shared_state_memo, _approx_owned_bytes
+
+    class Streamed:
+        def __init__(self):
+            self.rng = np.random.RandomState(3)
+
+    class Nested:
+        def __init__(self):
+            self.policy = {'explore': [Streamed()]}
+
+    class Generator:
+        def __init__(self):
+            self.g = np.random.default_rng(5)
+
+    class Model:
+        def __init__(self):
+            self.coef = np.zeros((1000, 100))
+            self.counts = np.zeros(4)
+
+    assert not batch_safe(Streamed()) and not batch_safe(Nested()) and not batch_safe(Generator())
+    assert batch_safe(Model())
+    s = Streamed(); s.batch_safe = True
+    m = Model(); m.batch_safe = False
+    assert batch_safe(s) and not batch_safe(m)
+    m = Model()
+    memo = _shared_state_memo(m)
+    c = deepcopy(m, dict(memo))
+    assert c.coef is m.coef and c.counts is not m.counts           # 800 KB shared, the per-user state owned
+    assert _approx_owned_bytes(m, memo) < 4096
+    # the framework's own agents draw by address (user, t): batch-safe by construction
+    from recogym_amd.agents import RandomAgent, OrganicUserEventCounterAgent
+    from recogym_amd.envs.configuration import Configuration
+    assert batch_safe(RandomAgent(Configuration({'num_products': 10, 'random_seed': 1, 'with_ps_all': True})))
