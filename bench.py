@@ -203,13 +203,21 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
         tf = 2.0 * P * K * swept / (prof['draw_mfma_ms'] * 1e-3) / 1e12
         peak = F16_MFMA_PEAK_TFLOPS if K <= 64 else FP32_MFMA_PEAK_TFLOPS
         exp_ms = 1e3 * float(P) * swept / EXP_PEAK_PER_S
-        out['draw_sweep'] = dict(kernel=('k_sweep_xh' if (cached and K <= 20 and os.environ.get('RECOGYM_XH', '1') != '0') else 'k_draw_bf16p') if K <= 21 else 'k_draw_* (K class)', bound='mfma',
+        tp = (not cached) and K <= 20 and prof.get('sweep_lds', 0) and prof['draw_search_ms'] > 0
+        out['draw_sweep'] = dict(kernel=('k_sweep_xh' if (cached and K <= 20 and os.environ.get('RECOGYM_XH', '1') != '0') else
+                                         ('k_draw_tp (unsliced rounds; k_draw_bf16p the sliced ones)' if tp else 'k_draw_bf16p')) if K <= 21 else 'k_draw_* (K class)', bound='mfma',
                                  ms=round(prof['draw_mfma_ms'], 2), units=int(swept), unit_name='swept draws',
                                  achieved=round(tf, 2), peak=peak, unit='TFLOP/s', frac=round(tf / peak, 4),
                                  executed_mfma_tflops=round(tf * ((112.0 if K > 8 else 48.0) if (cached and K <= 20 and os.environ.get('RECOGYM_XH', '1') != '0')
                                                                   else (64.0 if f16_split else 144.0)) / K, 1) if K <= 21 else None,
                                  # one v_exp_f32 per logit at a quarter of the fp32 lane rate: the kernel's real ceiling
                                  exp_bound_ms=round(exp_ms, 2), frac_of_exp_bound=round(exp_ms / prof['draw_mfma_ms'], 4))
+        if tp:
+            # k_pick: the draw inside its 128-product tile on the matrix cores, 32 draws of one tile per wave: 2 x 128 x K flop per draw
+            tfp = 2.0 * 128 * K * swept / (prof['draw_search_ms'] * 1e-3) / 1e12
+            out['draw_pick'] = dict(kernel='k_pick (+ k_draw_search on sliced rounds)', bound='mfma', ms=round(prof['draw_search_ms'], 2), units=int(swept),
+                                    unit_name='draws', achieved=round(tfp, 3), peak=peak, unit='TFLOP/s', frac=round(tfp / peak, 5),
+                                    note='latency-bound: a wave per 32 draws of one tile, ~9 dependent round trips per group')
     walked = prof.get('walk1_ms', 0.0) > 0
     b_survey = survey_bytes_per_event(cfg, pol)
     # the user-major walk (sigma_omega = 0, run to the end).  `bytes_per_unit` is SURVEY.md 8d's figure; what the
@@ -373,6 +381,19 @@ def main():
         users_total = args.users or total
         first_user, users = parallel.shard_range(users_total, rank, world)
 
+    # N > 1: what every rank saw of the job — world size as torch.distributed reports it, its device — so that the line of a real
+    # multi-GPU run proves the collective spanned N ranks on N devices
+    rank_info = None
+    if dist:
+        mine = dict(rank=rank, world_size=int(dist.get_world_size()), backend=str(dist.get_backend()), device=str(device),
+                    device_name=torch.cuda.get_device_name(device), host=os.uname().nodename)
+        try:
+            mine['pci_bus_id'] = str(torch.cuda.get_device_properties(device).pci_bus_id)
+        except Exception:
+            pass
+        rank_info = [None] * world
+        dist.all_gather_object(rank_info, mine)
+
     def build(workload, n):
         cfg = make_config(workload)
         log_rows = 0 if args.no_log else default_log_capacity(cfg, n)
@@ -450,6 +471,10 @@ def main():
                 s.run()
                 c = s.counters()
             prof = s.profile()
+            try:
+                prof['sweep_lds'] = s.get_option('sweep_lds_kernel') and s.get_option('sweep_lds')
+            except Exception:
+                prof['sweep_lds'] = 0
             s.set_profiling(False)
             counters.append((c, prof))
             arm_pol = name if name in ('ouc', 'random', 'none') else name
@@ -551,20 +576,21 @@ def main():
     drift = None
     if args.workload == 'c3' and not args.no_drift_line:
         dcfg, darms = build('c3drift', users)
-        d_el, d_tot, d_last = timed(darms, 1, 1)
+        d_steps = 2
+        d_el, d_tot, d_last = timed(darms, d_steps, 1)
         if rank == 0:
             d_counters, d_k = profile(darms, dcfg)
             d_c = d_counters[0][0]
             drift = dict(workload='c3drift: the same with sigma_omega=0.1 (omega drifts at every organic transition)',
-                         value=float(d_tot[0] + d_tot[1]) / d_el, unit='events/s', ms_per_step=1e3 * d_el,
-                         steps=1, warmup=1, kernels=d_k,
+                         value=float(d_tot[0] + d_tot[1]) / d_el, unit='events/s', ms_per_step=1e3 * d_el / d_steps,
+                         steps=d_steps, warmup=1, kernels=d_k,
                          exact_fraction=round(d_c['exact_draws'] / max(d_c['organic'], 1), 5))
         for _, s in darms:
             s.close()
         del darms
         torch.cuda.empty_cache()
 
-    # --- the other BASELINE configurations, one timed step each (after one warm-up), so that the driver's clock sees them too:
+    # --- the other BASELINE configurations, three timed steps each (after one warm-up), so that the driver's clock sees them too:
     # config 2, one rank's share of config 4, config 5 (both arms) — compact entries: value, ms per step, the kernel with the most time ---
     others = None
     if args.workload == 'c3' and world == 1 and not args.no_other_workloads and not args.shard:
@@ -573,14 +599,15 @@ def main():
         for wl in ('c2', 'c4shard', 'c5'):
             first_user, users = 0, WORKLOADS[wl][1]
             ocfg, oarms = build(wl, users)
-            o_el, o_tot, o_last = timed(oarms, 1, 1)
+            o_steps = 3
+            o_el, o_tot, o_last = timed(oarms, o_steps, 1)
             for c in o_last:
                 assert c['hist_overflow'] == 0 and c['log_dropped'] == 0 and c['live'] == 0 and c['exact_overflow'] == 0, c
             _, o_k = profile(oarms, ocfg)
             o_dom = max(o_k, key=lambda k: o_k[k]['ms'])
             others[wl] = dict(workload=f'{wl}: reco-gym-v1 P={ocfg.num_products} K={ocfg.K} sigma_omega={ocfg.sigma_omega} policy={WORKLOADS[wl][3]}',
-                              users=users, value=float(o_tot[0] + o_tot[1]) / o_el, unit='events/s', ms_per_step=round(1e3 * o_el, 2),
-                              events_per_step=int(o_tot[0] + o_tot[1]), steps=1, warmup=1,
+                              users=users, value=float(o_tot[0] + o_tot[1]) / o_el, unit='events/s', ms_per_step=round(1e3 * o_el / o_steps, 2),
+                              events_per_step=int(o_tot[0] + o_tot[1]) // o_steps, steps=o_steps, warmup=1,
                               dominant=o_dom, dominant_kernel=o_k[o_dom]['kernel'], dominant_ms=o_k[o_dom]['ms'],
                               dominant_bound=o_k[o_dom]['bound'], dominant_frac=o_k[o_dom].get('frac'),
                               frac_of_exp_bound=o_k[o_dom].get('frac_of_exp_bound'),
@@ -669,7 +696,17 @@ def main():
             'other_workloads': others,
             'cpu_baseline': cpu,
         }
+        if materialise is not None:
+            # the reference's generate_logs returns ORDERED rows (abstract.py:299-327): the same figure with rg_sim_sort_log on the
+            # whole log of a step inside it (the sort is timed on the benched run's log, second call)
+            ms_ord = 1e3 * elapsed / args.steps + materialise['sort_log_ms']
+            out['value_ordered'] = (events / args.steps) / (ms_ord * 1e-3)
+            out['ms_per_step_ordered'] = ms_ord
+        if roofline is not None and kernels and 'issue_roofline' in kernels.get('walk', {}):
+            roofline['issue_frac'] = kernels['walk']['issue_roofline']['frac']          # (the walk's vector-issue roofline beside its HBM one)
+            roofline['issue_bound_ms'] = kernels['walk']['issue_roofline']['issue_bound_ms']
         if world > 1:
+            out['ranks'] = rank_info
             out['per_rank_ms_per_step'] = ranks_ms
             out['other_scaling'] = other
             out['allreduce_us'] = None if allreduce is None else allreduce['median_us']

@@ -99,6 +99,13 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // step's organic list: the draw's uniform, the total and the prefix at the start of the draw's 128-product tile (fp32 roundings of
 // the float64 running prefix), the reference and the certificate's delta, the tile (>= n_tiles: no tile found — float64).
 struct TpRec { double u; float S, pb, q, dlt; uint32_t ti, pad; };
+// ... followed in the same record by the user's omega32 (2 KH floats: what k_pick builds its B operands from) — a record is one
+// 128-byte line at K <= 20 (64 bytes at K <= 8).  The draws of a step are counted and listed per (tile, shard): a device-scope
+// atomic on ONE address sustains ~6 M/s on this chip (measured: 264 M draws over 79 counters ran at the atomics' rate,
+// profiles/r6/ab_call3_tp.jsonl), so every tile has kTpShards counters, taken by work item modulo kTpShards.
+constexpr uint32_t kTpShards = 16, kTpBins = 128;
+__host__ __device__ constexpr uint32_t tp_rec_stride(uint32_t KH) { return (32u + 8u * KH + 63u) & ~63u; }                     // bytes
+inline uint32_t tp_shard_cap(uint64_t n) { return static_cast<uint32_t>((((n + 127) / 128 + kTpShards - 1) / kTpShards) * 128); }   // draws of one (tile, shard) at most
 
 // Everything a kernel needs, passed by value.
 struct DevSim {
@@ -142,10 +149,11 @@ struct DevSim {
     uint32_t exact_last;      // this is the last batch launched for the step
     float2* sc_scratch;       // [kMaxGrid*4 waves][kMaxSC][32] {sum, reference} of the MFMA draw kernel
     float* chunk_scratch;     // [kMaxGrid*4 waves][n_chunks][32] exp-sum of every 32-product chunk
-    TpRec* tp_rec;            // [n_cap] k_draw_tp -> k_pick (null: the configuration has no k_draw_tp)
-    uint32_t* tp_hist;        // [128 + 4] draws of the step per 128-product tile (k_draw_tp counts, k_pick's last block clears), then
-                              // the blocks of k_pick that are done
-    uint32_t* tp_order;       // [n_chunks / 4][n_cap] list positions of the step's draws, by tile
+    char* tp_rec;             // [n_cap][tp_rec_stride] k_draw_tp -> k_pick: {TpRec, omega32} (null: the configuration has no k_draw_tp)
+    uint32_t* tp_hist;        // [kTpBins x kTpShards + 4] draws of the step per (128-product tile, shard) (k_draw_tp counts, k_pick's last
+                              // block clears), then the blocks of k_pick that are done
+    uint32_t* tp_order;       // [n_chunks / 4][kTpShards][tp_cap] list positions of the step's draws, by tile and shard
+    uint32_t tp_cap;
     float* stats;             // [2*KH] max_p |Gamma[p][k]|, then max_p ||Gamma[p]||_2, max_p |mu_o[p]|
     // geometry of the MFMA draw kernel
     uint32_t KH;              // MFMA k-steps per chunk (each 32x32x2 step consumes 2 k); 0 = no MFMA path
@@ -643,11 +651,11 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint32_t* pv0 = w.take<uint32_t>(c.env_kind ? n : 1);
     unsigned long long* run_ctl = w.take<unsigned long long>(4);
     const bool tp = g.F16 == 1 && g.KH <= 10 && !cache;          // k_draw_tp's classes (tp_kernel_for), every draw a sweep
-    TpRec* tp_rec = w.take<TpRec>(tp ? n : 1);
-    uint32_t* tp_hist = w.take<uint32_t>(128 + 4);
-    uint32_t* tp_order = w.take<uint32_t>(tp ? static_cast<size_t>(g.n_chunks / 4) * n : 1);
+    char* tp_rec = w.take<char>(tp ? static_cast<size_t>(n) * tp_rec_stride(g.KH) : 1);
+    uint32_t* tp_hist = w.take<uint32_t>(kTpBins * kTpShards + 4);
+    uint32_t* tp_order = w.take<uint32_t>(tp ? static_cast<size_t>(g.n_chunks / 4) * kTpShards * tp_shard_cap(n) : 1);
     if (d) {
-        d->tp_rec = tp ? tp_rec : nullptr; d->tp_hist = tp_hist; d->tp_order = tp_order;
+        d->tp_rec = tp ? tp_rec : nullptr; d->tp_hist = tp_hist; d->tp_order = tp_order; d->tp_cap = tp_shard_cap(n);
         d->ev = ev; d->run_ctl = run_ctl; d->run_ahead = 0; d->pv0 = pv0;
         d->phantom_ps = phantom_ps; d->utime = utime; d->phantom_time = phantom_time;
         d->drift_list = drift_list; d->drift_sig = drift_sig; d->drift_cnt = drift_cnt;

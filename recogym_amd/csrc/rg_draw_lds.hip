@@ -80,6 +80,12 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
         const float Ahat = ahat_of(d, mumax, g2max, absdot, sq);
         const double delta_fixed = kDeltaFixedBf16 + f16_extra_delta(d, Ahat, absw);
         if (h == 0) for (uint32_t i = n_pt; i < NTs; ++i) trow[i] = INFINITY;        // (row padding: never counted)
+        char* recp = d.tp_rec + static_cast<size_t>(active ? pos : 0u) * tp_rec_stride(KH);
+        if (active) {              // omega32 behind the record's header: k_pick's B operands (each lane its half)
+            float* rw = reinterpret_cast<float*>(recp + sizeof(TpRec)) + h * KH;
+#pragma unroll
+            for (int s = 0; s < KH; ++s) rw[s] = omu[h * KH + s];
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         // ---- B fragments: [w1 | w1 | w2 | 0 .. | -q] ----
@@ -278,10 +284,11 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
             TpRec r;
             r.u = u_draw; r.S = Sf; r.pb = pbf; r.q = q; r.dlt = static_cast<float>(delta * 1.000001);      // (rounded up: the budget must not shrink)
             r.ti = found_t ? cnt : 0xFFFFFFFFu; r.pad = 0u;
-            d.tp_rec[pos] = r;
-            if (found_t) {         // the step's draws BY TILE: k_pick takes 32 of one tile at a time
-                const uint32_t k = atomicAdd(&d.tp_hist[cnt], 1u);
-                d.tp_order[static_cast<size_t>(cnt) * d.n_cap + k] = pos;
+            *reinterpret_cast<TpRec*>(recp) = r;
+            if (found_t) {         // the step's draws BY TILE (and shard: the work item's): k_pick takes 32 of one list at a time
+                const uint32_t bs = cnt * kTpShards + (tb % kTpShards);
+                const uint32_t k = atomicAdd(&d.tp_hist[bs], 1u);
+                d.tp_order[static_cast<size_t>(bs) * d.tp_cap + k] = pos;
             } else {               // no tile (sums that overflowed, u S beyond the last prefix): float64
                 const uint32_t xi = atomicAdd(&d.exact_cnt[t], 1u);
                 d.exact_list[xi] = pos;
@@ -304,57 +311,62 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
 // (rows 8 g + 4 h + r of a chunk in register 4 g + r of lane (user, h)).  The certificate is search_and_emit's
 // (cert_correlated) with A = the tile's start.  ~1 400 vector instructions per 32 draws, no scratch.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kPickBins = 128;          // tiles the draws are grouped by (k_draw_tp's LDS holds <= ~100 tile prefixes per user)
+constexpr uint32_t kPickLists = kTpBins * kTpShards;      // (tile, shard) lists of a step's draws
 
 template <int KH, int N1>
 __global__ void __launch_bounds__(kBlock, 4) k_pick(DevSim d, uint32_t t, uint32_t unused) {
     constexpr int K2 = 2 * KH;
     constexpr uint32_t RSc = 32 * N1 + 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);            // [kPickBins] draws per tile
-    uint32_t* gstart = hist + kPickBins;                               // [kPickBins + 1] first group of the tile
-    float* om_stage = reinterpret_cast<float*>(gstart + kPickBins + 4);   // [4 waves][32][K2]
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);            // [kPickLists] draws per (tile, shard)
+    uint32_t* gstart = hist + kPickLists;                              // [kPickLists + 1] first group of the list
+    float* om_stage = reinterpret_cast<float*>(gstart + kPickLists + 4);   // [4 waves][32][K2]
+    __shared__ uint32_t wave_tot[kBlock / 64];
+    __shared__ uint32_t last_flag;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     const int j = lane & 31, h = lane >> 5;
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
     (void)unused;
-    // ---- the step's draws per tile (k_draw_tp counted them and listed them by tile): groups of 32 of one tile ----
-    if (wave == 0) {
-        const uint32_t c0 = d.tp_hist[lane], c1 = d.tp_hist[64 + lane];
-        hist[lane] = c0; hist[64 + lane] = c1;
-        const uint32_t g0 = (c0 + 31u) >> 5, g1 = (c1 + 31u) >> 5;
-        uint32_t sg = g0;
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(sg, o); if (lane >= o) sg += y; }
-        const uint32_t tg = __shfl(sg, 63);
-        gstart[lane] = sg - g0;
-        uint32_t sg1 = g1;
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(sg1, o); if (lane >= o) sg1 += y; }
-        gstart[64 + lane] = tg + sg1 - g1;
-        if (lane == 63) gstart[kPickBins] = tg + sg1;
+    // ---- the step's draws per list (k_draw_tp counted and listed them): groups of 32 of one list; exclusive scan of the groups ----
+    {
+        constexpr uint32_t PER = kPickLists / kBlock;                  // consecutive lists per thread
+        uint32_t c[PER], gsum = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < PER; ++i) { c[i] = d.tp_hist[threadIdx.x * PER + i]; hist[threadIdx.x * PER + i] = c[i]; gsum += (c[i] + 31u) >> 5; }
+        uint32_t sc = gsum;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(sc, o); if (lane >= o) sc += y; }
+        if (lane == 63) wave_tot[wave] = sc;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < wave; ++w) base += wave_tot[w];
+        uint32_t run = base + sc - gsum;
+#pragma unroll
+        for (uint32_t i = 0; i < PER; ++i) { gstart[threadIdx.x * PER + i] = run; run += (c[i] + 31u) >> 5; }
+        if (threadIdx.x == kBlock - 1) gstart[kPickLists] = run;
     }
     __syncthreads();
-    const uint32_t n_groups = gstart[kPickBins];
+    const uint32_t n_groups = gstart[kPickLists];
     float* omw = om_stage + wave * 32 * K2;
     for (uint32_t g = blockIdx.x * (kBlock / 64) + wave; g < n_groups; g += gridDim.x * (kBlock / 64)) {
-        // the group's tile: the last bin whose first group is <= g (wave-uniform; bins with no draws have no groups)
-        uint32_t lo = 0, hi = kPickBins;
+        // the group's list: the last one whose first group is <= g (wave-uniform; lists with no draws have no groups)
+        uint32_t lo = 0, hi = kPickLists;
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (gstart[mid] <= g) lo = mid; else hi = mid; }
-        const uint32_t tile = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lo)));
-        const uint32_t gi = g - gstart[tile];
-        const uint32_t cnt = min(32u, hist[tile] - 32u * gi);
+        const uint32_t lst = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lo)));
+        const uint32_t tile = lst / kTpShards;
+        const uint32_t gi = g - gstart[lst];
+        const uint32_t cnt = min(32u, hist[lst] - 32u * gi);
         const bool active = static_cast<uint32_t>(j) < cnt;
-        const uint32_t pos = d.tp_order[static_cast<size_t>(tile) * d.n_cap + 32u * gi + (active ? j : 0)];
+        const uint32_t pos = d.tp_order[static_cast<size_t>(lst) * d.tp_cap + 32u * gi + (active ? j : 0)];
         const uint32_t slot = cur[pos];
-        const TpRec rec = d.tp_rec[pos];
-        // ---- omega32 of the 32 users -> the wave's stage -> B fragments [w1 | w1 | w2 | 0 .. | -q] (as the sweep built them) ----
+        const char* recp = d.tp_rec + static_cast<size_t>(pos) * tp_rec_stride(KH);
+        const TpRec rec = *reinterpret_cast<const TpRec*>(recp);
+        // ---- omega32 of the 32 users (behind the record's header) -> the wave's stage -> B fragments [w1 | w1 | w2 | 0 .. | -q] (as
+        // the sweep built them) ----
         {
             float* o = omw + j * K2 + h * KH;
-            const double* om_row = d.omega + static_cast<size_t>(slot) * d.OMS;
+            const float* rw = reinterpret_cast<const float*>(recp + sizeof(TpRec)) + h * KH;
 #pragma unroll
-            for (int s = 0; s < KH; ++s) {
-                const uint32_t k = h * KH + s;
-                o[s] = k < d.K ? static_cast<float>(om_row[k]) : 0.0f;
-            }
+            for (int s = 0; s < KH; ++s) o[s] = rw[s];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -460,10 +472,12 @@ __global__ void __launch_bounds__(kBlock, 4) k_pick(DevSim d, uint32_t t, uint32
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        if (atomicAdd(&d.tp_hist[kPickBins], 1u) == gridDim.x - 1u) {
-            for (uint32_t i = 0; i <= kPickBins; ++i) d.tp_hist[i] = 0u;
-            __threadfence();
-        }
+        last_flag = atomicAdd(&d.tp_hist[kPickLists], 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last_flag) {
+        for (uint32_t i = threadIdx.x; i <= kPickLists; i += kBlock) d.tp_hist[i] = 0u;
+        __threadfence();
     }
 }
 

@@ -602,8 +602,8 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         if (int rc = prof_mark(sim, st)) return rc;
         if (tp) {
             // k_pick: a wave per 32 draws of one tile (the sweep listed the draws by tile), grid-stride over the groups
-            const size_t psmem = (2 * 128 + 8) * sizeof(uint32_t) + 4 * 32 * 2 * static_cast<size_t>(d.KH) * sizeof(float);
-            uint32_t pgrid = upper / 128u + 33u;                       // groups / 4 waves (<= 128 part-filled groups more)
+            const size_t psmem = (2 * kTpBins * kTpShards + 8) * sizeof(uint32_t) + 4 * 32 * 2 * static_cast<size_t>(d.KH) * sizeof(float);
+            uint32_t pgrid = upper / 128u + (d.n_chunks / 4) * kTpShards / 4u + 1u;      // groups / 4 waves (a part-filled group per (tile, shard))
             const uint32_t pcap = static_cast<uint32_t>(device_cus(sim)) * 4u;
             if (pgrid > pcap) pgrid = pcap;
             hipLaunchKernelGGL(sim->pick_kernel, dim3(pgrid), dim3(kBlock), psmem, st, d, t, 0u);
@@ -1480,7 +1480,7 @@ int rg_sim_reset_users(rg_sim* sim, uint64_t first_user_id, uint64_t n, uint64_t
     if (d.lr_dirty) HIP_TRY(hipMemsetAsync(d.lr_cnt, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
     if (d.sigma_omega != 0.0) HIP_TRY(hipMemsetAsync(d.drift_cnt, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
     HIP_TRY(hipMemsetAsync(d.counters, 0, sizeof(unsigned long long) * RG_CNT_N, st));
-    HIP_TRY(hipMemsetAsync(d.tp_hist, 0, sizeof(uint32_t) * (128 + 4), st));
+    HIP_TRY(hipMemsetAsync(d.tp_hist, 0, sizeof(uint32_t) * (kTpBins * kTpShards + 4), st));
     hipLaunchKernelGGL(k_reset_users, dim3(grid_for(n)), dim3(kBlock), 0, st, d);
     HIP_TRY(hipGetLastError());
     sim->t = 0;

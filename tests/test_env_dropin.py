@@ -555,6 +555,36 @@ def test_env0_test_agent_runs_on_the_device_path():
     assert q == recogym.test_agent(deepcopy(env), deepcopy(agent), 200, 400)
 
 
+class StreamedAgent(Agent):
+    """An agent with a sequential random stream of its own, like the reference's RandomAgent / EpsilonGreedy
+    (`random_agent.py:14-20`): its users must see ONE stream consumed in order, not a copy of it each."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.rng = np.random.RandomState(config.random_seed)
+
+    def act(self, observation, reward, done):
+        return {**super().act(observation, reward, done),
+                'a': int(self.rng.choice(self.config.num_products)), 'ps': 1.0 / self.config.num_products, 'ps-a': ()}
+
+
+def test_an_agent_with_its_own_random_stream_keeps_the_sequential_path():
+    """`generate_logs` batches B users per launch only for agents whose copies cannot share a random stream.
+    With a RandomState inside, the default route is the reference's one-user-at-a-time loop: consecutive users draw from ONE
+    stream (the batched path's per-slot copies would all replay the same draws), and the rows are those of the per-user path."""
+    over = dict(random_seed=92, num_products=14, K=4)
+    agent = StreamedAgent(Configuration({'num_products': 14, 'random_seed': 5}))
+    env = make_env(over)
+    a = env.generate_logs(60, deepcopy(agent))
+    b = make_env(over)._generate_logs_per_user(60, deepcopy(agent), 0)
+    pd.testing.assert_frame_equal(a, b)
+    # what batching would have done: every user slot replays the same stream
+    c = make_env(over)._generate_logs_batched(60, deepcopy(agent), 0)
+    first_acts = lambda df: [int(df[(df['u'] == u) & (df['z'] == 'bandit')]['a'].iloc[0]) for u in range(40)]
+    assert len(set(first_acts(c))) == 1 and len(set(first_acts(a))) > 3
+    env.close()
+
+
 @pytest.mark.parametrize('sizes', [(70, 0, 4096), (33, 5, 16), (3, 0, 1)])
 def test_batched_episode_path_equals_the_per_user_path_and_the_oracle(sizes):
     """`generate_logs(n, arbitrary agent)` drives B users per rg_sim_step launch (a copy of the agent per user slot): the rows of
