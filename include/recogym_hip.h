@@ -333,6 +333,10 @@ int rg_sim_export_time(rg_sim* sim, double* d_time, void* stream);
  * float64 resolve (n bytes). */
 int rg_sim_debug_set_omega(rg_sim* sim, const double* d_omega, void* stream);
 int rg_sim_debug_set_uniforms(rg_sim* sim, const double* d_u);
+/* rg_sim_debug_set_row_base: the raw log of every later reset range starts at row `rows` instead of 0 (rg_sim_reset_users marks
+ * the entries below it unused, so the attached log must hold them): the regression test of raw-row arithmetic beyond 2^31 rows
+ * (a full-size log reaches that line at ~20 M users of BASELINE config 3) without simulating 20 M users.  0 restores the default. */
+int rg_sim_debug_set_row_base(rg_sim* sim, uint64_t rows);
 int rg_sim_debug_uncertified(rg_sim* sim, uint8_t* d_flags, void* stream);
 
 /* ---- test hooks of the two "decide cheaply, float64 inside a band" paths of the user-major walk ----

@@ -110,6 +110,7 @@ SYMBOLS = {
     'rg_sim_export_time': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_debug_set_omega': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_debug_set_uniforms': (C.c_int, [_SIM, C.c_void_p]),
+    'rg_sim_debug_set_row_base': (C.c_int, [_SIM, C.c_uint64]),
     'rg_sim_debug_uncertified': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_debug_walk_fate': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_debug_click_decisions': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -281,6 +281,7 @@ struct DevSim {
     double* phantom_ps;       // [n_users] float64 propensity of the phantom row
     // test hooks (rg_sim_debug_*): per-user-index uniforms replacing the organic draw's u at the next step
     const double* u_override;
+    uint64_t debug_row_base;  // rg_sim_debug_set_row_base: first raw-log row of a reset range (0 outside that test)
     // reco-gym-v0 (env_kind = 1, reco_env_v0.py): the user's state is its current product view, every draw a table look-up
     uint32_t env_kind, e0_cluster;
     const double* e0_cdf_init; const double* e0_cdf_cluster; const double* e0_click_p; const double* e0_click_qn; const double* e0_click_px1;
@@ -727,6 +728,12 @@ __device__ __forceinline__ uint32_t prefix_in_mask(unsigned long long mask) {
 // a 64-bit value of the wave's first active lane, as a scalar (the builtin returns a SIGNED int: OR-ing its low word into a 64-bit
 // value without the cast sign-extends it — a raw-log row base beyond 2^31 rows, a mask with bit 31 set)
 __device__ __forceinline__ unsigned long long readfirstlane_u64(unsigned long long x) {
+#ifdef RG_TEST_SIGNED_RFL
+    // (A/B build of tests/test_hip_parity.py::test_raw_log_rows_beyond_2_31_are_kept only: round 5's bug put back, to show that the
+    // test sees it — the low word sign-extended into the high one)
+    return (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<int>(x >> 32))) << 32) |
+           static_cast<unsigned long long>(static_cast<long long>(__builtin_amdgcn_readfirstlane(static_cast<int>(x))));
+#endif
     const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(x)));
     const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(x >> 32)));
     return (static_cast<unsigned long long>(hi) << 32) | lo;

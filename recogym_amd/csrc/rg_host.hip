@@ -12,7 +12,7 @@ __global__ void __launch_bounds__(kBlock) k_reset_users(DevSim d) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         d.step_cnt[0] = d.n_users;   // everyone starts organic (abstract.py:93)
         d.step_cnt[1] = 0;
-        d.log_base[0] = 0;
+        d.log_base[0] = d.debug_row_base;
     }
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) {
         const uint32_t user = static_cast<uint32_t>(d.first_user + i);
@@ -174,7 +174,7 @@ __global__ void k_tail_finish(DevSim d, uint32_t t0) {
 // closes the books of a walked run: no lock-step step holds events; step 1 exists, is empty and starts after the raw rows
 __global__ void k_walk_finish(DevSim d) {
     d.step_cnt[0] = 0; d.step_cnt[1] = 0; d.step_cnt[2] = 0; d.step_cnt[3] = 0;
-    d.log_base[0] = 0;
+    d.log_base[0] = d.debug_row_base;
     d.log_base[1] = d.counters[kCntTailRows];
 }
 
@@ -679,6 +679,8 @@ int prof_collect(rg_sim* sim) {
 int run_walk(rg_sim* sim, hipStream_t st) {
     const DevSim& d = sim->d;
     (void)device_cus(sim);
+    if (d.debug_row_base)      // test hook: the walk reserves its raw rows from this counter
+        HIP_TRY(hipMemcpyAsync(d.counters + kCntTailRows, &sim->d.debug_row_base, sizeof(unsigned long long), hipMemcpyHostToDevice, st));
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     auto mark = [&](int i) -> int {
         if (!sim->profiling) return RG_OK;
@@ -826,6 +828,8 @@ walked:
 int run_walk_pipe(rg_sim* sim, hipStream_t st) {
     const DevSim& d = sim->d;
     const int n_cus = device_cus(sim);
+    if (d.debug_row_base)      // test hook: the walk reserves its raw rows from this counter
+        HIP_TRY(hipMemcpyAsync(d.counters + kCntTailRows, &sim->d.debug_row_base, sizeof(unsigned long long), hipMemcpyHostToDevice, st));
     const uint32_t n = d.n_users;
     // groups: equal sizes, multiples of 256 users, each large enough for the unsliced sweep (>= 1024 user tiles)
     uint32_t G = static_cast<uint32_t>(sim->pipe_groups);
@@ -1481,6 +1485,11 @@ int rg_sim_reset_users(rg_sim* sim, uint64_t first_user_id, uint64_t n, uint64_t
     if (d.sigma_omega != 0.0) HIP_TRY(hipMemsetAsync(d.drift_cnt, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
     HIP_TRY(hipMemsetAsync(d.counters, 0, sizeof(unsigned long long) * RG_CNT_N, st));
     HIP_TRY(hipMemsetAsync(d.tp_hist, 0, sizeof(uint32_t) * (kTpBins * kTpShards + 4), st));
+    if (d.debug_row_base && d.log) {       // test hook: the raw log starts at that row; what lies below is marked unused
+        if (d.debug_row_base > d.log_cap) return fail(RG_EINVAL, "debug row base %llu beyond the log capacity %llu",
+                                                      (unsigned long long)d.debug_row_base, (unsigned long long)d.log_cap);
+        HIP_TRY(hipMemsetAsync(d.log, 0xFF, sizeof(rg_event) * d.debug_row_base, st));
+    }
     hipLaunchKernelGGL(k_reset_users, dim3(grid_for(n)), dim3(kBlock), 0, st, d);
     HIP_TRY(hipGetLastError());
     sim->t = 0;
@@ -1686,6 +1695,12 @@ int rg_sim_export_time(rg_sim* sim, double* d_time, void* stream) {
     if (!sim || !d_time) return fail(RG_EINVAL, "NULL argument");
     hipLaunchKernelGGL(k_export_time, dim3(grid_for(sim->d.n_users)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), sim->d, sim->t, d_time);
     HIP_TRY(hipGetLastError());
+    return RG_OK;
+}
+
+int rg_sim_debug_set_row_base(rg_sim* sim, uint64_t rows) {
+    if (!sim) return fail(RG_EINVAL, "sim is NULL");
+    sim->d.debug_row_base = rows;
     return RG_OK;
 }
 

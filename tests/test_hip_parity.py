@@ -1278,3 +1278,47 @@ def test_sampled_oracle_parity_at_bench_size(workload, users):
         if workload in ('c3', 'c2'):
             k = line['kinds']
             assert k['float64_batch_and_round_2'] > 0 and k['finished_by_the_last_round'] > 0 and k['round_1_only'] > 0, k
+
+
+@pytest.mark.parametrize('form', ['walk_pipe', 'walk_pipe_solo', 'run_walk', 'k_walk', 'rounds', 'lockstep', 'tail'])
+def test_raw_log_rows_beyond_2_31_are_kept(form, monkeypatch):
+    """Raw-log row arithmetic past 2^31 rows (a full-size log gets there at ~20 M users of BASELINE config 3; round 5 found the
+    three walk kernels assembling a reserved row base from a SIGNED readfirstlane: every row of a chunk beyond 2^31 fell outside
+    the capacity check and was dropped, and no check ever saw it).  The test hook rg_sim_debug_set_row_base starts the raw log of
+    a few thousand users at row 2^31 - 4096, so that their rows straddle the line, for every kernel that reserves or addresses
+    raw rows: k_walk2 + k_walk_solo (run_walk_pipe / run_walk), k_walk, k_advance_run (rounds), k_advance (lock-step), k_tail.
+    Rows against the oracle, nothing dropped."""
+    from oracle import oracle as orc
+    from recogym_amd.sim import Simulator, default_log_capacity
+    for k in ('RECOGYM_DRAW', 'RECOGYM_WALK', 'RECOGYM_WALK_HANDOVER', 'RECOGYM_PIPE_MIN', 'RECOGYM_RUN_AHEAD', 'RECOGYM_TAIL', 'RECOGYM_PIPE'):
+        monkeypatch.delenv(k, raising=False)
+    sigma = 0.0
+    if form in ('walk_pipe', 'walk_pipe_solo'):
+        monkeypatch.setenv('RECOGYM_PIPE_MIN', '256')
+        if form == 'walk_pipe_solo':
+            monkeypatch.setenv('RECOGYM_WALK_HANDOVER', '64')
+    elif form == 'run_walk':
+        monkeypatch.setenv('RECOGYM_PIPE', '0')
+    elif form == 'k_walk':
+        monkeypatch.setenv('RECOGYM_WALK', '1')
+    else:
+        sigma = 0.1
+        monkeypatch.setenv('RECOGYM_RUN_AHEAD', '32' if form == 'rounds' else '0')
+        monkeypatch.setenv('RECOGYM_TAIL', '100000' if form == 'tail' else '0')
+    n = 3000
+    cfg = Configuration({**env_1_args, 'random_seed': 231, 'num_products': 200, 'K': 20, 'sigma_omega': sigma})
+    pol = dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=9)
+    base = (1 << 31) - 4096
+    cap = base + default_log_capacity(cfg, n)
+    sim = Simulator(cfg, n, device='cuda:0', log_capacity=cap, p_click=False, **pol)
+    _abi.check(sim.lib.rg_sim_debug_set_row_base(sim._h, base), 'debug_set_row_base')
+    sim.reset_users(0, n)
+    sim.run()
+    cnt = sim.counters()
+    rows = sim.rows()
+    sim.close()
+    torch.cuda.empty_cache()
+    assert cnt['log_dropped'] == 0 and cnt['log_rows'] > (1 << 31), cnt
+    want = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol).generate_logs(n)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps')}, ps_rtol=1e-12, what=f'row base 2^31 - 4096, {form}')
+    assert (rows['phantom'] == want['phantom']).all()
