@@ -20,6 +20,17 @@
 
 #include "rg_common.hpp"
 
+// -DRG_TP_ABL=bits: timing experiments on k_draw_tp (results wrong by design; A/B builds only, loaded with RECOGYM_HIP_LIB).
+// 1: no epilogue (uniform, tile count, record, list entry), 2: the first 8 product tiles only (what a work item costs besides its
+// tile loop), 4: exps replaced by a multiply, 8: no MFMAs, 16: no tile barrier / DMA beyond the first two tiles, 32: no books,
+// 64: no mu loads.  -DRG_PICK_ABL=bits on k_pick: 1: no row / history, 2: no chunk loop, 4: no next-group prefetch
+#ifndef RG_TP_ABL
+#define RG_TP_ABL 0
+#endif
+#ifndef RG_PICK_ABL
+#define RG_PICK_ABL 0
+#endif
+
 namespace rgk {
 
 template <int KH, int N1>
@@ -41,7 +52,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
     const uint32_t n_tiles = (n_o + 127) / 128;
     const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
     const float mumax = d.stats[2 * KH + 1], g2max = d.stats[2 * KH];
-    const uint32_t n_pt = d.n_chunks / 4;                             // product tiles
+    const uint32_t n_pt = (RG_TP_ABL & 2) ? min(d.n_chunks / 4, 8u) : d.n_chunks / 4;   // product tiles
     const uint32_t np = 2 * n_pt;                                     // pairs of chunks
     float* trow = tpref + static_cast<size_t>(wave * 32 + j) * NTs;   // this lane's user's prefixes
 
@@ -113,13 +124,16 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
             else o.A1[idx - N1 < N1 ? idx - N1 : 0] = *reinterpret_cast<const bf16x8*>(ab + 32 * RSc + 32 * (idx - N1));
         };
         auto load_mu = [&](f32x16& acc, const char* mb, int which, int qq) {   // mu quad qq, into the accumulator it seeds
+            if (RG_TP_ABL & 64) return;
             const float4 m = *reinterpret_cast<const float4*>(mb + 128 * which + 32 * qq);
             acc[4 * qq] = m.x; acc[4 * qq + 1] = m.y; acc[4 * qq + 2] = m.z; acc[4 * qq + 3] = m.w;
         };
         auto mm = [](const bf16x8& a, const bf16x8& b, const f32x16& c) -> f32x16 {
             using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+            if (RG_TP_ABL & 8) return c;
             return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
         };
+        auto ex2 = [](float x) -> float { return (RG_TP_ABL & 4) ? x * 0.5f : __builtin_amdgcn_exp2f(x); };
         using f32x2 = __attribute__((ext_vector_type(2))) float;
         // One pair (k_draw_bf16p's stream): MFMAs of (co) into (a0, a1), which already hold the pair's mu | exp-sum of
         // (p0, p1) -> (s0, s1) | A rows of pair pi_next -> no, its mu -> (p0, p1) once their exps are done
@@ -138,7 +152,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
                     for (int i = (2 * m) * (2 * N1) / (2 * EXS); i < (2 * m + 1) * (2 * N1) / (2 * EXS); ++i) load_a(no, ab, i);
 #pragma unroll
                     for (int e = (m * 8 / EXS) * 2; e < ((m + 1) * 8 / EXS) * 2; e += 2) {       // exps in pairs
-                        f32x2 y = {__builtin_amdgcn_exp2f(p0[e]), __builtin_amdgcn_exp2f(p0[e + 1])};
+                        f32x2 y = {ex2(p0[e]), ex2(p0[e + 1])};
                         asm volatile("" : "+v"(y));
                         if (e < 8) x0[e / 2] = y; else x0[(e / 2) & 3] += y;
                     }
@@ -154,7 +168,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
                     for (int i = (2 * m + 1) * (2 * N1) / (2 * EXS); i < (2 * m + 2) * (2 * N1) / (2 * EXS); ++i) load_a(no, ab, i);
 #pragma unroll
                     for (int e = (m * 8 / EXS) * 2; e < ((m + 1) * 8 / EXS) * 2; e += 2) {
-                        f32x2 y = {__builtin_amdgcn_exp2f(p1[e]), __builtin_amdgcn_exp2f(p1[e + 1])};
+                        f32x2 y = {ex2(p1[e]), ex2(p1[e + 1])};
                         asm volatile("" : "+v"(y));
                         if (e < 8) x1[e / 2] = y; else x1[(e / 2) & 3] += y;
                     }
@@ -185,6 +199,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
         double run_pref = 0.0;     // running prefix of the exp-sums (every lane of the user holds it)
         float wlo = 0.0f;
         auto book = [&](uint32_t pe, float s0, float s1) {    // sums of pair pe (chunks 2 pe, 2 pe + 1)
+            if (RG_TP_ABL & 32) { wlo += s0 + s1; return; }
             float s = s0 + s1;
             s += swap32(s);
             if (!(pe & 1)) { wlo = s; return; }
@@ -239,8 +254,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
             const uint32_t T = pi >> 1;
             // tile barrier: every wave holds tile T's operands (its buffer is refilled with tile T + 2); tile T + 1, whose DMA
             // went out at the last barrier, has landed (no other vector-memory operation is in flight in this loop)
-            RG_TILE_BARRIER(0);
-            if (T + 2 < n_pt) fetch_tile(T + 2);
+            if (!(RG_TP_ABL & 16)) RG_TILE_BARRIER(0);
+            if (T + 2 < n_pt && !(RG_TP_ABL & 16)) fetch_tile(T + 2);
             stream(ob, oa, pi + 1, p0, p1, a0, a1, s0, s1);                  // MFMAs of pair pi | sums of pair pi - 1
             book(pi - 1, s0, s1);
             stream(oa, ob, pi + 2, a0, a1, p0, p1, s0, s1);                  // MFMAs of pair pi + 1 | sums of pair pi
@@ -256,6 +271,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
         }
 
         // ---- what the search needs from here: the tile of the draw (a count in LDS) and five numbers; k_pick does the rest ----
+        if (RG_TP_ABL & 1) { if (active && h == 0 && run_pref + wlo == 12345.0) d.tp_rec[0] = 1; continue; }
         const uint32_t uidx = d.uid[slot];
         const uint32_t user = static_cast<uint32_t>(d.first_user + uidx);
         const double u_draw = organic_uniform(d, uidx, user, t);
@@ -313,8 +329,11 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kPickLists = kTpBins * kTpShards;      // (tile, shard) lists of a step's draws
 
+#ifndef RG_PICK_OCC
+#define RG_PICK_OCC 4
+#endif
 template <int KH, int N1>
-__global__ void __launch_bounds__(kBlock, 4) k_pick(DevSim d, uint32_t t, uint32_t unused) {
+__global__ void __launch_bounds__(kBlock, RG_PICK_OCC) k_pick(DevSim d, uint32_t t, uint32_t unused) {
     constexpr int K2 = 2 * KH;
     constexpr uint32_t RSc = 32 * N1 + 16;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -347,26 +366,43 @@ __global__ void __launch_bounds__(kBlock, 4) k_pick(DevSim d, uint32_t t, uint32
     __syncthreads();
     const uint32_t n_groups = gstart[kPickLists];
     float* omw = om_stage + wave * 32 * K2;
-    for (uint32_t g = blockIdx.x * (kBlock / 64) + wave; g < n_groups; g += gridDim.x * (kBlock / 64)) {
-        // the group's list: the last one whose first group is <= g (wave-uniform; lists with no draws have no groups)
+    // A group's chain of dependent loads — its list entry, then the user's slot and record — is requested one group AHEAD: the
+    // wave works on group g while the loads of group g + stride are in flight (the kernel is a wave per group and ~10 round
+    // trips per group otherwise: profiles/r6/ab_call4_tp.jsonl)
+    struct Grp { uint32_t lst, gi, cnt, pos, slot, uidx; TpRec rec; float w[KH]; };
+    auto locate = [&](uint32_t g, Grp& o) {        // the group's list: the last one whose first group is <= g (wave-uniform)
         uint32_t lo = 0, hi = kPickLists;
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (gstart[mid] <= g) lo = mid; else hi = mid; }
-        const uint32_t lst = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lo)));
-        const uint32_t tile = lst / kTpShards;
-        const uint32_t gi = g - gstart[lst];
-        const uint32_t cnt = min(32u, hist[lst] - 32u * gi);
+        o.lst = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lo)));
+        o.gi = g - gstart[o.lst];
+        o.cnt = min(32u, hist[o.lst] - 32u * o.gi);
+        o.pos = d.tp_order[static_cast<size_t>(o.lst) * d.tp_cap + 32u * o.gi + (static_cast<uint32_t>(j) < o.cnt ? j : 0)];
+    };
+    auto load_user = [&](Grp& o) {                 // (needs o.pos)
+        o.slot = cur[o.pos];
+        const char* recp = d.tp_rec + static_cast<size_t>(o.pos) * tp_rec_stride(KH);
+        o.rec = *reinterpret_cast<const TpRec*>(recp);
+        const float* rw = reinterpret_cast<const float*>(recp + sizeof(TpRec)) + h * KH;
+#pragma unroll
+        for (int s = 0; s < KH; ++s) o.w[s] = rw[s];
+    };
+    const uint32_t g_stride = gridDim.x * (kBlock / 64);
+    uint32_t g = blockIdx.x * (kBlock / 64) + wave;
+    Grp nx;
+    if (g < n_groups) { locate(g, nx); load_user(nx); nx.uidx = d.uid[nx.slot]; }
+    for (; g < n_groups; g += g_stride) {
+        const Grp cu = nx;
+        const uint32_t lst = cu.lst, tile = lst / kTpShards, cnt = cu.cnt, pos = cu.pos, slot = cu.slot;
         const bool active = static_cast<uint32_t>(j) < cnt;
-        const uint32_t pos = d.tp_order[static_cast<size_t>(lst) * d.tp_cap + 32u * gi + (active ? j : 0)];
-        const uint32_t slot = cur[pos];
-        const char* recp = d.tp_rec + static_cast<size_t>(pos) * tp_rec_stride(KH);
-        const TpRec rec = *reinterpret_cast<const TpRec*>(recp);
+        const TpRec rec = cu.rec;
+        const bool more = g + g_stride < n_groups;
+        if (more && !(RG_PICK_ABL & 4)) locate(g + g_stride, nx);        // (its list entry: in flight while this group's B operands are built)
         // ---- omega32 of the 32 users (behind the record's header) -> the wave's stage -> B fragments [w1 | w1 | w2 | 0 .. | -q] (as
         // the sweep built them) ----
         {
             float* o = omw + j * K2 + h * KH;
-            const float* rw = reinterpret_cast<const float*>(recp + sizeof(TpRec)) + h * KH;
 #pragma unroll
-            for (int s = 0; s < KH; ++s) o[s] = rw[s];
+            for (int s = 0; s < KH; ++s) o[s] = cu.w[s];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -386,6 +422,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_pick(DevSim d, uint32_t t, uint32
             if (h == 1) Bm[N1 - 1][7] = static_cast<short>(__builtin_bit_cast(unsigned short, static_cast<_Float16>(-rec.q)));
         }
         __builtin_amdgcn_wave_barrier();                                   // (the stage is rewritten by the next group)
+        if (more && !(RG_PICK_ABL & 4)) load_user(nx);                     // (in flight during this group's chunks)
         const double S = static_cast<double>(rec.S), pb = static_cast<double>(rec.pb);
         const float rems = static_cast<float>(rec.u * S - pb);
         // ---- the tile's four chunks: logits on the matrix cores, then two lanes per user in the accumulator layout ----
@@ -408,7 +445,7 @@ __global__ void __launch_bounds__(kBlock, 4) k_pick(DevSim d, uint32_t t, uint32
         };
         fetch_chunk(0);
 #pragma unroll 1
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < ((RG_PICK_ABL & 2) ? 0 : 4); ++c) {
             f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A_n[0]), __builtin_bit_cast(f16x8, Bm[0]), acc_n, 0, 0, 0);
 #pragma unroll
             for (int m = 1; m < N1; ++m)
@@ -456,9 +493,11 @@ __global__ void __launch_bounds__(kBlock, 4) k_pick(DevSim d, uint32_t t, uint32
         const bool ok = r_idx >= 0 && v < d.P && ct.valid &&
                         (v == 0 || rec.u * ct.den_lo > ct.num_lo) &&
                         (v == d.P - 1 || rec.u * ct.den_hi < ct.num_hi);
-        if (active && h == 0) {
+        if (more && (RG_PICK_ABL & 4)) { locate(g + g_stride, nx); load_user(nx); }
+        if (more) nx.uidx = d.uid[nx.slot];
+        if (active && h == 0 && !((RG_PICK_ABL & 1) && v != 0x7fffffffu)) {
             if (ok) {
-                const uint32_t user = static_cast<uint32_t>(d.first_user + d.uid[slot]);
+                const uint32_t user = static_cast<uint32_t>(d.first_user + cu.uidx);
                 write_organic_row(d, t, pos, slot, user, v);
                 if (d.hist_cap) history_add(d, slot, v);
             } else {
