@@ -23,7 +23,7 @@
 // -DRG_TP_ABL=bits: timing experiments on k_draw_tp (results wrong by design; A/B builds only, loaded with RECOGYM_HIP_LIB).
 // 1: no epilogue (uniform, tile count, record, list entry), 2: the first 8 product tiles only (what a work item costs besides its
 // tile loop), 4: exps replaced by a multiply, 8: no MFMAs, 16: no tile barrier / DMA beyond the first two tiles, 32: no books,
-// 64: no mu loads.  -DRG_PICK_ABL=bits on k_pick: 1: no row / history, 2: no chunk loop, 4: no next-group prefetch
+// 64: no mu loads.  -DRG_PICK_ABL=bits on k_pick: 1: no row / history, 2: no chunk loop
 #ifndef RG_TP_ABL
 #define RG_TP_ABL 0
 #endif
@@ -134,11 +134,30 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
             return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
         };
         auto ex2 = [](float x) -> float { return (RG_TP_ABL & 4) ? x * 0.5f : __builtin_amdgcn_exp2f(x); };
+        // ---- the books: one float64 add and one 4-byte LDS store per 128-product tile.  The sums of a pair are produced at the
+        // end of a stream() and BOOKED inside the next one, behind its first MFMA (`filler`): closed right where they are
+        // produced, behind the sums they depend on, they were 19 % of the kernel (profiles/r6/ab_call6_tp_ablation.jsonl) ----
+        double run_pref = 0.0;     // running prefix of the exp-sums (every lane of the user holds it)
+        float wlo = 0.0f;
+        auto book_even = [&](float s0, float s1) {            // first pair of a tile
+            if (RG_TP_ABL & 32) { wlo += s0 + s1; return; }
+            const float s = s0 + s1;
+            wlo = s + swap32(s);
+        };
+        auto book_odd = [&](uint32_t ti, float s0, float s1) {    // second pair of tile ti: the tile is complete
+            if (RG_TP_ABL & 32) { wlo += s0 + s1; return; }
+            float s = s0 + s1;
+            s += swap32(s);
+            // (fp32 inside the tile: <= 10 roundings per term from the exp to here, part of the fixed budget; the prefix itself
+            // float64, stored as one fp32 rounding: rho)
+            run_pref += static_cast<double>(wlo + s);
+            if (h == 0) trow[ti] = static_cast<float>(run_pref);
+        };
         using f32x2 = __attribute__((ext_vector_type(2))) float;
         // One pair (k_draw_bf16p's stream): MFMAs of (co) into (a0, a1), which already hold the pair's mu | exp-sum of
         // (p0, p1) -> (s0, s1) | A rows of pair pi_next -> no, its mu -> (p0, p1) once their exps are done
         auto stream = [&](const PairOps& co, PairOps& no, uint32_t pi_next, f32x16& a0, f32x16& a1,
-                          f32x16& p0, f32x16& p1, float& s0, float& s1) {
+                          f32x16& p0, f32x16& p1, float& s0, float& s1, auto&& filler) {
             f32x2 x0[4], x1[4];
             const char* ab = a_base(pi_next);
             const char* mb = m_base(pi_next);
@@ -146,6 +165,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 a0 = mm(co.A0[m], Bm[m], a0);
+                if (m == 0) filler();          // (the books of the pair before: independent of this pair's MFMAs and exps)
                 if (m < EXS) {
                     asm volatile("" : "+v"(p0));                        // (exps may not float above this slot)
 #pragma unroll
@@ -195,20 +215,6 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
             return x0[0] + x0[1];
         };
 
-        // ---- the books: one float64 add and one 4-byte LDS store per 128-product tile ----
-        double run_pref = 0.0;     // running prefix of the exp-sums (every lane of the user holds it)
-        float wlo = 0.0f;
-        auto book = [&](uint32_t pe, float s0, float s1) {    // sums of pair pe (chunks 2 pe, 2 pe + 1)
-            if (RG_TP_ABL & 32) { wlo += s0 + s1; return; }
-            float s = s0 + s1;
-            s += swap32(s);
-            if (!(pe & 1)) { wlo = s; return; }
-            // (fp32 inside the tile: <= 10 roundings per term from the exp to here, part of the fixed budget; the prefix itself
-            // float64, stored as one fp32 rounding: rho)
-            run_pref += static_cast<double>(wlo + s);
-            if (h == 0) trow[pe >> 1] = static_cast<float>(run_pref);
-        };
-
         PairOps oa, ob;
         f32x16 a0, a1, p0, p1;
         RG_DMA_WAIT();
@@ -249,6 +255,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
         RG_PIN();
         // Steady state, straight-line: [second pair of tile T | first pair of tile T + 1] per iteration
         uint32_t pi = 1;
+        float q0s = 0.0f, q1s = 0.0f;       // sums of the pair before, waiting for their books
         for (; pi + 1 < np; pi += 2) {
             float s0, s1;
             const uint32_t T = pi >> 1;
@@ -256,18 +263,18 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
             // went out at the last barrier, has landed (no other vector-memory operation is in flight in this loop)
             if (!(RG_TP_ABL & 16)) RG_TILE_BARRIER(0);
             if (T + 2 < n_pt && !(RG_TP_ABL & 16)) fetch_tile(T + 2);
-            stream(ob, oa, pi + 1, p0, p1, a0, a1, s0, s1);                  // MFMAs of pair pi | sums of pair pi - 1
-            book(pi - 1, s0, s1);
-            stream(oa, ob, pi + 2, a0, a1, p0, p1, s0, s1);                  // MFMAs of pair pi + 1 | sums of pair pi
-            book(pi, s0, s1);
+            stream(ob, oa, pi + 1, p0, p1, a0, a1, s0, s1, [&] { if (pi > 1) book_odd((pi - 2) >> 1, q0s, q1s); });   // MFMAs of pair pi | sums of pair pi - 1 | books of pair pi - 2
+            q0s = s0; q1s = s1;
+            stream(oa, ob, pi + 2, a0, a1, p0, p1, s0, s1, [&] { book_even(q0s, q1s); });                           // MFMAs of pair pi + 1 | sums of pair pi | books of pair pi - 1
+            q0s = s0; q1s = s1;
         }
         {   // the last pair (second pair of the last tile), then its own sums
             float s0, s1;
-            stream(ob, oa, pi, p0, p1, a0, a1, s0, s1);                      // (operand fetch of a "next" pair: this one again, unused)
-            book(pi - 1, s0, s1);
+            stream(ob, oa, pi, p0, p1, a0, a1, s0, s1, [&] { if (pi > 1) book_odd((pi - 2) >> 1, q0s, q1s); });      // (operand fetch of a "next" pair: this one again, unused)
+            book_even(s0, s1);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { p0[r] = __builtin_amdgcn_exp2f(p0[r]); p1[r] = __builtin_amdgcn_exp2f(p1[r]); }
-            book(pi, tree(p0), tree(p1));
+            for (int r = 0; r < 16; ++r) { p0[r] = ex2(p0[r]); p1[r] = ex2(p1[r]); }
+            book_odd(pi >> 1, tree(p0), tree(p1));
         }
 
         // ---- what the search needs from here: the tile of the draw (a count in LDS) and five numbers; k_pick does the rest ----
@@ -330,7 +337,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
 constexpr uint32_t kPickLists = kTpBins * kTpShards;      // (tile, shard) lists of a step's draws
 
 #ifndef RG_PICK_OCC
-#define RG_PICK_OCC 4
+#define RG_PICK_OCC 3
 #endif
 template <int KH, int N1>
 __global__ void __launch_bounds__(kBlock, RG_PICK_OCC) k_pick(DevSim d, uint32_t t, uint32_t unused) {
@@ -366,43 +373,28 @@ __global__ void __launch_bounds__(kBlock, RG_PICK_OCC) k_pick(DevSim d, uint32_t
     __syncthreads();
     const uint32_t n_groups = gstart[kPickLists];
     float* omw = om_stage + wave * 32 * K2;
-    // A group's chain of dependent loads — its list entry, then the user's slot and record — is requested one group AHEAD: the
-    // wave works on group g while the loads of group g + stride are in flight (the kernel is a wave per group and ~10 round
-    // trips per group otherwise: profiles/r6/ab_call4_tp.jsonl)
-    struct Grp { uint32_t lst, gi, cnt, pos, slot, uidx; TpRec rec; float w[KH]; };
-    auto locate = [&](uint32_t g, Grp& o) {        // the group's list: the last one whose first group is <= g (wave-uniform)
+    // (the next group's list entry / record / omega requested a group ahead: measured, no gain — the kernel is bound by its
+    // scattered 128-byte accesses, not by a wave's chain of round trips: profiles/r6/ab_call6_tp_ablation.jsonl, pkabl4)
+    for (uint32_t g = blockIdx.x * (kBlock / 64) + wave; g < n_groups; g += gridDim.x * (kBlock / 64)) {
+        // the group's list: the last one whose first group is <= g (wave-uniform; lists with no draws have no groups)
         uint32_t lo = 0, hi = kPickLists;
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (gstart[mid] <= g) lo = mid; else hi = mid; }
-        o.lst = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lo)));
-        o.gi = g - gstart[o.lst];
-        o.cnt = min(32u, hist[o.lst] - 32u * o.gi);
-        o.pos = d.tp_order[static_cast<size_t>(o.lst) * d.tp_cap + 32u * o.gi + (static_cast<uint32_t>(j) < o.cnt ? j : 0)];
-    };
-    auto load_user = [&](Grp& o) {                 // (needs o.pos)
-        o.slot = cur[o.pos];
-        const char* recp = d.tp_rec + static_cast<size_t>(o.pos) * tp_rec_stride(KH);
-        o.rec = *reinterpret_cast<const TpRec*>(recp);
-        const float* rw = reinterpret_cast<const float*>(recp + sizeof(TpRec)) + h * KH;
-#pragma unroll
-        for (int s = 0; s < KH; ++s) o.w[s] = rw[s];
-    };
-    const uint32_t g_stride = gridDim.x * (kBlock / 64);
-    uint32_t g = blockIdx.x * (kBlock / 64) + wave;
-    Grp nx;
-    if (g < n_groups) { locate(g, nx); load_user(nx); nx.uidx = d.uid[nx.slot]; }
-    for (; g < n_groups; g += g_stride) {
-        const Grp cu = nx;
-        const uint32_t lst = cu.lst, tile = lst / kTpShards, cnt = cu.cnt, pos = cu.pos, slot = cu.slot;
+        const uint32_t lst = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lo)));
+        const uint32_t tile = lst / kTpShards;
+        const uint32_t gi = g - gstart[lst];
+        const uint32_t cnt = min(32u, hist[lst] - 32u * gi);
         const bool active = static_cast<uint32_t>(j) < cnt;
-        const TpRec rec = cu.rec;
-        const bool more = g + g_stride < n_groups;
-        if (more && !(RG_PICK_ABL & 4)) locate(g + g_stride, nx);        // (its list entry: in flight while this group's B operands are built)
+        const uint32_t pos = d.tp_order[static_cast<size_t>(lst) * d.tp_cap + 32u * gi + (active ? j : 0)];
+        const uint32_t slot = cur[pos];
+        const char* recp = d.tp_rec + static_cast<size_t>(pos) * tp_rec_stride(KH);
+        const TpRec rec = *reinterpret_cast<const TpRec*>(recp);
         // ---- omega32 of the 32 users (behind the record's header) -> the wave's stage -> B fragments [w1 | w1 | w2 | 0 .. | -q] (as
         // the sweep built them) ----
         {
             float* o = omw + j * K2 + h * KH;
+            const float* rw = reinterpret_cast<const float*>(recp + sizeof(TpRec)) + h * KH;
 #pragma unroll
-            for (int s = 0; s < KH; ++s) o[s] = cu.w[s];
+            for (int s = 0; s < KH; ++s) o[s] = rw[s];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -422,7 +414,6 @@ __global__ void __launch_bounds__(kBlock, RG_PICK_OCC) k_pick(DevSim d, uint32_t
             if (h == 1) Bm[N1 - 1][7] = static_cast<short>(__builtin_bit_cast(unsigned short, static_cast<_Float16>(-rec.q)));
         }
         __builtin_amdgcn_wave_barrier();                                   // (the stage is rewritten by the next group)
-        if (more && !(RG_PICK_ABL & 4)) load_user(nx);                     // (in flight during this group's chunks)
         const double S = static_cast<double>(rec.S), pb = static_cast<double>(rec.pb);
         const float rems = static_cast<float>(rec.u * S - pb);
         // ---- the tile's four chunks: logits on the matrix cores, then two lanes per user in the accumulator layout ----
@@ -493,11 +484,9 @@ __global__ void __launch_bounds__(kBlock, RG_PICK_OCC) k_pick(DevSim d, uint32_t
         const bool ok = r_idx >= 0 && v < d.P && ct.valid &&
                         (v == 0 || rec.u * ct.den_lo > ct.num_lo) &&
                         (v == d.P - 1 || rec.u * ct.den_hi < ct.num_hi);
-        if (more && (RG_PICK_ABL & 4)) { locate(g + g_stride, nx); load_user(nx); }
-        if (more) nx.uidx = d.uid[nx.slot];
         if (active && h == 0 && !((RG_PICK_ABL & 1) && v != 0x7fffffffu)) {
             if (ok) {
-                const uint32_t user = static_cast<uint32_t>(d.first_user + cu.uidx);
+                const uint32_t user = static_cast<uint32_t>(d.first_user + d.uid[slot]);
                 write_organic_row(d, t, pos, slot, user, v);
                 if (d.hist_cap) history_add(d, slot, v);
             } else {
