@@ -135,8 +135,11 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
         };
         auto ex2 = [](float x) -> float { return (RG_TP_ABL & 4) ? x * 0.5f : __builtin_amdgcn_exp2f(x); };
         // ---- the books: one float64 add and one 4-byte LDS store per 128-product tile.  The sums of a pair are produced at the
-        // end of a stream() and BOOKED inside the next one, behind its first MFMA (`filler`): closed right where they are
-        // produced, behind the sums they depend on, they were 19 % of the kernel (profiles/r6/ab_call6_tp_ablation.jsonl) ----
+        // end of a stream() and booked inside the next one, behind its first MFMA (`filler`).  (Measured: the same time as closing
+        // them right where they are produced, profiles/r6/ab_call7_tp_probe.jsonl; so is consuming an exp a slot later, and plain
+        // v_add_f32 instead of v_pk_add_f32 is 4 % SLOWER — 16 more vector instructions per pair: ab_call8_tp_probe.jsonl.  The
+        // loop is bound by its vector instruction count: 32 v_exp_f32 at ~8 cycles + ~24 others per pair and wave next to 8 MFMAs
+        // of 32 cycles, the two waves of a SIMD taking turns.) ----
         double run_pref = 0.0;     // running prefix of the exp-sums (every lane of the user holds it)
         float wlo = 0.0f;
         auto book_even = [&](float s0, float s1) {            // first pair of a tile
@@ -156,49 +159,26 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
         using f32x2 = __attribute__((ext_vector_type(2))) float;
         // One pair (k_draw_bf16p's stream): MFMAs of (co) into (a0, a1), which already hold the pair's mu | exp-sum of
         // (p0, p1) -> (s0, s1) | A rows of pair pi_next -> no, its mu -> (p0, p1) once their exps are done
-        // Scheduling rules of this loop (measured: profiles/r6/ab_call6_tp_ablation.jsonl — its parts were ADDITIVE, i.e. a wave's
-        // in-order issue stalled on dependent vector instructions instead of running them beside its MFMAs):
-        //   * an exp's result is consumed a SLOT later (the adds of a slot's exps sit in the next slot): no add waits for v_exp;
-        //   * plain v_add_f32, not v_pk_add_f32: packed fp32 beside MFMAs costs ~13 cycles more per instruction on this chip
-        //     (MI355X_MICROARCH.md, "price of one filler beside MFMAs"); written as asm so that the SLP pass cannot re-pack them;
-        //   * the reduction trees sit in the pair's last slot, the books (cross-lane + float64) behind the NEXT pair's first MFMA.
-        auto fadd = [](float a, float b) -> float {
-            float r;
-            asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-            return r;
-        };
-        constexpr int YN = (16 + EXS - 1) / EXS + 1;           // exps of one slot at most
-        auto e_lo = [](int m) { return (m * 8 / EXS) * 2; };
         auto stream = [&](const PairOps& co, PairOps& no, uint32_t pi_next, f32x16& a0, f32x16& a1,
                           f32x16& p0, f32x16& p1, float& s0, float& s1, auto&& filler) {
-            float x0[4], x1[4], Y0[YN], Y1[YN];
+            f32x2 x0[4], x1[4];
             const char* ab = a_base(pi_next);
             const char* mb = m_base(pi_next);
-            auto expo = [&](f32x16& p, float* Y, int m) {      // the exps of slot m -> Y (consumed a slot later)
-#pragma unroll
-                for (int e = e_lo(m); e < e_lo(m + 1); e += 2) {
-                    float ya = ex2(p[e]), yb = ex2(p[e + 1]);
-                    asm volatile("" : "+v"(ya), "+v"(yb));      // (these pure ops stay in this slot)
-                    Y[e - e_lo(m)] = ya; Y[e - e_lo(m) + 1] = yb;
-                }
-            };
-            auto consume = [&](float* x, const float* Y, int m) {    // the running sums take the exps of slot m
-#pragma unroll
-                for (int e = e_lo(m); e < e_lo(m + 1); ++e) {
-                    if (e < 4) x[e] = Y[e - e_lo(m)]; else x[e & 3] = fadd(x[e & 3], Y[e - e_lo(m)]);
-                }
-            };
             RG_PIN();
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 a0 = mm(co.A0[m], Bm[m], a0);
                 if (m == 0) filler();          // (the books of the pair before: independent of this pair's MFMAs and exps)
-                if (m > 0 && m <= EXS) consume(x1, Y1, m - 1);
                 if (m < EXS) {
                     asm volatile("" : "+v"(p0));                        // (exps may not float above this slot)
 #pragma unroll
                     for (int i = (2 * m) * (2 * N1) / (2 * EXS); i < (2 * m + 1) * (2 * N1) / (2 * EXS); ++i) load_a(no, ab, i);
-                    expo(p0, Y0, m);
+#pragma unroll
+                    for (int e = (m * 8 / EXS) * 2; e < ((m + 1) * 8 / EXS) * 2; e += 2) {       // exps in pairs
+                        f32x2 y = {ex2(p0[e]), ex2(p0[e + 1])};
+                        asm volatile("" : "+v"(y));
+                        if (e < 8) x0[e / 2] = y; else x0[(e / 2) & 3] += y;
+                    }
                 } else {
 #pragma unroll
                     for (int qq = (m - EXS) * 4 / (NM > EXS ? NM - EXS : 1); qq < (m - EXS + 1) * 4 / (NM > EXS ? NM - EXS : 1); ++qq) load_mu(p0, mb, 0, qq);
@@ -206,30 +186,29 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
                 RG_PIN();
                 a1 = mm(co.A1[m], Bm[m], a1);
                 if (m < EXS) {
-                    consume(x0, Y0, m);
                     asm volatile("" : "+v"(p1));
 #pragma unroll
                     for (int i = (2 * m + 1) * (2 * N1) / (2 * EXS); i < (2 * m + 2) * (2 * N1) / (2 * EXS); ++i) load_a(no, ab, i);
-                    expo(p1, Y1, m);
-                } else {
-                    if (m == EXS) {            // the pair's last exps are in: the trees' first level
-                        x0[0] = fadd(x0[0], x0[2]); x0[1] = fadd(x0[1], x0[3]);
-                        x1[0] = fadd(x1[0], x1[2]); x1[1] = fadd(x1[1], x1[3]);
+#pragma unroll
+                    for (int e = (m * 8 / EXS) * 2; e < ((m + 1) * 8 / EXS) * 2; e += 2) {
+                        f32x2 y = {ex2(p1[e]), ex2(p1[e + 1])};
+                        asm volatile("" : "+v"(y));
+                        if (e < 8) x1[e / 2] = y; else x1[(e / 2) & 3] += y;
                     }
+                } else {
 #pragma unroll
                     for (int qq = (m - EXS) * 4 / (NM > EXS ? NM - EXS : 1); qq < (m - EXS + 1) * 4 / (NM > EXS ? NM - EXS : 1); ++qq) load_mu(p1, mb, 1, qq);
                 }
                 RG_PIN();
             }
-            if (NM == EXS) {       // single-MFMA class: no slot left for the last adds and the mu quads
-                consume(x1, Y1, EXS - 1);
-                x0[0] = fadd(x0[0], x0[2]); x0[1] = fadd(x0[1], x0[3]);
-                x1[0] = fadd(x1[0], x1[2]); x1[1] = fadd(x1[1], x1[3]);
+            if (NM == EXS) {       // single-MFMA class: no slot left for the mu quads
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) { load_mu(p0, mb, 0, qq); load_mu(p1, mb, 1, qq); }
             }
-            s0 = fadd(x0[0], x0[1]);
-            s1 = fadd(x1[0], x1[1]);
+            x0[0] += x0[2]; x0[1] += x0[3]; x0[0] += x0[1];
+            x1[0] += x1[2]; x1[1] += x1[3]; x1[0] += x1[1];
+            s0 = x0[0][0] + x0[0][1];
+            s1 = x1[0][0] + x1[0][1];
             RG_PIN();
         };
         auto tree = [](const f32x16& y) -> float {
