@@ -157,7 +157,7 @@ def spot_check(workload, users=None, n_sample=2000, first_user=0, env=None, seed
                                     sampled_users=int(ids.numel()), kinds=kinds, rows_compared=int(len(rows)),
                                     longest_sampled_user_rows=int(lens.max()), oracle_threads=threads, oracle_seconds=round(oracle_s, 1),
                                     counters={k: cnt[k] for k in ('organic', 'bandit', 'clicks', 'phantom', 'exact_draws', 'exact_sweeps',
-                                                                  'anchored', 'memo_hits', 'lr_acts', 'lr_exact')},
+                                                                  'anchored', 'memo_hits', 'lr_acts', 'lr_exact', 'log_rows', 'log_dropped')},
                                     verdict='rows identical to the oracle (u, t, z, v, a, c, phantom bit-exact; ps'
                                             + (', p_click' if p_click else '') + ' within tolerance)'))
     finally:

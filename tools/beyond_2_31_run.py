@@ -16,9 +16,10 @@ out = sys.argv[sys.argv.index('--out') + 1] if '--out' in sys.argv else ''
 res = osc.spot_check('c3', users, 2000, p_click_modes=(False,))
 for line in res:
     c = line['counters']
-    raw_rows_at_least = c['organic'] + c['bandit']
-    line['real_rows'] = raw_rows_at_least
-    line['beyond_2_31_raw_rows'] = raw_rows_at_least > (1 << 31)
+    line['real_rows'] = c['organic'] + c['bandit']
+    line['raw_rows'] = c['log_rows']              # incl. the unused entries of the walk's reserved row chunks
+    line['beyond_2_31_raw_rows'] = c['log_rows'] > (1 << 31) and c['log_dropped'] == 0
+    line['beyond_2_31_real_rows'] = line['real_rows'] > (1 << 31)
     line['events_per_s_incl_reset'] = None
     s = json.dumps(line)
     print(s)
