@@ -203,9 +203,10 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
         tf = 2.0 * P * K * swept / (prof['draw_mfma_ms'] * 1e-3) / 1e12
         peak = F16_MFMA_PEAK_TFLOPS if K <= 64 else FP32_MFMA_PEAK_TFLOPS
         exp_ms = 1e3 * float(P) * swept / EXP_PEAK_PER_S
-        tp = (not cached) and K <= 20 and prof.get('sweep_lds', 0) and prof['draw_search_ms'] > 0
+        tp = (not cached) and (K <= 20 or 21 < K <= 64) and prof.get('sweep_lds', 0) and prof['draw_search_ms'] > 0
         out['draw_sweep'] = dict(kernel=('k_sweep_xh' if (cached and K <= 20 and os.environ.get('RECOGYM_XH', '1') != '0') else
-                                         ('k_draw_tp (unsliced rounds; k_draw_bf16p the sliced ones)' if tp else 'k_draw_bf16p')) if K <= 21 else 'k_draw_* (K class)', bound='mfma',
+                                         ('k_draw_tp (unsliced rounds; k_draw_bf16p the sliced ones)' if tp else 'k_draw_bf16p')) if K <= 21 else
+                                        ('k_draw_tpw (unsliced rounds; k_draw_f16w the sliced ones)' if tp else 'k_draw_* (K class)'), bound='mfma',
                                  ms=round(prof['draw_mfma_ms'], 2), units=int(swept), unit_name='swept draws',
                                  achieved=round(tf, 2), peak=peak, unit='TFLOP/s', frac=round(tf / peak, 4),
                                  executed_mfma_tflops=round(tf * ((112.0 if K > 8 else 48.0) if (cached and K <= 20 and os.environ.get('RECOGYM_XH', '1') != '0')
@@ -213,8 +214,10 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
                                  # one v_exp_f32 per logit at a quarter of the fp32 lane rate: the kernel's real ceiling
                                  exp_bound_ms=round(exp_ms, 2), frac_of_exp_bound=round(exp_ms / prof['draw_mfma_ms'], 4))
         if tp:
-            # k_pick: the draw inside its 128-product tile on the matrix cores, 32 draws of one tile per wave: 2 x 128 x K flop per draw
-            tfp = 2.0 * 128 * K * swept / (prof['draw_search_ms'] * 1e-3) / 1e12
+            # k_pick: the draw inside its tile (128 products; the wide sweep's super-tiles: ~1 300) on the matrix cores, 32 draws of one
+            # tile per wave: 2 x tile x K flop per draw
+            tile_products = 128 if K <= 20 else prof.get('tp_tile_products', 1344)
+            tfp = 2.0 * tile_products * K * swept / (prof['draw_search_ms'] * 1e-3) / 1e12
             out['draw_pick'] = dict(kernel='k_pick (+ k_draw_search on sliced rounds)', bound='mfma', ms=round(prof['draw_search_ms'], 2), units=int(swept),
                                     unit_name='draws', achieved=round(tfp, 3), peak=peak, unit='TFLOP/s', frac=round(tfp / peak, 5),
                                     note='latency-bound: a wave per 32 draws of one tile, ~9 dependent round trips per group')

@@ -104,7 +104,7 @@ struct TpRec { double u; float S, pb, q, dlt; uint32_t ti, pad; };
 // atomic on ONE address sustains ~6 M/s on this chip (measured: 264 M draws over 79 counters ran at the atomics' rate,
 // profiles/r6/ab_call3_tp.jsonl), so every tile has kTpShards counters, taken by work item modulo kTpShards.
 constexpr uint32_t kTpShards = 16, kTpBins = 128;
-__host__ __device__ constexpr uint32_t tp_rec_stride(uint32_t KH) { return (32u + 8u * KH + 63u) & ~63u; }                     // bytes
+__host__ __device__ constexpr uint32_t tp_rec_stride(uint32_t KH) { return (32u + 8u * KH + 63u) & ~63u; }   // (KH = 32: 320)                     // bytes
 inline uint32_t tp_shard_cap(uint64_t n) { return static_cast<uint32_t>((((n + 127) / 128 + kTpShards - 1) / kTpShards) * 128); }   // draws of one (tile, shard) at most
 
 // Everything a kernel needs, passed by value.
@@ -154,6 +154,7 @@ struct DevSim {
                               // block clears), then the blocks of k_pick that are done
     uint32_t* tp_order;       // [n_chunks / 4][kTpShards][tp_cap] list positions of the step's draws, by tile and shard
     uint32_t tp_cap;
+    uint32_t tp_cpt;          // 32-product chunks per list tile: 4 (k_draw_tp's 128-product tiles); the wide sweep's super-tiles: 2 x its tiles per stored prefix
     float* stats;             // [2*KH] max_p |Gamma[p][k]|, then max_p ||Gamma[p]||_2, max_p |mu_o[p]|
     // geometry of the MFMA draw kernel
     uint32_t KH;              // MFMA k-steps per chunk (each 32x32x2 step consumes 2 k); 0 = no MFMA path
@@ -393,6 +394,7 @@ cached_kernel_t cached_kernel_for(const DevSim& d);
 draw_kernel_t bf16p_kernel_for(const DevSim& d);
 draw_kernel_t f16w_kernel_for(const DevSim& d);            // part 5
 draw_kernel_t tp_kernel_for(const DevSim& d);              // part 9 (nullptr: k_draw_bf16p serves the configuration)
+draw_kernel_t tpw_kernel_for(const DevSim& d);             // k_draw_tpw: the same for the wide-K classes (64 users per wave, a prefix per super-tile)
 draw_kernel_t pick_kernel_for(const DevSim& d);            // k_pick: its second half (the draws grouped by tile, one tile on the matrix cores)
 draw_kernel_t xh_kernel_for(const DevSim& d, int waves);   // part 8 (nullptr: no error-free sweep for this K class); waves per block: 4 or 8
 void (*xh_table_kernel())(DevSim);
@@ -651,12 +653,13 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     uint32_t* ev = w.take<uint32_t>(n);
     uint32_t* pv0 = w.take<uint32_t>(c.env_kind ? n : 1);
     unsigned long long* run_ctl = w.take<unsigned long long>(4);
-    const bool tp = g.F16 == 1 && g.KH <= 10 && !cache;          // k_draw_tp's classes (tp_kernel_for), every draw a sweep
+    // k_draw_tp's / k_draw_tpw's classes (tp_kernel_for), every draw a sweep; k_draw_tp: a user's <= 128 tile prefixes in LDS
+    const bool tp = ((g.F16 == 1 && g.KH <= 10 && g.n_chunks / 4 <= kTpBins) || g.F16 == 2) && !cache;
     char* tp_rec = w.take<char>(tp ? static_cast<size_t>(n) * tp_rec_stride(g.KH) : 1);
     uint32_t* tp_hist = w.take<uint32_t>(kTpBins * kTpShards + 4);
-    uint32_t* tp_order = w.take<uint32_t>(tp ? static_cast<size_t>(g.n_chunks / 4) * kTpShards * tp_shard_cap(n) : 1);
+    uint32_t* tp_order = w.take<uint32_t>(tp ? static_cast<size_t>(g.F16 == 2 ? kTpBins : g.n_chunks / 4) * kTpShards * tp_shard_cap(n) : 1);
     if (d) {
-        d->tp_rec = tp ? tp_rec : nullptr; d->tp_hist = tp_hist; d->tp_order = tp_order; d->tp_cap = tp_shard_cap(n);
+        d->tp_rec = tp ? tp_rec : nullptr; d->tp_hist = tp_hist; d->tp_order = tp_order; d->tp_cap = tp_shard_cap(n); d->tp_cpt = 4;
         d->ev = ev; d->run_ctl = run_ctl; d->run_ahead = 0; d->pv0 = pv0;
         d->phantom_ps = phantom_ps; d->utime = utime; d->phantom_time = phantom_time;
         d->drift_list = drift_list; d->drift_sig = drift_sig; d->drift_cnt = drift_cnt;

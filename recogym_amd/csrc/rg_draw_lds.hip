@@ -420,8 +420,11 @@ __global__ void __launch_bounds__(kBlock, RG_PICK_OCC) k_pick(DevSim d, uint32_t
         const double S = static_cast<double>(rec.S), pb = static_cast<double>(rec.pb);
         const float rems = static_cast<float>(rec.u * S - pb);
         // ---- the tile's four chunks: logits on the matrix cores, then two lanes per user in the accumulator layout ----
-        const char* a_lane = reinterpret_cast<const char*>(d.gsplit) + (static_cast<size_t>(tile) * 128 + j) * RSc + 16 * h;
-        const float* mu_lane = d.mu32s + static_cast<size_t>(tile) * 128 + 4 * h;
+        const uint32_t cpt = d.tp_cpt;                                     // chunks of a list tile (4; the wide sweep's super-tiles: more)
+        const uint32_t c_first = tile * cpt;
+        const int c_n = static_cast<int>(min(cpt, d.n_chunks - c_first));
+        const char* a_lane = reinterpret_cast<const char*>(d.gsplit) + (static_cast<size_t>(c_first) * 32 + j) * RSc + 16 * h;
+        const float* mu_lane = d.mu32s + static_cast<size_t>(c_first) * 32 + 4 * h;
         int r_idx = -1;
         float r_a = 0.0f, r_b = 0.0f, off = 0.0f;
         // (a chunk's operands are requested a chunk ahead: the loop is a chain of L2 round trips otherwise)
@@ -439,12 +442,12 @@ __global__ void __launch_bounds__(kBlock, RG_PICK_OCC) k_pick(DevSim d, uint32_t
         };
         fetch_chunk(0);
 #pragma unroll 1
-        for (int c = 0; c < ((RG_PICK_ABL & 2) ? 0 : 4); ++c) {
+        for (int c = 0; c < ((RG_PICK_ABL & 2) ? 0 : c_n); ++c) {
             f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A_n[0]), __builtin_bit_cast(f16x8, Bm[0]), acc_n, 0, 0, 0);
 #pragma unroll
             for (int m = 1; m < N1; ++m)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A_n[m]), __builtin_bit_cast(f16x8, Bm[m]), acc, 0, 0, 0);
-            if (c < 3) fetch_chunk(c + 1);         // (the MFMAs above have read their operands: the registers take the next chunk's)
+            if (c + 1 < c_n) fetch_chunk(c + 1);   // (the MFMAs above have read their operands: the registers take the next chunk's)
             // in-group inclusive prefixes (a group = 4 consecutive products: rows 8 gq + 4 h .. + 3), the groups' sums
             float p[16], sg[4], so[4];
 #pragma unroll
@@ -481,7 +484,7 @@ __global__ void __launch_bounds__(kBlock, RG_PICK_OCC) k_pick(DevSim d, uint32_t
             }
             if (__ballot(active && r_idx < 0) == 0ull) break;                // every user of the group has its product
         }
-        const uint32_t v = tile * 128u + static_cast<uint32_t>(max(r_idx, 0));
+        const uint32_t v = c_first * 32u + static_cast<uint32_t>(max(r_idx, 0));
         // (S, pb: fp32 roundings of the sweep's float64 running prefix; a, b: fp32 sums of the tile's terms before / with v)
         const CertLin ct = cert_correlated(S, pb, static_cast<double>(r_a), static_cast<double>(r_b), static_cast<double>(rec.dlt));
         const bool ok = r_idx >= 0 && v < d.P && ct.valid &&
@@ -520,9 +523,298 @@ draw_kernel_t tp_kernel_for(const DevSim& d) {
     return nullptr;
 }
 draw_kernel_t pick_kernel_for(const DevSim& d) {
-    if (!d.f16 || d.wide) return nullptr;
+    if (!d.f16) return nullptr;
 #define RG_CASE(kh, a) if (d.KH == kh && d.N1 == a) return k_pick<kh, a>;
     RG_CASE(4, 1) RG_CASE(4, 2) RG_CASE(10, 2) RG_CASE(10, 3) RG_CASE(10, 4)
+    RG_CASE(16, 7) RG_CASE(32, 7) RG_CASE(32, 10) RG_CASE(32, 13)
+#undef RG_CASE
+    return nullptr;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// k_draw_tpw — the same sweep for WIDE embeddings (21 < K <= 64: BASELINE config 4's K = 64; replaces k_draw_f16w on unsliced
+// steps without a per-user cache).
+//
+// At N1 = 13 k-steps per chunk a 32x32x16 MFMA needs 1 KB of A operand from LDS per 32 matrix-pipe cycles and SIMD: exactly the
+// CU's LDS bandwidth, so k_draw_f16w's 8 waves x 32 users are LDS-bound as much as MFMA-bound (and measured at the SUM of its
+// MFMA, LDS and vector time: 4 100 cycles per 64-product tile against 1 664 of MFMA).  Its variant with two user groups per wave
+// — every A fragment feeds two MFMAs, half the LDS traffic — lost because the per-chunk scratch stores kept spilled pointers in the
+// loop, and every reload waits for the tile DMA in flight (profiles/r6/ab_call10_wide_step0.txt).  Here the loop has no global
+// memory operation but the tile DMA: ONE wave per SIMD, 64 users per wave (2 groups of 32: an A fragment from the LDS ring feeds
+// two MFMAs), 256 users per block; the books are a float64 running prefix per user, stored to LDS once per SUPER-TILE of
+// `tp_cpt / 2` tiles (a user's <= ~70 prefixes: what fits beside three 27 KB tile buffers); the draw's super-tile is a count in
+// LDS at the end, k_pick finds the product inside it on the matrix cores (tp_cpt chunks instead of 4).  Two accumulator sets
+// alternate between the tile being multiplied and the tile being exp-summed: no copies.
+// ------------------------------------------------------------------------------------------
+template <int KH, int N1>
+__global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, uint32_t NTs) {
+    constexpr uint32_t RSc = 32 * N1 + 16, TILE_B = 64 * RSc, NT = (TILE_B + 1023) / 1024, NB = 3;
+    constexpr int NW = 4, UG = 2, K2 = 2 * KH;
+    using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // [tile buffer 0][mu x 3][tile buffers 1, 2][prefixes]; omega32 of the block's 256 users is staged over buffers 1, 2 and the
+    // prefix rows while the B rows are built (before their first use)
+    char* g_buf0 = smem_raw;
+    float* mu_buf = reinterpret_cast<float*>(smem_raw + TILE_B);          // [3][64]
+    char* g_buf12 = smem_raw + TILE_B + 1024;
+    float* tpref = reinterpret_cast<float*>(g_buf12 + 2 * TILE_B);        // [256 users][NTs]
+    float* om_stage = reinterpret_cast<float*>(g_buf12);                  // [256][K2]
+    auto buf_of = [&](uint32_t b) -> char* { return b == 0 ? g_buf0 : g_buf12 + (b - 1) * TILE_B; };
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    const int j = lane & 31, h = lane >> 5;
+    const uint32_t n_o = d.step_cnt[2 * t + RG_STATE_ORGANIC];
+    const uint32_t n_items = (n_o + 255) / 256;
+    const uint32_t* cur = list_ptr(d, t & 1, RG_STATE_ORGANIC);
+    const float mumax = d.stats[2 * KH + 1], g2max = d.stats[2 * KH];
+    const uint32_t n_t = d.n_chunks / 2;                                  // 64-product tiles
+    const uint32_t G = d.tp_cpt / 2;                                      // tiles per stored prefix
+    const uint32_t n_s = (n_t + G - 1) / G;                               // super-tiles
+    const int my_dma = static_cast<int>((NT - wave + NW - 1) / NW) + (wave == NW - 1 ? 1 : 0);
+    float* trow_own = tpref + static_cast<size_t>((wave * UG + h) * 32 + j) * NTs;     // lane (j, h) keeps the books of group h's user j
+
+    for (uint32_t tb = blockIdx.x; tb < n_items; tb += gridDim.x) {
+        uint32_t pos[UG], slot[UG];
+        bool active[UG];
+#pragma unroll
+        for (int g = 0; g < UG; ++g) {
+            pos[g] = tb * 256 + (wave * UG + g) * 32 + j;
+            active[g] = pos[g] < n_o;
+            slot[g] = active[g] ? cur[pos[g]] : 0u;
+        }
+        __syncthreads();           // every wave is done with the LDS buffers (previous work item)
+        const uint32_t lane16 = static_cast<uint32_t>(lane) * 16u;
+        const rg_v4i rs_g = raw_buffer_rsrc(d.gsplit), rs_m = raw_buffer_rsrc(d.mu32s);
+        const uint32_t lds0 = lds_addr_of(g_buf0), lds12 = lds_addr_of(g_buf12), mu_lds = lds_addr_of(mu_buf);
+        auto fetch_tile = [&](uint32_t ti) {
+            const uint32_t b = ti % NB;
+            const uint32_t base = b == 0 ? lds0 : lds12 + (b - 1) * TILE_B;
+            for (uint32_t off = static_cast<uint32_t>(wave) * 1024u; off < TILE_B; off += NW * 1024u)
+                dma_to_lds_b128(rs_g, base + off, lane16, ti * TILE_B + off);
+            if (wave == NW - 1 && lane < 16) dma_to_lds_b128(rs_m, mu_lds + b * 256u, lane16, ti * 256u);
+        };
+        fetch_tile(0);
+        // ---- omega32 of the users -> LDS stage (also the logit error bound) and behind the draw's record (k_pick's B operands) ----
+        float Ahat[UG];
+        double delta_fixed[UG];
+        float* omu[UG];
+#pragma unroll
+        for (int g = 0; g < UG; ++g) {
+            omu[g] = om_stage + ((wave * UG + g) * 32 + j) * K2;
+            float* rw = reinterpret_cast<float*>(d.tp_rec + static_cast<size_t>(active[g] ? pos[g] : 0u) * tp_rec_stride(KH) + sizeof(TpRec)) + h * KH;
+            float absdot = 0.0f, sq = 0.0f, absw = 0.0f;
+#pragma unroll
+            for (int s2 = 0; s2 < KH; ++s2) {
+                const uint32_t k = h * KH + s2;
+                float w = 0.0f;
+                if (active[g] && k < d.K) w = static_cast<float>(d.omega[static_cast<size_t>(slot[g]) * d.OMS + k]);
+                omu[g][k] = w;
+                if (active[g]) rw[s2] = w;
+                absdot = fmaf(fabsf(w), d.stats[k], absdot);
+                sq = fmaf(w, w, sq);
+                absw += fabsf(w);
+            }
+            absdot += swap32(absdot);
+            sq += swap32(sq);
+            absw += swap32(absw);
+            Ahat[g] = ahat_of(d, mumax, g2max, absdot, sq);
+            delta_fixed[g] = kDeltaFixedBf16 + f16_extra_delta(d, Ahat[g], absw);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // ---- B fragments [w1 | w1 | w2 | 0 .. | -q]: lane (j, h) holds elements ke = 16 s + 8 h + e of its user's row ----
+        bf16x8 Bm[UG][N1];
+        {
+            const uint32_t K = d.K;
+#pragma unroll
+            for (int g = 0; g < UG; ++g)
+#pragma unroll
+                for (int s2 = 0; s2 < N1; ++s2)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t ke = 16 * s2 + 8 * h + e;
+                        unsigned short sp[2] = {0, 0};
+                        if (ke < 3 * K) f16_split2(omu[g][ke % K], sp);
+                        Bm[g][s2][e] = static_cast<short>(ke < 2 * K ? sp[0] : sp[1]);
+                    }
+        }
+        float q[UG] = {0.0f, 0.0f};
+        // Register plan (512 per lane at one wave per SIMD, but the vector ALU only reads the 256 architectural ones): both
+        // accumulator sets in VGPRs (the exps read them), the B rows and the A ring — MFMA operands only — in AGPRs.  The
+        // allocator does not find that split by itself (228 spilled registers, a third of them inside the tile loop): pinned here.
+        auto mm = [](const bf16x8& a, const bf16x8& b, const f32x16& c) -> f32x16 {
+            return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+        };
+        auto load_mu = [&](f32x16& acc, const char* mb, int which) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const float4 m = *reinterpret_cast<const float4*>(mb + 128 * which + 32 * qq);
+                acc[4 * qq] = m.x; acc[4 * qq + 1] = m.y; acc[4 * qq + 2] = m.z; acc[4 * qq + 3] = m.w;
+            }
+        };
+        // ---- the books: a float64 running prefix per user, one fp32 rounding of it to LDS per super-tile ----
+        double run_pref[UG] = {0.0, 0.0};
+        const uint32_t n_c = d.n_chunks, cps = d.tp_cpt;                  // chunks; chunks per super-tile
+        auto book = [&](uint32_t ci_done, float s0, float s1) {          // s_g: group g's exp-sum of chunk ci_done (this lane's half)
+            s0 += swap32(s0);
+            s1 += swap32(s1);
+            run_pref[0] += static_cast<double>(s0);
+            run_pref[1] += static_cast<double>(s1);
+            if ((ci_done + 1) % cps == 0 || ci_done + 1 == n_c) trow_own[ci_done / cps] = static_cast<float>(h ? run_pref[1] : run_pref[0]);
+        };
+        RG_DMA_WAIT();
+        __syncthreads();           // tile 0 landed; every wave has built its B rows from the stage (which tiles 1, 2 and the prefix rows now overwrite)
+        for (uint32_t i = n_s; i < NTs; ++i) trow_own[i] = INFINITY;     // (row padding: never counted)
+        if (1 < n_t) fetch_tile(1);
+        if (2 < n_t) fetch_tile(2);
+        const char* a_lane0 = g_buf0 + j * RSc + 16 * h;
+        {   // first chunk with reference 0: its max (an integer after ceil, exact in one fp16 piece) becomes the reference
+#pragma unroll
+            for (int g = 0; g < UG; ++g) {
+                f32x16 y;
+                load_mu(y, reinterpret_cast<const char*>(mu_buf) + 16 * h, 0);
+#pragma unroll
+                for (int s2 = 0; s2 < N1; ++s2) y = mm(*reinterpret_cast<const bf16x8*>(a_lane0 + 32 * s2), Bm[g][s2], y);
+                float cm = y[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) cm = fmaxf(cm, y[r]);
+                float qn = fmaxf(ceilf(fmaxf(cm, swap32(cm))), -1.0e30f);
+                qn = fminf(fmaxf(qn, -2047.0f), 2047.0f);
+                q[g] = qn;
+                if (h == 1) Bm[g][N1 - 1][7] = static_cast<short>(__builtin_bit_cast(unsigned short, static_cast<_Float16>(-qn)));
+            }
+        }
+        // One CHUNK (32 products x the wave's 64 users): its 2 N1 MFMAs into `ac` (seeded with mu) — every A fragment of the ring
+        // feeds both user groups — | the exps and sums of the chunk before, in `pv` | the books of that chunk.  The pipeline is a
+        // chunk deep, not a tile: two accumulator sets of 2 x 16 registers, so that B rows (8 N1 registers), accumulators, ring
+        // and sums fit the 256 architectural registers (a tile deep, the allocator moved accumulators through AGPRs and scratch:
+        // 32 scratch stores per tile, each reload behind a vmcnt(0) that also waits for the tile DMA).
+        constexpr int NSLOT = UG * N1, NEP = 8 * UG, EPS = (NEP + NSLOT - 1) / NSLOT;      // exp PAIRS per slot
+        constexpr int RD = 4;                                          // A ring: k-steps read ahead of the MFMAs
+        auto chunk_step = [&](uint32_t ci, f32x16 (&ac)[UG], f32x16 (&pv)[UG], bool have_p) {
+            const uint32_t ti = ci >> 1;
+            if ((ci & 1u) == 0 && ci > 0) {
+                // tile ti has landed once at most this wave's DMA of tile ti + 1 (issued after it) is still in flight
+                if (ti + 1 >= n_t) RG_TILE_BARRIER(0);
+                else if (my_dma >= 8) RG_TILE_BARRIER(8);
+                else if (my_dma == 7) RG_TILE_BARRIER(7);
+                else if (my_dma == 6) RG_TILE_BARRIER(6);
+                else if (my_dma == 5) RG_TILE_BARRIER(5);
+                else if (my_dma == 4) RG_TILE_BARRIER(4);
+                else if (my_dma == 3) RG_TILE_BARRIER(3);
+                else RG_TILE_BARRIER(2);
+                if (ti + 2 < n_t) fetch_tile(ti + 2);        // into the buffer of tile ti - 1: every wave is past it
+            }
+            const uint32_t b = ti % NB;
+            const char* ab = buf_of(b) + ((ci & 1u) * 32 + j) * RSc + 16 * h;
+            const char* mb = reinterpret_cast<const char*>(mu_buf) + 16 * h + b * 256u;
+            load_mu(ac[0], mb, static_cast<int>(ci & 1u));
+            ac[1] = ac[0];
+            f32x2 x[UG][4];
+            bf16x8 Ar[RD];
+#pragma unroll
+            for (int s2 = 0; s2 < RD - 1 && s2 < N1; ++s2) Ar[s2] = *reinterpret_cast<const bf16x8*>(ab + 32 * s2);
+            RG_PIN();
+            auto exps = [&](int slot_i) {
+#pragma unroll
+                for (int e = slot_i * EPS; e < (slot_i + 1) * EPS && e < NEP; ++e) {
+                    const int g = e >> 3, r = e & 7;                  // accumulator of group g, register pair r
+                    asm volatile("" : "+v"(pv[g]));
+                    f32x2 y = {__builtin_amdgcn_exp2f(pv[g][2 * r]), __builtin_amdgcn_exp2f(pv[g][2 * r + 1])};
+                    asm volatile("" : "+v"(y));
+                    if (r < 4) x[g][r] = y; else x[g][r & 3] += y;
+                }
+            };
+#pragma unroll
+            for (int s2 = 0; s2 < N1; ++s2) {
+                if (s2 + RD - 1 < N1) Ar[(s2 + RD - 1) % RD] = *reinterpret_cast<const bf16x8*>(ab + 32 * (s2 + RD - 1));
+#pragma unroll
+                for (int g = 0; g < UG; ++g) {
+                    ac[g] = mm(Ar[s2 % RD], Bm[g][s2], ac[g]);
+                    if (have_p) exps(s2 * UG + g);
+                    RG_PIN();
+                }
+            }
+            if (have_p) {
+                float sm[UG];
+#pragma unroll
+                for (int g = 0; g < UG; ++g) {
+                    const f32x2 z = (x[g][0] + x[g][2]) + (x[g][1] + x[g][3]);
+                    sm[g] = z[0] + z[1];
+                }
+                book(ci - 1, sm[0], sm[1]);
+            }
+        };
+        f32x16 accA[UG], accB[UG];
+        chunk_step(0, accA, accB, false);
+        uint32_t ci = 1;
+        for (; ci + 1 < n_c; ci += 2) {
+            chunk_step(ci, accB, accA, true);
+            chunk_step(ci + 1, accA, accB, true);
+        }
+        chunk_step(ci, accB, accA, true);               // (n_c is even: the last chunk goes into accB)
+        {   // the last chunk's own sums
+            float sm[UG];
+#pragma unroll
+            for (int g = 0; g < UG; ++g) {
+                float e0 = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e0 += __builtin_amdgcn_exp2f(accB[g][r]);
+                sm[g] = e0;
+            }
+            book(n_c - 1, sm[0], sm[1]);
+        }
+        // ---- the draw's super-tile (a count in LDS) and what k_pick needs ----
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < UG; ++g) {
+            const uint32_t uidx = d.uid[slot[g]];
+            const uint32_t user = static_cast<uint32_t>(d.first_user + uidx);
+            const double u_draw = organic_uniform(d, uidx, user, t);
+            const float Sf = static_cast<float>(run_pref[g]);
+            const double S = static_cast<double>(Sf);
+            const double tau = u_draw * S;
+            float tf = static_cast<float>(tau);
+            if (static_cast<double>(tf) > tau) tf = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, tf) - 1u);   // (tau >= 0)
+            const float* trow = tpref + static_cast<size_t>((wave * UG + g) * 32 + j) * NTs;
+            uint32_t cnt = 0;
+            {
+                const float4* r4 = reinterpret_cast<const float4*>(trow);
+                const uint32_t n4 = NTs / 4;
+                for (uint32_t i = h; i < n4; i += 2) {
+                    const float4 x = r4[i];
+                    cnt += (x.x <= tf) + (x.y <= tf) + (x.z <= tf) + (x.w <= tf);
+                }
+            }
+            cnt += static_cast<uint32_t>(__shfl_xor(static_cast<int>(cnt), 32));
+            const bool found_t = cnt < n_s && S > 0.0 && S < 3.0e38;
+            const float pbf = (found_t && cnt) ? trow[cnt - 1u] : 0.0f;
+            if (active[g] && h == 0) {
+                const double delta = static_cast<double>(d.K + 5) * 5.9604644775390625e-08 * static_cast<double>(Ahat[g]) + delta_fixed[g];
+                TpRec r;
+                r.u = u_draw; r.S = Sf; r.pb = pbf; r.q = q[g]; r.dlt = static_cast<float>(delta * 1.000001);
+                r.ti = found_t ? cnt : 0xFFFFFFFFu; r.pad = 0u;
+                *reinterpret_cast<TpRec*>(d.tp_rec + static_cast<size_t>(pos[g]) * tp_rec_stride(KH)) = r;
+                if (found_t) {
+                    const uint32_t bs = cnt * kTpShards + (tb % kTpShards);
+                    const uint32_t k = atomicAdd(&d.tp_hist[bs], 1u);
+                    d.tp_order[static_cast<size_t>(bs) * d.tp_cap + k] = pos[g];
+                } else {
+                    const uint32_t xi = atomicAdd(&d.exact_cnt[t], 1u);
+                    d.exact_list[xi] = pos[g];
+                    d.exact_ref[xi] = q[g];
+                }
+            }
+        }
+    }
+}
+
+draw_kernel_t tpw_kernel_for(const DevSim& d) {
+    if (!d.f16 || !d.wide) return nullptr;
+#define RG_CASE(kh, a) if (d.KH == kh && d.N1 == a) return k_draw_tpw<kh, a>;
+    RG_CASE(16, 7) RG_CASE(32, 7) RG_CASE(32, 10) RG_CASE(32, 13)
 #undef RG_CASE
     return nullptr;
 }

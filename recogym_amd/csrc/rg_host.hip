@@ -603,6 +603,7 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         if (tp) {
             // k_pick: a wave per 32 draws of one tile (the sweep listed the draws by tile), grid-stride over the groups
             const size_t psmem = (2 * kTpBins * kTpShards + 8) * sizeof(uint32_t) + 4 * 32 * 2 * static_cast<size_t>(d.KH) * sizeof(float);
+            if (psmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sim->pick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(psmem));
             uint32_t pgrid = upper / 128u + (d.n_chunks / 4) * kTpShards / 4u + 1u;      // groups / 4 waves (a part-filled group per (tile, shard))
             const uint32_t pcap = static_cast<uint32_t>(device_cus(sim)) * 4u;
             if (pgrid > pcap) pgrid = pcap;
@@ -1135,6 +1136,28 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
             const size_t smem = 2 * (128 * static_cast<size_t>(d.RS) + 512) + 256 + 4 * 32 * static_cast<size_t>(nts) * sizeof(float);
             if (smem <= 160 * 1024 && d.n_chunks / 4 <= 128u) {          // (k_pick sorts a segment's draws into <= 128 tile bins)
                 s->tp_kernel = kt; s->pick_kernel = kp; s->tp_smem = smem; s->tp_nts = nts;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
+            }
+        }
+    }
+    if (d.use_mfma == 2 && !d.use_cache && d.wide && s->bf16_kernel && s->bf16_kernel == f16w_kernel_for(d) && d.tp_rec) {
+        // wide K: k_draw_tpw keeps a prefix per SUPER-TILE of G 64-product tiles — what fits beside its three tile buffers
+        draw_kernel_t kt = tpw_kernel_for(d), kp = pick_kernel_for(d);
+        const size_t tile_b = 64 * static_cast<size_t>(d.RS);
+        const size_t avail = 160 * 1024 - 3 * tile_b - 1024;
+        uint32_t nts_max = static_cast<uint32_t>(avail / (256 * sizeof(float))) & ~3u;
+        if (nts_max > kTpBins) nts_max = kTpBins;
+        if (kt && kp && nts_max >= 8) {
+            const uint32_t n_t = d.n_chunks / 2;
+            const uint32_t G = (n_t + nts_max - 1) / nts_max;
+            const uint32_t n_s = (n_t + G - 1) / G;
+            uint32_t nts = (n_s + 3u) & ~3u;
+            // (the omega32 stage of the block's 256 users lies over tile buffers 1, 2 and the prefix rows)
+            while (2 * tile_b + 256 * static_cast<size_t>(nts) * sizeof(float) < 256 * 2 * static_cast<size_t>(d.KH) * sizeof(float)) nts += 4;
+            const size_t smem = 3 * tile_b + 1024 + 256 * static_cast<size_t>(nts) * sizeof(float);
+            if (smem <= 160 * 1024) {
+                s->tp_kernel = kt; s->pick_kernel = kp; s->tp_smem = smem; s->tp_nts = nts;
+                d.tp_cpt = 2 * G;
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
             }
         }

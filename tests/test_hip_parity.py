@@ -669,15 +669,20 @@ LDS_EXTRA_CASES = [
     (dict(num_products=128, K=8, random_seed=63, sigma_omega=0.5), 900, 0, {}),
     (dict(num_products=2000, K=20, random_seed=64, sigma_omega=0.3, sigma_mu_organic=12.0), 500, 0,
      dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=27, ouc=dict(gu.OUC_DEFAULTS))),
+    # k_draw_tpw, the wide classes (N1 = 7, 10: K = 30, 45; 13 is oracle case 14 / 3): several super-tiles, P off a tile boundary
+    (dict(num_products=5000, K=30, random_seed=65, sigma_omega=0.2), 600, 0, {}),
+    (dict(num_products=9001, K=45, random_seed=66), 500, 3, dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=8)),
 ]
 
 
 @pytest.mark.parametrize('run_ahead', ['32', '0'])
-@pytest.mark.parametrize('case', [0, 2, 6, 7, 8, 9, 10, 'x0', 'x1', 'x2', 'x3'])
+@pytest.mark.parametrize('case', [0, 2, 3, 4, 6, 7, 8, 9, 10, 14, 'x0', 'x1', 'x2', 'x3', 'x4', 'x5'])
 def test_lds_search_sweep_matches_the_oracle(case, run_ahead, monkeypatch):
-    """k_draw_tp (rg_draw_lds.hip: tile prefixes in LDS, the search on them, one tile of Gamma recomputed) is the sweep of every
-    UNSLICED step of a run whose draws cannot be cached; populations the oracle finishes in seconds take the sliced form, so the
-    unsliced one is forced here (RECOGYM_SLICES=1) on every (KH, N1) class it is instantiated for, in rounds and in lock-step."""
+    """k_draw_tp / k_draw_tpw + k_pick (rg_draw_lds.hip: a user's tile prefixes in LDS, the draw's tile a count on them, the product
+    inside the tile on the matrix cores, 32 draws of one tile per wave) are the sweep of every UNSLICED step of a run whose draws
+    cannot be cached; populations the oracle finishes in seconds take the sliced form, so the unsliced one is forced here
+    (RECOGYM_SLICES=1) on every (KH, N1) class they are instantiated for — K <= 20 and the wide classes up to K = 64 — in rounds and
+    in lock-step."""
     from oracle import oracle as orc
     from recogym_amd.sim import Simulator
     monkeypatch.setenv('RECOGYM_SLICES', '1')
