@@ -105,7 +105,8 @@ struct TpRec { double u; float S, pb, q, dlt; uint32_t ti, pad; };
 // profiles/r6/ab_call3_tp.jsonl), so every tile has kTpShards counters, taken by work item modulo kTpShards.
 constexpr uint32_t kTpShards = 16, kTpBins = 128;
 __host__ __device__ constexpr uint32_t tp_rec_stride(uint32_t KH) { return (32u + 8u * KH + 63u) & ~63u; }   // (KH = 32: 320)                     // bytes
-inline uint32_t tp_shard_cap(uint64_t n) { return static_cast<uint32_t>((((n + 127) / 128 + kTpShards - 1) / kTpShards) * 128); }   // draws of one (tile, shard) at most
+// draws of one (tile, shard) list at most: every work item (128 users of k_draw_tp, 256 of k_draw_tpw) may put all its draws into one
+inline uint32_t tp_shard_cap(uint64_t n) { return static_cast<uint32_t>((((n + 255) / 256 + kTpShards - 1) / kTpShards) * 256); }
 
 // Everything a kernel needs, passed by value.
 struct DevSim {

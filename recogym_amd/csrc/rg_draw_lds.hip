@@ -30,6 +30,11 @@
 #ifndef RG_PICK_ABL
 #define RG_PICK_ABL 0
 #endif
+// -DRG_TPW_ABL=bits on k_draw_tpw: 1: exps replaced by a multiply, 2: no MFMAs, 4: no tile barrier / DMA beyond the first three
+// tiles, 8: no books, 16: no mu seeds, 32: the A ring is not re-read (one fragment for every k-step)
+#ifndef RG_TPW_ABL
+#define RG_TPW_ABL 0
+#endif
 
 namespace rgk {
 
@@ -657,6 +662,7 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
         double run_pref[UG] = {0.0, 0.0};
         const uint32_t n_c = d.n_chunks, cps = d.tp_cpt;                  // chunks; chunks per super-tile
         auto book = [&](uint32_t ci_done, float s0, float s1) {          // s_g: group g's exp-sum of chunk ci_done (this lane's half)
+            if (RG_TPW_ABL & 8) { run_pref[0] += static_cast<double>(s0 + s1); return; }
             s0 += swap32(s0);
             s1 += swap32(s1);
             run_pref[0] += static_cast<double>(s0);
@@ -694,7 +700,7 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
         constexpr int RD = 4;                                          // A ring: k-steps read ahead of the MFMAs
         auto chunk_step = [&](uint32_t ci, f32x16 (&ac)[UG], f32x16 (&pv)[UG], bool have_p) {
             const uint32_t ti = ci >> 1;
-            if ((ci & 1u) == 0 && ci > 0) {
+            if ((ci & 1u) == 0 && ci > 0 && !(RG_TPW_ABL & 4)) {
                 // tile ti has landed once at most this wave's DMA of tile ti + 1 (issued after it) is still in flight
                 if (ti + 1 >= n_t) RG_TILE_BARRIER(0);
                 else if (my_dma >= 8) RG_TILE_BARRIER(8);
@@ -709,8 +715,7 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
             const uint32_t b = ti % NB;
             const char* ab = buf_of(b) + ((ci & 1u) * 32 + j) * RSc + 16 * h;
             const char* mb = reinterpret_cast<const char*>(mu_buf) + 16 * h + b * 256u;
-            load_mu(ac[0], mb, static_cast<int>(ci & 1u));
-            ac[1] = ac[0];
+            if (!(RG_TPW_ABL & 16)) { load_mu(ac[0], mb, static_cast<int>(ci & 1u)); ac[1] = ac[0]; }
             f32x2 x[UG][4];
             bf16x8 Ar[RD];
 #pragma unroll
@@ -721,17 +726,18 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
                 for (int e = slot_i * EPS; e < (slot_i + 1) * EPS && e < NEP; ++e) {
                     const int g = e >> 3, r = e & 7;                  // accumulator of group g, register pair r
                     asm volatile("" : "+v"(pv[g]));
-                    f32x2 y = {__builtin_amdgcn_exp2f(pv[g][2 * r]), __builtin_amdgcn_exp2f(pv[g][2 * r + 1])};
+                    f32x2 y = {(RG_TPW_ABL & 1) ? pv[g][2 * r] * 0.5f : __builtin_amdgcn_exp2f(pv[g][2 * r]),
+                               (RG_TPW_ABL & 1) ? pv[g][2 * r + 1] * 0.5f : __builtin_amdgcn_exp2f(pv[g][2 * r + 1])};
                     asm volatile("" : "+v"(y));
                     if (r < 4) x[g][r] = y; else x[g][r & 3] += y;
                 }
             };
 #pragma unroll
             for (int s2 = 0; s2 < N1; ++s2) {
-                if (s2 + RD - 1 < N1) Ar[(s2 + RD - 1) % RD] = *reinterpret_cast<const bf16x8*>(ab + 32 * (s2 + RD - 1));
+                if (s2 + RD - 1 < N1 && !(RG_TPW_ABL & 32)) Ar[(s2 + RD - 1) % RD] = *reinterpret_cast<const bf16x8*>(ab + 32 * (s2 + RD - 1));
 #pragma unroll
                 for (int g = 0; g < UG; ++g) {
-                    ac[g] = mm(Ar[s2 % RD], Bm[g][s2], ac[g]);
+                    if (!(RG_TPW_ABL & 2)) ac[g] = mm(Ar[(RG_TPW_ABL & 32) ? 0 : s2 % RD], Bm[g][s2], ac[g]);
                     if (have_p) exps(s2 * UG + g);
                     RG_PIN();
                 }
