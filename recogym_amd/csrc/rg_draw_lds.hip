@@ -713,8 +713,13 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
                 if (ti + 2 < n_t) fetch_tile(ti + 2);        // into the buffer of tile ti - 1: every wave is past it
             }
             const uint32_t b = ti % NB;
-            const char* ab = buf_of(b) + ((ci & 1u) * 32 + j) * RSc + 16 * h;
-            const char* mb = reinterpret_cast<const char*>(mu_buf) + 16 * h + b * 256u;
+            // (the lane's row / half are REBUILT here from the lane id: kept across the loop they were spilled, and a reload inside
+            // the loop is followed by s_waitcnt vmcnt(0), which also waits for the tile DMA in flight — a round trip per chunk)
+            const int ln = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+            int jl = ln & 31, hl = ln >> 5;
+            asm volatile("" : "+v"(jl), "+v"(hl));
+            const char* ab = buf_of(b) + ((ci & 1u) * 32 + jl) * RSc + 16 * hl;
+            const char* mb = reinterpret_cast<const char*>(mu_buf) + 16 * hl + b * 256u;
             if (!(RG_TPW_ABL & 16)) { load_mu(ac[0], mb, static_cast<int>(ci & 1u)); ac[1] = ac[0]; }
             f32x2 x[UG][4];
             bf16x8 Ar[RD];
