@@ -19,6 +19,7 @@
 // k_draw_bf16p.
 
 #include "rg_common.hpp"
+#include <type_traits>
 
 // -DRG_TP_ABL=bits: timing experiments on k_draw_tp (results wrong by design; A/B builds only, loaded with RECOGYM_HIP_LIB).
 // 1: no epilogue (uniform, tile count, record, list entry), 2: the first 8 product tiles only (what a work item costs besides its
@@ -672,8 +673,7 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
         RG_DMA_WAIT();
         __syncthreads();           // tile 0 landed; every wave has built its B rows from the stage (which tiles 1, 2 and the prefix rows now overwrite)
         for (uint32_t i = n_s; i < NTs; ++i) trow_own[i] = INFINITY;     // (row padding: never counted)
-        if (1 < n_t) fetch_tile(1);
-        if (2 < n_t) fetch_tile(2);
+        if (1 < n_t) fetch_tile(1);                      // (tile 2 goes out at the barrier inside chunk 1)
         const char* a_lane0 = g_buf0 + j * RSc + 16 * h;
         {   // first chunk with reference 0: its max (an integer after ceil, exact in one fp16 piece) becomes the reference
 #pragma unroll
@@ -691,80 +691,119 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
                 if (h == 1) Bm[g][N1 - 1][7] = static_cast<short>(__builtin_bit_cast(unsigned short, static_cast<_Float16>(-qn)));
             }
         }
-        // One CHUNK (32 products x the wave's 64 users): its 2 N1 MFMAs into `ac` (seeded with mu) — every A fragment of the ring
-        // feeds both user groups — | the exps and sums of the chunk before, in `pv` | the books of that chunk.  The pipeline is a
-        // chunk deep, not a tile: two accumulator sets of 2 x 16 registers, so that B rows (8 N1 registers), accumulators, ring
-        // and sums fit the 256 architectural registers (a tile deep, the allocator moved accumulators through AGPRs and scratch:
-        // 32 scratch stores per tile, each reload behind a vmcnt(0) that also waits for the tile DMA).
-        constexpr int NSLOT = UG * N1, NEP = 8 * UG, EPS = (NEP + NSLOT - 1) / NSLOT;      // exp PAIRS per slot
+        // One CHUNK (32 products x the wave's 64 users): its 2 N1 MFMAs into `ac` — every A fragment of the ring feeds both user
+        // groups — and, in the issue slots behind those MFMAs, everything else: the exps and sums of the chunk before (in `pv`), its
+        // books, then the NEXT chunk's mu seeds into `pv` (whose exps are done) and the next chunk's first A fragments into the
+        // ring; the tile barrier sits in the middle of a tile's second chunk.  Nothing is left outside the MFMA stream: with one
+        // wave per SIMD whatever a chunk step did before its first or after its last MFMA ran with the matrix pipe idle — 40 % of
+        // the first form's time (profiles/r6/ab_call13_tpw_ablation.txt: MFMA 0.66 us of 1.96 per tile, the rest additive).
+        // The pipeline is a chunk deep, not a tile: two accumulator sets of 2 x 16 registers, so that B rows (8 N1 registers),
+        // accumulators, ring and sums fit the 256 architectural registers.
+        constexpr int NSLOT = UG * N1, NEP = 8 * UG, EPS = NSLOT >= NEP + 9 ? 1 : (NSLOT >= NEP / 2 + 9 ? 2 : 4), ESL = NEP / EPS;     // exp PAIRS per slot; slots that carry exps
+        static_assert(ESL + 9 <= NSLOT, "a chunk's slots must hold its exps, books and the next chunk's seeds");
         constexpr int RD = 4;                                          // A ring: k-steps read ahead of the MFMAs
-        auto chunk_step = [&](uint32_t ci, f32x16 (&ac)[UG], f32x16 (&pv)[UG], bool have_p) {
+        auto load_mu_q = [&](f32x16& acc, const char* mb, int qq) {
+            const float4 m = *reinterpret_cast<const float4*>(mb + 32 * qq);
+            acc[4 * qq] = m.x; acc[4 * qq + 1] = m.y; acc[4 * qq + 2] = m.z; acc[4 * qq + 3] = m.w;
+        };
+        bf16x8 Ar[RD];
+        auto chunk_step = [&](auto roff_, auto odd_, auto hp_, auto hn_, uint32_t ci, f32x16 (&ac)[UG], f32x16 (&pv)[UG]) {
+            constexpr int ROFF = decltype(roff_)::value;               // ring slot of this chunk's k-step 0
+            constexpr bool ODD = decltype(odd_)::value;                // second chunk of its tile
+            constexpr bool have_p = decltype(hp_)::value;              // there is a chunk before (its logits in `pv`)
+            constexpr bool has_next = decltype(hn_)::value;            // ... and one behind
             const uint32_t ti = ci >> 1;
-            if ((ci & 1u) == 0 && ci > 0 && !(RG_TPW_ABL & 4)) {
-                // tile ti has landed once at most this wave's DMA of tile ti + 1 (issued after it) is still in flight
-                if (ti + 1 >= n_t) RG_TILE_BARRIER(0);
-                else if (my_dma >= 8) RG_TILE_BARRIER(8);
-                else if (my_dma == 7) RG_TILE_BARRIER(7);
-                else if (my_dma == 6) RG_TILE_BARRIER(6);
-                else if (my_dma == 5) RG_TILE_BARRIER(5);
-                else if (my_dma == 4) RG_TILE_BARRIER(4);
-                else if (my_dma == 3) RG_TILE_BARRIER(3);
-                else RG_TILE_BARRIER(2);
-                if (ti + 2 < n_t) fetch_tile(ti + 2);        // into the buffer of tile ti - 1: every wave is past it
-            }
-            const uint32_t b = ti % NB;
             // (the lane's row / half are REBUILT here from the lane id: kept across the loop they were spilled, and a reload inside
-            // the loop is followed by s_waitcnt vmcnt(0), which also waits for the tile DMA in flight — a round trip per chunk)
+            // the loop is followed by s_waitcnt vmcnt(0), which also waits for the tile DMA in flight)
             const int ln = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
             int jl = ln & 31, hl = ln >> 5;
             asm volatile("" : "+v"(jl), "+v"(hl));
-            const char* ab = buf_of(b) + ((ci & 1u) * 32 + jl) * RSc + 16 * hl;
-            const char* mb = reinterpret_cast<const char*>(mu_buf) + 16 * hl + b * 256u;
-            if (!(RG_TPW_ABL & 16)) { load_mu(ac[0], mb, static_cast<int>(ci & 1u)); ac[1] = ac[0]; }
+            const uint32_t b = ti % NB, bn = ODD ? (ti + 1) % NB : b;
+            const char* ab = buf_of(b) + ((ODD ? 32 : 0) + jl) * RSc + 16 * hl;
+            const char* abn = buf_of(bn) + ((ODD ? 0 : 32) + jl) * RSc + 16 * hl;            // the next chunk's rows
+            const char* mbn = reinterpret_cast<const char*>(mu_buf) + 16 * hl + bn * 256u + (ODD ? 0u : 128u);
             f32x2 x[UG][4];
-            bf16x8 Ar[RD];
+            auto slot = [&](int i) {
+                if (i < ESL) {
+                    if (have_p) {
 #pragma unroll
-            for (int s2 = 0; s2 < RD - 1 && s2 < N1; ++s2) Ar[s2] = *reinterpret_cast<const bf16x8*>(ab + 32 * s2);
-            RG_PIN();
-            auto exps = [&](int slot_i) {
+                        for (int e = i * EPS; e < (i + 1) * EPS; ++e) {
+                            const int g = e >> 3, r = e & 7;              // accumulator of group g, register pair r
+                            asm volatile("" : "+v"(pv[g]));
+                            f32x2 y = {(RG_TPW_ABL & 1) ? pv[g][2 * r] * 0.5f : __builtin_amdgcn_exp2f(pv[g][2 * r]),
+                                       (RG_TPW_ABL & 1) ? pv[g][2 * r + 1] * 0.5f : __builtin_amdgcn_exp2f(pv[g][2 * r + 1])};
+                            asm volatile("" : "+v"(y));
+                            if (r < 4) x[g][r] = y; else x[g][r & 3] += y;
+                        }
+                    }
+                } else if (i == ESL) {
+                    if (have_p) {
+                        float sm[UG];
 #pragma unroll
-                for (int e = slot_i * EPS; e < (slot_i + 1) * EPS && e < NEP; ++e) {
-                    const int g = e >> 3, r = e & 7;                  // accumulator of group g, register pair r
-                    asm volatile("" : "+v"(pv[g]));
-                    f32x2 y = {(RG_TPW_ABL & 1) ? pv[g][2 * r] * 0.5f : __builtin_amdgcn_exp2f(pv[g][2 * r]),
-                               (RG_TPW_ABL & 1) ? pv[g][2 * r + 1] * 0.5f : __builtin_amdgcn_exp2f(pv[g][2 * r + 1])};
-                    asm volatile("" : "+v"(y));
-                    if (r < 4) x[g][r] = y; else x[g][r & 3] += y;
+                        for (int g = 0; g < UG; ++g) {
+                            const f32x2 z = (x[g][0] + x[g][2]) + (x[g][1] + x[g][3]);
+                            sm[g] = z[0] + z[1];
+                        }
+                        book(ci - 1, sm[0], sm[1]);
+                    }
+                } else if (i <= ESL + 4) {
+                    if (has_next && !(RG_TPW_ABL & 16)) load_mu_q(pv[0], mbn, i - ESL - 1);
+                } else if (i <= ESL + 8) {
+                    if (has_next && !(RG_TPW_ABL & 16)) load_mu_q(pv[1], mbn, i - ESL - 5);
                 }
             };
+            RG_PIN();
 #pragma unroll
             for (int s2 = 0; s2 < N1; ++s2) {
-                if (s2 + RD - 1 < N1 && !(RG_TPW_ABL & 32)) Ar[(s2 + RD - 1) % RD] = *reinterpret_cast<const bf16x8*>(ab + 32 * (s2 + RD - 1));
+                if (ODD && s2 == N1 - RD + 1 && has_next && !(RG_TPW_ABL & 4)) {
+                    // the next chunk opens tile ti + 1: it has landed once this wave's DMA (issued a tile ago) is done; every wave is
+                    // past tile ti - 1, whose buffer takes tile ti + 2
+                    RG_TILE_BARRIER(0);
+                    if (ti + 2 < n_t) fetch_tile(ti + 2);
+                }
+                {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int qn = s2 + RD - 1;
+                    if (!(RG_TPW_ABL & 32)) {
+                        if (qn < N1) Ar[(ROFF + qn) % RD] = *reinterpret_cast<const bf16x8*>(ab + 32 * qn);
+                        else if (has_next) Ar[(ROFF + qn) % RD] = *reinterpret_cast<const bf16x8*>(abn + 32 * (qn - N1));
+                    }
+                }
 #pragma unroll
                 for (int g = 0; g < UG; ++g) {
-                    if (!(RG_TPW_ABL & 2)) ac[g] = mm(Ar[(RG_TPW_ABL & 32) ? 0 : s2 % RD], Bm[g][s2], ac[g]);
-                    if (have_p) exps(s2 * UG + g);
+                    if (!(RG_TPW_ABL & 2)) ac[g] = mm(Ar[(ROFF + s2) % RD], Bm[g][s2], ac[g]);
+                    slot(s2 * UG + g);
                     RG_PIN();
                 }
             }
-            if (have_p) {
-                float sm[UG];
-#pragma unroll
-                for (int g = 0; g < UG; ++g) {
-                    const f32x2 z = (x[g][0] + x[g][2]) + (x[g][1] + x[g][3]);
-                    sm[g] = z[0] + z[1];
-                }
-                book(ci - 1, sm[0], sm[1]);
-            }
         };
         f32x16 accA[UG], accB[UG];
-        chunk_step(0, accA, accB, false);
-        uint32_t ci = 1;
-        for (; ci + 1 < n_c; ci += 2) {
-            chunk_step(ci, accB, accA, true);
-            chunk_step(ci + 1, accA, accB, true);
+        {   // chunk 0's seeds and first A fragments
+            const char* mb0 = reinterpret_cast<const char*>(mu_buf) + 16 * h;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) { load_mu_q(accA[0], mb0, qq); load_mu_q(accA[1], mb0, qq); }
+#pragma unroll
+            for (int s2 = 0; s2 < RD - 1 && s2 < N1; ++s2) Ar[s2] = *reinterpret_cast<const bf16x8*>(a_lane0 + 32 * s2);
         }
-        chunk_step(ci, accB, accA, true);               // (n_c is even: the last chunk goes into accB)
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, N1 % RD>;
+        using I2 = std::integral_constant<int, (2 * N1) % RD>; using I3 = std::integral_constant<int, (3 * N1) % RD>;
+        // (n_chunks is a multiple of 4: four chunk steps bring the ring back to slot 0; first / last group: compile-time flags, so
+        // that no chunk step carries a branch per slot)
+        using T_ = std::true_type; using F_ = std::false_type;
+        auto group = [&](uint32_t ci, auto first_, auto last_) {
+            constexpr bool FIRST = decltype(first_)::value, LAST = decltype(last_)::value;
+            chunk_step(I0{}, F_{}, std::bool_constant<!FIRST>{}, T_{}, ci, accA, accB);
+            chunk_step(I1{}, T_{}, T_{}, T_{}, ci + 1, accB, accA);
+            chunk_step(I2{}, F_{}, T_{}, T_{}, ci + 2, accA, accB);
+            chunk_step(I3{}, T_{}, T_{}, std::bool_constant<!LAST>{}, ci + 3, accB, accA);
+        };
+        if (n_c == 4) group(0, T_{}, T_{});
+        else {
+            group(0, T_{}, F_{});
+            uint32_t ci = 4;
+            for (; ci + 4 < n_c; ci += 4) group(ci, F_{}, F_{});
+            group(ci, F_{}, T_{});
+        }
         {   // the last chunk's own sums
             float sm[UG];
 #pragma unroll
