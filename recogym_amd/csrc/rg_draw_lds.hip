@@ -32,7 +32,8 @@
 #define RG_PICK_ABL 0
 #endif
 // -DRG_TPW_ABL=bits on k_draw_tpw: 1: exps replaced by a multiply, 2: no MFMAs, 4: no tile barrier / DMA beyond the first three
-// tiles, 8: no books, 16: no mu seeds, 32: the A ring is not re-read (one fragment for every k-step)
+// tiles, 8: no books, 16: no mu seeds, 32: the A ring is not re-read (one fragment for every k-step), 64: print the shader clock
+// under the kernel's load (s_memtime against the 100 MHz s_memrealtime over one work item)
 #ifndef RG_TPW_ABL
 #define RG_TPW_ABL 0
 #endif
@@ -601,6 +602,9 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
             if (wave == NW - 1 && lane < 16) dma_to_lds_b128(rs_m, mu_lds + b * 256u, lane16, ti * 256u);
         };
         fetch_tile(0);
+#if (RG_TPW_ABL & 64)
+        const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
         // ---- omega32 of the users -> LDS stage (also the logit error bound) and behind the draw's record (k_pick's B operands) ----
         float Ahat[UG];
         double delta_fixed[UG];
@@ -816,6 +820,14 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
             book(n_c - 1, sm[0], sm[1]);
         }
         // ---- the draw's super-tile (a count in LDS) and what k_pick needs ----
+#if (RG_TPW_ABL & 64)
+        // the shader clock under this kernel's load: cycles (s_memtime) per 100 MHz tick (s_memrealtime) over one work item's sweep
+        if (blockIdx.x == 7 && threadIdx.x == 0 && tb == blockIdx.x) {
+            const unsigned long long c1 = __builtin_amdgcn_s_memtime() - clk0, r1 = __builtin_amdgcn_s_memrealtime() - rt0;
+            printf("k_draw_tpw work item: %llu shader cycles in %llu ticks of 100 MHz = %.0f MHz; %u tiles: %.0f cycles per tile\n", c1, r1,
+                   100.0 * static_cast<double>(c1) / static_cast<double>(r1), n_t, static_cast<double>(c1) / n_t);
+        }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
