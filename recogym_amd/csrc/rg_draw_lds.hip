@@ -666,13 +666,17 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
         // ---- the books: a float64 running prefix per user, one fp32 rounding of it to LDS per super-tile ----
         double run_pref[UG] = {0.0, 0.0};
         const uint32_t n_c = d.n_chunks, cps = d.tp_cpt;                  // chunks; chunks per super-tile
+        uint32_t st_left = cps, st_idx = 0;                              // chunks left in the super-tile being summed; its index
         auto book = [&](uint32_t ci_done, float s0, float s1) {          // s_g: group g's exp-sum of chunk ci_done (this lane's half)
             if (RG_TPW_ABL & 8) { run_pref[0] += static_cast<double>(s0 + s1); return; }
             s0 += swap32(s0);
             s1 += swap32(s1);
             run_pref[0] += static_cast<double>(s0);
             run_pref[1] += static_cast<double>(s1);
-            if ((ci_done + 1) % cps == 0 || ci_done + 1 == n_c) trow_own[ci_done / cps] = static_cast<float>(h ? run_pref[1] : run_pref[0]);
+            if (--st_left == 0 || ci_done + 1 == n_c) {                  // (counters, not ci_done % cps: an integer division per chunk is ~20 scalar instructions in a one-wave stream)
+                trow_own[st_idx] = static_cast<float>(h ? run_pref[1] : run_pref[0]);
+                ++st_idx; st_left = cps;
+            }
         };
         RG_DMA_WAIT();
         __syncthreads();           // tile 0 landed; every wave has built its B rows from the stage (which tiles 1, 2 and the prefix rows now overwrite)
@@ -711,7 +715,7 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
             acc[4 * qq] = m.x; acc[4 * qq + 1] = m.y; acc[4 * qq + 2] = m.z; acc[4 * qq + 3] = m.w;
         };
         bf16x8 Ar[RD];
-        auto chunk_step = [&](auto roff_, auto odd_, auto hp_, auto hn_, uint32_t ci, f32x16 (&ac)[UG], f32x16 (&pv)[UG]) {
+        auto chunk_step = [&](auto roff_, auto odd_, auto hp_, auto hn_, uint32_t ci, uint32_t b, f32x16 (&ac)[UG], f32x16 (&pv)[UG]) {
             constexpr int ROFF = decltype(roff_)::value;               // ring slot of this chunk's k-step 0
             constexpr bool ODD = decltype(odd_)::value;                // second chunk of its tile
             constexpr bool have_p = decltype(hp_)::value;              // there is a chunk before (its logits in `pv`)
@@ -722,7 +726,7 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
             const int ln = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
             int jl = ln & 31, hl = ln >> 5;
             asm volatile("" : "+v"(jl), "+v"(hl));
-            const uint32_t b = ti % NB, bn = ODD ? (ti + 1) % NB : b;
+            const uint32_t bn = ODD ? (b == NB - 1 ? 0u : b + 1u) : b;           // (b = ti % NB, carried by the caller)
             const char* ab = buf_of(b) + ((ODD ? 32 : 0) + jl) * RSc + 16 * hl;
             const char* abn = buf_of(bn) + ((ODD ? 0 : 32) + jl) * RSc + 16 * hl;            // the next chunk's rows
             const char* mbn = reinterpret_cast<const char*>(mu_buf) + 16 * hl + bn * 256u + (ODD ? 0u : 128u);
@@ -794,12 +798,15 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
         // (n_chunks is a multiple of 4: four chunk steps bring the ring back to slot 0; first / last group: compile-time flags, so
         // that no chunk step carries a branch per slot)
         using T_ = std::true_type; using F_ = std::false_type;
+        uint32_t b0 = 0;                                 // LDS buffer of the group's first tile (tile index mod NB)
         auto group = [&](uint32_t ci, auto first_, auto last_) {
             constexpr bool FIRST = decltype(first_)::value, LAST = decltype(last_)::value;
-            chunk_step(I0{}, F_{}, std::bool_constant<!FIRST>{}, T_{}, ci, accA, accB);
-            chunk_step(I1{}, T_{}, T_{}, T_{}, ci + 1, accB, accA);
-            chunk_step(I2{}, F_{}, T_{}, T_{}, ci + 2, accA, accB);
-            chunk_step(I3{}, T_{}, T_{}, std::bool_constant<!LAST>{}, ci + 3, accB, accA);
+            const uint32_t b1 = b0 == NB - 1 ? 0u : b0 + 1u;
+            chunk_step(I0{}, F_{}, std::bool_constant<!FIRST>{}, T_{}, ci, b0, accA, accB);
+            chunk_step(I1{}, T_{}, T_{}, T_{}, ci + 1, b0, accB, accA);
+            chunk_step(I2{}, F_{}, T_{}, T_{}, ci + 2, b1, accA, accB);
+            chunk_step(I3{}, T_{}, T_{}, std::bool_constant<!LAST>{}, ci + 3, b1, accB, accA);
+            b0 = b1 == NB - 1 ? 0u : b1 + 1u;
         };
         if (n_c == 4) group(0, T_{}, T_{});
         else {

@@ -16,7 +16,7 @@ for spec in sys.argv[2:]:
     for p in range(1, g.N_PARTS + 1):
         if p != unit:
             shutil.copy2(os.path.join(csrc, 'build', f'part{p}.o'), os.path.join(objdir, f'part{p}.o'))
-    cmd = [g.HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', *flags.split(','), '-c', '-o',
+    cmd = [g.HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', *g.UNIT_FLAGS.get(g.UNITS[unit - 1], []), *flags.split(','), '-c', '-o',
            os.path.join(objdir, f'part{unit}.o'), os.path.join(csrc, g.UNITS[unit - 1] + '.hip')]
     procs.append((name, objdir, subprocess.Popen(cmd)))
     if len(procs) % 6 == 0:
