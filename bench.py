@@ -51,7 +51,7 @@ F64_VALU_PEAK_TFLOPS = 78.6
 HBM_PEAK_GBPS = 8000.0
 EXP_PEAK_PER_S = 1024 * 4 * 2.4e9  # v_exp_f32: quarter rate, 4 lanes per cycle and SIMD (MI355X_MICROARCH.md: transcendentals)
 VALU_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 4   # a SIMD issues one full-rate vector wave-instruction per 4 cycles: 256 CUs x 4 SIMDs
-PROFILE_ROUNDS = ('r5', 'r4', 'r3', 'r2')      # profiles/<round>/pmc_traffic.json, newest first
+PROFILE_ROUNDS = ('r6', 'r5', 'r4', 'r3', 'r2')      # profiles/<round>/pmc_traffic.json, newest first
 
 
 def policy_kwargs(pol):
@@ -542,11 +542,11 @@ def main():
             # PCIe into pinned buffers the simulator keeps (first call: incl. their allocation; second: steady state)
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
-            cols = s0.log_columns()
+            cols = s0.log_columns(copy=False)
             torch.cuda.synchronize(device)
             dt_first = time.perf_counter() - t0
             t0 = time.perf_counter()
-            cols = s0.log_columns()
+            cols = s0.log_columns(copy=False)
             torch.cuda.synchronize(device)
             dt = time.perf_counter() - t0
             n_cols = int(len(cols['t']))

@@ -141,6 +141,9 @@ typedef struct rg_event {
 #define RG_CNT_ANCHORED 24      /* sigma_omega = 0 walk: the part of RG_CNT_EXACT_DRAWS that the float64-ANCHORED certificate resolved
                                    (the user's float64 prefix at the start of the draw's 64-product chunk + fp32 inside it) instead
                                    of a float64 walk of the chunk's products */
+#define RG_CNT_BAD_ACTION 25   /* RG_POLICY_EXTERNAL: events whose action was outside [0, num_products): rg_sim_step evaluates them with
+                                 * product 0 (it must not index beta / mu_b with them) and LOGS a = 0 — a caller bug made visible here
+                                 * (rg_sim_step_user rejects the same input with RG_EINVAL before it reaches the device) */
 #define RG_CNT_N 32             /* out[] of rg_sim_read_counters; slots 16..23 are internal */
 
 typedef struct rg_sim rg_sim;

@@ -27,6 +27,7 @@ RG_EV_INDEX_MASK = 0x1FFFFFFF
  RG_CNT_LOG_ROWS, RG_CNT_LOG_DROPPED, RG_CNT_EXACT_DRAWS, RG_CNT_HIST_OVERFLOW,
  RG_CNT_EXACT_SWEEPS, RG_CNT_EXACT_OVERFLOW, RG_CNT_LR_ACTS, RG_CNT_LR_ROWS, RG_CNT_LR_EXACT, RG_CNT_MEMO_HITS) = range(16)
 RG_CNT_ANCHORED = 24
+RG_CNT_BAD_ACTION = 25
 RG_CNT_N = 32
 
 RG_ERRORS = {-1: 'RG_EINVAL', -2: 'RG_ENODEV', -3: 'RG_ENOMEM', -4: 'RG_ESTATE', -5: 'RG_ELIMIT'}

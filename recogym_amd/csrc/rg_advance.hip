@@ -436,7 +436,9 @@ __global__ void __launch_bounds__(kAdvBlock) k_advance(DevSim d, uint32_t t, con
                 if (d.policy == RG_POLICY_EXTERNAL) {
                     // (an action outside [0, P) — e.g. the -1 of a caller that had none — must not index beta / mu_b: product 0)
                     const int32_t ai = actions[uidx];
-                    a = (ai < 0 || static_cast<uint32_t>(ai) >= d.P) ? 0u : static_cast<uint32_t>(ai);
+                    const bool bad = ai < 0 || static_cast<uint32_t>(ai) >= d.P;
+                    if (bad) atomicAdd(&d.counters[RG_CNT_BAD_ACTION], 1ull);      // (a caller bug: counted, see recogym_hip.h)
+                    a = bad ? 0u : static_cast<uint32_t>(ai);
                     ps = __builtin_nan("");
                 }
                 else if (d.policy == RG_POLICY_LOGREG_FROZEN) { a = lr_a; ps = d.lr_sample ? d.lr_ps[uidx] : 1.0; }

@@ -359,6 +359,7 @@ struct rg_sim {
     size_t tp_smem;
     uint32_t tp_nts;         // its LDS row stride (floats) of a user's tile prefixes
     uint32_t sweep_lds;      // option: 1 = use it (default), 0 = k_draw_bf16p everywhere (A/B tests)
+    bool handover_auto;      // walk_handover follows the reset range (16 below 2 M users, else 32) until it is set explicitly
     uint32_t draw_threads, draw_users;   // block size of that kernel and the users one block sweeps for (256 / 128; wide K: 512 / 256)
     bool profiling;
     std::vector<hipEvent_t> prof_events;   // 6 per profiled step: before draw, after mfma, after search, after exact, after the frozen LogReg acts, after advance
@@ -1945,13 +1946,15 @@ __device__ __forceinline__ bool xh_eligible(double Ahat, double qabs) {
 template <int NL>
 __device__ __forceinline__ double xh_delta(const DevSim& d, double Ahat, double absw, double egam, double lob, double qabs) {
     constexpr double e24 = 5.9604644775390625e-08, ln2 = 0.6931471805599453, log2e = 1.4426950408889634;
-    if (!xh_eligible(Ahat, qabs))      // the leading sum may round: the two-way split kernel's budget (same accumulation model)
-        return static_cast<double>(d.K + 5) * e24 * Ahat + kDeltaFixedBf16 + f16_extra_delta(d, static_cast<float>(Ahat), static_cast<float>(absw));
     const double e_lo = (16.0 * NL + 4.0) * e24 * (lob + 1.6e-5);        // every add of the residual chain rounds at its own size
     const double e_x = e24 * (Ahat * log2e + qabs) * 1.01;               // the join H + 2^-9 L: one rounding of the exp2 argument
     // what the pieces leave out, per coordinate: Glo wlo <= 2^-9 2^-21, the omega tail <= |Ghi| 2^-33 <= 2^-30, the second scaled
     // copies of Glo / wmid (a bit below fp16's normal range at most): 4e-9 covers 2^-29
     const double e_drop = static_cast<double>(d.K) * 4.0e-9;
+    if (!xh_eligible(Ahat, qabs))      // the leading sum may round: the two-way split kernel's accumulation budget ON TOP of this kernel's own
+        // representation / residual / join terms (the sums are k_sweep_xh's, whatever the budget that certifies them)
+        return static_cast<double>(d.K + 5) * e24 * Ahat + kDeltaFixedBf16 + f16_extra_delta(d, static_cast<float>(Ahat), static_cast<float>(absw)) +
+               ln2 * (egam + e_drop + e_lo + e_x);
     (void)absw;
     const double sweep = ln2 * (egam + e_drop + e_lo + e_x) + kDeltaFixedXh;
 #if RG_WALK_PRECISE_CHUNK

@@ -425,9 +425,27 @@ __global__ void __launch_bounds__(kBlock) k_cache_finalize(DevSim d) {
                 rec[2 * q] = make_float2(x.x, x.y); rec[2 * q + 1] = make_float2(x.z, x.w);
             }
         }
-        float Q = -INFINITY;
+        float Q = -INFINITY, qabs = 0.0f;
 #pragma unroll
-        for (uint32_t sc = 0; sc < kMaxSC; ++sc) if (sc < d.n_sc) Q = fmaxf(Q, rec[sc].y);
+        for (uint32_t sc = 0; sc < kMaxSC; ++sc) if (sc < d.n_sc) { Q = fmaxf(Q, rec[sc].y); qabs = fmaxf(qabs, fabsf(rec[sc].y)); }
+        if (d.XNH) {
+            // the sums are k_sweep_xh's (a user whose reference moved, or a run with the finalize output left to this kernel): its own
+            // representation / residual / join terms on top of the accumulation budget above (xh_delta's ineligible branch), with the
+            // residual bound taken at its largest (|omega - whi| <= 2^-9) — ADVICE round 5
+            const float glomax = d.xstats[2 * KH];
+            float egam = 0.0f, lob = d.xstats[2 * KH + 1];
+#pragma unroll
+            for (int k = 0; k < K2; ++k) {
+                const float wf = fabsf(om[k]) * 1.0000002f, r1f = 0.001953125f * 1.002f;
+                egam = fmaf(wf, d.xstats[k], egam);
+                lob = fmaf(r1f, d.stats[k] * kLog2e * 1.000001f + 0.00390625f, lob);
+                lob = fmaf(wf + r1f, glomax, lob);
+            }
+            const double e24 = 5.9604644775390625e-08;
+            const double e_lo = (16.0 * d.XNL + 4.0) * e24 * (static_cast<double>(lob) + 1.6e-5);
+            const double e_x = e24 * (static_cast<double>(Ahat) * 1.4426950408889634 + static_cast<double>(qabs)) * 1.01;
+            delta += 0.6931471805599453 * (static_cast<double>(egam) + static_cast<double>(d.K) * 4.0e-9 + e_lo + e_x);
+        }
         uint32_t offw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         float W[kMaxSC];
 #pragma unroll

@@ -1188,7 +1188,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     d.walk_bias = 8;
     d.walk_refill = 8;
     d.walk_handover = 32;
-    if (const char* e = getenv("RECOGYM_WALK_HANDOVER")) d.walk_handover = static_cast<uint32_t>(atoi(e));
+    s->handover_auto = true;
+    if (const char* e = getenv("RECOGYM_WALK_HANDOVER")) { d.walk_handover = static_cast<uint32_t>(atoi(e)); s->handover_auto = false; }
     d.walk_click_batch = 8;
     if (const char* e = getenv("RECOGYM_WALK_CLICK_BATCH")) d.walk_click_batch = static_cast<uint32_t>(atoi(e));
     d.walk_search_batch = 16;
@@ -1335,6 +1336,7 @@ int rg_sim_set_option(rg_sim* sim, const char* name, int64_t value) {
         if (!strcmp(name, "run_ahead") && value > 64) return fail(RG_EINVAL, "run_ahead must be <= 64 events");
         if (!strcmp(name, "run_ahead") && value && sim->d.env_kind) return fail(RG_EINVAL, "env_kind 1 (reco-gym-v0) runs lock-step (run_ahead = 0)");
         if (!strcmp(name, "walk_search_batch") && value < 1) value = 1;
+        if (!strcmp(name, "walk_handover")) sim->handover_auto = false;
         if (!strcmp(name, "walk_click_join") && value > 1) return fail(RG_EINVAL, "walk_click_join is a flag (0 or 1)");
         if (!strcmp(name, "walk_helpers") && value > kWalkHelpersMax) return fail(RG_EINVAL, "walk_helpers must be in [0, %u]", kWalkHelpersMax);
         if (!strcmp(name, "pipe_min_users") && value < 256) return fail(RG_EINVAL, "pipe_min_users must be >= 256");
@@ -1501,6 +1503,10 @@ int rg_sim_reset_users(rg_sim* sim, uint64_t first_user_id, uint64_t n, uint64_t
     d.n_users = static_cast<uint32_t>(n);      // lists stay strided by the carve-time n_cap
     d.grp_lo = 0; d.grp_n = d.n_users;
     d.run_ahead = 0;                           // rg_sim_run turns the rounds on for a run to the end
+    // live lanes at which a draining wave hands its users to the next round: what it hands over also goes through the float64
+    // batch, and a small shard's rounds drain sooner — 16 below 2 M users (a 1.25 M-user shard of C3: 21.3 -> 20.0 ms), else 32
+    // (profiles/r6/ab_call19_handover.jsonl)
+    if (sim->handover_auto) d.walk_handover = n < 2000000ull ? 16u : 32u;
     HIP_TRY(hipMemsetAsync(d.step_cnt, 0, sizeof(uint32_t) * 2 * (kMaxSteps + 2), st));
     HIP_TRY(hipMemsetAsync(d.exact_cnt, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
     HIP_TRY(hipMemsetAsync(d.exact_cnt_b, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));

@@ -600,7 +600,10 @@ __global__ void __launch_bounds__(kBlock) k_cache_prefix(DevSim d, int fused) {
                 // prefixes (<= 5 of 2^-24 each, relative to the prefix: the same kind of error the budget is made of), Q, an empty memo
                 float4* hot = reinterpret_cast<float4*>(d.walk_hot + row * 32);
                 hot[0] = make_float4(static_cast<float>(run), hdr.y * 1.000001f + 4.8e-7f, hdr.x, __builtin_bit_cast(float, 0u));
-                reinterpret_cast<float*>(hot)[31] = kRhoLoose;      // (these prefixes went through several fp32 / rescaling roundings)
+                // (these prefixes went through several fp32 / rescaling roundings: rho = 2^-20.  Behind k_sweep_xh the records of a
+                // user whose reference moved are fp32 DIFFERENCES of staged prefixes — each off by ~2 x 2^-24 of the prefix, up to
+                // kMaxSC = 32 of them summed again here: 2^-19 at worst, so such rows get 2^-18.  ADVICE round 5)
+                reinterpret_cast<float*>(hot)[31] = (d.XNH && d.cache_resc[row]) ? 4.0f * kRhoLoose : kRhoLoose;
             }
         }
     }

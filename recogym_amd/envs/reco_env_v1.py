@@ -590,9 +590,10 @@ class RecoEnv1(_EnvBase):
         users, `agent.act` called on the host for every user that needs an action — a copy of the agent per user slot
         (`deepcopy`, the way the reference's harness copies agents: bench_agents.py:79,85), reset per user like `env.reset` does.
         Rows are those of the one-user-at-a-time path (`_generate_logs_per_user`) for every agent whose `act` depends on its
-        own user's observations only; an agent that carries state ACROSS users (a sequential RNG stream of its own, a model it
-        trains while acting) sees its users interleaved here — set `agent.per_user_path = True` (or the env arg
-        `per_user_path`) to keep the sequential path for it."""
+        own user's observations only.  `generate_logs` takes this route only for agents that pass `batch_safe()`: an agent that
+        owns a sequential random stream (its per-slot copies would all replay the SAME draws) keeps the one-user-at-a-time
+        path, and so does any agent with `per_user_path = True` / `batch_safe = False` (a model it trains while acting).  The
+        copies share large read-only model state (`_shared_state_memo`); what a copy still owns bounds the batch."""
         P = self.config.num_products
         total = num_offline_users + num_organic_offline_users
         org_below = first_user_id + num_organic_offline_users

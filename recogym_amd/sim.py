@@ -281,6 +281,7 @@ class Simulator:
                  'lr_exact', 'memo_hits']
         res = {k: int(out[i]) for i, k in enumerate(names)}
         res['anchored'] = int(out[_abi.RG_CNT_ANCHORED])
+        res['bad_actions'] = int(out[_abi.RG_CNT_BAD_ACTION])        # external actions outside [0, P) that reached the device
         return res
 
     def set_profiling(self, on=True):
@@ -373,15 +374,16 @@ class Simulator:
             uniform = 1.0 / float(self.config.num_products)
         return out.cpu().numpy(), uniform
 
-    def log_columns(self, on_device=False, chunk_rows=1 << 25):
+    def log_columns(self, on_device=False, chunk_rows=1 << 25, copy=True):
         """The log in the reference's row order, decoded ON THE DEVICE into the columns of the reference's DataFrame
         (SURVEY.md §8f-2): dict(t f32, u i32, is_bandit bool, v i32, a i32, c f32 (NaN on organic rows), ps f64 (NaN)).
 
         To the host (the default) the columns travel in chunks of `chunk_rows` rows: chunk i is decoded into one of two staging
         sets on the simulator's stream while chunk i - 1 crosses PCIe on a copy stream, straight into PINNED host buffers the
-        simulator keeps between calls (allocated on the first call, grown when a log is longer); the arrays returned are
-        zero-copy NumPy views of those buffers — valid until the next log_columns() of this simulator (they keep the buffers
-        alive on their own: closing the simulator does not invalidate them)."""
+        simulator keeps between calls (allocated on the first call, grown when a log is longer).  `copy=True` (the default)
+        returns arrays that OWN their memory; `copy=False` returns zero-copy NumPy views of those pinned buffers — valid only
+        until the next log_columns() of this simulator, which reuses them, and page-locked for as long as anything references them
+        (for callers that control that lifetime: bench.py's materialise figure, a DataFrame built and dropped at once)."""
         out, offsets = self.sorted_log()
         ps64, _ = self.sorted_aux(offsets, out.shape[0])
         n = int(out.shape[0])
@@ -448,7 +450,7 @@ class Simulator:
                     done[i & 1] = torch.cuda.Event()
                     done[i & 1].record(cs)
             cs.synchronize()
-            return {k: v[:n].numpy() for k, v in host.items()}
+            return {k: (v[:n].numpy().copy() if copy else v[:n].numpy()) for k, v in host.items()}
 
     _HOST_COLS = (('t', torch.float32), ('u', torch.int32), ('is_bandit', torch.bool), ('v', torch.int32), ('a', torch.int32),
                   ('c', torch.float32), ('ps', torch.float64))

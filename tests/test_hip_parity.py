@@ -1327,3 +1327,28 @@ def test_raw_log_rows_beyond_2_31_are_kept(form, monkeypatch):
     want = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol).generate_logs(n)
     gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps')}, ps_rtol=1e-12, what=f'row base 2^31 - 4096, {form}')
     assert (rows['phantom'] == want['phantom']).all()
+
+
+def test_external_actions_out_of_range_are_counted():
+    """RG_POLICY_EXTERNAL (the gym path's actions arrive from the host): an action outside [0, P) must not index beta / mu_b — the
+    batched rg_sim_step evaluates it with product 0 — and is COUNTED (RG_CNT_BAD_ACTION), so that a caller bug is visible instead of
+    producing plausible rows (rg_sim_step_user rejects the same input with RG_EINVAL)."""
+    from recogym_amd.sim import Simulator
+    cfg = Configuration({**env_1_args, 'random_seed': 3, 'num_products': 12, 'K': 4, 'sigma_omega': 0.0})
+    n = 4096
+    sim = Simulator(cfg, n, device='cuda:0', policy=_abi.RG_POLICY_EXTERNAL)
+    sim.reset_users(0, n)
+    acts = torch.zeros(n, dtype=torch.int32, device='cuda:0')
+    bad = 0
+    for t in range(6):
+        a = torch.randint(0, 12, (n,), dtype=torch.int32, device='cuda:0')
+        a[::7] = -1
+        a[3::11] = 12
+        st = sim.states()                                   # who is at a bandit event now: only their action is read
+        is_b = torch.zeros(n, dtype=torch.bool, device='cuda:0')
+        is_b[:st.numel()] = st == 1
+        bad += int((is_b & ((a < 0) | (a >= 12))).sum().item())
+        sim.step(a)
+    c = sim.counters()
+    sim.close()
+    assert bad > 0 and c['bad_actions'] == bad, (bad, c['bad_actions'])

@@ -79,6 +79,14 @@ def main():
                                               dd['kernels']['draw_sweep']['units'], 'swept draws', f"c3drift, {dd['config']['users_per_gpu']} users"))
     except Exception as e:
         print('skipped c3drift', repr(e))
+    try:     # round 6: the sweep without a scratch and its search on the matrix cores
+        dd = bench_line('pmc_c3drift_fetch')
+        for kern in ('k_draw_tp', 'k_pick', 'k_advance_run', 'k_exact_sums'):
+            try_add(kern, lambda kern=kern: entry('c3drift', 'pmc_c3drift_fetch', 'pmc_c3drift_write', kern,
+                                                  dd['kernels']['draw_sweep']['units'] if kern != 'k_advance_run' else dd['config']['events_per_step'],
+                                                  'swept draws' if kern != 'k_advance_run' else 'events', f"c3drift, {dd['config']['users_per_gpu']} users"))
+    except Exception as e:
+        print('skipped c3drift (r6 kernels)', repr(e))
     try:
         d5 = bench_line('pmc_c5_fetch')
         k5 = d5['kernels']['logreg_ips_frozen.logreg_acts']
