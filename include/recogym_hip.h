@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION 5
+#define RG_ABI_VERSION 6
 
 /* error codes */
 #define RG_OK 0
@@ -230,6 +230,13 @@ int rg_sim_set_logreg_fp32(rg_sim* sim, const float* d_coef32_t, const float* d_
  * sum_p views_p (2^-11 wmax[p] + 2^-25) + (views + 3) 2^-24 (bmax + sum_p views_p wmax[p]) of the best one, and decides among
  * them by float64 scores in scipy's order (rg_sim_set_logreg's arrays): sklearn's predict() bit for bit.  NULL = off. */
 int rg_sim_set_logreg_fp16(rg_sim* sim, const uint16_t* d_coef16_t);
+
+/* Optional: the screening pass from an 8-bit copy of coef^T instead of the fp16 one (after rg_sim_set_logreg_fp16; ABI v6): the rows
+ * the pass streams are a QUARTER of the float32 bytes.  d_coef8_t [num_products][n_classes] unsigned bytes q + 128 with
+ * q = rint(coef^T[p][c] / d_scale8[p]) in [-127, 127], d_scale8[p] = wmax[p] / 127 (fp32, rounded up): a weight is off by at most
+ * d_scale8[p] / 2, so the pass's bound is sum_p views_p wmax[p] / 254 (+ the fp32 accumulation terms) where the fp16 pass has
+ * sum_p views_p wmax[p] 2^-11 — more classes survive it, float64 scores still decide among them.  NULL = the fp16 pass. */
+int rg_sim_set_logreg_int8(rg_sim* sim, const uint8_t* d_coef8_t, const float* d_scale8);
 
 /* Where rows go.  d_log == NULL (or capacity 0) disables logging: only counters are kept. */
 int rg_sim_set_log(rg_sim* sim, rg_event* d_log, uint64_t capacity);

@@ -7,7 +7,7 @@ infrastructure and is never imported from this package.)
 import ctypes as C
 import os
 
-RG_ABI_VERSION = 5
+RG_ABI_VERSION = 6
 
 RG_STATE_ORGANIC, RG_STATE_BANDIT, RG_STATE_STOP = 0, 1, 2
 
@@ -90,6 +90,7 @@ SYMBOLS = {
     'rg_sim_set_logreg': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     'rg_sim_set_logreg_fp32': (C.c_int, [_SIM, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]),
     'rg_sim_set_logreg_fp16': (C.c_int, [_SIM, C.c_void_p]),
+    'rg_sim_set_logreg_int8': (C.c_int, [_SIM, C.c_void_p, C.c_void_p]),
     'rg_sim_set_log': (C.c_int, [_SIM, C.c_void_p, C.c_uint64]),
     'rg_sim_reset_users': (C.c_int, [_SIM, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     'rg_sim_reseed': (C.c_int, [_SIM, C.c_uint64, C.c_uint64]),

@@ -232,7 +232,11 @@ __global__ void __launch_bounds__(kBlock) k_logreg_screen(DevSim d, uint32_t t) 
             V += cnt;
         }
         for (int o = 32; o > 0; o >>= 1) { A += __shfl_xor(A, o); V += __shfl_xor(V, o); }
-        const float B = (A * 4.8828125e-4f + V * 2.98023224e-8f + static_cast<float>(nd + 3) * 5.9604644775390625e-08f * (d.lr_bmax + A)) * 1.02f;
+        // (the rows' own error: 2^-11 of wmax per weight from the fp16 copy, wmax / 254 from the 8-bit one)
+        const bool q8 = d.lr_coef8_t != nullptr;
+        // (8-bit: the sums are taken on q + 128 and the offset removed at the end: partial sums up to ~3 A instead of A)
+        const float B = (A * (q8 ? 3.9764e-3f : 4.8828125e-4f) + V * 2.98023224e-8f +
+                         static_cast<float>(nd + 3) * 5.9604644775390625e-08f * (d.lr_bmax + (q8 ? 3.1f : 1.0f) * A)) * 1.02f;
         const float thr = 2.0f * B * 1.01f + 1e-30f;
         const uint32_t c_lo = r * RC, c_hi = min(c_lo + RC, C);
         float rb = -INFINITY;
@@ -248,6 +252,34 @@ __global__ void __launch_bounds__(kBlock) k_logreg_screen(DevSim d, uint32_t t) 
                 const float4 b1 = *reinterpret_cast<const float4*>(d.lr_intercept32 + cl + 4);
                 acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
             }
+            if (q8) {
+                // 8-bit rows: 8 bytes per lane and row (q + 128: v_cvt_f32_ubyte*), count x scale folded into one factor, the
+                // offset 128 sum(count x scale) taken off once at the end
+                float corr = 0.0f;
+                for (uint32_t i0 = 0; i0 < nd; i0 += 8) {            // eight rows in flight
+                    uint2 bv[8];
+                    float cs[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const hent_t x = hr[min(i0 + e, nd - 1)];
+                        const uint32_t pp = h_prod(x);
+                        cs[e] = i0 + e < nd ? static_cast<float>(h_cnt(x)) * d.lr_scale8[pp] : 0.0f;
+                        bv[e] = *reinterpret_cast<const uint2*>(d.lr_coef8_t + static_cast<size_t>(pp) * C + cl);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (i0 + e < nd) {
+                            corr = fmaf(cs[e], 128.0f, corr);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                acc[j] = fmaf(cs[e], static_cast<float>((bv[e].x >> (8 * j)) & 0xFFu), acc[j]);
+                                acc[4 + j] = fmaf(cs[e], static_cast<float>((bv[e].y >> (8 * j)) & 0xFFu), acc[4 + j]);
+                            }
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] -= corr;
+            } else
             for (uint32_t i0 = 0; i0 < nd; i0 += 8) {                // eight rows in flight
                 half8 hv[8];
                 float cn[8];

@@ -256,6 +256,7 @@ struct DevSim {
     // (lr_dirty, set by history_add) and kept per user; k_logreg_select / k_logreg_acts run before k_advance
     const float* lr_coef32_t; const float* lr_intercept32; const float* lr_wmax; float lr_bmax;   // fp32 copies + max_c |coef[p][c]|, max |b|
     const unsigned short* lr_coef16_t;   // fp16 copy of coef^T (screening pass of k_logreg_acts16), or null
+    const uint8_t* lr_coef8_t; const float* lr_scale8;   // 8-bit copy (q + 128) and its per-row scale: the screening pass reads it instead, or null
     uint32_t* lr_action;      // [n_cap] by user index: action of the user's current history
     // select_randomly (rg_config.lr_select_randomly): the act is SAMPLED per event from softmax(scores) — k_logreg_sample leaves the
     // action and its probability for the step's bandit event (or, for an organic user that stops at this step, for its trailing

@@ -1438,7 +1438,7 @@ int rg_sim_set_logreg(rg_sim* sim, const double* d_coef_t, const double* d_inter
     sim->d.lr_n = n_classes;
     // a new model invalidates the optional copies of the old one (their shapes and bounds belong to it): set them again
     sim->d.lr_coef32_t = nullptr; sim->d.lr_intercept32 = nullptr; sim->d.lr_wmax = nullptr; sim->d.lr_bmax = 0.0f;
-    sim->d.lr_coef16_t = nullptr;
+    sim->d.lr_coef16_t = nullptr; sim->d.lr_coef8_t = nullptr; sim->d.lr_scale8 = nullptr;
     return RG_OK;
 }
 
@@ -1450,6 +1450,7 @@ int rg_sim_set_logreg_fp32(rg_sim* sim, const float* d_coef32_t, const float* d_
     if (!(bmax >= 0.0f)) return fail(RG_EINVAL, "bmax must be >= 0");
     sim->d.lr_coef32_t = d_coef32_t; sim->d.lr_intercept32 = d_intercept32; sim->d.lr_wmax = d_wmax; sim->d.lr_bmax = bmax;
     sim->d.lr_coef16_t = nullptr;      // the screening pass reads intercept32 / wmax / bmax: attach it again after this call
+    sim->d.lr_coef8_t = nullptr; sim->d.lr_scale8 = nullptr;
     return RG_OK;
 }
 
@@ -1459,6 +1460,16 @@ int rg_sim_set_logreg_fp16(rg_sim* sim, const uint16_t* d_coef16_t) {
     if (d_coef16_t && !sim->d.lr_coef32_t) return fail(RG_ESTATE, "rg_sim_set_logreg_fp32 must be called first (intercept32, wmax, bmax)");
     if (d_coef16_t && sim->d.lr_n % 8u) return fail(RG_EINVAL, "the fp16 screening pass needs n_classes %% 8 == 0 (have %u)", sim->d.lr_n);
     sim->d.lr_coef16_t = d_coef16_t;
+    sim->d.lr_coef8_t = nullptr; sim->d.lr_scale8 = nullptr;
+    return RG_OK;
+}
+
+int rg_sim_set_logreg_int8(rg_sim* sim, const uint8_t* d_coef8_t, const float* d_scale8) {
+    if (!sim) return fail(RG_EINVAL, "sim is NULL");
+    if (sim->d.policy != RG_POLICY_LOGREG_FROZEN) return fail(RG_ESTATE, "policy is not RG_POLICY_LOGREG_FROZEN");
+    if ((d_coef8_t != nullptr) != (d_scale8 != nullptr)) return fail(RG_EINVAL, "both arrays or none");
+    if (d_coef8_t && !sim->d.lr_coef16_t) return fail(RG_ESTATE, "rg_sim_set_logreg_fp16 must be called first (the 8-bit copy replaces the rows the screening pass reads)");
+    sim->d.lr_coef8_t = d_coef8_t; sim->d.lr_scale8 = d_scale8;
     return RG_OK;
 }
 

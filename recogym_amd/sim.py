@@ -165,6 +165,18 @@ class Simulator:
                             and float(self.logreg[0].abs().max().item()) < 6.0e4):
                         self.logreg16 = self.logreg[0].to(torch.float16).contiguous()
                         _abi.check(self.lib.rg_sim_set_logreg_fp16(self._h, self.logreg16.data_ptr()), 'rg_sim_set_logreg_fp16')
+                        # round 6: the screening pass from an 8-BIT copy (a quarter of the fp32 row bytes): q = rint(w / scale) + 128,
+                        # scale = wmax / 127 per product row — |w - scale q| <= scale / 2 (RECOGYM_LOGREG=fp16 keeps the half copy)
+                        if logreg.get('int8', True) and os.environ.get('RECOGYM_LOGREG', 'int8') == 'int8':
+                            scale = (wmax.to(torch.float64) / 127.0 * (1.0 + 1e-6)).clamp_min(1e-30)
+                            q = torch.round(self.logreg[0] / scale[:, None]).clamp_(-127, 127)
+                            assert bool(((self.logreg[0] - q * scale[:, None]).abs() <= 0.5 * scale[:, None] * (1.0 + 1e-9)).all())
+                            self.logreg8 = ((q + 128.0).to(torch.uint8).contiguous(), scale.to(torch.float32).contiguous())
+                            # (the float32 scale the kernel multiplies with must not be SMALLER than the one the weights were divided
+                            # by, or the half-step bound would be off by the rounding: compare against the float64 value)
+                            assert bool((self.logreg8[1].to(torch.float64) * (1.0 + 2e-7) >= scale).all())
+                            _abi.check(self.lib.rg_sim_set_logreg_int8(self._h, self.logreg8[0].data_ptr(), self.logreg8[1].data_ptr()),
+                                       'rg_sim_set_logreg_int8')
             if log_capacity is None:
                 log_capacity = default_log_capacity(config, self.n_users)
             self.log = None

@@ -626,10 +626,11 @@ def test_sampled_frozen_logreg_matches_the_oracle(P):
     assert len(np.unique(rows['a'][rows['z'] == 1])) > min(P, 20) // 2          # it does sample
 
 
-@pytest.mark.parametrize('screen', ['fp16', 'fp32', 'fp16_cap3'])
+@pytest.mark.parametrize('screen', ['int8', 'fp16', 'fp32', 'fp16_cap3'])
 def test_frozen_logreg_at_config_5_scale_matches_the_oracle(screen, monkeypatch):
     """BASELINE config 5's policy shape: one class per product, 4 096 products.  The act screens every class score from
-    the half copy of coef^T (RECOGYM_LOGREG=fp32: from the fp32 copy), keeps the classes within twice the rounding
+    the 8-bit copy of coef^T (round 6, the default: q = rint(w / scale) + 128, scale = wmax / 127 per product row; RECOGYM_LOGREG=fp16:
+    from the half copy, =fp32: from the fp32 copy), keeps the classes within twice the rounding
     bound of the best and lets float64 scores in scipy's order decide among them.  Small coefficients (N(0, 0.1)) make
     near-ties common; classes duplicated exactly (first maximum wins) and almost exactly (1e-9 apart: far inside the
     fp16 bound, decided by float64) must come out as the oracle's argmax."""
