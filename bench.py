@@ -266,14 +266,15 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
                                      peak=F64_VALU_PEAK_TFLOPS, unit='TFLOP/s', frac=round(tf / F64_VALU_PEAK_TFLOPS, 4),
                                      resolved_draws=int(c['exact_draws']))
     # frozen LogReg acts: the act of a user is recomputed when its view history changed; per act the coef^T rows of its
-    # viewed products over all classes at the precision the screening pass stores them in (fp16: 2 B per weight, the
-    # default; RECOGYM_LOGREG=fp32: 4 B) — what the kernel has to read (the float64 refine touches a few values per act)
+    # viewed products over all classes at the precision the screening pass stores them in (8-bit: 1 B per weight, the default since
+    # round 6; RECOGYM_LOGREG=fp16: 2 B, =fp32: 4 B) — what the kernel has to read (the float64 refine touches a few values per act)
     if prof.get('logreg_ms', 0.0) > 0 and c.get('lr_acts', 0) > 0:
         n_classes = P
-        wbytes = 4.0 if os.environ.get('RECOGYM_LOGREG', 'fp16') == 'fp32' or n_classes % 8 else 2.0
+        mode = os.environ.get('RECOGYM_LOGREG', 'int8')
+        wbytes = 4.0 if mode == 'fp32' or n_classes % 8 else (1.0 if mode == 'int8' else 2.0)
         by = wbytes * n_classes * c['lr_rows']
         gbps = by / (prof['logreg_ms'] * 1e-3) / 1e9
-        out['logreg_acts'] = dict(kernel='k_logreg_select + k_logreg_screen + k_logreg_decide' if wbytes == 2.0 else 'k_logreg_select + k_logreg_acts',
+        out['logreg_acts'] = dict(kernel='k_logreg_select + k_logreg_screen + k_logreg_decide' if wbytes <= 2.0 else 'k_logreg_select + k_logreg_acts',
                                   bound='hbm', ms=round(prof['logreg_ms'], 2),
                                   units=int(c['lr_acts']), unit_name='acts', bytes_per_unit=round(by / c['lr_acts'], 1),
                                   rows_per_act=round(c['lr_rows'] / c['lr_acts'], 2), float64_refined_acts=int(c.get('lr_exact', 0)),
