@@ -266,11 +266,11 @@ def kernel_rooflines(cfg, prof, c, users, cached, pol):
                                      peak=F64_VALU_PEAK_TFLOPS, unit='TFLOP/s', frac=round(tf / F64_VALU_PEAK_TFLOPS, 4),
                                      resolved_draws=int(c['exact_draws']))
     # frozen LogReg acts: the act of a user is recomputed when its view history changed; per act the coef^T rows of its
-    # viewed products over all classes at the precision the screening pass stores them in (8-bit: 1 B per weight, the default since
-    # round 6; RECOGYM_LOGREG=fp16: 2 B, =fp32: 4 B) — what the kernel has to read (the float64 refine touches a few values per act)
+    # viewed products over all classes at the precision the screening pass stores them in (fp16: 2 B per weight, the default;
+    # RECOGYM_LOGREG=int8: 1 B — round 6, measured slower —, =fp32: 4 B) — what the kernel has to read (the float64 refine touches a few values per act)
     if prof.get('logreg_ms', 0.0) > 0 and c.get('lr_acts', 0) > 0:
         n_classes = P
-        mode = os.environ.get('RECOGYM_LOGREG', 'int8')
+        mode = os.environ.get('RECOGYM_LOGREG', 'fp16')
         wbytes = 4.0 if mode == 'fp32' or n_classes % 8 else (1.0 if mode == 'int8' else 2.0)
         by = wbytes * n_classes * c['lr_rows']
         gbps = by / (prof['logreg_ms'] * 1e-3) / 1e9

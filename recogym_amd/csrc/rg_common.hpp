@@ -103,10 +103,18 @@ struct TpRec { double u; float S, pb, q, dlt; uint32_t ti, pad; };
 // 128-byte line at K <= 20 (64 bytes at K <= 8).  The draws of a step are counted and listed per (tile, shard): a device-scope
 // atomic on ONE address sustains ~6 M/s on this chip (measured: 264 M draws over 79 counters ran at the atomics' rate,
 // profiles/r6/ab_call3_tp.jsonl), so every tile has kTpShards counters, taken by work item modulo kTpShards.
-constexpr uint32_t kTpShards = 16, kTpBins = 128;
+constexpr uint32_t kTpShards = 16, kTpBins = 128, kTpLists = kTpBins * kTpShards;
+// ... and MORE shards where the tiles are few (a table of P <= 1024 has <= 8 of them: with 16 shards its draws hit <= 128
+// counters — BASELINE config 5 with the reference-fitted policies, P = 100, ran 4x slower on 16: profiles/r6/ab_call21_c5.jsonl):
+// as many as keep tiles x shards <= kTpLists, at most 128
+__host__ __device__ constexpr uint32_t tp_shards_of(uint32_t n_tiles) {
+    uint32_t s = kTpShards;
+    while (s < 128u && 2u * s * (n_tiles ? n_tiles : 1u) <= kTpLists) s *= 2u;
+    return s;
+}
 __host__ __device__ constexpr uint32_t tp_rec_stride(uint32_t KH) { return (32u + 8u * KH + 63u) & ~63u; }   // (KH = 32: 320)                     // bytes
 // draws of one (tile, shard) list at most: every work item (128 users of k_draw_tp, 256 of k_draw_tpw) may put all its draws into one
-inline uint32_t tp_shard_cap(uint64_t n) { return static_cast<uint32_t>((((n + 255) / 256 + kTpShards - 1) / kTpShards) * 256); }
+inline uint32_t tp_shard_cap(uint64_t n, uint32_t shards) { return static_cast<uint32_t>((((n + 255) / 256 + shards - 1) / shards) * 256); }
 
 // Everything a kernel needs, passed by value.
 struct DevSim {
@@ -154,7 +162,7 @@ struct DevSim {
     uint32_t* tp_hist;        // [kTpBins x kTpShards + 4] draws of the step per (128-product tile, shard) (k_draw_tp counts, k_pick's last
                               // block clears), then the blocks of k_pick that are done
     uint32_t* tp_order;       // [n_chunks / 4][kTpShards][tp_cap] list positions of the step's draws, by tile and shard
-    uint32_t tp_cap;
+    uint32_t tp_cap, tp_shards;   // capacity of one (tile, shard) list; shards per tile (tp_shards_of)
     uint32_t tp_cpt;          // 32-product chunks per list tile: 4 (k_draw_tp's 128-product tiles); the wide sweep's super-tiles: 2 x its tiles per stored prefix
     float* stats;             // [2*KH] max_p |Gamma[p][k]|, then max_p ||Gamma[p]||_2, max_p |mu_o[p]|
     // geometry of the MFMA draw kernel
@@ -660,9 +668,12 @@ inline size_t carve_all(const rg_config& c, uint64_t n, void* base, DevSim* d) {
     const bool tp = ((g.F16 == 1 && g.KH <= 10 && g.n_chunks / 4 <= kTpBins) || g.F16 == 2) && !cache;
     char* tp_rec = w.take<char>(tp ? static_cast<size_t>(n) * tp_rec_stride(g.KH) : 1);
     uint32_t* tp_hist = w.take<uint32_t>(kTpBins * kTpShards + 4);
-    uint32_t* tp_order = w.take<uint32_t>(tp ? static_cast<size_t>(g.F16 == 2 ? kTpBins : g.n_chunks / 4) * kTpShards * tp_shard_cap(n) : 1);
+    // (lists: tiles x shards; the wide sweep's super-tiles are fixed at create: sized for the 16-shard case, which is the largest product)
+    const uint32_t tp_tiles = g.F16 == 2 ? kTpBins : g.n_chunks / 4;
+    const uint32_t tp_sh = g.F16 == 2 ? kTpShards : tp_shards_of(tp_tiles);
+    uint32_t* tp_order = w.take<uint32_t>(tp ? static_cast<size_t>(tp_tiles) * tp_sh * tp_shard_cap(n, tp_sh) : 1);
     if (d) {
-        d->tp_rec = tp ? tp_rec : nullptr; d->tp_hist = tp_hist; d->tp_order = tp_order; d->tp_cap = tp_shard_cap(n); d->tp_cpt = 4;
+        d->tp_rec = tp ? tp_rec : nullptr; d->tp_hist = tp_hist; d->tp_order = tp_order; d->tp_cap = tp_shard_cap(n, tp_sh); d->tp_shards = tp_sh; d->tp_cpt = 4;
         d->ev = ev; d->run_ctl = run_ctl; d->run_ahead = 0; d->pv0 = pv0;
         d->phantom_ps = phantom_ps; d->utime = utime; d->phantom_time = phantom_time;
         d->drift_list = drift_list; d->drift_sig = drift_sig; d->drift_cnt = drift_cnt;

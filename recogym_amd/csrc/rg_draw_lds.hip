@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
             r.ti = found_t ? cnt : 0xFFFFFFFFu; r.pad = 0u;
             *reinterpret_cast<TpRec*>(recp) = r;
             if (found_t) {         // the step's draws BY TILE (and shard: the work item's): k_pick takes 32 of one list at a time
-                const uint32_t bs = cnt * kTpShards + (tb % kTpShards);
+                const uint32_t bs = cnt * d.tp_shards + (tb % d.tp_shards);
                 const uint32_t k = atomicAdd(&d.tp_hist[bs], 1u);
                 d.tp_order[static_cast<size_t>(bs) * d.tp_cap + k] = pos;
             } else {               // no tile (sums that overflowed, u S beyond the last prefix): float64
@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_draw_tp(DevSim d, uint32_t t, uin
 // (rows 8 g + 4 h + r of a chunk in register 4 g + r of lane (user, h)).  The certificate is search_and_emit's
 // (cert_correlated) with A = the tile's start.  ~1 400 vector instructions per 32 draws, no scratch.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kPickLists = kTpBins * kTpShards;      // (tile, shard) lists of a step's draws
+constexpr uint32_t kPickLists = kTpLists;      // (tile, shard) lists of a step's draws (tile * d.tp_shards + shard)
 
 #ifndef RG_PICK_OCC
 #define RG_PICK_OCC 3
@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(kBlock, RG_PICK_OCC) k_pick(DevSim d, uint32_t
         uint32_t lo = 0, hi = kPickLists;
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (gstart[mid] <= g) lo = mid; else hi = mid; }
         const uint32_t lst = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lo)));
-        const uint32_t tile = lst / kTpShards;
+        const uint32_t tile = lst / d.tp_shards;
         const uint32_t gi = g - gstart[lst];
         const uint32_t cnt = min(32u, hist[lst] - 32u * gi);
         const bool active = static_cast<uint32_t>(j) < cnt;
@@ -867,7 +867,7 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
                 r.ti = found_t ? cnt : 0xFFFFFFFFu; r.pad = 0u;
                 *reinterpret_cast<TpRec*>(d.tp_rec + static_cast<size_t>(pos[g]) * tp_rec_stride(KH)) = r;
                 if (found_t) {
-                    const uint32_t bs = cnt * kTpShards + (tb % kTpShards);
+                    const uint32_t bs = cnt * d.tp_shards + (tb % d.tp_shards);
                     const uint32_t k = atomicAdd(&d.tp_hist[bs], 1u);
                     d.tp_order[static_cast<size_t>(bs) * d.tp_cap + k] = pos[g];
                 } else {

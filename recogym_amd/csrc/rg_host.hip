@@ -604,7 +604,7 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
             // k_pick: a wave per 32 draws of one tile (the sweep listed the draws by tile), grid-stride over the groups
             const size_t psmem = (2 * kTpBins * kTpShards + 8) * sizeof(uint32_t) + 4 * 32 * 2 * static_cast<size_t>(d.KH) * sizeof(float);
             if (psmem > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sim->pick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(psmem));
-            uint32_t pgrid = upper / 128u + (d.n_chunks / 4) * kTpShards / 4u + 1u;      // groups / 4 waves (a part-filled group per (tile, shard))
+            uint32_t pgrid = upper / 128u + kTpLists / 4u + 1u;      // groups / 4 waves (a part-filled group per (tile, shard))
             const uint32_t pcap = static_cast<uint32_t>(device_cus(sim)) * 4u;
             if (pgrid > pcap) pgrid = pcap;
             hipLaunchKernelGGL(sim->pick_kernel, dim3(pgrid), dim3(kBlock), psmem, st, d, t, 0u);
@@ -1134,7 +1134,9 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
         if (kt && kp && d.tp_rec) {
             const uint32_t nts = ((d.n_chunks / 4) + 3u) & ~3u;
             const size_t smem = 2 * (128 * static_cast<size_t>(d.RS) + 512) + 256 + 4 * 32 * static_cast<size_t>(nts) * sizeof(float);
-            if (smem <= 160 * 1024 && d.n_chunks / 4 <= 128u) {          // (k_pick sorts a segment's draws into <= 128 tile bins)
+            // (<= 128 tile lists; and >= 4 tiles: below that — P <= 384 — the sweep is a few hundred MFMAs per draw and the per-draw
+            // list atomic on <= 3 x 128 counters would pace it: those tables keep k_draw_bf16p)
+            if (smem <= 160 * 1024 && d.n_chunks / 4 <= 128u && d.n_chunks / 4 >= 4u) {
                 s->tp_kernel = kt; s->pick_kernel = kp; s->tp_smem = smem; s->tp_nts = nts;
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem));
             }

@@ -165,9 +165,11 @@ class Simulator:
                             and float(self.logreg[0].abs().max().item()) < 6.0e4):
                         self.logreg16 = self.logreg[0].to(torch.float16).contiguous()
                         _abi.check(self.lib.rg_sim_set_logreg_fp16(self._h, self.logreg16.data_ptr()), 'rg_sim_set_logreg_fp16')
-                        # round 6: the screening pass from an 8-BIT copy (a quarter of the fp32 row bytes): q = rint(w / scale) + 128,
-                        # scale = wmax / 127 per product row — |w - scale q| <= scale / 2 (RECOGYM_LOGREG=fp16 keeps the half copy)
-                        if logreg.get('int8', True) and os.environ.get('RECOGYM_LOGREG', 'int8') == 'int8':
+                        # round 6, opt-in (RECOGYM_LOGREG=int8 or logreg['int8']): the screening pass from an 8-BIT copy (a quarter of the
+                        # fp32 row bytes): q = rint(w / scale) + 128, scale = wmax / 127 per product row — |w - scale q| <= scale / 2.
+                        # Measured on C5 and NOT the default: its band is 8x the fp16 copy's, 21 % of the acts (3 %) go to the float64
+                        # refine, acts 232 -> 342 ms (profiles/r6/ab_call21_c5.jsonl)
+                        if logreg.get('int8', False) or os.environ.get('RECOGYM_LOGREG', 'fp16') == 'int8':
                             scale = (wmax.to(torch.float64) / 127.0 * (1.0 + 1e-6)).clamp_min(1e-30)
                             q = torch.round(self.logreg[0] / scale[:, None]).clamp_(-127, 127)
                             assert bool(((self.logreg[0] - q * scale[:, None]).abs() <= 0.5 * scale[:, None] * (1.0 + 1e-9)).all())

@@ -629,8 +629,8 @@ def test_sampled_frozen_logreg_matches_the_oracle(P):
 @pytest.mark.parametrize('screen', ['int8', 'fp16', 'fp32', 'fp16_cap3'])
 def test_frozen_logreg_at_config_5_scale_matches_the_oracle(screen, monkeypatch):
     """BASELINE config 5's policy shape: one class per product, 4 096 products.  The act screens every class score from
-    the 8-bit copy of coef^T (round 6, the default: q = rint(w / scale) + 128, scale = wmax / 127 per product row; RECOGYM_LOGREG=fp16:
-    from the half copy, =fp32: from the fp32 copy), keeps the classes within twice the rounding
+    the half copy of coef^T (RECOGYM_LOGREG=int8: from the 8-bit copy of round 6, q = rint(w / scale) + 128 with scale = wmax / 127 per
+    product row — opt-in, measured slower; =fp32: from the fp32 copy), keeps the classes within twice the rounding
     bound of the best and lets float64 scores in scipy's order decide among them.  Small coefficients (N(0, 0.1)) make
     near-ties common; classes duplicated exactly (first maximum wins) and almost exactly (1e-9 apart: far inside the
     fp16 bound, decided by float64) must come out as the oracle's argmax."""
@@ -664,20 +664,26 @@ def test_frozen_logreg_at_config_5_scale_matches_the_oracle(screen, monkeypatch)
 
 
 LDS_EXTRA_CASES = [
-    # the (KH, N1) classes of k_draw_tp the oracle cases above do not reach: (10, 2) K = 10, (10, 3) K = 13, (4, 2) at P around a tile
-    (dict(num_products=300, K=10, random_seed=61, sigma_omega=0.2), 1200, 0, {}),
-    (dict(num_products=129, K=13, random_seed=62), 900, 5, dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=7)),
-    (dict(num_products=128, K=8, random_seed=63, sigma_omega=0.5), 900, 0, {}),
+    # the (KH, N1) classes of k_draw_tp at tables of >= 4 product tiles (what it serves): (4, 1) K = 3 / 5, (4, 2) K = 6 / 8,
+    # (10, 2) K = 10, (10, 3) K = 13, (10, 4) K = 17 / 20; P on and off tile boundaries
+    (dict(num_products=600, K=5, random_seed=60), 1500, 20, {}),
+    (dict(num_products=700, K=10, random_seed=61, sigma_omega=0.2), 1200, 0, {}),
+    (dict(num_products=641, K=13, random_seed=62), 900, 5, dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=7)),
+    (dict(num_products=512, K=8, random_seed=63, sigma_omega=0.5), 900, 0, {}),
     (dict(num_products=2000, K=20, random_seed=64, sigma_omega=0.3, sigma_mu_organic=12.0), 500, 0,
      dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=27, ouc=dict(gu.OUC_DEFAULTS))),
     # k_draw_tpw, the wide classes (N1 = 7, 10: K = 30, 45; 13 is oracle case 14 / 3): several super-tiles, P off a tile boundary
     (dict(num_products=5000, K=30, random_seed=65, sigma_omega=0.2), 600, 0, {}),
     (dict(num_products=9001, K=45, random_seed=66), 500, 3, dict(policy=_abi.RG_POLICY_RANDOM_AGENT, policy_seed=8)),
+    (dict(num_products=900, K=3, random_seed=67, sigma_omega=0.3), 1200, 0, {}),
+    (dict(num_products=530, K=6, random_seed=68), 1000, 0,
+     dict(policy=_abi.RG_POLICY_ORGANIC_USER_COUNT, policy_seed=22, ouc=dict(gu.OUC_DEFAULTS, epsilon=0.25))),
+    (dict(num_products=1500, K=8, random_seed=69, prob_leave_organic=0.05, prob_organic_to_bandit=0.5, prob_bandit_to_organic=0.2), 1500, 0, {}),
 ]
 
 
 @pytest.mark.parametrize('run_ahead', ['32', '0'])
-@pytest.mark.parametrize('case', [0, 2, 3, 4, 6, 7, 8, 9, 10, 14, 'x0', 'x1', 'x2', 'x3', 'x4', 'x5'])
+@pytest.mark.parametrize('case', [3, 4, 6, 7, 14, 'x0', 'x1', 'x2', 'x3', 'x4', 'x5', 'x6', 'x7', 'x8', 'x9'])
 def test_lds_search_sweep_matches_the_oracle(case, run_ahead, monkeypatch):
     """k_draw_tp / k_draw_tpw + k_pick (rg_draw_lds.hip: a user's tile prefixes in LDS, the draw's tile a count on them, the product
     inside the tile on the matrix cores, 32 draws of one tile per wave) are the sweep of every UNSLICED step of a run whose draws
