@@ -1517,9 +1517,10 @@ int rg_sim_reset_users(rg_sim* sim, uint64_t first_user_id, uint64_t n, uint64_t
     d.grp_lo = 0; d.grp_n = d.n_users;
     d.run_ahead = 0;                           // rg_sim_run turns the rounds on for a run to the end
     // live lanes at which a draining wave hands its users to the next round: what it hands over also goes through the float64
-    // batch, and a small shard's rounds drain sooner — 16 below 2 M users (a 1.25 M-user shard of C3: 21.3 -> 20.0 ms), else 32
-    // (profiles/r6/ab_call19_handover.jsonl)
-    if (sim->handover_auto) d.walk_handover = n < 2000000ull ? 16u : 32u;
+    // batch — a sweep of P x K per user — while a later hand-over lengthens the round's drain.  16 below 2 M users where a
+    // float64 sweep is expensive (P x K >= 10^5: a 1.25 M-user shard of C3 21.3 -> 20.0 ms, profiles/r6/ab_call19_handover.jsonl),
+    // else 32 (C2, P x K = 2 10^4, 1 M users: 8.1 ms at 32, 8.9 at 16: profiles/r6/c3_bench_line_call22.json against _call9)
+    if (sim->handover_auto) d.walk_handover = (n < 2000000ull && static_cast<uint64_t>(d.P) * d.K >= 100000ull) ? 16u : 32u;
     HIP_TRY(hipMemsetAsync(d.step_cnt, 0, sizeof(uint32_t) * 2 * (kMaxSteps + 2), st));
     HIP_TRY(hipMemsetAsync(d.exact_cnt, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
     HIP_TRY(hipMemsetAsync(d.exact_cnt_b, 0, sizeof(uint32_t) * (kMaxSteps + 2), st));
