@@ -209,20 +209,57 @@ __global__ void __launch_bounds__(kBlock) k_logreg_acts(DevSim d, uint32_t t) {
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_logreg_screen(DevSim d, uint32_t t) {
-    __shared__ uint32_t s_cand[kBlock / 64][32];
-    __shared__ float s_cval[kBlock / 64][32];
+// (blocks per CU = waves per SIMD of k_logreg_screen: acts of C5 169 ms at 4, 176 at 5, 233 at 6 where it spills: ab_call29_c5.jsonl)
+#ifndef RG_LR_OCC
+#define RG_LR_OCC 4
+#endif
+// acc + a * (fp16 half of w): v_fma_mix_f32 takes the fp16 operand as it lies in the row (one instruction and no converted copy;
+// left to itself the compiler converts all 64 halves of a batch first — 64 more live registers — for packed fp32 fmas)
+__device__ __forceinline__ float fma_mix_lo(float a, uint32_t w, float acc) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ float fma_mix_hi(float a, uint32_t w, float acc) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(acc));
+    return r;
+}
+template <bool Q8>
+__global__ void __launch_bounds__(kBlock, RG_LR_OCC) k_logreg_screen(DevSim d, uint32_t t) {
+    constexpr uint32_t kCandCap = 64;          // candidates of a range while it streams (a lane each in the second level)
+    __shared__ uint32_t s_cand[kBlock / 64][kCandCap];
+    __shared__ float s_cval[kBlock / 64][kCandCap];
     typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const uint32_t n = min(d.lr_cnt[t], d.lr_part_cap);         // (the rest: k_logreg_acts)
     const uint32_t C = d.lr_n;
     const uint32_t RC = ((C + kLrSplit - 1) / kLrSplit + 7u) & ~7u;       // classes per range (a multiple of 8)
     const uint32_t waves_total = gridDim.x * (kBlock / 64);
     for (uint32_t item = blockIdx.x * (kBlock / 64) + wave; item < n * kLrSplit; item += waves_total) {
         const uint32_t w = item / kLrSplit, r = item % kLrSplit;
-        const uint32_t slot = d.lr_list[w];
+        // (everything about the act is wave-uniform: kept in scalar registers, the history's loads scalar or broadcast)
+        const uint32_t slot = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(d.lr_list[w])));
         const hent_t* hr = hist_row(d, slot) + 1;
-        const uint32_t nd = h_cnt(hr[-1]);
+        // the header and the first eight entries leave TOGETHER (one 128-byte line; entries beyond the count are whatever the row
+        // held before: replaced below, never used as an address) — the screen is a chain of dependent round trips, list -> history
+        // -> rows -> rows ..., and each one fewer is worth ~8 % of it
+        hent_t h8[8];
+        const hent_t hdr = hr[-1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h8[e] = hr[e];
+        const uint32_t nd = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(h_cnt(hdr))));   // (scalar loop control)
+        {
+            hent_t prev = 0;       // (product 0, count 0)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(h8[e]))));
+                uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(h8[e] >> 32))));
+                const hent_t x = (static_cast<hent_t>(hi) << 32) | lo;
+                h8[e] = static_cast<uint32_t>(e) < nd ? x : prev;
+                prev = h8[e];
+            }
+        }
         // ---- the error bound of this history ----
         float A = 0.0f, V = 0.0f;
         for (uint32_t i = lane; i < nd; i += 64) {
@@ -233,69 +270,19 @@ __global__ void __launch_bounds__(kBlock) k_logreg_screen(DevSim d, uint32_t t) 
         }
         for (int o = 32; o > 0; o >>= 1) { A += __shfl_xor(A, o); V += __shfl_xor(V, o); }
         // (the rows' own error: 2^-11 of wmax per weight from the fp16 copy, wmax / 254 from the 8-bit one)
-        const bool q8 = d.lr_coef8_t != nullptr;
+        constexpr bool q8 = Q8;
         // (8-bit: the sums are taken on q + 128 and the offset removed at the end: partial sums up to ~3 A instead of A)
-        const float B = (A * (q8 ? 3.9764e-3f : 4.8828125e-4f) + V * 2.98023224e-8f +
-                         static_cast<float>(nd + 3) * 5.9604644775390625e-08f * (d.lr_bmax + (q8 ? 3.1f : 1.0f) * A)) * 1.02f;
-        const float thr = 2.0f * B * 1.01f + 1e-30f;
+        const float B16 = (A * 4.8828125e-4f + V * 2.98023224e-8f +
+                           static_cast<float>(nd + 3) * 5.9604644775390625e-08f * (d.lr_bmax + A)) * 1.02f;
+        const float B = !q8 ? B16 : (A * 3.9764e-3f + V * 2.98023224e-8f +
+                                     static_cast<float>(nd + 3) * 5.9604644775390625e-08f * (d.lr_bmax + 3.1f * A)) * 1.02f;
+        float thr = 2.0f * B * 1.01f + 1e-30f;
         const uint32_t c_lo = r * RC, c_hi = min(c_lo + RC, C);
         float rb = -INFINITY;
         uint32_t n_cand = 0;
         bool overflow = false;
-        for (uint32_t c0 = c_lo; c0 < c_hi && !overflow; c0 += 512) {
-            const uint32_t c = c0 + 8u * static_cast<uint32_t>(lane);
-            const bool in = c < c_hi;                                // (a lane's 8 classes are all in or all out)
-            const uint32_t cl = in ? c : c_lo;
-            float acc[8];
-            {
-                const float4 b0 = *reinterpret_cast<const float4*>(d.lr_intercept32 + cl);
-                const float4 b1 = *reinterpret_cast<const float4*>(d.lr_intercept32 + cl + 4);
-                acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
-            }
-            if (q8) {
-                // 8-bit rows: 8 bytes per lane and row (q + 128: v_cvt_f32_ubyte*), count x scale folded into one factor, the
-                // offset 128 sum(count x scale) taken off once at the end
-                float corr = 0.0f;
-                for (uint32_t i0 = 0; i0 < nd; i0 += 8) {            // eight rows in flight
-                    uint2 bv[8];
-                    float cs[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const hent_t x = hr[min(i0 + e, nd - 1)];
-                        const uint32_t pp = h_prod(x);
-                        cs[e] = i0 + e < nd ? static_cast<float>(h_cnt(x)) * d.lr_scale8[pp] : 0.0f;
-                        bv[e] = *reinterpret_cast<const uint2*>(d.lr_coef8_t + static_cast<size_t>(pp) * C + cl);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (i0 + e < nd) {
-                            corr = fmaf(cs[e], 128.0f, corr);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                acc[j] = fmaf(cs[e], static_cast<float>((bv[e].x >> (8 * j)) & 0xFFu), acc[j]);
-                                acc[4 + j] = fmaf(cs[e], static_cast<float>((bv[e].y >> (8 * j)) & 0xFFu), acc[4 + j]);
-                            }
-                        }
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] -= corr;
-            } else
-            for (uint32_t i0 = 0; i0 < nd; i0 += 8) {                // eight rows in flight
-                half8 hv[8];
-                float cn[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const hent_t x = hr[min(i0 + e, nd - 1)];
-                    cn[e] = i0 + e < nd ? static_cast<float>(h_cnt(x)) : 0.0f;
-                    hv[e] = *reinterpret_cast<const half8*>(d.lr_coef16_t + static_cast<size_t>(h_prod(x)) * C + cl);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (i0 + e < nd) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[j] = fmaf(cn[e], static_cast<float>(hv[e][j]), acc[j]);
-                    }
-            }
+        // candidates of one batch of 512 classes (lane = 8 consecutive classes) against the running maximum
+        auto collect = [&](uint32_t c, bool in, const float (&acc)[8]) {
             float m = -INFINITY;
 #pragma unroll
             for (int j = 0; j < 8; ++j) m = fmaxf(m, acc[j]);
@@ -309,16 +296,166 @@ __global__ void __launch_bounds__(kBlock) k_logreg_screen(DevSim d, uint32_t t) 
                 const unsigned long long pm = __ballot(pass);
                 if (pm && !overflow) {
                     const uint32_t np = static_cast<uint32_t>(__popcll(pm));
-                    if (n_cand + np > 32u) overflow = true;
+                    if (n_cand + np > kCandCap) overflow = true;
                     else {
                         if (pass) { const uint32_t k = n_cand + prefix_in_mask(pm); s_cand[wave][k] = c + j; s_cval[wave][k] = acc[j]; }
                         n_cand += np;
                     }
                 }
             }
+        };
+        if (!q8) {
+            // fp16 rows.  The first eight history rows of a batch and its intercepts are one round trip; rows beyond the eighth (long
+            // histories) four at a time.  (The next batch's rows in flight while this one is summed — 40 more registers — LOST to
+            // the waves per SIMD it costs: acts 198 ms at 3 waves with the prefetch, 173 at 4 without: ab_call28_c5.jsonl)
+            struct Batch { uint4 hv[8]; float4 b0, b1; };
+            const uint32_t p8[8] = {h_prod(h8[0]), h_prod(h8[1]), h_prod(h8[2]), h_prod(h8[3]), h_prod(h8[4]), h_prod(h8[5]), h_prod(h8[6]), h_prod(h8[7])};
+            float cn8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cn8[e] = static_cast<uint32_t>(e) < nd ? static_cast<float>(h_cnt(h8[e])) : 0.0f;
+            auto fetch = [&](uint32_t c0, Batch& bt) {
+                const uint32_t c = c0 + 8u * static_cast<uint32_t>(lane);
+                const uint32_t cl = c < c_hi ? c : c_lo;
+                bt.b0 = *reinterpret_cast<const float4*>(d.lr_intercept32 + cl);
+                bt.b1 = *reinterpret_cast<const float4*>(d.lr_intercept32 + cl + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bt.hv[e] = *reinterpret_cast<const uint4*>(d.lr_coef16_t + static_cast<size_t>(p8[e]) * C + cl);
+            };
+            Batch cur;
+            fetch(c_lo, cur);
+            for (uint32_t c0 = c_lo; c0 < c_hi && !overflow; c0 += 512) {
+                const bool more = c0 + 512 < c_hi;
+                const uint32_t c = c0 + 8u * static_cast<uint32_t>(lane);
+                const bool in = c < c_hi;
+                const uint32_t cl = in ? c : c_lo;
+                float acc[8] = {cur.b0.x, cur.b0.y, cur.b0.z, cur.b0.w, cur.b1.x, cur.b1.y, cur.b1.z, cur.b1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {                        // (rows beyond the history: count 0, no branch)
+                    const uint32_t wq[4] = {cur.hv[e].x, cur.hv[e].y, cur.hv[e].z, cur.hv[e].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[2 * j] = fma_mix_lo(cn8[e], wq[j], acc[2 * j]);
+                        acc[2 * j + 1] = fma_mix_hi(cn8[e], wq[j], acc[2 * j + 1]);
+                    }
+                }
+                for (uint32_t i0 = 8; i0 < nd; i0 += 4) {            // long histories: four more rows in flight
+                    uint4 hv[4];
+                    float cn[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const hent_t x = hr[min(i0 + e, nd - 1)];
+                        cn[e] = i0 + e < nd ? static_cast<float>(h_cnt(x)) : 0.0f;
+                        hv[e] = *reinterpret_cast<const uint4*>(d.lr_coef16_t + static_cast<size_t>(h_prod(x)) * C + cl);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t wq[4] = {hv[e].x, hv[e].y, hv[e].z, hv[e].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc[2 * j] = fma_mix_lo(cn[e], wq[j], acc[2 * j]);
+                            acc[2 * j + 1] = fma_mix_hi(cn[e], wq[j], acc[2 * j + 1]);
+                        }
+                    }
+                }
+                collect(c, in, acc);
+                if (more) fetch(c0 + 512, cur);
+            }
+        } else {
+            // 8-bit rows (q + 128, 8 bytes per lane and row: v_cvt_f32_ubyte*), count x scale folded into one factor per row, the
+            // offset 128 sum(count x scale) taken off once at the end; the same chain of round trips as above
+            uint32_t p8[8];
+            float cs8[8];
+            float corr8 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                p8[e] = h_prod(h8[e]);
+                cs8[e] = static_cast<uint32_t>(e) < nd ? static_cast<float>(h_cnt(h8[e])) * d.lr_scale8[p8[e]] : 0.0f;   // (p8 is a product always)
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) corr8 = fmaf(cs8[e], 128.0f, corr8);
+            struct Batch8 { uint2 bv[8]; float4 b0, b1; };
+            auto fetch = [&](uint32_t c0, Batch8& bt) {
+                const uint32_t c = c0 + 8u * static_cast<uint32_t>(lane);
+                const uint32_t cl = c < c_hi ? c : c_lo;
+                bt.b0 = *reinterpret_cast<const float4*>(d.lr_intercept32 + cl);
+                bt.b1 = *reinterpret_cast<const float4*>(d.lr_intercept32 + cl + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bt.bv[e] = *reinterpret_cast<const uint2*>(d.lr_coef8_t + static_cast<size_t>(p8[e]) * C + cl);
+            };
+            Batch8 cur;
+            fetch(c_lo, cur);
+            for (uint32_t c0 = c_lo; c0 < c_hi && !overflow; c0 += 512) {
+                const bool more = c0 + 512 < c_hi;
+                const uint32_t c = c0 + 8u * static_cast<uint32_t>(lane);
+                const bool in = c < c_hi;
+                const uint32_t cl = in ? c : c_lo;
+                float acc[8] = {cur.b0.x, cur.b0.y, cur.b0.z, cur.b0.w, cur.b1.x, cur.b1.y, cur.b1.z, cur.b1.w};
+                float corr = corr8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[j] = fmaf(cs8[e], static_cast<float>((cur.bv[e].x >> (8 * j)) & 0xFFu), acc[j]);
+                        acc[4 + j] = fmaf(cs8[e], static_cast<float>((cur.bv[e].y >> (8 * j)) & 0xFFu), acc[4 + j]);
+                    }
+                }
+                for (uint32_t i0 = 8; i0 < nd; i0 += 4) {            // long histories: four more rows in flight
+                    uint2 bv[4];
+                    float cs[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const hent_t x = hr[min(i0 + e, nd - 1)];
+                        const uint32_t pp = h_prod(x);
+                        cs[e] = static_cast<float>(h_cnt(x)) * d.lr_scale8[pp] * (i0 + e < nd ? 1.0f : 0.0f);     // (the load unconditional)
+                        bv[e] = *reinterpret_cast<const uint2*>(d.lr_coef8_t + static_cast<size_t>(pp) * C + cl);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        corr = fmaf(cs[e], 128.0f, corr);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc[j] = fmaf(cs[e], static_cast<float>((bv[e].x >> (8 * j)) & 0xFFu), acc[j]);
+                            acc[4 + j] = fmaf(cs[e], static_cast<float>((bv[e].y >> (8 * j)) & 0xFFu), acc[4 + j]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] -= corr;
+                collect(c, in, acc);
+                if (more) fetch(c0 + 512, cur);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
+        if (q8 && !overflow) {
+            // ---- second level of the 8-bit screen: the range's true maximum is among the candidates above (within 2 B8 of the
+            // range's 8-bit maximum); their scores once more from the fp16 rows — a lane per candidate, the fp16 pass's own
+            // arithmetic (intercept32, then fma in history order), so that pass's bound B16 holds for them: from here on the
+            // range's maximum is the candidates' fp16 maximum and the band 2 B16, and k_logreg_decide works as it does on the
+            // fp16 screen (the true argmax is a candidate, its fp16 score within 2 B16 of any other candidate's) ----
+            const bool mine2 = static_cast<uint32_t>(lane) < n_cand;
+            const uint32_t cc = mine2 ? s_cand[wave][lane] : c_lo;
+            float acc = d.lr_intercept32[cc];
+            for (uint32_t i0 = 0; i0 < nd; i0 += 8) {                // eight values in flight
+                unsigned short wv[8];
+                float cn[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const hent_t x = hr[min(i0 + e, nd - 1)];
+                    cn[e] = i0 + e < nd ? static_cast<float>(h_cnt(x)) : 0.0f;
+                    wv[e] = d.lr_coef16_t[static_cast<size_t>(h_prod(x)) * C + cc];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = fmaf(cn[e], static_cast<float>(__builtin_bit_cast(_Float16, wv[e])), acc);
+            }
+            float m2 = mine2 ? acc : -INFINITY;
+            if (mine2) s_cval[wave][lane] = acc;
+            for (int o = 32; o > 0; o >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, o));
+            rb = m2;
+            thr = 2.0f * B16 * 1.01f + 1e-30f;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
         // ---- what survives the range's final maximum ----
         uint32_t* part = d.lr_part + (static_cast<size_t>(w) * kLrSplit + r) * kLrPartWords;
         const bool mine = !overflow && static_cast<uint32_t>(lane) < n_cand;
@@ -374,9 +511,17 @@ __global__ void __launch_bounds__(kBlock) k_logreg_decide(DevSim d, uint32_t t) 
                 double sc = -INFINITY;
                 if (keep) {
                     sc = 0.0;
-                    for (uint32_t i = 0; i < nd; ++i) {
-                        const hent_t x = hr[i];
-                        sc = __dadd_rn(sc, __dmul_rn(static_cast<double>(h_cnt(x)), d.lr_coef_t[static_cast<size_t>(h_prod(x)) * C + cc]));
+                    for (uint32_t i0 = 0; i0 < nd; i0 += 8) {        // eight coefficients in flight, summed in history order
+                        double wv[8], cn[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const hent_t x = hr[min(i0 + e, nd - 1)];
+                            cn[e] = static_cast<double>(h_cnt(x));
+                            wv[e] = d.lr_coef_t[static_cast<size_t>(h_prod(x)) * C + cc];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (i0 + e < nd) sc = __dadd_rn(sc, __dmul_rn(cn[e], wv[e]));
                     }
                     sc = __dadd_rn(sc, d.lr_intercept[cc]);
                     best_c = cc;
@@ -1113,7 +1258,7 @@ __global__ void __launch_bounds__(kBlock) k_tail(DevSim d, uint32_t t0) {
 }
 search_kernel_t logreg_select_kernel() { return k_logreg_select; }
 search_kernel_t logreg_acts_kernel() { return k_logreg_acts; }
-search_kernel_t logreg_screen_kernel() { return k_logreg_screen; }
+search_kernel_t logreg_screen_kernel(bool q8) { return q8 ? k_logreg_screen<true> : k_logreg_screen<false>; }
 search_kernel_t logreg_decide_kernel() { return k_logreg_decide; }
 search_kernel_t logreg_sample_kernel() { return k_logreg_sample; }
 advance_kernel_t advance_kernel() { return k_advance; }

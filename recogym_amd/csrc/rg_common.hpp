@@ -413,7 +413,7 @@ void (*xh_stats_kernel())(DevSim);
 search_kernel_t drift_kernel();                            // part 6
 search_kernel_t logreg_select_kernel();
 search_kernel_t logreg_acts_kernel();
-search_kernel_t logreg_screen_kernel();
+search_kernel_t logreg_screen_kernel(bool q8);
 search_kernel_t logreg_decide_kernel();
 search_kernel_t logreg_sample_kernel();
 advance_kernel_t advance_kernel();

@@ -3,6 +3,9 @@
 
 #include "rg_common.hpp"
 
+#ifndef RG_TP_SMEM_PAD
+#define RG_TP_SMEM_PAD 0
+#endif
 namespace rgk {
 
 // ------------------------------------------------------------------------------------------
@@ -636,7 +639,7 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         if (d.lr_sample)           // select_randomly: a softmax and a draw per act (a wave each)
             hipLaunchKernelGGL(logreg_sample_kernel(), dim3(grid_for(static_cast<uint64_t>(upper) + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
         else if (d.lr_coef16_t) {       // screen (a wave per act and class range), then decide (a wave per act)
-            hipLaunchKernelGGL(logreg_screen_kernel(), dim3(grid_for((static_cast<uint64_t>(upper) / 4 + 64) * kLrSplit, kBlock / 64)),
+            hipLaunchKernelGGL(logreg_screen_kernel(d.lr_coef8_t != nullptr), dim3(grid_for((static_cast<uint64_t>(upper) / 4 + 64) * kLrSplit, kBlock / 64)),
                                dim3(kBlock), 0, st, d, t);
             hipLaunchKernelGGL(logreg_decide_kernel(), dim3(grid_for(static_cast<uint64_t>(upper) / 4 + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
             if (upper > d.lr_part_cap)     // the step may list more acts than the screen's scratch has rows: the rest in fp32 / float64
@@ -1133,7 +1136,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
         draw_kernel_t kt = tp_kernel_for(d), kp = pick_kernel_for(d);
         if (kt && kp && d.tp_rec) {
             const uint32_t nts = ((d.n_chunks / 4) + 3u) & ~3u;
-            const size_t smem = 2 * (128 * static_cast<size_t>(d.RS) + 512) + 256 + 4 * 32 * static_cast<size_t>(nts) * sizeof(float);
+            // (-DRG_TP_SMEM_PAD=bytes: a timing build that pushes the kernel to ONE block per CU — what the second block is worth)
+            const size_t smem = 2 * (128 * static_cast<size_t>(d.RS) + 512) + 256 + 4 * 32 * static_cast<size_t>(nts) * sizeof(float) + RG_TP_SMEM_PAD;
             // (<= 128 tile lists; and >= 4 tiles: below that — P <= 384 — the sweep is a few hundred MFMAs per draw and the per-draw
             // list atomic on <= 3 x 128 counters would pace it: those tables keep k_draw_bf16p)
             if (smem <= 160 * 1024 && d.n_chunks / 4 <= 128u && d.n_chunks / 4 >= 4u) {
