@@ -235,7 +235,9 @@ int rg_sim_set_logreg_fp16(rg_sim* sim, const uint16_t* d_coef16_t);
  * the pass streams are a QUARTER of the float32 bytes.  d_coef8_t [num_products][n_classes] unsigned bytes q + 128 with
  * q = rint(coef^T[p][c] / d_scale8[p]) in [-127, 127], d_scale8[p] = wmax[p] / 127 (fp32, rounded up): a weight is off by at most
  * d_scale8[p] / 2, so the pass's bound is sum_p views_p wmax[p] / 254 (+ the fp32 accumulation terms) where the fp16 pass has
- * sum_p views_p wmax[p] 2^-11 — more classes survive it, float64 scores still decide among them.  NULL = the fp16 pass. */
+ * sum_p views_p wmax[p] 2^-11 — more classes survive it; they are scored once more from the fp16 rows (that pass's bound), float64
+ * scores still decide among what is left.  The pass reads 20 bytes per lane and row: d_coef8_t must be readable 16 bytes past its
+ * last row, and n_classes % 4 == 0.  NULL = the fp16 pass. */
 int rg_sim_set_logreg_int8(rg_sim* sim, const uint8_t* d_coef8_t, const float* d_scale8);
 
 /* Where rows go.  d_log == NULL (or capacity 0) disables logging: only counters are kept. */

@@ -213,6 +213,25 @@ __global__ void __launch_bounds__(kBlock) k_logreg_acts(DevSim d, uint32_t t) {
 #ifndef RG_LR_OCC
 #define RG_LR_OCC 4
 #endif
+#ifndef RG_LR_RANGE_MAJOR
+#define RG_LR_RANGE_MAJOR 0
+#endif
+// maximum over the 64 lanes (all active), in every lane: DPP inside the rows of 16, v_readlane across them — no LDS round trip
+// (six dependent ds_bpermute per maximum were ~0.3 us of latency per batch of the screen)
+__device__ __forceinline__ float wave_max_dpp(float x) {
+    auto dpp = [](float v, auto ctrl) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    x = fmaxf(x, dpp(x, std::integral_constant<int, 0xB1>{}));      // quad_perm:[1,0,3,2]
+    x = fmaxf(x, dpp(x, std::integral_constant<int, 0x4E>{}));      // quad_perm:[2,3,0,1]
+    x = fmaxf(x, dpp(x, std::integral_constant<int, 0x141>{}));     // row_half_mirror
+    x = fmaxf(x, dpp(x, std::integral_constant<int, 0x140>{}));     // row_mirror
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
 // acc + a * (fp16 half of w): v_fma_mix_f32 takes the fp16 operand as it lies in the row (one instruction and no converted copy;
 // left to itself the compiler converts all 64 halves of a batch first — 64 more live registers — for packed fp32 fmas)
 __device__ __forceinline__ float fma_mix_lo(float a, uint32_t w, float acc) {
@@ -237,7 +256,11 @@ __global__ void __launch_bounds__(kBlock, RG_LR_OCC) k_logreg_screen(DevSim d, u
     const uint32_t RC = ((C + kLrSplit - 1) / kLrSplit + 7u) & ~7u;       // classes per range (a multiple of 8)
     const uint32_t waves_total = gridDim.x * (kBlock / 64);
     for (uint32_t item = blockIdx.x * (kBlock / 64) + wave; item < n * kLrSplit; item += waves_total) {
+#if RG_LR_RANGE_MAJOR
+        const uint32_t w = item % n, r = item / n;      // range-major: the waves in flight read ONE eighth of the table's columns
+#else
         const uint32_t w = item / kLrSplit, r = item % kLrSplit;
+#endif
         // (everything about the act is wave-uniform: kept in scalar registers, the history's loads scalar or broadcast)
         const uint32_t slot = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(d.lr_list[w])));
         const hent_t* hr = hist_row(d, slot) + 1;
@@ -287,9 +310,9 @@ __global__ void __launch_bounds__(kBlock, RG_LR_OCC) k_logreg_screen(DevSim d, u
 #pragma unroll
             for (int j = 0; j < 8; ++j) m = fmaxf(m, acc[j]);
             if (!in) m = -INFINITY;
-            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            rb = fmaxf(rb, m);
+            rb = fmaxf(rb, wave_max_dpp(m));
             const float cut = rb - thr;
+            if (__ballot(m >= cut) == 0ull) return;          // (no lane holds a class within the band: most batches but one)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const bool pass = in && acc[j] >= cut;
@@ -313,13 +336,16 @@ __global__ void __launch_bounds__(kBlock, RG_LR_OCC) k_logreg_screen(DevSim d, u
             float cn8[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) cn8[e] = static_cast<uint32_t>(e) < nd ? static_cast<float>(h_cnt(h8[e])) : 0.0f;
+            const unsigned short* rp[8];           // (the rows' base addresses once per act, not per batch)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rp[e] = d.lr_coef16_t + static_cast<size_t>(p8[e]) * C;
             auto fetch = [&](uint32_t c0, Batch& bt) {
                 const uint32_t c = c0 + 8u * static_cast<uint32_t>(lane);
                 const uint32_t cl = c < c_hi ? c : c_lo;
                 bt.b0 = *reinterpret_cast<const float4*>(d.lr_intercept32 + cl);
                 bt.b1 = *reinterpret_cast<const float4*>(d.lr_intercept32 + cl + 4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) bt.hv[e] = *reinterpret_cast<const uint4*>(d.lr_coef16_t + static_cast<size_t>(p8[e]) * C + cl);
+                for (int e = 0; e < 8; ++e) bt.hv[e] = *reinterpret_cast<const uint4*>(rp[e] + cl);
             };
             Batch cur;
             fetch(c_lo, cur);
@@ -361,8 +387,14 @@ __global__ void __launch_bounds__(kBlock, RG_LR_OCC) k_logreg_screen(DevSim d, u
                 if (more) fetch(c0 + 512, cur);
             }
         } else {
-            // 8-bit rows (q + 128, 8 bytes per lane and row: v_cvt_f32_ubyte*), count x scale folded into one factor per row, the
-            // offset 128 sum(count x scale) taken off once at the end; the same chain of round trips as above
+            // 8-bit rows (q + 128: v_cvt_f32_ubyte*), count x scale folded into one factor per row, the offset 128 sum(count x scale)
+            // taken off once at the end.  A lane takes kCpl8 = 20 consecutive classes — 20 bytes per row — so that a range of
+            // <= 1 280 classes (C5: 1 256) is ONE round trip for its first eight history rows: the screen is a chain of dependent
+            // round trips (list -> history -> rows), not bytes — the 8-bit rows at 8 classes per lane took as long as the fp16 ones
+            // (profiles/r6/ab_call29_c5.jsonl).  Rows are read up to 16 bytes past a range's last class (rg_sim_set_logreg_int8: the
+            // array carries 16 bytes of padding).
+            constexpr int kCpl8 = 20;
+            struct __attribute__((packed, aligned(4))) Row8 { uint32_t w[kCpl8 / 4]; };
             uint32_t p8[8];
             float cs8[8];
             float corr8 = 0.0f;
@@ -373,56 +405,73 @@ __global__ void __launch_bounds__(kBlock, RG_LR_OCC) k_logreg_screen(DevSim d, u
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) corr8 = fmaf(cs8[e], 128.0f, corr8);
-            struct Batch8 { uint2 bv[8]; float4 b0, b1; };
-            auto fetch = [&](uint32_t c0, Batch8& bt) {
-                const uint32_t c = c0 + 8u * static_cast<uint32_t>(lane);
-                const uint32_t cl = c < c_hi ? c : c_lo;
-                bt.b0 = *reinterpret_cast<const float4*>(d.lr_intercept32 + cl);
-                bt.b1 = *reinterpret_cast<const float4*>(d.lr_intercept32 + cl + 4);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bt.bv[e] = *reinterpret_cast<const uint2*>(d.lr_coef8_t + static_cast<size_t>(p8[e]) * C + cl);
-            };
-            Batch8 cur;
-            fetch(c_lo, cur);
-            for (uint32_t c0 = c_lo; c0 < c_hi && !overflow; c0 += 512) {
-                const bool more = c0 + 512 < c_hi;
-                const uint32_t c = c0 + 8u * static_cast<uint32_t>(lane);
-                const bool in = c < c_hi;
+            for (uint32_t c0 = c_lo; c0 < c_hi && !overflow; c0 += 64 * kCpl8) {
+                const uint32_t c = c0 + static_cast<uint32_t>(kCpl8) * static_cast<uint32_t>(lane);
+                const bool in = c < c_hi;                            // (some of the lane's classes; each is checked below)
                 const uint32_t cl = in ? c : c_lo;
-                float acc[8] = {cur.b0.x, cur.b0.y, cur.b0.z, cur.b0.w, cur.b1.x, cur.b1.y, cur.b1.z, cur.b1.w};
+                Row8 bv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bv[e] = *reinterpret_cast<const Row8*>(d.lr_coef8_t + static_cast<size_t>(p8[e]) * C + cl);
+                float acc[kCpl8];
+#pragma unroll
+                for (int q = 0; q < kCpl8 / 4; ++q) {
+                    const float4 b = *reinterpret_cast<const float4*>(d.lr_intercept32 + min(cl + 4u * q, C - 4u));
+                    acc[4 * q] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+                }
                 float corr = corr8;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[j] = fmaf(cs8[e], static_cast<float>((cur.bv[e].x >> (8 * j)) & 0xFFu), acc[j]);
-                        acc[4 + j] = fmaf(cs8[e], static_cast<float>((cur.bv[e].y >> (8 * j)) & 0xFFu), acc[4 + j]);
-                    }
+                    for (int j = 0; j < kCpl8; ++j)
+                        acc[j] = fmaf(cs8[e], static_cast<float>((bv[e].w[j / 4] >> (8 * (j % 4))) & 0xFFu), acc[j]);
                 }
-                for (uint32_t i0 = 8; i0 < nd; i0 += 4) {            // long histories: four more rows in flight
-                    uint2 bv[4];
-                    float cs[4];
+                for (uint32_t i0 = 8; i0 < nd; i0 += 2) {            // long histories: two more rows in flight
+                    Row8 bw[2];
+                    float cs[2];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < 2; ++e) {
                         const hent_t x = hr[min(i0 + e, nd - 1)];
                         const uint32_t pp = h_prod(x);
                         cs[e] = static_cast<float>(h_cnt(x)) * d.lr_scale8[pp] * (i0 + e < nd ? 1.0f : 0.0f);     // (the load unconditional)
-                        bv[e] = *reinterpret_cast<const uint2*>(d.lr_coef8_t + static_cast<size_t>(pp) * C + cl);
+                        bw[e] = *reinterpret_cast<const Row8*>(d.lr_coef8_t + static_cast<size_t>(pp) * C + cl);
                     }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < 2; ++e) {
                         corr = fmaf(cs[e], 128.0f, corr);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            acc[j] = fmaf(cs[e], static_cast<float>((bv[e].x >> (8 * j)) & 0xFFu), acc[j]);
-                            acc[4 + j] = fmaf(cs[e], static_cast<float>((bv[e].y >> (8 * j)) & 0xFFu), acc[4 + j]);
+                        for (int j = 0; j < kCpl8; ++j)
+                            acc[j] = fmaf(cs[e], static_cast<float>((bw[e].w[j / 4] >> (8 * (j % 4))) & 0xFFu), acc[j]);
+                    }
+                }
+                float m = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < kCpl8; ++j) {
+                    acc[j] -= corr;
+                    if (c + j < c_hi) m = fmaxf(m, acc[j]);
+                }
+                if (!in) m = -INFINITY;
+                rb = fmaxf(rb, wave_max_dpp(m));
+                const float cut = rb - thr;
+                // (few classes pass: one ballot over "any of mine", then the passing lanes' classes one by one)
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < kCpl8; ++j) any = any || (c + j < c_hi && acc[j] >= cut);
+                if (!in) any = false;
+                if (__ballot(any)) {
+#pragma unroll
+                    for (int j = 0; j < kCpl8; ++j) {
+                        const bool pass = in && c + j < c_hi && acc[j] >= cut;
+                        const unsigned long long pm = __ballot(pass);
+                        if (pm && !overflow) {
+                            const uint32_t np = static_cast<uint32_t>(__popcll(pm));
+                            if (n_cand + np > kCandCap) overflow = true;
+                            else {
+                                if (pass) { const uint32_t k = n_cand + prefix_in_mask(pm); s_cand[wave][k] = c + j; s_cval[wave][k] = acc[j]; }
+                                n_cand += np;
+                            }
                         }
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] -= corr;
-                collect(c, in, acc);
-                if (more) fetch(c0 + 512, cur);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -537,10 +586,21 @@ __global__ void __launch_bounds__(kBlock) k_logreg_decide(DevSim d, uint32_t t) 
         }
         if (lane == 0) { d.lr_action[uidx] = action; d.lr_dirty[uidx] = 0; }
     }
+    // the counters once per BLOCK: per wave — one act each on a grid sized for the step's worst case — these three atomics on three
+    // addresses were the kernel's whole time (profiles/r6/c5_fp16_kernel_stats_call31.csv)
+    __shared__ unsigned long long s_cnt[3];
+    if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0ull;
+    __syncthreads();
     if (lane == 0 && c_acts) {
-        atomicAdd(&d.counters[RG_CNT_LR_ACTS], c_acts);
-        atomicAdd(&d.counters[RG_CNT_LR_ROWS], c_rows);
-        if (c_exact) atomicAdd(&d.counters[RG_CNT_LR_EXACT], c_exact);
+        atomicAdd(&s_cnt[0], c_acts);
+        atomicAdd(&s_cnt[1], c_rows);
+        if (c_exact) atomicAdd(&s_cnt[2], c_exact);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt[0]) {
+        atomicAdd(&d.counters[RG_CNT_LR_ACTS], s_cnt[0]);
+        atomicAdd(&d.counters[RG_CNT_LR_ROWS], s_cnt[1]);
+        if (s_cnt[2]) atomicAdd(&d.counters[RG_CNT_LR_EXACT], s_cnt[2]);
     }
 }
 

@@ -639,13 +639,24 @@ int launch_step(rg_sim* sim, const int32_t* d_actions, hipStream_t st) {
         if (d.lr_sample)           // select_randomly: a softmax and a draw per act (a wave each)
             hipLaunchKernelGGL(logreg_sample_kernel(), dim3(grid_for(static_cast<uint64_t>(upper) + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
         else if (d.lr_coef16_t) {       // screen (a wave per act and class range), then decide (a wave per act)
-            hipLaunchKernelGGL(logreg_screen_kernel(d.lr_coef8_t != nullptr), dim3(grid_for((static_cast<uint64_t>(upper) / 4 + 64) * kLrSplit, kBlock / 64)),
+            // (the number of acts is only known on the device — at most a quarter of the live users, usually a fiftieth: the kernels
+            // walk their lists grid-stride, and the grids are capped at a few blocks per CU.  Sized for the worst case they were
+            // mostly blocks that start and leave — and k_logreg_decide's three counter atomics per WAVE, one act each, were all of
+            // its time: 41 of the 169 ms of C5's acts, profiles/r6/c5_fp16_kernel_stats_call31.csv)
+            const int cus = device_cus(sim);
+            auto capped = [&](uint64_t waves, int blocks_per_cu) {
+                const int g = grid_for(waves, kBlock / 64);
+                return g < cus * blocks_per_cu ? g : cus * blocks_per_cu;
+            };
+            hipLaunchKernelGGL(logreg_screen_kernel(d.lr_coef8_t != nullptr), dim3(capped((static_cast<uint64_t>(upper) / 4 + 64) * kLrSplit, 16)),
                                dim3(kBlock), 0, st, d, t);
-            hipLaunchKernelGGL(logreg_decide_kernel(), dim3(grid_for(static_cast<uint64_t>(upper) / 4 + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
+            hipLaunchKernelGGL(logreg_decide_kernel(), dim3(capped(static_cast<uint64_t>(upper) / 4 + 64, 8)), dim3(kBlock), 0, st, d, t);
             if (upper > d.lr_part_cap)     // the step may list more acts than the screen's scratch has rows: the rest in fp32 / float64
-                hipLaunchKernelGGL(logreg_acts_kernel(), dim3(grid_for(static_cast<uint64_t>(upper - d.lr_part_cap) / 4 + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
-        } else
-            hipLaunchKernelGGL(logreg_acts_kernel(), dim3(grid_for(static_cast<uint64_t>(upper) / 4 + 64, kBlock / 64)), dim3(kBlock), 0, st, d, t);
+                hipLaunchKernelGGL(logreg_acts_kernel(), dim3(capped(static_cast<uint64_t>(upper - d.lr_part_cap) / 4 + 64, 8)), dim3(kBlock), 0, st, d, t);
+        } else {
+            const int g = grid_for(static_cast<uint64_t>(upper) / 4 + 64, kBlock / 64), cap = device_cus(sim) * 8;
+            hipLaunchKernelGGL(logreg_acts_kernel(), dim3(g < cap ? g : cap), dim3(kBlock), 0, st, d, t);
+        }
     }
     if (int rc = prof_mark(sim, st)) return rc;
     // 2. click draws, transitions, drift, next lists, bandit + phantom rows

@@ -167,13 +167,16 @@ class Simulator:
                         _abi.check(self.lib.rg_sim_set_logreg_fp16(self._h, self.logreg16.data_ptr()), 'rg_sim_set_logreg_fp16')
                         # round 6, opt-in (RECOGYM_LOGREG=int8 or logreg['int8']): the screening pass from an 8-BIT copy (a quarter of the
                         # fp32 row bytes): q = rint(w / scale) + 128, scale = wmax / 127 per product row — |w - scale q| <= scale / 2.
-                        # Measured on C5 and NOT the default: its band is 8x the fp16 copy's, 21 % of the acts (3 %) go to the float64
-                        # refine, acts 232 -> 342 ms (profiles/r6/ab_call21_c5.jsonl)
+                        # Its band is 8x the fp16 copy's, so the classes it keeps are scored once more from the fp16 rows (second level,
+                        # inside the screen kernel) before float64 decides
                         if logreg.get('int8', False) or os.environ.get('RECOGYM_LOGREG', 'fp16') == 'int8':
                             scale = (wmax.to(torch.float64) / 127.0 * (1.0 + 1e-6)).clamp_min(1e-30)
                             q = torch.round(self.logreg[0] / scale[:, None]).clamp_(-127, 127)
                             assert bool(((self.logreg[0] - q * scale[:, None]).abs() <= 0.5 * scale[:, None] * (1.0 + 1e-9)).all())
-                            self.logreg8 = ((q + 128.0).to(torch.uint8).contiguous(), scale.to(torch.float32).contiguous())
+                            # (16 bytes of padding behind the last row: the pass reads 20 bytes per lane and row)
+                            q8 = torch.zeros(q.numel() + 16, dtype=torch.uint8, device=q.device)
+                            q8[:q.numel()] = (q + 128.0).to(torch.uint8).reshape(-1)
+                            self.logreg8 = (q8, scale.to(torch.float32).contiguous())
                             # (the float32 scale the kernel multiplies with must not be SMALLER than the one the weights were divided
                             # by, or the half-step bound would be off by the rounding: compare against the float64 value)
                             assert bool((self.logreg8[1].to(torch.float64) * (1.0 + 2e-7) >= scale).all())
