@@ -604,6 +604,26 @@ def test_frozen_logreg_with_more_than_256_classes_matches_the_oracle():
     assert (used >= classes[256]).any() and (used >= classes[512]).any()     # later class blocks do win
 
 
+def test_frozen_logreg_steps_with_more_acts_than_the_capped_grids_hold():
+    """k_logreg_screen / k_logreg_decide walk a step's act list grid-stride on grids capped at a few blocks per CU (round 6): with
+    40 000 users the first steps list ~10^4 acts — 8 x 10^4 (act, class range) items, several per wave — and every row must
+    still be the oracle's."""
+    from oracle import oracle as orc
+    P = C = 64
+    rng = np.random.RandomState(11)
+    coef_t = rng.standard_normal((P, C)) * 0.3
+    intercept = rng.standard_normal(C) * 0.1
+    pol = dict(policy=_abi.RG_POLICY_LOGREG_FROZEN, policy_seed=0,
+               logreg=dict(coef_t=coef_t, intercept=intercept, classes=np.arange(C, dtype=np.int32)))
+    cfg = Configuration({**env_1_args, 'random_seed': 77, 'num_products': P, 'K': 8})
+    n = 40000
+    want = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX, **pol).generate_logs(n)
+    rows, cnt = run_sim(cfg, n, **pol)
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps', 'p_click')},
+                         ps_rtol=1e-12, what='logreg, 40 000 users')
+    assert cnt['live'] == 0 and cnt['log_dropped'] == 0
+
+
 @pytest.mark.parametrize('P', [10, 200, 1024])
 def test_sampled_frozen_logreg_matches_the_oracle(P):
     """LogregMulticlassIps with select_randomly = True on the device (k_logreg_sample: softmax of the float64 class scores, the
