@@ -420,6 +420,104 @@ __global__ void __launch_bounds__(kBlock) k_scatter_rows(DevSim d, uint64_t n_ro
     }
 }
 
+// k_scatter_rows through LDS.  The walk writes its raw log a wave iteration at a time — one row of each of its 64 users — so 64
+// consecutive raw rows go to 64 different places of the ordered log, 16 bytes each: the plain scatter above ran at 1.6 TB/s of
+// rows read + written (19.2 ms of rg_sim_sort_log's 20.2 on the C3 log: profiles/r6/sort_kernel_stats_call37.csv).  Here a block
+// takes a TILE of kSortTile consecutive raw rows, groups them by user in LDS (a small hash table of the tile's users: count, first
+// and last event index; a user's rows inside a tile are a run of consecutive event indices) and writes every user's run as one
+// contiguous piece.  A tile whose users do not fit the table (the logs of lock-step / round runs: one row per user), or where a
+// user's indices have a gap, is written the plain way.
+constexpr uint32_t kSortTile = 2048, kSortHash = 512;
+__global__ void __launch_bounds__(kBlock, 3) k_scatter_rows_tiled(DevSim d, uint64_t n_rows, const int64_t* off,
+                                                                 rg_event* out, uint64_t out_cap) {
+    constexpr uint32_t RPT = kSortTile / kBlock;               // rows per thread
+    __shared__ rg_event s_rows[kSortTile];
+    __shared__ unsigned short s_slot[kSortTile];
+    __shared__ uint32_t h_key[kSortHash], h_tmin[kSortHash], h_tmax[kSortHash], h_cnt[kSortHash], h_base[kSortHash];
+    __shared__ unsigned long long h_dst[kSortHash];
+    __shared__ uint32_t s_scan[kBlock], s_bad;
+    const uint64_t n_tiles = (n_rows + kSortTile - 1) / kSortTile;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t r0 = tile * kSortTile;
+        for (uint32_t i = threadIdx.x; i < kSortHash; i += kBlock) { h_key[i] = 0xFFFFFFFFu; h_tmin[i] = 0xFFFFFFFFu; h_tmax[i] = 0u; h_cnt[i] = 0u; }
+        if (threadIdx.x == 0) s_bad = 0u;
+        __syncthreads();
+        rg_event e[RPT];
+        uint32_t slot[RPT];
+#pragma unroll
+        for (uint32_t q = 0; q < RPT; ++q) {                     // (coalesced: thread x takes rows x, x + 256, ...)
+            const uint64_t r = r0 + q * kBlock + threadIdx.x;
+            if (r < n_rows) e[q] = d.log[r];
+            else { e[q].u = 0; e[q].t = 0; e[q].code = kHoleCode; e[q].ps = 0.0f; }
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < RPT; ++q) {
+            slot[q] = 0xFFFFFFFFu;
+            if (e[q].code == kHoleCode) continue;
+            uint32_t h = (e[q].u * 2654435761u) >> 23;            // 9 bits
+            for (uint32_t probe = 0; probe < 16; ++probe) {
+                const uint32_t k = atomicCAS(&h_key[h], 0xFFFFFFFFu, e[q].u);
+                if (k == 0xFFFFFFFFu || k == e[q].u) { slot[q] = h; break; }
+                h = (h + 1) & (kSortHash - 1);
+            }
+            if (slot[q] == 0xFFFFFFFFu) { s_bad = 1u; continue; }
+            atomicMin(&h_tmin[slot[q]], e[q].t);
+            atomicMax(&h_tmax[slot[q]], e[q].t);
+            atomicAdd(&h_cnt[slot[q]], 1u);
+        }
+        __syncthreads();
+        // runs without a gap?  their places in the tile: an exclusive scan of the counts in table order
+        uint32_t mine = 0;
+        for (uint32_t i = threadIdx.x * (kSortHash / kBlock); i < (threadIdx.x + 1) * (kSortHash / kBlock); ++i) {
+            if (h_cnt[i] && h_tmax[i] - h_tmin[i] + 1u != h_cnt[i]) s_bad = 1u;
+            mine += h_cnt[i];
+        }
+        s_scan[threadIdx.x] = mine;
+        __syncthreads();
+        for (uint32_t o = 1; o < kBlock; o <<= 1) {
+            const uint32_t y = threadIdx.x >= o ? s_scan[threadIdx.x - o] : 0u;
+            __syncthreads();
+            s_scan[threadIdx.x] += y;
+            __syncthreads();
+        }
+        const bool bad = s_bad != 0u;
+        if (bad) {                                               // the plain scatter for this tile
+#pragma unroll
+            for (uint32_t q = 0; q < RPT; ++q) {
+                if (e[q].code == kHoleCode) continue;
+                const uint64_t dst = static_cast<uint64_t>(off[e[q].u - d.first_user]) + e[q].t;
+                if (dst < out_cap) out[dst] = e[q];
+            }
+            __syncthreads();
+            continue;
+        }
+        {
+            uint32_t run = s_scan[threadIdx.x] - mine;
+            for (uint32_t i = threadIdx.x * (kSortHash / kBlock); i < (threadIdx.x + 1) * (kSortHash / kBlock); ++i) {
+                h_base[i] = run;
+                if (h_cnt[i]) h_dst[i] = static_cast<unsigned long long>(off[h_key[i] - d.first_user]) + h_tmin[i];
+                run += h_cnt[i];
+            }
+        }
+        const uint32_t total = s_scan[kBlock - 1];
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < RPT; ++q) {
+            if (e[q].code == kHoleCode) continue;
+            const uint32_t pos = h_base[slot[q]] + (e[q].t - h_tmin[slot[q]]);
+            s_rows[pos] = e[q];
+            s_slot[pos] = static_cast<unsigned short>(slot[q]);
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < total; i += kBlock) {
+            const uint32_t sl = s_slot[i];
+            const uint64_t dst = h_dst[sl] + (i - h_base[sl]);
+            if (dst < out_cap) out[dst] = s_rows[i];
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) k_scatter_phantom(DevSim d, const int64_t* off, rg_event* out,
                                                           uint64_t out_cap) {
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < d.n_users; i += gridDim.x * kBlock) {
@@ -1852,8 +1950,14 @@ int rg_sim_sort_log(rg_sim* sim, int64_t* d_row_offsets, int64_t* d_scratch, rg_
     HIP_TRY(hipStreamSynchronize(st));
     if (n_rows > d.log_cap) return fail(RG_ELIMIT, "log overflow: %llu rows emitted, capacity %llu",
                                         (unsigned long long)n_rows, (unsigned long long)d.log_cap);
-    hipLaunchKernelGGL(k_scatter_rows, dim3(grid_for(n_rows)), dim3(kBlock), 0, st, d, n_rows, d_row_offsets,
-                       d_sorted, sorted_capacity);
+    {
+        static const bool plain = getenv("RECOGYM_SORT_PLAIN") != nullptr;      // (A/B: the scatter without the LDS tiles)
+        const uint64_t tiles = (n_rows + kSortTile - 1) / kSortTile;
+        const uint64_t cap = static_cast<uint64_t>(device_cus(sim)) * 12u;
+        if (plain) hipLaunchKernelGGL(k_scatter_rows, dim3(grid_for(n_rows)), dim3(kBlock), 0, st, d, n_rows, d_row_offsets, d_sorted, sorted_capacity);
+        else hipLaunchKernelGGL(k_scatter_rows_tiled, dim3(static_cast<unsigned>(tiles < cap ? (tiles ? tiles : 1) : cap)), dim3(kBlock), 0, st, d, n_rows,
+                                d_row_offsets, d_sorted, sorted_capacity);
+    }
     hipLaunchKernelGGL(k_scatter_phantom, dim3(grid_for(n)), dim3(kBlock), 0, st, d, d_row_offsets, d_sorted,
                        sorted_capacity);
     HIP_TRY(hipGetLastError());
