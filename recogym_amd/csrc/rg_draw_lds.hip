@@ -25,6 +25,12 @@
 // 1: no epilogue (uniform, tile count, record, list entry), 2: the first 8 product tiles only (what a work item costs besides its
 // tile loop), 4: exps replaced by a multiply, 8: no MFMAs, 16: no tile barrier / DMA beyond the first two tiles, 32: no books,
 // 64: no mu loads.  -DRG_PICK_ABL=bits on k_pick: 1: no row / history, 2: no chunk loop
+// k_draw_tpw's exp sums with plain v_add_f32 (the same sums in the same order): at one wave per SIMD a packed fp32 add beside MFMAs
+// costs more than the two adds it replaces (MI355X_MICROARCH.md): 3 393 -> 3 247 cycles per tile, but the clock under this load falls
+// with it (2.06 -> 1.99 GHz): 1.2 % per tile, C4's sweep 1 265 -> 1 245 ms (profiles/r6/ab_call39_*)
+#ifndef RG_TPW_SCALAR_ADD
+#define RG_TPW_SCALAR_ADD 1
+#endif
 #ifndef RG_TP_ABL
 #define RG_TP_ABL 0
 #endif
@@ -731,6 +737,10 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
             const char* abn = buf_of(bn) + ((ODD ? 0 : 32) + jl) * RSc + 16 * hl;            // the next chunk's rows
             const char* mbn = reinterpret_cast<const char*>(mu_buf) + 16 * hl + bn * 256u + (ODD ? 0u : 128u);
             f32x2 x[UG][4];
+#if RG_TPW_SCALAR_ADD
+            float xs[UG][8];
+            auto addf = [](float a, float b2) -> float { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b2)); return r; };
+#endif
             auto slot = [&](int i) {
                 if (i < ESL) {
                     if (have_p) {
@@ -741,7 +751,13 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
                             f32x2 y = {(RG_TPW_ABL & 1) ? pv[g][2 * r] * 0.5f : __builtin_amdgcn_exp2f(pv[g][2 * r]),
                                        (RG_TPW_ABL & 1) ? pv[g][2 * r + 1] * 0.5f : __builtin_amdgcn_exp2f(pv[g][2 * r + 1])};
                             asm volatile("" : "+v"(y));
+#if RG_TPW_SCALAR_ADD
+                            // (same sums, same order per component as the packed form: x[r & 3] component-wise)
+                            if (r < 4) { xs[g][2 * r] = y[0]; xs[g][2 * r + 1] = y[1]; }
+                            else { xs[g][2 * (r & 3)] = addf(xs[g][2 * (r & 3)], y[0]); xs[g][2 * (r & 3) + 1] = addf(xs[g][2 * (r & 3) + 1], y[1]); }
+#else
                             if (r < 4) x[g][r] = y; else x[g][r & 3] += y;
+#endif
                         }
                     }
                 } else if (i == ESL) {
@@ -749,8 +765,14 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
                         float sm[UG];
 #pragma unroll
                         for (int g = 0; g < UG; ++g) {
+#if RG_TPW_SCALAR_ADD
+                            const float z0 = addf(addf(xs[g][0], xs[g][4]), addf(xs[g][2], xs[g][6]));
+                            const float z1 = addf(addf(xs[g][1], xs[g][5]), addf(xs[g][3], xs[g][7]));
+                            sm[g] = addf(z0, z1);
+#else
                             const f32x2 z = (x[g][0] + x[g][2]) + (x[g][1] + x[g][3]);
                             sm[g] = z[0] + z[1];
+#endif
                         }
                         book(ci - 1, sm[0], sm[1]);
                     }

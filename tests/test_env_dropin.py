@@ -598,3 +598,17 @@ def test_batched_episode_path_equals_the_per_user_path_and_the_oracle(sizes):
     assert [str(x) for x in a.dtypes] == [str(x) for x in b.dtypes]
     pd.testing.assert_frame_equal(a, b)
     assert len(env.generate_logs(n, deepcopy(agent), n_org)) == len(a)        # (the default route of generate_logs)
+
+@pytest.mark.gpu
+def test_rccl_communicator_and_all_reduce_on_this_box():
+    """The only piece of the multi-GPU path a one-GPU box can run on the real backend: an RCCL ("nccl") process group of ONE rank on
+    the device and an all_reduce of the counters' tensor through it (tools/rccl_probe.py; two ranks on one device are refused by RCCL
+    — "Duplicate GPU detected", profiles/r6/rccl_probe_2ranks_one_device.txt — so the exchange between ranks is covered by the gloo
+    tests only)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'rccl_probe.py'), '1'], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'RCCL ok: backend nccl, world 1' in r.stdout
