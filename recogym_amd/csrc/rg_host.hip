@@ -454,6 +454,7 @@ __global__ void __launch_bounds__(kBlock, 3) k_scatter_rows_tiled(DevSim d, uint
         for (uint32_t q = 0; q < RPT; ++q) {
             slot[q] = 0xFFFFFFFFu;
             if (e[q].code == kHoleCode) continue;
+            if (e[q].u == 0xFFFFFFFFu) { s_bad = 1u; continue; }   // (the highest user id is the table's "empty" key: the plain path)
             uint32_t h = (e[q].u * 2654435761u) >> 23;            // 9 bits
             for (uint32_t probe = 0; probe < 16; ++probe) {
                 const uint32_t k = atomicCAS(&h_key[h], 0xFFFFFFFFu, e[q].u);

@@ -604,6 +604,20 @@ def test_frozen_logreg_with_more_than_256_classes_matches_the_oracle():
     assert (used >= classes[256]).any() and (used >= classes[512]).any()     # later class blocks do win
 
 
+@pytest.mark.parametrize('sigma_omega', [0.0, 0.1])
+def test_the_highest_user_ids_sort_like_any_other(sigma_omega):
+    """User ids up to 2^32 - 1 (rg_sim_reset_users' bound): the ordered log's LDS-tiled scatter keys its table of a tile's users by
+    id with 0xFFFFFFFF as the empty key — a tile holding that user takes the plain path — and every row must come out as the
+    oracle's (user-major walk at sigma_omega = 0, rounds otherwise)."""
+    from oracle import oracle as orc
+    cfg = Configuration({**env_1_args, 'random_seed': 9, 'num_products': 40, 'K': 5, 'sigma_omega': sigma_omega})
+    n, first = 700, (1 << 32) - 700
+    want = orc.OracleEnv(cfg, rng_mode=orc.RNG_PHILOX).generate_logs(n, first_user_id=first)
+    rows, cnt = run_sim(cfg, n, first_user=first)
+    assert int(rows['u'].astype(np.int64).max()) == (1 << 32) - 1
+    gu.assert_rows_equal(rows, {k: want[k] for k in ('u', 't', 'z', 'v', 'a', 'c', 'ps', 'p_click')}, ps_rtol=1e-12, what='highest user ids')
+
+
 def test_frozen_logreg_steps_with_more_acts_than_the_capped_grids_hold():
     """k_logreg_screen / k_logreg_decide walk a step's act list grid-stride on grids capped at a few blocks per CU (round 6): with
     40 000 users the first steps list ~10^4 acts — 8 x 10^4 (act, class range) items, several per wave — and every row must
