@@ -1288,6 +1288,11 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
         // kernels sweep all P per step, so for them the tail kernel wins much earlier)
         const double tb = 4096.0 * ((scale < 1.0 && d.use_mfma == 2) ? scale : 1.0);
         s->tail_below = tb < 64.0 ? 64u : static_cast<uint32_t>(tb);
+        // ... and not at all beyond P x K = 10^6 there: a block streams the whole float64 table per draw (51 MB at 10^5 x 64: 0.4 ms,
+        // as long as a sliced round of ALL the users left).  A C4 shard with the tail from 128 users 1 615 ms, from 32 1 582, from 2
+        // 1 538, never 1 503 (profiles/r6/ab_call45_c4_tail.jsonl, ab_call46_c4_tail.jsonl); at 10^4 x 20 it makes no difference
+        // (c3drift 801 / 795 / 801 ms from 4 096 / 1 024 / never: ab_call47_tail.jsonl)
+        if (d.use_mfma == 2 && static_cast<double>(d.P) * static_cast<double>(d.K) > 1.0e6) s->tail_below = 0;
         // the tail kernel runs a policy on one thread: fine for a history walk, not for n_classes x views
         // score loops — the frozen LogReg policy stays in lock-step (wave-cooperative acts) to the end
         if (d.policy == RG_POLICY_LOGREG_FROZEN) s->tail_below = 0;
@@ -1353,7 +1358,8 @@ int rg_sim_create(rg_sim** out, const rg_config* cfg, uint64_t n_users, void* d_
     if (const char* e = getenv("RECOGYM_PIPE_MIN")) { const int o = atoi(e); if (o >= 256) s->pipe_min_users = static_cast<uint32_t>(o); }
     d.grp_lo = 0; d.grp_n = d.n_users; d.list_in = 0;
     d.q_ticket = d.counters + kCntWalkTicket; d.q_park = d.counters + kCntParkCnt; d.q_count = nullptr;
-    if (const char* e = getenv("RECOGYM_TAIL")) s->tail_below = static_cast<uint32_t>(atoi(e));
+    if (const char* e = getenv("RECOGYM_TAIL"))        // (never for the frozen LogReg policy: k_tail acts on one thread — 46 s per C5 step)
+        if (d.policy != RG_POLICY_LOGREG_FROZEN) s->tail_below = static_cast<uint32_t>(atoi(e));
     if (const char* e = getenv("RECOGYM_REPACK")) s->repack_every = static_cast<uint32_t>(atoi(e));
     s->run_ahead = 32;         // events a round of a run to the end may take a user through (0: lock-step, an event per launch)
     if (const char* e = getenv("RECOGYM_RUN_AHEAD")) s->run_ahead = static_cast<uint32_t>(atoi(e));
