@@ -716,6 +716,7 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
         constexpr int NSLOT = UG * N1, NEP = 8 * UG, EPS = NSLOT >= NEP + 9 ? 1 : (NSLOT >= NEP / 2 + 9 ? 2 : 4), ESL = NEP / EPS;     // exp PAIRS per slot; slots that carry exps
         static_assert(ESL + 9 <= NSLOT, "a chunk's slots must hold its exps, books and the next chunk's seeds");
         constexpr int RD = 4;                                          // A ring: k-steps read ahead of the MFMAs
+        constexpr int BAR_S2 = ((ESL + 1) / UG) < (N1 - RD + 1) ? ((ESL + 1) / UG) : (N1 - RD + 1);     // the tile barrier's k-step in a tile's second chunk
         auto load_mu_q = [&](f32x16& acc, const char* mb, int qq) {
             const float4 m = *reinterpret_cast<const float4*>(mb + 32 * qq);
             acc[4 * qq] = m.x; acc[4 * qq + 1] = m.y; acc[4 * qq + 2] = m.z; acc[4 * qq + 3] = m.w;
@@ -785,9 +786,13 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
             RG_PIN();
 #pragma unroll
             for (int s2 = 0; s2 < N1; ++s2) {
-                if (ODD && s2 == N1 - RD + 1 && has_next && !(RG_TPW_ABL & 4)) {
+                if (ODD && s2 == BAR_S2 && has_next && !(RG_TPW_ABL & 4)) {
                     // the next chunk opens tile ti + 1: it has landed once this wave's DMA (issued a tile ago) is done; every wave is
-                    // past tile ti - 1, whose buffer takes tile ti + 2
+                    // past tile ti - 1, whose buffer takes tile ti + 2.  The barrier sits BEFORE the first slot that touches tile
+                    // ti + 1 — its mu seeds (slot ESL + 1), then its first A fragments (k-step N1 - RD + 1).  (Until call 53 it sat
+                    // at k-step N1 - RD + 1 only: the first mu quads of the next tile — DMA'd by the block's LAST wave — were read
+                    // up to three slots before it; almost always landed, ~300 wrong draws in the 2.8 10^7 of a C4 shard when not:
+                    // profiles/r6/determinism_call51.jsonl)
                     RG_TILE_BARRIER(0);
                     if (ti + 2 < n_t) fetch_tile(ti + 2);
                 }

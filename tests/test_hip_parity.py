@@ -604,6 +604,35 @@ def test_frozen_logreg_with_more_than_256_classes_matches_the_oracle():
     assert (used >= classes[256]).any() and (used >= classes[512]).any()     # later class blocks do win
 
 
+@pytest.mark.parametrize('workload,users', [('c4shard', 262144), ('c3drift', 1000000), ('c3', 1000000)])
+def test_two_runs_of_a_bench_shape_give_the_same_log(workload, users):
+    """Rows are keyed by (seed, user, event): two runs of the same job must agree row for row whatever the order of their atomics.
+    Round 6's wide-K sweep (k_draw_tpw) read the first mu quads of a tile up to three issue slots before the barrier behind which
+    that tile is known to have landed — almost always fine, ~300 wrong draws in the 2.8 10^7 of a C4 shard when not; no small
+    case and no 2 000-user oracle sample sees a rate of 10^-5, two runs of a chip-filling shape against each other do
+    (profiles/r6/determinism_call51.jsonl: 330 rows; call 53: 0)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from recogym_amd.sim import Simulator, default_log_capacity
+    cfg = bench.make_config(workload)
+    name, kw = bench.arms_of(workload, cfg)[0]
+    sim = Simulator(cfg, users, device='cuda:0', log_capacity=default_log_capacity(cfg, users), **kw)
+    logs = []
+    for _ in range(3):
+        sim.reset_users(0, users)
+        sim.run()
+        log, _off = sim.sorted_log()
+        logs.append(log.clone())
+    sim.close()
+    for other in logs[1:]:
+        assert other.shape == logs[0].shape
+        assert int((other != logs[0]).any(dim=1).sum().item()) == 0
+
+
 @pytest.mark.parametrize('sigma_omega', [0.0, 0.1])
 def test_the_highest_user_ids_sort_like_any_other(sigma_omega):
     """User ids up to 2^32 - 1 (rg_sim_reset_users' bound): the ordered log's LDS-tiled scatter keys its table of a tile's users by
