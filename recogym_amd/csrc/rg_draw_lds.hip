@@ -716,7 +716,11 @@ __global__ void __launch_bounds__(kBlock, 1) k_draw_tpw(DevSim d, uint32_t t, ui
         constexpr int NSLOT = UG * N1, NEP = 8 * UG, EPS = NSLOT >= NEP + 9 ? 1 : (NSLOT >= NEP / 2 + 9 ? 2 : 4), ESL = NEP / EPS;     // exp PAIRS per slot; slots that carry exps
         static_assert(ESL + 9 <= NSLOT, "a chunk's slots must hold its exps, books and the next chunk's seeds");
         constexpr int RD = 4;                                          // A ring: k-steps read ahead of the MFMAs
+#ifdef RG_TEST_TPW_LATE_BARRIER     // (the bug put back, for tests/test_hip_parity.py::test_two_runs_of_a_bench_shape_give_the_same_log)
+        constexpr int BAR_S2 = N1 - RD + 1;
+#else
         constexpr int BAR_S2 = ((ESL + 1) / UG) < (N1 - RD + 1) ? ((ESL + 1) / UG) : (N1 - RD + 1);     // the tile barrier's k-step in a tile's second chunk
+#endif
         auto load_mu_q = [&](f32x16& acc, const char* mb, int qq) {
             const float4 m = *reinterpret_cast<const float4*>(mb + 32 * qq);
             acc[4 * qq] = m.x; acc[4 * qq + 1] = m.y; acc[4 * qq + 2] = m.z; acc[4 * qq + 3] = m.w;
