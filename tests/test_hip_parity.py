@@ -604,7 +604,7 @@ def test_frozen_logreg_with_more_than_256_classes_matches_the_oracle():
     assert (used >= classes[256]).any() and (used >= classes[512]).any()     # later class blocks do win
 
 
-@pytest.mark.parametrize('workload,users', [('c4shard', 262144), ('c3drift', 1000000), ('c3', 1000000),
+@pytest.mark.parametrize('workload,users', [('c4shard', 262144), ('c3drift', 1000000), ('c3', 1000000), ('c5#1', 262144),
                                             ('wide:K=30:P=20000', 524288), ('wide:K=45:P=20000', 524288), ('wide:K=64:P=5000', 524288)])
 def test_two_runs_of_a_bench_shape_give_the_same_log(workload, users):
     """Rows are keyed by (seed, user, event): two runs of the same job must agree row for row whatever the order of their atomics.
@@ -623,9 +623,10 @@ def test_two_runs_of_a_bench_shape_give_the_same_log(workload, users):
         over = {k: int(v) for k, v in (kv.split('=') for kv in workload.split(':')[1:])}
         cfg = Configuration({**env_1_args, 'random_seed': 42, 'num_products': over['P'], 'K': over['K'], 'sigma_omega': 0.1})
         kw = bench.policy_kwargs('none')
-    else:
-        cfg = bench.make_config(workload)
-        name, kw = bench.arms_of(workload, cfg)[0]
+    else:                                     # ("c5#1": the second arm of C5 — the frozen LogReg policy at 10^4 classes)
+        wl, _, arm = workload.partition('#')
+        cfg = bench.make_config(wl)
+        name, kw = bench.arms_of(wl, cfg)[int(arm or 0)]
     sim = Simulator(cfg, users, device='cuda:0', log_capacity=default_log_capacity(cfg, users), **kw)
     logs = []
     for _ in range(3):
