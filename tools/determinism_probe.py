@@ -1,5 +1,5 @@
 """The same run N times on one simulator: every ordered log against the first one (rows are keyed by (seed, user, event), so any
-difference is a bug, not noise).  usage: python tools/determinism_probe.py <workload> [runs] [p_click 0/1] [arm index]"""
+difference is a bug, not noise).  usage: python tools/determinism_probe.py <workload> [runs] [p_click 0/1] [arm index] [users]"""
 import json
 import os
 import sys
@@ -12,7 +12,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else 'c4shard'
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 pc = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
 cfg = bench.make_config(wl)
-users = bench.WORKLOADS[wl][1]
+users = int(sys.argv[5]) if len(sys.argv) > 5 else bench.WORKLOADS[wl][1]
 arm = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 name, kw = bench.arms_of(wl, cfg)[arm]
 sim = Simulator(cfg, users, device='cuda:0', log_capacity=default_log_capacity(cfg, users), p_click=pc, **kw)
